@@ -1,0 +1,205 @@
+/*
+ * multike_hip.h — C-ABI of libmultike_hip.so: the MI355X (gfx950) hot path of MultiKE training.
+ *
+ * Boundary contract:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch on the Python side) unless the
+ *     parameter comment says "host". The library never allocates, frees or synchronises; every entry
+ *     point only enqueues kernels on the given hipStream_t (passed as void* so that the header does not
+ *     need the HIP headers; NULL = the legacy default stream).
+ *   - Return value: 0 = ok, <0 = bad argument (MKE_E_*), >0 = a hipError_t from the launch.
+ *     mke_last_error() returns a thread-local human-readable message for the last non-zero return.
+ *   - No global mutable state: the library is re-entrant; two host threads may enqueue on two streams.
+ *
+ * The reference (nju-websoft/MultiKE) has NO native code; each entry point below replaces a group of
+ * TensorFlow-1.x graph ops that the reference builds in Python.  The "replaces" lines cite the
+ * reference Python that constructs those ops (paths relative to the reference root).
+ *
+ * Table layout in HBM (all tables, Adagrad slots and gradient scratch share it):
+ *   float32 [n_rows][stride], row-major, stride % 16 == 0 and stride >= dim; columns [dim, stride) are
+ *   ZERO and stay zero (their gradients are exactly zero), so kernels may run over the padded width.
+ *   One 16-lane quarter-wavefront owns one row: lane j holds columns {j, j+16, j+32, ...}.
+ */
+#ifndef MULTIKE_HIP_H
+#define MULTIKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKE_VERSION 100 /* 0.1.0 */
+
+/* error codes (negative = argument errors) */
+#define MKE_OK 0
+#define MKE_E_NULL (-1)     /* a required pointer is NULL */
+#define MKE_E_SHAPE (-2)    /* bad dim / stride / count */
+#define MKE_E_UNSUPPORTED (-3)
+#define MKE_E_RANGE (-4)    /* id does not fit the packed key / table */
+
+/* Number of per-block loss partials every loss-producing kernel writes (doubles).  The caller passes a
+ * double[MKE_LOSS_PARTIALS] scratch; the kernel OVERWRITES all entries; the loss is their sum. */
+#define MKE_LOSS_PARTIALS 1024
+
+/* Largest supported stride (floats). */
+#define MKE_MAX_STRIDE 320
+
+/* optimizer kinds for mke_rows_update — code/MultiKE_model.py:15-25 get_optimizer */
+#define MKE_OPT_ADAGRAD 0 /* tf.train.AdagradOptimizer: acc += g*g; w -= lr*g/sqrt(acc); acc0 = 0.1, no eps */
+#define MKE_OPT_SGD 1     /* tf.train.GradientDescentOptimizer: w -= lr*g */
+
+int mke_version(void);
+const char* mke_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) Fused relation-view triple step: gather + normalise-on-read + translation score + logistic loss
+ *     + gradient scatter-add (normalised space).
+ *
+ * replaces: code/MultiKE_model.py:122-130 (six embedding_lookup + relation_logistic_loss),
+ *           code/losses.py:4-12 (a1), :30-34 (a2, n_neg = 0), :44-50 (a3, pos_w != NULL, n_neg = 0),
+ *           code/base/initializers.py:26 (l2_normalize on read), and the backward half of
+ *           optimizer.compute_gradients at code/MultiKE_model.py:28-31 for those graphs.
+ *
+ *   loss = scale * ( sum_p pw_p * log(1+exp(||h+r-t||^2)) + sum_n nw_n * log(1+exp(-||h'+r'-t'||^2)) )
+ *   rows are read through x * rsqrt(max(sum x^2, 1e-12)) when the table's normalise flag is set.
+ *
+ *   Gradients w.r.t. the NORMALISED rows are atomically added into grad_ent / grad_rel (same layout as
+ *   the tables, all-zero on entry by invariant — mke_rows_update re-zeroes what it consumes), and
+ *   touched_*[row] = tag is stored for every row that received a contribution.
+ *   grad_ent == NULL means forward only (loss only).
+ *
+ *   neg_per_pos > 0: negatives are grouped, negatives [i*neg_per_pos, (i+1)*neg_per_pos) belong to
+ *   positive i (the layout code/base/batch.py:86-116 produces) and n_neg must equal n_pos*neg_per_pos;
+ *   rows a negative shares with its positive are loaded once and their gradients pre-reduced in
+ *   registers.  neg_per_pos == 0 with n_neg > 0: arbitrary negatives (scored independently).
+ * ------------------------------------------------------------------------------------------------ */
+int mke_triple_score_fwd_bwd(
+    const float* ent_table, int64_t n_ent, int ent_normalize,
+    const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim,
+    const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w /*nullable*/,
+    int64_t n_pos,
+    const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w /*nullable*/,
+    int64_t n_neg, int neg_per_pos,
+    float scale,
+    float* grad_ent /*nullable*/, float* grad_rel /*nullable iff grad_ent is*/,
+    int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+    double* loss_partials /* [MKE_LOSS_PARTIALS] */,
+    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) Per-row optimizer step on the rows touched in this step: Jacobian of normalise-on-read, then
+ *     the optimizer update; consumes (re-zeroes) the gradient rows.
+ *
+ * replaces: the gradient of tf.nn.l2_normalize at code/base/initializers.py:26 and
+ *           optimizer.apply_gradients at code/MultiKE_model.py:31 (tf.train.AdagradOptimizer,
+ *           code/MultiKE_model.py:17).  TF applies it densely to the whole [n,dim] variable; rows
+ *           with a zero gradient are left bit-identical by TF too, so touching only rows with
+ *           touched[row] == tag gives the same result.
+ *
+ *   for every row with touched[row] == tag:
+ *     ghat = grad[row];  grad[row] = 0
+ *     normalize: s = sum w^2; inv = rsqrt(max(s,1e-12)); what = w*inv;
+ *                g = (s > 1e-12) ? (ghat - what*(what.ghat))*inv : ghat*inv     else g = ghat
+ *     ADAGRAD: acc += g*g; w -= lr*g/sqrt(acc)        SGD: w -= lr*g   (acc may be NULL)
+ * ------------------------------------------------------------------------------------------------ */
+int mke_rows_update(
+    float* table, float* acc /*nullable for SGD*/, float* grad,
+    const int32_t* touched, int32_t tag,
+    int64_t n_rows, int stride, int dim,
+    int normalize, int optimizer, float lr,
+    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) Uniform / truncated negative sampler (counter-based Philox4x32-10; see oracle/sampler_spec.md).
+ *
+ * replaces: code/base/batch.py:86-116 generate_neg_triples_fast as called from
+ *           code/base/batch.py:40-41 (one call per KG per step).
+ *
+ *   For positive i (of n_pos), up to max_try rounds: one fair coin per round picks the corrupted side;
+ *   `need` distinct candidates are drawn without replacement from the candidate list of the positive's
+ *   head (or tail): cand_table row of that entity if cand_table != NULL and cand_valid[entity] != 0,
+ *   else the KG's entity list (ent_list, or the contiguous range [ent_lo, ent_lo+n_cand_all) when
+ *   ent_list == NULL).  In rounds 0..max_try-2 candidates forming a known triple are dropped; the last
+ *   round keeps everything.  Exactly neg_per_pos negatives per positive are written at
+ *   neg_*[i*neg_per_pos ...]; neg_r is a copy of the positive's relation.
+ *
+ *   known_keys: open-addressing hash set built by mke_tripleset_build (NULL = no filter).
+ *   RNG stream = Philox key (seed_lo, seed_hi), counter (i + pos_offset, round, draw_block, stream_id).
+ * ------------------------------------------------------------------------------------------------ */
+int mke_neg_sample(
+    const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, int64_t pos_offset,
+    int neg_per_pos, int max_try,
+    const int32_t* ent_list /*nullable*/, int32_t ent_lo, int32_t n_cand_all,
+    const int32_t* cand_table /*nullable, [n_ent_total][cand_k]*/, const uint8_t* cand_valid /*nullable*/,
+    int32_t cand_k,
+    const uint64_t* known_keys /*nullable*/, uint64_t known_capacity /* power of two */,
+    uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+    int32_t* neg_h, int32_t* neg_r, int32_t* neg_t,
+    void* stream);
+
+/* Known-triple hash set.  key = h<<38 | t<<12 | r  (h,t < 2^26, r < 2^12); empty slot = ~0.
+ * keys must be filled with 0xFF bytes by the caller before the first build call; capacity is a power
+ * of two >= 2 * (number of triples).  Several build calls may add to the same set.
+ * replaces: the Python set `all_triples_set` membership test at code/base/batch.py:109. */
+int mke_tripleset_build(
+    const int32_t* h, const int32_t* r, const int32_t* t, int64_t n,
+    uint64_t* keys, uint64_t capacity, void* stream);
+
+/* Membership query (used by tests and by the host-side mirror of the filter): out[i] = 1 if present. */
+int mke_tripleset_query(
+    const int32_t* h, const int32_t* r, const int32_t* t, int64_t n,
+    const uint64_t* keys, uint64_t capacity, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) Loss ops over ALREADY GATHERED rows — the losses.py surface itself (forward + gradient w.r.t.
+ *     every gathered row in one pass; rows are dense [n][ld] with ld >= dim, no padding rule).
+ *
+ * replaces: code/losses.py:4-12 relation_logistic_loss, :15-27 attribute_logistic_loss,
+ *           :30-34 / :37-41 *_wo_negs, :44-50 logistic_loss_wo_negs (weights != NULL).
+ *   sign = +1: sum w * log(1+exp(+||h+r-t||^2))   (positives)
+ *   sign = -1: sum w * log(1+exp(-||h+r-t||^2))   (negatives)
+ *   gh/gr/gt (nullable, all or none): gradient rows, OVERWRITTEN.  gt = -gh.
+ * ------------------------------------------------------------------------------------------------ */
+int mke_gathered_logistic_fwd_bwd(
+    const float* hs, const float* rs, const float* ts, const float* ws /*nullable*/,
+    int64_t n, int dim, int ld, int sign,
+    float* gh, float* gr, float* gt,
+    double* loss_partials /* [MKE_LOSS_PARTIALS] */,
+    void* stream);
+
+/* replaces: code/losses.py:66-69 alignment_loss — sum ||a-b||^2 ; ga = 2(a-b), gb = -ga (nullable). */
+int mke_gathered_alignment_fwd_bwd(
+    const float* a, const float* b, int64_t n, int dim, int ld,
+    float* ga, float* gb,
+    double* loss_partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (5) Fused alignment step over table rows (common-space learning, one term):
+ *       loss = weight * sum_i || A^[ia_i] - B^[ib_i] ||^2
+ *     with normalise-on-read per table flag; grads (normalised space) atomically added to grad_a /
+ *     grad_b (either may be NULL = constant table), touched flags stored.
+ * replaces: code/MultiKE_model.py:229-236 (_define_common_space_learning_graph lookups + the three
+ *           alignment_loss terms, one call per term).
+ * ------------------------------------------------------------------------------------------------ */
+int mke_align_fwd_bwd(
+    const float* table_a, int a_normalize, const float* table_b, int b_normalize,
+    int stride, int dim,
+    const int32_t* ia, const int32_t* ib, int64_t n,
+    float weight,
+    float* grad_a /*nullable*/, int32_t* touched_a, float* grad_b /*nullable*/, int32_t* touched_b,
+    int32_t tag,
+    double* loss_partials, void* stream);
+
+/* Gather normalised rows into a dense [n][dim] matrix (the `.eval()` / embedding_lookup read path).
+ * replaces: code/MultiKE_model.py:263-277 eval_kg*_ent_embeddings. */
+int mke_gather_rows(
+    const float* table, int normalize, int stride, int dim,
+    const int32_t* idx /*nullable = identity*/, int64_t n,
+    float* out /* [n][dim] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTIKE_HIP_H */

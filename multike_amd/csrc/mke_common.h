@@ -1,0 +1,159 @@
+// mke_common.h — device helpers shared by the gfx950 kernels of libmultike_hip.so.
+//
+// Execution shape used by every row kernel: one 16-lane quarter-wavefront ("sub16") owns one embedding
+// row; lane j of the quarter holds columns {j, j+16, j+32, ...} (FPL = stride/16 floats per lane).
+// A 64-wide wavefront therefore works on 4 rows at a time, each row access is a run of 64-byte
+// contiguous segments, reductions over a row are four DPP adds that never leave the 16-lane DPP row,
+// and a gradient row is scattered with FPL `global_atomic_add_f32`, each covering 64 contiguous bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/multike_hip.h"
+
+#define MKE_BLOCK 256                 // threads per workgroup: 4 wavefronts, 16 quarter-waves
+#define MKE_SUBS_PER_BLOCK (MKE_BLOCK / 16)
+#define MKE_L2_EPS 1e-12f             // tf.nn.l2_normalize epsilon (code/base/initializers.py:26)
+
+namespace mke {
+
+// host-side error plumbing (mke_api.hip)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 16 lanes of a DPP row; every lane receives the total.
+__device__ __forceinline__ float sub16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7-i inside each 8
+  v += dpp_mov<0x140>(v);  // row_mirror:      lane i <-> 15-i
+  return v;
+}
+
+template <int FPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int stride, int j,
+                                         float (&v)[FPL]) {
+  const float* p = base + row * (int64_t)stride + j;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) v[k] = p[k * 16];
+}
+
+// x * rsqrt(max(sum x^2, eps)) — tf.nn.l2_normalize(x, 1).  Returns the inverse norm factor used.
+template <int FPL>
+__device__ __forceinline__ float l2_normalize_row(float (&v)[FPL], bool on) {
+  if (!on) return 1.0f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) s = fmaf(v[k], v[k], s);
+  s = sub16_sum(s);
+  const float inv = rsqrtf(fmaxf(s, MKE_L2_EPS));
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) v[k] *= inv;
+  return inv;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  // relaxed, agent scope, no return value -> global_atomic_add_f32 (built with -munsafe-fp-atomics)
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Atomically add a row held in sub16 layout into grad[row]; columns >= dim are never written.
+template <int FPL>
+__device__ __forceinline__ void atomic_add_row(float* __restrict__ grad, int64_t row, int stride, int dim,
+                                               int j, const float (&v)[FPL], float sgn) {
+  float* p = grad + row * (int64_t)stride + j;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    if (k * 16 + 16 <= dim || k * 16 + j < dim) atomic_add_f32(p + k * 16, sgn * v[k]);
+  }
+}
+
+// log(1 + exp(x)) and sigmoid for x in the range the path produces (|x| <= 9 on unit rows; written to
+// stay finite for any x).
+__device__ __forceinline__ float softplus_f(float x) {
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Block-wide sum of one float per thread, accumulated in double; thread 0 gets the result.
+__device__ __forceinline__ double block_sum_double(float v) {
+  __shared__ double s_part[MKE_BLOCK / 64];
+  double d = (double)v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_part[wave] = d;
+  __syncthreads();
+  double tot = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < MKE_BLOCK / 64; ++w) tot += s_part[w];
+  }
+  return tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG of the negative sampler.
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0;
+    const uint64_t p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// known-triple key: h<<38 | t<<12 | r
+__host__ __device__ __forceinline__ uint64_t triple_key(uint32_t h, uint32_t r, uint32_t t) {
+  return ((uint64_t)h << 38) | ((uint64_t)t << 12) | (uint64_t)r;
+}
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+#define MKE_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+}  // namespace mke
+
+// Dispatch a kernel template on FPL = stride/16 (1..20).
+#define MKE_DISPATCH_FPL(fpl, ...)                                                   \
+  switch (fpl) {                                                                     \
+    case 1: { constexpr int FPL = 1; __VA_ARGS__; } break;                           \
+    case 2: { constexpr int FPL = 2; __VA_ARGS__; } break;                           \
+    case 3: { constexpr int FPL = 3; __VA_ARGS__; } break;                           \
+    case 4: { constexpr int FPL = 4; __VA_ARGS__; } break;                           \
+    case 5: { constexpr int FPL = 5; __VA_ARGS__; } break;                           \
+    case 6: { constexpr int FPL = 6; __VA_ARGS__; } break;                           \
+    case 7: { constexpr int FPL = 7; __VA_ARGS__; } break;                           \
+    case 8: { constexpr int FPL = 8; __VA_ARGS__; } break;                           \
+    case 10: { constexpr int FPL = 10; __VA_ARGS__; } break;                         \
+    case 12: { constexpr int FPL = 12; __VA_ARGS__; } break;                         \
+    case 13: { constexpr int FPL = 13; __VA_ARGS__; } break;                         \
+    case 16: { constexpr int FPL = 16; __VA_ARGS__; } break;                         \
+    case 20: { constexpr int FPL = 20; __VA_ARGS__; } break;                         \
+    default:                                                                         \
+      mke::set_error("unsupported stride %d (stride/16 must be one of 1-8,10,12,13,16,20)", (fpl) * 16); \
+      return MKE_E_UNSUPPORTED;                                                      \
+  }

@@ -1,0 +1,204 @@
+// mke_sampler.hip — on-device negative sampler + known-triple hash set (gfx950).
+//
+// Distribution = code/base/batch.py:86-116 generate_neg_triples_fast: per positive, up
+// to max_try rounds; one fair coin per round chooses the corrupted side; `need` distinct candidates are
+// drawn without replacement from that side's candidate list; known triples are dropped except in the
+// last round; stop at neg_per_pos.  The reference draws from CPython's Mersenne Twister through
+// Manager-queue worker processes; here the stream is Philox4x32-10 keyed by (seed, stream id) and
+// indexed by (positive, round, slot, attempt), so any positive can be sampled by any wavefront in any
+// order and the CPU oracle (oracle/sampler_oracle.py) reproduces the device output bit for bit.
+//
+// Shape: one 64-lane wavefront per positive, lane q = slot q of the round (neg_per_pos <= 64).
+#include "mke_common.h"
+
+namespace mke {
+
+struct SampleParams {
+  const int32_t* __restrict__ ph;
+  const int32_t* __restrict__ pr;
+  const int32_t* __restrict__ pt;
+  int64_t n_pos, pos_offset;
+  int npp, max_try;
+  const int32_t* __restrict__ ent_list;
+  int32_t ent_lo, n_all;
+  const int32_t* __restrict__ cand_table;
+  const uint8_t* __restrict__ cand_valid;
+  int32_t cand_k;
+  const uint64_t* __restrict__ keys;
+  uint64_t cap;
+  uint32_t seed_lo, seed_hi, sid;
+  int32_t* __restrict__ nh;
+  int32_t* __restrict__ nr;
+  int32_t* __restrict__ nt;
+};
+
+// Next accepted bounded draw in [0,n) for (positive gi, round, slot): attempts are consumed in order;
+// attempt a uses word (a&3) of Philox block (a>>2).  Lemire's multiply-shift with exact rejection.
+__host__ __device__ __forceinline__ uint32_t draw_next(uint32_t gi, uint32_t round, uint32_t slot, uint32_t sid,
+                                                       uint32_t k0, uint32_t k1, uint32_t n, uint32_t& attempt) {
+  for (;;) {
+    const uint32_t blk = attempt >> 2, word = attempt & 3u;
+    const Philox4 ph = philox4x32_10(gi, round | (blk << 8), slot, sid, k0, k1);
+    const uint32_t x = ph.v[word];
+    ++attempt;
+    const uint64_t m = (uint64_t)x * (uint64_t)n;
+    const uint32_t l = (uint32_t)m;
+    if (l < n) {
+      const uint32_t thresh = (0u - n) % n;
+      if (l < thresh) continue;
+    }
+    return (uint32_t)(m >> 32);
+  }
+}
+
+__device__ __forceinline__ bool set_contains(const uint64_t* __restrict__ keys, uint64_t cap, uint64_t key) {
+  uint64_t slot = mix64(key) & (cap - 1);
+  for (;;) {
+    const uint64_t k = keys[slot];
+    if (k == key) return true;
+    if (k == MKE_EMPTY_KEY) return false;
+    slot = (slot + 1) & (cap - 1);
+  }
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  if (i >= p.n_pos) return;
+  const int h = p.ph[i], r = p.pr[i], t = p.pt[i];
+  const uint32_t gi = (uint32_t)(i + p.pos_offset);
+  const int N = p.npp;
+  int collected = 0;
+  for (int round = 0; round < p.max_try && collected < N; ++round) {
+    const int need = N - collected;
+    const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, p.sid, p.seed_lo, p.seed_hi);
+    const bool corrupt_head = (cph.v[0] >> 31) != 0;
+    const int x = corrupt_head ? h : t;
+    const bool use_tbl = p.cand_table != nullptr && (p.cand_valid == nullptr || p.cand_valid[x] != 0);
+    const uint32_t n = use_tbl ? (uint32_t)p.cand_k : (uint32_t)p.n_all;
+    const bool active = lane < need;
+    uint32_t attempt = 0;
+    uint32_t pos = 0xFFFFFFFFu;
+    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, p.sid, p.seed_lo, p.seed_hi, n, attempt);
+    // duplicate detection among first draws
+    bool dup = false;
+    for (int q = 0; q < need; ++q) {
+      const uint32_t v = (uint32_t)__shfl((int)pos, q, 64);
+      dup |= active && lane > q && pos == v;
+    }
+    if (__ballot(dup)) {
+      // sequential without-replacement semantics: slot q must differ from the final draws of slots < q
+      for (int q = 1; q < need; ++q) {
+        for (;;) {
+          const uint32_t v = (uint32_t)__shfl((int)pos, q, 64);
+          const bool hit = lane < q && pos == v;
+          if (!__ballot(hit)) break;
+          if (lane == q) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, p.sid, p.seed_lo, p.seed_hi, n, attempt);
+        }
+      }
+    }
+    int ent = 0;
+    if (active) {
+      ent = use_tbl ? p.cand_table[(int64_t)x * p.cand_k + pos]
+                    : (p.ent_list ? p.ent_list[pos] : p.ent_lo + (int32_t)pos);
+    }
+    const int nh = corrupt_head ? ent : h;
+    const int nt = corrupt_head ? t : ent;
+    bool keep = active;
+    if (active && round < p.max_try - 1 && p.keys != nullptr) {
+      keep = !set_contains(p.keys, p.cap, triple_key((uint32_t)nh, (uint32_t)r, (uint32_t)nt));
+    }
+    const uint64_t mask = __ballot(keep);
+    if (keep) {
+      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      const int64_t o = i * (int64_t)N + collected + rank;
+      p.nh[o] = nh; p.nr[o] = r; p.nt[o] = nt;
+    }
+    collected += __popcll(mask);
+  }
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_tripleset_build(const int32_t* __restrict__ h, const int32_t* __restrict__ r,
+                                                               const int32_t* __restrict__ t, int64_t n,
+                                                               uint64_t* __restrict__ keys, uint64_t cap) {
+  const int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = triple_key((uint32_t)h[i], (uint32_t)r[i], (uint32_t)t[i]);
+  uint64_t slot = mix64(key) & (cap - 1);
+  for (;;) {
+    const unsigned long long prev =
+        atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)MKE_EMPTY_KEY, (unsigned long long)key);
+    if (prev == MKE_EMPTY_KEY || prev == key) return;
+    slot = (slot + 1) & (cap - 1);
+  }
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_tripleset_query(const int32_t* __restrict__ h, const int32_t* __restrict__ r,
+                                                               const int32_t* __restrict__ t, int64_t n,
+                                                               const uint64_t* __restrict__ keys, uint64_t cap,
+                                                               uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  out[i] = set_contains(keys, cap, triple_key((uint32_t)h[i], (uint32_t)r[i], (uint32_t)t[i])) ? 1 : 0;
+}
+
+}  // namespace mke
+
+extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
+                              int64_t pos_offset, int neg_per_pos, int max_try, const int32_t* ent_list,
+                              int32_t ent_lo, int32_t n_cand_all, const int32_t* cand_table,
+                              const uint8_t* cand_valid, int32_t cand_k, const uint64_t* known_keys,
+                              uint64_t known_capacity, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                              int32_t* neg_h, int32_t* neg_r, int32_t* neg_t, void* stream) {
+  using namespace mke;
+  if (n_pos < 0) { set_error("negative n_pos"); return MKE_E_SHAPE; }
+  if (n_pos == 0 || neg_per_pos == 0) return MKE_OK;
+  if (!pos_h || !pos_r || !pos_t || !neg_h || !neg_r || !neg_t) { set_error("mke_neg_sample: NULL index stream"); return MKE_E_NULL; }
+  if (neg_per_pos < 0 || neg_per_pos > 64) { set_error("neg_per_pos must be in [0,64], got %d", neg_per_pos); return MKE_E_UNSUPPORTED; }
+  if (max_try < 1 || max_try > 255) { set_error("max_try must be in [1,255]"); return MKE_E_SHAPE; }
+  // random.sample raises ValueError when the population is smaller than the sample (batch.py:98,101)
+  if (n_cand_all < neg_per_pos) { set_error("candidate population (%d) smaller than neg_per_pos (%d)", n_cand_all, neg_per_pos); return MKE_E_SHAPE; }
+  if (cand_table && cand_k < neg_per_pos) { set_error("neighbour list (%d) shorter than neg_per_pos (%d)", cand_k, neg_per_pos); return MKE_E_SHAPE; }
+  if (known_keys && (known_capacity == 0 || (known_capacity & (known_capacity - 1)) != 0)) { set_error("known_capacity must be a power of two"); return MKE_E_SHAPE; }
+  SampleParams p;
+  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.n_pos = n_pos; p.pos_offset = pos_offset;
+  p.npp = neg_per_pos; p.max_try = max_try;
+  p.ent_list = ent_list; p.ent_lo = ent_lo; p.n_all = n_cand_all;
+  p.cand_table = cand_table; p.cand_valid = cand_valid; p.cand_k = cand_k;
+  p.keys = known_keys; p.cap = known_capacity;
+  p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.sid = stream_id;
+  p.nh = neg_h; p.nr = neg_r; p.nt = neg_t;
+  const int64_t waves_per_block = MKE_BLOCK / 64;
+  const int64_t blocks = (n_pos + waves_per_block - 1) / waves_per_block;
+  hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  return check_launch("k_neg_sample");
+}
+
+extern "C" int mke_tripleset_build(const int32_t* h, const int32_t* r, const int32_t* t, int64_t n, uint64_t* keys,
+                                   uint64_t capacity, void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!h || !r || !t || !keys) { set_error("mke_tripleset_build: NULL pointer"); return MKE_E_NULL; }
+  if (capacity == 0 || (capacity & (capacity - 1)) != 0 || capacity < (uint64_t)n + 1) {
+    set_error("capacity must be a power of two > n");
+    return MKE_E_SHAPE;
+  }
+  const int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
+  hipLaunchKernelGGL(k_tripleset_build, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, h, r, t, n,
+                     keys, capacity);
+  return check_launch("k_tripleset_build");
+}
+
+extern "C" int mke_tripleset_query(const int32_t* h, const int32_t* r, const int32_t* t, int64_t n,
+                                   const uint64_t* keys, uint64_t capacity, uint8_t* out, void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!h || !r || !t || !keys || !out) { set_error("mke_tripleset_query: NULL pointer"); return MKE_E_NULL; }
+  if (capacity == 0 || (capacity & (capacity - 1)) != 0) { set_error("capacity must be a power of two"); return MKE_E_SHAPE; }
+  const int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
+  hipLaunchKernelGGL(k_tripleset_query, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, h, r, t, n,
+                     keys, capacity, out);
+  return check_launch("k_tripleset_query");
+}

@@ -1,0 +1,267 @@
+// mke_score.hip — fused relation-view triple step for gfx950:
+//   gather (h,r,t) rows -> normalise-on-read -> d = h + r - t -> ||d||^2 -> logistic loss
+//   -> coefficient -> gradient rows (normalised space) scattered with fp32 atomics.
+//
+// What it computes is what the reference's relation-view graph computes
+// (code/MultiKE_model.py:122-130 + code/losses.py:4-12 + code/base/initializers.py:26); how it is
+// organised is new.  A 16-lane quarter-wave owns one "group" = a positive and (a slice of) its
+// neg_per_pos negatives.  The positive's three rows are loaded and normalised once and stay in
+// registers; a negative that differs from its positive in exactly one entity (what
+// code/base/batch.py:86-116 produces) costs ONE more row gather and ONE row scatter; the gradients of
+// the shared rows are pre-reduced in registers and flushed with one scatter per group.  Any other
+// negative falls back to an independent (3 gathers, 3 scatters) triple — same arithmetic.
+#include "mke_common.h"
+
+namespace mke {
+
+struct ScoreParams {
+  const float* __restrict__ ent;
+  const float* __restrict__ rel;
+  int ent_norm, rel_norm;
+  int stride, dim;
+  const int32_t* __restrict__ ph;
+  const int32_t* __restrict__ pr;
+  const int32_t* __restrict__ pt;
+  const float* __restrict__ pw;
+  int64_t n_pos;
+  const int32_t* __restrict__ nh;
+  const int32_t* __restrict__ nr;
+  const int32_t* __restrict__ nt;
+  const float* __restrict__ nw;
+  int64_t n_neg;
+  int npp;     // negatives per positive (grouped) or 0
+  int splits;  // quarter-waves sharing one group's negatives
+  float scale;
+  float* __restrict__ gent;
+  float* __restrict__ grel;
+  int32_t* __restrict__ tent;
+  int32_t* __restrict__ trel;
+  int32_t tag;
+  double* __restrict__ lossp;
+};
+
+// One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
+template <int FPL>
+__device__ __forceinline__ float independent_triple(const ScoreParams& p, int j, int h, int r, int t, float w,
+                                                    float sign) {
+  float H[FPL], R[FPL], T[FPL];
+  load_row<FPL>(p.ent, h, p.stride, j, H);
+  load_row<FPL>(p.rel, r, p.stride, j, R);
+  load_row<FPL>(p.ent, t, p.stride, j, T);
+  l2_normalize_row<FPL>(H, p.ent_norm);
+  l2_normalize_row<FPL>(R, p.rel_norm);
+  l2_normalize_row<FPL>(T, p.ent_norm);
+  float x = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    H[k] = (H[k] + R[k]) - T[k];  // d
+    x = fmaf(H[k], H[k], x);
+  }
+  x = sub16_sum(x);
+  const float z = sign * x;
+  const float l = w * softplus_f(z);
+  if (p.gent) {
+    const float c = 2.0f * sign * w * p.scale * sigmoid_f(z);
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) H[k] *= c;
+    atomic_add_row<FPL>(p.gent, h, p.stride, p.dim, j, H, 1.0f);
+    atomic_add_row<FPL>(p.grel, r, p.stride, p.dim, j, H, 1.0f);
+    atomic_add_row<FPL>(p.gent, t, p.stride, p.dim, j, H, -1.0f);
+    if (j == 0) {
+      p.tent[h] = p.tag;
+      p.tent[t] = p.tag;
+      p.trel[r] = p.tag;
+    }
+  }
+  return l;
+}
+
+template <int FPL, int U>
+__global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  const bool bwd = p.gent != nullptr;
+  float loss = 0.f;  // identical on the 16 lanes of a quarter-wave; lane j==0 contributes
+
+  const int npp = p.npp;
+  const int S = p.splits;
+  const int64_t nwork = p.n_pos * S;
+  for (int64_t wk = sub0; wk < nwork; wk += nsub) {
+    const int64_t g = wk / S;
+    const int s = (int)(wk - g * S);
+    const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
+    float H[FPL], R[FPL], T[FPL];
+    load_row<FPL>(p.ent, ph, p.stride, j, H);
+    load_row<FPL>(p.rel, pr, p.stride, j, R);
+    load_row<FPL>(p.ent, pt, p.stride, j, T);
+    l2_normalize_row<FPL>(H, p.ent_norm);
+    l2_normalize_row<FPL>(R, p.rel_norm);
+    l2_normalize_row<FPL>(T, p.ent_norm);
+    float gH[FPL], gR[FPL], gT[FPL];  // gT holds the NEGATED t-gradient (sum of c*d)
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) gH[k] = gR[k] = gT[k] = 0.f;
+
+    if (s == 0) {  // the positive itself
+      const float w = p.pw ? p.pw[g] : 1.0f;
+      float d[FPL];
+      float x = 0.f;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        d[k] = (H[k] + R[k]) - T[k];
+        x = fmaf(d[k], d[k], x);
+      }
+      x = sub16_sum(x);
+      loss += w * softplus_f(x);
+      const float c = 2.0f * w * p.scale * sigmoid_f(x);
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        const float gd = c * d[k];
+        gH[k] += gd; gR[k] += gd; gT[k] += gd;
+      }
+    }
+
+    // this quarter-wave's slice of the group's negatives
+    const int per = (npp + S - 1) / S;
+    const int n_lo = s * per;
+    const int n_hi = min(npp, n_lo + per);
+    const int64_t nbase = g * (int64_t)npp;
+    for (int n0 = n_lo; n0 < n_hi; n0 += U) {
+      int e[U];
+      bool fast[U], sideH[U], live[U];
+      float w[U];
+      float C[U][FPL];
+      // phase 1: ids
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        live[u] = (n0 + u) < n_hi;
+        const int64_t idx = nbase + (live[u] ? n0 + u : n_lo);
+        const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+        w[u] = p.nw ? p.nw[idx] : 1.0f;
+        const bool dh = nh != ph, dt = nt != pt;
+        fast[u] = live[u] && (nr == pr) && (dh != dt);
+        sideH[u] = dh;
+        e[u] = dh ? nh : nt;
+        if (live[u] && !fast[u]) {  // rare: negative shares nothing usable / equals the positive
+          loss += independent_triple<FPL>(p, j, nh, nr, nt, w[u], -1.0f);
+        }
+      }
+      // phase 2: all corrupt-row gathers of the chunk in flight together
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (fast[u]) {
+          load_row<FPL>(p.ent, e[u], p.stride, j, C[u]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) C[u][k] = 0.f;
+        }
+      }
+      // phase 3: score, loss, gradient
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (fast[u]) {
+          l2_normalize_row<FPL>(C[u], p.ent_norm);
+          float d[FPL];
+          float y = 0.f;
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) {
+            const float hh = sideH[u] ? C[u][k] : H[k];
+            const float tt = sideH[u] ? T[k] : C[u][k];
+            d[k] = (hh + R[k]) - tt;
+            y = fmaf(d[k], d[k], y);
+          }
+          y = sub16_sum(y);
+          loss += w[u] * softplus_f(-y);
+          if (bwd) {
+            const float c = -2.0f * w[u] * p.scale * sigmoid_f(-y);
+            const float toH = sideH[u] ? 0.f : 1.f;
+            const float toT = sideH[u] ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+              d[k] *= c;
+              gR[k] += d[k];
+              gH[k] = fmaf(toH, d[k], gH[k]);
+              gT[k] = fmaf(toT, d[k], gT[k]);
+            }
+            atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
+            if (j == 0) p.tent[e[u]] = p.tag;
+          }
+        }
+      }
+    }
+
+    if (bwd && (s == 0 || n_lo < n_hi)) {
+      atomic_add_row<FPL>(p.gent, ph, p.stride, p.dim, j, gH, 1.0f);
+      atomic_add_row<FPL>(p.grel, pr, p.stride, p.dim, j, gR, 1.0f);
+      atomic_add_row<FPL>(p.gent, pt, p.stride, p.dim, j, gT, -1.0f);
+      if (j == 0) {
+        p.tent[ph] = p.tag;
+        p.tent[pt] = p.tag;
+        p.trel[pr] = p.tag;
+      }
+    }
+  }
+
+  // ungrouped negatives: independent triples
+  if (npp == 0) {
+    for (int64_t i = sub0; i < p.n_neg; i += nsub) {
+      const float w = p.nw ? p.nw[i] : 1.0f;
+      loss += independent_triple<FPL>(p, j, p.nh[i], p.nr[i], p.nt[i], w, -1.0f);
+    }
+  }
+
+  const double tot = block_sum_double(j == 0 ? loss : 0.f);
+  if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)p.scale;
+}
+
+}  // namespace mke
+
+extern "C" int mke_triple_score_fwd_bwd(
+    const float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel,
+    int rel_normalize, int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t,
+    const float* pos_w, int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t,
+    const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
+    int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream) {
+  using namespace mke;
+  if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
+  if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
+  if (n_pos > 0 && (!pos_h || !pos_r || !pos_t)) { set_error("NULL positive index stream"); return MKE_E_NULL; }
+  if (n_neg > 0 && (!neg_h || !neg_r || !neg_t)) { set_error("NULL negative index stream"); return MKE_E_NULL; }
+  if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) {
+    set_error("bad stride/dim: stride=%d dim=%d (stride %% 16 == 0, dim <= stride <= %d)", stride, dim, MKE_MAX_STRIDE);
+    return MKE_E_SHAPE;
+  }
+  if (neg_per_pos < 0 || (neg_per_pos > 0 && n_neg != n_pos * (int64_t)neg_per_pos)) {
+    set_error("grouped negatives: n_neg (%lld) != n_pos (%lld) * neg_per_pos (%d)", (long long)n_neg,
+              (long long)n_pos, neg_per_pos);
+    return MKE_E_SHAPE;
+  }
+  if ((grad_ent == nullptr) != (grad_rel == nullptr)) { set_error("grad_ent and grad_rel must both be given or both NULL"); return MKE_E_NULL; }
+  if (grad_ent && (!touched_ent || !touched_rel)) { set_error("NULL touched array"); return MKE_E_NULL; }
+
+  ScoreParams p;
+  p.ent = ent_table; p.rel = rel_table; p.ent_norm = ent_normalize; p.rel_norm = rel_normalize;
+  p.stride = stride; p.dim = dim;
+  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.pw = pos_w; p.n_pos = n_pos;
+  p.nh = neg_h; p.nr = neg_r; p.nt = neg_t; p.nw = neg_w; p.n_neg = n_neg;
+  p.npp = neg_per_pos;
+  const int64_t total_subs = (int64_t)MKE_LOSS_PARTIALS * MKE_SUBS_PER_BLOCK;
+  int splits = 1;
+  if (neg_per_pos > 0 && n_pos > 0) {
+    int64_t s = total_subs / n_pos;
+    if (s < 1) s = 1;
+    if (s > neg_per_pos) s = neg_per_pos;
+    splits = (int)s;
+  }
+  p.splits = splits;
+  p.scale = scale;
+  p.gent = grad_ent; p.grel = grad_rel; p.tent = touched_ent; p.trel = touched_rel; p.tag = tag;
+  p.lossp = loss_partials;
+  hipStream_t st = (hipStream_t)stream;
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    constexpr int U = FPL <= 5 ? 4 : (FPL <= 8 ? 2 : 1);
+    hipLaunchKernelGGL((k_triple_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+  });
+  return check_launch("k_triple_score");
+}

@@ -1,0 +1,122 @@
+// mke_update.hip — per-row optimizer step on the rows touched in this step (gfx950).
+//
+// Semantics: TF1's dense apply_gradients on a variable read through tf.nn.l2_normalize(var, 1)
+// (code/base/initializers.py:26, code/MultiKE_model.py:15-31).  TF back-propagates through the
+// normalisation (Jacobian below) and runs ApplyAdagrad over the whole [n,dim] variable; a row whose
+// gradient is exactly zero is left bit-identical (acc += 0, w -= 0), so visiting only the rows flagged
+// by the scatter kernels is the same function at a fraction of the traffic.
+//
+// Shape: a 16-lane quarter-wave takes 16 consecutive rows; lane j reads touched[base+j] (one 64-byte
+// read), the quarter ballots the flags and walks the set bits; each visited row is 3 row reads
+// (grad, w, acc) + 3 row writes (0, w, acc).
+#include "mke_common.h"
+
+namespace mke {
+
+struct UpdateParams {
+  float* __restrict__ table;
+  float* __restrict__ acc;
+  float* __restrict__ grad;
+  const int32_t* __restrict__ touched;
+  int32_t tag;
+  int64_t n_rows;
+  int stride, dim;
+  int normalize, optimizer;
+  float lr;
+};
+
+template <int FPL>
+__device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t row, int j) {
+  float* gp = p.grad + row * (int64_t)p.stride + j;
+  float* wp = p.table + row * (int64_t)p.stride + j;
+  float g[FPL], w[FPL], a[FPL];
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) g[k] = gp[k * 16];
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
+  const bool adagrad = p.optimizer == MKE_OPT_ADAGRAD;
+  float* ap = adagrad ? p.acc + row * (int64_t)p.stride + j : nullptr;
+  if (adagrad) {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) a[k] = ap[k * 16];
+  }
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) gp[k * 16] = 0.f;  // consume: restore the all-zero invariant
+
+  if (p.normalize) {
+    float s = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      s = fmaf(w[k], w[k], s);
+      dot = fmaf(w[k], g[k], dot);
+    }
+    s = sub16_sum(s);
+    dot = sub16_sum(dot);
+    const float inv = rsqrtf(fmaxf(s, MKE_L2_EPS));
+    // g = (ghat - what*(what.ghat)) * inv ; what.ghat = inv*dot ; what = w*inv
+    const float coef = (s > MKE_L2_EPS) ? dot * inv * inv : 0.f;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) g[k] = (g[k] - w[k] * coef) * inv;
+  }
+  if (adagrad) {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      a[k] = fmaf(g[k], g[k], a[k]);
+      w[k] -= p.lr * g[k] / sqrtf(a[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) ap[k * 16] = a[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) w[k] -= p.lr * g[k];
+  }
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
+}
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_rows_update(const UpdateParams p) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t base = sub * 16;
+  if (base >= p.n_rows) return;
+  const int64_t r = base + j;
+  const bool mine = (r < p.n_rows) && (p.touched[r] == p.tag);
+  // 64-bit wave ballot -> this quarter's 16 bits
+  const uint64_t ball = __ballot(mine);
+  const int q = (threadIdx.x & 63) >> 4;
+  uint32_t m = (uint32_t)((ball >> (q * 16)) & 0xFFFFu);
+  while (m) {
+    const int b = __builtin_ctz(m);
+    m &= m - 1;
+    update_one_row<FPL>(p, base + b, j);
+  }
+}
+
+}  // namespace mke
+
+extern "C" int mke_rows_update(float* table, float* acc, float* grad, const int32_t* touched, int32_t tag,
+                               int64_t n_rows, int stride, int dim, int normalize, int optimizer, float lr,
+                               void* stream) {
+  using namespace mke;
+  if (!table || !grad || !touched) { set_error("mke_rows_update: NULL table/grad/touched"); return MKE_E_NULL; }
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
+  if (n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
+  if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) {
+    set_error("bad stride/dim: stride=%d dim=%d", stride, dim);
+    return MKE_E_SHAPE;
+  }
+  if (n_rows == 0) return MKE_OK;
+  UpdateParams p;
+  p.table = table; p.acc = acc; p.grad = grad; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
+  p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
+  const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
+  const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+  hipStream_t st = (hipStream_t)stream;
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_rows_update<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
+  });
+  return check_launch("k_rows_update");
+}

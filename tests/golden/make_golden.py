@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by EXECUTING THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py [--reference /root/reference]
+
+What runs, and how:
+  * `code/losses.py` is imported unmodified.  Its only dependency is `import tensorflow as tf`, which is
+    not installable here, so a module named `tensorflow` is placed in `sys.modules` that forwards the
+    dozen op NAMES losses.py uses (reduce_sum, square, log, exp, add, multiply, pow, matmul,
+    nn.l2_normalize) to torch.  The op SEQUENCE is therefore the reference's; TF's own kernels are not
+    reproduced ("parity unpinned at the TF boundary").
+  * `code/base/batch.py` and `code/attr_batch.py` are imported unmodified with empty stand-in modules
+    for the imports they never use on this path (`tensorflow`, `gensim`), and run under fixed
+    `random.seed` / `np.random.seed`.
+  * graph-level pieces that exist only inside TF (gradient of l2_normalize, ApplyAdagrad) are produced
+    with torch autograd and `torch.optim.Adagrad(initial_accumulator_value=0.1, eps=0)` on top of the
+    reference's loss functions.
+
+Only data (inputs and expected outputs) is written; no reference source text is stored.
+"""
+import argparse
+import importlib
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------
+def install_tf_forwarder():
+    import importlib.machinery
+    tf = types.ModuleType("tensorflow")
+    tf.__spec__ = importlib.machinery.ModuleSpec("tensorflow", None)  # torch probes find_spec("tensorflow")
+    tf.reduce_sum = lambda x, axis=None: torch.sum(x) if axis is None else torch.sum(x, dim=axis)
+    tf.square = torch.square
+    tf.log = torch.log
+    tf.exp = torch.exp
+    tf.add = torch.add
+    tf.multiply = torch.mul
+    tf.pow = torch.pow
+    tf.matmul = lambda a, b, transpose_b=False: a @ (b.T if transpose_b else b)
+    nn = types.ModuleType("tensorflow.nn")
+
+    def l2_normalize(x, axis=None, epsilon=1e-12, dim=None):
+        axis = dim if axis is None else axis
+        ssq = torch.sum(x * x) if axis is None else torch.sum(x * x, dim=axis, keepdim=True)
+        return x * torch.rsqrt(torch.clamp_min(ssq, epsilon))
+
+    nn.l2_normalize = l2_normalize
+    tf.nn = nn
+    sys.modules["tensorflow"] = tf
+    sys.modules["tensorflow.nn"] = nn
+    return tf
+
+
+def install_empty_standins():
+    for name in ("gensim", "gensim.models", "gensim.models.word2vec", "Levenshtein"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["gensim.models.word2vec"].Word2Vec = object
+
+
+def T(a, dtype):
+    return torch.tensor(np.asarray(a), dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+def make_case(rng, E, R, d, P, N):
+    """Tables + one grouped batch with duplicates, a few arbitrary negatives and weights."""
+    sigma_e = np.sqrt(2.6 / (E + d))
+    ent = (rng.standard_normal((E, d)).clip(-2, 2) * sigma_e).astype(np.float32)
+    rel = (rng.standard_normal((R, d)).clip(-2, 2) * np.sqrt(2.6 / (R + d))).astype(np.float32)
+    ph = rng.integers(0, E, P)
+    pr = rng.integers(0, R, P)
+    pt = rng.integers(0, E, P)
+    if P > 3:  # force duplicates: same entity as head, tail and in several positives
+        ph[1] = ph[0]
+        pt[2] = ph[0]
+    nh = np.repeat(ph, N)
+    nr = np.repeat(pr, N)
+    nt = np.repeat(pt, N)
+    side = rng.integers(0, 2, P * N).astype(bool)
+    corrupt = rng.integers(0, E, P * N)
+    nh = np.where(side, corrupt, nh)
+    nt = np.where(side, nt, corrupt)
+    # a few irregular negatives: identical to the positive, both sides changed, other relation
+    if P * N > 6:
+        nh[0], nt[0] = ph[0], pt[0]
+        nh[3], nt[3] = rng.integers(0, E), rng.integers(0, E)
+        nr[5] = (nr[5] + 1) % R
+    pw = rng.uniform(0.2, 1.0, P).astype(np.float32)
+    nw = rng.uniform(0.2, 1.0, P * N).astype(np.float32)
+    return dict(ent=ent, rel=rel, ph=ph.astype(np.int32), pr=pr.astype(np.int32), pt=pt.astype(np.int32),
+                nh=nh.astype(np.int32), nr=nr.astype(np.int32), nt=nt.astype(np.int32), pw=pw, nw=nw)
+
+
+def losses_fixture(ref_losses, tf, out):
+    cases = [(0, 40, 6, 4, 7, 1), (1, 40, 6, 4, 7, 10), (2, 40, 6, 4, 64, 10), (0, 80, 9, 75, 16, 10),
+             (1, 80, 9, 75, 7, 1)]
+    lr = 0.001
+    for ci, (seed, E, R, d, P, N) in enumerate(cases):
+        rng = np.random.default_rng(1000 + seed + 17 * ci)
+        c = make_case(rng, E, R, d, P, N)
+        pre = f"c{ci}_"
+        for k, v in c.items():
+            out[pre + k] = v
+        out[pre + "meta"] = np.array([seed, E, R, d, P, N], dtype=np.int64)
+        idx = {k: torch.tensor(c[k].astype(np.int64)) for k in ("ph", "pr", "pt", "nh", "nr", "nt")}
+        M_np = (np.linalg.qr(rng.standard_normal((d, d)))[0] + 0.05 * rng.standard_normal((d, d))).astype(np.float32)
+        out[pre + "a6_M"] = M_np
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            ent = T(c["ent"], dt).requires_grad_(True)
+            rel = T(c["rel"], dt).requires_grad_(True)
+
+            def gathered():
+                En = tf.nn.l2_normalize(ent, 1)
+                Rn = tf.nn.l2_normalize(rel, 1)
+                return [En[idx["ph"]], Rn[idx["pr"]], En[idx["pt"]], En[idx["nh"]], Rn[idx["nr"]], En[idx["nt"]]]
+
+            # a1 on gathered rows: loss, grads w.r.t. gathered rows and w.r.t. the raw tables
+            rows = gathered()
+            for r_ in rows:
+                r_.retain_grad()
+            loss = ref_losses.relation_logistic_loss(*rows)
+            loss.backward()
+            out[pre + "a1_loss_" + tag] = np.float64(loss.item())
+            if tag == "f64":
+                for name, r_ in zip(("gph", "gpr", "gpt", "gnh", "gnr", "gnt"), rows):
+                    out[pre + "a1_" + name] = r_.grad.numpy()
+                out[pre + "a1_gent_raw"] = ent.grad.numpy().copy()
+                out[pre + "a1_grel_raw"] = rel.grad.numpy().copy()
+            # three optimizer steps on the same batch (TF1 Adagrad: acc0 = 0.1, no epsilon)
+            ent2 = T(c["ent"], dt).requires_grad_(True)
+            rel2 = T(c["rel"], dt).requires_grad_(True)
+            opt = torch.optim.Adagrad([ent2, rel2], lr=lr, initial_accumulator_value=0.1, eps=0.0)
+            step_losses = []
+            for step in range(3):
+                opt.zero_grad()
+                En = tf.nn.l2_normalize(ent2, 1)
+                Rn = tf.nn.l2_normalize(rel2, 1)
+                L = ref_losses.relation_logistic_loss(En[idx["ph"]], Rn[idx["pr"]], En[idx["pt"]], En[idx["nh"]],
+                                                      Rn[idx["nr"]], En[idx["nt"]])
+                L.backward()
+                opt.step()
+                step_losses.append(L.item())
+                if step in (0, 2) and tag == "f64":
+                    out[pre + f"a1_ent_after{step + 1}"] = ent2.detach().numpy().copy()
+                    out[pre + f"a1_rel_after{step + 1}"] = rel2.detach().numpy().copy()
+            out[pre + "a1_step_losses_" + tag] = np.array(step_losses)
+
+            # the other losses.py functions on gathered rows (loss + grads w.r.t. inputs), f64 grads only
+            with torch.no_grad():
+                base = [x.detach().clone() for x in gathered()]
+            pw, nw = T(c["pw"], dt), T(c["nw"], dt)
+
+            def run(name, fn, args, store_grads=True):
+                leaves = [a.clone().requires_grad_(True) if a.is_floating_point() and a.dim() == 2 else a for a in args]
+                val = fn(*leaves)
+                out[pre + name + "_loss_" + tag] = np.float64(val.item())
+                if tag == "f64" and store_grads:
+                    val.backward()
+                    for k, a in enumerate(leaves):
+                        if a.requires_grad:
+                            out[pre + f"{name}_g{k}"] = a.grad.numpy()
+
+            run("a2", ref_losses.relation_logistic_loss_wo_negs, base[:3])
+            run("a2b", ref_losses.attribute_logistic_loss_wo_negs, base[:3], store_grads=False)
+            run("a3", ref_losses.logistic_loss_wo_negs, base[:3] + [pw])
+            run("a4", ref_losses.attribute_logistic_loss, base[:3] + [pw] + base[3:] + [nw])
+            run("a5", ref_losses.alignment_loss, [base[0], base[2]])
+            M = T(M_np, dt)
+            eye = torch.eye(d, dtype=dt)
+            run("a6", lambda v, s, m: ref_losses.space_mapping_loss(v, s, m, eye, 2.0), [base[0], base[2], M])
+            run("a6o", lambda m: ref_losses.orthogonal_loss(m, eye), [M])
+
+
+def toy_kgs(rng):
+    n1, n2 = 50, 50
+    ents1, ents2 = list(range(n1)), list(range(n1, n1 + n2))
+
+    def triples(ents, rels, n):
+        s = set()
+        while len(s) < n:
+            s.add((int(rng.choice(ents)), int(rng.choice(rels)), int(rng.choice(ents))))
+        return sorted(s)
+
+    t1 = triples(ents1, list(range(6)), 130)
+    t2 = triples(ents2, list(range(6, 11)), 110)
+    # "known" sets are supersets of the positives (the reference's alias includes swapped triples)
+    k1 = set(t1) | set(triples(ents1, list(range(6)), 60))
+    k2 = set(t2) | set(triples(ents2, list(range(6, 11)), 60))
+    return ents1, ents2, t1, t2, k1, k2
+
+
+def sampler_fixture(ref_batch, ref_attr_batch, out_json):
+    rng = np.random.default_rng(77)
+    ents1, ents2, t1, t2, k1, k2 = toy_kgs(rng)
+    out_json["ents1"], out_json["ents2"] = ents1, ents2
+    out_json["triples1"], out_json["triples2"] = t1, t2
+    out_json["known1"], out_json["known2"] = sorted(k1), sorted(k2)
+    # truncated-sampling neighbour dicts for some entities (code/base/batch.py:94-95 neighbor.get(x, all))
+    near1 = {e: [int(x) for x in rng.choice(ents1, 12, replace=False)] for e in ents1[::3]}
+    near2 = {e: [int(x) for x in rng.choice(ents2, 12, replace=False)] for e in ents2[::2]}
+    out_json["near1"] = {str(k): v for k, v in near1.items()}
+    out_json["near2"] = {str(k): v for k, v in near2.items()}
+    runs = []
+    for seed, bs, N, use_near in ((0, 20, 5, False), (1, 20, 5, True), (2, 48, 10, False), (3, 240, 3, True)):
+        steps = int(np.ceil((len(t1) + len(t2)) / bs))
+        random.seed(seed)
+        np.random.seed(seed)
+        per_step = []
+        for step in range(steps + 1):  # one step past the end: empty slices
+            pos, neg = ref_batch.generate_relation_triple_batch(t1, t2, k1, k2, ents1, ents2, bs, step,
+                                                                near1 if use_near else None,
+                                                                near2 if use_near else None, N)
+            per_step.append({"pos": [list(x) for x in pos], "neg": [list(x) for x in neg]})
+        runs.append({"seed": seed, "batch_size": bs, "neg": N, "use_near": use_near, "steps": per_step})
+    out_json["relation_runs"] = runs
+    # attribute batches (weights ride along; the live call passes neg_triples_num = 0 — MultiKE_model.py:331)
+    a1 = [(h, r, t, round(0.2 + 0.01 * i, 4)) for i, (h, r, t) in enumerate(t1[:70])]
+    a2 = [(h, r, t, round(0.5 + 0.005 * i, 4)) for i, (h, r, t) in enumerate(t2[:45])]
+    out_json["attr1"], out_json["attr2"] = [list(x) for x in a1], [list(x) for x in a2]
+    arun = []
+    for step in range(5):
+        pos, neg = ref_attr_batch.generate_attribute_triple_batch(a1, a2, set(a1), set(a2), ents1, ents2, 30, step,
+                                                                  None, None, 0)
+        arun.append({"pos": [list(x) for x in pos], "neg": [list(x) for x in neg]})
+    out_json["attribute_run"] = {"batch_size": 30, "steps": arun}
+
+
+def host_fixture(ref_utils, out_json):
+    td = []
+    for total, n in ((183, 4), (3, 4), (4, 4), (0, 4), (10, 3), (7, 0), (9, 2)):
+        td.append({"total": total, "n": n, "tasks": [list(map(int, x)) for x in ref_utils.task_divide(list(range(total)), n)]})
+    out_json["task_divide"] = td
+    sp = []
+    for n1, n2, B in ((460000, 450000, 5000), (130, 110, 20), (1, 999, 5000), (105000, 95000, 5000), (7, 7, 3)):
+        b1 = int(n1 / (n1 + n2) * B)  # code/base/batch.py:36-37 evaluated here as the expected value
+        sp.append({"n1": n1, "n2": n2, "batch": B, "b1": b1, "b2": B - b1})
+    out_json["kg_batch_split"] = sp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    a = ap.parse_args()
+    code = os.path.join(a.reference, "code")
+    if not os.path.isdir(code):
+        sys.exit(f"reference not found at {code} (this script only runs in the build container)")
+    sys.path.insert(0, code)
+    tf = install_tf_forwarder()
+    install_empty_standins()
+    ref_losses = importlib.import_module("losses")
+    ref_batch = importlib.import_module("base.batch")
+    ref_attr_batch = importlib.import_module("attr_batch")
+    ref_utils = importlib.import_module("utils")
+
+    out = {}
+    losses_fixture(ref_losses, tf, out)
+    np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
+    js = {}
+    sampler_fixture(ref_batch, ref_attr_batch, js)
+    host_fixture(ref_utils, js)
+    with open(os.path.join(HERE, "sampler_golden.json"), "w") as f:
+        json.dump(js, f, separators=(",", ":"))
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()
