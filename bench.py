@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — scored (pos+neg) triples/s of the MultiKE relation-view train step on MI355X.
+
+A "step" is one pass of the hot path over one batch: on-device negative sampling -> fused gather /
+normalise / score / logistic loss / gradient scatter -> per-row Jacobian + Adagrad on both tables
+(what one `session.run([relation_loss, relation_optimizer])` of the reference does,
+code/MultiKE_model.py:304-310).  Workload at N=1: BASELINE.json configs[1] shape on synthetic triples
+(|E|=200K, |R|=550, dim=75, neg=25, batch 5000 => 130K scored triples per step; SURVEY.md §8d "C2-synth").
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=366)  # two synthetic "epochs" of 183 steps
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n-ent", type=int, default=200_000)
+    ap.add_argument("--n-rel", type=int, default=550)
+    ap.add_argument("--dim", type=int, default=75)
+    ap.add_argument("--neg", type=int, default=25)
+    ap.add_argument("--batch", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=60)
+    return ap.parse_args()
+
+
+def b_alg(dim):
+    """Algorithmic bytes per scored triple: 3 ids + 3 gathered rows + 3 gradient rows."""
+    return 12 + 24 * dim
+
+
+def cpu_baseline(args, kgs, ent, rel):
+    """The oracle's C restatement (oracle/mke_oracle.c) timed on this box's host cores, 1 thread, on a bounded
+    sample of the same workload: `cpu_steps` steps (sampler + step, touched-rows update)."""
+    from oracle import c_oracle as co
+    from oracle import multike_oracle as mo
+    d, N, B = args.dim, args.neg, args.batch
+    t1, t2 = kgs.triples
+    b1, b2 = mo.kg_batch_split(len(t1), len(t2), B)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in (t1, t2)]
+    out = {}
+    for dense, steps in ((False, args.cpu_steps), (True, max(2, args.cpu_steps // 5))):
+        e, r = ent.copy(), rel.copy()
+        a, b = np.full_like(e, 0.1), np.full_like(r, 0.1)
+        orc = co.RelationStepOracle(e.shape[0], r.shape[0], d, np.float32, dense=dense)
+        scored = 0
+        t0 = time.perf_counter()
+        for s in range(steps):
+            pos_parts, neg_parts = [], []
+            for k, (t, bs) in enumerate(((t1, b1), (t2, b2))):
+                p = t[s * bs:(s + 1) * bs]
+                lo, hi = kgs.ent_range[k]
+                neg_parts.append(co.neg_sample(p[:, 0], p[:, 1], p[:, 2], N, hi - lo, ent_lo=lo, known=sets[k],
+                                               seed=(1, 0), stream_id=k, pos_offset=s * bs))
+                pos_parts.append(p)
+            pos = [np.concatenate([pos_parts[0][:, i], pos_parts[1][:, i]]) for i in range(3)]
+            neg = [np.concatenate([neg_parts[0][i], neg_parts[1][i]]) for i in range(3)]
+            orc.step(e, r, a, b, pos, neg, 0.001)
+            scored += len(pos[0]) * (1 + N)
+        dt = time.perf_counter() - t0
+        out["dense" if dense else "sparse"] = (scored / dt, steps, dt)
+    v, steps, dt = out["sparse"]
+    vd, dsteps, ddt = out["dense"]
+    return {
+        "value": v, "unit": "scored triples/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} steps of the same workload ({dt:.1f}s): C restatement of sampler + relation-view step, "
+                  f"touched-rows update, fp32, 1 thread",
+        "dense_semantics_value": vd,
+        "dense_semantics_sample": f"{dsteps} steps ({ddt:.1f}s) with the reference's whole-table normalise + dense "
+                                  f"Jacobian/Adagrad cost model",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (multike_amd has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    from oracle import multike_oracle as mo  # xavier init values only (shared with cpu_baseline)
+
+    d, N, B = args.dim, args.neg, args.batch
+    kgs = SyntheticKGs(n_ent=args.n_ent, n_rel=args.n_rel, seed=1234)
+    rng = np.random.default_rng(1234)
+    ent0 = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
+    rel0 = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
+
+    if world > 1:
+        from multike_amd.distributed import ShardedRelationTrainer
+        trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234)
+        run_step = trainer.step
+        n_steps_epoch = trainer.steps
+        triples_of = trainer.global_scored
+        score_ms = None
+    else:
+        E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", values=ent0)
+        R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=rel0)
+        sides = []
+        for k in (0, 1):
+            t = torch.as_tensor(kgs.triples[k], device="cuda")
+            sides.append(KGSide(kgs.entities(k),
+                                KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
+        bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=1234)
+        eng = StepEngine()
+        n_steps_epoch = bat.steps
+        negbuf = tuple(torch.empty(B * N, dtype=torch.int32, device="cuda") for _ in range(3))
+        ev = []
+
+        def run_step(i, timed=False):
+            s = i % n_steps_epoch
+            if s == 0 and i > 0:
+                bat.shuffle()
+            n = int(bat.off[s + 1] - bat.off[s]) * N
+            pos, neg = bat.batch(s, out=tuple(x[:n] for x in negbuf))
+            if timed:  # HIP events around the dominant kernel only, on the stream it is launched on
+                from multike_amd import _lib
+                tag, lp = eng._next()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.triple_score_fwd_bwd(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
+                                          E.touched, R.touched, tag, lp)
+                e1.record()
+                ev.append((e0, e1, pos[0].numel() * (1 + N)))
+                eng._apply(E, "relation", "Adagrad", 0.001, tag)
+                eng._apply(R, "relation", "Adagrad", 0.001, tag)
+            else:
+                eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.001)
+
+        def triples_of(i):
+            s = i % n_steps_epoch
+            return int(bat.off[s + 1] - bat.off[s]) * (1 + N)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        run_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        run_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    scored = sum(triples_of(i) for i in range(args.warmup, args.warmup + args.steps))
+    value = scored / dt
+
+    roofline = None
+    if world == 1:
+        # instrumented pass over the same K steps: HIP events bracket every launch of the dominant kernel
+        base = args.warmup + args.steps
+        for i in range(base, base + args.steps):
+            run_step(i, timed=True)
+        torch.cuda.synchronize()
+        ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
+        tr = np.array([n for _, _, n in ev])
+        avg_ms = float(ms.mean())
+        achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
+        roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": avg_ms * 1e3, "alg_bytes_per_triple": b_alg(d),
+                    "triples_per_launch": float(tr.mean())}
+
+    if rank == 0:
+        out = {
+            "metric": "scored triples/sec (pos+neg)", "value": value, "unit": "triples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "relation-view ITC train step (sampler + fused score/grad + Adagrad), "
+                                   f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}"
+                                   + (f" per GPU, entity rows sharded id%{world}" if world > 1 else ""),
+                       "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,
+                       "scored_per_step": B * (1 + N) * world, "steps_per_epoch": n_steps_epoch},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+"""ctypes binding of libmultike_hip.so (the C-ABI declared in include/multike_hip.h).
+
+This is the only place the product touches native code.  There is NO fallback: if the library is
+missing or a tensor is not on the GPU the call raises.  PyTorch is used for device memory and streams
+only — every pointer handed to the library is `tensor.data_ptr()` of a CUDA(HIP) tensor and the stream
+is torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmultike_hip.so")
+
+LOSS_PARTIALS = 1024  # MKE_LOSS_PARTIALS
+MAX_STRIDE = 320  # MKE_MAX_STRIDE
+OPT_ADAGRAD, OPT_SGD = 0, 1
+_SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
+
+# every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
+SYMBOLS = (
+    "mke_version", "mke_last_error", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_neg_sample",
+    "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
+    "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows",
+)
+
+_lib = None
+
+
+class MultiKEHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built — there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MultiKEHipError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C multike_amd/csrc`.  multike_amd has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        L.mke_version.restype = C.c_int
+        L.mke_last_error.restype = C.c_char_p
+        for name in SYMBOLS[2:]:
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def stride_for(dim: int) -> int:
+    """Smallest supported row stride (floats) >= dim: a multiple of 16 whose /16 the kernels instantiate."""
+    need = (dim + 15) // 16
+    for f in _SUPPORTED_FPL:
+        if f >= need:
+            return f * 16
+    raise MultiKEHipError(f"dim {dim} exceeds the largest supported stride {MAX_STRIDE}")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mke_last_error().decode("utf-8", "replace")
+        raise MultiKEHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def _dev(t: torch.Tensor | None, dtype, name: str):
+    """data_ptr of a contiguous CUDA tensor of the given dtype (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise MultiKEHipError(f"{name}: expected a CUDA/HIP tensor, got device {t.device} (no CPU path exists)")
+    if t.dtype != dtype:
+        raise MultiKEHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MultiKEHipError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def version() -> int:
+    return lib().mke_version()
+
+
+def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale,
+                         grad_ent, grad_rel, touched_ent, touched_rel, tag, loss_partials):
+    """mke_triple_score_fwd_bwd.  pos/neg = (h, r, t) int32 CUDA tensors (neg may be None)."""
+    ph, pr, pt = pos
+    n_pos = ph.numel()
+    if neg is None:
+        nh = nr = nt = None
+        n_neg = 0
+    else:
+        nh, nr, nt = neg
+        n_neg = nh.numel()
+    rc = lib().mke_triple_score_fwd_bwd(
+        _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
+        _dev(rel, torch.float32, "rel_table"), C.c_int64(rel.shape[0]), C.c_int(int(rel_normalize)),
+        C.c_int(ent.shape[1]), C.c_int(dim),
+        _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+        _dev(pos_w, torch.float32, "pos_w"), C.c_int64(n_pos),
+        _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"),
+        _dev(neg_w, torch.float32, "neg_w"), C.c_int64(n_neg), C.c_int(neg_per_pos), C.c_float(scale),
+        _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"),
+        _dev(touched_ent, torch.int32, "touched_ent"), _dev(touched_rel, torch.int32, "touched_rel"), C.c_int32(tag),
+        _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_triple_score_fwd_bwd")
+
+
+def rows_update(table, acc, grad, touched, tag, dim, normalize, optimizer, lr):
+    rc = lib().mke_rows_update(
+        _dev(table, torch.float32, "table"), _dev(acc, torch.float32, "acc"), _dev(grad, torch.float32, "grad"),
+        _dev(touched, torch.int32, "touched"), C.c_int32(tag), C.c_int64(table.shape[0]), C.c_int(table.shape[1]),
+        C.c_int(dim), C.c_int(int(normalize)), C.c_int(optimizer), C.c_float(lr), _stream())
+    _check(rc, "mke_rows_update")
+
+
+def neg_sample(pos, pos_offset, neg_per_pos, max_try, ent_list, ent_lo, n_cand_all, cand_table, cand_valid, known_keys,
+               seed, stream_id, neg_out):
+    ph, pr, pt = pos
+    nh, nr, nt = neg_out
+    cand_k = 0 if cand_table is None else cand_table.shape[1]
+    cap = 0 if known_keys is None else known_keys.numel()
+    rc = lib().mke_neg_sample(
+        _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+        C.c_int64(ph.numel()), C.c_int64(pos_offset), C.c_int(neg_per_pos), C.c_int(max_try),
+        _dev(ent_list, torch.int32, "ent_list"), C.c_int32(ent_lo), C.c_int32(n_cand_all),
+        _dev(cand_table, torch.int32, "cand_table"), _dev(cand_valid, torch.uint8, "cand_valid"), C.c_int32(cand_k),
+        _dev(known_keys, torch.int64, "known_keys"), C.c_uint64(cap), C.c_uint32(seed[0] & 0xFFFFFFFF),
+        C.c_uint32(seed[1] & 0xFFFFFFFF), C.c_uint32(stream_id & 0xFFFFFFFF),
+        _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"), _stream())
+    _check(rc, "mke_neg_sample")
+
+
+def tripleset_build(h, r, t, keys):
+    rc = lib().mke_tripleset_build(_dev(h, torch.int32, "h"), _dev(r, torch.int32, "r"), _dev(t, torch.int32, "t"),
+                                   C.c_int64(h.numel()), _dev(keys, torch.int64, "keys"), C.c_uint64(keys.numel()),
+                                   _stream())
+    _check(rc, "mke_tripleset_build")
+
+
+def tripleset_query(h, r, t, keys, out):
+    rc = lib().mke_tripleset_query(_dev(h, torch.int32, "h"), _dev(r, torch.int32, "r"), _dev(t, torch.int32, "t"),
+                                   C.c_int64(h.numel()), _dev(keys, torch.int64, "keys"), C.c_uint64(keys.numel()),
+                                   _dev(out, torch.uint8, "out"), _stream())
+    _check(rc, "mke_tripleset_query")
+
+
+def gathered_logistic_fwd_bwd(hs, rs, ts, ws, sign, gh, gr, gt, loss_partials):
+    n, dim = hs.shape
+    rc = lib().mke_gathered_logistic_fwd_bwd(
+        _dev(hs, torch.float32, "hs"), _dev(rs, torch.float32, "rs"), _dev(ts, torch.float32, "ts"),
+        _dev(ws, torch.float32, "ws"), C.c_int64(n), C.c_int(dim), C.c_int(dim), C.c_int(sign),
+        _dev(gh, torch.float32, "gh"), _dev(gr, torch.float32, "gr"), _dev(gt, torch.float32, "gt"),
+        _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_gathered_logistic_fwd_bwd")
+
+
+def gathered_alignment_fwd_bwd(a, b, ga, gb, loss_partials):
+    n, dim = a.shape
+    rc = lib().mke_gathered_alignment_fwd_bwd(
+        _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b"), C.c_int64(n), C.c_int(dim), C.c_int(dim),
+        _dev(ga, torch.float32, "ga"), _dev(gb, torch.float32, "gb"),
+        _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_gathered_alignment_fwd_bwd")
+
+
+def align_fwd_bwd(table_a, a_normalize, table_b, b_normalize, dim, ia, ib, weight, grad_a, touched_a, grad_b, touched_b,
+                  tag, loss_partials):
+    rc = lib().mke_align_fwd_bwd(
+        _dev(table_a, torch.float32, "table_a"), C.c_int(int(a_normalize)), _dev(table_b, torch.float32, "table_b"),
+        C.c_int(int(b_normalize)), C.c_int(table_a.shape[1]), C.c_int(dim), _dev(ia, torch.int32, "ia"),
+        _dev(ib, torch.int32, "ib"), C.c_int64(ia.numel()), C.c_float(weight), _dev(grad_a, torch.float32, "grad_a"),
+        _dev(touched_a, torch.int32, "touched_a"), _dev(grad_b, torch.float32, "grad_b"),
+        _dev(touched_b, torch.int32, "touched_b"), C.c_int32(tag), _dev(loss_partials, torch.float64, "loss_partials"),
+        _stream())
+    _check(rc, "mke_align_fwd_bwd")
+
+
+def gather_rows(table, normalize, dim, idx, out):
+    n = out.shape[0]
+    rc = lib().mke_gather_rows(_dev(table, torch.float32, "table"), C.c_int(int(normalize)), C.c_int(table.shape[1]),
+                               C.c_int(dim), _dev(idx, torch.int32, "idx"), C.c_int64(n),
+                               _dev(out, torch.float32, "out"), _stream())
+    _check(rc, "mke_gather_rows")

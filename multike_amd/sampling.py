@@ -1,0 +1,157 @@
+"""Device-resident relation-triple batches and negative sampling.
+
+Host-side mirror of what the reference's producer processes do per step
+(code/base/batch.py:22-54,86-116, driven from code/MultiKE_model.py:291-303), restructured for one GPU:
+the positive lists of both KGs live in HBM as int32 columns, an epoch is one device permutation per KG,
+a step's positives are a contiguous slice [KG1 part | KG2 part] (proportional split,
+code/base/batch.py:36-37), and negatives come from `mke_neg_sample` (Philox stream, see
+oracle/sampler_oracle.py for the specification the kernel is tested against bit for bit).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def kg_batch_split(n1: int, n2: int, batch_size: int):
+    """code/base/batch.py:36-37."""
+    b1 = int(n1 / (n1 + n2) * batch_size)
+    return b1, batch_size - b1
+
+
+class KnownTripleSet:
+    """Open-addressing hash set of packed (h, r, t) keys in HBM — the `all_triples_set` membership test of
+    code/base/batch.py:109."""
+
+    MAX_ENT, MAX_REL = 1 << 26, 1 << 12
+
+    def __init__(self, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor):
+        n = h.numel()
+        if n and (int(h.max()) >= self.MAX_ENT or int(t.max()) >= self.MAX_ENT or int(r.max()) >= self.MAX_REL):
+            raise _lib.MultiKEHipError("entity id >= 2^26 or relation id >= 2^12 does not fit the packed triple key")
+        cap = 1
+        while cap < 2 * n + 2:
+            cap *= 2
+        self.keys = torch.full((cap,), -1, dtype=torch.int64, device=h.device)
+        self.add(h, r, t)
+
+    def add(self, h, r, t):
+        _lib.tripleset_build(h.contiguous(), r.contiguous(), t.contiguous(), self.keys)
+
+    def contains(self, h, r, t) -> torch.Tensor:
+        out = torch.empty(h.numel(), dtype=torch.uint8, device=h.device)
+        _lib.tripleset_query(h.contiguous(), r.contiguous(), t.contiguous(), self.keys, out)
+        return out.bool()
+
+
+class KGSide:
+    """Everything the sampler needs about one KG: candidate population, known triples, neighbour table."""
+
+    def __init__(self, entities, known: KnownTripleSet | None, device="cuda"):
+        ents = np.asarray(entities, dtype=np.int64)
+        self.n_ent = len(ents)
+        if self.n_ent and np.array_equal(ents, np.arange(ents[0], ents[0] + self.n_ent)):
+            self.ent_lo, self.ent_list = int(ents[0]), None  # contiguous id range (code/base/read.py:75-84)
+        else:
+            self.ent_lo, self.ent_list = 0, torch.as_tensor(ents, dtype=torch.int32, device=device)
+        self.known = known
+        self.cand_table = None  # [n_ent_total, k] int32: truncated-sampling neighbours (code/base/batch.py:119-150)
+        self.cand_valid = None  # [n_ent_total] uint8: entity has a neighbour list (dict membership)
+
+    def set_neighbours(self, cand_table: torch.Tensor | None, cand_valid: torch.Tensor | None):
+        self.cand_table, self.cand_valid = cand_table, cand_valid
+
+
+def sample_negatives(pos, side: KGSide, neg_per_pos: int, seed=(0, 0), stream_id=0, pos_offset=0, max_try=10,
+                     out=None):
+    """generate_neg_triples_fast for one KG's slice of positives, on device."""
+    ph, pr, pt = pos
+    n = ph.numel() * neg_per_pos
+    if out is None:
+        out = tuple(torch.empty(n, dtype=torch.int32, device=ph.device) for _ in range(3))
+    if n:
+        _lib.neg_sample(pos, pos_offset, neg_per_pos, max_try, side.ent_list, side.ent_lo, side.n_ent, side.cand_table,
+                        side.cand_valid, None if side.known is None else side.known.keys, seed, stream_id, out)
+    return out
+
+
+class RelationBatcher:
+    """Epoch/step bookkeeping of the relation view on device.
+
+    triples1/triples2: array-like [n, 3] (h, r, t) of each KG's `local_relation_triples_list`.
+    """
+
+    def __init__(self, triples1, triples2, side1: KGSide, side2: KGSide, batch_size: int, neg_per_pos: int,
+                 device="cuda", seed: int = 0):
+        self.device = torch.device(device)
+        self.t1 = torch.as_tensor(np.asarray(triples1, dtype=np.int32).reshape(-1, 3), device=self.device)
+        self.t2 = torch.as_tensor(np.asarray(triples2, dtype=np.int32).reshape(-1, 3), device=self.device)
+        self.side1, self.side2 = side1, side2
+        self.batch_size, self.neg_per_pos = int(batch_size), int(neg_per_pos)
+        self.n1, self.n2 = self.t1.shape[0], self.t2.shape[0]
+        self.b1, self.b2 = kg_batch_split(self.n1, self.n2, self.batch_size)
+        # the reference's step count: ceil((n1+n2)/batch_size) (code/MultiKE_CSL.py:38-40)
+        self.steps = int(math.ceil((self.n1 + self.n2) / self.batch_size))
+        self.seed = int(seed)
+        self.epoch = 0
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self.seed)
+        self._layout()
+        self._materialise(None, None)
+
+    def _layout(self):
+        """Per-step [lo, hi) of each KG's slice (code/base/batch.py:45-54: short or empty at the end)."""
+        s = np.arange(self.steps, dtype=np.int64)
+        self.lo1, self.hi1 = np.minimum(s * self.b1, self.n1), np.minimum((s + 1) * self.b1, self.n1)
+        self.lo2, self.hi2 = np.minimum(s * self.b2, self.n2), np.minimum((s + 1) * self.b2, self.n2)
+        c1, c2 = self.hi1 - self.lo1, self.hi2 - self.lo2
+        self.off = np.zeros(self.steps + 1, dtype=np.int64)
+        self.off[1:] = np.cumsum(c1 + c2)
+        self.cnt1 = c1
+        # gather map: epoch position -> (kg, index into that KG's (shuffled) list)
+        src = np.empty(int(self.off[-1]), dtype=np.int64)
+        for i in range(self.steps):
+            o = self.off[i]
+            src[o:o + c1[i]] = np.arange(self.lo1[i], self.hi1[i])
+            src[o + c1[i]:self.off[i + 1]] = self.n1 + np.arange(self.lo2[i], self.hi2[i])
+        self._src = torch.as_tensor(src, device=self.device)
+
+    def _materialise(self, perm1, perm2):
+        t1 = self.t1 if perm1 is None else self.t1[perm1]
+        t2 = self.t2 if perm2 is None else self.t2[perm2]
+        allt = torch.cat([t1, t2], 0)[self._src]  # epoch order, step-contiguous
+        self.pos_h = allt[:, 0].contiguous()
+        self.pos_r = allt[:, 1].contiguous()
+        self.pos_t = allt[:, 2].contiguous()
+        self.t1, self.t2 = t1, t2
+
+    def shuffle(self):
+        """random.shuffle of both positive lists after an epoch (code/MultiKE_model.py:314-315)."""
+        p1 = torch.randperm(self.n1, generator=self._gen, device=self.device)
+        p2 = torch.randperm(self.n2, generator=self._gen, device=self.device)
+        self._materialise(p1, p2)
+        self.epoch += 1
+
+    def positives(self, step: int):
+        lo, hi = int(self.off[step]), int(self.off[step + 1])
+        return self.pos_h[lo:hi], self.pos_r[lo:hi], self.pos_t[lo:hi]
+
+    def batch(self, step: int, out=None):
+        """(pos, neg) of one step; negatives grouped neg_per_pos per positive in positive order."""
+        lo, hi = int(self.off[step]), int(self.off[step + 1])
+        mid = lo + int(self.cnt1[step])
+        N = self.neg_per_pos
+        if out is None:
+            out = tuple(torch.empty((hi - lo) * N, dtype=torch.int32, device=self.device) for _ in range(3))
+        sid = (self.epoch * 2) & 0xFFFFFFFF
+        seed = (self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        for (a, b, side, kg) in ((lo, mid, self.side1, 0), (mid, hi, self.side2, 1)):
+            if b > a:
+                pos = (self.pos_h[a:b], self.pos_r[a:b], self.pos_t[a:b])
+                o = tuple(x[(a - lo) * N:(b - lo) * N] for x in out)
+                sample_negatives(pos, side, N, seed=seed, stream_id=sid + kg, pos_offset=a, out=o)
+        return (self.pos_h[lo:hi], self.pos_r[lo:hi], self.pos_t[lo:hi]), out

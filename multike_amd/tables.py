@@ -1,0 +1,150 @@
+"""Embedding tables in HBM and the step executor that drives the HIP kernels.
+
+`EmbeddingTable` plays the role of a TF variable created by `xavier_init(shape, name, is_l2_norm)`
+(reference code/base/initializers.py:22-26, code/MultiKE_model.py:86-99): raw trainable rows plus the
+"read through l2_normalize" flag.  Layout: float32 [n_rows, stride], stride = multiple of 16 >= dim, pad
+columns are zero and stay zero.  Each optimizer that touches the table owns its own Adagrad accumulator
+("slot") exactly as each `generate_optimizer` call does in the reference (code/MultiKE_model.py:28-31;
+SURVEY.md §9.3-4).
+
+`StepEngine` runs one "session.run([loss, optimizer])" worth of work as kernel launches on the current
+stream: scatter kernel(s) -> per-table row update.  No host synchronisation happens here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_value (TF1)
+
+
+class EmbeddingTable:
+    def __init__(self, n_rows: int, dim: int, name: str = "", normalize: bool = True, trainable: bool = True,
+                 device="cuda", values=None, seed=None):
+        self.n_rows, self.dim, self.name = int(n_rows), int(dim), name
+        self.normalize, self.trainable = bool(normalize), bool(trainable)
+        self.stride = _lib.stride_for(self.dim)
+        self.device = torch.device(device)
+        self.data = torch.zeros(self.n_rows, self.stride, dtype=torch.float32, device=self.device)
+        if values is not None:
+            v = torch.as_tensor(np.asarray(values), dtype=torch.float32)
+            assert v.shape == (self.n_rows, self.dim), (v.shape, (self.n_rows, self.dim))
+            self.data[:, :self.dim] = v.to(self.device)
+        elif trainable:
+            self.data[:, :self.dim] = xavier_truncated_normal(self.n_rows, self.dim, self.device, seed)
+        self.slots: dict[str, torch.Tensor] = {}
+        self._grad = None
+        self._touched = None
+
+    # -- scratch (shared by every optimizer of this table; steps are serial on the stream) --
+    @property
+    def grad(self) -> torch.Tensor:
+        if self._grad is None:
+            self._grad = torch.zeros_like(self.data)
+        return self._grad
+
+    @property
+    def touched(self) -> torch.Tensor:
+        if self._touched is None:
+            self._touched = torch.zeros(self.n_rows, dtype=torch.int32, device=self.device)
+        return self._touched
+
+    def slot(self, optimizer_name: str) -> torch.Tensor:
+        """Adagrad accumulator of one optimizer (created on first use, filled with 0.1)."""
+        s = self.slots.get(optimizer_name)
+        if s is None:
+            s = torch.full_like(self.data, ADAGRAD_INIT_ACC)
+            self.slots[optimizer_name] = s
+        return s
+
+    # -- read paths --
+    def lookup(self, idx: torch.Tensor | None = None) -> torch.Tensor:
+        """embedding_lookup on the normalised view -> dense [n, dim] float32 (HIP gather kernel)."""
+        n = self.n_rows if idx is None else idx.numel()
+        out = torch.empty(n, self.dim, dtype=torch.float32, device=self.device)
+        if idx is not None and idx.dtype != torch.int32:
+            idx = idx.to(torch.int32)
+        _lib.gather_rows(self.data, self.normalize, self.dim, idx, out)
+        return out
+
+    def eval(self, session=None) -> np.ndarray:
+        """`tensor.eval(session=...)` of the reference (code/MultiKE_model.py:280-285): the normalised view."""
+        return self.lookup(None).cpu().numpy()
+
+    def raw(self) -> torch.Tensor:
+        return self.data[:, :self.dim]
+
+
+def xavier_truncated_normal(n, d, device, seed=None) -> torch.Tensor:
+    """TF1 xavier_initializer(uniform=False) (code/base/initializers.py:24-25): truncated
+    normal (resample outside 2 sigma), sigma = sqrt(1.3 * 2 / (n + d))."""
+    g = torch.Generator(device="cpu")
+    if seed is not None:
+        g.manual_seed(int(seed))
+    x = torch.empty(n, d, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(x, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+    return (x * float(np.sqrt(2.6 / (n + d)))).to(device)
+
+
+_OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
+
+
+class StepEngine:
+    """Enqueues the kernels of one training step.  One instance per model (per HIP stream)."""
+
+    def __init__(self, device="cuda", loss_ring: int = 256):
+        self.device = torch.device(device)
+        self.tag = 0
+        self.loss_ring = torch.zeros(loss_ring, _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
+        self._ring_pos = 0
+
+    def _next(self):
+        self.tag += 1
+        if self.tag >= 2 ** 31 - 1:
+            raise _lib.MultiKEHipError("step tag overflow")
+        slot = self.loss_ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % self.loss_ring.shape[0]
+        return self.tag, slot
+
+    def _apply(self, table: EmbeddingTable, opt_name: str, optimizer: str, lr: float, tag: int):
+        if optimizer not in _OPT:
+            raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
+        acc = table.slot(opt_name) if optimizer == "Adagrad" else None
+        _lib.rows_update(table.data, acc, table.grad, table.touched, tag, table.dim, table.normalize, _OPT[optimizer], lr)
+
+    def relation_step(self, ent: EmbeddingTable, rel: EmbeddingTable, opt_name: str, pos, neg=None, neg_per_pos=0,
+                      lr=0.001, pos_w=None, neg_w=None, scale=1.0, optimizer="Adagrad", update=True) -> torch.Tensor:
+        """loss + optimizer of a relation-view style graph (a1/a2/a3).  Returns the [1024] loss partials
+        (a view into the ring; `.sum()` is the loss) without synchronising."""
+        tag, lp = self._next()
+        _lib.triple_score_fwd_bwd(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
+                                  neg_per_pos, scale, ent.grad if update else None, rel.grad if update else None,
+                                  ent.touched, rel.touched, tag, lp)
+        if update:
+            self._apply(ent, opt_name, optimizer, lr, tag)
+            self._apply(rel, opt_name, optimizer, lr, tag)
+        return lp
+
+    def alignment_step(self, terms, opt_name: str, lr: float, optimizer="Adagrad") -> torch.Tensor:
+        """terms: list of (table_a, idx_a, table_b, idx_b, weight).  One optimizer step over the sum of the
+        terms (code/MultiKE_model.py:229-239).  Returns the summed loss as a device scalar."""
+        tag = None
+        total = None
+        tables = []
+        for (ta, ia, tb, ib, w) in terms:
+            t, lp = self._next()
+            if tag is None:
+                tag = t
+            _lib.align_fwd_bwd(ta.data, ta.normalize, tb.data, tb.normalize, ta.dim, ia, ib, float(w),
+                               ta.grad if ta.trainable else None, ta.touched if ta.trainable else None,
+                               tb.grad if tb.trainable else None, tb.touched if tb.trainable else None, tag, lp)
+            s = lp.sum()
+            total = s if total is None else total + s
+            for tb_ in (ta, tb):
+                if tb_.trainable and all(tb_ is not x for x in tables):
+                    tables.append(tb_)
+        for tb_ in tables:
+            self._apply(tb_, opt_name, optimizer, lr, tag)
+        return total

@@ -1,0 +1,225 @@
+"""GPU parity of the fused relation-view step (mke_triple_score_fwd_bwd + mke_rows_update) against the
+oracle and the golden vectors.  Tolerances: per-batch loss relative 1e-4 (north_star; we hold 2e-6),
+rows after the update rtol 2e-5 / atol 1e-7 against float64 (fp32 arithmetic + atomic order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import multike_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 2e-6
+ROW_RTOL, ROW_ATOL = 2e-5, 2e-7
+
+
+def _case(g, ci):
+    pre = f"c{ci}_"
+    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_golden_three_steps(losses_golden, ci):
+    from gpu_util import dev_i32, make_tables
+    from multike_amd.tables import StepEngine
+    c = _case(losses_golden, ci)
+    N = int(c["meta"][5])
+    E, R = make_tables(c["ent"], c["rel"])
+    eng = StepEngine()
+    pos = tuple(dev_i32(c[k]) for k in ("ph", "pr", "pt"))
+    neg = tuple(dev_i32(c[k]) for k in ("nh", "nr", "nt"))
+    losses = []
+    for step in range(3):
+        lp = eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.001)
+        losses.append(float(lp.sum()))
+        if step in (0, 2):
+            np.testing.assert_allclose(E.raw().cpu().numpy(), c[f"a1_ent_after{step + 1}"], rtol=ROW_RTOL, atol=ROW_ATOL)
+            np.testing.assert_allclose(R.raw().cpu().numpy(), c[f"a1_rel_after{step + 1}"], rtol=ROW_RTOL, atol=ROW_ATOL)
+    np.testing.assert_allclose(losses, c["a1_step_losses_f64"], rtol=LOSS_RTOL)
+    # invariants: gradient scratch consumed, pad columns still zero
+    assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+    assert float(E.data[:, E.dim:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d,P,N,grouped", [(75, 300, 25, True), (75, 300, 25, False), (4, 50, 3, True),
+                                           (256, 120, 64, True), (100, 64, 10, True), (32, 77, 1, True),
+                                           (75, 513, 0, True)])
+def test_scatter_gradients_and_update_vs_oracle(d, P, N, grouped):
+    from gpu_util import dev_i32, grouped_batch, make_tables
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(d * 1000 + P + N)
+    n_ent, n_rel = 2000, 37
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    pos, neg = grouped_batch(rng, n_ent, n_rel, P, max(N, 1))
+    if N == 0:
+        neg = None
+    E, R = make_tables(ent, rel)
+    eng = StepEngine()
+    dpos = tuple(dev_i32(a) for a in pos)
+    dneg = None if neg is None else tuple(dev_i32(a) for a in neg)
+    # forward + scatter only: inspect the normalised-space gradient buffers
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    L, ghat_e, ghat_r = mo.relation_view_step_dense(e64, r64, None, None, pos, neg, 0.0, update=False)
+    from multike_amd import _lib
+    tag, lp = eng._next()
+    _lib.triple_score_fwd_bwd(E.data, True, R.data, True, d, dpos, None, dneg, None, (N if grouped else 0), 1.0,
+                              E.grad, R.grad, E.touched, R.touched, tag, lp)
+    np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.grad[:, :d].cpu().numpy(), ghat_e, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(R.grad[:, :d].cpu().numpy(), ghat_r, rtol=1e-4, atol=2e-5)
+    if E.stride > d:
+        assert float(E.grad[:, d:].abs().max()) == 0.0
+    touched = np.zeros(n_ent, bool)
+    touched[pos[0]] = touched[pos[2]] = True
+    if neg is not None:
+        touched[neg[0]] = touched[neg[2]] = True
+    assert np.array_equal((E.touched == tag).cpu().numpy(), touched)
+    # now the row update
+    before = E.data.clone()
+    eng._apply(E, "relation", "Adagrad", 0.001, tag)
+    eng._apply(R, "relation", "Adagrad", 0.001, tag)
+    acc_e, acc_r = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    mo.relation_view_step_dense(e64, r64, acc_e, acc_r, pos, neg, 0.001)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=ROW_RTOL, atol=ROW_ATOL)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=ROW_RTOL, atol=ROW_ATOL)
+    np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), acc_e, rtol=1e-4, atol=1e-7)
+    # untouched rows are bit-identical (dense TF semantics == touched-rows-only)
+    ut = torch.as_tensor(~touched, device="cuda")
+    assert torch.equal(E.data[ut], before[ut])
+    assert float(E.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", ["a2_x2", "a3_weighted_x2", "a4_both_weighted", "sgd", "rel_unnormalised"])
+def test_variants(variant):
+    """a2: positives only, caller's x2 (MultiKE_model.py:168); a3: weighted positives x2 (:198);
+    a4: weights on both signs; SGD optimizer; a table read without normalisation (attr_embeds, :97)."""
+    from gpu_util import dev_f32, dev_i32, grouped_batch, make_tables
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(5)
+    d, n_ent, n_rel, P, N = 75, 900, 11, 200, 4
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    pos, neg = grouped_batch(rng, n_ent, n_rel, P, N)
+    pw = rng.uniform(0.2, 1, P).astype(np.float32)
+    nw = rng.uniform(0.2, 1, P * N).astype(np.float32)
+    kw = dict(scale=1.0, pos_w=None, neg_w=None)
+    use_neg, rel_norm, opt = True, True, "Adagrad"
+    if variant == "a2_x2":
+        use_neg, kw["scale"] = False, 2.0
+    elif variant == "a3_weighted_x2":
+        use_neg, kw["scale"], kw["pos_w"] = False, 2.0, pw
+    elif variant == "a4_both_weighted":
+        kw["pos_w"], kw["neg_w"] = pw, nw
+    elif variant == "sgd":
+        opt = "SGD"
+    elif variant == "rel_unnormalised":
+        rel_norm = False
+    E, R = make_tables(ent, rel, rel_norm=rel_norm)
+    eng = StepEngine()
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    acc_e, acc_r = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    lp = eng.relation_step(E, R, "x", tuple(dev_i32(a) for a in pos),
+                           tuple(dev_i32(a) for a in neg) if use_neg else None, neg_per_pos=N if use_neg else 0,
+                           lr=0.01, pos_w=None if kw["pos_w"] is None else dev_f32(kw["pos_w"]),
+                           neg_w=None if kw["neg_w"] is None else dev_f32(kw["neg_w"]), scale=kw["scale"],
+                           optimizer=opt)
+    if opt == "SGD":
+        L, ge, gr = mo.relation_view_step_dense(e64, r64, None, None, pos, neg, 0.0, update=False)
+        e64 -= 0.01 * mo.l2_normalize_rows_backward(e64, ge)
+        r64 -= 0.01 * mo.l2_normalize_rows_backward(r64, gr)
+    else:
+        L, _, _ = mo.relation_view_step_dense(e64, r64, acc_e, acc_r, pos, neg if use_neg else None, 0.01,
+                                              pos_w=kw["pos_w"], neg_w=kw["neg_w"], scale=kw["scale"],
+                                              rel_norm=rel_norm)
+    np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=ROW_RTOL, atol=ROW_ATOL)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=ROW_RTOL, atol=ROW_ATOL)
+
+
+def test_edge_cases():
+    from gpu_util import dev_i32, make_tables
+    from multike_amd import _lib
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(9)
+    ent = mo.xavier_truncated_normal((64, 75), rng)
+    rel = mo.xavier_truncated_normal((5, 75), rng)
+    E, R = make_tables(ent, rel)
+    eng = StepEngine()
+    z = dev_i32(np.zeros(0))
+    # empty batch (the reference's last slice can be empty, code/base/batch.py:45-54): loss 0, nothing moves
+    before = E.data.clone()
+    lp = eng.relation_step(E, R, "o", (z, z, z), (z, z, z), neg_per_pos=3)
+    assert float(lp.sum()) == 0.0 and torch.equal(E.data, before)
+    # one positive whose head == tail, negatives that all equal the positive
+    one = (dev_i32([7]), dev_i32([2]), dev_i32([7]))
+    neg = (dev_i32([7, 7]), dev_i32([2, 2]), dev_i32([7, 7]))
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a, b = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    L, _, _ = mo.relation_view_step_dense(e64, r64, a, b, ([7], [2], [7]), ([7, 7], [2, 2], [7, 7]), 0.001)
+    lp = eng.relation_step(E, R, "o", one, neg, neg_per_pos=2)
+    np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=ROW_RTOL, atol=ROW_ATOL)
+    # a row of zeros: ssq <= eps branch of the normalisation and its gradient
+    E.data[3].zero_()
+    e64 = E.raw().cpu().numpy().astype(np.float64)
+    r64 = R.raw().cpu().numpy().astype(np.float64)
+    a, b = E.slot("o")[:, :75].cpu().numpy().astype(np.float64), R.slot("o")[:, :75].cpu().numpy().astype(np.float64)
+    L, _, _ = mo.relation_view_step_dense(e64, r64, a, b, ([3], [1], [9]), None, 0.001)
+    lp = eng.relation_step(E, R, "o", (dev_i32([3]), dev_i32([1]), dev_i32([9])), None)
+    np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=1e-6)
+    # argument errors come back as exceptions with the library's message
+    with pytest.raises(_lib.MultiKEHipError, match="n_neg"):
+        eng.relation_step(E, R, "o", one, neg, neg_per_pos=3)
+    with pytest.raises(_lib.MultiKEHipError, match="CUDA"):
+        eng.relation_step(E, R, "o", (torch.zeros(1, dtype=torch.int32),) * 3, None)
+
+
+def test_full_size_c2_batch_vs_c_oracle():
+    """BASELINE configs[1] shape: |E|=200K |R|=550 d=75 N=25 P=5000 (T=130K).  Checked against the C oracle in
+    float64, plus size-independent properties (scratch consumed, untouched rows bit-identical, loss additivity)."""
+    from gpu_util import dev_i32, make_tables
+    from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import StepEngine
+    kgs = SyntheticKGs()
+    rng = np.random.default_rng(3)
+    d = 75
+    ent = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
+    rel = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
+    E, R = make_tables(ent, rel)
+    eng = StepEngine()
+    sides = []
+    for k in (0, 1):
+        t = dev_i32(kgs.triples[k])
+        sides.append(KGSide(kgs.entities(k), KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], 5000, 25, seed=11)
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    orc = co.RelationStepOracle(kgs.entities_num, kgs.relations_num, d, np.float64)
+    for step in (0, 1, bat.steps - 1):
+        pos, neg = bat.batch(step)
+        before = E.data.clone()
+        lp = eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=25, lr=0.001)
+        hp = tuple(x.cpu().numpy() for x in pos)
+        hn = tuple(x.cpu().numpy() for x in neg)
+        L = orc.step(e64, r64, a64, b64, hp, hn, 0.001)
+        np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+        np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=5e-7)
+        np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
+        touched = torch.zeros(kgs.entities_num, dtype=torch.bool, device="cuda")
+        for x in (pos[0], pos[2], neg[0], neg[2]):
+            touched[x.long()] = True
+        assert torch.equal(E.data[~touched], before[~touched])
+        assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+    # additivity: loss(batch) == loss(first half) + loss(second half), forward only
+    pos, neg = bat.batch(2)
+    h = pos[0].numel() // 2
+    full = float(eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=25, update=False).sum())
+    p1 = tuple(x[:h] for x in pos); n1 = tuple(x[:h * 25] for x in neg)
+    p2 = tuple(x[h:] for x in pos); n2 = tuple(x[h * 25:] for x in neg)
+    parts = float(eng.relation_step(E, R, "relation", p1, n1, neg_per_pos=25, update=False).sum()) + \
+        float(eng.relation_step(E, R, "relation", p2, n2, neg_per_pos=25, update=False).sum())
+    np.testing.assert_allclose(full, parts, rtol=1e-9)
