@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=75)
     ap.add_argument("--neg", type=int, default=25)
     ap.add_argument("--batch", type=int, default=5000)
+    ap.add_argument("--sample-chunk", type=int, default=0, help="steps sampled per sampler launch (0 = whole epoch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
     return ap.parse_args()
@@ -135,30 +136,38 @@ def main():
             sides.append(KGSide(kgs.entities(k),
                                 KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
         bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=1234)
+        from multike_amd.runner import RelationViewRunner
+        runner = RelationViewRunner(E, R, bat, "relation", lr=0.001, sample_chunk=args.sample_chunk or None)
         eng = StepEngine()
         n_steps_epoch = bat.steps
-        negbuf = tuple(torch.empty(B * N, dtype=torch.int32, device="cuda") for _ in range(3))
         ev = []
 
-        def run_step(i, timed=False):
+        def run_steps(i0, i1):
+            """global step indices [i0, i1): each (partial) epoch is ONE call into the native runner."""
+            i = i0
+            while i < i1:
+                s = i % n_steps_epoch
+                e = min(n_steps_epoch, s + (i1 - i))
+                if s == 0 and i > 0:
+                    bat.shuffle()
+                runner.run(s, e)
+                i += e - s
+
+        def run_step_timed(i):
+            """Python-driven step with HIP events around the dominant kernel only (same stream)."""
+            from multike_amd import _lib
             s = i % n_steps_epoch
-            if s == 0 and i > 0:
-                bat.shuffle()
-            n = int(bat.off[s + 1] - bat.off[s]) * N
-            pos, neg = bat.batch(s, out=tuple(x[:n] for x in negbuf))
-            if timed:  # HIP events around the dominant kernel only, on the stream it is launched on
-                from multike_amd import _lib
-                tag, lp = eng._next()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                _lib.triple_score_fwd_bwd(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
-                                          E.touched, R.touched, tag, lp)
-                e1.record()
-                ev.append((e0, e1, pos[0].numel() * (1 + N)))
-                eng._apply(E, "relation", "Adagrad", 0.001, tag)
-                eng._apply(R, "relation", "Adagrad", 0.001, tag)
-            else:
-                eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.001)
+            pos, neg = bat.batch(s)
+            tag, lp = eng._next()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.triple_score_fwd_bwd(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
+                                      E.touched, R.touched, tag, lp)
+            e1.record()
+            ev.append((e0, e1, pos[0].numel() * (1 + N)))
+            _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
+                                    (E.data, E.slot("relation"), E.grad, E.touched, True)], tag, E.stride, d,
+                                   _lib.OPT_ADAGRAD, 0.001)
 
         def triples_of(i):
             s = i % n_steps_epoch
@@ -168,14 +177,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(args.warmup):
-        run_step(i)
+    if world > 1:
+        def run_steps(i0, i1):
+            for i in range(i0, i1):
+                run_step(i)
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        run_step(i)
+    run_steps(args.warmup, args.warmup + args.steps)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -192,7 +203,7 @@ def main():
         # instrumented pass over the same K steps: HIP events bracket every launch of the dominant kernel
         base = args.warmup + args.steps
         for i in range(base, base + args.steps):
-            run_step(i, timed=True)
+            run_step_timed(i)
         torch.cuda.synchronize()
         ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
         tr = np.array([n for _, _, n in ev])

@@ -111,30 +111,55 @@ int mke_rows_update(
     int normalize, int optimizer, float lr,
     void* stream);
 
+/* Same update over up to MKE_MAX_UPDATE_TABLES tables of one stride/dim in ONE launch (e.g. the entity and the
+ * relation table of the relation-view graph).  tables is a HOST array. */
+#define MKE_MAX_UPDATE_TABLES 4
+typedef struct mke_update_table {
+  float* table;
+  float* acc;   /* nullable for SGD */
+  float* grad;
+  const int32_t* touched;
+  int64_t n_rows;
+  int normalize;
+} mke_update_table;
+int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
+                          int optimizer, float lr, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
- * (3) Uniform / truncated negative sampler (counter-based Philox4x32-10; see oracle/sampler_spec.md).
+ * (3) Uniform / truncated negative sampler (counter-based Philox4x32-10; specification:
+ *     oracle/sampler_oracle.py philox_negatives).
  *
  * replaces: code/base/batch.py:86-116 generate_neg_triples_fast as called from
  *           code/base/batch.py:40-41 (one call per KG per step).
  *
- *   For positive i (of n_pos), up to max_try rounds: one fair coin per round picks the corrupted side;
- *   `need` distinct candidates are drawn without replacement from the candidate list of the positive's
- *   head (or tail): cand_table row of that entity if cand_table != NULL and cand_valid[entity] != 0,
- *   else the KG's entity list (ent_list, or the contiguous range [ent_lo, ent_lo+n_cand_all) when
- *   ent_list == NULL).  In rounds 0..max_try-2 candidates forming a known triple are dropped; the last
- *   round keeps everything.  Exactly neg_per_pos negatives per positive are written at
- *   neg_*[i*neg_per_pos ...]; neg_r is a copy of the positive's relation.
- *
- *   known_keys: open-addressing hash set built by mke_tripleset_build (NULL = no filter).
- *   RNG stream = Philox key (seed_lo, seed_hi), counter (i + pos_offset, round, draw_block, stream_id).
+ *   One KG's sampling context (the arguments batch.py:40-41 passes per KG):
  * ------------------------------------------------------------------------------------------------ */
+typedef struct mke_kg_side {
+  const int32_t* ent_list;     /* entities_list of the KG, or NULL = contiguous range [ent_lo, ent_lo+n_ent) */
+  int32_t ent_lo;
+  int32_t n_ent;               /* size of the candidate population when no neighbour list applies */
+  const int32_t* cand_table;   /* nullable [n_ent_total][cand_k]: truncated-sampling neighbours, indexed by entity id */
+  const uint8_t* cand_valid;   /* nullable [n_ent_total]: entity has a neighbour list (dict membership, batch.py:94-95) */
+  int32_t cand_k;
+  const uint64_t* known_keys;  /* nullable: hash set built by mke_tripleset_build */
+  uint64_t known_capacity;     /* power of two */
+} mke_kg_side;
+
+/*   For positive i (of n_pos), up to max_try rounds: one fair coin per round picks the corrupted side;
+ *   `need` distinct candidates are drawn without replacement from the candidate list of the positive's
+ *   head (or tail): cand_table row of that entity if it has one, else the KG's entity list.  In rounds
+ *   0..max_try-2 candidates forming a known triple are dropped; the last round keeps everything.
+ *   Exactly neg_per_pos (<= 64) negatives per positive are written at neg_*[i*neg_per_pos ...]; neg_r is a
+ *   copy of the positive's relation.
+ *
+ *   sides: HOST pointer to 2 contexts; pos_kg (device, nullable = all KG 0) selects the context per
+ *   positive, so one launch can cover many steps of [KG1 part | KG2 part] batches.
+ *   RNG stream of positive i = Philox key (seed_lo, seed_hi), counter (i + pos_offset, round | blk<<8,
+ *   slot, stream_id + kg).  The output does not depend on how a range of positives is split into calls. */
 int mke_neg_sample(
     const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, int64_t pos_offset,
+    const uint8_t* pos_kg /*nullable*/, const mke_kg_side* sides /* host, [2] */,
     int neg_per_pos, int max_try,
-    const int32_t* ent_list /*nullable*/, int32_t ent_lo, int32_t n_cand_all,
-    const int32_t* cand_table /*nullable, [n_ent_total][cand_k]*/, const uint8_t* cand_valid /*nullable*/,
-    int32_t cand_k,
-    const uint64_t* known_keys /*nullable*/, uint64_t known_capacity /* power of two */,
     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
     int32_t* neg_h, int32_t* neg_r, int32_t* neg_t,
     void* stream);
@@ -198,6 +223,43 @@ int mke_gather_rows(
     const float* table, int normalize, int stride, int dim,
     const int32_t* idx /*nullable = identity*/, int64_t n,
     float* out /* [n][dim] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (6) Native step runner of the relation view: enqueues steps [step_begin, step_end) of an epoch —
+ *     negative sampling (batched `sample_chunk` steps per launch), the fused triple step and the row
+ *     update of both tables — without returning to the host language between steps.
+ *
+ * replaces: the loop body of code/MultiKE_model.py:302-312 (batch_queue.get + session.run) together with
+ *           the producer side code/base/batch.py:22-42; the epoch shuffle (code/MultiKE_model.py:314-315)
+ *           stays with the caller, who rewrites pos_* in place between epochs.
+ *
+ *   Positives are epoch-ordered and step-contiguous: step s owns [step_off[s], step_off[s+1]) and the first
+ *   pos_kg==0 part of it is KG1's slice, the rest KG2's (code/base/batch.py:36-42).
+ *   Loss of step s: loss_partials + (s % loss_ring) * MKE_LOSS_PARTIALS.
+ *   tag of step s = tag_base + s (must stay < 2^31 and never repeat for these touched arrays).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mke_relation_plan {
+  float* ent_table; int64_t n_ent; int ent_normalize;
+  float* rel_table; int64_t n_rel; int rel_normalize;
+  float* ent_acc; float* rel_acc;            /* this optimizer's Adagrad slots (NULL for SGD) */
+  float* ent_grad; float* rel_grad;          /* zero-invariant gradient scratch */
+  int32_t* ent_touched; int32_t* rel_touched;
+  int stride, dim;
+  const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t;  /* device, epoch order */
+  const uint8_t* pos_kg;                     /* device, [n positives] 0/1 */
+  const int64_t* step_off;                   /* HOST [n_steps+1] */
+  int n_steps;
+  mke_kg_side sides[2];
+  int neg_per_pos, max_try;
+  int sample_chunk;                          /* steps sampled per sampler launch (>=1) */
+  int32_t* neg_h; int32_t* neg_r; int32_t* neg_t;  /* device scratch, >= max positives of any sample_chunk consecutive steps * neg_per_pos */
+  uint32_t seed_lo, seed_hi, stream_id;
+  int optimizer; float lr; float scale;
+  double* loss_partials; int loss_ring;      /* device [loss_ring][MKE_LOSS_PARTIALS] */
+  int32_t tag_base;
+} mke_relation_plan;
+
+int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,10 +22,40 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
-    "mke_version", "mke_last_error", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_neg_sample",
-    "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
-    "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows",
+    "mke_version", "mke_last_error", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_rows_update_multi",
+    "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
+    "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
 )
+
+
+class KGSideStruct(C.Structure):
+    """mke_kg_side"""
+    _fields_ = [("ent_list", C.c_void_p), ("ent_lo", C.c_int32), ("n_ent", C.c_int32), ("cand_table", C.c_void_p),
+                ("cand_valid", C.c_void_p), ("cand_k", C.c_int32), ("known_keys", C.c_void_p),
+                ("known_capacity", C.c_uint64)]
+
+
+class UpdateTableStruct(C.Structure):
+    """mke_update_table"""
+    _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p),
+                ("n_rows", C.c_int64), ("normalize", C.c_int)]
+
+
+class RelationPlanStruct(C.Structure):
+    """mke_relation_plan"""
+    _fields_ = [
+        ("ent_table", C.c_void_p), ("n_ent", C.c_int64), ("ent_normalize", C.c_int),
+        ("rel_table", C.c_void_p), ("n_rel", C.c_int64), ("rel_normalize", C.c_int),
+        ("ent_acc", C.c_void_p), ("rel_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("rel_grad", C.c_void_p),
+        ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("stride", C.c_int), ("dim", C.c_int),
+        ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("pos_kg", C.c_void_p),
+        ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("sides", KGSideStruct * 2),
+        ("neg_per_pos", C.c_int), ("max_try", C.c_int), ("sample_chunk", C.c_int),
+        ("neg_h", C.c_void_p), ("neg_r", C.c_void_p), ("neg_t", C.c_void_p),
+        ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("stream_id", C.c_uint32),
+        ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float),
+        ("loss_partials", C.c_void_p), ("loss_ring", C.c_int), ("tag_base", C.c_int32),
+    ]
 
 _lib = None
 
@@ -120,21 +150,42 @@ def rows_update(table, acc, grad, touched, tag, dim, normalize, optimizer, lr):
     _check(rc, "mke_rows_update")
 
 
-def neg_sample(pos, pos_offset, neg_per_pos, max_try, ent_list, ent_lo, n_cand_all, cand_table, cand_valid, known_keys,
-               seed, stream_id, neg_out):
+def ptr(t: torch.Tensor | None, dtype, name: str) -> int | None:
+    """Raw device address (for the plan / side structs)."""
+    return _dev(t, dtype, name).value
+
+
+def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
+    """tables: list of (data, acc, grad, touched, normalize)."""
+    arr = (UpdateTableStruct * len(tables))()
+    for k, (data, acc, grad, touched, normalize) in enumerate(tables):
+        arr[k].table = ptr(data, torch.float32, "table")
+        arr[k].acc = ptr(acc, torch.float32, "acc")
+        arr[k].grad = ptr(grad, torch.float32, "grad")
+        arr[k].touched = ptr(touched, torch.int32, "touched")
+        arr[k].n_rows = data.shape[0]
+        arr[k].normalize = int(normalize)
+    rc = lib().mke_rows_update_multi(arr, C.c_int(len(tables)), C.c_int32(tag), C.c_int(stride), C.c_int(dim),
+                                     C.c_int(optimizer), C.c_float(lr), _stream())
+    _check(rc, "mke_rows_update_multi")
+
+
+def neg_sample(pos, pos_offset, pos_kg, sides, neg_per_pos, max_try, seed, stream_id, neg_out):
+    """sides: (KGSideStruct * 2) host array; pos_kg: uint8 CUDA tensor or None (all KG 0)."""
     ph, pr, pt = pos
     nh, nr, nt = neg_out
-    cand_k = 0 if cand_table is None else cand_table.shape[1]
-    cap = 0 if known_keys is None else known_keys.numel()
     rc = lib().mke_neg_sample(
         _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
-        C.c_int64(ph.numel()), C.c_int64(pos_offset), C.c_int(neg_per_pos), C.c_int(max_try),
-        _dev(ent_list, torch.int32, "ent_list"), C.c_int32(ent_lo), C.c_int32(n_cand_all),
-        _dev(cand_table, torch.int32, "cand_table"), _dev(cand_valid, torch.uint8, "cand_valid"), C.c_int32(cand_k),
-        _dev(known_keys, torch.int64, "known_keys"), C.c_uint64(cap), C.c_uint32(seed[0] & 0xFFFFFFFF),
-        C.c_uint32(seed[1] & 0xFFFFFFFF), C.c_uint32(stream_id & 0xFFFFFFFF),
-        _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"), _stream())
+        C.c_int64(ph.numel()), C.c_int64(pos_offset), _dev(pos_kg, torch.uint8, "pos_kg"), sides,
+        C.c_int(neg_per_pos), C.c_int(max_try), C.c_uint32(seed[0] & 0xFFFFFFFF), C.c_uint32(seed[1] & 0xFFFFFFFF),
+        C.c_uint32(stream_id & 0xFFFFFFFF), _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"),
+        _dev(nt, torch.int32, "neg_t"), _stream())
     _check(rc, "mke_neg_sample")
+
+
+def relation_steps(plan: RelationPlanStruct, step_begin: int, step_end: int):
+    rc = lib().mke_relation_steps(C.byref(plan), C.c_int(step_begin), C.c_int(step_end), _stream())
+    _check(rc, "mke_relation_steps")
 
 
 def tripleset_build(h, r, t, keys):

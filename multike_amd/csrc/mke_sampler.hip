@@ -17,15 +17,10 @@ struct SampleParams {
   const int32_t* __restrict__ ph;
   const int32_t* __restrict__ pr;
   const int32_t* __restrict__ pt;
+  const uint8_t* __restrict__ pos_kg;
   int64_t n_pos, pos_offset;
   int npp, max_try;
-  const int32_t* __restrict__ ent_list;
-  int32_t ent_lo, n_all;
-  const int32_t* __restrict__ cand_table;
-  const uint8_t* __restrict__ cand_valid;
-  int32_t cand_k;
-  const uint64_t* __restrict__ keys;
-  uint64_t cap;
+  mke_kg_side side[2];
   uint32_t seed_lo, seed_hi, sid;
   int32_t* __restrict__ nh;
   int32_t* __restrict__ nr;
@@ -66,20 +61,24 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) 
   const int64_t i = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   if (i >= p.n_pos) return;
   const int h = p.ph[i], r = p.pr[i], t = p.pt[i];
+  const int kg = p.pos_kg ? (p.pos_kg[i] != 0) : 0;
+  const mke_kg_side& sd = p.side[kg];
+  const uint32_t sid = p.sid + (uint32_t)kg;
+  const uint64_t* __restrict__ keys = sd.known_keys;
   const uint32_t gi = (uint32_t)(i + p.pos_offset);
   const int N = p.npp;
   int collected = 0;
   for (int round = 0; round < p.max_try && collected < N; ++round) {
     const int need = N - collected;
-    const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, p.sid, p.seed_lo, p.seed_hi);
+    const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, sid, p.seed_lo, p.seed_hi);
     const bool corrupt_head = (cph.v[0] >> 31) != 0;
     const int x = corrupt_head ? h : t;
-    const bool use_tbl = p.cand_table != nullptr && (p.cand_valid == nullptr || p.cand_valid[x] != 0);
-    const uint32_t n = use_tbl ? (uint32_t)p.cand_k : (uint32_t)p.n_all;
+    const bool use_tbl = sd.cand_table != nullptr && (sd.cand_valid == nullptr || sd.cand_valid[x] != 0);
+    const uint32_t n = use_tbl ? (uint32_t)sd.cand_k : (uint32_t)sd.n_ent;
     const bool active = lane < need;
     uint32_t attempt = 0;
     uint32_t pos = 0xFFFFFFFFu;
-    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, p.sid, p.seed_lo, p.seed_hi, n, attempt);
+    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, sid, p.seed_lo, p.seed_hi, n, attempt);
     // duplicate detection among first draws
     bool dup = false;
     for (int q = 0; q < need; ++q) {
@@ -93,20 +92,20 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) 
           const uint32_t v = (uint32_t)__shfl((int)pos, q, 64);
           const bool hit = lane < q && pos == v;
           if (!__ballot(hit)) break;
-          if (lane == q) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, p.sid, p.seed_lo, p.seed_hi, n, attempt);
+          if (lane == q) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, sid, p.seed_lo, p.seed_hi, n, attempt);
         }
       }
     }
     int ent = 0;
     if (active) {
-      ent = use_tbl ? p.cand_table[(int64_t)x * p.cand_k + pos]
-                    : (p.ent_list ? p.ent_list[pos] : p.ent_lo + (int32_t)pos);
+      ent = use_tbl ? sd.cand_table[(int64_t)x * sd.cand_k + pos]
+                    : (sd.ent_list ? sd.ent_list[pos] : sd.ent_lo + (int32_t)pos);
     }
     const int nh = corrupt_head ? ent : h;
     const int nt = corrupt_head ? t : ent;
     bool keep = active;
-    if (active && round < p.max_try - 1 && p.keys != nullptr) {
-      keep = !set_contains(p.keys, p.cap, triple_key((uint32_t)nh, (uint32_t)r, (uint32_t)nt));
+    if (active && round < p.max_try - 1 && keys != nullptr) {
+      keep = !set_contains(keys, sd.known_capacity, triple_key((uint32_t)nh, (uint32_t)r, (uint32_t)nt));
     }
     const uint64_t mask = __ballot(keep);
     if (keep) {
@@ -144,34 +143,48 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_tripleset_query(const int32_t* __
 
 }  // namespace mke
 
-extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
-                              int64_t pos_offset, int neg_per_pos, int max_try, const int32_t* ent_list,
-                              int32_t ent_lo, int32_t n_cand_all, const int32_t* cand_table,
-                              const uint8_t* cand_valid, int32_t cand_k, const uint64_t* known_keys,
-                              uint64_t known_capacity, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
-                              int32_t* neg_h, int32_t* neg_r, int32_t* neg_t, void* stream) {
-  using namespace mke;
-  if (n_pos < 0) { set_error("negative n_pos"); return MKE_E_SHAPE; }
-  if (n_pos == 0 || neg_per_pos == 0) return MKE_OK;
-  if (!pos_h || !pos_r || !pos_t || !neg_h || !neg_r || !neg_t) { set_error("mke_neg_sample: NULL index stream"); return MKE_E_NULL; }
-  if (neg_per_pos < 0 || neg_per_pos > 64) { set_error("neg_per_pos must be in [0,64], got %d", neg_per_pos); return MKE_E_UNSUPPORTED; }
-  if (max_try < 1 || max_try > 255) { set_error("max_try must be in [1,255]"); return MKE_E_SHAPE; }
+namespace mke {
+int validate_side(const mke_kg_side& sd, int neg_per_pos) {
   // random.sample raises ValueError when the population is smaller than the sample (batch.py:98,101)
-  if (n_cand_all < neg_per_pos) { set_error("candidate population (%d) smaller than neg_per_pos (%d)", n_cand_all, neg_per_pos); return MKE_E_SHAPE; }
-  if (cand_table && cand_k < neg_per_pos) { set_error("neighbour list (%d) shorter than neg_per_pos (%d)", cand_k, neg_per_pos); return MKE_E_SHAPE; }
-  if (known_keys && (known_capacity == 0 || (known_capacity & (known_capacity - 1)) != 0)) { set_error("known_capacity must be a power of two"); return MKE_E_SHAPE; }
+  if (sd.n_ent < neg_per_pos) { set_error("candidate population (%d) smaller than neg_per_pos (%d)", sd.n_ent, neg_per_pos); return MKE_E_SHAPE; }
+  if (sd.cand_table && sd.cand_k < neg_per_pos) { set_error("neighbour list (%d) shorter than neg_per_pos (%d)", sd.cand_k, neg_per_pos); return MKE_E_SHAPE; }
+  if (sd.known_keys && (sd.known_capacity == 0 || (sd.known_capacity & (sd.known_capacity - 1)) != 0)) { set_error("known_capacity must be a power of two"); return MKE_E_SHAPE; }
+  return MKE_OK;
+}
+
+int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, int64_t pos_offset,
+                      const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos, int max_try, uint32_t seed_lo,
+                      uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h, int32_t* neg_r, int32_t* neg_t, hipStream_t st) {
   SampleParams p;
-  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.n_pos = n_pos; p.pos_offset = pos_offset;
+  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.pos_kg = pos_kg; p.n_pos = n_pos; p.pos_offset = pos_offset;
   p.npp = neg_per_pos; p.max_try = max_try;
-  p.ent_list = ent_list; p.ent_lo = ent_lo; p.n_all = n_cand_all;
-  p.cand_table = cand_table; p.cand_valid = cand_valid; p.cand_k = cand_k;
-  p.keys = known_keys; p.cap = known_capacity;
+  p.side[0] = sides[0];
+  p.side[1] = pos_kg ? sides[1] : sides[0];
   p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.sid = stream_id;
   p.nh = neg_h; p.nr = neg_r; p.nt = neg_t;
   const int64_t waves_per_block = MKE_BLOCK / 64;
   const int64_t blocks = (n_pos + waves_per_block - 1) / waves_per_block;
-  hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_neg_sample");
+}
+}  // namespace mke
+
+extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
+                              int64_t pos_offset, const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos,
+                              int max_try, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h,
+                              int32_t* neg_r, int32_t* neg_t, void* stream) {
+  using namespace mke;
+  if (n_pos < 0) { set_error("negative n_pos"); return MKE_E_SHAPE; }
+  if (n_pos == 0 || neg_per_pos == 0) return MKE_OK;
+  if (!pos_h || !pos_r || !pos_t || !neg_h || !neg_r || !neg_t || !sides) { set_error("mke_neg_sample: NULL pointer"); return MKE_E_NULL; }
+  if (neg_per_pos < 0 || neg_per_pos > 64) { set_error("neg_per_pos must be in [0,64], got %d", neg_per_pos); return MKE_E_UNSUPPORTED; }
+  if (max_try < 1 || max_try > 255) { set_error("max_try must be in [1,255]"); return MKE_E_SHAPE; }
+  for (int k = 0; k < (pos_kg ? 2 : 1); ++k) {
+    const int rc = validate_side(sides[k], neg_per_pos);
+    if (rc) return rc;
+  }
+  return launch_neg_sample(pos_h, pos_r, pos_t, n_pos, pos_offset, pos_kg, sides, neg_per_pos, max_try, seed_lo, seed_hi,
+                           stream_id, neg_h, neg_r, neg_t, (hipStream_t)stream);
 }
 
 extern "C" int mke_tripleset_build(const int32_t* h, const int32_t* r, const int32_t* t, int64_t n, uint64_t* keys,

@@ -93,6 +93,59 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update(const UpdateParams p)
   }
 }
 
+struct MultiUpdateParams {
+  UpdateParams t[MKE_MAX_UPDATE_TABLES];
+  int64_t block_end[MKE_MAX_UPDATE_TABLES];  // exclusive prefix of blocks per table
+  int n_tables;
+};
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
+  int ti = 0;
+  int64_t first = 0;
+#pragma unroll
+  for (int k = 0; k < MKE_MAX_UPDATE_TABLES - 1; ++k) {
+    if (ti == k && k + 1 < mp.n_tables && (int64_t)blockIdx.x >= mp.block_end[k]) { first = mp.block_end[k]; ti = k + 1; }
+  }
+  const UpdateParams& p = mp.t[ti];
+  const int j = threadIdx.x & 15;
+  const int64_t sub = (((int64_t)blockIdx.x - first) * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t base = sub * 16;
+  if (base >= p.n_rows) return;
+  const int64_t r = base + j;
+  const bool mine = (r < p.n_rows) && (p.touched[r] == p.tag);
+  const uint64_t ball = __ballot(mine);
+  const int q = (threadIdx.x & 63) >> 4;
+  uint32_t m = (uint32_t)((ball >> (q * 16)) & 0xFFFFu);
+  while (m) {
+    const int b = __builtin_ctz(m);
+    m &= m - 1;
+    update_one_row<FPL>(p, base + b, j);
+  }
+}
+
+int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
+                             float lr, hipStream_t st) {
+  MultiUpdateParams mp;
+  mp.n_tables = n_tables;
+  const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
+  int64_t blocks = 0;
+  for (int k = 0; k < n_tables; ++k) {
+    UpdateParams& p = mp.t[k];
+    p.table = tables[k].table; p.acc = tables[k].acc; p.grad = tables[k].grad; p.touched = tables[k].touched;
+    p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
+    p.optimizer = optimizer; p.lr = lr;
+    blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
+    mp.block_end[k] = blocks;
+  }
+  if (blocks == 0) return MKE_OK;
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_rows_update_multi<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp);
+  });
+  return check_launch("k_rows_update_multi");
+}
+
 }  // namespace mke
 
 extern "C" int mke_rows_update(float* table, float* acc, float* grad, const int32_t* touched, int32_t tag,
@@ -119,4 +172,19 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, const int3
     hipLaunchKernelGGL((k_rows_update<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
   });
   return check_launch("k_rows_update");
+}
+
+extern "C" int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
+                                     int optimizer, float lr, void* stream) {
+  using namespace mke;
+  if (!tables) { set_error("mke_rows_update_multi: NULL tables"); return MKE_E_NULL; }
+  if (n_tables < 1 || n_tables > MKE_MAX_UPDATE_TABLES) { set_error("n_tables must be in [1,%d]", MKE_MAX_UPDATE_TABLES); return MKE_E_SHAPE; }
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim: stride=%d dim=%d", stride, dim); return MKE_E_SHAPE; }
+  for (int k = 0; k < n_tables; ++k) {
+    if (!tables[k].table || !tables[k].grad || !tables[k].touched) { set_error("table %d: NULL table/grad/touched", k); return MKE_E_NULL; }
+    if (optimizer == MKE_OPT_ADAGRAD && !tables[k].acc) { set_error("table %d: Adagrad needs an accumulator", k); return MKE_E_NULL; }
+    if (tables[k].n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
+  }
+  return launch_rows_update_multi(tables, n_tables, tag, stride, dim, optimizer, lr, (hipStream_t)stream);
 }

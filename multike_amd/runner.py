@@ -1,0 +1,90 @@
+"""RelationViewRunner — drives `mke_relation_steps`, the native (C++) step loop of the relation view.
+
+One call enqueues many consecutive steps (sampler chunk -> fused triple step -> row update) on the current
+stream with no Python between the steps; this is the replacement of the reference's per-step
+`batch_queue.get()` + `session.run()` loop (code/MultiKE_model.py:302-312).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .sampling import RelationBatcher
+from .tables import EmbeddingTable
+
+_OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
+
+
+class RelationViewRunner:
+    def __init__(self, ent: EmbeddingTable, rel: EmbeddingTable, batcher: RelationBatcher, opt_name: str = "relation",
+                 lr: float = 0.001, optimizer: str = "Adagrad", scale: float = 1.0, sample_chunk: int | None = None,
+                 max_try: int = 10):
+        if optimizer not in _OPT:
+            raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
+        self.ent, self.rel, self.bat = ent, rel, batcher
+        self.opt_name, self.lr, self.optimizer, self.scale, self.max_try = opt_name, lr, optimizer, scale, max_try
+        self.steps = batcher.steps
+        N = batcher.neg_per_pos
+        # negatives of a whole chunk of steps are sampled by one launch; by default the whole epoch
+        # (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB of HBM)
+        self.sample_chunk = self.steps if sample_chunk is None else max(1, min(int(sample_chunk), self.steps))
+        off = batcher.off
+        span = max(int(off[min(s + self.sample_chunk, self.steps)] - off[s]) for s in range(self.steps)) if self.steps else 0
+        self.neg = tuple(torch.empty(max(1, span * N), dtype=torch.int32, device=ent.device) for _ in range(3))
+        self.loss = torch.zeros(max(1, self.steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=ent.device)
+        self._step_off = np.ascontiguousarray(off, dtype=np.int64)
+        self.tag = 0  # tags handed out so far; each epoch consumes `steps` of them
+        self._epoch_tag_base = None
+        self.plan = _lib.RelationPlanStruct()
+        self._fill_static()
+
+    def _fill_static(self):
+        p, e, r, b = self.plan, self.ent, self.rel, self.bat
+        if e.stride != r.stride or e.dim != r.dim:
+            raise _lib.MultiKEHipError("entity and relation tables must share dim/stride")
+        adagrad = self.optimizer == "Adagrad"
+        p.ent_table, p.n_ent, p.ent_normalize = _lib.ptr(e.data, torch.float32, "ent"), e.n_rows, int(e.normalize)
+        p.rel_table, p.n_rel, p.rel_normalize = _lib.ptr(r.data, torch.float32, "rel"), r.n_rows, int(r.normalize)
+        p.ent_acc = _lib.ptr(e.slot(self.opt_name), torch.float32, "acc") if adagrad else None
+        p.rel_acc = _lib.ptr(r.slot(self.opt_name), torch.float32, "acc") if adagrad else None
+        p.ent_grad, p.rel_grad = _lib.ptr(e.grad, torch.float32, "g"), _lib.ptr(r.grad, torch.float32, "g")
+        p.ent_touched, p.rel_touched = _lib.ptr(e.touched, torch.int32, "t"), _lib.ptr(r.touched, torch.int32, "t")
+        p.stride, p.dim = e.stride, e.dim
+        p.pos_kg = _lib.ptr(b.pos_kg, torch.uint8, "pos_kg")
+        p.step_off = self._step_off.ctypes.data_as(C.POINTER(C.c_int64))
+        p.n_steps = self.steps
+        p.neg_per_pos, p.max_try, p.sample_chunk = b.neg_per_pos, self.max_try, self.sample_chunk
+        p.neg_h, p.neg_r, p.neg_t = (_lib.ptr(x, torch.int32, "neg") for x in self.neg)
+        p.optimizer, p.lr, p.scale = _OPT[self.optimizer], self.lr, self.scale
+        p.loss_partials, p.loss_ring = _lib.ptr(self.loss, torch.float64, "loss"), self.loss.shape[0]
+
+    def _fill_epoch(self):
+        p, b = self.plan, self.bat
+        b.side1.fill(p.sides[0])
+        b.side2.fill(p.sides[1])
+        # positives are re-materialised (new tensors) by every shuffle
+        p.pos_h, p.pos_r, p.pos_t = (_lib.ptr(x, torch.int32, "pos") for x in (b.pos_h, b.pos_r, b.pos_t))
+        p.seed_lo, p.seed_hi = b.rng_seed
+        p.stream_id = b.rng_stream
+
+    def run(self, step_begin: int = 0, step_end: int | None = None):
+        """Enqueue steps [step_begin, step_end) of the current epoch (default: all).  A call with step_begin == 0
+        starts a new epoch (fresh tag range); other calls continue the current one."""
+        step_end = self.steps if step_end is None else step_end
+        if step_begin == 0 or self._epoch_tag_base is None:
+            self._epoch_tag_base = self.tag
+            self.tag += self.steps
+        self._fill_epoch()
+        # StepEngine and this runner may share touched arrays: keep the tag spaces apart (runner: upper half)
+        self.plan.tag_base = (1 << 30) + 1 + self._epoch_tag_base
+        _lib.relation_steps(self.plan, step_begin, step_end)
+
+    def epoch_loss_sum(self) -> torch.Tensor:
+        """Sum of the batch losses of the steps run in this epoch (device scalar, float64)."""
+        return self.loss.sum()
+
+    def step_losses(self) -> torch.Tensor:
+        return self.loss.sum(dim=1)

@@ -65,17 +65,34 @@ class KGSide:
     def set_neighbours(self, cand_table: torch.Tensor | None, cand_valid: torch.Tensor | None):
         self.cand_table, self.cand_valid = cand_table, cand_valid
 
+    def fill(self, st: "_lib.KGSideStruct"):
+        """Write this context into an mke_kg_side (the tensors must outlive the struct's use)."""
+        st.ent_list = _lib.ptr(self.ent_list, torch.int32, "ent_list")
+        st.ent_lo, st.n_ent = self.ent_lo, self.n_ent
+        st.cand_table = _lib.ptr(self.cand_table, torch.int32, "cand_table")
+        st.cand_valid = _lib.ptr(self.cand_valid, torch.uint8, "cand_valid")
+        st.cand_k = 0 if self.cand_table is None else self.cand_table.shape[1]
+        st.known_keys = None if self.known is None else _lib.ptr(self.known.keys, torch.int64, "known_keys")
+        st.known_capacity = 0 if self.known is None else self.known.keys.numel()
+
+
+def side_array(side0: KGSide, side1: KGSide | None = None):
+    arr = (_lib.KGSideStruct * 2)()
+    side0.fill(arr[0])
+    (side1 or side0).fill(arr[1])
+    return arr
+
 
 def sample_negatives(pos, side: KGSide, neg_per_pos: int, seed=(0, 0), stream_id=0, pos_offset=0, max_try=10,
-                     out=None):
-    """generate_neg_triples_fast for one KG's slice of positives, on device."""
+                     out=None, side1: KGSide | None = None, pos_kg: torch.Tensor | None = None):
+    """generate_neg_triples_fast on device.  With `pos_kg` (uint8 per positive) and `side1`, one call covers
+    positives of both KGs (KG k uses RNG stream `stream_id + k`)."""
     ph, pr, pt = pos
     n = ph.numel() * neg_per_pos
     if out is None:
         out = tuple(torch.empty(n, dtype=torch.int32, device=ph.device) for _ in range(3))
     if n:
-        _lib.neg_sample(pos, pos_offset, neg_per_pos, max_try, side.ent_list, side.ent_lo, side.n_ent, side.cand_table,
-                        side.cand_valid, None if side.known is None else side.known.keys, seed, stream_id, out)
+        _lib.neg_sample(pos, pos_offset, pos_kg, side_array(side, side1), neg_per_pos, max_try, seed, stream_id, out)
     return out
 
 
@@ -119,6 +136,10 @@ class RelationBatcher:
             src[o:o + c1[i]] = np.arange(self.lo1[i], self.hi1[i])
             src[o + c1[i]:self.off[i + 1]] = self.n1 + np.arange(self.lo2[i], self.hi2[i])
         self._src = torch.as_tensor(src, device=self.device)
+        kg = np.zeros(int(self.off[-1]), dtype=np.uint8)
+        for i in range(self.steps):
+            kg[self.off[i] + c1[i]:self.off[i + 1]] = 1
+        self.pos_kg = torch.as_tensor(kg, device=self.device)  # fixed across epochs: only the contents shuffle
 
     def _materialise(self, perm1, perm2):
         t1 = self.t1 if perm1 is None else self.t1[perm1]
@@ -140,18 +161,22 @@ class RelationBatcher:
         lo, hi = int(self.off[step]), int(self.off[step + 1])
         return self.pos_h[lo:hi], self.pos_r[lo:hi], self.pos_t[lo:hi]
 
+    @property
+    def rng_seed(self):
+        return (self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+
+    @property
+    def rng_stream(self):
+        return (self.epoch * 2) & 0xFFFFFFFF
+
     def batch(self, step: int, out=None):
         """(pos, neg) of one step; negatives grouped neg_per_pos per positive in positive order."""
         lo, hi = int(self.off[step]), int(self.off[step + 1])
-        mid = lo + int(self.cnt1[step])
         N = self.neg_per_pos
         if out is None:
             out = tuple(torch.empty((hi - lo) * N, dtype=torch.int32, device=self.device) for _ in range(3))
-        sid = (self.epoch * 2) & 0xFFFFFFFF
-        seed = (self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
-        for (a, b, side, kg) in ((lo, mid, self.side1, 0), (mid, hi, self.side2, 1)):
-            if b > a:
-                pos = (self.pos_h[a:b], self.pos_r[a:b], self.pos_t[a:b])
-                o = tuple(x[(a - lo) * N:(b - lo) * N] for x in out)
-                sample_negatives(pos, side, N, seed=seed, stream_id=sid + kg, pos_offset=a, out=o)
-        return (self.pos_h[lo:hi], self.pos_r[lo:hi], self.pos_t[lo:hi]), out
+        pos = (self.pos_h[lo:hi], self.pos_r[lo:hi], self.pos_t[lo:hi])
+        if hi > lo:
+            sample_negatives(pos, self.side1, N, seed=self.rng_seed, stream_id=self.rng_stream, pos_offset=lo, out=out,
+                             side1=self.side2, pos_kg=self.pos_kg[lo:hi])
+        return pos, out

@@ -1,0 +1,96 @@
+"""The native step runner (mke_relation_steps) against (a) the Python-driven per-step path and (b) the CPU
+oracle over a whole synthetic epoch: sampler chunking must not change the negatives, per-step losses and the
+final tables must agree."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import multike_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=3, n_ent=4000, n_rel=30, d=75, B=500, N=10):
+    from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import EmbeddingTable
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, seed=seed)
+    rng = np.random.default_rng(seed)
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    sides = []
+    for k in (0, 1):
+        t = torch.as_tensor(kgs.triples[k], device="cuda")
+        sides.append(KGSide(kgs.entities(k), KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
+
+    def fresh():
+        E = EmbeddingTable(n_ent, d, "e", values=ent)
+        R = EmbeddingTable(n_rel, d, "r", values=rel)
+        bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=42)
+        return E, R, bat
+    return kgs, ent, rel, fresh
+
+
+@pytest.mark.parametrize("chunk", [1, 7, None])
+def test_runner_equals_python_steps_and_oracle(chunk):
+    from multike_amd.runner import RelationViewRunner
+    from multike_amd.tables import StepEngine
+    kgs, ent, rel, fresh = _setup()
+    d, N = 75, 10
+    # (a) native runner, one call for the whole epoch
+    E1, R1, bat1 = fresh()
+    run = RelationViewRunner(E1, R1, bat1, "relation", lr=0.01, sample_chunk=chunk)
+    run.run()
+    l_native = run.step_losses().cpu().numpy()
+    # (b) python-driven steps
+    E2, R2, bat2 = fresh()
+    eng = StepEngine()
+    l_py, negs = [], []
+    for s in range(bat2.steps):
+        pos, neg = bat2.batch(s)
+        negs.append([x.cpu().numpy() for x in neg])
+        l_py.append(float(eng.relation_step(E2, R2, "relation", pos, neg, neg_per_pos=N, lr=0.01).sum()))
+    np.testing.assert_allclose(l_native, l_py, rtol=2e-6)
+    np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    # (c) oracle: same epoch with the oracle's sampler (bit-exact negatives) and float64 step
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    orc = co.RelationStepOracle(len(e64), len(r64), d, np.float64)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    ph, pr, pt = (x.cpu().numpy() for x in (bat2.pos_h, bat2.pos_r, bat2.pos_t))
+    l_or = []
+    for s in range(bat2.steps):
+        lo, hi = int(bat2.off[s]), int(bat2.off[s + 1])
+        mid = lo + int(bat2.cnt1[s])
+        parts = []
+        for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+            elo, ehi = kgs.ent_range[k]
+            parts.append(co.neg_sample(ph[a:b], pr[a:b], pt[a:b], N, ehi - elo, ent_lo=elo, known=sets[k], seed=(42, 0),
+                                       stream_id=k, pos_offset=a))
+        neg = [np.concatenate([parts[0][i], parts[1][i]]) for i in range(3)]
+        for i in range(3):
+            assert np.array_equal(neg[i], negs[s][i]), f"negatives differ at step {s}"
+        l_or.append(orc.step(e64, r64, a64, b64, (ph[lo:hi], pr[lo:hi], pt[lo:hi]), neg, 0.01))
+    np.testing.assert_allclose(l_native, l_or, rtol=1e-5)
+    np.testing.assert_allclose(E1.raw().cpu().numpy(), e64, rtol=5e-4, atol=5e-6)
+    np.testing.assert_allclose(R1.raw().cpu().numpy(), r64, rtol=5e-4, atol=5e-6)
+    # the epoch metric the reference prints: sum(batch_loss)/#positives (code/MultiKE_model.py:313)
+    np.testing.assert_allclose(float(run.epoch_loss_sum()) / len(ph), np.sum(l_or) / len(ph), rtol=1e-5)
+
+
+def test_runner_partial_ranges_and_second_epoch():
+    from multike_amd.runner import RelationViewRunner
+    kgs, ent, rel, fresh = _setup(seed=5)
+    E1, R1, bat1 = fresh()
+    E2, R2, bat2 = fresh()
+    r1 = RelationViewRunner(E1, R1, bat1, lr=0.01, sample_chunk=4)
+    r2 = RelationViewRunner(E2, R2, bat2, lr=0.01)
+    for ep in range(2):
+        r1.run(0, 5); r1.run(5, 6); r1.run(6, None)          # same epoch in three calls
+        r2.run()
+        np.testing.assert_allclose(r1.step_losses().cpu().numpy(), r2.step_losses().cpu().numpy(), rtol=2e-6)
+        bat1.shuffle(); bat2.shuffle()
+    np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert not torch.equal(bat1.pos_h, _setup(seed=5)[3]()[2].pos_h)  # the shuffle really permuted the epoch
