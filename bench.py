@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--neg", type=int, default=25)
     ap.add_argument("--batch", type=int, default=5000)
     ap.add_argument("--sample-chunk", type=int, default=0, help="steps sampled per sampler launch (0 = whole epoch)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded multi-GPU path even at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
     return ap.parse_args()
@@ -120,9 +121,15 @@ def main():
     ent0 = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
     rel0 = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        if dist is None:  # exercise the sharded path on one GPU (1-rank RCCL group)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from multike_amd.distributed import ShardedRelationTrainer
         trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234)
+        trainer.bat.shuffle()
         run_step = trainer.step
         n_steps_epoch = trainer.steps
         triples_of = trainer.global_scored
@@ -136,6 +143,7 @@ def main():
             sides.append(KGSide(kgs.entities(k),
                                 KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
         bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=1234)
+        bat.shuffle()  # epoch-boundary code path (randperm + regather) exercised once before the timed region
         from multike_amd.runner import RelationViewRunner
         runner = RelationViewRunner(E, R, bat, "relation", lr=0.001, sample_chunk=args.sample_chunk or None)
         eng = StepEngine()
@@ -177,7 +185,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         def run_steps(i0, i1):
             for i in range(i0, i1):
                 run_step(i)
@@ -199,7 +208,7 @@ def main():
     value = scored / dt
 
     roofline = None
-    if world == 1:
+    if not sharded:
         # instrumented pass over the same K steps: HIP events bracket every launch of the dominant kernel
         base = args.warmup + args.steps
         for i in range(base, base + args.steps):
@@ -221,12 +230,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "relation-view ITC train step (sampler + fused score/grad + Adagrad), "
                                    f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}"
-                                   + (f" per GPU, entity rows sharded id%{world}" if world > 1 else ""),
+                                   + (f" per GPU, entity rows sharded id%{world}" if sharded else ""),
                        "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,
                        "scored_per_step": B * (1 + N) * world, "steps_per_epoch": n_steps_epoch},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,52 @@
+"""CPU compute backend for the distributed host logic, built on the oracle (TEST infrastructure only).
+It lets `ShardedRelationTrainer`'s exchange code run under gloo without a GPU; the product backend is
+multike_amd.distributed.HipBackend."""
+import numpy as np
+
+from oracle import c_oracle as co
+from oracle import multike_oracle as mo
+
+
+class OracleBackend:
+    device_type = "cpu"
+
+    def make_known(self, h, r, t):
+        return co.TripleSet(h.numpy(), r.numpy(), t.numpy())
+
+    def sample(self, pos, pos_offset, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
+        ph, pr, pt = (x.numpy() for x in pos)
+        kg = pos_kg.numpy()
+        n1 = int((kg == 0).sum())
+        assert np.all(kg[:n1] == 0) and np.all(kg[n1:] == 1)  # [KG1 part | KG2 part]
+        for k, (a, b, side) in enumerate(((0, n1, side1), (n1, len(kg), side2))):
+            if b > a:
+                assert side.ent_list is None
+                nh, nr, nt = co.neg_sample(ph[a:b], pr[a:b], pt[a:b], neg_per_pos, side.n_ent, ent_lo=side.ent_lo,
+                                           known=side.known, seed=seed, stream_id=stream_id + k, pos_offset=pos_offset + a)
+                for o, v in zip(out, (nh, nr, nt)):
+                    o.numpy()[a * neg_per_pos:b * neg_per_pos] = v
+
+    def score(self, ent, ent_norm, rel, rel_norm, dim, pos, neg, neg_per_pos, grad_ent, grad_rel, touched_ent, touched_rel,
+              tag, loss_partials):
+        p = tuple(x.numpy() for x in pos)
+        n = tuple(x.numpy() for x in neg)
+        L, ge, gr = mo.relation_view_step_dense(ent.numpy(), rel.numpy(), None, None, p, n, 0.0, ent_norm=ent_norm,
+                                                rel_norm=rel_norm, update=False)
+        grad_ent.numpy()[...] += ge
+        grad_rel.numpy()[...] += gr
+        te, tr = touched_ent.numpy(), touched_rel.numpy()
+        for a in (p[0], p[2], n[0], n[2]):
+            te[a] = tag
+        tr[p[1]] = tag
+        tr[n[1]] = tag
+        lp = loss_partials.numpy()
+        lp[:] = 0
+        lp[0] = L
+
+    def update(self, table, acc, grad, touched, tag, dim, normalize, lr):
+        rows = np.nonzero(touched.numpy() == tag)[0]
+        w, a, g = table.numpy(), acc.numpy(), grad.numpy()
+        gg = mo.l2_normalize_rows_backward(w[rows], g[rows]) if normalize else g[rows]
+        a[rows] += gg * gg
+        w[rows] -= lr * gg / np.sqrt(a[rows])
+        g[rows] = 0

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd .db (kernel trace) into a per-kernel stats table (markdown)."""
+import sqlite3
+import sys
+
+
+def summarise(db, top=12):
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = (f"select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+         f"sum(d.end-d.start), max(s.arch_vgpr_count), max(s.sgpr_count) from {kd} d join {ks} s on d.kernel_id=s.id "
+         f"group by s.kernel_name order by 6 desc")
+    rows = list(c.execute(q))
+    tot = sum(r[5] for r in rows)
+    out = ["| kernel | calls | avg us | min us | max us | % GPU time | vgpr | sgpr |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows[:top]:
+        out.append(f"| `{r[0][:80]}` | {r[1]} | {r[2] / 1e3:.2f} | {r[3] / 1e3:.2f} | {r[4] / 1e3:.2f} | "
+                   f"{100 * r[5] / tot:.1f} | {r[6]} | {r[7]} |")
+    span = list(c.execute(f"select min(start), max(end) from {kd}"))[0]
+    out.append("")
+    out.append(f"total kernel time {tot / 1e6:.2f} ms over a {(span[1] - span[0]) / 1e6:.2f} ms span, {sum(r[1] for r in rows)} dispatches")
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    print(summarise(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12))
