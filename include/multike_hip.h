@@ -52,6 +52,11 @@ extern "C" {
 int mke_version(void);
 const char* mke_last_error(void);
 
+/* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
+ *   "score_splits"  : quarter-waves sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
+ * Returns the previous value through *old_value when it is not NULL. */
+int mke_set_option(const char* name, int value, int* old_value);
+
 /* ------------------------------------------------------------------------------------------------
  * (1) Fused relation-view triple step: gather + normalise-on-read + translation score + logistic loss
  *     + gradient scatter-add (normalised space).

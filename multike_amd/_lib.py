@@ -22,7 +22,7 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
-    "mke_version", "mke_last_error", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_rows_update_multi",
+    "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_rows_update_multi",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
 )
@@ -115,6 +115,12 @@ def _stream():
 
 def version() -> int:
     return lib().mke_version()
+
+
+def set_option(name: str, value: int) -> int:
+    old = C.c_int(0)
+    _check(lib().mke_set_option(name.encode(), C.c_int(value), C.byref(old)), "mke_set_option")
+    return old.value
 
 
 def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale,

@@ -1,6 +1,7 @@
 // mke_api.hip — error plumbing and version of libmultike_hip.so.
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "mke_common.h"
 
@@ -25,6 +26,21 @@ int check_launch(const char* what) {
 }
 
 }  // namespace mke
+
+namespace mke {
+int g_score_splits = 0;
+}
+
+extern "C" int mke_set_option(const char* name, int value, int* old_value) {
+  if (!name) { mke::set_error("mke_set_option: NULL name"); return MKE_E_NULL; }
+  if (!strcmp(name, "score_splits")) {
+    if (old_value) *old_value = mke::g_score_splits;
+    mke::g_score_splits = value < 0 ? 0 : value;
+    return MKE_OK;
+  }
+  mke::set_error("mke_set_option: unknown option '%s'", name);
+  return MKE_E_UNSUPPORTED;
+}
 
 extern "C" int mke_version(void) { return MKE_VERSION; }
 extern "C" const char* mke_last_error(void) { return mke::g_err; }

@@ -14,6 +14,8 @@
 
 namespace mke {
 
+extern int g_score_splits;  // mke_set_option("score_splits")
+
 struct ScoreParams {
   const float* __restrict__ ent;
   const float* __restrict__ rel;
@@ -250,6 +252,7 @@ extern "C" int mke_triple_score_fwd_bwd(
   if (neg_per_pos > 0 && n_pos > 0) {
     int64_t s = total_subs / n_pos;
     if (s < 1) s = 1;
+    if (g_score_splits > 0) s = g_score_splits;
     if (s > neg_per_pos) s = neg_per_pos;
     splits = (int)s;
   }
