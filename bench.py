@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--neg", type=int, default=25)
     ap.add_argument("--batch", type=int, default=5000)
     ap.add_argument("--sample-chunk", type=int, default=0, help="steps sampled per sampler launch (0 = whole epoch)")
+    ap.add_argument("--rel-grad-copies", type=int, default=1, help="privatised copies of the relation gradient scratch")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded multi-GPU path even at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -136,7 +137,7 @@ def main():
         score_ms = None
     else:
         E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", values=ent0)
-        R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=rel0)
+        R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=rel0, grad_copies=args.rel_grad_copies)
         sides = []
         for k in (0, 1):
             t = torch.as_tensor(kgs.triples[k], device="cuda")
@@ -218,8 +219,16 @@ def main():
         tr = np.array([n for _, _, n in ev])
         avg_ms = float(ms.mean())
         achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
+        traffic = None  # PMC bytes per launch of this kernel: collected by separate rocprofv3 --pmc passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+                pmc = json.load(f)
+            if pmc["workload"] == f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}":
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "alg_bytes_per_triple": b_alg(d),
                     "triples_per_launch": float(tr.mean())}
 

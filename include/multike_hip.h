@@ -40,7 +40,7 @@ extern "C" {
 
 /* Number of per-block loss partials every loss-producing kernel writes (doubles).  The caller passes a
  * double[MKE_LOSS_PARTIALS] scratch; the kernel OVERWRITES all entries; the loss is their sum. */
-#define MKE_LOSS_PARTIALS 1024
+#define MKE_LOSS_PARTIALS 2048
 
 /* Largest supported stride (floats). */
 #define MKE_MAX_STRIDE 320
@@ -74,6 +74,10 @@ int mke_set_option(const char* name, int value, int* old_value);
  *   touched_*[row] = tag is stored for every row that received a contribution.
  *   grad_ent == NULL means forward only (loss only).
  *
+ *   grad_rel_copies = K >= 1: grad_rel is [K][n_rel][stride]; work item i adds into copy i % K.  The few
+ *   hundred relation rows each receive thousands of row-adds per step and same-address atomics serialise in
+ *   the memory-side atomic units, so the hot table is privatised K ways; mke_rows_update sums the copies.
+ *
  *   neg_per_pos > 0: negatives are grouped, negatives [i*neg_per_pos, (i+1)*neg_per_pos) belong to
  *   positive i (the layout code/base/batch.py:86-116 produces) and n_neg must equal n_pos*neg_per_pos;
  *   rows a negative shares with its positive are loaded once and their gradients pre-reduced in
@@ -88,7 +92,7 @@ int mke_triple_score_fwd_bwd(
     const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w /*nullable*/,
     int64_t n_neg, int neg_per_pos,
     float scale,
-    float* grad_ent /*nullable*/, float* grad_rel /*nullable iff grad_ent is*/,
+    float* grad_ent /*nullable*/, float* grad_rel /*nullable iff grad_ent is*/, int grad_rel_copies,
     int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
     double* loss_partials /* [MKE_LOSS_PARTIALS] */,
     void* stream);
@@ -110,7 +114,7 @@ int mke_triple_score_fwd_bwd(
  *     ADAGRAD: acc += g*g; w -= lr*g/sqrt(acc)        SGD: w -= lr*g   (acc may be NULL)
  * ------------------------------------------------------------------------------------------------ */
 int mke_rows_update(
-    float* table, float* acc /*nullable for SGD*/, float* grad,
+    float* table, float* acc /*nullable for SGD*/, float* grad, int grad_copies /* grad is [copies][n_rows][stride] */,
     const int32_t* touched, int32_t tag,
     int64_t n_rows, int stride, int dim,
     int normalize, int optimizer, float lr,
@@ -126,6 +130,7 @@ typedef struct mke_update_table {
   const int32_t* touched;
   int64_t n_rows;
   int normalize;
+  int grad_copies; /* grad is [grad_copies][n_rows][stride] */
 } mke_update_table;
 int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                           int optimizer, float lr, void* stream);
@@ -247,7 +252,8 @@ typedef struct mke_relation_plan {
   float* ent_table; int64_t n_ent; int ent_normalize;
   float* rel_table; int64_t n_rel; int rel_normalize;
   float* ent_acc; float* rel_acc;            /* this optimizer's Adagrad slots (NULL for SGD) */
-  float* ent_grad; float* rel_grad;          /* zero-invariant gradient scratch */
+  float* ent_grad; float* rel_grad;          /* zero-invariant gradient scratch; rel_grad is [rel_grad_copies][n_rel][stride] */
+  int rel_grad_copies;
   int32_t* ent_touched; int32_t* rel_touched;
   int stride, dim;
   const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t;  /* device, epoch order */

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libmultike_hip.so")
 
-LOSS_PARTIALS = 1024  # MKE_LOSS_PARTIALS
+LOSS_PARTIALS = 2048  # MKE_LOSS_PARTIALS
 MAX_STRIDE = 320  # MKE_MAX_STRIDE
 OPT_ADAGRAD, OPT_SGD = 0, 1
 _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
@@ -38,7 +38,7 @@ class KGSideStruct(C.Structure):
 class UpdateTableStruct(C.Structure):
     """mke_update_table"""
     _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p),
-                ("n_rows", C.c_int64), ("normalize", C.c_int)]
+                ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int)]
 
 
 class RelationPlanStruct(C.Structure):
@@ -47,6 +47,7 @@ class RelationPlanStruct(C.Structure):
         ("ent_table", C.c_void_p), ("n_ent", C.c_int64), ("ent_normalize", C.c_int),
         ("rel_table", C.c_void_p), ("n_rel", C.c_int64), ("rel_normalize", C.c_int),
         ("ent_acc", C.c_void_p), ("rel_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("rel_grad", C.c_void_p),
+        ("rel_grad_copies", C.c_int),
         ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("stride", C.c_int), ("dim", C.c_int),
         ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("pos_kg", C.c_void_p),
         ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("sides", KGSideStruct * 2),
@@ -125,7 +126,9 @@ def set_option(name: str, value: int) -> int:
 
 def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale,
                          grad_ent, grad_rel, touched_ent, touched_rel, tag, loss_partials):
-    """mke_triple_score_fwd_bwd.  pos/neg = (h, r, t) int32 CUDA tensors (neg may be None)."""
+    """mke_triple_score_fwd_bwd.  pos/neg = (h, r, t) int32 CUDA tensors (neg may be None).
+    grad_rel may be [K, n_rel, stride] (K privatised copies) or [n_rel, stride]."""
+    rel_copies = 1 if grad_rel is None or grad_rel.dim() == 2 else grad_rel.shape[0]
     ph, pr, pt = pos
     n_pos = ph.numel()
     if neg is None:
@@ -142,16 +145,17 @@ def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w
         _dev(pos_w, torch.float32, "pos_w"), C.c_int64(n_pos),
         _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"),
         _dev(neg_w, torch.float32, "neg_w"), C.c_int64(n_neg), C.c_int(neg_per_pos), C.c_float(scale),
-        _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"),
+        _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"), C.c_int(rel_copies),
         _dev(touched_ent, torch.int32, "touched_ent"), _dev(touched_rel, torch.int32, "touched_rel"), C.c_int32(tag),
         _dev(loss_partials, torch.float64, "loss_partials"), _stream())
     _check(rc, "mke_triple_score_fwd_bwd")
 
 
 def rows_update(table, acc, grad, touched, tag, dim, normalize, optimizer, lr):
+    copies = 1 if grad.dim() == 2 else grad.shape[0]
     rc = lib().mke_rows_update(
         _dev(table, torch.float32, "table"), _dev(acc, torch.float32, "acc"), _dev(grad, torch.float32, "grad"),
-        _dev(touched, torch.int32, "touched"), C.c_int32(tag), C.c_int64(table.shape[0]), C.c_int(table.shape[1]),
+        C.c_int(copies), _dev(touched, torch.int32, "touched"), C.c_int32(tag), C.c_int64(table.shape[0]), C.c_int(table.shape[1]),
         C.c_int(dim), C.c_int(int(normalize)), C.c_int(optimizer), C.c_float(lr), _stream())
     _check(rc, "mke_rows_update")
 
@@ -171,6 +175,7 @@ def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
         arr[k].touched = ptr(touched, torch.int32, "touched")
         arr[k].n_rows = data.shape[0]
         arr[k].normalize = int(normalize)
+        arr[k].grad_copies = 1 if grad.dim() == 2 else grad.shape[0]
     rc = lib().mke_rows_update_multi(arr, C.c_int(len(tables)), C.c_int32(tag), C.c_int(stride), C.c_int(dim),
                                      C.c_int(optimizer), C.c_float(lr), _stream())
     _check(rc, "mke_rows_update_multi")

@@ -14,6 +14,9 @@
 
 namespace mke {
 
+#ifndef MKE_SCORE_U
+#define MKE_SCORE_U 4
+#endif
 extern int g_score_splits;  // mke_set_option("score_splits")
 
 struct ScoreParams {
@@ -36,6 +39,8 @@ struct ScoreParams {
   float scale;
   float* __restrict__ gent;
   float* __restrict__ grel;
+  int grel_copies;
+  int64_t grel_copy_elems;  // n_rel * stride
   int32_t* __restrict__ tent;
   int32_t* __restrict__ trel;
   int32_t tag;
@@ -44,8 +49,8 @@ struct ScoreParams {
 
 // One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
 template <int FPL>
-__device__ __forceinline__ float independent_triple(const ScoreParams& p, int j, int h, int r, int t, float w,
-                                                    float sign) {
+__device__ __forceinline__ float independent_triple(const ScoreParams& p, float* __restrict__ grel, int j, int h, int r,
+                                                    int t, float w, float sign) {
   float H[FPL], R[FPL], T[FPL];
   load_row<FPL>(p.ent, h, p.stride, j, H);
   load_row<FPL>(p.rel, r, p.stride, j, R);
@@ -67,7 +72,7 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, int j,
 #pragma unroll
     for (int k = 0; k < FPL; ++k) H[k] *= c;
     atomic_add_row<FPL>(p.gent, h, p.stride, p.dim, j, H, 1.0f);
-    atomic_add_row<FPL>(p.grel, r, p.stride, p.dim, j, H, 1.0f);
+    atomic_add_row<FPL>(grel, r, p.stride, p.dim, j, H, 1.0f);
     atomic_add_row<FPL>(p.gent, t, p.stride, p.dim, j, H, -1.0f);
     if (j == 0) {
       p.tent[h] = p.tag;
@@ -78,137 +83,176 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, int j,
   return l;
 }
 
+// Grouped kernel: one 64-lane wavefront owns one (slice of a) group = a positive and its negatives.
+// The four quarter-waves load the positive's rows redundantly (one TA broadcast), take the group's negatives
+// round-robin, keep the shared rows' gradients in registers, reduce them across the quarters with two
+// butterfly steps and flush them with ONE scatter of three rows (quarter 0 -> head row, 1 -> relation row,
+// 2 -> tail row).  Lanes of one wave-instruction therefore never add to the same address (measured on
+// MI355X: S quarter-waves of one wave adding to the same rows cost ~15-25 us per extra S at this shape).
 template <int FPL, int U>
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
-  const int j = threadIdx.x & 15;
-  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
-  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
   const bool bwd = p.gent != nullptr;
   float loss = 0.f;  // identical on the 16 lanes of a quarter-wave; lane j==0 contributes
 
   const int npp = p.npp;
-  const int S = p.splits;
-  const int64_t nwork = p.n_pos * S;
-  for (int64_t wk = sub0; wk < nwork; wk += nsub) {
-    const int64_t g = wk / S;
-    const int s = (int)(wk - g * S);
-    const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
-    float H[FPL], R[FPL], T[FPL];
-    load_row<FPL>(p.ent, ph, p.stride, j, H);
-    load_row<FPL>(p.rel, pr, p.stride, j, R);
-    load_row<FPL>(p.ent, pt, p.stride, j, T);
-    l2_normalize_row<FPL>(H, p.ent_norm);
-    l2_normalize_row<FPL>(R, p.rel_norm);
-    l2_normalize_row<FPL>(T, p.ent_norm);
-    float gH[FPL], gR[FPL], gT[FPL];  // gT holds the NEGATED t-gradient (sum of c*d)
+  if (npp > 0) {
+    const int S = p.splits;  // wavefronts sharing one group's negatives
+    const int64_t nwork = p.n_pos * S;
+    for (int64_t wk = wave0; wk < nwork; wk += nwaves) {
+      const int64_t g = wk % p.n_pos;  // slices of one group are n_pos work items apart: different CUs
+      const int s = (int)(wk / p.n_pos);
+      float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
+      const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
+      float H[FPL], R[FPL], T[FPL];
+      load_row<FPL>(p.ent, ph, p.stride, j, H);
+      load_row<FPL>(p.rel, pr, p.stride, j, R);
+      load_row<FPL>(p.ent, pt, p.stride, j, T);
+      l2_normalize_row<FPL>(H, p.ent_norm);
+      l2_normalize_row<FPL>(R, p.rel_norm);
+      l2_normalize_row<FPL>(T, p.ent_norm);
+      float gH[FPL], gR[FPL], gT[FPL];  // gT holds the NEGATED t-gradient (sum of c*d)
 #pragma unroll
-    for (int k = 0; k < FPL; ++k) gH[k] = gR[k] = gT[k] = 0.f;
+      for (int k = 0; k < FPL; ++k) gH[k] = gR[k] = gT[k] = 0.f;
 
-    if (s == 0) {  // the positive itself
-      const float w = p.pw ? p.pw[g] : 1.0f;
-      float d[FPL];
-      float x = 0.f;
+      if (s == 0 && q == 0) {  // the positive itself
+        const float w = p.pw ? p.pw[g] : 1.0f;
+        float d[FPL];
+        float x = 0.f;
 #pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        d[k] = (H[k] + R[k]) - T[k];
-        x = fmaf(d[k], d[k], x);
-      }
-      x = sub16_sum(x);
-      loss += w * softplus_f(x);
-      const float c = 2.0f * w * p.scale * sigmoid_f(x);
+        for (int k = 0; k < FPL; ++k) {
+          d[k] = (H[k] + R[k]) - T[k];
+          x = fmaf(d[k], d[k], x);
+        }
+        x = sub16_sum(x);
+        loss += w * softplus_f(x);
+        const float c = 2.0f * w * p.scale * sigmoid_f(x);
 #pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        const float gd = c * d[k];
-        gH[k] += gd; gR[k] += gd; gT[k] += gd;
-      }
-    }
-
-    // this quarter-wave's slice of the group's negatives
-    const int per = (npp + S - 1) / S;
-    const int n_lo = s * per;
-    const int n_hi = min(npp, n_lo + per);
-    const int64_t nbase = g * (int64_t)npp;
-    for (int n0 = n_lo; n0 < n_hi; n0 += U) {
-      int e[U];
-      bool fast[U], sideH[U], live[U];
-      float w[U];
-      float C[U][FPL];
-      // phase 1: ids
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        live[u] = (n0 + u) < n_hi;
-        const int64_t idx = nbase + (live[u] ? n0 + u : n_lo);
-        const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
-        w[u] = p.nw ? p.nw[idx] : 1.0f;
-        const bool dh = nh != ph, dt = nt != pt;
-        fast[u] = live[u] && (nr == pr) && (dh != dt);
-        sideH[u] = dh;
-        e[u] = dh ? nh : nt;
-        if (live[u] && !fast[u]) {  // rare: negative shares nothing usable / equals the positive
-          loss += independent_triple<FPL>(p, j, nh, nr, nt, w[u], -1.0f);
+        for (int k = 0; k < FPL; ++k) {
+          const float gd = c * d[k];
+          gH[k] += gd; gR[k] += gd; gT[k] += gd;
         }
       }
-      // phase 2: all corrupt-row gathers of the chunk in flight together
+
+      // this wave's slice of the group's negatives; quarter q takes n_lo+q, n_lo+q+4, ...
+      const int per = (npp + S - 1) / S;
+      const int n_lo = s * per;
+      const int n_hi = min(npp, n_lo + per);
+      const int64_t nbase = g * (int64_t)npp;
+      bool any_slow = false;
+      for (int n0 = n_lo + q; n0 < n_hi; n0 += 4 * U) {
+        int e[U];
+        bool fast[U], sideH[U];
+        float w[U];
+        float C[U][FPL];
+        // phase 1: ids
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (fast[u]) {
-          load_row<FPL>(p.ent, e[u], p.stride, j, C[u]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < FPL; ++k) C[u][k] = 0.f;
+        for (int u = 0; u < U; ++u) {
+          const int n = n0 + 4 * u;
+          const bool live = n < n_hi;
+          const int64_t idx = nbase + (live ? n : n_lo);
+          const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+          w[u] = p.nw ? p.nw[idx] : 1.0f;
+          const bool dh = nh != ph, dt = nt != pt;
+          fast[u] = live && (nr == pr) && (dh != dt);
+          sideH[u] = dh;
+          e[u] = dh ? nh : nt;
+          any_slow |= live && !fast[u];
         }
-      }
-      // phase 3: score, loss, gradient
+        // phase 2: all corrupt-row gathers of the chunk in flight together
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (fast[u]) {
-          l2_normalize_row<FPL>(C[u], p.ent_norm);
-          float d[FPL];
-          float y = 0.f;
+        for (int u = 0; u < U; ++u) {
+          if (fast[u]) {
+            load_row<FPL>(p.ent, e[u], p.stride, j, C[u]);
+          } else {
 #pragma unroll
-          for (int k = 0; k < FPL; ++k) {
-            const float hh = sideH[u] ? C[u][k] : H[k];
-            const float tt = sideH[u] ? T[k] : C[u][k];
-            d[k] = (hh + R[k]) - tt;
-            y = fmaf(d[k], d[k], y);
+            for (int k = 0; k < FPL; ++k) C[u][k] = 0.f;
           }
-          y = sub16_sum(y);
-          loss += w[u] * softplus_f(-y);
-          if (bwd) {
-            const float c = -2.0f * w[u] * p.scale * sigmoid_f(-y);
-            const float toH = sideH[u] ? 0.f : 1.f;
-            const float toT = sideH[u] ? 1.f : 0.f;
+        }
+        // phase 3: score, loss, gradient
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (fast[u]) {
+            l2_normalize_row<FPL>(C[u], p.ent_norm);
+            float d[FPL];
+            float y = 0.f;
 #pragma unroll
             for (int k = 0; k < FPL; ++k) {
-              d[k] *= c;
-              gR[k] += d[k];
-              gH[k] = fmaf(toH, d[k], gH[k]);
-              gT[k] = fmaf(toT, d[k], gT[k]);
+              const float hh = sideH[u] ? C[u][k] : H[k];
+              const float tt = sideH[u] ? T[k] : C[u][k];
+              d[k] = (hh + R[k]) - tt;
+              y = fmaf(d[k], d[k], y);
             }
-            atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
-            if (j == 0) p.tent[e[u]] = p.tag;
+            y = sub16_sum(y);
+            loss += w[u] * softplus_f(-y);
+            if (bwd) {
+              const float c = -2.0f * w[u] * p.scale * sigmoid_f(-y);
+              const float toH = sideH[u] ? 0.f : 1.f;
+              const float toT = sideH[u] ? 1.f : 0.f;
+#pragma unroll
+              for (int k = 0; k < FPL; ++k) {
+                d[k] *= c;
+                gR[k] += d[k];
+                gH[k] = fmaf(toH, d[k], gH[k]);
+                gT[k] = fmaf(toT, d[k], gT[k]);
+              }
+              atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
+              if (j == 0) p.tent[e[u]] = p.tag;
+            }
+          }
+        }
+      }
+
+      if (any_slow) {
+        // rare: negatives that are not "the positive with exactly one entity replaced" (both sides or the
+        // relation differ, or the negative equals the positive) are scored as independent triples
+#pragma unroll 1
+        for (int n = n_lo + q; n < n_hi; n += 4) {
+          const int64_t idx = nbase + n;
+          const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+          if (!((nr == pr) && ((nh != ph) != (nt != pt))))
+            loss += independent_triple<FPL>(p, grel, j, nh, nr, nt, p.nw ? p.nw[idx] : 1.0f, -1.0f);
+        }
+      }
+
+      if (bwd) {
+        // reduce the shared rows' gradients over the four quarter-waves (all lanes converge here)
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) {
+          gH[k] += __shfl_xor(gH[k], 16, 64); gH[k] += __shfl_xor(gH[k], 32, 64);
+          gR[k] += __shfl_xor(gR[k], 16, 64); gR[k] += __shfl_xor(gR[k], 32, 64);
+          gT[k] += __shfl_xor(gT[k], 16, 64); gT[k] += __shfl_xor(gT[k], 32, 64);
+        }
+        if (s == 0 || n_lo < n_hi) {
+          // one scatter instruction stream covers the three rows: quarter 0 -> h, 1 -> r, 2 -> t
+          float v[FPL];
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : (q == 1 ? gR[k] : -gT[k]);
+          float* __restrict__ base = q == 1 ? grel : p.gent;
+          const int row = q == 0 ? ph : (q == 1 ? pr : pt);
+          if (q < 3) {
+            atomic_add_row<FPL>(base, row, p.stride, p.dim, j, v, 1.0f);
+            if (j == 0) (q == 1 ? p.trel : p.tent)[row] = p.tag;
           }
         }
       }
     }
-
-    if (bwd && (s == 0 || n_lo < n_hi)) {
-      atomic_add_row<FPL>(p.gent, ph, p.stride, p.dim, j, gH, 1.0f);
-      atomic_add_row<FPL>(p.grel, pr, p.stride, p.dim, j, gR, 1.0f);
-      atomic_add_row<FPL>(p.gent, pt, p.stride, p.dim, j, gT, -1.0f);
-      if (j == 0) {
-        p.tent[ph] = p.tag;
-        p.tent[pt] = p.tag;
-        p.trel[pr] = p.tag;
+  } else {
+    // no grouping: every positive / negative is an independent triple, one quarter-wave each
+    const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+    const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+    for (int64_t i = sub0; i < p.n_pos + p.n_neg; i += nsub) {
+      float* __restrict__ grel = bwd ? p.grel + (i % p.grel_copies) * p.grel_copy_elems : nullptr;
+      if (i < p.n_pos) {
+        loss += independent_triple<FPL>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f);
+      } else {
+        const int64_t n = i - p.n_pos;
+        loss += independent_triple<FPL>(p, grel, j, p.nh[n], p.nr[n], p.nt[n], p.nw ? p.nw[n] : 1.0f, -1.0f);
       }
-    }
-  }
-
-  // ungrouped negatives: independent triples
-  if (npp == 0) {
-    for (int64_t i = sub0; i < p.n_neg; i += nsub) {
-      const float w = p.nw ? p.nw[i] : 1.0f;
-      loss += independent_triple<FPL>(p, j, p.nh[i], p.nr[i], p.nt[i], w, -1.0f);
     }
   }
 
@@ -223,7 +267,7 @@ extern "C" int mke_triple_score_fwd_bwd(
     int rel_normalize, int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t,
     const float* pos_w, int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t,
     const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
-    int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream) {
+    int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream) {
   using namespace mke;
   if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
   if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
@@ -240,6 +284,7 @@ extern "C" int mke_triple_score_fwd_bwd(
   }
   if ((grad_ent == nullptr) != (grad_rel == nullptr)) { set_error("grad_ent and grad_rel must both be given or both NULL"); return MKE_E_NULL; }
   if (grad_ent && (!touched_ent || !touched_rel)) { set_error("NULL touched array"); return MKE_E_NULL; }
+  if (grad_ent && (grad_rel_copies < 1 || grad_rel_copies > 64)) { set_error("grad_rel_copies must be in [1,64]"); return MKE_E_SHAPE; }
 
   ScoreParams p;
   p.ent = ent_table; p.rel = rel_table; p.ent_norm = ent_normalize; p.rel_norm = rel_normalize;
@@ -247,10 +292,12 @@ extern "C" int mke_triple_score_fwd_bwd(
   p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.pw = pos_w; p.n_pos = n_pos;
   p.nh = neg_h; p.nr = neg_r; p.nt = neg_t; p.nw = neg_w; p.n_neg = n_neg;
   p.npp = neg_per_pos;
-  const int64_t total_subs = (int64_t)MKE_LOSS_PARTIALS * MKE_SUBS_PER_BLOCK;
+  const int64_t total_waves = (int64_t)MKE_LOSS_PARTIALS * (MKE_BLOCK / 64);
   int splits = 1;
   if (neg_per_pos > 0 && n_pos > 0) {
-    int64_t s = total_subs / n_pos;
+    int64_t s = total_waves / n_pos;  // spread small batches over the chip
+    const int64_t smax = (neg_per_pos + 3) / 4;
+    if (s > smax) s = smax;
     if (s < 1) s = 1;
     if (g_score_splits > 0) s = g_score_splits;
     if (s > neg_per_pos) s = neg_per_pos;
@@ -258,12 +305,14 @@ extern "C" int mke_triple_score_fwd_bwd(
   }
   p.splits = splits;
   p.scale = scale;
-  p.gent = grad_ent; p.grel = grad_rel; p.tent = touched_ent; p.trel = touched_rel; p.tag = tag;
+  p.gent = grad_ent; p.grel = grad_rel; p.grel_copies = grad_rel_copies < 1 ? 1 : grad_rel_copies;
+  p.grel_copy_elems = n_rel * (int64_t)stride;
+  p.tent = touched_ent; p.trel = touched_rel; p.tag = tag;
   p.lossp = loss_partials;
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;
   MKE_DISPATCH_FPL(fpl, {
-    constexpr int U = FPL <= 5 ? 4 : (FPL <= 8 ? 2 : 1);
+    constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);  // corrupt rows in flight per quarter-wave
     hipLaunchKernelGGL((k_triple_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
   });
   return check_launch("k_triple_score");

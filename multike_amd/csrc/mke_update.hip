@@ -17,6 +17,7 @@ struct UpdateParams {
   float* __restrict__ table;
   float* __restrict__ acc;
   float* __restrict__ grad;
+  int copies;
   const int32_t* __restrict__ touched;
   int32_t tag;
   int64_t n_rows;
@@ -32,6 +33,14 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
   float g[FPL], w[FPL], a[FPL];
 #pragma unroll
   for (int k = 0; k < FPL; ++k) g[k] = gp[k * 16];
+  if (p.copies > 1) {  // privatised gradient: sum (and consume) the other copies
+    const int64_t ce = p.n_rows * (int64_t)p.stride;
+    for (int c = 1; c < p.copies; ++c) {
+      float* gc = gp + c * ce;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) { g[k] += gc[k * 16]; gc[k * 16] = 0.f; }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
   const bool adagrad = p.optimizer == MKE_OPT_ADAGRAD;
@@ -133,6 +142,7 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
   for (int k = 0; k < n_tables; ++k) {
     UpdateParams& p = mp.t[k];
     p.table = tables[k].table; p.acc = tables[k].acc; p.grad = tables[k].grad; p.touched = tables[k].touched;
+    p.copies = tables[k].grad_copies < 1 ? 1 : tables[k].grad_copies;
     p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
     p.optimizer = optimizer; p.lr = lr;
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
@@ -148,7 +158,7 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
 
 }  // namespace mke
 
-extern "C" int mke_rows_update(float* table, float* acc, float* grad, const int32_t* touched, int32_t tag,
+extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_copies, const int32_t* touched, int32_t tag,
                                int64_t n_rows, int stride, int dim, int normalize, int optimizer, float lr,
                                void* stream) {
   using namespace mke;
@@ -162,7 +172,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, const int3
   }
   if (n_rows == 0) return MKE_OK;
   UpdateParams p;
-  p.table = table; p.acc = acc; p.grad = grad; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
+  p.table = table; p.acc = acc; p.grad = grad; p.copies = grad_copies < 1 ? 1 : grad_copies; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
   const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
   const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;

@@ -51,6 +51,9 @@ class RelationViewRunner:
         p.ent_acc = _lib.ptr(e.slot(self.opt_name), torch.float32, "acc") if adagrad else None
         p.rel_acc = _lib.ptr(r.slot(self.opt_name), torch.float32, "acc") if adagrad else None
         p.ent_grad, p.rel_grad = _lib.ptr(e.grad, torch.float32, "g"), _lib.ptr(r.grad, torch.float32, "g")
+        p.rel_grad_copies = r.grad_copies
+        if e.grad_copies != 1:
+            raise _lib.MultiKEHipError("the entity table's gradient scratch cannot be privatised")
         p.ent_touched, p.rel_touched = _lib.ptr(e.touched, torch.int32, "t"), _lib.ptr(r.touched, torch.int32, "t")
         p.stride, p.dim = e.stride, e.dim
         p.pos_kg = _lib.ptr(b.pos_kg, torch.uint8, "pos_kg")

@@ -22,7 +22,7 @@ ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_
 
 class EmbeddingTable:
     def __init__(self, n_rows: int, dim: int, name: str = "", normalize: bool = True, trainable: bool = True,
-                 device="cuda", values=None, seed=None):
+                 device="cuda", values=None, seed=None, grad_copies: int = 1):
         self.n_rows, self.dim, self.name = int(n_rows), int(dim), name
         self.normalize, self.trainable = bool(normalize), bool(trainable)
         self.stride = _lib.stride_for(self.dim)
@@ -34,6 +34,9 @@ class EmbeddingTable:
             self.data[:, :self.dim] = v.to(self.device)
         elif trainable:
             self.data[:, :self.dim] = xavier_truncated_normal(self.n_rows, self.dim, self.device, seed)
+        # hot tables (a few hundred relation rows hit thousands of times per step) privatise their gradient
+        # scratch `grad_copies` ways so that same-address atomics do not serialise (mke_triple_score_fwd_bwd)
+        self.grad_copies = int(grad_copies)
         self.slots: dict[str, torch.Tensor] = {}
         self._grad = None
         self._touched = None
@@ -42,7 +45,8 @@ class EmbeddingTable:
     @property
     def grad(self) -> torch.Tensor:
         if self._grad is None:
-            self._grad = torch.zeros_like(self.data)
+            self._grad = torch.zeros_like(self.data) if self.grad_copies == 1 else \
+                torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
         return self._grad
 
     @property

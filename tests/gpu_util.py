@@ -14,9 +14,9 @@ def dev_f32(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
 
 
-def make_tables(ent, rel, ent_norm=True, rel_norm=True):
+def make_tables(ent, rel, ent_norm=True, rel_norm=True, rel_grad_copies=1):
     E = EmbeddingTable(ent.shape[0], ent.shape[1], "ent", normalize=ent_norm, values=ent)
-    R = EmbeddingTable(rel.shape[0], rel.shape[1], "rel", normalize=rel_norm, values=rel)
+    R = EmbeddingTable(rel.shape[0], rel.shape[1], "rel", normalize=rel_norm, values=rel, grad_copies=rel_grad_copies)
     return E, R
 
 

@@ -62,21 +62,21 @@ def test_struct_layouts_match_header():
 def test_argument_validation_without_gpu(lib):
     """Bad arguments are rejected before any launch: error code < 0 and a message."""
     null = C.c_void_p(0)
-    rc = lib.mke_rows_update(null, null, null, null, C.c_int32(1), C.c_int64(4), C.c_int(80), C.c_int(75), C.c_int(1),
+    rc = lib.mke_rows_update(null, null, null, C.c_int(1), null, C.c_int32(1), C.c_int64(4), C.c_int(80), C.c_int(75), C.c_int(1),
                              C.c_int(0), C.c_float(0.1), null)
     assert rc == -1 and b"NULL" in lib.mke_last_error()
     one = C.c_void_p(16)
-    rc = lib.mke_rows_update(one, one, one, one, C.c_int32(1), C.c_int64(4), C.c_int(75), C.c_int(75), C.c_int(1),
+    rc = lib.mke_rows_update(one, one, one, C.c_int(1), one, C.c_int32(1), C.c_int64(4), C.c_int(75), C.c_int(75), C.c_int(1),
                              C.c_int(0), C.c_float(0.1), null)
     assert rc == -2 and b"stride" in lib.mke_last_error()
-    rc = lib.mke_rows_update(one, one, one, one, C.c_int32(1), C.c_int64(4), C.c_int(80), C.c_int(75), C.c_int(1),
+    rc = lib.mke_rows_update(one, one, one, C.c_int(1), one, C.c_int32(1), C.c_int64(4), C.c_int(80), C.c_int(75), C.c_int(1),
                              C.c_int(7), C.c_float(0.1), null)
     assert rc == -3
     rc = lib.mke_gathered_logistic_fwd_bwd(one, one, one, null, C.c_int64(3), C.c_int(75), C.c_int(75), C.c_int(2), null,
                                            null, null, one, null)
     assert rc == -2 and b"sign" in lib.mke_last_error()
     # empty work is a no-op success without touching the device
-    assert lib.mke_rows_update(one, one, one, one, C.c_int32(1), C.c_int64(0), C.c_int(80), C.c_int(75), C.c_int(1),
+    assert lib.mke_rows_update(one, one, one, C.c_int(1), one, C.c_int32(1), C.c_int64(0), C.c_int(80), C.c_int(75), C.c_int(1),
                                C.c_int(0), C.c_float(0.1), null) == 0
 
 

@@ -26,7 +26,7 @@ def _setup(seed=3, n_ent=4000, n_rel=30, d=75, B=500, N=10):
 
     def fresh():
         E = EmbeddingTable(n_ent, d, "e", values=ent)
-        R = EmbeddingTable(n_rel, d, "r", values=rel)
+        R = EmbeddingTable(n_rel, d, "r", values=rel, grad_copies=2)
         bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=42)
         return E, R, bat
     return kgs, ent, rel, fresh

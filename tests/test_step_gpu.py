@@ -19,13 +19,14 @@ def _case(g, ci):
     return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
 
 
+@pytest.mark.parametrize("copies", [1, 8])
 @pytest.mark.parametrize("ci", range(5))
-def test_golden_three_steps(losses_golden, ci):
+def test_golden_three_steps(losses_golden, ci, copies):
     from gpu_util import dev_i32, make_tables
     from multike_amd.tables import StepEngine
     c = _case(losses_golden, ci)
     N = int(c["meta"][5])
-    E, R = make_tables(c["ent"], c["rel"])
+    E, R = make_tables(c["ent"], c["rel"], rel_grad_copies=copies)
     eng = StepEngine()
     pos = tuple(dev_i32(c[k]) for k in ("ph", "pr", "pt"))
     neg = tuple(dev_i32(c[k]) for k in ("nh", "nr", "nt"))
@@ -189,7 +190,7 @@ def test_full_size_c2_batch_vs_c_oracle():
     d = 75
     ent = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
     rel = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
-    E, R = make_tables(ent, rel)
+    E, R = make_tables(ent, rel, rel_grad_copies=8)
     eng = StepEngine()
     sides = []
     for k in (0, 1):
