@@ -272,6 +272,28 @@ typedef struct mke_relation_plan {
 
 int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (7) Bookkeeping of the entity-row sharded (multi-GPU) step.  New design — the reference has no multi-device
+ *     code.  Entity rows are owned by rank id % n_ranks (local row id / n_ranks).  Everything
+ *     is fixed-capacity so that the exchanges are equal-split all-to-alls with no host synchronisation.
+ *
+ *   mke_rowset_build: distinct ids of up to four index streams -> req[owner][slot] = id / n_ranks (req is
+ *     [n_ranks][capacity], pre-filled with -1 by the caller), id_map[id] = owner*capacity + slot, counts[owner] =
+ *     rows requested of that owner.  flags ([n_ent], zero) and counts ([n_ranks], zero) are scratch; flags are left
+ *     dirty and are cleared by mke_rowset_remap.  *overflow is set to 1 when a segment is full (result invalid).
+ *     Slot order inside a segment is unspecified.
+ *   mke_rowset_remap: out[i] = id_map[ids[i]] and flags[ids[i]] = 0.
+ *   mke_rows_gather_padded: out[i][:] = idx[i] >= 0 ? table[idx[i]][:] : 0   (raw padded rows, no normalisation)
+ *   mke_rows_scatter_add: grad[idx[i]][:] += rows[i][:] (atomic), touched[idx[i]] = tag, for idx[i] >= 0.
+ * ------------------------------------------------------------------------------------------------ */
+int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* ids1, int64_t n1, const int32_t* ids2, int64_t n2,
+                     const int32_t* ids3, int64_t n3, int32_t* flags, int32_t* counts, int32_t* req, int32_t* id_map,
+                     int32_t* overflow, int n_ranks, int capacity, void* stream);
+int mke_rowset_remap(const int32_t* ids, int64_t n, const int32_t* id_map, int32_t* out, int32_t* flags, void* stream);
+int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out, void* stream);
+int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int stride, int dim, float* grad,
+                         int32_t* touched, int32_t tag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

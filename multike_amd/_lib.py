@@ -25,6 +25,7 @@ SYMBOLS = (
     "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_rows_update_multi",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
+    "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
 )
 
 
@@ -250,3 +251,36 @@ def gather_rows(table, normalize, dim, idx, out):
                                C.c_int(dim), _dev(idx, torch.int32, "idx"), C.c_int64(n),
                                _dev(out, torch.float32, "out"), _stream())
     _check(rc, "mke_gather_rows")
+
+
+def rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
+    """streams: up to four int32 id tensors."""
+    args = []
+    for k in range(4):
+        t = streams[k] if k < len(streams) else None
+        args += [_dev(t, torch.int32, f"ids{k}"), C.c_int64(0 if t is None else t.numel())]
+    rc = lib().mke_rowset_build(*args, _dev(flags, torch.int32, "flags"), _dev(counts, torch.int32, "counts"),
+                                _dev(req, torch.int32, "req"), _dev(id_map, torch.int32, "id_map"),
+                                _dev(overflow, torch.int32, "overflow"), C.c_int(n_ranks), C.c_int(capacity), _stream())
+    _check(rc, "mke_rowset_build")
+
+
+def rowset_remap(ids, id_map, out, flags):
+    rc = lib().mke_rowset_remap(_dev(ids, torch.int32, "ids"), C.c_int64(ids.numel()), _dev(id_map, torch.int32, "id_map"),
+                                _dev(out, torch.int32, "out"), _dev(flags, torch.int32, "flags"), _stream())
+    _check(rc, "mke_rowset_remap")
+
+
+def rows_gather_padded(table, idx, out):
+    rc = lib().mke_rows_gather_padded(_dev(table, torch.float32, "table"), C.c_int(table.shape[1]),
+                                      _dev(idx, torch.int32, "idx"), C.c_int64(idx.numel()),
+                                      _dev(out, torch.float32, "out"), _stream())
+    _check(rc, "mke_rows_gather_padded")
+
+
+def rows_scatter_add(idx, rows, dim, grad, touched, tag):
+    rc = lib().mke_rows_scatter_add(_dev(idx, torch.int32, "idx"), _dev(rows, torch.float32, "rows"),
+                                    C.c_int64(idx.numel()), C.c_int(grad.shape[1]), C.c_int(dim),
+                                    _dev(grad, torch.float32, "grad"), _dev(touched, torch.int32, "touched"), C.c_int32(tag),
+                                    _stream())
+    _check(rc, "mke_rows_scatter_add")

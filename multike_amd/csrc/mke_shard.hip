@@ -1,0 +1,187 @@
+// mke_shard.hip — device-side bookkeeping of the entity-row sharded (multi-GPU) step (gfx950).
+//
+// New design (the reference has no multi-device code).  Entity rows are sharded by id % G.  Per step a
+// rank needs the set of distinct entity rows its triples reference, grouped by owner, in a FIXED-CAPACITY layout
+// [G][C] so that every exchange is an equal-split all-to-all with no size negotiation and no host synchronisation:
+//   k_rowset_build : ids -> first-touch detection (atomicExch on a flag per entity) -> slot in the owner's segment
+//                    (block-aggregated counters) -> req[owner][slot] = id / G, id_map[id] = owner*C + slot
+//   k_rowset_remap : index streams -> compact indices through id_map; clears the flags it used
+//   k_rows_gather_padded : owner side, req (local rows, -1 = pad) -> raw rows [n][stride] (pad -> zero row)
+//   k_rows_scatter_add   : owner side, returned gradient rows -> atomic add into the shard's gradient scratch
+#include "mke_common.h"
+
+namespace mke {
+
+#define MKE_MAX_RANKS 64
+
+struct RowsetParams {
+  const int32_t* ids[4];
+  int64_t len[4];
+  int64_t total;
+  int32_t* flags;    // [n_ent] 0 on entry
+  int32_t* counts;   // [G] 0 on entry
+  int32_t* req;      // [G][C] pre-filled with -1
+  int32_t* id_map;   // [n_ent]
+  int32_t* overflow; // [1] set to 1 when an owner's segment is full
+  int G, C;
+};
+
+__device__ __forceinline__ int32_t stream_at(const RowsetParams& p, int64_t i) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (i < p.len[s]) return p.ids[s][i];
+    i -= p.len[s];
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_rowset_build(const RowsetParams p) {
+  __shared__ int s_cnt[MKE_MAX_RANKS];
+  __shared__ int s_base[MKE_MAX_RANKS];
+  const int64_t stride = (int64_t)gridDim.x * MKE_BLOCK;
+  for (int64_t base = (int64_t)blockIdx.x * MKE_BLOCK; base < p.total; base += stride) {  // block-uniform trip count
+    if (threadIdx.x < p.G) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    int id = -1, owner = 0, local = 0;
+    bool first = false;
+    if (i < p.total) {
+      id = stream_at(p, i);
+      first = atomicExch(&p.flags[id], 1) == 0;
+      owner = id % p.G;
+      if (first) local = atomicAdd(&s_cnt[owner], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < p.G) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&p.counts[threadIdx.x], s_cnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (first) {
+      const int slot = s_base[owner] + local;
+      if (slot < p.C) {
+        p.req[(int64_t)owner * p.C + slot] = id / p.G;
+        p.id_map[id] = owner * p.C + slot;
+      } else {
+        *p.overflow = 1;
+        p.id_map[id] = owner * p.C;  // keep indices in range; the step's result is invalid and flagged
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const int32_t* __restrict__ ids, int64_t n,
+                                                            const int32_t* __restrict__ id_map, int32_t* __restrict__ out,
+                                                            int32_t* __restrict__ flags) {
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    const int id = ids[i];
+    out[i] = id_map[id];
+    flags[id] = 0;
+  }
+}
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_rows_gather_padded(const float* __restrict__ table, int stride,
+                                                                  const int32_t* __restrict__ idx, int64_t n,
+                                                                  float* __restrict__ out) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  for (int64_t i = sub0; i < n; i += nsub) {
+    const int row = idx[i];
+    float v[FPL];
+    if (row >= 0) {
+      load_row<FPL>(table, row, stride, j, v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) v[k] = 0.f;
+    }
+    float* o = out + i * (int64_t)stride + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) o[k * 16] = v[k];
+  }
+}
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_rows_scatter_add(const int32_t* __restrict__ idx, const float* __restrict__ rows,
+                                                                int64_t n, int stride, int dim, float* __restrict__ grad,
+                                                                int32_t* __restrict__ touched, int32_t tag) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  for (int64_t i = sub0; i < n; i += nsub) {
+    const int row = idx[i];
+    if (row < 0) continue;
+    float v[FPL];
+    load_row<FPL>(rows, i, stride, j, v);
+    atomic_add_row<FPL>(grad, row, stride, dim, j, v, 1.0f);
+    if (j == 0) touched[row] = tag;
+  }
+}
+
+static inline unsigned blocks_for(int64_t n, int per_block) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (unsigned)b;
+}
+
+}  // namespace mke
+
+extern "C" int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* ids1, int64_t n1, const int32_t* ids2,
+                                int64_t n2, const int32_t* ids3, int64_t n3, int32_t* flags, int32_t* counts, int32_t* req,
+                                int32_t* id_map, int32_t* overflow, int n_ranks, int capacity, void* stream) {
+  using namespace mke;
+  if (n0 < 0 || n1 < 0 || n2 < 0 || n3 < 0) { set_error("negative length"); return MKE_E_SHAPE; }
+  if (n_ranks < 1 || n_ranks > MKE_MAX_RANKS || capacity < 1) { set_error("n_ranks must be in [1,%d], capacity >= 1", MKE_MAX_RANKS); return MKE_E_SHAPE; }
+  if (!flags || !counts || !req || !id_map || !overflow) { set_error("mke_rowset_build: NULL pointer"); return MKE_E_NULL; }
+  RowsetParams p;
+  p.ids[0] = ids0; p.ids[1] = ids1; p.ids[2] = ids2; p.ids[3] = ids3;
+  p.len[0] = n0; p.len[1] = n1; p.len[2] = n2; p.len[3] = n3;
+  p.total = n0 + n1 + n2 + n3;
+  for (int s = 0; s < 4; ++s)
+    if (p.len[s] > 0 && !p.ids[s]) { set_error("NULL id stream %d", s); return MKE_E_NULL; }
+  if (p.total == 0) return MKE_OK;
+  p.flags = flags; p.counts = counts; p.req = req; p.id_map = id_map; p.overflow = overflow; p.G = n_ranks; p.C = capacity;
+  // few, fat blocks: one global atomic per (block iteration, owner) on n_ranks counters
+  hipLaunchKernelGGL(k_rowset_build, dim3(blocks_for(p.total, MKE_BLOCK * 4) > 512 ? 512 : blocks_for(p.total, MKE_BLOCK * 4)),
+                     dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  return check_launch("k_rowset_build");
+}
+
+extern "C" int mke_rowset_remap(const int32_t* ids, int64_t n, const int32_t* id_map, int32_t* out, int32_t* flags,
+                                void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!ids || !id_map || !out || !flags) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
+  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(n, MKE_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, ids, n, id_map,
+                     out, flags);
+  return check_launch("k_rowset_remap");
+}
+
+extern "C" int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out, void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!table || !idx || !out) { set_error("mke_rows_gather_padded: NULL pointer"); return MKE_E_NULL; }
+  if (stride <= 0 || stride % 16 != 0 || stride > MKE_MAX_STRIDE) { set_error("bad stride %d", stride); return MKE_E_SHAPE; }
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_rows_gather_padded<FPL>), dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0,
+                       (hipStream_t)stream, table, stride, idx, n, out);
+  });
+  return check_launch("k_rows_gather_padded");
+}
+
+extern "C" int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int stride, int dim, float* grad,
+                                    int32_t* touched, int32_t tag, void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!idx || !rows || !grad || !touched) { set_error("mke_rows_scatter_add: NULL pointer"); return MKE_E_NULL; }
+  if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim"); return MKE_E_SHAPE; }
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_rows_scatter_add<FPL>), dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0,
+                       (hipStream_t)stream, idx, rows, n, stride, dim, grad, touched, tag);
+  });
+  return check_launch("k_rows_scatter_add");
+}

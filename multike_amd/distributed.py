@@ -6,11 +6,14 @@ The reference has no multi-device code; this is new design.  On
   * a global step is `world` x batch_size positives in the reference's epoch order; rank r scores the r-th
     contiguous slice with its own negatives (the Philox stream is indexed by the GLOBAL epoch position, so the
     negatives of a positive do not depend on the world size);
-  * exchange per step:  all-to-all(v) of the needed remote row ids  ->  all-to-all(v) of the raw rows  ->  local fused
-    triple step on the compact [U, stride] row set  ->  all-to-all(v) of the gradient rows back to their owners
-    (already pre-reduced per sender by the scatter kernel), owner adds them and runs the row update ONCE per row
-    per step (dense-Adagrad-equivalent, SURVEY.md §8e "semantics note");  all-reduce of the replicated relation
-    gradient, then every rank applies the identical relation update.
+  * exchange per step, all FIXED-CAPACITY ([world][C] slots per rank, C sized from the batch) so that every
+    collective is an equal-split all-to-all and nothing on the host ever waits for the device:
+      row-set build (HIP: distinct ids grouped by owner)  ->  all-to-all of the requested local rows (ids)
+      ->  owner gathers raw rows  ->  all-to-all of the rows  ->  local fused triple step on the compact
+      [world*C, stride] row set  ->  all-to-all of the gradient rows back (pre-reduced per sender by the scatter
+      kernel)  ->  owner scatter-adds them and runs the row update ONCE per row per step (dense-Adagrad-equivalent,
+      SURVEY.md §8e "semantics note")  ->  all-reduce of the replicated relation gradient, identical relation
+      update on every rank.
 xGMI is point-to-point, so the row exchange is an all-to-all (every link busy), not a ring.
 
 The compute steps go through a small backend object: `HipBackend` (the product, HIP kernels) — tests inject a
@@ -30,7 +33,7 @@ from .tables import ADAGRAD_INIT_ACC
 
 
 class HipBackend:
-    """Product backend: every compute step is a HIP kernel of libmultike_hip.so."""
+    """Product backend: every compute / bookkeeping step is a HIP kernel of libmultike_hip.so."""
 
     device_type = "cuda"
 
@@ -39,6 +42,18 @@ class HipBackend:
 
     def sample(self, pos, pos_offset, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
         _lib.neg_sample(pos, pos_offset, pos_kg, side_array(side1, side2), neg_per_pos, 10, seed, stream_id, out)
+
+    def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
+        _lib.rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity)
+
+    def rowset_remap(self, ids, id_map, out, flags):
+        _lib.rowset_remap(ids, id_map, out, flags)
+
+    def gather_padded(self, table, idx, out):
+        _lib.rows_gather_padded(table, idx, out)
+
+    def scatter_add(self, idx, rows, dim, grad, touched, tag):
+        _lib.rows_scatter_add(idx, rows, dim, grad, touched, tag)
 
     def score(self, ent, ent_norm, rel, rel_norm, dim, pos, neg, neg_per_pos, grad_ent, grad_rel, touched_ent,
               touched_rel, tag, loss_partials):
@@ -86,7 +101,26 @@ class ShardedRelationTrainer:
         self.tag = 0
         self.loss_partials = torch.zeros(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
         self.loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        self._id_map = torch.zeros(self.n_ent, dtype=torch.int32, device=dev)  # global id -> compact row (scratch)
+        # --- fixed-capacity exchange buffers ---------------------------------------------------------
+        G = world
+        max_pos = int(math.ceil(batch_size * world / world))                     # positives of one rank per step
+        bound = max_pos * (2 + neg_per_pos)                                      # distinct rows a rank can need
+        max_local = int(math.ceil(self.n_ent / G))
+        self.C = C = int(min(max_local, math.ceil(bound / G * 1.25) + 256))
+        i32 = dict(dtype=torch.int32, device=dev)
+        self._flags = torch.zeros(self.n_ent, **i32)
+        self._id_map = torch.zeros(self.n_ent, **i32)                            # global id -> compact row
+        self._counts = torch.zeros(G, **i32)
+        self._overflow = torch.zeros(1, **i32)
+        self._req = torch.empty(G * C, **i32)
+        self._want = torch.empty(G * C, **i32)
+        self._rows_out = torch.empty(G * C, st, dtype=dtype, device=dev)
+        self._rows_in = torch.empty(G * C, st, dtype=dtype, device=dev)
+        self._cgrad = torch.zeros(G * C, st, dtype=dtype, device=dev)
+        self._ggot = torch.empty(G * C, st, dtype=dtype, device=dev)
+        self._ctouched = torch.zeros(G * C, **i32)
+        self._cidx = [torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)]
+        self._neg = tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3))
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -101,58 +135,50 @@ class ShardedRelationTrainer:
         s = i % self.steps
         return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
 
-    def _all_to_all(self, send: torch.Tensor, send_counts, recv_counts):
-        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
-                               input_split_sizes=list(send_counts))
-        return out
-
     def step(self, i: int):
         s = i % self.steps
         if s == 0 and i > 0:
             self.bat.shuffle()
-        b, N, G, dev = self.bat, self.N, self.world, self.device
+        b, N, G, C, be = self.bat, self.N, self.world, self.C, self.backend
         a, e = self.my_slice(s)
-        pos = (b.pos_h[a:e], b.pos_r[a:e], b.pos_t[a:e])
         n_pos = e - a
-        neg = tuple(torch.empty(n_pos * N, dtype=torch.int32, device=dev) for _ in range(3))
+        pos = (b.pos_h[a:e], b.pos_r[a:e], b.pos_t[a:e])
+        neg = tuple(x[:n_pos * N] for x in self._neg)
         if n_pos and N:
-            self.backend.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
-        # ---- which entity rows does this rank need, and who owns them -------------------------------
-        ids = torch.cat([pos[0], pos[2], neg[0], neg[2]]).long()
-        uniq = torch.unique(ids)                                   # sorted global ids
-        owner = uniq % G
-        order = torch.argsort(owner, stable=True)                  # compact order = grouped by owner
-        req = uniq[order]
-        send_counts = torch.bincount(owner, minlength=G)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()         # host sync: sizes of the variable exchanges
-        U = int(req.numel())
-        self._id_map[req] = torch.arange(U, dtype=torch.int32, device=dev)
-        # ---- ids out, raw rows back -------------------------------------------------------------------
-        want = self._all_to_all((req // G).to(torch.int32), sc, rc).long()   # local rows other ranks ask of me
-        rows = self._all_to_all(self.ent.index_select(0, want), rc, sc)       # [U, stride] in compact order
-        # ---- local fused step on the compact row set ---------------------------------------------------
-        cpos = (self._id_map[pos[0].long()], pos[1], self._id_map[pos[2].long()])
-        cneg = (self._id_map[neg[0].long()], neg[1], self._id_map[neg[2].long()])
-        cgrad = torch.zeros_like(rows)
-        ctouched = torch.zeros(max(U, 1), dtype=torch.int32, device=dev)
+            be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
+        # ---- distinct entity rows this rank needs, grouped by owner in [G][C] slots (device only) ---------------
+        self._req.fill_(-1)
+        self._counts.zero_()
+        streams = [pos[0], pos[2], neg[0], neg[2]]
+        be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
+        # ---- requested local rows out, raw rows back (equal-split all-to-alls) -----------------------------------
+        dist.all_to_all_single(self._want, self._req)
+        be.gather_padded(self.ent, self._want, self._rows_out)
+        dist.all_to_all_single(self._rows_in, self._rows_out)
+        # ---- local fused step on the compact row set ------------------------------------------------------------
+        cidx = [self._cidx[k][:streams[k].numel()] for k in range(4)]
+        for k in range(4):
+            be.rowset_remap(streams[k], self._id_map, cidx[k], self._flags)
+        self._cgrad.zero_()
         self.tag += 1
         tag = self.tag
-        self.backend.score(rows, True, self.rel, True, self.dim, cpos, cneg, N, cgrad, self.rel_grad, ctouched,
-                           self.rel_touched, tag, self.loss_partials)
+        be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos[1], cidx[1]), (cidx[2], neg[1], cidx[3]), N,
+                 self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_partials)
         self.loss_sum += self.loss_partials.sum()
-        # ---- gradient rows back to their owners; owner reduces and updates once per row ----------------
-        got = self._all_to_all(cgrad, sc, rc)
-        self.ent_grad.index_add_(0, want, got)
-        self.ent_touched[want] = tag
-        self.backend.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
-        # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere
+        # ---- gradient rows home; the owner reduces and updates each row once -------------------------------------
+        dist.all_to_all_single(self._ggot, self._cgrad)
+        be.scatter_add(self._want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
+        be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
+        # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere -------
         dist.all_reduce(self.rel_grad)
         self.rel_touched.fill_(tag)
-        self.backend.update(self.rel, self.rel_acc, self.rel_grad, self.rel_touched, tag, self.dim, True, self.lr)
-        self.last_stats = {"unique_rows": U, "remote_rows": U - sc[self.rank], "positives": n_pos}
+        be.update(self.rel, self.rel_acc, self.rel_grad, self.rel_touched, tag, self.dim, True, self.lr)
+
+    def stats(self) -> dict:
+        """Synchronising debug view of the last step's row set."""
+        c = self._counts.tolist()
+        return {"unique_rows": int(sum(c)), "remote_rows": int(sum(c) - c[self.rank]), "capacity": self.C,
+                "overflow": int(self._overflow.item())}
 
     # ------------------------------------------------------------------------------------------------
     def gather_entity_table(self) -> torch.Tensor:
@@ -169,6 +195,8 @@ class ShardedRelationTrainer:
         return full
 
     def epoch_loss(self) -> float:
+        if int(self._overflow.item()):
+            raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded: results of this epoch are invalid")
         t = self.loss_sum.clone()
         dist.all_reduce(t)
         self.loss_sum.zero_()

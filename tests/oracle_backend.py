@@ -26,6 +26,40 @@ class OracleBackend:
                 for o, v in zip(out, (nh, nr, nt)):
                     o.numpy()[a * neg_per_pos:b * neg_per_pos] = v
 
+    # ---- bookkeeping ops (numpy restatements of mke_rowset_build / _remap / mke_rows_gather_padded / _scatter_add) ----
+    def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
+        ids = np.concatenate([x.numpy() for x in streams])
+        f, cnt, rq, im = flags.numpy(), counts.numpy(), req.numpy(), id_map.numpy()
+        for i in ids:
+            if f[i]:
+                continue
+            f[i] = 1
+            o = int(i) % n_ranks
+            if cnt[o] < capacity:
+                rq[o * capacity + cnt[o]] = int(i) // n_ranks
+                im[i] = o * capacity + cnt[o]
+            else:
+                overflow.numpy()[0] = 1
+                im[i] = o * capacity
+            cnt[o] += 1
+
+    def rowset_remap(self, ids, id_map, out, flags):
+        i = ids.numpy()
+        out.numpy()[:] = id_map.numpy()[i]
+        flags.numpy()[i] = 0
+
+    def gather_padded(self, table, idx, out):
+        i = idx.numpy()
+        o = out.numpy()
+        o[:] = 0
+        o[i >= 0] = table.numpy()[i[i >= 0]]
+
+    def scatter_add(self, idx, rows, dim, grad, touched, tag):
+        i = idx.numpy()
+        m = i >= 0
+        np.add.at(grad.numpy(), i[m], rows.numpy()[m])
+        touched.numpy()[i[m]] = tag
+
     def score(self, ent, ent_norm, rel, rel_norm, dim, pos, neg, neg_per_pos, grad_ent, grad_rel, touched_ent, touched_rel,
               tag, loss_partials):
         p = tuple(x.numpy() for x in pos)
