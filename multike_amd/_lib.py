@@ -265,22 +265,27 @@ def rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacit
     _check(rc, "mke_rowset_build")
 
 
-def rowset_remap(ids, id_map, out, flags):
-    rc = lib().mke_rowset_remap(_dev(ids, torch.int32, "ids"), C.c_int64(ids.numel()), _dev(id_map, torch.int32, "id_map"),
-                                _dev(out, torch.int32, "out"), _dev(flags, torch.int32, "flags"), _stream())
+def rowset_remap(streams, outs, id_map, flags):
+    args = []
+    for k in range(4):
+        t = streams[k] if k < len(streams) else None
+        o = outs[k] if k < len(outs) else None
+        args += [_dev(t, torch.int32, f"ids{k}"), _dev(o, torch.int32, f"out{k}"), C.c_int64(0 if t is None else t.numel())]
+    rc = lib().mke_rowset_remap(*args, _dev(id_map, torch.int32, "id_map"), _dev(flags, torch.int32, "flags"), _stream())
     _check(rc, "mke_rowset_remap")
 
 
-def rows_gather_padded(table, idx, out):
+def rows_gather_padded(table, idx, out, zero_rows=None):
     rc = lib().mke_rows_gather_padded(_dev(table, torch.float32, "table"), C.c_int(table.shape[1]),
                                       _dev(idx, torch.int32, "idx"), C.c_int64(idx.numel()),
-                                      _dev(out, torch.float32, "out"), _stream())
+                                      _dev(out, torch.float32, "out"), _dev(zero_rows, torch.float32, "zero_rows"), _stream())
     _check(rc, "mke_rows_gather_padded")
 
 
-def rows_scatter_add(idx, rows, dim, grad, touched, tag):
+def rows_scatter_add(idx, rows, dim, grad, touched, tag, reset_req=None, reset_counts=None):
     rc = lib().mke_rows_scatter_add(_dev(idx, torch.int32, "idx"), _dev(rows, torch.float32, "rows"),
                                     C.c_int64(idx.numel()), C.c_int(grad.shape[1]), C.c_int(dim),
                                     _dev(grad, torch.float32, "grad"), _dev(touched, torch.int32, "touched"), C.c_int32(tag),
-                                    _stream())
+                                    _dev(reset_req, torch.int32, "reset_req"), _dev(reset_counts, torch.int32, "reset_counts"),
+                                    C.c_int(0 if reset_counts is None else reset_counts.numel()), _stream())
     _check(rc, "mke_rows_scatter_add")

@@ -67,20 +67,32 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_build(const RowsetParams p
   }
 }
 
-__global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const int32_t* __restrict__ ids, int64_t n,
-                                                            const int32_t* __restrict__ id_map, int32_t* __restrict__ out,
-                                                            int32_t* __restrict__ flags) {
-  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    const int id = ids[i];
-    out[i] = id_map[id];
-    flags[id] = 0;
+struct RemapParams {
+  const int32_t* ids[4];
+  int32_t* out[4];
+  int64_t len[4];
+  int64_t total;
+  const int32_t* id_map;
+  int32_t* flags;
+};
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p) {
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.total; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    int64_t k = i;
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (s == q && k >= p.len[q]) { k -= p.len[q]; s = q + 1; }
+    const int id = p.ids[s][k];
+    p.out[s][k] = p.id_map[id];
+    p.flags[id] = 0;
   }
 }
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_gather_padded(const float* __restrict__ table, int stride,
                                                                   const int32_t* __restrict__ idx, int64_t n,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, float* __restrict__ zero_rows) {
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
@@ -96,18 +108,27 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_gather_padded(const float* _
     float* o = out + i * (int64_t)stride + j;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) o[k * 16] = v[k];
+    if (zero_rows) {
+      float* z = zero_rows + i * (int64_t)stride + j;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) z[k * 16] = 0.f;
+    }
   }
 }
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_scatter_add(const int32_t* __restrict__ idx, const float* __restrict__ rows,
                                                                 int64_t n, int stride, int dim, float* __restrict__ grad,
-                                                                int32_t* __restrict__ touched, int32_t tag) {
+                                                                int32_t* __restrict__ touched, int32_t tag,
+                                                                int32_t* __restrict__ reset_req, int32_t* __restrict__ reset_counts,
+                                                                int n_counts) {
+  if (reset_counts && blockIdx.x == 0 && threadIdx.x < n_counts) reset_counts[threadIdx.x] = 0;
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
   for (int64_t i = sub0; i < n; i += nsub) {
     const int row = idx[i];
+    if (reset_req && j == 0) reset_req[i] = -1;
     if (row < 0) continue;
     float v[FPL];
     load_row<FPL>(rows, i, stride, j, v);
@@ -146,18 +167,29 @@ extern "C" int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* 
   return check_launch("k_rowset_build");
 }
 
-extern "C" int mke_rowset_remap(const int32_t* ids, int64_t n, const int32_t* id_map, int32_t* out, int32_t* flags,
-                                void* stream) {
+extern "C" int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, const int32_t* ids1, int32_t* out1, int64_t n1,
+                                const int32_t* ids2, int32_t* out2, int64_t n2, const int32_t* ids3, int32_t* out3, int64_t n3,
+                                const int32_t* id_map, int32_t* flags, void* stream) {
   using namespace mke;
-  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
-  if (n == 0) return MKE_OK;
-  if (!ids || !id_map || !out || !flags) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
-  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(n, MKE_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, ids, n, id_map,
-                     out, flags);
+  RemapParams p;
+  p.ids[0] = ids0; p.ids[1] = ids1; p.ids[2] = ids2; p.ids[3] = ids3;
+  p.out[0] = out0; p.out[1] = out1; p.out[2] = out2; p.out[3] = out3;
+  p.len[0] = n0; p.len[1] = n1; p.len[2] = n2; p.len[3] = n3;
+  p.total = 0;
+  for (int s = 0; s < 4; ++s) {
+    if (p.len[s] < 0) { set_error("negative length"); return MKE_E_SHAPE; }
+    if (p.len[s] > 0 && (!p.ids[s] || !p.out[s])) { set_error("NULL stream %d", s); return MKE_E_NULL; }
+    p.total += p.len[s];
+  }
+  if (p.total == 0) return MKE_OK;
+  if (!id_map || !flags) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
+  p.id_map = id_map; p.flags = flags;
+  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(p.total, MKE_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   return check_launch("k_rowset_remap");
 }
 
-extern "C" int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out, void* stream) {
+extern "C" int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out,
+                                      float* zero_rows, void* stream) {
   using namespace mke;
   if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
   if (n == 0) return MKE_OK;
@@ -166,22 +198,24 @@ extern "C" int mke_rows_gather_padded(const float* table, int stride, const int3
   const int fpl = stride / 16;
   MKE_DISPATCH_FPL(fpl, {
     hipLaunchKernelGGL((k_rows_gather_padded<FPL>), dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0,
-                       (hipStream_t)stream, table, stride, idx, n, out);
+                       (hipStream_t)stream, table, stride, idx, n, out, zero_rows);
   });
   return check_launch("k_rows_gather_padded");
 }
 
 extern "C" int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int stride, int dim, float* grad,
-                                    int32_t* touched, int32_t tag, void* stream) {
+                                    int32_t* touched, int32_t tag, int32_t* reset_req, int32_t* reset_counts, int n_counts,
+                                    void* stream) {
   using namespace mke;
   if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
   if (n == 0) return MKE_OK;
   if (!idx || !rows || !grad || !touched) { set_error("mke_rows_scatter_add: NULL pointer"); return MKE_E_NULL; }
+  if (reset_counts && (n_counts < 0 || n_counts > MKE_MAX_RANKS)) { set_error("bad n_counts"); return MKE_E_SHAPE; }
   if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim"); return MKE_E_SHAPE; }
   const int fpl = stride / 16;
   MKE_DISPATCH_FPL(fpl, {
     hipLaunchKernelGGL((k_rows_scatter_add<FPL>), dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0,
-                       (hipStream_t)stream, idx, rows, n, stride, dim, grad, touched, tag);
+                       (hipStream_t)stream, idx, rows, n, stride, dim, grad, touched, tag, reset_req, reset_counts, n_counts);
   });
   return check_launch("k_rows_scatter_add");
 }

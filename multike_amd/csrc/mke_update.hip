@@ -90,7 +90,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update(const UpdateParams p)
   const int64_t base = sub * 16;
   if (base >= p.n_rows) return;
   const int64_t r = base + j;
-  const bool mine = (r < p.n_rows) && (p.touched[r] == p.tag);
+  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
   // 64-bit wave ballot -> this quarter's 16 bits
   const uint64_t ball = __ballot(mine);
   const int q = (threadIdx.x & 63) >> 4;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   const int64_t base = sub * 16;
   if (base >= p.n_rows) return;
   const int64_t r = base + j;
-  const bool mine = (r < p.n_rows) && (p.touched[r] == p.tag);
+  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
   const uint64_t ball = __ballot(mine);
   const int q = (threadIdx.x & 63) >> 4;
   uint32_t m = (uint32_t)((ball >> (q * 16)) & 0xFFFFu);
@@ -162,7 +162,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
                                int64_t n_rows, int stride, int dim, int normalize, int optimizer, float lr,
                                void* stream) {
   using namespace mke;
-  if (!table || !grad || !touched) { set_error("mke_rows_update: NULL table/grad/touched"); return MKE_E_NULL; }
+  if (!table || !grad) { set_error("mke_rows_update: NULL table/grad"); return MKE_E_NULL; }
   if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
   if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
   if (n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }

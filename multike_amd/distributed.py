@@ -46,14 +46,14 @@ class HipBackend:
     def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
         _lib.rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity)
 
-    def rowset_remap(self, ids, id_map, out, flags):
-        _lib.rowset_remap(ids, id_map, out, flags)
+    def rowset_remap(self, streams, outs, id_map, flags):
+        _lib.rowset_remap(streams, outs, id_map, flags)
 
-    def gather_padded(self, table, idx, out):
-        _lib.rows_gather_padded(table, idx, out)
+    def gather_padded(self, table, idx, out, zero_rows=None):
+        _lib.rows_gather_padded(table, idx, out, zero_rows)
 
-    def scatter_add(self, idx, rows, dim, grad, touched, tag):
-        _lib.rows_scatter_add(idx, rows, dim, grad, touched, tag)
+    def scatter_add(self, idx, rows, dim, grad, touched, tag, reset_req=None, reset_counts=None):
+        _lib.rows_scatter_add(idx, rows, dim, grad, touched, tag, reset_req, reset_counts)
 
     def score(self, ent, ent_norm, rel, rel_norm, dim, pos, neg, neg_per_pos, grad_ent, grad_rel, touched_ent,
               touched_rel, tag, loss_partials):
@@ -99,8 +99,7 @@ class ShardedRelationTrainer:
                                    device=dev, seed=seed)
         self.steps = self.bat.steps
         self.tag = 0
-        self.loss_partials = torch.zeros(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
-        self.loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.loss_ring = torch.zeros(max(1, self.steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
         # --- fixed-capacity exchange buffers ---------------------------------------------------------
         G = world
         max_pos = int(math.ceil(batch_size * world / world))                     # positives of one rank per step
@@ -111,8 +110,10 @@ class ShardedRelationTrainer:
         self._flags = torch.zeros(self.n_ent, **i32)
         self._id_map = torch.zeros(self.n_ent, **i32)                            # global id -> compact row
         self._counts = torch.zeros(G, **i32)
+        self._counts_last = torch.zeros(G, **i32)
+        self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
         self._overflow = torch.zeros(1, **i32)
-        self._req = torch.empty(G * C, **i32)
+        self._req = torch.full((G * C,), -1, **i32)                              # re-initialised by scatter_add each step
         self._want = torch.empty(G * C, **i32)
         self._rows_out = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._rows_in = torch.empty(G * C, st, dtype=dtype, device=dev)
@@ -147,36 +148,35 @@ class ShardedRelationTrainer:
         if n_pos and N:
             be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
         # ---- distinct entity rows this rank needs, grouped by owner in [G][C] slots (device only) ---------------
-        self._req.fill_(-1)
-        self._counts.zero_()
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
         # ---- requested local rows out, raw rows back (equal-split all-to-alls) -----------------------------------
         dist.all_to_all_single(self._want, self._req)
-        be.gather_padded(self.ent, self._want, self._rows_out)
+        be.gather_padded(self.ent, self._want, self._rows_out, self._cgrad)      # also clears the compact grad scratch
         dist.all_to_all_single(self._rows_in, self._rows_out)
         # ---- local fused step on the compact row set ------------------------------------------------------------
         cidx = [self._cidx[k][:streams[k].numel()] for k in range(4)]
-        for k in range(4):
-            be.rowset_remap(streams[k], self._id_map, cidx[k], self._flags)
-        self._cgrad.zero_()
+        be.rowset_remap(streams, cidx, self._id_map, self._flags)
         self.tag += 1
         tag = self.tag
         be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos[1], cidx[1]), (cidx[2], neg[1], cidx[3]), N,
-                 self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_partials)
-        self.loss_sum += self.loss_partials.sum()
+                 self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
         # ---- gradient rows home; the owner reduces and updates each row once -------------------------------------
         dist.all_to_all_single(self._ggot, self._cgrad)
-        be.scatter_add(self._want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
+        be.scatter_add(self._want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag, self._req, self._counts_prev())
         be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
         # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere -------
         dist.all_reduce(self.rel_grad)
-        self.rel_touched.fill_(tag)
-        be.update(self.rel, self.rel_acc, self.rel_grad, self.rel_touched, tag, self.dim, True, self.lr)
+        be.update(self.rel, self.rel_acc, self.rel_grad, None, tag, self.dim, True, self.lr)     # touched=None: all rows
+
+    def _counts_prev(self):
+        """counts are double-buffered so that `stats()` can read the last step's numbers after they were reset."""
+        self._counts_last.copy_(self._counts) if self.keep_stats else None
+        return self._counts
 
     def stats(self) -> dict:
         """Synchronising debug view of the last step's row set."""
-        c = self._counts.tolist()
+        c = self._counts_last.tolist()
         return {"unique_rows": int(sum(c)), "remote_rows": int(sum(c) - c[self.rank]), "capacity": self.C,
                 "overflow": int(self._overflow.item())}
 
@@ -197,7 +197,7 @@ class ShardedRelationTrainer:
     def epoch_loss(self) -> float:
         if int(self._overflow.item()):
             raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded: results of this epoch are invalid")
-        t = self.loss_sum.clone()
+        t = self.loss_ring.sum()
         dist.all_reduce(t)
-        self.loss_sum.zero_()
+        self.loss_ring.zero_()
         return float(t)

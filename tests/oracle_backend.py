@@ -43,22 +43,29 @@ class OracleBackend:
                 im[i] = o * capacity
             cnt[o] += 1
 
-    def rowset_remap(self, ids, id_map, out, flags):
-        i = ids.numpy()
-        out.numpy()[:] = id_map.numpy()[i]
-        flags.numpy()[i] = 0
+    def rowset_remap(self, streams, outs, id_map, flags):
+        for ids, out in zip(streams, outs):
+            i = ids.numpy()
+            out.numpy()[:] = id_map.numpy()[i]
+            flags.numpy()[i] = 0
 
-    def gather_padded(self, table, idx, out):
+    def gather_padded(self, table, idx, out, zero_rows=None):
         i = idx.numpy()
         o = out.numpy()
         o[:] = 0
         o[i >= 0] = table.numpy()[i[i >= 0]]
+        if zero_rows is not None:
+            zero_rows.numpy()[:] = 0
 
-    def scatter_add(self, idx, rows, dim, grad, touched, tag):
+    def scatter_add(self, idx, rows, dim, grad, touched, tag, reset_req=None, reset_counts=None):
         i = idx.numpy()
         m = i >= 0
         np.add.at(grad.numpy(), i[m], rows.numpy()[m])
         touched.numpy()[i[m]] = tag
+        if reset_req is not None:
+            reset_req.numpy()[:] = -1
+        if reset_counts is not None:
+            reset_counts.numpy()[:] = 0
 
     def score(self, ent, ent_norm, rel, rel_norm, dim, pos, neg, neg_per_pos, grad_ent, grad_rel, touched_ent, touched_rel,
               tag, loss_partials):
@@ -78,8 +85,8 @@ class OracleBackend:
         lp[0] = L
 
     def update(self, table, acc, grad, touched, tag, dim, normalize, lr):
-        rows = np.nonzero(touched.numpy() == tag)[0]
         w, a, g = table.numpy(), acc.numpy(), grad.numpy()
+        rows = np.arange(len(w)) if touched is None else np.nonzero(touched.numpy() == tag)[0]
         gg = mo.l2_normalize_rows_backward(w[rows], g[rows]) if normalize else g[rows]
         a[rows] += gg * gg
         w[rows] -= lr * gg / np.sqrt(a[rows])

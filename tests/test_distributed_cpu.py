@@ -40,6 +40,7 @@ def _worker(rank, world, port, ret):
         tr = ShardedRelationTrainer(kgs, ent0, rel0, B, NEG, rank, world, seed=SEED, lr=0.05, backend=OracleBackend(),
                                     device="cpu", dtype=torch.float64)
         stats = []
+        tr.keep_stats = True
         for i in range(STEPS):
             tr.step(i)
             stats.append(tr.stats())

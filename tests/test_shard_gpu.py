@@ -32,9 +32,9 @@ def test_rowset_build_remap_gather_scatter(G, n_ent, lens):
     slots = im[uniq]
     assert np.array_equal(rq.reshape(-1)[slots].astype(np.int64) * G + slots // C, uniq)
     # remap + flags cleared
-    for x_np, x in zip(streams_np, streams):
-        out = torch.empty_like(x)
-        _lib.rowset_remap(x, id_map, out, flags)
+    outs = [torch.empty_like(x) for x in streams]
+    _lib.rowset_remap(streams, outs, id_map, flags)
+    for x_np, out in zip(streams_np, outs):
         assert np.array_equal(out.cpu().numpy(), im[x_np])
     assert int(flags.abs().sum()) == 0
     # owner side: gather padded rows / scatter-add them back
@@ -43,15 +43,19 @@ def test_rowset_build_remap_gather_scatter(G, n_ent, lens):
     table[:, dim:] = 0
     want = req  # with G ranks each owner would receive its own column; here rank 0 plays every owner
     rows = torch.empty(G * C, stride, device="cuda")
-    _lib.rows_gather_padded(table, want, rows)
+    scratch = torch.ones(G * C, stride, device="cuda")
+    _lib.rows_gather_padded(table, want, rows, scratch)
+    assert float(scratch.abs().max()) == 0.0
     w = want.cpu().numpy()
     exp = np.zeros((G * C, stride), np.float32)
     exp[w >= 0] = table.cpu().numpy()[w[w >= 0]]
     assert np.array_equal(rows.cpu().numpy(), exp)
     grad = torch.zeros_like(table)
     touched = torch.zeros(table.shape[0], **i32)
-    _lib.rows_scatter_add(want, rows, dim, grad, touched, 7)
-    ge = np.zeros_like(exp[:table.shape[0]])
+    want_before = want.clone()
+    _lib.rows_scatter_add(want_before, rows, dim, grad, touched, 7, req, counts)
+    assert int((req != -1).sum()) == 0 and int(counts.abs().sum()) == 0      # re-initialised for the next step
+    ge = np.zeros((table.shape[0], stride), np.float32)
     np.add.at(ge, w[w >= 0], exp[w >= 0])
     np.testing.assert_allclose(grad.cpu().numpy(), ge, rtol=1e-6, atol=1e-6)
     tt = np.zeros(table.shape[0], np.int32)
