@@ -1,0 +1,88 @@
+"""base/batch.py surface of the reference (code/base/batch.py) over Python lists, backed by the device sampler.
+
+These functions keep the reference's names and argument orders so that code written against `bat.*` runs
+unchanged; each call converts its list arguments to device tensors (cached per list object), runs
+`mke_neg_sample` and converts back.  The training loops in `MultiKE_model.py` do NOT go through this list
+interface (it would put Python back on the critical path) — they use `sampling.RelationBatcher` directly.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..sampling import KGSide, KnownTripleSet, kg_batch_split, sample_negatives
+
+_cache: dict = {}
+_call_counter = [0]
+
+
+def _known(triples_set, device):
+    key = ("known", id(triples_set), len(triples_set))
+    if key not in _cache:
+        arr = np.asarray(sorted(triples_set), dtype=np.int32).reshape(-1, 3)
+        t = torch.as_tensor(arr, device=device)
+        _cache[key] = KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
+    return _cache[key]
+
+
+def _side(entities_list, triples_set, neighbor, device):
+    key = ("side", id(entities_list), len(entities_list), id(triples_set), id(neighbor))
+    if key not in _cache:
+        side = KGSide(entities_list, _known(triples_set, device) if triples_set is not None else None, device=device)
+        if neighbor:
+            n_total = max(max(entities_list), max(neighbor)) + 1
+            k = min(len(v) for v in neighbor.values())
+            table = np.zeros((n_total, k), dtype=np.int32)
+            valid = np.zeros(n_total, dtype=np.uint8)
+            for e, lst in neighbor.items():
+                table[e] = np.asarray(lst[:k], dtype=np.int32)
+                valid[e] = 1
+            side.set_neighbours(torch.as_tensor(table, device=device), torch.as_tensor(valid, device=device))
+        _cache[key] = side
+    return _cache[key]
+
+
+def generate_pos_triples(triples, batch_size, step, is_fixed_size=False):
+    """code/base/batch.py:45-54."""
+    lo = step * batch_size
+    chunk = triples[lo:min(lo + batch_size, len(triples))]
+    if is_fixed_size and len(chunk) < batch_size:
+        chunk = chunk + triples[:batch_size - len(chunk)]
+    return chunk
+
+
+def generate_neg_triples_fast(pos_batch, all_triples_set, entities_list, neg_triples_num, neighbor=None, max_try=10,
+                              seed=None, device="cuda"):
+    """code/base/batch.py:86-116 on the device: same distribution, Philox stream (`seed` defaults to a per-call
+    counter, as the reference draws from an unseeded global RNG)."""
+    if len(pos_batch) == 0 or neg_triples_num == 0:
+        return []
+    side = _side(entities_list, all_triples_set, neighbor, device)
+    arr = torch.as_tensor(np.asarray(pos_batch, dtype=np.int32).reshape(-1, 3), device=device)
+    pos = (arr[:, 0].contiguous(), arr[:, 1].contiguous(), arr[:, 2].contiguous())
+    if seed is None:
+        _call_counter[0] += 1
+        seed = (0x5EED, _call_counter[0])
+    nh, nr, nt = sample_negatives(pos, side, neg_triples_num, seed=seed, max_try=max_try)
+    out = torch.stack([nh, nr, nt], 1).cpu().numpy()
+    return [tuple(int(v) for v in row) for row in out]
+
+
+def generate_relation_triple_batch(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1, entity_list2,
+                                   batch_size, step, neighbor1, neighbor2, neg_triples_num):
+    """code/base/batch.py:33-42."""
+    b1, b2 = kg_batch_split(len(triple_list1), len(triple_list2), batch_size)
+    pos1 = generate_pos_triples(triple_list1, b1, step)
+    pos2 = generate_pos_triples(triple_list2, b2, step)
+    neg1 = generate_neg_triples_fast(pos1, triple_set1, entity_list1, neg_triples_num, neighbor=neighbor1)
+    neg2 = generate_neg_triples_fast(pos2, triple_set2, entity_list2, neg_triples_num, neighbor=neighbor2)
+    return pos1 + pos2, neg1 + neg2
+
+
+def generate_relation_triple_batch_queue(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1, entity_list2,
+                                         batch_size, steps, out_queue, neighbor1, neighbor2, neg_triples_num):
+    """code/base/batch.py:22-30 (without the producer process's exit(0): there is no forked producer here)."""
+    for step in steps:
+        out_queue.put(generate_relation_triple_batch(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1,
+                                                     entity_list2, batch_size, step, neighbor1, neighbor2,
+                                                     neg_triples_num))

@@ -105,7 +105,9 @@ class ShardedRelationTrainer:
         max_pos = int(math.ceil(batch_size * world / world))                     # positives of one rank per step
         bound = max_pos * (2 + neg_per_pos)                                      # distinct rows a rank can need
         max_local = int(math.ceil(self.n_ent / G))
-        self.C = C = int(min(max_local, math.ceil(bound / G * 1.25) + 256))
+        C = int(min(max_local, math.ceil(bound / G * 1.25) + 256))              # worst case: every referenced row distinct
+        C = self._calibrate_capacity(C, max_local)
+        self.C = C
         i32 = dict(dtype=torch.int32, device=dev)
         self._flags = torch.zeros(self.n_ent, **i32)
         self._id_map = torch.zeros(self.n_ent, **i32)                            # global id -> compact row
@@ -123,6 +125,36 @@ class ShardedRelationTrainer:
         self._cidx = [torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)]
         self._neg = tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3))
         self.last_stats = {}
+
+    def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
+        """Fixed-capacity buffers are what every rank moves per step, so size them from the data instead of the
+        all-distinct worst case: build the row set of the first few steps (setup time, synchronising), take the
+        largest per-owner count over all ranks, add slack.  An overflow later is detected on device and raised."""
+        G, dev, be = self.world, self.device, self.backend
+        i32 = dict(dtype=torch.int32, device=dev)
+        flags, id_map = torch.zeros(self.n_ent, **i32), torch.zeros(self.n_ent, **i32)
+        worst = 0
+        for s in range(min(probe_steps, self.steps)):
+            a, e = self.my_slice(s)
+            n_pos = e - a
+            if n_pos == 0:
+                continue
+            b = self.bat
+            pos = (b.pos_h[a:e], b.pos_r[a:e], b.pos_t[a:e])
+            neg = tuple(torch.empty(n_pos * self.N, **i32) for _ in range(3))
+            if self.N:
+                be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, self.N, b.rng_seed, b.rng_stream, neg)
+            counts, overflow = torch.zeros(G, **i32), torch.zeros(1, **i32)
+            req = torch.full((G * c_bound,), -1, **i32)
+            streams = [pos[0], pos[2], neg[0], neg[2]]
+            be.rowset_build(streams, flags, counts, req, id_map, overflow, G, c_bound)
+            be.rowset_remap(streams, [torch.empty_like(x) for x in streams], id_map, flags)
+            worst = max(worst, int(counts.max()))
+        t = torch.tensor([worst], dtype=torch.int64, device=dev)
+        if dist.is_initialized() and G > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst = int(t)
+        return int(min(max_local, c_bound, math.ceil(worst * slack) + 64)) if worst else c_bound
 
     # ------------------------------------------------------------------------------------------------
     def my_slice(self, s: int):

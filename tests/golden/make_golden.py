@@ -248,6 +248,53 @@ def host_fixture(ref_utils, out_json):
     out_json["kg_batch_split"] = sp
 
 
+def cnn_fixture(out):
+    """The attribute-view CNN scorer (code/MultiKE_model.py:34-63) cannot be executed (tf.layers); its TF1 semantics
+    are restated here with torch.nn.functional ops — an implementation independent of oracle/attr_cnn_oracle.py —
+    and differentiated by autograd in float64.  Pins the oracle's forward and hand-derived backward."""
+    import torch.nn.functional as F
+    for ci, (d, B, weighted, scale) in enumerate(((8, 13, False, 2.0), (75, 37, True, 1.0))):
+        rng = np.random.default_rng(500 + ci)
+        P = {"gamma": 1 + 0.2 * rng.standard_normal(d), "beta": 0.1 * rng.standard_normal(d),
+             "K1": 0.5 * rng.standard_normal((2, 4, 1, 2)), "b1": 0.1 * rng.standard_normal(2),
+             "K2": 0.5 * rng.standard_normal((2, 4, 2, 2)), "b2": 0.1 * rng.standard_normal(2),
+             "W": rng.standard_normal((4 * d, d)) * np.sqrt(6.0 / (5 * d)), "bias": 0.1 * rng.standard_normal(d)}
+        hs = rng.standard_normal((B, d)); hs /= np.linalg.norm(hs, axis=1, keepdims=True)
+        as_ = 0.3 * rng.standard_normal((B, d))
+        vs = rng.standard_normal((B, d)); vs /= np.linalg.norm(vs, axis=1, keepdims=True)
+        ws = rng.uniform(0.2, 1.0, B) if weighted else None
+        T_ = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in P.items()}
+        th, ta = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (hs, as_))
+        tv = torch.tensor(vs, dtype=torch.float64)
+        x = torch.stack([ta, tv], 1)                                            # [B,2,d]
+        x = x * (T_["gamma"] / np.sqrt(1.0 + 1e-3)) + T_["beta"]                 # BN inference, axis = width
+        x = x[:, None]                                                          # NCHW [B,1,2,d]
+        for K, b in ((T_["K1"], T_["b1"]), (T_["K2"], T_["b2"])):
+            x = F.pad(x, (1, 2, 0, 1))                                          # SAME for a 2x4 kernel
+            x = torch.tanh(F.conv2d(x, K.permute(3, 2, 0, 1), b))
+        x = x.permute(0, 2, 3, 1)                                               # NHWC [B,2,d,2]
+        x = x * torch.rsqrt(torch.clamp_min((x * x).sum(2, keepdim=True), 1e-12))   # l2_normalize(axis=2)
+        flat = x.reshape(B, -1)
+        z = torch.tanh(flat @ T_["W"] + T_["bias"])
+        o = z * torch.rsqrt(torch.clamp_min((z * z).sum(), 1e-12))              # l2_normalize, no axis
+        score = -((th - o) ** 2).sum(1)
+        per = torch.log(1 + torch.exp(-score))
+        loss = scale * ((per * torch.tensor(ws)) if ws is not None else per).sum()
+        loss.backward()
+        pre = f"n{ci}_"
+        out[pre + "meta"] = np.array([d, B, int(weighted)], dtype=np.int64)
+        out[pre + "scale"] = np.float64(scale)
+        for k, v in P.items():
+            out[pre + "p_" + k] = v
+            out[pre + "g_" + k] = T_[k].grad.numpy()
+        out[pre + "hs"], out[pre + "as"], out[pre + "vs"] = hs, as_, vs
+        if ws is not None:
+            out[pre + "ws"] = ws
+        out[pre + "score"] = score.detach().numpy()
+        out[pre + "loss"] = np.float64(loss.item())
+        out[pre + "g_hs"], out[pre + "g_as"] = th.grad.numpy(), ta.grad.numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -266,6 +313,9 @@ def main():
     out = {}
     losses_fixture(ref_losses, tf, out)
     np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
+    cnn = {}
+    cnn_fixture(cnn)
+    np.savez_compressed(os.path.join(HERE, "cnn_golden.npz"), **cnn)
     js = {}
     sampler_fixture(ref_batch, ref_attr_batch, js)
     host_fixture(ref_utils, js)
