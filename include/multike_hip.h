@@ -301,6 +301,48 @@ int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int s
                          int32_t* touched, int32_t tag, int32_t* reset_req /*nullable*/, int32_t* reset_counts /*nullable*/,
                          int n_counts, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (8) Attribute-view CNN scorer.
+ *
+ * replaces: `conv()` at code/MultiKE_model.py:34-63 and the loss lines of the three graphs that call it
+ *           (:145-148 attribute view, :182-183 ckge_attr x2, :214-218 ckga_attr), forward and backward.
+ *
+ *   Parameters of one CNN are ONE packed float buffer (so that one update launch covers them):
+ *     gamma[dim] | beta[dim] | K1[2][4][1][2] | b1[2] | K2[2][4][2][2] | b2[2] | W[4*dim][dim] | bias[dim]
+ *     (conv kernels in TF HWIO order, W row index = h*2*dim + w*2 + c).  MKE_CNN_CONV_PARAMS(dim) floats belong to
+ *     the conv stack; W / bias follow.
+ *   Pipeline of one step (all enqueue-only):
+ *     mke_attr_conv_fwd   : gather attribute (table flag) + literal rows, BN affine, 2 x conv+tanh, width l2-norm -> flat [n][4*dim]
+ *     (library GEMM)      : zpre = flat @ W
+ *     mke_attr_tail_z     : z = tanh(zpre + bias) in place; per-block partial sums of z^2
+ *     mke_attr_tail_loss  : out = z / ||z||_F (whole batch); loss = scale * sum w log(1+exp(||h-out||^2)); scatter of the
+ *                           entity-row gradient; gout = dL/dout; per-block partials of sum gout.z
+ *     mke_attr_tail_bwd   : gout <- dL/dzpre (through the batch-global normalisation and tanh), in place
+ *     (library GEMMs)     : dW = flat^T @ dzpre ; dflat = dzpre @ W^T ; dbias = column sums
+ *     mke_attr_conv_bwd   : recomputes the conv stack, back-propagates it, scatters the attribute-row gradient and
+ *                           accumulates the conv / BN parameter gradients into grad_params (atomic)
+ *     mke_dense_update    : Adagrad / SGD over the packed parameter buffer (consumes = zeroes the gradient)
+ * ------------------------------------------------------------------------------------------------ */
+#define MKE_CNN_CONV_PARAMS(dim) (2 * (dim) + 52)
+#define MKE_CNN_PARAMS(dim) (MKE_CNN_CONV_PARAMS(dim) + 4 * (dim) * (dim) + (dim))
+int mke_attr_conv_fwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table, int lit_stride,
+                      int dim, const int32_t* ia, const int32_t* iv, int64_t n, const float* params, float* flat,
+                      void* stream);
+int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table, int lit_stride,
+                      int dim, const int32_t* ia, const int32_t* iv, int64_t n, const float* params, const float* dflat,
+                      float* grad_params, float* grad_attr /*nullable*/, int32_t* touched_attr, int32_t tag, void* stream);
+int mke_attr_tail_z(float* z /* in: zpre, out: z */, const float* bias, int64_t n, int dim,
+                    double* sumsq_partials /* [MKE_LOSS_PARTIALS] */, void* stream);
+int mke_attr_tail_loss(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
+                       int ent_normalize, const int32_t* ih, const float* weights /*nullable*/, float scale, int64_t n,
+                       int dim, float* gout /* [n][dim] */, double* dot_partials, float* grad_ent /*nullable*/,
+                       int32_t* touched_ent, int32_t tag, double* loss_partials, void* stream);
+int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials, int64_t n,
+                      int dim, void* stream);
+/* dense Adagrad / SGD over n contiguous floats; grad is zeroed — tf.train.AdagradOptimizer on the CNN variables */
+int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

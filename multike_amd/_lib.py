@@ -26,6 +26,8 @@ SYMBOLS = (
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
+    "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
+    "mke_dense_update",
 )
 
 
@@ -289,3 +291,64 @@ def rows_scatter_add(idx, rows, dim, grad, touched, tag, reset_req=None, reset_c
                                     _dev(reset_req, torch.int32, "reset_req"), _dev(reset_counts, torch.int32, "reset_counts"),
                                     C.c_int(0 if reset_counts is None else reset_counts.numel()), _stream())
     _check(rc, "mke_rows_scatter_add")
+
+
+def cnn_conv_params(dim: int) -> int:
+    return 2 * dim + 52
+
+
+def cnn_params(dim: int) -> int:
+    return cnn_conv_params(dim) + 4 * dim * dim + dim
+
+
+def attr_conv_fwd(attr, attr_normalize, lit, dim, ia, iv, params, flat):
+    rc = lib().mke_attr_conv_fwd(_dev(attr, torch.float32, "attr_table"), C.c_int(attr.shape[1]), C.c_int(int(attr_normalize)),
+                                 _dev(lit, torch.float32, "lit_table"), C.c_int(lit.shape[1]), C.c_int(dim),
+                                 _dev(ia, torch.int32, "ia"), _dev(iv, torch.int32, "iv"), C.c_int64(ia.numel()),
+                                 _dev(params, torch.float32, "params"), _dev(flat, torch.float32, "flat"), _stream())
+    _check(rc, "mke_attr_conv_fwd")
+
+
+def attr_conv_bwd(attr, attr_normalize, lit, dim, ia, iv, params, dflat, grad_params, grad_attr, touched_attr, tag):
+    rc = lib().mke_attr_conv_bwd(_dev(attr, torch.float32, "attr_table"), C.c_int(attr.shape[1]), C.c_int(int(attr_normalize)),
+                                 _dev(lit, torch.float32, "lit_table"), C.c_int(lit.shape[1]), C.c_int(dim),
+                                 _dev(ia, torch.int32, "ia"), _dev(iv, torch.int32, "iv"), C.c_int64(ia.numel()),
+                                 _dev(params, torch.float32, "params"), _dev(dflat, torch.float32, "dflat"),
+                                 _dev(grad_params, torch.float32, "grad_params"), _dev(grad_attr, torch.float32, "grad_attr"),
+                                 _dev(touched_attr, torch.int32, "touched_attr"), C.c_int32(tag), _stream())
+    _check(rc, "mke_attr_conv_bwd")
+
+
+def attr_tail_z(z, bias, sumsq_partials):
+    n, dim = z.shape
+    rc = lib().mke_attr_tail_z(_dev(z, torch.float32, "z"), _dev(bias, torch.float32, "bias"), C.c_int64(n), C.c_int(dim),
+                               _dev(sumsq_partials, torch.float64, "sumsq_partials"), _stream())
+    _check(rc, "mke_attr_tail_z")
+
+
+def attr_tail_loss(z, sumsq_partials, ent, ent_normalize, ih, weights, scale, gout, dot_partials, grad_ent, touched_ent, tag,
+                   loss_partials):
+    n, dim = z.shape
+    rc = lib().mke_attr_tail_loss(_dev(z, torch.float32, "z"), _dev(sumsq_partials, torch.float64, "sumsq"),
+                                  _dev(ent, torch.float32, "ent_table"), C.c_int(ent.shape[1]), C.c_int(int(ent_normalize)),
+                                  _dev(ih, torch.int32, "ih"), _dev(weights, torch.float32, "weights"), C.c_float(scale),
+                                  C.c_int64(n), C.c_int(dim), _dev(gout, torch.float32, "gout"),
+                                  _dev(dot_partials, torch.float64, "dot_partials"), _dev(grad_ent, torch.float32, "grad_ent"),
+                                  _dev(touched_ent, torch.int32, "touched_ent"), C.c_int32(tag),
+                                  _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_attr_tail_loss")
+
+
+def attr_tail_bwd(z, gout, sumsq_partials, dot_partials):
+    n, dim = z.shape
+    rc = lib().mke_attr_tail_bwd(_dev(z, torch.float32, "z"), _dev(gout, torch.float32, "gout"),
+                                 _dev(sumsq_partials, torch.float64, "sumsq"), _dev(dot_partials, torch.float64, "dot"),
+                                 C.c_int64(n), C.c_int(dim), _stream())
+    _check(rc, "mke_attr_tail_bwd")
+
+
+def dense_update(param, acc, grad, optimizer, lr):
+    rc = lib().mke_dense_update(_dev(param, torch.float32, "param"), _dev(acc, torch.float32, "acc"),
+                                _dev(grad, torch.float32, "grad"), C.c_int64(param.numel()), C.c_int(optimizer), C.c_float(lr),
+                                _stream())
+    _check(rc, "mke_dense_update")

@@ -1,0 +1,575 @@
+// mke_attr_cnn.hip — the attribute-view CNN scorer (code/MultiKE_model.py:34-63 `conv`) for gfx950.
+//
+// TF1 semantics restated: stack (attribute row, literal row) -> [2, d, 1]; batch-norm in
+// inference mode along the width axis (gamma[w] * x / sqrt(1 + 1e-3) + beta[w]); two conv2d(2 filters, 2x4, SAME,
+// tanh); l2-normalise over the width axis per (row, channel); flatten (index h*2d + w*2 + c); dense 4d -> d with
+// tanh (the GEMM is a plain library GEMM on the host side); l2-normalise over the WHOLE [B, d] batch; score =
+// -||h - out||^2; loss = scale * sum w * log(1 + exp(-score)).
+//
+// Shape: the conv stack is one 64-lane wavefront per triple, lane = width position (WPL positions per lane), rows
+// staged through per-wave LDS strips for the +-2 neighbour reads.  The backward kernel recomputes the (cheap)
+// forward instead of storing activations, back-propagates through both convolutions, the width normalisation and
+// the batch-norm affine, scatters the attribute-row gradient with atomics and block-reduces the parameter gradients.
+// The batch-global normalisation needs two batch-wide sums (sum z^2, sum g.z): kernels write per-block partials
+// and the next kernel's blocks add them up themselves — no extra reduction launches, no host round trip.
+#include "mke_common.h"
+
+namespace mke {
+
+#define CNN_BN_EPS 1e-3f
+#define CNN_NCONV 52  // K1 16 + b1 2 + K2 32 + b2 2
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = sub16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct ConvParams {
+  const float* __restrict__ attr;
+  int attr_stride, attr_norm;
+  const float* __restrict__ lit;
+  int lit_stride;
+  int dim;
+  const int32_t* __restrict__ ia;
+  const int32_t* __restrict__ iv;
+  int64_t n;
+  const float* __restrict__ params;  // packed: gamma[d] beta[d] K1[16] b1[2] K2[32] b2[2] ...
+  float* __restrict__ flat;          // fwd out [n][4d]
+  const float* __restrict__ dflat;   // bwd in  [n][4d]
+  float* __restrict__ gparams;       // bwd out, same packing, atomically accumulated
+  float* __restrict__ gattr;         // bwd out: attribute-table gradient scratch (nullable)
+  int32_t* __restrict__ tattr;
+  int32_t tag;
+};
+
+// K1[kh][kw][0][f] at k1[(kh*4+kw)*2+f]; K2[kh][kw][c][f] at k2[((kh*4+kw)*2+c)*2+f]  (TF HWIO order)
+template <int WPL, bool BWD>
+__global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
+  constexpr int DP = 64 * WPL + 4;
+  __shared__ float s_x[MKE_BLOCK / 64][2][DP];
+  __shared__ float s_c1[MKE_BLOCK / 64][2][2][DP];
+  __shared__ float s_d2[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
+  __shared__ float s_d1[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
+  __shared__ float s_red[BWD ? CNN_NCONV : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int d = p.dim;
+  const float bn_s = rsqrtf(1.0f + CNN_BN_EPS);
+  const float* __restrict__ gamma = p.params;
+  const float* __restrict__ beta = p.params + d;
+  float k1[16], b1[2], k2[32], b2[2];
+  {
+    const float* cp = p.params + 2 * d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k1[i] = cp[i];
+    b1[0] = cp[16]; b1[1] = cp[17];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) k2[i] = cp[18 + i];
+    b2[0] = cp[50]; b2[1] = cp[51];
+  }
+  float gam[WPL], bet[WPL];
+#pragma unroll
+  for (int i = 0; i < WPL; ++i) {
+    const int w = lane + 64 * i;
+    gam[i] = w < d ? gamma[w] : 0.f;
+    bet[i] = w < d ? beta[w] : 0.f;
+  }
+  // parameter-gradient accumulators (BWD)
+  float a_k1[BWD ? 16 : 1], a_k2[BWD ? 32 : 1], a_b1[2], a_b2[2], a_gam[WPL], a_bet[WPL];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a_k1[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a_k2[i] = 0.f;
+    a_b1[0] = a_b1[1] = a_b2[0] = a_b2[1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) a_gam[i] = a_bet[i] = 0.f;
+  }
+  float(*xs)[DP] = s_x[wv];
+  float(*c1s)[2][DP] = s_c1[wv];
+
+  const int64_t wave0 = (int64_t)blockIdx.x * (MKE_BLOCK / 64) + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * (MKE_BLOCK / 64);
+  const int64_t iters = (p.n + nwaves - 1) / nwaves;  // block-uniform trip count (barriers inside)
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t t = wave0 + it * nwaves;
+    const bool live = t < p.n;
+    const int ra = live ? p.ia[t] : 0, rv = live ? p.iv[t] : 0;
+    float raw[2][WPL];
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const int w = lane + 64 * i;
+      raw[0][i] = (live && w < d) ? p.attr[(int64_t)ra * p.attr_stride + w] : 0.f;
+      raw[1][i] = (live && w < d) ? p.lit[(int64_t)rv * p.lit_stride + w] : 0.f;
+    }
+    if (p.attr_norm) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) s = fmaf(raw[0][i], raw[0][i], s);
+      s = wave_sum(s);
+      const float inv = rsqrtf(fmaxf(s, MKE_L2_EPS));
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) raw[0][i] *= inv;
+    }
+    // ---- batch-norm affine, stage x with zero pads: index w+1 <-> width w ---------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const int w = lane + 64 * i;
+        xs[h][w + 1] = w < d ? fmaf(gam[i] * bn_s, raw[h][i], bet[i]) : 0.f;
+      }
+      if (lane < 4) xs[h][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
+    }
+    __syncthreads();
+    // ---- conv1 ---------------------------------------------------------------------------------------------
+    float c1[2][2][WPL];
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const int w = lane + 64 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          float acc = b1[f];
+#pragma unroll
+          for (int kh = 0; kh + h < 2; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) acc = fmaf(k1[(kh * 4 + kw) * 2 + f], xs[h + kh][w + kw], acc);
+          c1[h][f][i] = w < d ? tanhf(acc) : 0.f;
+          c1s[h][f][w + 1] = c1[h][f][i];
+        }
+    }
+    if (lane < 4) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) c1s[h][f][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
+    }
+    __syncthreads();
+    // ---- conv2 + width normalisation -----------------------------------------------------------------------
+    float c2[2][2][WPL], nrm[2][2], ssq[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) ssq[h][f] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      const int w = lane + 64 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          float acc = b2[f];
+#pragma unroll
+          for (int kh = 0; kh + h < 2; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], c1s[h + kh][c][w + kw], acc);
+          c2[h][f][i] = w < d ? tanhf(acc) : 0.f;
+          ssq[h][f] = fmaf(c2[h][f][i], c2[h][f][i], ssq[h][f]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        ssq[h][f] = wave_sum(ssq[h][f]);
+        nrm[h][f] = rsqrtf(fmaxf(ssq[h][f], MKE_L2_EPS));
+      }
+    if constexpr (!BWD) {
+      if (live) {
+        float* o = p.flat + t * (int64_t)(4 * d);
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+          const int w = lane + 64 * i;
+          if (w < d) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float2 v = make_float2(c2[h][0][i] * nrm[h][0], c2[h][1][i] * nrm[h][1]);
+              *reinterpret_cast<float2*>(o + h * 2 * d + w * 2) = v;
+            }
+          }
+        }
+      }
+      __syncthreads();  // LDS strips are rewritten by the next iteration
+      continue;
+    }
+    if constexpr (BWD) {
+      float(*d2s)[2][DP] = s_d2[wv];
+      float(*d1s)[2][DP] = s_d1[wv];
+      // ---- width-normalisation backward, tanh', parameter gradients of conv2 -------------------------------
+      float dy[2][2][WPL], dot[2][2];
+      const float* gi = p.dflat + t * (int64_t)(4 * d);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) dot[h][f] = 0.f;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const int w = lane + 64 * i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float2 v = make_float2(0.f, 0.f);
+          if (live && w < d) v = *reinterpret_cast<const float2*>(gi + h * 2 * d + w * 2);
+          dy[h][0][i] = v.x; dy[h][1][i] = v.y;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) dot[h][f] = fmaf(dy[h][f][i], c2[h][f][i] * nrm[h][f], dot[h][f]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) dot[h][f] = wave_sum(dot[h][f]);
+      float dp2[2][2][WPL];
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const int w = lane + 64 * i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float y = c2[h][f][i] * nrm[h][f];
+            const float dc2 = ssq[h][f] > MKE_L2_EPS ? nrm[h][f] * (dy[h][f][i] - y * dot[h][f]) : nrm[h][f] * dy[h][f][i];
+            dp2[h][f][i] = (w < d) ? dc2 * (1.0f - c2[h][f][i] * c2[h][f][i]) : 0.f;
+            d2s[h][f][w + 2] = dp2[h][f][i];  // index w+2 <-> width w
+            a_b2[f] += dp2[h][f][i];
+#pragma unroll
+            for (int kh = 0; kh + h < 2; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                  a_k2[((kh * 4 + kw) * 2 + c) * 2 + f] = fmaf(dp2[h][f][i], c1s[h + kh][c][w + kw], a_k2[((kh * 4 + kw) * 2 + c) * 2 + f]);
+          }
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) d2s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
+      }
+      __syncthreads();
+      // ---- conv2 transposed -> dc1, tanh', parameter gradients of conv1 -----------------------------------
+      float dp1[2][2][WPL];
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const int w = lane + 64 * i;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int kh = 0; kh <= hh; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], d2s[hh - kh][f][w + 3 - kw], acc);
+            dp1[hh][c][i] = (w < d) ? acc * (1.0f - c1[hh][c][i] * c1[hh][c][i]) : 0.f;
+            d1s[hh][c][w + 2] = dp1[hh][c][i];
+            a_b1[c] += dp1[hh][c][i];
+#pragma unroll
+            for (int kh = 0; kh + hh < 2; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 4; ++kw) a_k1[(kh * 4 + kw) * 2 + c] = fmaf(dp1[hh][c][i], xs[hh + kh][w + kw], a_k1[(kh * 4 + kw) * 2 + c]);
+          }
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) d1s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
+      }
+      __syncthreads();
+      // ---- conv1 transposed -> dx, batch-norm affine backward, attribute-row gradient ---------------------
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        const int w = lane + 64 * i;
+        float dx[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float acc = 0.f;
+#pragma unroll
+          for (int kh = 0; kh <= hh; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+              for (int f = 0; f < 2; ++f) acc = fmaf(k1[(kh * 4 + kw) * 2 + f], d1s[hh - kh][f][w + 3 - kw], acc);
+          dx[hh] = (live && w < d) ? acc : 0.f;
+        }
+        a_gam[i] += (dx[0] * raw[0][i] + dx[1] * raw[1][i]) * bn_s;
+        a_bet[i] += dx[0] + dx[1];
+        if (live && w < d && p.gattr) atomic_add_f32(p.gattr + (int64_t)ra * p.attr_stride + w, dx[0] * gam[i] * bn_s);
+      }
+      if (live && lane == 0 && p.gattr) p.tattr[ra] = p.tag;
+      __syncthreads();
+    }
+  }
+
+  if constexpr (BWD) {
+    // ---- block-reduce the parameter gradients, one atomic per block per scalar --------------------------------
+    if (threadIdx.x < CNN_NCONV) s_red[threadIdx.x] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float v = wave_sum(a_k1[i]); if (lane == 0) atomicAdd(&s_red[i], v); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float v = wave_sum(a_b1[i]); if (lane == 0) atomicAdd(&s_red[16 + i], v); }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float v = wave_sum(a_k2[i]); if (lane == 0) atomicAdd(&s_red[18 + i], v); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float v = wave_sum(a_b2[i]); if (lane == 0) atomicAdd(&s_red[50 + i], v); }
+    // gamma / beta: reduce over the block's waves through the (now free) x strips
+    float* gsum = &s_x[0][0][0];
+    float* bsum = &s_c1[0][0][0][0];
+    __syncthreads();
+    for (int w = threadIdx.x; w < 64 * WPL; w += MKE_BLOCK) { gsum[w] = 0.f; bsum[w] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+      atomicAdd(&gsum[lane + 64 * i], a_gam[i]);
+      atomicAdd(&bsum[lane + 64 * i], a_bet[i]);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < d; w += MKE_BLOCK) {
+      atomic_add_f32(p.gparams + w, gsum[w]);
+      atomic_add_f32(p.gparams + d + w, bsum[w]);
+    }
+    if (threadIdx.x < CNN_NCONV) atomic_add_f32(p.gparams + 2 * d + threadIdx.x, s_red[threadIdx.x]);
+  }
+}
+
+// ---- tail: z = tanh(zpre + bias), partial sums of z^2 -------------------------------------------------------------
+__global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_z(float* __restrict__ z, const float* __restrict__ bias, int64_t n,
+                                                           int dim, double* __restrict__ partials) {
+  const int64_t total = n * dim;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    const float v = tanhf(z[i] + bias[i % dim]);
+    z[i] = v;
+    s = fmaf(v, v, s);
+  }
+  const double tot = block_sum_double(s);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// every block adds up the MKE_LOSS_PARTIALS partials of the previous kernel itself
+__device__ __forceinline__ double total_of_partials(const double* __restrict__ partials) {
+  __shared__ double s_tot;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < MKE_LOSS_PARTIALS; i += MKE_BLOCK) v += partials[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __shared__ double s_w[MKE_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < MKE_BLOCK / 64; ++w) t += s_w[w];
+    s_tot = t;
+  }
+  __syncthreads();
+  return s_tot;
+}
+
+struct TailParams {
+  const float* __restrict__ z;
+  const double* __restrict__ sumsq;
+  const float* __restrict__ ent;
+  int ent_stride, ent_norm;
+  const int32_t* __restrict__ ih;
+  const float* __restrict__ ws;
+  float scale;
+  int64_t n;
+  int dim;
+  float* __restrict__ gout;
+  double* __restrict__ dotp;
+  float* __restrict__ gent;
+  int32_t* __restrict__ tent;
+  int32_t tag;
+  double* __restrict__ lossp;
+};
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p) {
+  const double S = total_of_partials(p.sumsq);
+  const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  float loss = 0.f, dotacc = 0.f;
+  for (int64_t i = sub0; i < p.n; i += nsub) {
+    const int row = p.ih[i];
+    float H[FPL], Z[FPL];
+    load_row<FPL>(p.ent, row, p.ent_stride, j, H);
+    l2_normalize_row<FPL>(H, p.ent_norm);
+    const float* zp = p.z + i * (int64_t)p.dim + j;
+    float x = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      Z[k] = (k * 16 + j < p.dim) ? zp[k * 16] : 0.f;
+      H[k] = H[k] - Z[k] * inv;  // diff = h - out
+      x = fmaf(H[k], H[k], x);
+    }
+    x = sub16_sum(x);
+    const float w = p.ws ? p.ws[i] : 1.0f;
+    loss += w * softplus_f(x);
+    const float c = 2.0f * p.scale * w * sigmoid_f(x);
+    float dz = 0.f;
+    float* go = p.gout + i * (int64_t)p.dim + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      H[k] *= c;  // g_h = 2 c diff ; g_out = -g_h
+      if (k * 16 + j < p.dim) go[k * 16] = -H[k];
+      dz = fmaf(-H[k], Z[k], dz);
+    }
+    dotacc += dz;  // per-lane partial of sum g_out . z
+    if (p.gent) {
+      atomic_add_row<FPL>(p.gent, row, p.ent_stride, p.dim, j, H, 1.0f);
+      if (j == 0) p.tent[row] = p.tag;
+    }
+  }
+  const double lt = block_sum_double(j == 0 ? loss : 0.f);
+  __syncthreads();
+  const double dt = block_sum_double(dotacc);
+  if (threadIdx.x == 0) {
+    p.lossp[blockIdx.x] = lt * (double)p.scale;
+    p.dotp[blockIdx.x] = dt;
+  }
+}
+
+// dzpre = inv * (g_out - out * (g_out . out)) * (1 - z^2), in place over gout
+__global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_bwd(const float* __restrict__ z, float* __restrict__ g,
+                                                             const double* __restrict__ sumsq, const double* __restrict__ dotp,
+                                                             int64_t n, int dim) {
+  const double S = total_of_partials(sumsq);
+  __syncthreads();
+  const double T = total_of_partials(dotp);
+  const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
+  const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;  // out * (g.out) = z * inv^2 * T
+  const int64_t total = n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    const float zv = z[i];
+    g[i] = inv * (g[i] - zv * coef) * (1.0f - zv * zv);
+  }
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(float* __restrict__ w, float* __restrict__ acc, float* __restrict__ g,
+                                                            int64_t n, int optimizer, float lr) {
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    const float gv = g[i];
+    g[i] = 0.f;
+    if (optimizer == MKE_OPT_ADAGRAD) {
+      const float a = fmaf(gv, gv, acc[i]);
+      acc[i] = a;
+      w[i] -= lr * gv / sqrtf(a);
+    } else {
+      w[i] -= lr * gv;
+    }
+  }
+}
+
+static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
+  const int wpl = (p.dim + 63) / 64;
+  int64_t blocks = (p.n + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+#define MKE_CONV_CASE(W)                                                                                        \
+  case W:                                                                                                       \
+    if (bwd) hipLaunchKernelGGL((k_attr_conv<W, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);      \
+    else hipLaunchKernelGGL((k_attr_conv<W, false>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);        \
+    break;
+  switch (wpl) {
+    MKE_CONV_CASE(1) MKE_CONV_CASE(2) MKE_CONV_CASE(3) MKE_CONV_CASE(4) MKE_CONV_CASE(5)
+    default:
+      set_error("attribute CNN: dim %d not supported (<= 320)", p.dim);
+      return MKE_E_UNSUPPORTED;
+  }
+#undef MKE_CONV_CASE
+  return check_launch("k_attr_conv");
+}
+
+}  // namespace mke
+
+extern "C" int mke_attr_conv_fwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table,
+                                 int lit_stride, int dim, const int32_t* ia, const int32_t* iv, int64_t n,
+                                 const float* params, float* flat, void* stream) {
+  using namespace mke;
+  if (n < 0 || dim <= 0 || dim > MKE_MAX_STRIDE || attr_stride < dim || lit_stride < dim) { set_error("mke_attr_conv_fwd: bad n/dim/stride"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!attr_table || !lit_table || !ia || !iv || !params || !flat) { set_error("mke_attr_conv_fwd: NULL pointer"); return MKE_E_NULL; }
+  ConvParams p{};
+  p.attr = attr_table; p.attr_stride = attr_stride; p.attr_norm = attr_normalize; p.lit = lit_table; p.lit_stride = lit_stride;
+  p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.flat = flat;
+  return conv_dispatch(p, false, (hipStream_t)stream);
+}
+
+extern "C" int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table,
+                                 int lit_stride, int dim, const int32_t* ia, const int32_t* iv, int64_t n,
+                                 const float* params, const float* dflat, float* grad_params, float* grad_attr,
+                                 int32_t* touched_attr, int32_t tag, void* stream) {
+  using namespace mke;
+  if (n < 0 || dim <= 0 || dim > MKE_MAX_STRIDE || attr_stride < dim || lit_stride < dim) { set_error("mke_attr_conv_bwd: bad n/dim/stride"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!attr_table || !lit_table || !ia || !iv || !params || !dflat || !grad_params) { set_error("mke_attr_conv_bwd: NULL pointer"); return MKE_E_NULL; }
+  if (grad_attr && !touched_attr) { set_error("NULL touched array"); return MKE_E_NULL; }
+  ConvParams p{};
+  p.attr = attr_table; p.attr_stride = attr_stride; p.attr_norm = attr_normalize; p.lit = lit_table; p.lit_stride = lit_stride;
+  p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.dflat = dflat; p.gparams = grad_params;
+  p.gattr = grad_attr; p.tattr = touched_attr; p.tag = tag;
+  return conv_dispatch(p, true, (hipStream_t)stream);
+}
+
+extern "C" int mke_attr_tail_z(float* z, const float* bias, int64_t n, int dim, double* sumsq_partials, void* stream) {
+  using namespace mke;
+  if (n < 0 || dim <= 0) { set_error("bad n/dim"); return MKE_E_SHAPE; }
+  if (!z || !bias || !sumsq_partials) { set_error("mke_attr_tail_z: NULL pointer"); return MKE_E_NULL; }
+  hipLaunchKernelGGL(k_attr_tail_z, dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, bias, n, dim,
+                     sumsq_partials);
+  return check_launch("k_attr_tail_z");
+}
+
+extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
+                                  int ent_normalize, const int32_t* ih, const float* weights, float scale, int64_t n, int dim,
+                                  float* gout, double* dot_partials, float* grad_ent, int32_t* touched_ent, int32_t tag,
+                                  double* loss_partials, void* stream) {
+  using namespace mke;
+  if (n < 0 || dim <= 0 || ent_stride % 16 != 0 || dim > ent_stride || ent_stride > MKE_MAX_STRIDE) { set_error("bad n/dim/stride"); return MKE_E_SHAPE; }
+  if (!z || !sumsq_partials || !ent_table || !gout || !dot_partials || !loss_partials || (n > 0 && !ih)) { set_error("mke_attr_tail_loss: NULL pointer"); return MKE_E_NULL; }
+  if (grad_ent && !touched_ent) { set_error("NULL touched array"); return MKE_E_NULL; }
+  TailParams p;
+  p.z = z; p.sumsq = sumsq_partials; p.ent = ent_table; p.ent_stride = ent_stride; p.ent_norm = ent_normalize; p.ih = ih;
+  p.ws = weights; p.scale = scale; p.n = n; p.dim = dim; p.gout = gout; p.dotp = dot_partials; p.gent = grad_ent;
+  p.tent = touched_ent; p.tag = tag; p.lossp = loss_partials;
+  const int fpl = ent_stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_attr_tail_loss<FPL>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  });
+  return check_launch("k_attr_tail_loss");
+}
+
+extern "C" int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials,
+                                 int64_t n, int dim, void* stream) {
+  using namespace mke;
+  if (n < 0 || dim <= 0) { set_error("bad n/dim"); return MKE_E_SHAPE; }
+  if (!z || !gout || !sumsq_partials || !dot_partials) { set_error("mke_attr_tail_bwd: NULL pointer"); return MKE_E_NULL; }
+  hipLaunchKernelGGL(k_attr_tail_bwd, dim3(1024), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, gout, sumsq_partials,
+                     dot_partials, n, dim);
+  return check_launch("k_attr_tail_bwd");
+}
+
+extern "C" int mke_dense_update(float* param, float* acc, float* grad, int64_t n, int optimizer, float lr, void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!param || !grad) { set_error("mke_dense_update: NULL pointer"); return MKE_E_NULL; }
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
+  int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, param, acc, grad, n,
+                     optimizer, lr);
+  return check_launch("k_dense_update");
+}

@@ -1,0 +1,85 @@
+"""GPU parity of the attribute-view CNN step against the golden (torch-autograd) vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import attr_cnn_oracle as ao
+from oracle import multike_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(hs, as_, vs):
+    """Put the gathered rows of a fixture into tables (identity indices; hs rows are unit so normalise = identity)."""
+    from multike_amd.tables import EmbeddingTable
+    B, d = hs.shape
+    ent = EmbeddingTable(B, d, "av_ent", normalize=True, values=hs)
+    attr = EmbeddingTable(B, d, "attr", normalize=False, values=as_)
+    lit = EmbeddingTable(B, d, "lit", normalize=False, trainable=False, values=vs)
+    idx = torch.arange(B, dtype=torch.int32, device="cuda")
+    return ent, attr, lit, idx
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_golden_loss_and_every_gradient(ci):
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import StepEngine
+    g = np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+    pre = f"n{ci}_"
+    d = int(g[pre + "meta"][0])
+    P = {k: g[pre + "p_" + k] for k in ao.PARAM_NAMES}
+    ws = torch.tensor(g[pre + "ws"], dtype=torch.float32, device="cuda") if (pre + "ws") in g.files else None
+    ent, attr, lit, idx = _tables(g[pre + "hs"], g[pre + "as"], g[pre + "vs"])
+    cnn = AttrCNN(d, params=P)
+    eng = StepEngine()
+    lp = cnn.step(eng, ent, attr, lit, idx, idx, idx, ws, scale=float(g[pre + "scale"]), update=False)
+    np.testing.assert_allclose(float(lp.sum()), g[pre + "loss"], rtol=5e-6)
+    for k in ao.PARAM_NAMES:
+        got = cnn.gviews[k].cpu().numpy()
+        ref = g[pre + "g_" + k]
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    np.testing.assert_allclose(ent.grad[:, :d].cpu().numpy(), g[pre + "g_hs"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(attr.grad[:, :d].cpu().numpy(), g[pre + "g_as"], rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("d,B,n_ent,n_attr,n_lit", [(75, 5000, 20000, 300, 8000), (75, 37, 100, 9, 50), (32, 513, 900, 20, 400),
+                                                    (130, 64, 200, 11, 90)])
+def test_three_steps_vs_oracle(d, B, n_ent, n_attr, n_lit):
+    """Full step (scatter with duplicate rows, Jacobian + Adagrad on the entity table, plain Adagrad on the raw attribute
+    table and on the packed CNN parameters) against the float64 dense oracle."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    rng = np.random.default_rng(d + B)
+    P = ao.init_params(d, rng)
+    P["bias"] = 0.05 * rng.standard_normal(d)
+    P["b1"] = 0.05 * rng.standard_normal(2)
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    attr = mo.xavier_truncated_normal((n_attr, d), rng)
+    lit = rng.standard_normal((n_lit, d)).astype(np.float32)
+    lit /= np.linalg.norm(lit, axis=1, keepdims=True)
+    E = EmbeddingTable(n_ent, d, "av_ent", normalize=True, values=ent)
+    A = EmbeddingTable(n_attr, d, "attr", normalize=False, values=attr)
+    L = EmbeddingTable(n_lit, d, "lit", normalize=False, trainable=False, values=lit)
+    cnn = AttrCNN(d, params=P)
+    eng = StepEngine()
+    p64 = {k: v.astype(np.float64) for k, v in P.items()}
+    acc = {k: np.full_like(v, 0.1) for k, v in p64.items()}
+    e64, a64, l64 = ent.astype(np.float64), attr.astype(np.float64), lit.astype(np.float64)
+    ae, aa = np.full_like(e64, 0.1), np.full_like(a64, 0.1)
+    for step in range(3):
+        ih, ia, iv = rng.integers(0, n_ent, B), rng.integers(0, n_attr, B), rng.integers(0, n_lit, B)
+        ws = rng.uniform(0.2, 1.0, B)
+        Lo, _ = ao.attribute_step_dense(p64, acc, e64, a64, l64, ae, aa, ih, ia, iv, ws, 2.0, 0.01)
+        t = lambda x: torch.as_tensor(x.astype(np.int32), device="cuda")
+        lp = cnn.step(eng, E, A, L, t(ih), t(ia), t(iv), torch.as_tensor(ws.astype(np.float32), device="cuda"), scale=2.0,
+                      opt_name="attribute", lr=0.01)
+        np.testing.assert_allclose(float(lp.sum()), Lo, rtol=1e-5)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(A.raw().cpu().numpy(), a64, rtol=2e-3, atol=2e-5)
+    got = cnn.numpy_params()
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(got[k], p64[k], rtol=2e-3, atol=1e-4, err_msg=k)
+    assert float(cnn.grads.abs().max()) == 0.0 and float(E.grad.abs().max()) == 0.0 and float(A.grad.abs().max()) == 0.0
