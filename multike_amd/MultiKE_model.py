@@ -1,0 +1,446 @@
+"""MultiKE_model.py — the reference's model / op surface (code/MultiKE_model.py) on the HIP hot path.
+
+Same public names, same argument orders, same epoch-loop semantics: `get_optimizer`, `generate_optimizer`, `conv`,
+class `MultiKE` with `_define_variables`, the eight `_define_*_graph` builders, the nine `train_*_1epo` loops,
+`eval_kg{1,2}[_useful]_ent_embeddings`, `save`.  What differs is how a "graph" runs: instead of a TF session
+executing dense whole-table ops fed from Python lists, every `train_*_1epo` enqueues fused HIP kernels over index
+streams that already live in HBM.  Each `_define_*_graph` therefore creates a small "graph" record: which
+tables, which optimizer slot (one Adagrad accumulator per graph per variable, as each `generate_optimizer` call
+creates in TF — SURVEY.md §9.3-4), which learning rate.
+
+`data`, `args`, `attr_align_model` are the reference's objects (DataModel / ARGs / PredicateAlignModel) or anything
+with the same attributes; only the attributes this file reads are required (see `synthetic.SyntheticData`).
+"""
+from __future__ import annotations
+
+import math
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import losses
+from .attr_cnn import AttrCNN
+from .runner import RelationViewRunner
+from .sampling import KGSide, KnownTripleSet, RelationBatcher
+from .tables import ADAGRAD_INIT_ACC, EmbeddingTable, StepEngine
+from .utils import generate_out_folder, save_embeddings
+
+_HIP_OPTS = ("Adagrad", "SGD")
+
+
+class Optimizer:
+    """What `get_optimizer` returns: the kind + learning rate; state lives in per-graph slots."""
+
+    def __init__(self, kind: str, learning_rate: float):
+        self.kind, self.learning_rate = kind, float(learning_rate)
+
+
+def get_optimizer(opt, learning_rate):
+    """code/MultiKE_model.py:15-25.  Adagrad (the reference's default, code/args.json:18) and SGD run on the HIP path;
+    Adadelta / Adam are accepted by name but not implemented (they are not touched-rows-equivalent)."""
+    if opt in ("Adagrad", "Adadelta", "Adam"):
+        return Optimizer(opt, learning_rate)
+    return Optimizer("SGD", learning_rate)
+
+
+class DenseOptimizerState:
+    """generate_optimizer for a loss over DENSE torch parameters (the 75x75 mapping matrices): autograd gradient +
+    TF1 update rule (ApplyAdagrad: acc0 = 0.1, no epsilon)."""
+
+    def __init__(self, var_list, learning_rate, opt="SGD"):
+        self.vars = list(var_list)
+        self.opt = get_optimizer(opt, learning_rate)
+        if self.opt.kind not in _HIP_OPTS:
+            raise _lib.MultiKEHipError(f"optimizer {self.opt.kind!r} not supported (Adagrad, SGD)")
+        self.acc = [torch.full_like(v, ADAGRAD_INIT_ACC) for v in self.vars]
+
+    @torch.no_grad()
+    def apply(self, grads):
+        for v, a, g in zip(self.vars, self.acc, grads):
+            if g is None:
+                continue
+            if self.opt.kind == "Adagrad":
+                a.add_(g * g)
+                v.sub_(self.opt.learning_rate * g / torch.sqrt(a))
+            else:
+                v.sub_(self.opt.learning_rate * g)
+
+
+def generate_optimizer(loss, learning_rate, var_list=None, opt="SGD"):
+    """code/MultiKE_model.py:28-31 for a torch scalar `loss` over dense leaf tensors `var_list`: computes the
+    gradients and applies one update.  Returns the optimizer state (keep it and call `.apply` for further steps)."""
+    if var_list is None:
+        raise _lib.MultiKEHipError("generate_optimizer needs var_list on this backend (table variables are updated "
+                                   "by the fused HIP steps, not through autograd)")
+    st = DenseOptimizerState(var_list, learning_rate, opt)
+    st.apply(torch.autograd.grad(loss, st.vars, allow_unused=True))
+    return st
+
+
+def conv(attr_hs, attr_as, attr_vs, dim, cnn: AttrCNN | None = None, feature_map_size=2, kernel_size=(2, 4),
+         activation="tanh", layer_num=2):
+    """code/MultiKE_model.py:34-63 on gathered rows: returns the score vector [B] (forward only — the training
+    graphs use `AttrCNN.step`, which fuses forward, backward and update).  `cnn` holds the parameters."""
+    if feature_map_size != 2 or tuple(kernel_size) != (2, 4) or layer_num != 2 or activation != "tanh":
+        raise _lib.MultiKEHipError("conv: only the reference's configuration (2 filters, 2x4, 2 layers, tanh) is built")
+    if cnn is None:
+        raise _lib.MultiKEHipError("conv: pass the AttrCNN that owns the parameters")
+    B = attr_hs.shape[0]
+    dev = attr_hs.device
+    a = EmbeddingTable(B, dim, normalize=False, trainable=False, values=attr_as.detach().cpu().numpy(), device=dev)
+    v = EmbeddingTable(B, dim, normalize=False, trainable=False, values=attr_vs.detach().cpu().numpy(), device=dev)
+    idx = torch.arange(B, dtype=torch.int32, device=dev)
+    flat = torch.empty(B, 4 * dim, dtype=torch.float32, device=dev)
+    _lib.attr_conv_fwd(a.data, False, v.data, dim, idx, idx, cnn.params, flat)
+    z = torch.matmul(flat, cnn.views["W"])
+    ssq = torch.empty(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
+    _lib.attr_tail_z(z, cnn.views["bias"], ssq)
+    out = z * torch.rsqrt(torch.clamp_min(ssq.sum().float(), 1e-12))
+    return -torch.sum(torch.square(attr_hs - out), 1)
+
+
+def _dev_i32(x, device):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32), device=device)
+
+
+class _TripleList:
+    """A Python list of (h, r, t[, w]) tuples mirrored in HBM as int32 columns (+ float32 weights)."""
+
+    def __init__(self, triples, device):
+        self.n = len(triples)
+        self.device = device
+        if self.n == 0:
+            self.cols, self.w = None, None
+            return
+        arr = np.asarray([t[:3] for t in triples], dtype=np.int32)
+        self.cols = tuple(torch.as_tensor(np.ascontiguousarray(arr[:, k]), device=device) for k in range(3))
+        self.w = (torch.as_tensor(np.asarray([t[3] for t in triples], dtype=np.float32), device=device)
+                  if len(triples[0]) > 3 else None)
+
+    def sample(self, batch_size, gen):
+        """random.sample(list, batch_size): without replacement inside a batch (code/MultiKE_model.py:358)."""
+        idx = torch.randperm(self.n, generator=gen, device=self.device)[:batch_size]
+        cols = tuple(c[idx].contiguous() for c in self.cols)
+        return cols, (None if self.w is None else self.w[idx].contiguous())
+
+
+class MultiKE:
+
+    def __check_args(self):
+        assert self.args.alignment_module == 'swapping'  # for cross-KG inference (code/MultiKE_model.py:68-69)
+
+    def __init__(self, data, args, attr_align_model):
+        self.predicate_align_model = attr_align_model
+        self.args = args
+        self.__check_args()
+        self.data = data
+        self.kgs = kgs = data.kgs
+        self.kg1 = kgs.kg1
+        self.kg2 = kgs.kg2
+        self.out_folder = generate_out_folder(self.args.output, self.args.training_data, '', self.__class__.__name__)
+        self.session = None  # there is no TF session; kept so that `x.eval(session=model.session)` call sites work
+        self.device = torch.device("cuda")
+        self.engine = StepEngine(self.device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(getattr(args, "seed", 0)))
+        self._lists: dict = {}
+        if self.args.optimizer not in _HIP_OPTS:
+            raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: only Adagrad and SGD run on the HIP path")
+
+    # ------------------------------------------------------------------------------------------------
+    def _define_variables(self):
+        """code/MultiKE_model.py:86-107."""
+        d, dev = self.args.dim, self.device
+        seed = int(getattr(self.args, "seed", 0))
+        self.literal_embeds = EmbeddingTable(len(self.data.value_vectors), d, "literal_embeds", normalize=False,
+                                             trainable=False, values=self.data.value_vectors, device=dev)
+        self.name_embeds = EmbeddingTable(self.kgs.entities_num, d, "name_embeds", normalize=False, trainable=False,
+                                          values=self.data.local_name_vectors, device=dev)
+        self.rv_ent_embeds = EmbeddingTable(self.kgs.entities_num, d, "rv_ent_embeds", True, device=dev, seed=seed + 1)
+        self.rel_embeds = EmbeddingTable(self.kgs.relations_num, d, "rel_embeds", True, device=dev, seed=seed + 2)
+        self.av_ent_embeds = EmbeddingTable(self.kgs.entities_num, d, "av_ent_embeds", True, device=dev, seed=seed + 3)
+        # "False important!" (code/MultiKE_model.py:96-97): attribute embeddings are NOT read through l2_normalize
+        self.attr_embeds = EmbeddingTable(self.kgs.attributes_num, d, "attr_embeds", False, device=dev, seed=seed + 4)
+        self.ent_embeds = EmbeddingTable(self.kgs.entities_num, d, "ent_embeds", True, device=dev, seed=seed + 5)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed + 6)
+
+        def orthogonal():  # tf.initializers.orthogonal(): QR of a normal matrix, sign-fixed
+            q, r = torch.linalg.qr(torch.randn(d, d, generator=g))
+            return (q * torch.sign(torch.diagonal(r))).to(dev).requires_grad_(True)
+
+        self.nv_mapping, self.rv_mapping, self.av_mapping = orthogonal(), orthogonal(), orthogonal()
+        self.eye_mat = torch.eye(d, device=dev)
+
+    # --- view-specific embedding models ---------------------------------------------------------------
+    def _define_name_view_graph(self):
+        pass
+
+    def _define_relation_view_graph(self):
+        """code/MultiKE_model.py:114-132.  The known-triple filter is `local_relation_triples_set`, which in the
+        reference aliases the set that also holds the swapped triples."""
+        dev = self.device
+        sides = []
+        for kg in (self.kg1, self.kg2):
+            known = np.asarray(sorted(kg.local_relation_triples_set), dtype=np.int32).reshape(-1, 3)
+            t = torch.as_tensor(known, device=dev)
+            sides.append(KGSide(kg.entities_list,
+                                KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous()), device=dev))
+        self._rel_batcher = RelationBatcher(self.kg1.local_relation_triples_list, self.kg2.local_relation_triples_list,
+                                            sides[0], sides[1], self.args.batch_size, self.args.neg_triple_num, device=dev,
+                                            seed=int(getattr(self.args, "seed", 0)))
+        self._rel_runner = RelationViewRunner(self.rv_ent_embeds, self.rel_embeds, self._rel_batcher, "relation",
+                                              lr=self.args.learning_rate, optimizer=self.args.optimizer)
+        self._neighbor_ids = (None, None)
+
+    def _define_attribute_view_graph(self):
+        """code/MultiKE_model.py:134-151 (variable_scope 'cnn')."""
+        self._attr_cnn = AttrCNN(self.args.dim, self.device, seed=int(getattr(self.args, "seed", 0)) + 11)
+
+    # --- cross-kg identity inference --------------------------------------------------------------------
+    def _define_cross_kg_name_view_graph(self):
+        pass
+
+    def _define_cross_kg_entity_reference_relation_view_graph(self):
+        """code/MultiKE_model.py:158-169: 2 * relation_logistic_loss_wo_negs, optimizer slot 'ckge_rel'."""
+        self._ckge_rel = dict(opt="ckge_rel", scale=2.0)
+
+    def _define_cross_kg_entity_reference_attribute_view_graph(self):
+        """code/MultiKE_model.py:171-185: its own CNN parameter set (name_scope only => new tf.layers variables)."""
+        self._ckge_attr_cnn = AttrCNN(self.args.dim, self.device, seed=int(getattr(self.args, "seed", 0)) + 12)
+
+    def _define_cross_kg_relation_reference_graph(self):
+        """code/MultiKE_model.py:187-201: 2 * logistic_loss_wo_negs (weighted), slot 'ckgp_rel'."""
+        self._ckgp_rel = dict(opt="ckgp_rel", scale=2.0)
+
+    def _define_cross_kg_attribute_reference_graph(self):
+        """code/MultiKE_model.py:203-221: weighted, NOT doubled (:218), third CNN parameter set."""
+        self._ckga_attr_cnn = AttrCNN(self.args.dim, self.device, seed=int(getattr(self.args, "seed", 0)) + 13)
+
+    # --- intermediate combination -----------------------------------------------------------------------
+    def _define_common_space_learning_graph(self):
+        """code/MultiKE_model.py:225-239: optimizer on cv_weight * loss with ITC_learning_rate, slot 'cross_name'."""
+        self._cross_name = dict(opt="cross_name", lr=self.args.ITC_learning_rate)
+
+    def _define_space_mapping_graph(self):
+        """code/MultiKE_model.py:241-261: only variables whose name starts with 'shared' are optimised:
+        ent_embeds ('shared'+'embeddings') and the three mappings ('shared'+'combination')."""
+        self._shared_comb = DenseOptimizerState([self.nv_mapping, self.rv_mapping, self.av_mapping], self.args.learning_rate,
+                                                self.args.optimizer)
+
+    # --- read paths -----------------------------------------------------------------------------------------
+    def eval_kg1_ent_embeddings(self):
+        return self.rv_ent_embeds.lookup(_dev_i32(self.kgs.kg1.entities_list, self.device)).cpu().numpy()
+
+    def eval_kg2_ent_embeddings(self):
+        return self.rv_ent_embeds.lookup(_dev_i32(self.kgs.kg2.entities_list, self.device)).cpu().numpy()
+
+    def eval_kg1_useful_ent_embeddings(self):
+        return self.rv_ent_embeds.lookup(_dev_i32(self.kgs.useful_entities_list1, self.device)).cpu().numpy()
+
+    def eval_kg2_useful_ent_embeddings(self):
+        return self.rv_ent_embeds.lookup(_dev_i32(self.kgs.useful_entities_list2, self.device)).cpu().numpy()
+
+    def save(self):
+        """code/MultiKE_model.py:279-287: same six .npy files and id TSVs."""
+        save_embeddings(self.out_folder, self.kgs, self.ent_embeds.eval(), self.name_embeds.eval(), self.rv_ent_embeds.eval(),
+                        self.av_ent_embeds.eval(), self.rel_embeds.eval(), self.attr_embeds.eval())
+
+    # --- helpers ----------------------------------------------------------------------------------------------
+    def _list(self, triples) -> _TripleList:
+        key = id(triples)
+        hit = self._lists.get(key)
+        if hit is None or hit[0] != len(triples):
+            hit = (len(triples), _TripleList(triples, self.device))
+            self._lists[key] = hit
+        return hit[1]
+
+    def _set_neighbours(self, neighbors1, neighbors2):
+        """Truncated-sampling dicts {entity: [k neighbours]} (code/base/batch.py:119-150) -> device candidate tables."""
+        ids = (id(neighbors1), id(neighbors2))
+        if ids == self._neighbor_ids:
+            return
+        self._neighbor_ids = ids
+        for side, nb in ((self._rel_batcher.side1, neighbors1), (self._rel_batcher.side2, neighbors2)):
+            if not nb:
+                side.set_neighbours(None, None)
+                continue
+            k = min(len(v) for v in nb.values())
+            table = np.zeros((self.kgs.entities_num, k), dtype=np.int32)
+            valid = np.zeros(self.kgs.entities_num, dtype=np.uint8)
+            for e, lst in nb.items():
+                table[e] = np.asarray(lst[:k], dtype=np.int32)
+                valid[e] = 1
+            side.set_neighbours(torch.as_tensor(table, device=self.device), torch.as_tensor(valid, device=self.device))
+
+    # --- training for multi-view embeddings ---------------------------------------------------------------
+    def train_relation_view_1epo(self, epoch, triple_steps, steps_tasks, batch_queue, neighbors1, neighbors2):
+        """code/MultiKE_model.py:291-317.  `steps_tasks` / `batch_queue` are accepted for driver compatibility; batches
+        are produced and consumed on the device by the native step runner."""
+        start = time.time()
+        self._set_neighbours(neighbors1, neighbors2)
+        run = self._rel_runner
+        steps = min(triple_steps, run.steps)
+        run.run(0, steps)
+        trained = int(self._rel_batcher.off[steps])
+        epoch_loss = float(run.loss[:steps].sum()) / max(trained, 1)
+        self._rel_batcher.shuffle()  # random.shuffle of both positive lists (:314-315)
+        print('epoch {} of rel. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
+        return epoch_loss
+
+    def _attr_lists(self):
+        pam = self.predicate_align_model
+        key = (id(pam.attribute_triples_w_weights1), id(pam.attribute_triples_w_weights2))
+        if getattr(self, "_attr_key", None) != key:
+            self._attr_key = key
+            self._attr1 = _TripleList(pam.attribute_triples_w_weights1, self.device)
+            self._attr2 = _TripleList(pam.attribute_triples_w_weights2, self.device)
+            self._attr_perm = [None, None]
+        return self._attr1, self._attr2
+
+    def train_attribute_view_1epo(self, epoch, triple_steps, steps_tasks, batch_queue, neighbors1, neighbors2):
+        """code/MultiKE_model.py:319-345: weighted positives only (neg_triples_num = 0, :331), CNN scorer."""
+        from .sampling import kg_batch_split
+        start = time.time()
+        l1, l2 = self._attr_lists()
+        B = self.args.attribute_batch_size
+        b1, b2 = kg_batch_split(l1.n, l2.n, B)
+        total = None
+        trained = 0
+        for step in range(triple_steps):
+            parts = []
+            for li, (lst, b) in enumerate(((l1, b1), (l2, b2))):
+                lo, hi = min(step * b, lst.n), min((step + 1) * b, lst.n)
+                if hi > lo:
+                    perm = self._attr_perm[li]
+                    sl = slice(lo, hi) if perm is None else perm[lo:hi]
+                    parts.append(tuple(c[sl] for c in lst.cols) + (lst.w[sl],))
+            if not parts:
+                continue
+            ih, ia, iv, w = (torch.cat([p[k] for p in parts]).contiguous() for k in range(4))
+            lp = self._attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds, ih, ia, iv, w,
+                                     scale=1.0, opt_name="attribute", lr=self.args.learning_rate,
+                                     optimizer=self.args.optimizer)
+            s = lp.sum()
+            total = s if total is None else total + s
+            trained += ih.numel()
+        epoch_loss = (float(total) if total is not None else 0.0) / max(trained, 1)
+        # random.shuffle of both weighted lists (:342-343): a device permutation applied at slicing time
+        self._attr_perm = [torch.randperm(l.n, generator=self._gen, device=self.device) if l.n else None for l in (l1, l2)]
+        print('epoch {} of att. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
+        return epoch_loss
+
+    # --- training for cross-kg identity inference ----------------------------------------------------------
+    def _positives_epoch(self, epoch, sup_triples, batch_size, step_fn, label):
+        """Shared loop shape of code/MultiKE_model.py:349-437: steps = ceil(len / B); each step is
+        random.sample(sup_triples, B) (B = len if one step)."""
+        if len(sup_triples) == 0:
+            return None
+        start = time.time()
+        lst = self._list(sup_triples)
+        steps = int(math.ceil(lst.n / batch_size))
+        bs = batch_size if steps > 1 else lst.n
+        total = None
+        for _ in range(steps):
+            cols, w = lst.sample(bs, self._gen)
+            s = step_fn(cols, w).sum()
+            total = s if total is None else total + s
+        epoch_loss = float(total) / (steps * bs)
+        print('epoch {} of {}, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, label, epoch_loss, time.time() - start))
+        return epoch_loss
+
+    def train_cross_kg_entity_inference_relation_view_1epo(self, epoch, sup_triples):
+        """code/MultiKE_model.py:349-369."""
+        g = self._ckge_rel
+        return self._positives_epoch(
+            epoch, sup_triples, self.args.batch_size,
+            lambda cols, w: self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, g["opt"], cols, None,
+                                                      lr=self.args.learning_rate, scale=g["scale"],
+                                                      optimizer=self.args.optimizer),
+            'cross-kg entity inference in rel. view')
+
+    def train_cross_kg_entity_inference_attribute_view_1epo(self, epoch, sup_triples):
+        """code/MultiKE_model.py:371-391: 2 * sum log(1+exp(-conv))."""
+        return self._positives_epoch(
+            epoch, sup_triples, self.args.attribute_batch_size,
+            lambda cols, w: self._ckge_attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
+                                                     cols[0], cols[1], cols[2], None, scale=2.0, opt_name="ckge_attr",
+                                                     lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            'cross-kg entity inference in attr. view')
+
+    def train_cross_kg_relation_inference_1epo(self, epoch, sup_triples):
+        """code/MultiKE_model.py:393-414: weighted 4-tuples, x2."""
+        g = self._ckgp_rel
+        return self._positives_epoch(
+            epoch, sup_triples, self.args.batch_size,
+            lambda cols, w: self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, g["opt"], cols, None,
+                                                      lr=self.args.learning_rate, pos_w=w, scale=g["scale"],
+                                                      optimizer=self.args.optimizer),
+            'cross-kg relation inference in rel. view')
+
+    def train_cross_kg_attribute_inference_1epo(self, epoch, sup_triples):
+        """code/MultiKE_model.py:416-437: weighted, not doubled."""
+        return self._positives_epoch(
+            epoch, sup_triples, self.args.attribute_batch_size,
+            lambda cols, w: self._ckga_attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
+                                                     cols[0], cols[1], cols[2], w, scale=1.0, opt_name="ckga_attr",
+                                                     lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            'cross-kg attribute inference in attr. view')
+
+    # --- shared / common space ------------------------------------------------------------------------------
+    def _entity_batches(self, entities, batch_size):
+        key = ("ents", id(entities), len(entities))
+        t = self._lists.get(key)
+        if t is None:
+            t = _dev_i32(entities, self.device)
+            self._lists[key] = t
+        steps = int(math.ceil(len(entities) / batch_size))
+        bs = batch_size if steps > 1 else len(entities)
+        for _ in range(steps):
+            yield t[torch.randperm(t.numel(), generator=self._gen, device=self.device)[:bs]].contiguous(), bs
+
+    def train_shared_space_mapping_1epo(self, epoch, entities):
+        """code/MultiKE_model.py:439-454 + graph :241-261 (SSL).  Three space_mapping_loss terms; the dense part is a
+        75x75 GEMM (torch / rocBLAS); the `ent_embeds` rows are updated through the HIP scatter + row update."""
+        start = time.time()
+        st = self._shared_comb
+        total, trained = None, 0
+        for idx, bs in self._entity_batches(entities, self.args.entity_batch_size):
+            final = self.ent_embeds.lookup(idx).requires_grad_(True)
+            views = (self.name_embeds.lookup(idx), self.rv_ent_embeds.lookup(idx), self.av_ent_embeds.lookup(idx))
+            loss = sum(losses.space_mapping_loss(v, final, m, self.eye_mat, self.args.orthogonal_weight)
+                       for v, m in zip(views, st.vars))
+            grads = torch.autograd.grad(loss, [final] + st.vars)
+            st.apply(grads[1:])
+            tag, _ = self.engine._next()
+            self.ent_embeds.grad[:, :self.args.dim].index_add_(0, idx.long(), grads[0])
+            self.ent_embeds.touched[idx.long()] = tag
+            self.engine._apply(self.ent_embeds, "shared_comb", self.args.optimizer, self.args.learning_rate, tag)
+            total = loss.detach() if total is None else total + loss.detach()
+            trained += bs
+        epoch_loss = float(total) / max(trained, 1)
+        print('epoch {} of shared space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
+                                                                                           time.time() - start))
+        return epoch_loss
+
+    def train_common_space_learning_1epo(self, epoch, entities):
+        """code/MultiKE_model.py:458-473 + graph :225-239 (ITC): cv_name_weight*align(ent,name) + align(ent,rv) +
+        align(ent,av); the optimizer minimises cv_weight * loss with ITC_learning_rate; the reported loss is unscaled."""
+        start = time.time()
+        g = self._cross_name
+        cvw = float(self.args.cv_weight)
+        total, trained = None, 0
+        for idx, bs in self._entity_batches(entities, self.args.entity_batch_size):
+            terms = [(self.ent_embeds, idx, self.name_embeds, idx, cvw * float(self.args.cv_name_weight)),
+                     (self.ent_embeds, idx, self.rv_ent_embeds, idx, cvw),
+                     (self.ent_embeds, idx, self.av_ent_embeds, idx, cvw)]
+            s = self.engine.alignment_step(terms, g["opt"], g["lr"], optimizer=self.args.optimizer)
+            total = s if total is None else total + s
+            trained += bs
+        epoch_loss = float(total) / cvw / max(trained, 1) if cvw != 0 else 0.0
+        print('epoch {} of common space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
+                                                                                           time.time() - start))
+        return epoch_loss
