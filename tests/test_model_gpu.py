@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 def _model(**over):
     from multike_amd.MultiKE_model import MultiKE
     from multike_amd.synthetic import SyntheticData, synthetic_args
-    data = SyntheticData(dim=32)
-    args = synthetic_args(dim=32, batch_size=700, attribute_batch_size=600, entity_batch_size=800, neg_triple_num=5,
+    data = SyntheticData(dim=20)
+    args = synthetic_args(dim=20, batch_size=700, attribute_batch_size=600, entity_batch_size=800, neg_triple_num=5,
                           learning_rate=0.01, **over)
     m = MultiKE(data, args, data.predicate_align_model)
     m._define_variables()
