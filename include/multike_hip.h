@@ -343,6 +343,22 @@ int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials,
 int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (9) Alignment evaluator ("next" row §8f-2): rank of the gold counterpart and arg-max column under the inner
+ *     product of (already normalised) embeddings, on the f32 matrix cores, without materialising the matrix.
+ *
+ * replaces: code/base/similarity.py:30-34 (sim = E1 . E2^T) + code/base/alignment.py:141-163 calculate_rank
+ *           (argsort / argpartition per row, gold located by position) as used by greedy_alignment (:8-79).
+ *
+ *   emb1   : [n1][ld1], columns [dim, kpad) zero.           emb2_t : [kpad][ld2t] = E2 TRANSPOSED, columns >= n2 zero,
+ *   ld2t >= round_up(max(n1, n2), 32).  Gold column of row i is i (so n2 >= n1).
+ *   rank[i] += #{j < n2 : sim[i][j] > sim[i][i]}  (rank zeroed by the caller);
+ *   best[i]  = max over j of (ordered(sim[i][j]) << 32 | 0xFFFFFFFF - j)  (best zeroed by the caller; arg-max column =
+ *              0xFFFFFFFF - low word, lowest column on ties).
+ * ------------------------------------------------------------------------------------------------ */
+int mke_align_rank(const float* emb1, int ld1, const float* emb2_t, int64_t ld2t, int kpad, int64_t n1, int64_t n2,
+                   int32_t* rank, uint64_t* best, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ SYMBOLS = (
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
-    "mke_dense_update",
+    "mke_dense_update", "mke_align_rank",
 )
 
 
@@ -352,3 +352,10 @@ def dense_update(param, acc, grad, optimizer, lr):
                                 _dev(grad, torch.float32, "grad"), C.c_int64(param.numel()), C.c_int(optimizer), C.c_float(lr),
                                 _stream())
     _check(rc, "mke_dense_update")
+
+
+def align_rank(emb1, emb2_t, kpad, n1, n2, rank, best):
+    rc = lib().mke_align_rank(_dev(emb1, torch.float32, "emb1"), C.c_int(emb1.shape[1]), _dev(emb2_t, torch.float32, "emb2_t"),
+                              C.c_int64(emb2_t.shape[1]), C.c_int(kpad), C.c_int64(n1), C.c_int64(n2),
+                              _dev(rank, torch.int32, "rank"), _dev(best, torch.int64, "best"), _stream())
+    _check(rc, "mke_align_rank")

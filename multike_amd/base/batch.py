@@ -86,3 +86,30 @@ def generate_relation_triple_batch_queue(triple_list1, triple_list2, triple_set1
         out_queue.put(generate_relation_triple_batch(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1,
                                                      entity_list2, batch_size, step, neighbor1, neighbor2,
                                                      neg_triples_num))
+
+
+def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, device="cuda", block_rows=4096):
+    """Truncated-sampling k-NN refresh on the device (code/base/batch.py:119-150): inner product of the (already
+    row-normalised) relation-view rows of one KG's useful entities, top `neighbors_num` per row INCLUDING the entity
+    itself, unordered.  Returns (cand_table [n_ent_total, k] int32, cand_valid [n_ent_total] uint8) for
+    `KGSide.set_neighbours`.  The similarity block and the top-k selection are library ops (rocBLAS GEMM, torch.topk)."""
+    e = torch.as_tensor(np.asarray(entity_embeds), dtype=torch.float32, device=device)
+    ids = torch.as_tensor(np.asarray(entity_list), dtype=torch.int64, device=device)
+    n = e.shape[0]
+    k = int(neighbors_num)
+    table = torch.zeros(n_ent_total, k, dtype=torch.int32, device=device)
+    valid = torch.zeros(n_ent_total, dtype=torch.uint8, device=device)
+    for lo in range(0, n, block_rows):
+        sim = e[lo:lo + block_rows] @ e.t()
+        idx = torch.topk(sim, k, dim=1, sorted=False).indices
+        table[ids[lo:lo + block_rows]] = ids[idx].to(torch.int32)
+    valid[ids] = 1
+    return table, valid
+
+
+def generate_neighbours(entity_embeds, entity_list, neighbors_num, threads_num):
+    """code/base/batch.py:119-140 — dict {entity: [k neighbours]} (the reference's return type)."""
+    n_total = int(max(entity_list)) + 1
+    table, _ = neighbour_table(entity_embeds, entity_list, neighbors_num, n_total)
+    rows = table[torch.as_tensor(np.asarray(entity_list), dtype=torch.int64, device=table.device)].cpu().numpy()
+    return {int(e): rows[i].tolist() for i, e in enumerate(entity_list)}

@@ -295,6 +295,30 @@ def cnn_fixture(out):
         out[pre + "g_hs"], out[pre + "g_as"] = th.grad.numpy(), ta.grad.numpy()
 
 
+def eval_fixture(ref_alignment, out):
+    """The reference's own greedy_alignment (code/base/alignment.py:8-79), single worker, on random embeddings."""
+    import contextlib, io
+    for ci, (n1, n2, d) in enumerate(((200, 300, 75), (64, 64, 20))):
+        rng = np.random.default_rng(900 + ci)
+        e2 = rng.standard_normal((n2, d)).astype(np.float32)
+        e1 = (0.6 * e2[:n1] + rng.standard_normal((n1, d))).astype(np.float32)   # gold = same index, noisy
+        top_k = [1, 5, 10, 50]
+        with contextlib.redirect_stdout(io.StringIO()):
+            rest_a, h1_a, mr_a, mrr_a = ref_alignment.greedy_alignment(e1, e2, top_k, 1, "inner", True, 0, True)
+            mr_q, mrr_q, hits_q, _ = ref_alignment.calculate_rank(list(range(n1)), ref_alignment.sim(e1, e2, normalize=True),
+                                                                   top_k, False, n1)
+            mr_x, mrr_x, hits_x, _ = ref_alignment.calculate_rank(list(range(n1)), ref_alignment.sim(e1, e2, normalize=True),
+                                                                   top_k, True, n1)
+        pre = f"e{ci}_"
+        out[pre + "e1"], out[pre + "e2"] = e1, e2
+        out[pre + "top_k"] = np.array(top_k)
+        out[pre + "hits_accurate"] = np.round(np.array(hits_x) / n1 * 100, 3)
+        out[pre + "hits_quick"] = np.round(np.array(hits_q) / n1 * 100, 3)
+        out[pre + "hits1"] = np.float64(h1_a)
+        out[pre + "mr"], out[pre + "mrr"] = np.float64(mr_a), np.float64(mrr_a)
+        out[pre + "rest"] = np.array(sorted(rest_a), dtype=np.int64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -316,6 +340,9 @@ def main():
     cnn = {}
     cnn_fixture(cnn)
     np.savez_compressed(os.path.join(HERE, "cnn_golden.npz"), **cnn)
+    ev = {}
+    eval_fixture(importlib.import_module("base.alignment"), ev)
+    np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **ev)
     js = {}
     sampler_fixture(ref_batch, ref_attr_batch, js)
     host_fixture(ref_utils, js)

@@ -1,0 +1,64 @@
+"""GPU parity of the MFMA alignment evaluator (mke_align_rank) and the k-NN refresh."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import eval_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_golden_metrics_from_reference(ci):
+    from multike_amd.base.alignment import greedy_alignment
+    from multike_amd.base import evaluation as eva
+    g = np.load(os.path.join(GOLDEN, "eval_golden.npz"))
+    pre = f"e{ci}_"
+    top_k = g[pre + "top_k"].tolist()
+    rest, hits1, mr, mrr = greedy_alignment(g[pre + "e1"], g[pre + "e2"], top_k, 8, "inner", True, 0, True)
+    assert hits1 == g[pre + "hits1"]
+    np.testing.assert_allclose(mr, g[pre + "mr"], rtol=1e-9)
+    np.testing.assert_allclose(mrr, g[pre + "mrr"], rtol=1e-9)
+    assert np.array_equal(np.array(sorted(rest)), g[pre + "rest"])
+    h1, mrr2 = eva.valid(g[pre + "e1"], g[pre + "e2"], None, top_k, 8, normalize=True)
+    assert h1 == g[pre + "hits1"]
+
+
+@pytest.mark.parametrize("n1,n2,d", [(1000, 1777, 75), (33, 33, 4), (4097, 6000, 256), (500, 501, 100)])
+def test_ranks_vs_oracle(n1, n2, d):
+    """Ranks are integers: exact except where two similarities are within fp32 rounding of each other."""
+    from multike_amd.base.alignment import alignment_ranks
+    rng = np.random.default_rng(n1 + d)
+    e2 = rng.standard_normal((n2, d)).astype(np.float32)
+    e1 = (0.5 * e2[:n1] + rng.standard_normal((n1, d))).astype(np.float32)
+    rank, best = alignment_ranks(e1, e2)
+    r64, b64 = eo.ranks(e1.astype(np.float64), e2.astype(np.float64))
+    got = rank.cpu().numpy()
+    assert np.mean(got == r64) > 0.995 and np.max(np.abs(got - r64)) <= 2
+    assert np.mean(best.cpu().numpy() == b64) > 0.995
+    # a row's own similarity never counts (gold taken from the same MFMA computation): perfect alignment -> rank 0
+    rank0, best0 = alignment_ranks(e2[:n1], e2)
+    assert int(rank0.max()) == 0 and np.array_equal(best0.cpu().numpy(), np.arange(n1))
+
+
+def test_neighbour_table_matches_reference_definition():
+    """top-k inner products per row, self included, unordered (code/base/batch.py:143-150)."""
+    import torch
+    from multike_amd.base.batch import generate_neighbours, neighbour_table
+    rng = np.random.default_rng(0)
+    n, d, k = 700, 20, 15
+    e = rng.standard_normal((n, d)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    ids = (np.arange(n) * 3 + 5).tolist()
+    table, valid = neighbour_table(e, ids, k, n_ent_total=3 * n + 10)
+    sim = e.astype(np.float64) @ e.astype(np.float64).T
+    t = table.cpu().numpy()
+    for i in (0, 13, 699):
+        exp = set(np.asarray(ids)[np.argpartition(-sim[i], k)[:k]].tolist())
+        got = set(t[ids[i]].tolist())
+        assert len(got & exp) >= k - 1 and ids[i] in got
+    assert int(valid.sum()) == n
+    dic = generate_neighbours(e, ids, k, 4)
+    assert set(dic.keys()) == set(ids) and len(dic[ids[0]]) == k
