@@ -1,0 +1,202 @@
+"""MultiKE_Late.py surface of the reference (code/MultiKE_Late.py): `valid` / `test` / weighted view averaging
+(`wva`, `valid_WVA`, `test_WVA`) and the SSL driver `MultiKE_Late` (late combination: view training, then
+`shared_learning_max_epoch` epochs of shared-space mapping).  The callers of the hot path — §8f-1 "next" row: same
+phase order, gates (`i > start_predicate_soft_alignment`, `i % eval_freq`, `i % truncated_freq`), step counts and loss
+normalisation as the reference; the work itself runs on the GPU through `MultiKE_model.MultiKE`."""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+
+from .base import evaluation as eva
+from .base.batch import neighbour_table
+from .MultiKE_model import MultiKE
+from .utils import task_divide
+
+
+def _view_embeddings(model, embed_choice, w):
+    """code/MultiKE_Late.py:15-28 / 40-53: which [|E|, dim] matrix an `embed_choice` denotes (normalised views)."""
+    pick = {"nv": model.name_embeds, "rv": model.rv_ent_embeds, "av": model.av_ent_embeds, "final": model.ent_embeds}
+    if embed_choice in pick:
+        return pick[embed_choice].eval(session=model.session)
+    if embed_choice == "avg":
+        return (w[0] * model.name_embeds.eval(session=model.session) + w[1] * model.rv_ent_embeds.eval(session=model.session)
+                + w[2] * model.av_ent_embeds.eval(session=model.session))
+    return model.ent_embeds.eval(session=model.session)
+
+
+def valid(model, embed_choice='avg', w=(1, 1, 1)):
+    """code/MultiKE_Late.py:14-36: valid entities of KG1 against valid+test entities of KG2."""
+    ent_embeds = _view_embeddings(model, embed_choice, w)
+    print(embed_choice, 'valid results:')
+    embeds1 = ent_embeds[model.kgs.valid_entities1, ]
+    embeds2 = ent_embeds[model.kgs.valid_entities2 + model.kgs.test_entities2, ]
+    _, mrr_12 = eva.valid(embeds1, embeds2, None, model.args.top_k, model.args.test_threads_num, normalize=True)
+    return mrr_12
+
+
+def test(model, embed_choice='avg', w=(1, 1, 1)):
+    """code/MultiKE_Late.py:39-61."""
+    ent_embeds = _view_embeddings(model, embed_choice, w)
+    print(embed_choice, 'test results:')
+    embeds1 = ent_embeds[model.kgs.test_entities1, ]
+    embeds2 = ent_embeds[model.kgs.test_entities2, ]
+    _, mrr_12 = eva.valid(embeds1, embeds2, None, model.args.top_k, model.args.test_threads_num, normalize=True)
+    return mrr_12
+
+
+def _unit_rows(x):
+    n = np.linalg.norm(x, axis=1, keepdims=True)
+    return x / np.where(n == 0, 1.0, n)
+
+
+def _compute_weight(embeds1, embeds2, embeds3):
+    """code/MultiKE_Late.py:64-81: mean cosine between a view and the average of the three views."""
+    other = _unit_rows((embeds1 + embeds2 + embeds3) / 3)
+    weights = np.sum(_unit_rows(embeds1) * other, axis=1)  # the diagonal of the similarity matrix, without the matrix
+    print(weights.shape, np.mean(weights))
+    return np.mean(weights)
+
+
+def wva(embeds1, embeds2, embeds3):
+    """code/MultiKE_Late.py:84-88 (the function returns after the three weights; the rest of its body is dead)."""
+    return (_compute_weight(embeds1, embeds2, embeds3), _compute_weight(embeds2, embeds1, embeds3),
+            _compute_weight(embeds3, embeds1, embeds2))
+
+
+def _wva_eval(model, ents1, ents2, label):
+    views = (model.name_embeds.eval(), model.rv_ent_embeds.eval(), model.av_ent_embeds.eval())
+    v1 = [v[ents1, ] for v in views]
+    v2 = [v[ents2, ] for v in views]
+    wsum = np.array(wva(*v1)) + np.array(wva(*v2))
+    wsum = wsum / wsum.sum()
+    print('weights', *wsum)
+    embeds1 = sum(w * v for w, v in zip(wsum, v1))
+    embeds2 = sum(w * v for w, v in zip(wsum, v2))
+    print(label)
+    _, mrr_12 = eva.valid(embeds1, embeds2, None, model.args.top_k, model.args.test_threads_num, normalize=True)
+    return mrr_12
+
+
+def valid_WVA(model):
+    """code/MultiKE_Late.py:99-135."""
+    return _wva_eval(model, model.kgs.valid_entities1, model.kgs.valid_entities2 + model.kgs.test_entities2,
+                     'wvag valid results:')
+
+
+def test_WVA(model):
+    """code/MultiKE_Late.py:138-173."""
+    return _wva_eval(model, model.kgs.test_entities1, model.kgs.test_entities2, 'wvag test results:')
+
+
+class _ScheduledMultiKE(MultiKE):
+    """What `MultiKE_CV.run` and `MultiKE_Late.run` share (code/MultiKE_CSL.py:36-56, code/MultiKE_Late.py:201-223):
+    step counts, supervision lists, the per-epoch view training block and the periodic refreshes."""
+
+    def _prepare(self):
+        kgs, pam, a = self.kgs, self.predicate_align_model, self.args
+        rel_n = kgs.kg1.local_relation_triples_num + kgs.kg2.local_relation_triples_num
+        attr_n = kgs.kg1.local_attribute_triples_num + kgs.kg2.local_attribute_triples_num
+        self._rel_steps = int(math.ceil(rel_n / a.batch_size))
+        self._attr_steps = int(math.ceil(attr_n / a.batch_size))  # the reference divides by batch_size here too
+        self._rel_tasks = task_divide(list(range(self._rel_steps)), a.batch_threads_num)
+        self._attr_tasks = task_divide(list(range(self._attr_steps)), a.batch_threads_num)
+        self._ckge_rel_triples = kgs.kg1.sup_relation_triples_list + kgs.kg2.sup_relation_triples_list
+        self._ckge_attr_triples = kgs.kg1.sup_attribute_triples_list + kgs.kg2.sup_attribute_triples_list
+        self._refresh_predicate_lists()
+        self._neighbors = (None, None)
+        self._entity_list = kgs.kg1.entities_list + kgs.kg2.entities_list
+
+    def _refresh_predicate_lists(self):
+        pam = self.predicate_align_model
+        self._ckgp_rel_triples = pam.sup_relation_alignment_triples1 + pam.sup_relation_alignment_triples2
+        self._ckga_attr_triples = pam.sup_attribute_alignment_triples1 + pam.sup_attribute_alignment_triples2
+
+    def _train_views(self, i):
+        """One epoch of the six view / cross-KG phases in the reference's order."""
+        a = self.args
+        n1, n2 = self._neighbors
+        self.train_relation_view_1epo(i, self._rel_steps, self._rel_tasks, None, n1, n2)
+        self.train_cross_kg_entity_inference_relation_view_1epo(i, self._ckge_rel_triples)
+        if i > a.start_predicate_soft_alignment:
+            self.train_cross_kg_relation_inference_1epo(i, self._ckgp_rel_triples)
+        self.train_attribute_view_1epo(i, self._attr_steps, self._attr_tasks, None, n1, n2)
+        self.train_cross_kg_entity_inference_attribute_view_1epo(i, self._ckge_attr_triples)
+        if i > a.start_predicate_soft_alignment:
+            self.train_cross_kg_attribute_inference_1epo(i, self._ckga_attr_triples)
+
+    def _update_predicate_alignment(self):
+        """code/MultiKE_CSL.py:80-87 / code/MultiKE_Late.py:244-251 (host-side soft predicate alignment)."""
+        pam = self.predicate_align_model
+        if hasattr(pam, "update_predicate_alignment"):
+            pam.update_predicate_alignment(self.rel_embeds.eval(session=self.session))
+            pam.update_predicate_alignment(self.attr_embeds.eval(session=self.session), predicate_type='attribute')
+        self._refresh_predicate_lists()
+
+    def _refresh_neighbours(self, i):
+        """Truncated negative sampling: k-NN candidate lists every `truncated_freq` epochs
+        (code/MultiKE_CSL.py:89-102).  Stays on the device: (candidate table, valid flags) per KG."""
+        a, kgs = self.args, self.kgs
+        if a.neg_sampling != 'truncated' or i % a.truncated_freq != 0:
+            return
+        t1 = time.time()
+        assert 0.0 < a.truncated_epsilon < 1.0
+        out = []
+        for kg, useful in ((kgs.kg1, kgs.useful_entities_list1), (kgs.kg2, kgs.useful_entities_list2)):
+            k = max(int((1 - a.truncated_epsilon) * kg.entities_num), a.neg_triple_num)
+            emb = self.rv_ent_embeds.lookup(self._ids(useful))
+            out.append(neighbour_table(emb, useful, k, kgs.entities_num, device=self.device))
+        self._neighbors = tuple(out)
+        print("generating neighbors of {} entities costs {:.3f} s.".format(len(self._entity_list), time.time() - t1))
+
+    def _ids(self, lst):
+        import torch
+        return torch.as_tensor(np.asarray(lst, dtype=np.int32), device=self.device)
+
+
+class MultiKE_Late(_ScheduledMultiKE):
+    """code/MultiKE_Late.py:176-280 — run_SSL.py's model."""
+
+    def __init__(self, data, args, attr_align_model):
+        super().__init__(data, args, attr_align_model)
+        self.flag1, self.flag2, self.early_stop = -1, -1, False
+        self._define_variables()
+        self._define_name_view_graph()
+        self._define_relation_view_graph()
+        self._define_attribute_view_graph()
+        self._define_cross_kg_entity_reference_relation_view_graph()
+        self._define_cross_kg_entity_reference_attribute_view_graph()
+        self._define_cross_kg_relation_reference_graph()
+        self._define_cross_kg_attribute_reference_graph()
+        self._define_common_space_learning_graph()
+        self._define_space_mapping_graph()
+
+    def run(self):
+        a = self.args
+        self._prepare()
+        valid(self, embed_choice='nv')
+        valid(self, embed_choice='avg')
+        for i in range(1, a.max_epoch + 1):
+            print('epoch {}:'.format(i))
+            self._train_views(i)
+            if i >= a.start_valid and i % a.eval_freq == 0:
+                valid(self, embed_choice='rv')
+                valid(self, embed_choice='av')
+                valid(self, embed_choice='avg')
+                valid_WVA(self)
+                if i >= a.start_predicate_soft_alignment:
+                    self._update_predicate_alignment()
+            if self.early_stop or i == a.max_epoch:
+                break
+            self._refresh_neighbours(i)
+        for i in range(1, a.shared_learning_max_epoch + 1):
+            self.train_shared_space_mapping_1epo(i, self._entity_list)
+            if i >= a.start_valid and i % a.eval_freq == 0:
+                valid(self, embed_choice='final')
+        self.save()
+        results = {k: test(self, embed_choice=k) for k in ('nv', 'rv', 'av', 'avg')}
+        results['wva'] = test_WVA(self)
+        results['final'] = test(self, embed_choice='final')
+        return results

@@ -265,8 +265,11 @@ class MultiKE:
             return
         self._neighbor_ids = ids
         for side, nb in ((self._rel_batcher.side1, neighbors1), (self._rel_batcher.side2, neighbors2)):
-            if not nb:
+            if nb is None or (isinstance(nb, dict) and not nb):
                 side.set_neighbours(None, None)
+                continue
+            if isinstance(nb, tuple):  # already a device (candidate table, valid flags) pair: base.batch.neighbour_table
+                side.set_neighbours(nb[0], nb[1])
                 continue
             k = min(len(v) for v in nb.values())
             table = np.zeros((self.kgs.entities_num, k), dtype=np.int32)

@@ -61,6 +61,12 @@ class SyntheticData:
         n1 = n_ent // 2
         links = [(i, n1 + i) for i in range(int(n1 * link_share))]
         kgs.train_links = links
+        n_tr = len(links)
+        n_va = int(n1 * 0.1)
+        kgs.valid_entities1 = list(range(n_tr, n_tr + n_va))
+        kgs.valid_entities2 = [n1 + i for i in kgs.valid_entities1]
+        kgs.test_entities1 = list(range(n_tr + n_va, n1))
+        kgs.test_entities2 = [n1 + i for i in kgs.test_entities1]
         a1 = max(1, int(n_attr * 0.5))
         kg_list = []
         for k in (0, 1):

@@ -159,3 +159,28 @@ def test_truncated_sampling_neighbours_are_used():
     for i in range(len(ph)):
         for a, b in zip(nh[i], nt[i]):
             assert (a == ph[i] and b in nb[pt[i]]) or (b == pt[i] and a in nb[ph[i]])
+
+
+@pytest.mark.parametrize("mode", ["ITC", "SSL"])
+def test_drivers_run_end_to_end(mode):
+    """run_ITC.py / run_SSL.py shape: Model(data, args, predicate_align_model).run() — a few epochs with every gate
+    exercised (soft-alignment phases from epoch 2, validation every 2 epochs, truncated-sampling refresh every 2)."""
+    from multike_amd.MultiKE_CSL import MultiKE_CV
+    from multike_amd.MultiKE_Late import MultiKE_Late
+    from multike_amd.synthetic import SyntheticData, synthetic_args
+    data = SyntheticData(dim=20)
+    # name vectors that carry the alignment signal: counterpart entities share a (noisy) name vector
+    n1 = data.kgs.entities_num // 2
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((n1, 20)).astype(np.float32)
+    nm = np.concatenate([base, base + 0.3 * rng.standard_normal((n1, 20)).astype(np.float32)])
+    data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
+    args = synthetic_args(dim=20, batch_size=700, attribute_batch_size=600, entity_batch_size=800, neg_triple_num=5,
+                          learning_rate=0.01, max_epoch=4, shared_learning_max_epoch=2, start_valid=2, eval_freq=2,
+                          start_predicate_soft_alignment=1, truncated_freq=2, truncated_epsilon=0.9)
+    cls = MultiKE_CV if mode == "ITC" else MultiKE_Late
+    model = cls(data, args, data.predicate_align_model)
+    res = model.run()
+    assert all(np.isfinite(v) for v in res.values())
+    assert res["nv"] > 0.5                       # the name view alone aligns the synthetic pairs
+    assert model._neighbors[0] is not None and model._rel_batcher.side1.cand_table is not None   # truncated mode active
