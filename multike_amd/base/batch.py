@@ -93,7 +93,8 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     row-normalised) relation-view rows of one KG's useful entities, top `neighbors_num` per row INCLUDING the entity
     itself, unordered.  Returns (cand_table [n_ent_total, k] int32, cand_valid [n_ent_total] uint8) for
     `KGSide.set_neighbours`.  The similarity block and the top-k selection are library ops (rocBLAS GEMM, torch.topk)."""
-    e = torch.as_tensor(np.asarray(entity_embeds), dtype=torch.float32, device=device)
+    e = (entity_embeds.to(device).float() if isinstance(entity_embeds, torch.Tensor)
+         else torch.as_tensor(np.asarray(entity_embeds), dtype=torch.float32, device=device))
     ids = torch.as_tensor(np.asarray(entity_list), dtype=torch.int64, device=device)
     n = e.shape[0]
     k = int(neighbors_num)
