@@ -114,13 +114,12 @@ def main():
     from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
     from multike_amd.synthetic import SyntheticKGs
     from multike_amd.tables import EmbeddingTable, StepEngine
-    from oracle import multike_oracle as mo  # xavier init values only (shared with cpu_baseline)
+    from multike_amd.tables import xavier_truncated_normal  # the product's initialiser (TF1 xavier)
 
     d, N, B = args.dim, args.neg, args.batch
     kgs = SyntheticKGs(n_ent=args.n_ent, n_rel=args.n_rel, seed=1234)
-    rng = np.random.default_rng(1234)
-    ent0 = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
-    rel0 = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
+    ent0 = xavier_truncated_normal(kgs.entities_num, d, "cpu", seed=1234).numpy()
+    rel0 = xavier_truncated_normal(kgs.relations_num, d, "cpu", seed=1235).numpy()
 
     if world > 1 or args.force_sharded:
         if dist is None:  # exercise the sharded path on one GPU (1-rank RCCL group)

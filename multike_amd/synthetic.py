@@ -11,8 +11,11 @@ import numpy as np
 
 
 class SyntheticKGs:
-    def __init__(self, n_ent=200_000, n_rel=550, triples_per_entity=4.6, seed=1234, kg1_share=0.5055):
+    def __init__(self, n_ent=200_000, n_rel=550, triples_per_entity=4.6, seed=1234, kg1_share=0.5055, zipf=0.0):
+        """zipf > 0: head/tail entities drawn with probability ~ rank^-zipf inside each KG (hub entities), the
+        contention variant of SURVEY.md §8d; 0 = uniform."""
         rng = np.random.default_rng(seed)
+        self.zipf = float(zipf)
         self.entities_num, self.relations_num = int(n_ent), int(n_rel)
         e1 = n_ent // 2
         r1 = max(1, int(round(n_rel * 0.6)))
@@ -22,14 +25,21 @@ class SyntheticKGs:
         counts = (int(total * kg1_share), total - int(total * kg1_share))
         self.triples = []
         for (elo, ehi), (rlo, rhi), n in zip(self.ent_range, self.rel_range, counts):
-            self.triples.append(self._uniform_unique(rng, elo, ehi, rlo, max(rhi, rlo + 1), n))
+            self.triples.append(self._uniform_unique(rng, elo, ehi, rlo, max(rhi, rlo + 1), n, self.zipf))
 
     @staticmethod
-    def _uniform_unique(rng, elo, ehi, rlo, rhi, n):
+    def _uniform_unique(rng, elo, ehi, rlo, rhi, n, zipf=0.0):
         got = np.zeros((0, 3), dtype=np.int32)
+        if zipf > 0:
+            pr = np.arange(1, ehi - elo + 1, dtype=np.float64) ** (-zipf)
+            cdf = np.cumsum(pr / pr.sum())
+            perm = rng.permutation(ehi - elo)  # hubs scattered over the id range
+            draw = lambda m: elo + perm[np.minimum(np.searchsorted(cdf, rng.random(m)), ehi - elo - 1)]
+        else:
+            draw = lambda m: rng.integers(elo, ehi, m)
         while len(got) < n:
             m = int((n - len(got)) * 1.1) + 16
-            cand = np.stack([rng.integers(elo, ehi, m), rng.integers(rlo, rhi, m), rng.integers(elo, ehi, m)], 1)
+            cand = np.stack([draw(m), rng.integers(rlo, rhi, m), draw(m)], 1)
             allt = np.concatenate([got, cand.astype(np.int32)], 0)
             key = (allt[:, 0].astype(np.int64) << 38) | (allt[:, 2].astype(np.int64) << 12) | allt[:, 1].astype(np.int64)
             _, first = np.unique(key, return_index=True)

@@ -12,9 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n-ent", type=int, default=200_000); ap.add_argument("--n-rel", type=int, default=550)
 ap.add_argument("--dim", type=int, default=75); ap.add_argument("--neg", type=int, default=25)
 ap.add_argument("--batch", type=int, default=5000); ap.add_argument("--iters", type=int, default=60)
-ap.add_argument("--splits", type=str, default="0,1,2,3,4,5"); ap.add_argument("--copies", type=int, default=8)
+ap.add_argument("--splits", type=str, default="0,1,2,3,4,5"); ap.add_argument("--copies", type=int, default=1); ap.add_argument("--zipf", type=float, default=0.0)
 a = ap.parse_args()
-kgs = SyntheticKGs(n_ent=a.n_ent, n_rel=a.n_rel)
+kgs = SyntheticKGs(n_ent=a.n_ent, n_rel=a.n_rel, zipf=a.zipf)
 d, N = a.dim, a.neg
 E = EmbeddingTable(kgs.entities_num, d, "e", seed=1); R = EmbeddingTable(kgs.relations_num, d, "r", seed=2, grad_copies=a.copies)
 sides = []
