@@ -112,18 +112,28 @@ class ShardedRelationTrainer:
         self._flags = torch.zeros(self.n_ent, **i32)
         self._id_map = torch.zeros(self.n_ent, **i32)                            # global id -> compact row
         self._counts = torch.zeros(G, **i32)
-        self._counts_last = torch.zeros(G, **i32)
-        self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
         self._overflow = torch.zeros(1, **i32)
         self._req = torch.full((G * C,), -1, **i32)                              # re-initialised by scatter_add each step
-        self._want = torch.empty(G * C, **i32)
         self._rows_out = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._rows_in = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._cgrad = torch.zeros(G * C, st, dtype=dtype, device=dev)
         self._ggot = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._ctouched = torch.zeros(G * C, **i32)
-        self._cidx = [torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)]
-        self._neg = tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3))
+        # --- plan phase (sampler -> row-set build -> id exchange -> remap) is table-independent: it runs one step
+        #     ahead on its own stream + communicator, double-buffered, off the critical path of the step ----------
+        self._want2 = [torch.empty(G * C, **i32) for _ in range(2)]
+        self._cidx2 = [[torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)] for _ in range(2)]
+        self._neg2 = [tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3)) for _ in range(2)]
+        self._counts_last = torch.zeros(G, **i32)
+        self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
+        self._cuda = self.device.type == "cuda"
+        if self._cuda:
+            self._plan_stream = torch.cuda.Stream(device=self.device)
+            self._plan_done = [torch.cuda.Event() for _ in range(2)]
+            self._main_done = [torch.cuda.Event() for _ in range(2)]
+            self._main_done_valid = [False, False]
+        self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1) else None
+        self._planned = None  # global step index whose plan is in flight / ready
         self.last_stats = {}
 
     def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
@@ -168,43 +178,81 @@ class ShardedRelationTrainer:
         s = i % self.steps
         return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
 
-    def step(self, i: int):
+    def _plan(self, i: int):
+        """Table-independent half of step i: negatives, row set, id exchange, compact indices -> slot i % 2."""
         s = i % self.steps
-        if s == 0 and i > 0:
-            self.bat.shuffle()
+        slot = i % 2
         b, N, G, C, be = self.bat, self.N, self.world, self.C, self.backend
         a, e = self.my_slice(s)
         n_pos = e - a
         pos = (b.pos_h[a:e], b.pos_r[a:e], b.pos_t[a:e])
-        neg = tuple(x[:n_pos * N] for x in self._neg)
+        neg = tuple(x[:n_pos * N] for x in self._neg2[slot])
         if n_pos and N:
             be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
-        # ---- distinct entity rows this rank needs, grouped by owner in [G][C] slots (device only) ---------------
+        self._req.fill_(-1)
+        self._counts.zero_()
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
-        # ---- requested local rows out, raw rows back (equal-split all-to-alls) -----------------------------------
-        dist.all_to_all_single(self._want, self._req)
-        be.gather_padded(self.ent, self._want, self._rows_out, self._cgrad)      # also clears the compact grad scratch
+        dist.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
+        cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
+        be.rowset_remap(streams, cidx, self._id_map, self._flags)
+        if self.keep_stats:
+            self._counts_last.copy_(self._counts)
+
+    def _enqueue_plan(self, i: int):
+        if not self._cuda:
+            self._plan(i)
+        else:
+            slot = i % 2
+            ps = self._plan_stream
+            ps.wait_stream(torch.cuda.current_stream())      # epoch shuffle / setup on the main stream is visible
+            if self._main_done_valid[slot]:
+                ps.wait_event(self._main_done[slot])         # the slot's previous user (step i-2) has finished with it
+            with torch.cuda.stream(ps):
+                self._plan(i)
+                self._plan_done[slot].record(ps)
+        self._planned = i
+
+    def step(self, i: int):
+        """Global step i.  Steps must be issued in order; the plan of step i+1 is enqueued right after step i."""
+        s = i % self.steps
+        if self._planned != i:                               # first step (or a jump): plan it now
+            if s == 0 and i > 0:
+                self.bat.shuffle()
+            self._enqueue_plan(i)
+        slot = i % 2
+        b, N, G, C, be = self.bat, self.N, self.world, self.C, self.backend
+        a, e = self.my_slice(s)
+        n_pos = e - a
+        pos_r = b.pos_r[a:e]
+        neg_r = self._neg2[slot][1][:n_pos * N]
+        want = self._want2[slot]
+        cidx = [self._cidx2[slot][k][:(n_pos if k < 2 else n_pos * N)] for k in range(4)]
+        if self._cuda:
+            torch.cuda.current_stream().wait_event(self._plan_done[slot])
+        # ---- requested rows: owner gathers raw rows, equal-split all-to-all back -------------------------------------
+        be.gather_padded(self.ent, want, self._rows_out, self._cgrad)           # also clears the compact grad scratch
         dist.all_to_all_single(self._rows_in, self._rows_out)
         # ---- local fused step on the compact row set ------------------------------------------------------------
-        cidx = [self._cidx[k][:streams[k].numel()] for k in range(4)]
-        be.rowset_remap(streams, cidx, self._id_map, self._flags)
         self.tag += 1
         tag = self.tag
-        be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos[1], cidx[1]), (cidx[2], neg[1], cidx[3]), N,
+        be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
                  self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
         # ---- gradient rows home; the owner reduces and updates each row once -------------------------------------
         dist.all_to_all_single(self._ggot, self._cgrad)
-        be.scatter_add(self._want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag, self._req, self._counts_prev())
+        be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
         be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
         # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere -------
         dist.all_reduce(self.rel_grad)
         be.update(self.rel, self.rel_acc, self.rel_grad, None, tag, self.dim, True, self.lr)     # touched=None: all rows
-
-    def _counts_prev(self):
-        """counts are double-buffered so that `stats()` can read the last step's numbers after they were reset."""
-        self._counts_last.copy_(self._counts) if self.keep_stats else None
-        return self._counts
+        if self._cuda:
+            self._main_done[slot].record(torch.cuda.current_stream())
+            self._main_done_valid[slot] = True
+        # ---- look ahead: plan step i+1 while this step's kernels and exchanges run ---------------------------------
+        nxt = i + 1
+        if nxt % self.steps == 0:
+            self.bat.shuffle()                                # epoch boundary: random.shuffle of both lists
+        self._enqueue_plan(nxt)
 
     def stats(self) -> dict:
         """Synchronising debug view of the last step's row set."""

@@ -145,9 +145,14 @@ class RelationBatcher:
         t1 = self.t1 if perm1 is None else self.t1[perm1]
         t2 = self.t2 if perm2 is None else self.t2[perm2]
         allt = torch.cat([t1, t2], 0)[self._src]  # epoch order, step-contiguous
-        self.pos_h = allt[:, 0].contiguous()
-        self.pos_r = allt[:, 1].contiguous()
-        self.pos_t = allt[:, 2].contiguous()
+        if getattr(self, "pos_h", None) is None:
+            self.pos_h = allt[:, 0].contiguous()
+            self.pos_r = allt[:, 1].contiguous()
+            self.pos_t = allt[:, 2].contiguous()
+        else:  # persistent epoch buffers: addresses stay valid across epochs (native plans, side streams)
+            self.pos_h.copy_(allt[:, 0])
+            self.pos_r.copy_(allt[:, 1])
+            self.pos_t.copy_(allt[:, 2])
         self.t1, self.t2 = t1, t2
 
     def shuffle(self):
