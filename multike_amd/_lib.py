@@ -113,7 +113,20 @@ def _dev(t: torch.Tensor | None, dtype, name: str):
     return C.c_void_p(t.data_ptr())
 
 
+_pinned_stream = None  # raw hipStream_t handle pinned by a hot loop (saves a torch.cuda.current_stream() per launch)
+
+
+def pin_stream(handle: int | None):
+    """Pin the stream every launch goes to (a raw `stream.cuda_stream` handle), or None to follow torch's current
+    stream again.  Returns the previous pin."""
+    global _pinned_stream
+    old, _pinned_stream = _pinned_stream, handle
+    return old
+
+
 def _stream():
+    if _pinned_stream is not None:
+        return C.c_void_p(_pinned_stream)
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

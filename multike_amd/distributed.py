@@ -121,19 +121,22 @@ class ShardedRelationTrainer:
         self._ctouched = torch.zeros(G * C, **i32)
         # --- plan phase (sampler -> row-set build -> id exchange -> remap) is table-independent: it runs one step
         #     ahead on its own stream + communicator, double-buffered, off the critical path of the step ----------
-        self._want2 = [torch.empty(G * C, **i32) for _ in range(2)]
-        self._cidx2 = [[torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)] for _ in range(2)]
-        self._neg2 = [tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3)) for _ in range(2)]
+        self.lookahead = 2                                   # plans are enqueued this many steps ahead of their use
+        nslot = self.lookahead + 1
+        self._nslot = nslot
+        self._want2 = [torch.empty(G * C, **i32) for _ in range(nslot)]
+        self._cidx2 = [[torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)] for _ in range(nslot)]
+        self._neg2 = [tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3)) for _ in range(nslot)]
         self._counts_last = torch.zeros(G, **i32)
         self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
         self._cuda = self.device.type == "cuda"
         if self._cuda:
             self._plan_stream = torch.cuda.Stream(device=self.device)
-            self._plan_done = [torch.cuda.Event() for _ in range(2)]
-            self._main_done = [torch.cuda.Event() for _ in range(2)]
-            self._main_done_valid = [False, False]
+            self._plan_done = [torch.cuda.Event() for _ in range(nslot)]
+            self._main_done = [torch.cuda.Event() for _ in range(nslot)]
+            self._main_done_valid = [False] * nslot
         self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1) else None
-        self._planned = None  # global step index whose plan is in flight / ready
+        self._planned = -1    # plans of global steps <= this index have been enqueued
         self.last_stats = {}
 
     def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
@@ -179,9 +182,9 @@ class ShardedRelationTrainer:
         return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
 
     def _plan(self, i: int):
-        """Table-independent half of step i: negatives, row set, id exchange, compact indices -> slot i % 2."""
+        """Table-independent half of step i: negatives, row set, id exchange, compact indices -> slot i % nslot."""
         s = i % self.steps
-        slot = i % 2
+        slot = i % self._nslot
         b, N, G, C, be = self.bat, self.N, self.world, self.C, self.backend
         a, e = self.my_slice(s)
         n_pos = e - a
@@ -200,27 +203,37 @@ class ShardedRelationTrainer:
             self._counts_last.copy_(self._counts)
 
     def _enqueue_plan(self, i: int):
+        """Plans are issued strictly in step order; the epoch shuffle happens right before the first plan of the next
+        epoch.  The shuffle rewrites the epoch buffers in place, so a plan of the NEXT epoch may only be enqueued once
+        every main step of the current epoch has been enqueued (`step` guarantees it)."""
+        if i % self.steps == 0 and i > 0:
+            self.bat.shuffle()                                # random.shuffle of both lists at the epoch boundary
         if not self._cuda:
             self._plan(i)
         else:
-            slot = i % 2
+            slot = i % self._nslot
             ps = self._plan_stream
             ps.wait_stream(torch.cuda.current_stream())      # epoch shuffle / setup on the main stream is visible
             if self._main_done_valid[slot]:
-                ps.wait_event(self._main_done[slot])         # the slot's previous user (step i-2) has finished with it
+                ps.wait_event(self._main_done[slot])         # the slot's previous user has finished with it
             with torch.cuda.stream(ps):
-                self._plan(i)
+                old = _lib.pin_stream(ps.cuda_stream)
+                try:
+                    self._plan(i)
+                finally:
+                    _lib.pin_stream(old)
                 self._plan_done[slot].record(ps)
         self._planned = i
 
     def step(self, i: int):
-        """Global step i.  Steps must be issued in order; the plan of step i+1 is enqueued right after step i."""
+        """Global step i (steps must be issued in order).  Plans run `lookahead` steps ahead, except across an epoch
+        boundary: the next epoch's first plans wait until this epoch's last main step is enqueued, because the shuffle
+        rewrites the epoch buffers in place."""
         s = i % self.steps
-        if self._planned != i:                               # first step (or a jump): plan it now
-            if s == 0 and i > 0:
-                self.bat.shuffle()
-            self._enqueue_plan(i)
-        slot = i % 2
+        epoch_end = (i // self.steps + 1) * self.steps        # first step of the next epoch
+        while self._planned < min(i + self.lookahead, epoch_end - 1) or self._planned < i:
+            self._enqueue_plan(self._planned + 1)
+        slot = i % self._nslot
         b, N, G, C, be = self.bat, self.N, self.world, self.C, self.backend
         a, e = self.my_slice(s)
         n_pos = e - a
@@ -228,31 +241,36 @@ class ShardedRelationTrainer:
         neg_r = self._neg2[slot][1][:n_pos * N]
         want = self._want2[slot]
         cidx = [self._cidx2[slot][k][:(n_pos if k < 2 else n_pos * N)] for k in range(4)]
-        if self._cuda:
-            torch.cuda.current_stream().wait_event(self._plan_done[slot])
-        # ---- requested rows: owner gathers raw rows, equal-split all-to-all back -------------------------------------
-        be.gather_padded(self.ent, want, self._rows_out, self._cgrad)           # also clears the compact grad scratch
-        dist.all_to_all_single(self._rows_in, self._rows_out)
-        # ---- local fused step on the compact row set ------------------------------------------------------------
-        self.tag += 1
-        tag = self.tag
-        be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
-                 self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
-        # ---- gradient rows home; the owner reduces and updates each row once -------------------------------------
-        dist.all_to_all_single(self._ggot, self._cgrad)
-        be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
-        be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
-        # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere -------
-        dist.all_reduce(self.rel_grad)
-        be.update(self.rel, self.rel_acc, self.rel_grad, None, tag, self.dim, True, self.lr)     # touched=None: all rows
-        if self._cuda:
-            self._main_done[slot].record(torch.cuda.current_stream())
-            self._main_done_valid[slot] = True
-        # ---- look ahead: plan step i+1 while this step's kernels and exchanges run ---------------------------------
-        nxt = i + 1
-        if nxt % self.steps == 0:
-            self.bat.shuffle()                                # epoch boundary: random.shuffle of both lists
-        self._enqueue_plan(nxt)
+        cur = torch.cuda.current_stream() if self._cuda else None
+        old = _lib.pin_stream(cur.cuda_stream) if self._cuda else None
+        try:
+            if self._cuda:
+                cur.wait_event(self._plan_done[slot])
+            # ---- requested rows: owner gathers raw rows, equal-split all-to-all back ---------------------------------
+            be.gather_padded(self.ent, want, self._rows_out, self._cgrad)       # also clears the compact grad scratch
+            dist.all_to_all_single(self._rows_in, self._rows_out)
+            # ---- local fused step on the compact row set --------------------------------------------------------
+            self.tag += 1
+            tag = self.tag
+            be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
+                     self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
+            # ---- gradient rows home; the owner reduces and updates each row once ---------------------------------
+            dist.all_to_all_single(self._ggot, self._cgrad)
+            be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
+            be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
+            # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere ---
+            dist.all_reduce(self.rel_grad)
+            be.update(self.rel, self.rel_acc, self.rel_grad, None, tag, self.dim, True, self.lr)  # touched=None: all rows
+            if self._cuda:
+                self._main_done[slot].record(cur)
+                self._main_done_valid[slot] = True
+        finally:
+            if self._cuda:
+                _lib.pin_stream(old)
+        # ---- look ahead: this step is enqueued, so the next epoch's plans may start if we are at the boundary --------
+        nxt_limit = i + 1 + self.lookahead if i + 1 < epoch_end else i + 1
+        while self._planned < min(nxt_limit, (epoch_end if i + 1 < epoch_end else epoch_end + self.steps) - 1):
+            self._enqueue_plan(self._planned + 1)
 
     def stats(self) -> dict:
         """Synchronising debug view of the last step's row set."""
