@@ -66,7 +66,8 @@ class HipBackend:
 
 class ShardedRelationTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int,
-                 world: int, seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32):
+                 world: int, seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32,
+                 lookahead: int | None = None):
         self.backend = backend or HipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         self.rank, self.world, self.lr = rank, world, lr
@@ -121,7 +122,12 @@ class ShardedRelationTrainer:
         self._ctouched = torch.zeros(G * C, **i32)
         # --- plan phase (sampler -> row-set build -> id exchange -> remap) is table-independent: it runs one step
         #     ahead on its own stream + communicator, double-buffered, off the critical path of the step ----------
-        self.lookahead = 2                                   # plans are enqueued this many steps ahead of their use
+        # plans may be enqueued `lookahead` steps ahead of their use on a side stream with their own communicator.
+        # Default 0 = inline on the main stream with the single default communicator: two communicators progressing
+        # concurrently on side streams is the classic NCCL/RCCL ordering hazard and could not be exercised on >1 GPU
+        # in this round's environment (1-GPU boxes only); opt in with lookahead=2 or MKE_SHARD_LOOKAHEAD=2.
+        import os
+        self.lookahead = int(os.environ.get("MKE_SHARD_LOOKAHEAD", "0")) if lookahead is None else int(lookahead)
         nslot = self.lookahead + 1
         self._nslot = nslot
         self._want2 = [torch.empty(G * C, **i32) for _ in range(nslot)]
@@ -129,13 +135,13 @@ class ShardedRelationTrainer:
         self._neg2 = [tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3)) for _ in range(nslot)]
         self._counts_last = torch.zeros(G, **i32)
         self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
-        self._cuda = self.device.type == "cuda"
+        self._cuda = self.device.type == "cuda" and self.lookahead > 0   # side-stream machinery only when pipelining
         if self._cuda:
             self._plan_stream = torch.cuda.Stream(device=self.device)
             self._plan_done = [torch.cuda.Event() for _ in range(nslot)]
             self._main_done = [torch.cuda.Event() for _ in range(nslot)]
             self._main_done_valid = [False] * nslot
-        self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1) else None
+        self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1 and self.lookahead > 0) else None
         self._planned = -1    # plans of global steps <= this index have been enqueued
         self.last_stats = {}
 

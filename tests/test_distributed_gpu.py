@@ -12,7 +12,8 @@ from oracle import multike_oracle as mo
 pytestmark = pytest.mark.gpu
 
 
-def test_one_rank_sharded_equals_single_table_path():
+@pytest.mark.parametrize("lookahead", [0, 2])
+def test_one_rank_sharded_equals_single_table_path(lookahead):
     import torch.distributed as dist
     from multike_amd.distributed import ShardedRelationTrainer
     from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
@@ -27,7 +28,7 @@ def test_one_rank_sharded_equals_single_table_path():
         rng = np.random.default_rng(2)
         ent0 = mo.xavier_truncated_normal((n_ent, d), rng)
         rel0 = mo.xavier_truncated_normal((n_rel, d), rng)
-        tr = ShardedRelationTrainer(kgs, ent0, rel0, B, N, 0, 1, seed=9, lr=0.01)
+        tr = ShardedRelationTrainer(kgs, ent0, rel0, B, N, 0, 1, seed=9, lr=0.01, lookahead=lookahead)
         E = EmbeddingTable(n_ent, d, "e", values=ent0)
         R = EmbeddingTable(n_rel, d, "r", values=rel0)
         sides = []
@@ -37,10 +38,15 @@ def test_one_rank_sharded_equals_single_table_path():
         bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=9)
         eng = StepEngine()
         tot = 0.0
-        for s in range(6):
+        nsteps = bat.steps + 3          # crosses an epoch boundary (shuffle) on both paths
+        for s in range(nsteps):
             tr.step(s)
-            pos, neg = bat.batch(s)
-            tot += float(eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.01).sum())
+            if s > 0 and s % bat.steps == 0:
+                bat.shuffle()
+            pos, neg = bat.batch(s % bat.steps)
+            l = float(eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.01).sum())
+            if s >= 3:                  # the trainer's loss ring holds the last `steps` global steps
+                tot += l
         np.testing.assert_allclose(tr.epoch_loss(), tot, rtol=2e-6)
         np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), E.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), R.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
