@@ -231,6 +231,20 @@ def main():
                     "avg_launch_us": avg_ms * 1e3, "alg_bytes_per_triple": b_alg(d),
                     "triples_per_launch": float(tr.mean())}
 
+    if sharded:
+        # same instrumentation on the sharded path: events around this rank's score-kernel launches (extra steps)
+        trainer.score_events = []
+        base = args.warmup + args.steps
+        run_steps(base, base + min(args.steps, 50))
+        torch.cuda.synchronize()
+        ms = np.array([a.elapsed_time(b) for a, b, _ in trainer.score_events])
+        tr = np.array([n for _, _, n in trainer.score_events])
+        trainer.score_events = None
+        achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
+        roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": float(ms.mean()) * 1e3,
+                    "alg_bytes_per_triple": b_alg(d), "triples_per_launch": float(tr.mean()), "scope": "per GPU (rank 0)"}
+
     if rank == 0:
         out = {
             "metric": "scored triples/sec (pos+neg)", "value": value, "unit": "triples/s", "n_gpus": world,

@@ -143,6 +143,7 @@ class ShardedRelationTrainer:
             self._main_done_valid = [False] * nslot
         self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1 and self.lookahead > 0) else None
         self._planned = -1    # plans of global steps <= this index have been enqueued
+        self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
         self.last_stats = {}
 
     def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
@@ -258,8 +259,15 @@ class ShardedRelationTrainer:
             # ---- local fused step on the compact row set --------------------------------------------------------
             self.tag += 1
             tag = self.tag
+            ev = self.score_events
+            if ev is not None:                                # bench instrumentation: HIP events around the score kernel
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
                      self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1, n_pos * (1 + N)))
             # ---- gradient rows home; the owner reduces and updates each row once ---------------------------------
             dist.all_to_all_single(self._ggot, self._cgrad)
             be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
