@@ -283,7 +283,8 @@ int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_e
  *     rows requested of that owner.  flags ([n_ent], zero) and counts ([n_ranks], zero) are scratch; flags are left
  *     dirty and are cleared by mke_rowset_remap.  *overflow is set to 1 when a segment is full (result invalid).
  *     Slot order inside a segment is unspecified.
- *   mke_rowset_remap: for up to four streams, out_s[i] = id_map[ids_s[i]] and flags[ids_s[i]] = 0.
+ *   mke_rowset_remap: for up to four streams, out_s[i] = id_map[ids_s[i]] and flags[ids_s[i]] = 0; optionally
+ *     re-initialises a req / counts pair for the next build (req[:] = -1, counts[:] = 0).
  *   mke_rows_gather_padded: out[i][:] = idx[i] >= 0 ? table[idx[i]][:] : 0   (raw padded rows, no normalisation);
  *     when zero_rows != NULL, zero_rows[i][:] = 0 as well (clears the compact gradient scratch in the same pass).
  *   mke_rows_scatter_add: grad[idx[i]][:] += rows[i][:] (atomic), touched[idx[i]] = tag, for idx[i] >= 0; when
@@ -294,7 +295,8 @@ int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* ids1, int64
                      int32_t* overflow, int n_ranks, int capacity, void* stream);
 int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, const int32_t* ids1, int32_t* out1, int64_t n1,
                      const int32_t* ids2, int32_t* out2, int64_t n2, const int32_t* ids3, int32_t* out3, int64_t n3,
-                     const int32_t* id_map, int32_t* flags, void* stream);
+                     const int32_t* id_map, int32_t* flags, int32_t* reset_req /*nullable*/, int64_t reset_req_len,
+                     int32_t* reset_counts /*nullable*/, int n_counts, void* stream);
 int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out,
                            float* zero_rows /*nullable*/, void* stream);
 int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int stride, int dim, float* grad,

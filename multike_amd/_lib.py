@@ -188,7 +188,7 @@ def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
         arr[k].table = ptr(data, torch.float32, "table")
         arr[k].acc = ptr(acc, torch.float32, "acc")
         arr[k].grad = ptr(grad, torch.float32, "grad")
-        arr[k].touched = ptr(touched, torch.int32, "touched")
+        arr[k].touched = ptr(touched, torch.int32, "touched") if touched is not None else None
         arr[k].n_rows = data.shape[0]
         arr[k].normalize = int(normalize)
         arr[k].grad_copies = 1 if grad.dim() == 2 else grad.shape[0]
@@ -280,13 +280,16 @@ def rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacit
     _check(rc, "mke_rowset_build")
 
 
-def rowset_remap(streams, outs, id_map, flags):
+def rowset_remap(streams, outs, id_map, flags, reset_req=None, reset_counts=None):
     args = []
     for k in range(4):
         t = streams[k] if k < len(streams) else None
         o = outs[k] if k < len(outs) else None
         args += [_dev(t, torch.int32, f"ids{k}"), _dev(o, torch.int32, f"out{k}"), C.c_int64(0 if t is None else t.numel())]
-    rc = lib().mke_rowset_remap(*args, _dev(id_map, torch.int32, "id_map"), _dev(flags, torch.int32, "flags"), _stream())
+    rc = lib().mke_rowset_remap(*args, _dev(id_map, torch.int32, "id_map"), _dev(flags, torch.int32, "flags"),
+                                _dev(reset_req, torch.int32, "reset_req"), C.c_int64(0 if reset_req is None else reset_req.numel()),
+                                _dev(reset_counts, torch.int32, "reset_counts"),
+                                C.c_int(0 if reset_counts is None else reset_counts.numel()), _stream())
     _check(rc, "mke_rowset_remap")
 
 

@@ -74,9 +74,17 @@ struct RemapParams {
   int64_t total;
   const int32_t* id_map;
   int32_t* flags;
+  int32_t* reset_req;     // nullable: req[i] = -1 for i < reset_req_len (re-initialise for the next build)
+  int64_t reset_req_len;
+  int32_t* reset_counts;  // nullable
+  int n_counts;
 };
 
 __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p) {
+  if (p.reset_counts && blockIdx.x == 0 && threadIdx.x < p.n_counts) p.reset_counts[threadIdx.x] = 0;
+  if (p.reset_req)
+    for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.reset_req_len; i += (int64_t)gridDim.x * MKE_BLOCK)
+      p.reset_req[i] = -1;
   for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.total; i += (int64_t)gridDim.x * MKE_BLOCK) {
     int64_t k = i;
     int s = 0;
@@ -89,29 +97,23 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p)
   }
 }
 
-template <int FPL>
+// pure row copy: 16 bytes per lane (a quarter-wave moves 256 contiguous bytes per instruction)
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_gather_padded(const float* __restrict__ table, int stride,
                                                                   const int32_t* __restrict__ idx, int64_t n,
                                                                   float* __restrict__ out, float* __restrict__ zero_rows) {
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t i = sub0; i < n; i += nsub) {
     const int row = idx[i];
-    float v[FPL];
-    if (row >= 0) {
-      load_row<FPL>(table, row, stride, j, v);
-    } else {
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) v[k] = 0.f;
-    }
-    float* o = out + i * (int64_t)stride + j;
-#pragma unroll
-    for (int k = 0; k < FPL; ++k) o[k * 16] = v[k];
-    if (zero_rows) {
-      float* z = zero_rows + i * (int64_t)stride + j;
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) z[k * 16] = 0.f;
+    const float* src = table + (int64_t)(row >= 0 ? row : 0) * stride;
+    float* o = out + i * (int64_t)stride;
+    float* zr = zero_rows ? zero_rows + i * (int64_t)stride : nullptr;
+    for (int c = 4 * j; c < stride; c += 64) {
+      const float4 v = row >= 0 ? *reinterpret_cast<const float4*>(src + c) : z;
+      *reinterpret_cast<float4*>(o + c) = v;
+      if (zr) *reinterpret_cast<float4*>(zr + c) = z;
     }
   }
 }
@@ -169,9 +171,13 @@ extern "C" int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* 
 
 extern "C" int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, const int32_t* ids1, int32_t* out1, int64_t n1,
                                 const int32_t* ids2, int32_t* out2, int64_t n2, const int32_t* ids3, int32_t* out3, int64_t n3,
-                                const int32_t* id_map, int32_t* flags, void* stream) {
+                                const int32_t* id_map, int32_t* flags, int32_t* reset_req, int64_t reset_req_len,
+                                int32_t* reset_counts, int n_counts, void* stream) {
   using namespace mke;
   RemapParams p;
+  p.reset_req = reset_req; p.reset_req_len = reset_req ? reset_req_len : 0; p.reset_counts = reset_counts;
+  p.n_counts = reset_counts ? n_counts : 0;
+  if (reset_req_len < 0 || n_counts < 0 || n_counts > MKE_MAX_RANKS) { set_error("bad reset lengths"); return MKE_E_SHAPE; }
   p.ids[0] = ids0; p.ids[1] = ids1; p.ids[2] = ids2; p.ids[3] = ids3;
   p.out[0] = out0; p.out[1] = out1; p.out[2] = out2; p.out[3] = out3;
   p.len[0] = n0; p.len[1] = n1; p.len[2] = n2; p.len[3] = n3;
@@ -181,10 +187,11 @@ extern "C" int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, 
     if (p.len[s] > 0 && (!p.ids[s] || !p.out[s])) { set_error("NULL stream %d", s); return MKE_E_NULL; }
     p.total += p.len[s];
   }
-  if (p.total == 0) return MKE_OK;
-  if (!id_map || !flags) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
+  if (p.total == 0 && !reset_req && !reset_counts) return MKE_OK;
+  if (p.total > 0 && (!id_map || !flags)) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
   p.id_map = id_map; p.flags = flags;
-  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(p.total, MKE_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(p.total > p.reset_req_len ? p.total : p.reset_req_len, MKE_BLOCK)), dim3(MKE_BLOCK), 0,
+                     (hipStream_t)stream, p);
   return check_launch("k_rowset_remap");
 }
 
@@ -195,11 +202,8 @@ extern "C" int mke_rows_gather_padded(const float* table, int stride, const int3
   if (n == 0) return MKE_OK;
   if (!table || !idx || !out) { set_error("mke_rows_gather_padded: NULL pointer"); return MKE_E_NULL; }
   if (stride <= 0 || stride % 16 != 0 || stride > MKE_MAX_STRIDE) { set_error("bad stride %d", stride); return MKE_E_SHAPE; }
-  const int fpl = stride / 16;
-  MKE_DISPATCH_FPL(fpl, {
-    hipLaunchKernelGGL((k_rows_gather_padded<FPL>), dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0,
-                       (hipStream_t)stream, table, stride, idx, n, out, zero_rows);
-  });
+  hipLaunchKernelGGL(k_rows_gather_padded, dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
+                     table, stride, idx, n, out, zero_rows);
   return check_launch("k_rows_gather_padded");
 }
 

@@ -192,7 +192,7 @@ extern "C" int mke_rows_update_multi(const mke_update_table* tables, int n_table
   if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
   if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim: stride=%d dim=%d", stride, dim); return MKE_E_SHAPE; }
   for (int k = 0; k < n_tables; ++k) {
-    if (!tables[k].table || !tables[k].grad || !tables[k].touched) { set_error("table %d: NULL table/grad/touched", k); return MKE_E_NULL; }
+    if (!tables[k].table || !tables[k].grad) { set_error("table %d: NULL table/grad", k); return MKE_E_NULL; }
     if (optimizer == MKE_OPT_ADAGRAD && !tables[k].acc) { set_error("table %d: Adagrad needs an accumulator", k); return MKE_E_NULL; }
     if (tables[k].n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
   }

@@ -46,8 +46,8 @@ class HipBackend:
     def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
         _lib.rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity)
 
-    def rowset_remap(self, streams, outs, id_map, flags):
-        _lib.rowset_remap(streams, outs, id_map, flags)
+    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None):
+        _lib.rowset_remap(streams, outs, id_map, flags, reset_req, reset_counts)
 
     def gather_padded(self, table, idx, out, zero_rows=None):
         _lib.rows_gather_padded(table, idx, out, zero_rows)
@@ -62,6 +62,10 @@ class HipBackend:
 
     def update(self, table, acc, grad, touched, tag, dim, normalize, lr):
         _lib.rows_update(table, acc, grad, touched, tag, dim, normalize, _lib.OPT_ADAGRAD, lr)
+
+    def update_pair(self, t0, t1, tag, dim, lr):
+        """One launch over two tables; each t = (table, acc, grad, touched, normalize); touched may be None."""
+        _lib.rows_update_multi([t0, t1], tag, t0[0].shape[1], dim, _lib.OPT_ADAGRAD, lr)
 
 
 class ShardedRelationTrainer:
@@ -199,15 +203,14 @@ class ShardedRelationTrainer:
         neg = tuple(x[:n_pos * N] for x in self._neg2[slot])
         if n_pos and N:
             be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
-        self._req.fill_(-1)
-        self._counts.zero_()
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
         dist.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
-        cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
-        be.rowset_remap(streams, cidx, self._id_map, self._flags)
         if self.keep_stats:
             self._counts_last.copy_(self._counts)
+        cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
+        # remap also re-initialises req / counts for the next build (they are consumed: the id exchange is enqueued)
+        be.rowset_remap(streams, cidx, self._id_map, self._flags, self._req, self._counts)
 
     def _enqueue_plan(self, i: int):
         """Plans are issued strictly in step order; the epoch shuffle happens right before the first plan of the next
@@ -270,11 +273,12 @@ class ShardedRelationTrainer:
                 ev.append((e0, e1, n_pos * (1 + N)))
             # ---- gradient rows home; the owner reduces and updates each row once ---------------------------------
             dist.all_to_all_single(self._ggot, self._cgrad)
-            be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
-            be.update(self.ent, self.ent_acc, self.ent_grad, self.ent_touched, tag, self.dim, True, self.lr)
-            # ---- replicated relation table: all-reduce the (tiny) dense gradient, identical update everywhere ---
+            # ---- replicated relation table: all-reduce the (tiny) dense gradient -----------------------------------
             dist.all_reduce(self.rel_grad)
-            be.update(self.rel, self.rel_acc, self.rel_grad, None, tag, self.dim, True, self.lr)  # touched=None: all rows
+            be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
+            # ---- one launch: identical relation update on every rank (touched=None: all rows) + this shard's rows
+            be.update_pair((self.rel, self.rel_acc, self.rel_grad, None, True),
+                           (self.ent, self.ent_acc, self.ent_grad, self.ent_touched, True), tag, self.dim, self.lr)
             if self._cuda:
                 self._main_done[slot].record(cur)
                 self._main_done_valid[slot] = True

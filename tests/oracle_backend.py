@@ -43,11 +43,19 @@ class OracleBackend:
                 im[i] = o * capacity
             cnt[o] += 1
 
-    def rowset_remap(self, streams, outs, id_map, flags):
+    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None):
         for ids, out in zip(streams, outs):
             i = ids.numpy()
             out.numpy()[:] = id_map.numpy()[i]
             flags.numpy()[i] = 0
+        if reset_req is not None:
+            reset_req.numpy()[:] = -1
+        if reset_counts is not None:
+            reset_counts.numpy()[:] = 0
+
+    def update_pair(self, t0, t1, tag, dim, lr):
+        for (table, acc, grad, touched, normalize) in (t0, t1):
+            self.update(table, acc, grad, touched, tag, dim, normalize, lr)
 
     def gather_padded(self, table, idx, out, zero_rows=None):
         i = idx.numpy()

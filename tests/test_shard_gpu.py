@@ -33,7 +33,9 @@ def test_rowset_build_remap_gather_scatter(G, n_ent, lens):
     assert np.array_equal(rq.reshape(-1)[slots].astype(np.int64) * G + slots // C, uniq)
     # remap + flags cleared
     outs = [torch.empty_like(x) for x in streams]
-    _lib.rowset_remap(streams, outs, id_map, flags)
+    probe_req, probe_cnt = torch.ones(37, **i32), torch.ones(G, **i32)
+    _lib.rowset_remap(streams, outs, id_map, flags, probe_req, probe_cnt)
+    assert int((probe_req != -1).sum()) == 0 and int(probe_cnt.abs().sum()) == 0
     for x_np, out in zip(streams_np, outs):
         assert np.array_equal(out.cpu().numpy(), im[x_np])
     assert int(flags.abs().sum()) == 0
