@@ -1,0 +1,43 @@
+"""bench.py's output contract (one JSON line with the fields the driver reads) on a short run, N=1 and the 1-rank
+sharded path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-steps", "2"]
+                         + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_n1_line():
+    d = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["scored_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] == 8000.0 and r["alg_bytes_per_triple"] == 12 + 24 * d["config"]["dim"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 50e6          # north_star floor: >= 50 M scored triples/s on one MI355X
+
+
+def test_sharded_line_one_rank():
+    d = _run(["--force-sharded"])
+    assert d["n_gpus"] == 1 and d["roofline"]["achieved"] > 0 and "cpu_baseline" not in d

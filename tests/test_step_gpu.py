@@ -224,3 +224,31 @@ def test_full_size_c2_batch_vs_c_oracle():
     parts = float(eng.relation_step(E, R, "relation", p1, n1, neg_per_pos=25, update=False).sum()) + \
         float(eng.relation_step(E, R, "relation", p2, n2, neg_per_pos=25, update=False).sum())
     np.testing.assert_allclose(full, parts, rtol=1e-6)  # fp32 per-lane partial sums regroup with the split
+
+
+def test_wide_rows_many_negatives_vs_c_oracle():
+    """configs[4]-like rows (dim 256, 64 negatives, batch 5000) on a 500K-entity table (the full 2M x 256 shape is
+    exercised by tools/kbench.py; here the float64 oracle has to fit the host): one step against the C oracle."""
+    from gpu_util import dev_i32, make_tables
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import StepEngine
+    kgs = SyntheticKGs(n_ent=500_000, n_rel=2000, triples_per_entity=1.0, seed=4)
+    rng = np.random.default_rng(4)
+    d, N = 256, 64
+    ent = mo.xavier_truncated_normal((kgs.entities_num, d), rng)
+    rel = mo.xavier_truncated_normal((kgs.relations_num, d), rng)
+    E, R = make_tables(ent, rel)
+    eng = StepEngine()
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None), KGSide(kgs.entities(1), None), 5000, N,
+                          seed=1)
+    pos, neg = bat.batch(3)
+    lp = eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.001)
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    del ent, rel
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    orc = co.RelationStepOracle(kgs.entities_num, kgs.relations_num, d, np.float64)
+    L = orc.step(e64, r64, a64, b64, tuple(x.cpu().numpy() for x in pos), tuple(x.cpu().numpy() for x in neg), 0.001)
+    np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
