@@ -148,7 +148,7 @@ def main():
         runner = RelationViewRunner(E, R, bat, "relation", lr=0.001, sample_chunk=args.sample_chunk or None)
         eng = StepEngine()
         n_steps_epoch = bat.steps
-        ev = []
+        ev, ev_upd = [], []
 
         def run_steps(i0, i1):
             """global step indices [i0, i1): each (partial) epoch is ONE call into the native runner."""
@@ -176,6 +176,9 @@ def main():
             _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
                                     (E.data, E.slot("relation"), E.grad, E.touched, True)], tag, E.stride, d,
                                    _lib.OPT_ADAGRAD, 0.001)
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
+            ev_upd.append((e1, e2, tag))
 
         def triples_of(i):
             s = i % n_steps_epoch
@@ -230,6 +233,13 @@ def main():
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "alg_bytes_per_triple": b_alg(d),
                     "triples_per_launch": float(tr.mean())}
+        # second kernel of the step, reported beside it: touched rows x 6 row streams (grad, w, acc read; 0, w, acc written)
+        touched_rows = int((E.touched == ev_upd[-1][2]).sum()) + int((R.touched == ev_upd[-1][2]).sum())
+        ums = np.array([a.elapsed_time(b) for a, b, _ in ev_upd])
+        upd_bytes = touched_rows * 6 * E.stride * 4
+        roofline["update_kernel"] = {"kernel": "k_rows_update_multi", "avg_launch_us": float(ums.mean()) * 1e3,
+                                     "touched_rows_last_step": touched_rows, "bytes_per_launch": upd_bytes,
+                                     "achieved": upd_bytes / (float(ums.mean()) * 1e-3) / 1e9, "unit": "GB/s"}
 
     if sharded:
         # same instrumentation on the sharded path: events around this rank's score-kernel launches (extra steps)
