@@ -22,7 +22,8 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
-    "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_rows_update", "mke_rows_update_multi",
+    "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_triple_score_fwd_bwd_x",
+    "mke_count_entity_refs", "mke_rows_update", "mke_rows_update_multi",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
@@ -41,7 +42,7 @@ class KGSideStruct(C.Structure):
 class UpdateTableStruct(C.Structure):
     """mke_update_table"""
     _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p),
-                ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int)]
+                ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int), ("ref_count", C.c_void_p)]
 
 
 class RelationPlanStruct(C.Structure):
@@ -51,7 +52,8 @@ class RelationPlanStruct(C.Structure):
         ("rel_table", C.c_void_p), ("n_rel", C.c_int64), ("rel_normalize", C.c_int),
         ("ent_acc", C.c_void_p), ("rel_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("rel_grad", C.c_void_p),
         ("rel_grad_copies", C.c_int),
-        ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("stride", C.c_int), ("dim", C.c_int),
+        ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("ent_ref_count", C.c_void_p),
+        ("stride", C.c_int), ("dim", C.c_int),
         ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("pos_kg", C.c_void_p),
         ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("sides", KGSideStruct * 2),
         ("neg_per_pos", C.c_int), ("max_try", C.c_int), ("sample_chunk", C.c_int),
@@ -167,6 +169,36 @@ def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w
     _check(rc, "mke_triple_score_fwd_bwd")
 
 
+def count_entity_refs(pos_h, pos_t, neg_h, neg_t, neg_per_pos, ref_count):
+    rc = lib().mke_count_entity_refs(_dev(pos_h, torch.int32, "pos_h"), _dev(pos_t, torch.int32, "pos_t"),
+                                     C.c_int64(pos_h.numel()), _dev(neg_h, torch.int32, "neg_h"),
+                                     _dev(neg_t, torch.int32, "neg_t"), C.c_int64(0 if neg_h is None else neg_h.numel()),
+                                     C.c_int(neg_per_pos), _dev(ref_count, torch.int32, "ref_count"), _stream())
+    _check(rc, "mke_count_entity_refs")
+
+
+def triple_score_fwd_bwd_x(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale, grad_ent,
+                           grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, loss_partials):
+    """mke_triple_score_fwd_bwd_x: the fused step with the exclusive-row fast path (ref_count filled by
+    count_entity_refs for the same batch)."""
+    ph, pr, pt = pos
+    nh, nr, nt = neg
+    rel_copies = 1 if grad_rel.dim() == 2 else grad_rel.shape[0]
+    rc = lib().mke_triple_score_fwd_bwd_x(
+        _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
+        _dev(rel, torch.float32, "rel_table"), C.c_int64(rel.shape[0]), C.c_int(int(rel_normalize)),
+        C.c_int(ent.shape[1]), C.c_int(dim),
+        _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+        _dev(pos_w, torch.float32, "pos_w"), C.c_int64(ph.numel()),
+        _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"),
+        _dev(neg_w, torch.float32, "neg_w"), C.c_int64(nh.numel()), C.c_int(neg_per_pos), C.c_float(scale),
+        _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"), C.c_int(rel_copies),
+        _dev(touched_ent, torch.int32, "touched_ent"), _dev(touched_rel, torch.int32, "touched_rel"), C.c_int32(tag),
+        _dev(ref_count, torch.int32, "ref_count"), _dev(ent_acc, torch.float32, "ent_acc"), C.c_int(optimizer), C.c_float(lr),
+        _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_triple_score_fwd_bwd_x")
+
+
 def rows_update(table, acc, grad, touched, tag, dim, normalize, optimizer, lr):
     copies = 1 if grad.dim() == 2 else grad.shape[0]
     rc = lib().mke_rows_update(
@@ -182,9 +214,11 @@ def ptr(t: torch.Tensor | None, dtype, name: str) -> int | None:
 
 
 def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
-    """tables: list of (data, acc, grad, touched, normalize)."""
+    """tables: list of (data, acc, grad, touched, normalize[, ref_count])."""
     arr = (UpdateTableStruct * len(tables))()
-    for k, (data, acc, grad, touched, normalize) in enumerate(tables):
+    for k, tpl in enumerate(tables):
+        data, acc, grad, touched, normalize = tpl[:5]
+        arr[k].ref_count = ptr(tpl[5], torch.int32, "ref_count") if len(tpl) > 5 and tpl[5] is not None else None
         arr[k].table = ptr(data, torch.float32, "table")
         arr[k].acc = ptr(acc, torch.float32, "acc")
         arr[k].grad = ptr(grad, torch.float32, "grad")

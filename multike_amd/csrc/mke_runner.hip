@@ -16,9 +16,9 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
 
   mke_update_table ut[2];
   ut[0].table = pl->rel_table; ut[0].acc = pl->rel_acc; ut[0].grad = pl->rel_grad; ut[0].touched = pl->rel_touched;
-  ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies;
+  ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies; ut[0].ref_count = nullptr;
   ut[1].table = pl->ent_table; ut[1].acc = pl->ent_acc; ut[1].grad = pl->ent_grad; ut[1].touched = pl->ent_touched;
-  ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1;
+  ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1; ut[1].ref_count = pl->ent_ref_count;
 
   int64_t chunk_lo = 0;  // first positive (epoch position) whose negatives sit at neg_*[0]
   int chunk_end = step_begin;  // steps < chunk_end are sampled
@@ -35,12 +35,18 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
     }
     const int64_t no = (lo - chunk_lo) * N;
     const int32_t tag = pl->tag_base + s;
-    int rc = mke_triple_score_fwd_bwd(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
-                                      pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
-                                      N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
-                                      nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies, pl->ent_touched,
-                                      pl->rel_touched, tag, pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS,
-                                      stream);
+    int32_t* refc = (N > 0) ? pl->ent_ref_count : nullptr;  // exclusive-row fast path
+    int rc = MKE_OK;
+    if (refc) {
+      rc = mke_count_entity_refs(pl->pos_h + lo, pl->pos_t + lo, hi - lo, pl->neg_h + no, pl->neg_t + no, (hi - lo) * N, N, refc, stream);
+      if (rc) return rc;
+    }
+    rc = mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
+                                    pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
+                                    N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
+                                    nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies,
+                                    pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,
+                                    pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, stream);
     if (rc) return rc;
     rc = mke_rows_update_multi(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, stream);
     if (rc) return rc;

@@ -45,6 +45,12 @@ struct ScoreParams {
   int32_t* __restrict__ trel;
   int32_t tag;
   double* __restrict__ lossp;
+  // exclusive-row fast path (nullable refcount = disabled)
+  int32_t* __restrict__ refcount;
+  float* __restrict__ ent_w;    // writable alias of ent
+  float* __restrict__ ent_acc;  // nullable (SGD)
+  int optimizer;
+  float lr;
 };
 
 // One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
@@ -89,7 +95,7 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // butterfly steps and flush them with ONE scatter of three rows (quarter 0 -> head row, 1 -> relation row,
 // 2 -> tail row).  Lanes of one wave-instruction therefore never add to the same address (measured on
 // MI355X: S quarter-waves of one wave adding to the same rows cost ~15-25 us per extra S at this shape).
-template <int FPL, int U>
+template <int FPL, int U, bool X>  // X: exclusive-row fast path compiled in
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
@@ -145,10 +151,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       const int64_t nbase = g * (int64_t)npp;
       bool any_slow = false;
       for (int n0 = n_lo + q; n0 < n_hi; n0 += 4 * U) {
-        int e[U];
+        int e[U], cnt[U];
         bool fast[U], sideH[U];
         float w[U];
-        float C[U][FPL];
+        float C[U][FPL];   // RAW corrupt rows (normalised on the fly: the raw values are needed for an in-place update)
+        float A[X ? U : 1][X ? FPL : 1];
         // phase 1: ids
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -166,8 +173,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         // phase 2: all corrupt-row gathers of the chunk in flight together
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          cnt[u] = 0;
           if (fast[u]) {
             load_row<FPL>(p.ent, e[u], p.stride, j, C[u]);
+            if constexpr (X) {
+              cnt[u] = p.refcount[e[u]];
+              if (p.ent_acc) load_row<FPL>(p.ent_acc, e[u], p.stride, j, A[u]);
+            }
           } else {
 #pragma unroll
             for (int k = 0; k < FPL; ++k) C[u][k] = 0.f;
@@ -177,13 +189,20 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (fast[u]) {
-            l2_normalize_row<FPL>(C[u], p.ent_norm);
+            float cinv = 1.0f;
+            if (p.ent_norm) {
+              float ss = 0.f;
+#pragma unroll
+              for (int k = 0; k < FPL; ++k) ss = fmaf(C[u][k], C[u][k], ss);
+              cinv = rsqrtf(fmaxf(sub16_sum(ss), MKE_L2_EPS));
+            }
             float d[FPL];
             float y = 0.f;
 #pragma unroll
             for (int k = 0; k < FPL; ++k) {
-              const float hh = sideH[u] ? C[u][k] : H[k];
-              const float tt = sideH[u] ? T[k] : C[u][k];
+              const float cn = C[u][k] * cinv;
+              const float hh = sideH[u] ? cn : H[k];
+              const float tt = sideH[u] ? T[k] : cn;
               d[k] = (hh + R[k]) - tt;
               y = fmaf(d[k], d[k], y);
             }
@@ -200,8 +219,42 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                 gH[k] = fmaf(toH, d[k], gH[k]);
                 gT[k] = fmaf(toT, d[k], gT[k]);
               }
-              atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
-              if (j == 0) p.tent[e[u]] = p.tag;
+              bool in_place = false;
+              if constexpr (X) in_place = cnt[u] == 1;
+              if (in_place) {
+                // the only reference to row e in this step: Jacobian of the normalisation + optimizer, right here
+                const float sg = sideH[u] ? 1.0f : -1.0f;
+                float g[FPL];
+                if (p.ent_norm) {
+                  float dot = 0.f;
+#pragma unroll
+                  for (int k = 0; k < FPL; ++k) dot = fmaf(C[u][k] * cinv, sg * d[k], dot);
+                  dot = sub16_sum(dot);
+                  const float coef = cinv < 0.99e6f ? dot * cinv : 0.f;  // sum w^2 > eps  <=>  cinv < rsqrt(eps) = 1e6
+#pragma unroll
+                  for (int k = 0; k < FPL; ++k) g[k] = (sg * d[k] - C[u][k] * coef) * cinv;
+                } else {
+#pragma unroll
+                  for (int k = 0; k < FPL; ++k) g[k] = sg * d[k];
+                }
+                float* wp = p.ent_w + (int64_t)e[u] * p.stride + j;
+                if (p.optimizer == MKE_OPT_ADAGRAD) {
+                  float* ap = p.ent_acc + (int64_t)e[u] * p.stride + j;
+#pragma unroll
+                  for (int k = 0; k < FPL; ++k) {
+                    const float a = fmaf(g[k], g[k], A[u][k]);
+                    ap[k * 16] = a;
+                    wp[k * 16] = C[u][k] - p.lr * g[k] / sqrtf(a);
+                  }
+                } else {
+#pragma unroll
+                  for (int k = 0; k < FPL; ++k) wp[k * 16] = C[u][k] - p.lr * g[k];
+                }
+                if (j == 0) p.refcount[e[u]] = 0;
+              } else {
+                atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
+                if (j == 0) p.tent[e[u]] = p.tag;
+              }
             }
           }
         }
@@ -260,14 +313,34 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
   if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)p.scale;
 }
 
+__global__ __launch_bounds__(MKE_BLOCK) void k_count_refs(const int32_t* __restrict__ ph, const int32_t* __restrict__ pt,
+                                                          int64_t n_pos, const int32_t* __restrict__ nh,
+                                                          const int32_t* __restrict__ nt, int64_t n_neg, int npp,
+                                                          int32_t* __restrict__ cnt) {
+  const int64_t total = n_pos + n_neg;
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    if (i < n_pos) {
+      atomicAdd(&cnt[ph[i]], 1);
+      atomicAdd(&cnt[pt[i]], 1);
+    } else {
+      const int64_t n = i - n_pos;
+      const int64_t g = n / npp;
+      const int a = nh[n], b = nt[n];
+      if (a != ph[g]) atomicAdd(&cnt[a], 1);
+      if (b != pt[g]) atomicAdd(&cnt[b], 1);
+    }
+  }
+}
+
 }  // namespace mke
 
-extern "C" int mke_triple_score_fwd_bwd(
+static int score_impl(
     const float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel,
     int rel_normalize, int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t,
     const float* pos_w, int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t,
     const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
-    int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream) {
+    int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream,
+    int32_t* ref_count, float* ent_w, float* ent_acc, int optimizer, float lr) {
   using namespace mke;
   if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
   if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
@@ -309,11 +382,56 @@ extern "C" int mke_triple_score_fwd_bwd(
   p.grel_copy_elems = n_rel * (int64_t)stride;
   p.tent = touched_ent; p.trel = touched_rel; p.tag = tag;
   p.lossp = loss_partials;
+  const bool excl = ref_count != nullptr && grad_ent != nullptr && neg_per_pos > 0;
+  p.refcount = excl ? ref_count : nullptr; p.ent_w = ent_w; p.ent_acc = ent_acc; p.optimizer = optimizer; p.lr = lr;
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;
   MKE_DISPATCH_FPL(fpl, {
     constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);  // corrupt rows in flight per quarter-wave
-    hipLaunchKernelGGL((k_triple_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+    if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_triple_score<FPL, U, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
   });
   return check_launch("k_triple_score");
+}
+
+extern "C" int mke_triple_score_fwd_bwd(
+    const float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel,
+    int rel_normalize, int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t,
+    const float* pos_w, int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t,
+    const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
+    int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream) {
+  return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
+                    n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
+                    touched_ent, touched_rel, tag, loss_partials, stream, nullptr, nullptr, nullptr, 0, 0.f);
+}
+
+extern "C" int mke_triple_score_fwd_bwd_x(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int grad_rel_copies, int32_t* touched_ent,
+    int32_t* touched_rel, int32_t tag, int32_t* ref_count, float* ent_acc, int optimizer, float lr, double* loss_partials,
+    void* stream) {
+  using namespace mke;
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (ref_count && optimizer == MKE_OPT_ADAGRAD && !ent_acc) { set_error("exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  if (ref_count && !grad_ent) { set_error("exclusive-row path needs the gradient scratch (it is a training step)"); return MKE_E_NULL; }
+  return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
+                    n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
+                    touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
+                    optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr);
+}
+
+extern "C" int mke_count_entity_refs(const int32_t* pos_h, const int32_t* pos_t, int64_t n_pos, const int32_t* neg_h,
+                                     const int32_t* neg_t, int64_t n_neg, int neg_per_pos, int32_t* ref_count, void* stream) {
+  using namespace mke;
+  if (n_pos < 0 || n_neg < 0) { set_error("negative count"); return MKE_E_SHAPE; }
+  if (n_pos + n_neg == 0) return MKE_OK;
+  if (!ref_count || !pos_h || !pos_t || (n_neg > 0 && (!neg_h || !neg_t))) { set_error("mke_count_entity_refs: NULL pointer"); return MKE_E_NULL; }
+  if (n_neg > 0 && (neg_per_pos < 1 || n_neg != n_pos * (int64_t)neg_per_pos)) { set_error("mke_count_entity_refs needs grouped negatives"); return MKE_E_SHAPE; }
+  int64_t blocks = (n_pos + n_neg + MKE_BLOCK - 1) / MKE_BLOCK;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_count_refs, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, pos_h, pos_t, n_pos, neg_h,
+                     neg_t, n_neg, neg_per_pos < 1 ? 1 : neg_per_pos, ref_count);
+  return check_launch("k_count_refs");
 }

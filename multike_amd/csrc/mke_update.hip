@@ -19,6 +19,7 @@ struct UpdateParams {
   float* __restrict__ grad;
   int copies;
   const int32_t* __restrict__ touched;
+  int32_t* __restrict__ refcount;  // nullable
   int32_t tag;
   int64_t n_rows;
   int stride, dim;
@@ -51,6 +52,7 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
   }
 #pragma unroll
   for (int k = 0; k < FPL; ++k) gp[k * 16] = 0.f;  // consume: restore the all-zero invariant
+  if (p.refcount && j == 0) p.refcount[row] = 0;
 
   if (p.normalize) {
     float s = 0.f, dot = 0.f;
@@ -143,6 +145,7 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
     UpdateParams& p = mp.t[k];
     p.table = tables[k].table; p.acc = tables[k].acc; p.grad = tables[k].grad; p.touched = tables[k].touched;
     p.copies = tables[k].grad_copies < 1 ? 1 : tables[k].grad_copies;
+    p.refcount = tables[k].ref_count;
     p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
     p.optimizer = optimizer; p.lr = lr;
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
@@ -173,6 +176,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   if (n_rows == 0) return MKE_OK;
   UpdateParams p;
   p.table = table; p.acc = acc; p.grad = grad; p.copies = grad_copies < 1 ? 1 : grad_copies; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
+  p.refcount = nullptr;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
   const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
   const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;

@@ -21,12 +21,13 @@ _OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
 class RelationViewRunner:
     def __init__(self, ent: EmbeddingTable, rel: EmbeddingTable, batcher: RelationBatcher, opt_name: str = "relation",
                  lr: float = 0.001, optimizer: str = "Adagrad", scale: float = 1.0, sample_chunk: int | None = None,
-                 max_try: int = 10):
+                 max_try: int = 10, exclusive_rows: bool = True):
         if optimizer not in _OPT:
             raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
         self.ent, self.rel, self.bat = ent, rel, batcher
         self.opt_name, self.lr, self.optimizer, self.scale, self.max_try = opt_name, lr, optimizer, scale, max_try
         self.steps = batcher.steps
+        self.exclusive_rows = exclusive_rows
         N = batcher.neg_per_pos
         # negatives of a whole chunk of steps are sampled by one launch; by default the whole epoch
         # (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB of HBM)
@@ -55,6 +56,7 @@ class RelationViewRunner:
         if e.grad_copies != 1:
             raise _lib.MultiKEHipError("the entity table's gradient scratch cannot be privatised")
         p.ent_touched, p.rel_touched = _lib.ptr(e.touched, torch.int32, "t"), _lib.ptr(r.touched, torch.int32, "t")
+        p.ent_ref_count = _lib.ptr(e.refcount, torch.int32, "refcount") if self.exclusive_rows else None
         p.stride, p.dim = e.stride, e.dim
         p.pos_kg = _lib.ptr(b.pos_kg, torch.uint8, "pos_kg")
         p.step_off = self._step_off.ctypes.data_as(C.POINTER(C.c_int64))

@@ -40,6 +40,14 @@ class EmbeddingTable:
         self.slots: dict[str, torch.Tensor] = {}
         self._grad = None
         self._touched = None
+        self._refcount = None
+
+    @property
+    def refcount(self) -> torch.Tensor:
+        """int32 [n_rows] zero-invariant scratch of the exclusive-row fast path (mke_count_entity_refs)."""
+        if self._refcount is None:
+            self._refcount = torch.zeros(self.n_rows, dtype=torch.int32, device=self.device)
+        return self._refcount
 
     # -- scratch (shared by every optimizer of this table; steps are serial on the stream) --
     @property
@@ -119,10 +127,23 @@ class StepEngine:
         _lib.rows_update(table.data, acc, table.grad, table.touched, tag, table.dim, table.normalize, _OPT[optimizer], lr)
 
     def relation_step(self, ent: EmbeddingTable, rel: EmbeddingTable, opt_name: str, pos, neg=None, neg_per_pos=0,
-                      lr=0.001, pos_w=None, neg_w=None, scale=1.0, optimizer="Adagrad", update=True) -> torch.Tensor:
-        """loss + optimizer of a relation-view style graph (a1/a2/a3).  Returns the [1024] loss partials
-        (a view into the ring; `.sum()` is the loss) without synchronising."""
+                      lr=0.001, pos_w=None, neg_w=None, scale=1.0, optimizer="Adagrad", update=True,
+                      exclusive_rows=True) -> torch.Tensor:
+        """loss + optimizer of a relation-view style graph (a1/a2/a3).  Returns the loss partials (a view into the
+        ring; `.sum()` is the loss) without synchronising.  With grouped negatives the exclusive-row fast path is
+        used (rows referenced once in the step are updated by the scoring quarter-wave itself)."""
         tag, lp = self._next()
+        if update and exclusive_rows and neg is not None and neg_per_pos > 0 and optimizer in _OPT:
+            _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], neg_per_pos, ent.refcount)
+            acc = ent.slot(opt_name) if optimizer == "Adagrad" else None
+            _lib.triple_score_fwd_bwd_x(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
+                                        neg_per_pos, scale, ent.grad, rel.grad, ent.touched, rel.touched, tag, ent.refcount,
+                                        acc, _OPT[optimizer], lr, lp)
+            _lib.rows_update_multi([(rel.data, rel.slot(opt_name) if optimizer == "Adagrad" else None, rel.grad, rel.touched,
+                                     rel.normalize),
+                                    (ent.data, acc, ent.grad, ent.touched, ent.normalize, ent.refcount)], tag, ent.stride,
+                                   ent.dim, _OPT[optimizer], lr)
+            return lp
         _lib.triple_score_fwd_bwd(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
                                   neg_per_pos, scale, ent.grad if update else None, rel.grad if update else None,
                                   ent.touched, rel.touched, tag, lp)

@@ -41,6 +41,7 @@ def test_golden_three_steps(losses_golden, ci, copies):
     # invariants: gradient scratch consumed, pad columns still zero
     assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
     assert float(E.data[:, E.dim:].abs().max()) == 0.0
+    assert int(E.refcount.abs().sum()) == 0          # exclusive-row bookkeeping restored
 
 
 @pytest.mark.parametrize("d,P,N,grouped", [(75, 300, 25, True), (75, 300, 25, False), (4, 50, 3, True),
@@ -215,6 +216,7 @@ def test_full_size_c2_batch_vs_c_oracle():
             touched[x.long()] = True
         assert torch.equal(E.data[~touched], before[~touched])
         assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+        assert int(E.refcount.abs().sum()) == 0
     # additivity: loss(batch) == loss(first half) + loss(second half), forward only
     pos, neg = bat.batch(2)
     h = pos[0].numel() // 2
