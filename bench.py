@@ -168,13 +168,14 @@ def main():
             pos, neg = bat.batch(s)
             tag, lp = eng._next()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], N, E.refcount)
             e0.record()
-            _lib.triple_score_fwd_bwd(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
-                                      E.touched, R.touched, tag, lp)
+            _lib.triple_score_fwd_bwd_x(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
+                                        E.touched, R.touched, tag, E.refcount, E.slot("relation"), _lib.OPT_ADAGRAD, 0.001, lp)
             e1.record()
             ev.append((e0, e1, pos[0].numel() * (1 + N)))
             _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
-                                    (E.data, E.slot("relation"), E.grad, E.touched, True)], tag, E.stride, d,
+                                    (E.data, E.slot("relation"), E.grad, E.touched, True, E.refcount)], tag, E.stride, d,
                                    _lib.OPT_ADAGRAD, 0.001)
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
@@ -233,7 +234,8 @@ def main():
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "alg_bytes_per_triple": b_alg(d),
                     "triples_per_launch": float(tr.mean())}
-        # second kernel of the step, reported beside it: touched rows x 6 row streams (grad, w, acc read; 0, w, acc written)
+        # second kernel of the step, reported beside it: rows left to it (referenced more than once in the step) x 6 row
+        # streams (grad, w, acc read; 0, w, acc written); rows referenced once were updated inside k_triple_score
         touched_rows = int((E.touched == ev_upd[-1][2]).sum()) + int((R.touched == ev_upd[-1][2]).sum())
         ums = np.array([a.elapsed_time(b) for a, b, _ in ev_upd])
         upd_bytes = touched_rows * 6 * E.stride * 4
