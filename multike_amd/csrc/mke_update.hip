@@ -6,9 +6,10 @@
 // gradient is exactly zero is left bit-identical (acc += 0, w -= 0), so visiting only the rows flagged
 // by the scatter kernels is the same function at a fraction of the traffic.
 //
-// Shape: a 16-lane quarter-wave takes 16 consecutive rows; lane j reads touched[base+j] (one 64-byte
-// read), the quarter ballots the flags and walks the set bits; each visited row is 3 row reads
-// (grad, w, acc) + 3 row writes (0, w, acc).
+// Shape: a wavefront takes 16 consecutive rows; lanes read touched[base + (lane & 15)] (one 64-byte read), the
+// wave ballots the flags and deals the set bits round-robin to its four 16-lane quarter-waves (a dense chunk — the
+// relation table, where every row is hit every step — is 4 rows deep per quarter instead of 16); each visited row is
+// 3 row reads (grad, w, acc) + 3 row writes (0, w, acc).
 #include "mke_common.h"
 
 namespace mke {
@@ -25,6 +26,7 @@ struct UpdateParams {
   int stride, dim;
   int normalize, optimizer;
   float lr;
+  int chunk;  // rows per wavefront: 16, or 4 for small dense tables (every quarter-wave gets its own row at once)
 };
 
 template <int FPL>
@@ -85,23 +87,30 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
   for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
 }
 
+// One wavefront, one 16-row chunk: ballot the flags, deal the set bits round-robin to the four quarter-waves.  Every
+// quarter looks up ITS row of the round (the (4*round + q)-th set bit) so that the four row visits of a round execute
+// together in one instruction stream — a branch per set bit would serialise them.
+template <int FPL>
+__device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, int j, int q) {
+  const int64_t base = wave * p.chunk;
+  if (base >= p.n_rows) return;  // wave-uniform
+  const int64_t r = base + (j & (p.chunk - 1));
+  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
+  const uint32_t m = (uint32_t)(__ballot(mine) & ((1ull << p.chunk) - 1ull));  // the quarters hold the same flags
+  const int total = __popc(m);
+  for (int round = 0; round * 4 < total; ++round) {
+    const int target = round * 4 + q;
+    uint32_t t = m;
+    for (int k = 0; k < target; ++k) t &= t - 1;  // drop the `target` lowest set bits (<= 15 iterations)
+    if (target < total) update_one_row<FPL>(p, base + __builtin_ctz(t), j);
+  }
+}
+
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update(const UpdateParams p) {
   const int j = threadIdx.x & 15;
-  const int64_t sub = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
-  const int64_t base = sub * 16;
-  if (base >= p.n_rows) return;
-  const int64_t r = base + j;
-  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
-  // 64-bit wave ballot -> this quarter's 16 bits
-  const uint64_t ball = __ballot(mine);
-  const int q = (threadIdx.x & 63) >> 4;
-  uint32_t m = (uint32_t)((ball >> (q * 16)) & 0xFFFFu);
-  while (m) {
-    const int b = __builtin_ctz(m);
-    m &= m - 1;
-    update_one_row<FPL>(p, base + b, j);
-  }
+  const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  walk_chunk<FPL>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
 struct MultiUpdateParams {
@@ -120,34 +129,25 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   }
   const UpdateParams& p = mp.t[ti];
   const int j = threadIdx.x & 15;
-  const int64_t sub = (((int64_t)blockIdx.x - first) * MKE_BLOCK + threadIdx.x) >> 4;
-  const int64_t base = sub * 16;
-  if (base >= p.n_rows) return;
-  const int64_t r = base + j;
-  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
-  const uint64_t ball = __ballot(mine);
-  const int q = (threadIdx.x & 63) >> 4;
-  uint32_t m = (uint32_t)((ball >> (q * 16)) & 0xFFFFu);
-  while (m) {
-    const int b = __builtin_ctz(m);
-    m &= m - 1;
-    update_one_row<FPL>(p, base + b, j);
-  }
+  const int64_t wave = (((int64_t)blockIdx.x - first) * MKE_BLOCK + threadIdx.x) >> 6;
+  walk_chunk<FPL>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
+
+static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : 16; }
 
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st) {
   MultiUpdateParams mp;
   mp.n_tables = n_tables;
-  const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
   int64_t blocks = 0;
   for (int k = 0; k < n_tables; ++k) {
+    const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * chunk_for(tables[k].n_rows);
     UpdateParams& p = mp.t[k];
     p.table = tables[k].table; p.acc = tables[k].acc; p.grad = tables[k].grad; p.touched = tables[k].touched;
     p.copies = tables[k].grad_copies < 1 ? 1 : tables[k].grad_copies;
     p.refcount = tables[k].ref_count;
     p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
-    p.optimizer = optimizer; p.lr = lr;
+    p.optimizer = optimizer; p.lr = lr; p.chunk = chunk_for(tables[k].n_rows);
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
     mp.block_end[k] = blocks;
   }
@@ -178,7 +178,8 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   p.table = table; p.acc = acc; p.grad = grad; p.copies = grad_copies < 1 ? 1 : grad_copies; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
   p.refcount = nullptr;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
-  const int64_t rows_per_block = (int64_t)MKE_SUBS_PER_BLOCK * 16;
+  p.chunk = n_rows <= 16384 ? 4 : 16;
+  const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * p.chunk;
   const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;

@@ -78,3 +78,18 @@ torch.cuda.synchronize()
 ms = np.array([x.elapsed_time(y) for x, y in ev]) * 1e3
 ntouch = int((E.touched == tag).sum())
 print(f"update alone: median {np.median(ms):7.1f} us; touched entity rows {ntouch} -> {ntouch*6*E.stride*4/np.median(ms)/1e3:7.1f} GB/s (6 row streams)")
+
+# split: relation table and entity table updated by separate launches (where does the update time go?)
+for name, tbl in (("rel", R), ("ent", E)):
+    ev = []
+    for i in range(a.iters):
+        tag = score(i)
+        other = E if tbl is R else R
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.rows_update(tbl.data, tbl.slot("x"), tbl.grad, tbl.touched, tag, d, True, 0, 0.001)
+        e1.record(); ev.append((e0, e1))
+        _lib.rows_update(other.data, other.slot("x"), other.grad, other.touched, tag, d, True, 0, 0.001)
+    torch.cuda.synchronize()
+    ms = np.array([x.elapsed_time(y) for x, y in ev]) * 1e3
+    print(f"update {name} table alone: median {np.median(ms):7.1f} us ({int((tbl.touched == tag).sum())} rows)")
