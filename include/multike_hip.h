@@ -285,7 +285,14 @@ typedef struct mke_relation_plan {
   float* ent_grad; float* rel_grad;          /* zero-invariant gradient scratch; rel_grad is [rel_grad_copies][n_rel][stride] */
   int rel_grad_copies;
   int32_t* ent_touched; int32_t* rel_touched;
-  int32_t* ent_ref_count;                    /* nullable: enables the exclusive-row fast path (zero-invariant scratch) */
+  int32_t* ent_ref_count;                    /* nullable: enables the exclusive-row fast path (zero-invariant scratch);
+                                                [2][n_ent] when overlap != 0 */
+  int overlap;                               /* != 0: the table-independent work of the NEXT step (reference counting) and of
+                                                the NEXT sample chunk (negative sampling) is enqueued on a second stream and
+                                                overlaps with scoring / updating the current step.  Needs neg_* to hold TWO
+                                                chunk buffers of neg_chunk_capacity elements each and ent_ref_count [2][n_ent].
+                                                The call creates and destroys its own stream and events. */
+  int64_t neg_chunk_capacity;                /* elements per negative chunk buffer (overlap mode) */
   int stride, dim;
   const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t;  /* device, epoch order */
   const uint8_t* pos_kg;                     /* device, [n positives] 0/1 */

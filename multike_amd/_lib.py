@@ -52,8 +52,8 @@ class RelationPlanStruct(C.Structure):
         ("rel_table", C.c_void_p), ("n_rel", C.c_int64), ("rel_normalize", C.c_int),
         ("ent_acc", C.c_void_p), ("rel_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("rel_grad", C.c_void_p),
         ("rel_grad_copies", C.c_int),
-        ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("ent_ref_count", C.c_void_p),
-        ("stride", C.c_int), ("dim", C.c_int),
+        ("ent_touched", C.c_void_p), ("rel_touched", C.c_void_p), ("ent_ref_count", C.c_void_p), ("overlap", C.c_int),
+        ("neg_chunk_capacity", C.c_int64), ("stride", C.c_int), ("dim", C.c_int),
         ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("pos_kg", C.c_void_p),
         ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("sides", KGSideStruct * 2),
         ("neg_per_pos", C.c_int), ("max_try", C.c_int), ("sample_chunk", C.c_int),

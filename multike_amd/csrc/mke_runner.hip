@@ -4,6 +4,106 @@
 // fused triple step -> one update launch covering the relation and the entity table.
 #include "mke_common.h"
 
+namespace mke {
+#define RUN_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("mke_relation_steps: %s: %s", #x, hipGetErrorString(e_)); rc = (int)e_; goto done; } } while (0)
+#define RUN_MKE(x) do { rc = (x); if (rc) goto done; } while (0)
+
+// Overlapped schedule: a second stream runs the work that does not depend on the tables — reference counting of step
+// s+1 and negative sampling of chunk c+1 — while the main stream scores and updates step s.
+static int run_overlapped(const mke_relation_plan* pl, int step_begin, int step_end, hipStream_t mainS, const mke_update_table* ut_in) {
+  int rc = MKE_OK;
+  const int N = pl->neg_per_pos, SC = pl->sample_chunk;
+  hipStream_t side = nullptr;
+  hipEvent_t evC[2] = {nullptr, nullptr}, evU[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr}, evFree[2] = {nullptr, nullptr},
+             evStart = nullptr;
+  bool uRecorded[2] = {false, false}, freeRecorded[2] = {false, false};
+  int sampled_hi = -1;  // highest chunk index whose sampler launch has been enqueued
+  mke_update_table ut[2] = {ut_in[0], ut_in[1]};
+  const int first_chunk = step_begin / SC;
+  auto chunk_lo = [&](int c) { int s = c * SC; if (s < step_begin) s = step_begin; return s; };
+  auto chunk_hi = [&](int c) { int s = (c + 1) * SC; return s < step_end ? s : step_end; };
+  auto sample_chunk = [&](int c) -> int {   // on the side stream; chunks are sampled in order, each once
+    if (c <= sampled_hi) return MKE_OK;
+    sampled_hi = c;
+    const int s0 = chunk_lo(c), s1 = chunk_hi(c);
+    if (s0 >= s1) return MKE_OK;
+    const int b = c & 1;
+    if (freeRecorded[b]) { hipError_t e = hipStreamWaitEvent(side, evFree[b], 0); if (e != hipSuccess) return (int)e; }
+    const int64_t lo = pl->step_off[s0], n = pl->step_off[s1] - lo;
+    if (n * N > pl->neg_chunk_capacity) { set_error("negative chunk buffer too small: %lld > %lld", (long long)(n * N), (long long)pl->neg_chunk_capacity); return MKE_E_SHAPE; }
+    const int64_t o = (int64_t)b * pl->neg_chunk_capacity;
+    int r = mke_neg_sample(pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, n, lo, pl->pos_kg ? pl->pos_kg + lo : nullptr, pl->sides, N,
+                           pl->max_try, pl->seed_lo, pl->seed_hi, pl->stream_id, pl->neg_h + o, pl->neg_r + o, pl->neg_t + o, side);
+    if (r) return r;
+    hipError_t e = hipEventRecord(evS[b], side);
+    return e == hipSuccess ? MKE_OK : (int)e;
+  };
+  auto neg_off = [&](int s) {  // element offset of step s's negatives inside neg_*
+    const int c = s / SC;
+    return (int64_t)(c & 1) * pl->neg_chunk_capacity + (pl->step_off[s] - pl->step_off[chunk_lo(c)]) * N;
+  };
+  auto side_step = [&](int s) -> int {      // reference counts of step s
+    const int b = s & 1;
+    { const int r0 = sample_chunk(s / SC); if (r0) return r0; }  // normally already done one chunk ahead (below)
+    if (uRecorded[b]) { hipError_t e = hipStreamWaitEvent(side, evU[b], 0); if (e != hipSuccess) return (int)e; }
+    const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1], no = neg_off(s);
+    int r = mke_count_entity_refs(pl->pos_h + lo, pl->pos_t + lo, hi - lo, pl->neg_h + no, pl->neg_t + no, (hi - lo) * N, N,
+                                  pl->ent_ref_count + (int64_t)b * pl->n_ent, side);
+    if (r) return r;
+    hipError_t e = hipEventRecord(evC[b], side);
+    return e == hipSuccess ? MKE_OK : (int)e;
+  };
+
+  RUN_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    RUN_HIP(hipEventCreateWithFlags(&evC[i], hipEventDisableTiming));
+    RUN_HIP(hipEventCreateWithFlags(&evU[i], hipEventDisableTiming));
+    RUN_HIP(hipEventCreateWithFlags(&evS[i], hipEventDisableTiming));
+    RUN_HIP(hipEventCreateWithFlags(&evFree[i], hipEventDisableTiming));
+  }
+  RUN_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+  RUN_HIP(hipEventRecord(evStart, mainS));           // everything the caller enqueued before (epoch shuffle) is visible
+  RUN_HIP(hipStreamWaitEvent(side, evStart, 0));
+  sampled_hi = first_chunk - 1;
+  RUN_MKE(side_step(step_begin));
+  for (int s = step_begin; s < step_end; ++s) {
+    if (s + 1 < step_end) RUN_MKE(side_step(s + 1));   // look ahead: overlaps with this step's kernels
+    const int b = s & 1, c = s / SC;
+    if (s == chunk_lo(c)) RUN_HIP(hipStreamWaitEvent(mainS, evS[c & 1], 0));
+    RUN_HIP(hipStreamWaitEvent(mainS, evC[b], 0));
+    const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1], no = neg_off(s);
+    const int32_t tag = pl->tag_base + s;
+    int32_t* refc = pl->ent_ref_count + (int64_t)b * pl->n_ent;
+    RUN_MKE(mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
+                                       pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
+                                       pl->neg_h + no, pl->neg_r + no, pl->neg_t + no, nullptr, (hi - lo) * N, N, pl->scale,
+                                       pl->ent_grad, pl->rel_grad, pl->rel_grad_copies, pl->ent_touched, pl->rel_touched, tag, refc,
+                                       pl->ent_acc, pl->optimizer, pl->lr,
+                                       pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, mainS));
+    ut[1].ref_count = refc;
+    RUN_MKE(mke_rows_update_multi(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, mainS));
+    RUN_HIP(hipEventRecord(evU[b], mainS));
+    uRecorded[b] = true;
+    if (s + 1 == chunk_hi(c)) { RUN_HIP(hipEventRecord(evFree[c & 1], mainS)); freeRecorded[c & 1] = true; }
+    // one chunk ahead: chunk c+1's negatives go to the buffer chunk c-1 used; its last step is enqueued by now
+    if (s == chunk_lo(c) && chunk_lo(c + 1) < step_end) RUN_MKE(sample_chunk(c + 1));
+  }
+  // the caller's stream must not run ahead of the side stream's last work (buffers are the caller's)
+  RUN_HIP(hipEventRecord(evStart, side));
+  RUN_HIP(hipStreamWaitEvent(mainS, evStart, 0));
+done:
+  for (int i = 0; i < 2; ++i) {
+    if (evC[i]) (void)hipEventDestroy(evC[i]);
+    if (evU[i]) (void)hipEventDestroy(evU[i]);
+    if (evS[i]) (void)hipEventDestroy(evS[i]);
+    if (evFree[i]) (void)hipEventDestroy(evFree[i]);
+  }
+  if (evStart) (void)hipEventDestroy(evStart);
+  if (side) (void)hipStreamDestroy(side);
+  return rc;
+}
+}  // namespace mke
+
 extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, int step_end, void* stream) {
   using namespace mke;
   if (!pl) { set_error("mke_relation_steps: NULL plan"); return MKE_E_NULL; }
@@ -19,6 +119,12 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
   ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies; ut[0].ref_count = nullptr;
   ut[1].table = pl->ent_table; ut[1].acc = pl->ent_acc; ut[1].grad = pl->ent_grad; ut[1].touched = pl->ent_touched;
   ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1; ut[1].ref_count = pl->ent_ref_count;
+
+  if (pl->overlap) {
+    if (N <= 0 || !pl->ent_ref_count) { set_error("overlap mode needs negatives and the reference-count scratch"); return MKE_E_SHAPE; }
+    if (step_begin == step_end) return MKE_OK;
+    return run_overlapped(pl, step_begin, step_end, (hipStream_t)stream, ut);
+  }
 
   int64_t chunk_lo = 0;  // first positive (epoch position) whose negatives sit at neg_*[0]
   int chunk_end = step_begin;  // steps < chunk_end are sampled

@@ -21,7 +21,7 @@ _OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
 class RelationViewRunner:
     def __init__(self, ent: EmbeddingTable, rel: EmbeddingTable, batcher: RelationBatcher, opt_name: str = "relation",
                  lr: float = 0.001, optimizer: str = "Adagrad", scale: float = 1.0, sample_chunk: int | None = None,
-                 max_try: int = 10, exclusive_rows: bool = True):
+                 max_try: int = 10, exclusive_rows: bool = True, overlap: bool | None = None):
         if optimizer not in _OPT:
             raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
         self.ent, self.rel, self.bat = ent, rel, batcher
@@ -29,12 +29,21 @@ class RelationViewRunner:
         self.steps = batcher.steps
         self.exclusive_rows = exclusive_rows
         N = batcher.neg_per_pos
-        # negatives of a whole chunk of steps are sampled by one launch; by default the whole epoch
-        # (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB of HBM)
-        self.sample_chunk = self.steps if sample_chunk is None else max(1, min(int(sample_chunk), self.steps))
+        # overlap mode (default with negatives + exclusive rows): the next step's reference counts and the next chunk's
+        # negatives are produced on a second stream while the current step is scored and updated (chunks of 8 steps,
+        # two chunk buffers).  Otherwise negatives of a whole chunk are sampled by one launch on the same stream, by
+        # default the whole epoch (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB).
+        self.overlap = (exclusive_rows and N > 0) if overlap is None else bool(overlap)
+        if self.overlap and not (exclusive_rows and N > 0):
+            raise _lib.MultiKEHipError("overlap mode needs negatives and exclusive_rows")
+        default_chunk = 8 if self.overlap else self.steps
+        self.sample_chunk = default_chunk if sample_chunk is None else max(1, min(int(sample_chunk), max(self.steps, 1)))
         off = batcher.off
         span = max(int(off[min(s + self.sample_chunk, self.steps)] - off[s]) for s in range(self.steps)) if self.steps else 0
-        self.neg = tuple(torch.empty(max(1, span * N), dtype=torch.int32, device=ent.device) for _ in range(3))
+        self.neg_chunk_capacity = max(1, span * N)
+        nbuf = 2 if self.overlap else 1
+        self.neg = tuple(torch.empty(nbuf * self.neg_chunk_capacity, dtype=torch.int32, device=ent.device) for _ in range(3))
+        self.refcount = torch.zeros(2 * ent.n_rows, dtype=torch.int32, device=ent.device) if self.overlap else None
         self.loss = torch.zeros(max(1, self.steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=ent.device)
         self._step_off = np.ascontiguousarray(off, dtype=np.int64)
         self.tag = 0  # tags handed out so far; each epoch consumes `steps` of them
@@ -56,7 +65,12 @@ class RelationViewRunner:
         if e.grad_copies != 1:
             raise _lib.MultiKEHipError("the entity table's gradient scratch cannot be privatised")
         p.ent_touched, p.rel_touched = _lib.ptr(e.touched, torch.int32, "t"), _lib.ptr(r.touched, torch.int32, "t")
-        p.ent_ref_count = _lib.ptr(e.refcount, torch.int32, "refcount") if self.exclusive_rows else None
+        if self.overlap:
+            p.ent_ref_count = _lib.ptr(self.refcount, torch.int32, "refcount")
+        else:
+            p.ent_ref_count = _lib.ptr(e.refcount, torch.int32, "refcount") if self.exclusive_rows else None
+        p.overlap = int(self.overlap)
+        p.neg_chunk_capacity = self.neg_chunk_capacity
         p.stride, p.dim = e.stride, e.dim
         p.pos_kg = _lib.ptr(b.pos_kg, torch.uint8, "pos_kg")
         p.step_off = self._step_off.ctypes.data_as(C.POINTER(C.c_int64))

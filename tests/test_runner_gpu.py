@@ -32,15 +32,15 @@ def _setup(seed=3, n_ent=4000, n_rel=30, d=75, B=500, N=10):
     return kgs, ent, rel, fresh
 
 
-@pytest.mark.parametrize("chunk", [1, 7, None])
-def test_runner_equals_python_steps_and_oracle(chunk):
+@pytest.mark.parametrize("chunk,overlap", [(1, False), (7, False), (None, False), (1, True), (3, True), (None, True)])
+def test_runner_equals_python_steps_and_oracle(chunk, overlap):
     from multike_amd.runner import RelationViewRunner
     from multike_amd.tables import StepEngine
     kgs, ent, rel, fresh = _setup()
     d, N = 75, 10
     # (a) native runner, one call for the whole epoch
     E1, R1, bat1 = fresh()
-    run = RelationViewRunner(E1, R1, bat1, "relation", lr=0.01, sample_chunk=chunk)
+    run = RelationViewRunner(E1, R1, bat1, "relation", lr=0.01, sample_chunk=chunk, overlap=overlap)
     run.run()
     l_native = run.step_losses().cpu().numpy()
     # (b) python-driven steps
@@ -85,12 +85,13 @@ def test_runner_partial_ranges_and_second_epoch():
     kgs, ent, rel, fresh = _setup(seed=5)
     E1, R1, bat1 = fresh()
     E2, R2, bat2 = fresh()
-    r1 = RelationViewRunner(E1, R1, bat1, lr=0.01, sample_chunk=4)
-    r2 = RelationViewRunner(E2, R2, bat2, lr=0.01)
+    r1 = RelationViewRunner(E1, R1, bat1, lr=0.01, sample_chunk=4, overlap=True)
+    r2 = RelationViewRunner(E2, R2, bat2, lr=0.01, overlap=False)
     for ep in range(2):
         r1.run(0, 5); r1.run(5, 6); r1.run(6, None)          # same epoch in three calls
         r2.run()
         np.testing.assert_allclose(r1.step_losses().cpu().numpy(), r2.step_losses().cpu().numpy(), rtol=2e-6)
         bat1.shuffle(); bat2.shuffle()
     np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(r1.refcount.abs().sum()) == 0 and int(E2.refcount.abs().sum()) == 0     # zero-invariant restored
     assert not torch.equal(bat1.pos_h, _setup(seed=5)[3]()[2].pos_h)  # the shuffle really permuted the epoch
