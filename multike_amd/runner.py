@@ -29,11 +29,13 @@ class RelationViewRunner:
         self.steps = batcher.steps
         self.exclusive_rows = exclusive_rows
         N = batcher.neg_per_pos
-        # overlap mode (default with negatives + exclusive rows): the next step's reference counts and the next chunk's
-        # negatives are produced on a second stream while the current step is scored and updated (chunks of 8 steps,
-        # two chunk buffers).  Otherwise negatives of a whole chunk are sampled by one launch on the same stream, by
-        # default the whole epoch (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB).
-        self.overlap = (exclusive_rows and N > 0) if overlap is None else bool(overlap)
+        # Default: negatives of a whole chunk are sampled by one launch on the same stream — by default the whole epoch
+        # (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB).
+        # overlap=True (opt-in): the next step's reference counts and the next chunk's negatives are produced on a
+        # second stream while the current step is scored and updated (chunks of 8 steps, two chunk buffers).  Measured
+        # on MI355X at the C2 shape it is SLOWER (87 vs 75 us/step): three cross-stream event waits per step cost more
+        # than the ~13 us of table-independent work they hide.
+        self.overlap = False if overlap is None else bool(overlap)
         if self.overlap and not (exclusive_rows and N > 0):
             raise _lib.MultiKEHipError("overlap mode needs negatives and exclusive_rows")
         default_chunk = 8 if self.overlap else self.steps
