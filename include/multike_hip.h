@@ -165,6 +165,18 @@ typedef struct mke_update_table {
 int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                           int optimizer, float lr, void* stream);
 
+/* The same launch can also carry the reference counting of the NEXT step (mke_count_entity_refs semantics into
+ * next_ref_count, a different buffer than the ones the tables reset): the counting blocks ride along with the update
+ * blocks instead of paying their own kernel boundary.  count == NULL: plain mke_rows_update_multi. */
+typedef struct mke_count_job {
+  const int32_t* pos_h; const int32_t* pos_t; int64_t n_pos;
+  const int32_t* neg_h; const int32_t* neg_t; int64_t n_neg;
+  int neg_per_pos;
+  int32_t* ref_count;
+} mke_count_job;
+int mke_rows_update_multi_count(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
+                                int optimizer, float lr, const mke_count_job* count /*nullable*/, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (3) Uniform / truncated negative sampler (counter-based Philox4x32-10; specification:
  *     oracle/sampler_oracle.py philox_negatives).
@@ -285,8 +297,9 @@ typedef struct mke_relation_plan {
   float* ent_grad; float* rel_grad;          /* zero-invariant gradient scratch; rel_grad is [rel_grad_copies][n_rel][stride] */
   int rel_grad_copies;
   int32_t* ent_touched; int32_t* rel_touched;
-  int32_t* ent_ref_count;                    /* nullable: enables the exclusive-row fast path (zero-invariant scratch);
-                                                [2][n_ent] when overlap != 0 */
+  int32_t* ent_ref_count;                    /* nullable: enables the exclusive-row fast path (zero-invariant scratch),
+                                                int32 [2][n_ent]: steps alternate between the two halves so that the
+                                                counting of step s+1 can ride in the update launch of step s */
   int overlap;                               /* != 0: the table-independent work of the NEXT step (reference counting) and of
                                                 the NEXT sample chunk (negative sampling) is enqueued on a second stream and
                                                 overlaps with scoring / updating the current step.  Needs neg_* to hold TWO

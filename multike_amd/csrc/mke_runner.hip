@@ -118,7 +118,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
   ut[0].table = pl->rel_table; ut[0].acc = pl->rel_acc; ut[0].grad = pl->rel_grad; ut[0].touched = pl->rel_touched;
   ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies; ut[0].ref_count = nullptr;
   ut[1].table = pl->ent_table; ut[1].acc = pl->ent_acc; ut[1].grad = pl->ent_grad; ut[1].touched = pl->ent_touched;
-  ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1; ut[1].ref_count = pl->ent_ref_count;
+  ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1; ut[1].ref_count = nullptr;
 
   if (pl->overlap) {
     if (N <= 0 || !pl->ent_ref_count) { set_error("overlap mode needs negatives and the reference-count scratch"); return MKE_E_SHAPE; }
@@ -128,6 +128,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
 
   int64_t chunk_lo = 0;  // first positive (epoch position) whose negatives sit at neg_*[0]
   int chunk_end = step_begin;  // steps < chunk_end are sampled
+  bool counted_ahead = false;  // the current step's references were counted by the previous step's update launch
   for (int s = step_begin; s < step_end; ++s) {
     const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1];
     if (N > 0 && s >= chunk_end) {
@@ -141,12 +142,15 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
     }
     const int64_t no = (lo - chunk_lo) * N;
     const int32_t tag = pl->tag_base + s;
-    int32_t* refc = (N > 0) ? pl->ent_ref_count : nullptr;  // exclusive-row fast path
+    // exclusive-row fast path: steps alternate between the two halves of ent_ref_count; the counting of step s+1
+    // rides in the update launch of step s when its negatives are already sampled (same chunk)
+    int32_t* refc = (N > 0 && pl->ent_ref_count) ? pl->ent_ref_count + (int64_t)(s & 1) * pl->n_ent : nullptr;
     int rc = MKE_OK;
-    if (refc) {
+    if (refc && !counted_ahead) {
       rc = mke_count_entity_refs(pl->pos_h + lo, pl->pos_t + lo, hi - lo, pl->neg_h + no, pl->neg_t + no, (hi - lo) * N, N, refc, stream);
       if (rc) return rc;
     }
+    counted_ahead = false;
     rc = mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
                                     pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
                                     N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
@@ -154,7 +158,18 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
                                     pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,
                                     pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, stream);
     if (rc) return rc;
-    rc = mke_rows_update_multi(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, stream);
+    ut[1].ref_count = refc;
+    mke_count_job cj{};
+    const mke_count_job* cjp = nullptr;
+    if (refc && s + 1 < step_end && s + 1 < chunk_end) {  // next step's negatives exist already: count them in this launch
+      const int64_t lo1 = pl->step_off[s + 1], hi1 = pl->step_off[s + 2], no1 = (lo1 - chunk_lo) * N;
+      cj.pos_h = pl->pos_h + lo1; cj.pos_t = pl->pos_t + lo1; cj.n_pos = hi1 - lo1;
+      cj.neg_h = pl->neg_h + no1; cj.neg_t = pl->neg_t + no1; cj.n_neg = (hi1 - lo1) * N; cj.neg_per_pos = N;
+      cj.ref_count = pl->ent_ref_count + (int64_t)((s + 1) & 1) * pl->n_ent;
+      cjp = &cj;
+      counted_ahead = true;
+    }
+    rc = mke_rows_update_multi_count(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, cjp, stream);
     if (rc) return rc;
   }
   return MKE_OK;

@@ -117,10 +117,31 @@ struct MultiUpdateParams {
   UpdateParams t[MKE_MAX_UPDATE_TABLES];
   int64_t block_end[MKE_MAX_UPDATE_TABLES];  // exclusive prefix of blocks per table
   int n_tables;
+  // optional rider: reference counting of the next step in blocks [block_end[n_tables-1], gridDim.x)
+  mke_count_job cj;
+  int count_blocks;
 };
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
+  const int64_t upd_blocks = mp.block_end[mp.n_tables - 1];
+  if ((int64_t)blockIdx.x >= upd_blocks) {  // rider blocks: count the next step's entity references
+    const mke_count_job& c = mp.cj;
+    const int64_t total = c.n_pos + c.n_neg;
+    for (int64_t i = ((int64_t)blockIdx.x - upd_blocks) * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)mp.count_blocks * MKE_BLOCK) {
+      if (i < c.n_pos) {
+        atomicAdd(&c.ref_count[c.pos_h[i]], 1);
+        atomicAdd(&c.ref_count[c.pos_t[i]], 1);
+      } else {
+        const int64_t n = i - c.n_pos;
+        const int64_t g = n / c.neg_per_pos;
+        const int a = c.neg_h[n], b = c.neg_t[n];
+        if (a != c.pos_h[g]) atomicAdd(&c.ref_count[a], 1);
+        if (b != c.pos_t[g]) atomicAdd(&c.ref_count[b], 1);
+      }
+    }
+    return;
+  }
   int ti = 0;
   int64_t first = 0;
 #pragma unroll
@@ -136,9 +157,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
 static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : 16; }
 
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
-                             float lr, hipStream_t st) {
+                             float lr, hipStream_t st, const mke_count_job* count = nullptr) {
   MultiUpdateParams mp;
   mp.n_tables = n_tables;
+  mp.count_blocks = 0;
+  mp.cj = mke_count_job{};
   int64_t blocks = 0;
   for (int k = 0; k < n_tables; ++k) {
     const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * chunk_for(tables[k].n_rows);
@@ -150,6 +173,14 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
     p.optimizer = optimizer; p.lr = lr; p.chunk = chunk_for(tables[k].n_rows);
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
     mp.block_end[k] = blocks;
+  }
+  if (count && count->n_pos + count->n_neg > 0) {
+    int64_t cb = (count->n_pos + count->n_neg + MKE_BLOCK - 1) / MKE_BLOCK;
+    if (cb > 1024) cb = 1024;
+    mp.cj = *count;
+    if (mp.cj.neg_per_pos < 1) mp.cj.neg_per_pos = 1;
+    mp.count_blocks = (int)cb;
+    blocks += cb;
   }
   if (blocks == 0) return MKE_OK;
   const int fpl = stride / 16;
@@ -189,9 +220,22 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   return check_launch("k_rows_update");
 }
 
+extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
+                                           int optimizer, float lr, const mke_count_job* count, void* stream);
+
 extern "C" int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                                      int optimizer, float lr, void* stream) {
+  return mke_rows_update_multi_count(tables, n_tables, tag, stride, dim, optimizer, lr, nullptr, stream);
+}
+
+extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
+                                           int optimizer, float lr, const mke_count_job* count, void* stream) {
   using namespace mke;
+  if (count) {
+    if (count->n_pos < 0 || count->n_neg < 0) { set_error("count job: negative count"); return MKE_E_SHAPE; }
+    if (count->n_pos + count->n_neg > 0 && (!count->ref_count || !count->pos_h || !count->pos_t || (count->n_neg > 0 && (!count->neg_h || !count->neg_t)))) { set_error("count job: NULL pointer"); return MKE_E_NULL; }
+    if (count->n_neg > 0 && (count->neg_per_pos < 1 || count->n_neg != count->n_pos * (int64_t)count->neg_per_pos)) { set_error("count job needs grouped negatives"); return MKE_E_SHAPE; }
+  }
   if (!tables) { set_error("mke_rows_update_multi: NULL tables"); return MKE_E_NULL; }
   if (n_tables < 1 || n_tables > MKE_MAX_UPDATE_TABLES) { set_error("n_tables must be in [1,%d]", MKE_MAX_UPDATE_TABLES); return MKE_E_SHAPE; }
   if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
@@ -201,5 +245,5 @@ extern "C" int mke_rows_update_multi(const mke_update_table* tables, int n_table
     if (optimizer == MKE_OPT_ADAGRAD && !tables[k].acc) { set_error("table %d: Adagrad needs an accumulator", k); return MKE_E_NULL; }
     if (tables[k].n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
   }
-  return launch_rows_update_multi(tables, n_tables, tag, stride, dim, optimizer, lr, (hipStream_t)stream);
+  return launch_rows_update_multi(tables, n_tables, tag, stride, dim, optimizer, lr, (hipStream_t)stream, count);
 }

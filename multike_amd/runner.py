@@ -45,7 +45,8 @@ class RelationViewRunner:
         self.neg_chunk_capacity = max(1, span * N)
         nbuf = 2 if self.overlap else 1
         self.neg = tuple(torch.empty(nbuf * self.neg_chunk_capacity, dtype=torch.int32, device=ent.device) for _ in range(3))
-        self.refcount = torch.zeros(2 * ent.n_rows, dtype=torch.int32, device=ent.device) if self.overlap else None
+        # two halves: steps alternate, so that step s+1 can be counted while step s is being updated
+        self.refcount = torch.zeros(2 * ent.n_rows, dtype=torch.int32, device=ent.device) if exclusive_rows else None
         self.loss = torch.zeros(max(1, self.steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=ent.device)
         self._step_off = np.ascontiguousarray(off, dtype=np.int64)
         self.tag = 0  # tags handed out so far; each epoch consumes `steps` of them
@@ -67,10 +68,7 @@ class RelationViewRunner:
         if e.grad_copies != 1:
             raise _lib.MultiKEHipError("the entity table's gradient scratch cannot be privatised")
         p.ent_touched, p.rel_touched = _lib.ptr(e.touched, torch.int32, "t"), _lib.ptr(r.touched, torch.int32, "t")
-        if self.overlap:
-            p.ent_ref_count = _lib.ptr(self.refcount, torch.int32, "refcount")
-        else:
-            p.ent_ref_count = _lib.ptr(e.refcount, torch.int32, "refcount") if self.exclusive_rows else None
+        p.ent_ref_count = _lib.ptr(self.refcount, torch.int32, "refcount") if self.exclusive_rows else None
         p.overlap = int(self.overlap)
         p.neg_chunk_capacity = self.neg_chunk_capacity
         p.stride, p.dim = e.stride, e.dim

@@ -93,5 +93,5 @@ def test_runner_partial_ranges_and_second_epoch():
         np.testing.assert_allclose(r1.step_losses().cpu().numpy(), r2.step_losses().cpu().numpy(), rtol=2e-6)
         bat1.shuffle(); bat2.shuffle()
     np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
-    assert int(r1.refcount.abs().sum()) == 0 and int(E2.refcount.abs().sum()) == 0     # zero-invariant restored
+    assert int(r1.refcount.abs().sum()) == 0 and int(r2.refcount.abs().sum()) == 0     # zero-invariant restored
     assert not torch.equal(bat1.pos_h, _setup(seed=5)[3]()[2].pos_h)  # the shuffle really permuted the epoch
