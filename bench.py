@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=366)  # two synthetic "epochs" of 183 steps
+    ap.add_argument("--steps", type=int, default=920)  # five synthetic epochs of 184 steps
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-ent", type=int, default=200_000)
     ap.add_argument("--n-rel", type=int, default=550)
