@@ -254,3 +254,48 @@ def test_wide_rows_many_negatives_vs_c_oracle():
     np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
     np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=5e-7)
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
+
+
+@pytest.mark.parametrize("n_ent,P,N", [(300, 400, 25), (5000, 2000, 10)])
+def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
+    """Few entities, many references: almost every row is referenced many times, some exactly once, the same corrupt
+    entity shows up twice inside one group — exercises every branch of the exclusive-row bookkeeping against the oracle."""
+    from gpu_util import dev_i32, make_tables
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(n_ent + P)
+    d, n_rel = 75, 7
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    # Zipf-like heads/tails, uniform corrupt entities
+    pr = 1.0 / np.arange(1, n_ent + 1)
+    pr /= pr.sum()
+    ph, pt = rng.choice(n_ent, P, p=pr), rng.choice(n_ent, P, p=pr)
+    prl = rng.integers(0, n_rel, P)
+    nh, nt, nr = np.repeat(ph, N), np.repeat(pt, N), np.repeat(prl, N)
+    side = rng.integers(0, 2, P * N).astype(bool)
+    c = rng.integers(0, n_ent, P * N)
+    nh = np.where(side, c, nh)
+    nt = np.where(side, nt, c)
+    nh[1], nt[1] = nh[0], nt[0]                    # the same negative twice in one group
+    pos = tuple(a.astype(np.int32) for a in (ph, prl, pt))
+    neg = tuple(a.astype(np.int32) for a in (nh, nr, nt))
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    E, R = make_tables(ent, rel)
+    eng = StepEngine()
+    for step in range(2):
+        L, _, _ = mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01)
+        lp = eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg),
+                               neg_per_pos=N, lr=0.01)
+        np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=5e-5, atol=5e-6)
+    np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=2e-4, atol=1e-6)
+    assert int(E.refcount.abs().sum()) == 0 and float(E.grad.abs().max()) == 0.0
+    # and the two paths agree with each other
+    E2, R2 = make_tables(ent, rel)
+    eng2 = StepEngine()
+    for step in range(2):
+        eng2.relation_step(E2, R2, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg), neg_per_pos=N,
+                           lr=0.01, exclusive_rows=False)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-5, atol=2e-7)
