@@ -411,6 +411,16 @@ int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad,
 int mke_align_rank(const float* emb1, int ld1, const float* emb2_t, int64_t ld2t, int kpad, int64_t n1, int64_t n2,
                    int32_t* rank, uint64_t* best, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (10) Small dense f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) with arbitrary operand strides:
+ *        C[M][N] (=|+=) A[M][K] . B[K][N],  A(i,k) = A[i*a_row_stride + k*a_col_stride], likewise B.
+ *      splits > 1: split-K, partial products are added atomically (accumulate must be 1; C zeroed or holding the
+ *      value to add to).  Used by mke_attr_step for the dense layer of the attribute CNN (tf.layers.dense,
+ *      code/MultiKE_model.py:59) and its two gradient products.
+ * ------------------------------------------------------------------------------------------------ */
+int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_stride, const float* B, int64_t b_row_stride,
+                 int64_t b_col_stride, float* C, int64_t ldc, int M, int N, int K, int splits, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

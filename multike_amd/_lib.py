@@ -28,7 +28,7 @@ SYMBOLS = (
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
-    "mke_dense_update", "mke_align_rank",
+    "mke_dense_update", "mke_align_rank", "mke_gemm_f32",
 )
 
 
@@ -409,3 +409,21 @@ def align_rank(emb1, emb2_t, kpad, n1, n2, rank, best):
                               C.c_int64(emb2_t.shape[1]), C.c_int(kpad), C.c_int64(n1), C.c_int64(n2),
                               _dev(rank, torch.int32, "rank"), _dev(best, torch.int64, "best"), _stream())
     _check(rc, "mke_align_rank")
+
+
+def gemm_f32(lhs, rhs, out, transpose_a=False, transpose_b=False, splits=1, accumulate=False):
+    """out (=|+=) op(lhs) @ op(rhs) for 2-D float32 CUDA tensors of any strides; `out` row-major."""
+    a = lhs.t() if transpose_a else lhs
+    b = rhs.t() if transpose_b else rhs
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2 or tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        raise MultiKEHipError(f"gemm_f32: shapes {tuple(a.shape)} x {tuple(b.shape)} -> {tuple(out.shape)}")
+    for t, nm in ((lhs, "lhs"), (rhs, "rhs"), (out, "out")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise MultiKEHipError(f"gemm_f32: {nm} must be a float32 CUDA tensor")
+    rc = lib().mke_gemm_f32(C.c_void_p(a.data_ptr()), C.c_int64(a.stride(0)), C.c_int64(a.stride(1)),
+                            C.c_void_p(b.data_ptr()), C.c_int64(b.stride(0)), C.c_int64(b.stride(1)),
+                            C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
+                            C.c_int(splits), C.c_int(int(accumulate)), _stream())
+    _check(rc, "mke_gemm_f32")
