@@ -391,6 +391,26 @@ int mke_attr_tail_loss(const float* z, const double* sumsq_partials, const float
                        int32_t* touched_ent, int32_t tag, double* loss_partials, void* stream);
 int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials, int64_t n,
                       int dim, void* stream);
+/* The whole pipeline above as ONE native call (the dense layer's three products run on mke_gemm_f32):
+ * conv_fwd -> GEMM -> tail_z -> tail_loss -> tail_bwd -> bias gradient -> GEMM (dW, split-K) -> GEMM (dflat) -> conv_bwd
+ * -> [update != 0] row updates of the entity / attribute tables and the dense update of the packed parameters.
+ * ent_grad / attr_grad NULL = that table is constant.  param_grads must be all-zero on entry (the dense update restores
+ * it; with update == 0 the caller inspects and clears it).  scratch: mke_attr_scratch_floats(n, dim) floats.
+ * partials: double[3 * MKE_LOSS_PARTIALS] (loss | sum z^2 | sum g.z); the loss is the sum of the first block. */
+typedef struct mke_attr_step_args {
+  float* ent_table; int64_t n_ent; int ent_stride; int ent_normalize; float* ent_acc; float* ent_grad; int32_t* ent_touched;
+  float* attr_table; int64_t n_attr; int attr_stride; int attr_normalize; float* attr_acc; float* attr_grad; int32_t* attr_touched;
+  const float* lit_table; int lit_stride;
+  int dim;
+  const int32_t* ih; const int32_t* ia; const int32_t* iv; const float* weights /*nullable*/; int64_t n;
+  float scale;
+  float* params; float* param_grads; float* param_acc /*nullable for SGD*/;
+  float* scratch; double* partials;
+  int optimizer; float lr; int32_t tag; int update;
+} mke_attr_step_args;
+int64_t mke_attr_scratch_floats(int64_t n, int dim);
+int mke_attr_step(const mke_attr_step_args* args, void* stream);
+
 /* dense Adagrad / SGD over n contiguous floats; grad is zeroed — tf.train.AdagradOptimizer on the CNN variables */
 int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,
                      void* stream);

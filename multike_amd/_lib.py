@@ -28,8 +28,23 @@ SYMBOLS = (
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
-    "mke_dense_update", "mke_align_rank", "mke_gemm_f32",
+    "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step",
 )
+
+
+class AttrStepArgs(C.Structure):
+    """mke_attr_step_args"""
+    _fields_ = [
+        ("ent_table", C.c_void_p), ("n_ent", C.c_int64), ("ent_stride", C.c_int), ("ent_normalize", C.c_int),
+        ("ent_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("ent_touched", C.c_void_p),
+        ("attr_table", C.c_void_p), ("n_attr", C.c_int64), ("attr_stride", C.c_int), ("attr_normalize", C.c_int),
+        ("attr_acc", C.c_void_p), ("attr_grad", C.c_void_p), ("attr_touched", C.c_void_p),
+        ("lit_table", C.c_void_p), ("lit_stride", C.c_int), ("dim", C.c_int),
+        ("ih", C.c_void_p), ("ia", C.c_void_p), ("iv", C.c_void_p), ("weights", C.c_void_p), ("n", C.c_int64),
+        ("scale", C.c_float), ("params", C.c_void_p), ("param_grads", C.c_void_p), ("param_acc", C.c_void_p),
+        ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
+        ("update", C.c_int),
+    ]
 
 
 class KGSideStruct(C.Structure):
@@ -83,6 +98,7 @@ def lib():
         L.mke_last_error.restype = C.c_char_p
         for name in SYMBOLS[2:]:
             getattr(L, name).restype = C.c_int
+        L.mke_attr_scratch_floats.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -427,3 +443,12 @@ def gemm_f32(lhs, rhs, out, transpose_a=False, transpose_b=False, splits=1, accu
                             C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
                             C.c_int(splits), C.c_int(int(accumulate)), _stream())
     _check(rc, "mke_gemm_f32")
+
+
+def attr_scratch_floats(n: int, dim: int) -> int:
+    return int(lib().mke_attr_scratch_floats(C.c_int64(n), C.c_int(dim)))
+
+
+def attr_step(args: AttrStepArgs):
+    rc = lib().mke_attr_step(C.byref(args), _stream())
+    _check(rc, "mke_attr_step")

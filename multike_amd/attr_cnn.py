@@ -28,6 +28,9 @@ class AttrCNN:
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros_like(self.params)
         self.slots: dict[str, torch.Tensor] = {}
+        self._scratch = None
+        self._partials = torch.zeros(8, 3 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
+        self._ring = 0
         d = dim
         o = 0
         self.views, self.gviews = {}, {}
@@ -74,34 +77,38 @@ class AttrCNN:
     def step(self, eng, ent: EmbeddingTable, attr: EmbeddingTable, lit: EmbeddingTable, ih, ia, iv, weights=None,
              scale: float = 1.0, opt_name: str = "attribute", lr: float = 0.001, optimizer: str = "Adagrad",
              update: bool = True) -> torch.Tensor:
-        """loss + optimizer of one attribute-view graph:  scale * sum w * log(1 + exp(-conv(h, a, v))).
-        Returns the loss partials (`.sum()` is the loss).  With update=False the gradients are left in
-        `self.grads`, `ent.grad`, `attr.grad` for inspection."""
-        d, n = self.dim, ih.numel()
-        dev = self.device
-        tag, lp = eng._next()
-        flat = torch.empty(n, 4 * d, dtype=torch.float32, device=dev)
-        _lib.attr_conv_fwd(attr.data, attr.normalize, lit.data, d, ia, iv, self.params, flat)
-        z = torch.matmul(flat, self.views["W"])                                  # library GEMM [n,4d] x [4d,d]
-        ssq = torch.empty(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
-        dot = torch.empty(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
-        _lib.attr_tail_z(z, self.views["bias"], ssq)
-        gout = torch.empty(n, d, dtype=torch.float32, device=dev)
-        _lib.attr_tail_loss(z, ssq, ent.data, ent.normalize, ih, weights, scale, gout, dot,
-                            ent.grad if ent.trainable else None, ent.touched if ent.trainable else None, tag, lp)
-        _lib.attr_tail_bwd(z, gout, ssq, dot)                                    # gout is now dL/dzpre
-        torch.matmul(flat.t(), gout, out=self.gviews["W"])
-        torch.sum(gout, 0, out=self.gviews["bias"])
-        dflat = torch.matmul(gout, self.views["W"].t())
-        _lib.attr_conv_bwd(attr.data, attr.normalize, lit.data, d, ia, iv, self.params, dflat, self.grads,
-                           attr.grad if attr.trainable else None, attr.touched if attr.trainable else None, tag)
-        if update:
-            if optimizer not in _OPT:
-                raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
-            if ent.trainable:
-                eng._apply(ent, opt_name, optimizer, lr, tag)
-            if attr.trainable:
-                eng._apply(attr, opt_name, optimizer, lr, tag)
-            _lib.dense_update(self.params, self.slot(opt_name) if optimizer == "Adagrad" else None, self.grads,
-                              _OPT[optimizer], lr)
-        return lp
+        """loss + optimizer of one attribute-view graph:  scale * sum w * log(1 + exp(-conv(h, a, v))), as ONE native
+        call (`mke_attr_step`: conv stack, the dense layer's three products on the MFMA GEMM kernel, loss tail,
+        backward, row updates, dense update).  Returns the loss partials (`.sum()` is the loss).  With update=False the
+        gradients are left in `self.grads`, `ent.grad`, `attr.grad` for inspection."""
+        if optimizer not in _OPT:
+            raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
+        d, n = self.dim, int(ih.numel())
+        need = _lib.attr_scratch_floats(n, d)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(max(need, 1), dtype=torch.float32, device=self.device)
+        tag, _ = eng._next()
+        part = self._partials[self._ring]
+        self._ring = (self._ring + 1) % self._partials.shape[0]
+        adagrad = optimizer == "Adagrad"
+        a = _lib.AttrStepArgs()
+        f32, i32 = torch.float32, torch.int32
+        a.ent_table, a.n_ent, a.ent_stride, a.ent_normalize = _lib.ptr(ent.data, f32, "ent"), ent.n_rows, ent.stride, int(ent.normalize)
+        a.ent_acc = _lib.ptr(ent.slot(opt_name), f32, "acc") if (adagrad and ent.trainable and update) else None
+        a.ent_grad = _lib.ptr(ent.grad, f32, "grad") if ent.trainable else None
+        a.ent_touched = _lib.ptr(ent.touched, i32, "touched") if ent.trainable else None
+        a.attr_table, a.n_attr, a.attr_stride = _lib.ptr(attr.data, f32, "attr"), attr.n_rows, attr.stride
+        a.attr_normalize = int(attr.normalize)
+        a.attr_acc = _lib.ptr(attr.slot(opt_name), f32, "acc") if (adagrad and attr.trainable and update) else None
+        a.attr_grad = _lib.ptr(attr.grad, f32, "grad") if attr.trainable else None
+        a.attr_touched = _lib.ptr(attr.touched, i32, "touched") if attr.trainable else None
+        a.lit_table, a.lit_stride, a.dim = _lib.ptr(lit.data, f32, "lit"), lit.stride, d
+        a.ih, a.ia, a.iv = _lib.ptr(ih, i32, "ih"), _lib.ptr(ia, i32, "ia"), _lib.ptr(iv, i32, "iv")
+        a.weights = _lib.ptr(weights, f32, "weights") if weights is not None else None
+        a.n, a.scale = n, float(scale)
+        a.params, a.param_grads = _lib.ptr(self.params, f32, "params"), _lib.ptr(self.grads, f32, "grads")
+        a.param_acc = _lib.ptr(self.slot(opt_name), f32, "acc") if (adagrad and update) else None
+        a.scratch, a.partials = _lib.ptr(self._scratch, f32, "scratch"), _lib.ptr(part, torch.float64, "partials")
+        a.optimizer, a.lr, a.tag, a.update = _OPT[optimizer], float(lr), tag, int(update)
+        _lib.attr_step(a)
+        return part[:_lib.LOSS_PARTIALS]

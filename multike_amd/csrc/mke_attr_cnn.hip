@@ -471,6 +471,18 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(float* __restrict__ 
   }
 }
 
+// out[j] += sum_i x[i][j]  (bias gradient of the dense layer): each block folds its rows, one atomic per column per block
+__global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restrict__ x, int64_t n, int dim, float* __restrict__ out) {
+  for (int j = threadIdx.x; j < dim; j += MKE_BLOCK) {
+    float s = 0.f;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) s += x[i * dim + j];
+    atomic_add_f32(out + j, s);
+  }
+}
+
+int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st);
+
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   const int wpl = (p.dim + 63) / 64;
   int64_t blocks = (p.n + 3) / 4;
@@ -572,4 +584,60 @@ extern "C" int mke_dense_update(float* param, float* acc, float* grad, int64_t n
   hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, param, acc, grad, n,
                      optimizer, lr);
   return check_launch("k_dense_update");
+}
+
+extern "C" int64_t mke_attr_scratch_floats(int64_t n, int dim) {
+  if (n < 0 || dim <= 0) return 0;
+  return n * (int64_t)dim * 10;  // flat n*4d | dflat n*4d | z n*d | gout n*d
+}
+
+extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
+  using namespace mke;
+  if (!a) { set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
+  if (a->n < 0 || a->dim <= 0) { set_error("mke_attr_step: bad n/dim"); return MKE_E_SHAPE; }
+  if (!a->ent_table || !a->attr_table || !a->lit_table || !a->params || !a->param_grads || !a->scratch || !a->partials) { set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
+  if (a->n == 0) {
+    hipError_t e = hipMemsetAsync(a->partials, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("mke_attr_step: memset failed"); return (int)e; }
+    return MKE_OK;
+  }
+  const int d = a->dim;
+  const int64_t n = a->n;
+  hipStream_t st = (hipStream_t)stream;
+  float* flat = a->scratch;
+  float* dflat = flat + n * 4 * d;
+  float* z = dflat + n * 4 * d;
+  float* gout = z + n * d;
+  double* lossp = a->partials;
+  double* ssq = a->partials + MKE_LOSS_PARTIALS;
+  double* dot = a->partials + 2 * MKE_LOSS_PARTIALS;
+  float* W = a->params + MKE_CNN_CONV_PARAMS(d);
+  float* bias = W + 4 * d * d;
+  float* gW = a->param_grads + MKE_CNN_CONV_PARAMS(d);
+  float* gbias = gW + 4 * d * d;
+  int rc;
+  // forward: conv stack -> dense -> tanh -> batch-global normalisation -> loss
+  if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
+                              a->params, flat, stream))) return rc;
+  if ((rc = launch_gemm_f32(flat, 4 * d, 1, W, d, 1, z, d, (int)n, d, 4 * d, 1, 0, st))) return rc;
+  if ((rc = mke_attr_tail_z(z, bias, n, d, ssq, stream))) return rc;
+  const bool upd = a->update != 0;
+  if ((rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
+                               a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
+  // backward
+  if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, stream))) return rc;   // gout = dL/dzpre
+  hipLaunchKernelGGL(k_colsum_add, dim3(128), dim3(MKE_BLOCK), 0, st, gout, n, d, gbias);
+  if ((rc = check_launch("k_colsum_add"))) return rc;
+  if ((rc = launch_gemm_f32(flat, 1, 4 * d, gout, d, 1, gW, d, 4 * d, d, (int)n, 32, 1, st))) return rc;   // dW = flat^T dz
+  if ((rc = launch_gemm_f32(gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st))) return rc;   // dflat = dz W^T
+  if ((rc = mke_attr_conv_bwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
+                              a->params, dflat, a->param_grads, a->attr_grad, a->attr_touched, a->tag, stream))) return rc;
+  if (upd) {
+    if (a->ent_grad && (rc = mke_rows_update(a->ent_table, a->ent_acc, a->ent_grad, 1, a->ent_touched, a->tag, a->n_ent,
+                                             a->ent_stride, d, a->ent_normalize, a->optimizer, a->lr, stream))) return rc;
+    if (a->attr_grad && (rc = mke_rows_update(a->attr_table, a->attr_acc, a->attr_grad, 1, a->attr_touched, a->tag, a->n_attr,
+                                              a->attr_stride, d, a->attr_normalize, a->optimizer, a->lr, stream))) return rc;
+    if ((rc = mke_dense_update(a->params, a->param_acc, a->param_grads, MKE_CNN_PARAMS(d), a->optimizer, a->lr, stream))) return rc;
+  }
+  return MKE_OK;
 }
