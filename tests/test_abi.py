@@ -26,7 +26,7 @@ def lib():
 
 def test_header_symbols_are_exported_and_bound(lib):
     from multike_amd import _lib
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(mke_\w+)\s*\(", _header(), flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(mke_\w+)\s*\(", _header(), flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     raw = C.CDLL(_lib.SO_PATH)
     for sym in declared:
