@@ -14,7 +14,6 @@ with the same attributes; only the attributes this file reads are required (see 
 from __future__ import annotations
 
 import math
-import random
 import time
 
 import numpy as np

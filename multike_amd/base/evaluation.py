@@ -1,19 +1,23 @@
-"""base/evaluation.py surface of the reference (code/base/evaluation.py:6-27)."""
+"""base/evaluation.py surface of the reference (code/base/evaluation.py:6-27): `valid` and `test` — thin wrappers that
+optionally push the first embedding set through a mapping matrix and hand over to the MFMA evaluator."""
 import numpy as np
 
 from .alignment import greedy_alignment
 
 
+def _evaluate(source, target, mapping, top_k, threads_num, metric, normalize, csls_k, accurate):
+    """Shared body: Hits@k / MR / MRR of `source` rows against `target` rows (gold = same index)."""
+    projected = source if mapping is None else np.matmul(source, mapping)
+    return greedy_alignment(projected, target, top_k, threads_num, metric, normalize, csls_k, accurate)
+
+
 def valid(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False, csls_k=0, accurate=False):
-    if mapping is not None:
-        embeds1 = np.matmul(embeds1, mapping)
-    _, hits1_12, mr_12, mrr_12 = greedy_alignment(embeds1, embeds2, top_k, threads_num, metric, normalize, csls_k, accurate)
-    return hits1_12, mrr_12
+    """-> (hits@1, MRR); quick mode by default, as the reference's validation."""
+    _pairs, hits1, _mr, mrr = _evaluate(embeds1, embeds2, mapping, top_k, threads_num, metric, normalize, csls_k, accurate)
+    return hits1, mrr
 
 
 def test(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False, csls_k=0, accurate=True):
-    if mapping is not None:
-        embeds1 = np.matmul(embeds1, mapping)
-    alignment_rest_12, hits1_12, mr_12, mrr_12 = greedy_alignment(embeds1, embeds2, top_k, threads_num, metric, normalize,
-                                                                  csls_k, accurate)
-    return alignment_rest_12, hits1_12, mrr_12
+    """-> (aligned pairs, hits@1, MRR); accurate mode by default, as the reference's test."""
+    pairs, hits1, _mr, mrr = _evaluate(embeds1, embeds2, mapping, top_k, threads_num, metric, normalize, csls_k, accurate)
+    return pairs, hits1, mrr

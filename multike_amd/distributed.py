@@ -148,7 +148,6 @@ class ShardedRelationTrainer:
         self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1 and self.lookahead > 0) else None
         self._planned = -1    # plans of global steps <= this index have been enqueued
         self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
-        self.last_stats = {}
 
     def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
         """Fixed-capacity buffers are what every rank moves per step, so size them from the data instead of the
