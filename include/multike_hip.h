@@ -9,7 +9,9 @@
  *     need the HIP headers; NULL = the legacy default stream).
  *   - Return value: 0 = ok, <0 = bad argument (MKE_E_*), >0 = a hipError_t from the launch.
  *     mke_last_error() returns a thread-local human-readable message for the last non-zero return.
- *   - No global mutable state: the library is re-entrant; two host threads may enqueue on two streams.
+ *   - No global mutable state except the process-wide tuning knobs of mke_set_option: the library is re-entrant;
+ *     two host threads may enqueue on two streams.  mke_relation_steps in overlap mode creates (and destroys) a
+ *     private stream and events for the duration of the call.
  *
  * The reference (nju-websoft/MultiKE) has NO native code; each entry point below replaces a group of
  * TensorFlow-1.x graph ops that the reference builds in Python.  The "replaces" lines cite the
@@ -53,7 +55,7 @@ int mke_version(void);
 const char* mke_last_error(void);
 
 /* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
- *   "score_splits"  : quarter-waves sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
+ *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
  * Returns the previous value through *old_value when it is not NULL. */
 int mke_set_option(const char* name, int value, int* old_value);
 
