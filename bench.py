@@ -151,10 +151,18 @@ def main():
         ev, ev_upd = [], []
 
         def run_steps(i0, i1):
-            """global step indices [i0, i1): each (partial) epoch is ONE call into the native runner."""
+            """global step indices [i0, i1): whole epochs go through runner.run_epochs (next epoch's permutation and
+            negatives prepared on a side stream meanwhile); a partial epoch is ONE call into the native runner."""
             i = i0
             while i < i1:
                 s = i % n_steps_epoch
+                if s == 0 and i1 - i >= n_steps_epoch:
+                    n_ep = (i1 - i) // n_steps_epoch
+                    if i > 0:
+                        bat.shuffle()
+                    runner.run_epochs(n_ep)
+                    i += n_ep * n_steps_epoch
+                    continue
                 e = min(n_steps_epoch, s + (i1 - i))
                 if s == 0 and i > 0:
                     bat.shuffle()

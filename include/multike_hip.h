@@ -316,6 +316,9 @@ typedef struct mke_relation_plan {
   mke_kg_side sides[2];
   int neg_per_pos, max_try;
   int sample_chunk;                          /* steps sampled per sampler launch (>=1) */
+  int negatives_ready;                       /* != 0: neg_* already hold the negatives of steps [step_begin, step_end) laid out
+                                                from step_begin (sampled earlier, e.g. on another stream during the previous
+                                                epoch): no sampler launch in this call */
   int32_t* neg_h; int32_t* neg_r; int32_t* neg_t;  /* device scratch, >= max positives of any sample_chunk consecutive steps * neg_per_pos */
   uint32_t seed_lo, seed_hi, stream_id;
   int optimizer; float lr; float scale;

@@ -71,7 +71,7 @@ class RelationPlanStruct(C.Structure):
         ("neg_chunk_capacity", C.c_int64), ("stride", C.c_int), ("dim", C.c_int),
         ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("pos_kg", C.c_void_p),
         ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("sides", KGSideStruct * 2),
-        ("neg_per_pos", C.c_int), ("max_try", C.c_int), ("sample_chunk", C.c_int),
+        ("neg_per_pos", C.c_int), ("max_try", C.c_int), ("sample_chunk", C.c_int), ("negatives_ready", C.c_int),
         ("neg_h", C.c_void_p), ("neg_r", C.c_void_p), ("neg_t", C.c_void_p),
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("stream_id", C.c_uint32),
         ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float),

@@ -131,6 +131,10 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
   bool counted_ahead = false;  // the current step's references were counted by the previous step's update launch
   for (int s = step_begin; s < step_end; ++s) {
     const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1];
+    if (N > 0 && s >= chunk_end && pl->negatives_ready) {  // sampled by the caller ahead of time
+      chunk_end = step_end;
+      chunk_lo = pl->step_off[step_begin];
+    }
     if (N > 0 && s >= chunk_end) {
       chunk_end = s + pl->sample_chunk < step_end ? s + pl->sample_chunk : step_end;
       chunk_lo = lo;

@@ -101,6 +101,71 @@ class RelationViewRunner:
         self.plan.tag_base = (1 << 30) + 1 + self._epoch_tag_base
         _lib.relation_steps(self.plan, step_begin, step_end)
 
+    # ------------------------------------------------------------------------------------------------
+    def run_epochs(self, n_epochs: int, on_epoch_end=None):
+        """Train `n_epochs` whole epochs.  While epoch e is being trained on the current stream, epoch e+1 is permuted
+        and its negatives are sampled on a second stream (ONE cross-stream hand-over per epoch — per-step hand-overs
+        cost more than they hide on this hardware), so the sampler leaves the critical path.
+        `on_epoch_end(epoch_index, runner)` is called after each epoch's work is enqueued (its losses are in
+        `self.loss`; reading them synchronises)."""
+        if self.overlap or self.bat.neg_per_pos == 0 or self.steps == 0:
+            for e in range(n_epochs):
+                if e > 0:
+                    self.bat.shuffle()
+                self.run()
+                if on_epoch_end:
+                    on_epoch_end(e, self)
+            return
+        b = self.bat
+        N = b.neg_per_pos
+        total = int(b.off[-1]) * N
+        if getattr(self, "_neg_sets", None) is None:
+            self._neg_sets = [tuple(x[:total] for x in self.neg) if self.neg[0].numel() >= total else
+                              tuple(torch.empty(total, dtype=torch.int32, device=self.ent.device) for _ in range(3)),
+                              tuple(torch.empty(total, dtype=torch.int32, device=self.ent.device) for _ in range(3))]
+            self._side = torch.cuda.Stream(device=self.ent.device)
+            self._ev_staged, self._ev_sampled = torch.cuda.Event(), torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        cur = 0
+        from .sampling import sample_negatives
+
+        def sample_epoch(pos, stream_id, out):
+            sample_negatives(pos, b.side1, N, seed=b.rng_seed, stream_id=stream_id, pos_offset=0, max_try=self.max_try, out=out,
+                             side1=b.side2, pos_kg=b.pos_kg)
+
+        sample_epoch((b.pos_h, b.pos_r, b.pos_t), b.rng_stream, self._neg_sets[cur])      # first epoch: inline
+        for e in range(n_epochs):
+            if e + 1 < n_epochs:
+                staged = b.stage_next_epoch()                       # tiny torch ops on the main stream
+                self._ev_staged.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(self._ev_staged)
+                    old = _lib.pin_stream(self._side.cuda_stream)
+                    try:
+                        sample_epoch(staged, ((b.epoch + 1) * 2) & 0xFFFFFFFF, self._neg_sets[1 - cur])
+                    finally:
+                        _lib.pin_stream(old)
+                    self._ev_sampled.record(self._side)
+            # this epoch's steps: negatives are ready in set `cur`
+            p = self.plan
+            p.neg_h, p.neg_r, p.neg_t = (_lib.ptr(x, torch.int32, "neg") for x in self._neg_sets[cur])
+            p.negatives_ready, p.sample_chunk = 1, self.steps
+            self._epoch_tag_base = self.tag
+            self.tag += self.steps
+            self._fill_epoch()
+            p.tag_base = (1 << 30) + 1 + self._epoch_tag_base
+            try:
+                _lib.relation_steps(p, 0, self.steps)
+            finally:
+                p.negatives_ready, p.sample_chunk = 0, self.sample_chunk
+                p.neg_h, p.neg_r, p.neg_t = (_lib.ptr(x, torch.int32, "neg") for x in self.neg)
+            if on_epoch_end:
+                on_epoch_end(e, self)
+            if e + 1 < n_epochs:
+                main.wait_event(self._ev_sampled)                   # the one hand-over of the epoch
+                b.commit_staged()
+                cur = 1 - cur
+
     def epoch_loss_sum(self) -> torch.Tensor:
         """Sum of the batch losses of the steps run in this epoch (device scalar, float64)."""
         return self.loss.sum()

@@ -155,6 +155,31 @@ class RelationBatcher:
             self.pos_t.copy_(allt[:, 2])
         self.t1, self.t2 = t1, t2
 
+    # -- next-epoch staging: lets a caller permute (and sample) epoch e+1 while epoch e is still being trained ------
+    def stage_next_epoch(self):
+        """Draw the next epoch's permutation into the ALTERNATE epoch buffers (the current ones are untouched).
+        Returns the staged (pos_h, pos_r, pos_t); `commit_staged()` makes them current."""
+        p1 = torch.randperm(self.n1, generator=self._gen, device=self.device)
+        p2 = torch.randperm(self.n2, generator=self._gen, device=self.device)
+        t1, t2 = self.t1[p1], self.t2[p2]
+        allt = torch.cat([t1, t2], 0)[self._src]
+        if getattr(self, "_alt", None) is None:
+            self._alt = tuple(allt[:, k].contiguous() for k in range(3))
+        else:
+            for k in range(3):
+                self._alt[k].copy_(allt[:, k])
+        self._staged_lists = (t1, t2)
+        return self._alt
+
+    def commit_staged(self):
+        """The staged epoch becomes the current one (buffer swap; same effect as `shuffle()`)."""
+        cur = (self.pos_h, self.pos_r, self.pos_t)
+        self.pos_h, self.pos_r, self.pos_t = self._alt
+        self._alt = cur
+        self.t1, self.t2 = self._staged_lists
+        self._staged_lists = None
+        self.epoch += 1
+
     def shuffle(self):
         """random.shuffle of both positive lists after an epoch (code/MultiKE_model.py:314-315)."""
         p1 = torch.randperm(self.n1, generator=self._gen, device=self.device)

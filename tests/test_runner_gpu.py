@@ -95,3 +95,24 @@ def test_runner_partial_ranges_and_second_epoch():
     np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
     assert int(r1.refcount.abs().sum()) == 0 and int(r2.refcount.abs().sum()) == 0     # zero-invariant restored
     assert not torch.equal(bat1.pos_h, _setup(seed=5)[3]()[2].pos_h)  # the shuffle really permuted the epoch
+
+
+def test_run_epochs_prefetch_equals_plain_epochs():
+    """run_epochs (next epoch permuted + sampled on a side stream) == the plain loop run(); shuffle(); run(); ..."""
+    from multike_amd.runner import RelationViewRunner
+    kgs, ent, rel, fresh = _setup(seed=8)
+    E1, R1, bat1 = fresh()
+    E2, R2, bat2 = fresh()
+    r1 = RelationViewRunner(E1, R1, bat1, lr=0.01)
+    r2 = RelationViewRunner(E2, R2, bat2, lr=0.01)
+    per_epoch = []
+    r1.run_epochs(3, on_epoch_end=lambda e, r: per_epoch.append(r.step_losses().cpu().numpy().copy()))
+    for e in range(3):
+        if e > 0:
+            bat2.shuffle()
+        r2.run()
+        np.testing.assert_allclose(per_epoch[e], r2.step_losses().cpu().numpy(), rtol=2e-6)
+    assert torch.equal(bat1.pos_h, bat2.pos_h) and bat1.epoch == bat2.epoch == 2
+    np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(r1.refcount.abs().sum()) == 0
