@@ -102,13 +102,14 @@ class RelationViewRunner:
         _lib.relation_steps(self.plan, step_begin, step_end)
 
     # ------------------------------------------------------------------------------------------------
-    def run_epochs(self, n_epochs: int, on_epoch_end=None):
-        """Train `n_epochs` whole epochs.  While epoch e is being trained on the current stream, epoch e+1 is permuted
-        and its negatives are sampled on a second stream (ONE cross-stream hand-over per epoch — per-step hand-overs
-        cost more than they hide on this hardware), so the sampler leaves the critical path.
-        `on_epoch_end(epoch_index, runner)` is called after each epoch's work is enqueued (its losses are in
-        `self.loss`; reading them synchronises)."""
-        if self.overlap or self.bat.neg_per_pos == 0 or self.steps == 0:
+    def run_epochs(self, n_epochs: int, on_epoch_end=None, prefetch: bool = False):
+        """Train `n_epochs` whole epochs; `on_epoch_end(epoch_index, runner)` is called after each epoch's work is
+        enqueued (its losses are in `self.loss`; reading them synchronises).
+        prefetch=True: while epoch e is trained on the current stream, epoch e+1 is permuted and its negatives are sampled
+        on a second stream (one cross-stream hand-over per epoch).  Measured on MI355X at the C2 shape this is SLOWER
+        (79 vs 71 us/step): the 1 ms epoch sampler fills the chip with 910K latency-bound waves and starves the
+        dependent score/update chain for longer than it would have taken in line.  Off by default."""
+        if not prefetch or self.overlap or self.bat.neg_per_pos == 0 or self.steps == 0:
             for e in range(n_epochs):
                 if e > 0:
                     self.bat.shuffle()

@@ -106,7 +106,7 @@ def test_run_epochs_prefetch_equals_plain_epochs():
     r1 = RelationViewRunner(E1, R1, bat1, lr=0.01)
     r2 = RelationViewRunner(E2, R2, bat2, lr=0.01)
     per_epoch = []
-    r1.run_epochs(3, on_epoch_end=lambda e, r: per_epoch.append(r.step_losses().cpu().numpy().copy()))
+    r1.run_epochs(3, on_epoch_end=lambda e, r: per_epoch.append(r.step_losses().cpu().numpy().copy()), prefetch=True)
     for e in range(3):
         if e > 0:
             bat2.shuffle()
