@@ -8,7 +8,8 @@
 // indexed by (positive, round, slot, attempt), so any positive can be sampled by any wavefront in any
 // order and the CPU oracle (oracle/sampler_oracle.py) reproduces the device output bit for bit.
 //
-// Shape: one 64-lane wavefront per positive, lane q = slot q of the round (neg_per_pos <= 64).
+// Shape: one group of 32 lanes (neg_per_pos <= 32: two positives per wavefront) or 64 lanes per positive, lane q of
+// the group = slot q of the round (neg_per_pos <= 64).
 #include "mke_common.h"
 
 namespace mke {
@@ -56,43 +57,56 @@ __device__ __forceinline__ bool set_contains(const uint64_t* __restrict__ keys, 
   }
 }
 
+// GS lanes per positive (GS = 32 when neg_per_pos <= 32: two positives per wavefront, else 64).  Everything that is
+// per positive (round count, collected, coin, candidate list) lives in the group's lanes; wave-wide primitives
+// (__shfl, __ballot) are used with group-relative indices / masks.
+template <int GS>
 __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) {
+  constexpr int PPW = 64 / GS;
   const int lane = threadIdx.x & 63;
-  const int64_t i = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
-  if (i >= p.n_pos) return;
-  const int h = p.ph[i], r = p.pr[i], t = p.pt[i];
-  const int kg = p.pos_kg ? (p.pos_kg[i] != 0) : 0;
+  const int gl = lane & (GS - 1);        // slot inside the group
+  const int gbase = lane & ~(GS - 1);    // first lane of the group
+  const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  const int64_t i = wave * PPW + (lane / GS);
+  const bool live = i < p.n_pos;
+  const int64_t ii = live ? i : 0;
+  const int h = p.ph[ii], r = p.pr[ii], t = p.pt[ii];
+  const int kg = p.pos_kg ? (p.pos_kg[ii] != 0) : 0;
   const mke_kg_side& sd = p.side[kg];
   const uint32_t sid = p.sid + (uint32_t)kg;
   const uint64_t* __restrict__ keys = sd.known_keys;
-  const uint32_t gi = (uint32_t)(i + p.pos_offset);
+  const uint32_t gi = (uint32_t)(ii + p.pos_offset);
   const int N = p.npp;
-  int collected = 0;
-  for (int round = 0; round < p.max_try && collected < N; ++round) {
-    const int need = N - collected;
+  const uint64_t gmask_all = GS == 64 ? ~0ull : (((1ull << (GS & 63)) - 1ull) << gbase);
+  int collected = live ? 0 : N;
+  for (int round = 0; round < p.max_try; ++round) {
+    if (!__ballot(collected < N)) break;  // every positive of the wave is done
+    const int need = N - collected;       // 0 for finished groups
     const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, sid, p.seed_lo, p.seed_hi);
     const bool corrupt_head = (cph.v[0] >> 31) != 0;
     const int x = corrupt_head ? h : t;
     const bool use_tbl = sd.cand_table != nullptr && (sd.cand_valid == nullptr || sd.cand_valid[x] != 0);
     const uint32_t n = use_tbl ? (uint32_t)sd.cand_k : (uint32_t)sd.n_ent;
-    const bool active = lane < need;
+    const bool active = gl < need;
     uint32_t attempt = 0;
     uint32_t pos = 0xFFFFFFFFu;
-    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, sid, p.seed_lo, p.seed_hi, n, attempt);
-    // duplicate detection among first draws
+    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)gl, sid, p.seed_lo, p.seed_hi, n, attempt);
+    // duplicate detection among first draws (q runs to the largest `need` of the wave)
+    const int need_max = max(need, __shfl_xor(need, 32, 64));
     bool dup = false;
-    for (int q = 0; q < need; ++q) {
-      const uint32_t v = (uint32_t)__shfl((int)pos, q, 64);
-      dup |= active && lane > q && pos == v;
+    for (int q = 0; q < need_max; ++q) {
+      const uint32_t v = (uint32_t)__shfl((int)pos, gbase + q, 64);
+      dup |= active && q < need && gl > q && pos == v;
     }
     if (__ballot(dup)) {
       // sequential without-replacement semantics: slot q must differ from the final draws of slots < q
-      for (int q = 1; q < need; ++q) {
+      for (int q = 1; q < need_max; ++q) {
         for (;;) {
-          const uint32_t v = (uint32_t)__shfl((int)pos, q, 64);
-          const bool hit = lane < q && pos == v;
-          if (!__ballot(hit)) break;
-          if (lane == q) pos = draw_next(gi, (uint32_t)round, (uint32_t)lane, sid, p.seed_lo, p.seed_hi, n, attempt);
+          const uint32_t v = (uint32_t)__shfl((int)pos, gbase + q, 64);
+          const bool hit = q < need && gl < q && pos == v;
+          const uint64_t hb = __ballot(hit);
+          if (!hb) break;
+          if ((hb & gmask_all) && gl == q) pos = draw_next(gi, (uint32_t)round, (uint32_t)gl, sid, p.seed_lo, p.seed_hi, n, attempt);
         }
       }
     }
@@ -107,9 +121,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) 
     if (active && round < p.max_try - 1 && keys != nullptr) {
       keep = !set_contains(keys, sd.known_capacity, triple_key((uint32_t)nh, (uint32_t)r, (uint32_t)nt));
     }
-    const uint64_t mask = __ballot(keep);
+    const uint64_t mask = (__ballot(keep) & gmask_all) >> gbase;  // this group's kept slots
     if (keep) {
-      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      const int rank = __popcll(mask & ((1ull << gl) - 1ull));
       const int64_t o = i * (int64_t)N + collected + rank;
       p.nh[o] = nh; p.nr[o] = r; p.nt[o] = nt;
     }
@@ -162,9 +176,10 @@ int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t*
   p.side[1] = pos_kg ? sides[1] : sides[0];
   p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.sid = stream_id;
   p.nh = neg_h; p.nr = neg_r; p.nt = neg_t;
-  const int64_t waves_per_block = MKE_BLOCK / 64;
-  const int64_t blocks = (n_pos + waves_per_block - 1) / waves_per_block;
-  hipLaunchKernelGGL(k_neg_sample, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
+  const int64_t pos_per_block = (MKE_BLOCK / 64) * (neg_per_pos <= 32 ? 2 : 1);
+  const int64_t blocks = (n_pos + pos_per_block - 1) / pos_per_block;
+  if (neg_per_pos <= 32) hipLaunchKernelGGL((k_neg_sample<32>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
+  else hipLaunchKernelGGL((k_neg_sample<64>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_neg_sample");
 }
 }  // namespace mke
