@@ -1,0 +1,458 @@
+"""On-disk inputs -> the id-space containers the hot path consumes.
+
+Host-side data preparation only (no kernels): the TSV readers, URI -> id assignment, the `KG` / `KGs` containers and
+the 'swapping' supervision triples of the reference (code/base/read.py:13-110,130-167,216-243,341-364,
+code/base/kg.py:1-143, code/base/kgs.py:5-97), rebuilt around one idea: every container keeps the reference's
+attribute names (lists / sets / dicts the drivers and batchers read) *and* a packed int32 array of its id triples
+(`relation_triples_array`, `sup_relation_triples_array`) that is what actually gets uploaded to HBM.
+
+Differences from the reference, all deliberate:
+  * `ordered=False` id assignment and every `list(set)` there follow Python's per-process string-hash order, i.e.
+    the reference is not reproducible run to run.  Here unordered means *first appearance in the input file*, and
+    set -> list conversions are sorted, so the same folder always yields the same ids.  The id *layout* is the
+    reference's: KG1 ids [0, n1), KG2 ids [n1, n1+n2) (code/base/read.py:75-84); `ordered=True` (frequency
+    order, interleaved 2i / 2i+1, code/base/read.py:61-74) is reproduced exactly and pinned by
+    tests/golden/data_golden.json.
+  * malformed lines raise `ValueError` naming file and line instead of a bare `assert`.
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+import numpy as np
+
+__all__ = ["KG", "KGs", "read_relation_triples", "read_attribute_triples", "read_links", "read_dict", "read_pair_ids",
+           "pair2file", "dict2file", "line2file", "sort_elements", "generate_mapping_id", "generate_sharing_id",
+           "uris_list_2ids", "uris_pair_2ids", "uris_relation_triple_2ids", "uris_attribute_triple_2ids",
+           "generate_sup_relation_triples", "generate_sup_attribute_triples", "read_kgs_from_folder",
+           "read_kgs_from_files", "parse_triples"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# readers / writers (code/base/read.py:216-299,341-364)
+# ----------------------------------------------------------------------------------------------------------------
+class _OrderedSet(dict):
+    """A set that remembers first-insertion order (what makes `ordered=False` deterministic here).  Behaves as a
+    set for everything the callers do with the reference's return values (len, in, iteration, |, -)."""
+
+    def add(self, x):
+        self[x] = None
+
+    def __or__(self, other):
+        out = _OrderedSet(self)
+        for x in other:
+            out[x] = None
+        return out
+
+    def __sub__(self, other):
+        return _OrderedSet((x, None) for x in self if x not in other)
+
+
+def _fields(path):
+    with open(path, "r", encoding="utf8") as f:
+        for no, line in enumerate(f, 1):
+            yield no, line.rstrip("\n").split("\t")
+
+
+def read_relation_triples(file_path):
+    """`h \\t r \\t t` per line -> (triples, entities, relations), fields stripped (code/base/read.py:216-232)."""
+    triples, entities, relations = _OrderedSet(), _OrderedSet(), _OrderedSet()
+    if file_path is None:
+        return triples, entities, relations
+    for no, p in _fields(file_path):
+        if len(p) != 3:
+            raise ValueError(f"{file_path}:{no}: expected 3 tab-separated fields, got {len(p)}")
+        h, r, t = (x.strip() for x in p)
+        triples.add((h, r, t))
+        entities.add(h)
+        entities.add(t)
+        relations.add(r)
+    return triples, entities, relations
+
+
+def read_attribute_triples(file_path):
+    """>= 3 tab fields (shorter lines skipped); fields past the third are appended to the value with single spaces;
+    a trailing '.' (N-Triples terminator) is dropped (code/base/read.py:341-364)."""
+    triples, entities, attributes = _OrderedSet(), _OrderedSet(), _OrderedSet()
+    if file_path is None:
+        return triples, entities, attributes
+    with open(file_path, "r", encoding="utf8") as f:
+        for line in f:
+            p = line.strip().split("\t")
+            if len(p) < 3:
+                continue
+            head, attr = p[0].strip(), p[1].strip()
+            value = " ".join([p[2].strip()] + [x.strip() for x in p[3:]]) if len(p) > 3 else p[2].strip()
+            value = value.strip().rstrip(".").strip()
+            triples.add((head, attr, value))
+            entities.add(head)
+            attributes.add(attr)
+    return triples, entities, attributes
+
+
+def read_links(file_path):
+    """`e1 \\t e2` per line -> list of pairs in file order (code/base/read.py:235-250)."""
+    links = []
+    for no, p in _fields(file_path):
+        if len(p) != 2:
+            raise ValueError(f"{file_path}:{no}: expected 2 tab-separated fields, got {len(p)}")
+        links.append((p[0].strip(), p[1].strip()))
+    return links
+
+
+def read_dict(file_path):
+    """`key \\t int` per line (the kg*_ids files `save_embeddings` writes; code/base/read.py:253-262)."""
+    out = {}
+    for no, p in _fields(file_path):
+        if len(p) != 2:
+            raise ValueError(f"{file_path}:{no}: expected 2 tab-separated fields")
+        out[p[0]] = int(p[1])
+    return out
+
+
+def read_pair_ids(file_path):
+    return [(int(a), int(b)) for _, (a, b) in _fields(file_path)]
+
+
+def pair2file(file, pairs):
+    if pairs is None:
+        return
+    with open(file, "w", encoding="utf8") as f:
+        f.writelines(f"{i}\t{j}\n" for i, j in pairs)
+
+
+def dict2file(file, dic):
+    if dic is None:
+        return
+    pair2file(file, dic.items())
+
+
+def line2file(file, lines):
+    if lines is None:
+        return
+    with open(file, "w", encoding="utf8") as f:
+        f.writelines(line + "\n" for line in lines)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# id assignment (code/base/read.py:13-84)
+# ----------------------------------------------------------------------------------------------------------------
+def sort_elements(triples, elements_set):
+    """Elements by descending (occurrence count over all three triple positions, URI) (code/base/read.py:13-25)."""
+    freq = Counter()
+    for tri in triples:
+        for x in tri:
+            if x in elements_set:
+                freq[x] += 1
+    ranked = sorted(freq.items(), key=lambda kv: (kv[1], kv[0]), reverse=True)
+    return [k for k, _ in ranked], dict(freq)
+
+
+def generate_mapping_id(kg1_triples, kg1_elements, kg2_triples, kg2_elements, ordered=True):
+    """Disjoint id spaces.  ordered: i-th most frequent element of KG1 -> 2i, of KG2 -> 2i+1, the longer tail
+    continues contiguously after 2*min(n1,n2) (code/base/read.py:59-74).  unordered: KG1 first, then KG2
+    (code/base/read.py:75-84)."""
+    if ordered:
+        o1, _ = sort_elements(kg1_triples, kg1_elements)
+        o2, _ = sort_elements(kg2_triples, kg2_elements)
+        m = min(len(o1), len(o2))
+        ids1 = {e: 2 * i if i < m else 2 * m + (i - m) for i, e in enumerate(o1)}
+        ids2 = {e: 2 * i + 1 if i < m else 2 * m + (i - m) for i, e in enumerate(o2)}
+    else:
+        ids1 = {e: i for i, e in enumerate(dict.fromkeys(kg1_elements))}
+        n1 = len(ids1)
+        ids2 = {e: n1 + i for i, e in enumerate(dict.fromkeys(kg2_elements))}
+    if len(ids1) != len(set(kg1_elements)) or len(ids2) != len(set(kg2_elements)):
+        raise ValueError("id assignment lost elements (an element never occurs in its KG's triples)")
+    return ids1, ids2
+
+
+def generate_sharing_id(train_links, kg1_triples, kg1_elements, kg2_triples, kg2_elements, ordered=True):
+    """Linked elements share one id (code/base/read.py:28-56)."""
+    if ordered:
+        partner = {y: x for x, y in train_links}
+        linked2 = [y for _, y in train_links]
+        ids1, ids2 = generate_mapping_id(kg1_triples, kg1_elements, kg2_triples,
+                                         [e for e in dict.fromkeys(kg2_elements) if e not in partner], ordered=True)
+        for y in linked2:
+            ids2[y] = ids1[partner[y]]
+    else:
+        ids1, ids2 = {}, {}
+        for e1, e2 in train_links:
+            if e1 not in kg1_elements or e2 not in kg2_elements:
+                raise ValueError(f"link ({e1}, {e2}) names an element outside the KGs")
+            ids1[e1] = ids2[e2] = len(ids1)
+        nxt = len(ids1)
+        for ids, elements in ((ids1, kg1_elements), (ids2, kg2_elements)):
+            for e in dict.fromkeys(elements):
+                if e not in ids:
+                    ids[e] = nxt
+                    nxt += 1
+    if len(ids1) != len(set(kg1_elements)) or len(ids2) != len(set(kg2_elements)):
+        raise ValueError("id assignment lost elements")
+    return ids1, ids2
+
+
+def _need(key, table, what):
+    try:
+        return table[key]
+    except KeyError:
+        raise ValueError(f"{what} {key!r} has no id") from None
+
+
+def uris_list_2ids(uris, ids):
+    return [_need(u, ids, "element") for u in uris]
+
+
+def uris_pair_2ids(uris, ids1, ids2):
+    return [(_need(a, ids1, "KG1 entity"), _need(b, ids2, "KG2 entity")) for a, b in uris]
+
+
+def uris_relation_triple_2ids(uris, ent_ids, rel_ids):
+    return [(_need(h, ent_ids, "entity"), _need(r, rel_ids, "relation"), _need(t, ent_ids, "entity")) for h, r, t in uris]
+
+
+def uris_attribute_triple_2ids(uris, ent_ids, attr_ids):
+    """Heads must be entities of the relation graph; the value stays a string (code/base/read.py:120-127)."""
+    return [(_need(h, ent_ids, "entity (attribute-triple head)"), _need(a, attr_ids, "attribute"), v) for h, a, v in uris]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# 'swapping' supervision (code/base/read.py:130-167)
+# ----------------------------------------------------------------------------------------------------------------
+def generate_sup_relation_triples(sup_links, rt_dict1, hr_dict1, rt_dict2, hr_dict2):
+    """Every triple touching a linked entity is re-stated with the counterpart in that position; the KG1-derived
+    set joins KG1's triples, the KG2-derived set KG2's."""
+    new1, new2 = set(), set()
+    for e1, e2 in sup_links:
+        new1.update((e2, r, t) for r, t in rt_dict1.get(e1, ()))
+        new1.update((h, r, e2) for h, r in hr_dict1.get(e1, ()))
+        new2.update((e1, r, t) for r, t in rt_dict2.get(e2, ()))
+        new2.update((h, r, e1) for h, r in hr_dict2.get(e2, ()))
+    return new1, new2
+
+
+def generate_sup_attribute_triples(sup_links, av_dict1, av_dict2):
+    new1, new2 = set(), set()
+    for e1, e2 in sup_links:
+        new1.update((e2, a, v) for a, v in av_dict1.get(e1, ()))
+        new2.update((e1, a, v) for a, v in av_dict2.get(e2, ()))
+    return new1, new2
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# containers (code/base/kg.py, code/base/kgs.py)
+# ----------------------------------------------------------------------------------------------------------------
+def parse_triples(triples):
+    s, p, o = set(), set(), set()
+    for a, b, c in triples:
+        s.add(a)
+        p.add(b)
+        o.add(c)
+    return s, p, o
+
+
+def _stable_list(items):
+    """set -> list in a reproducible order (ints / strings / tuples thereof)."""
+    try:
+        return sorted(items)
+    except TypeError:
+        return sorted(items, key=repr)
+
+
+def _group(pairs):
+    out = {}
+    for k, v in pairs:
+        out.setdefault(k, set()).add(v)
+    return out
+
+
+class KG:
+    """One knowledge graph, either in URI space or in id space (code/base/kg.py:10-143).
+
+    `relation_triples_set` and `local_relation_triples_set` are the SAME set object, as in the reference
+    (code/base/kg.py:58-61), so `add_sup_relation_triples` also grows the "local" set -- that is the set the
+    negative sampler filters against -- while `local_relation_triples_list` / `_num` keep the
+    pre-supervision triples the relation view trains on."""
+
+    def __init__(self, relation_triples, attribute_triples, verbose=False):
+        self.entities_id_dict = self.relations_id_dict = self.attributes_id_dict = None
+        self.sup_relation_triples_set, self.sup_relation_triples_list = None, None
+        self.sup_attribute_triples_set, self.sup_attribute_triples_list = None, None
+        self.set_relations(relation_triples)
+        self.set_attributes(attribute_triples)
+        if verbose:
+            print(self.statistics())
+
+    def statistics(self) -> str:
+        return (f"KG: {self.entities_num} entities, {self.relations_num} relations, {self.attributes_num} attributes, "
+                f"{self.relation_triples_num} relation triples ({self.local_relation_triples_num} local), "
+                f"{self.attribute_triples_num} attribute triples ({self.local_attribute_triples_num} local)")
+
+    # -- relation side --
+    def set_relations(self, relation_triples):
+        self.relation_triples_set = self.local_relation_triples_set = set(relation_triples)
+        self.relation_triples_list = self.local_relation_triples_list = _stable_list(self.relation_triples_set)
+        heads, self.relations_set, tails = parse_triples(self.relation_triples_set)
+        self.entities_set = heads | tails
+        self.entities_list = _stable_list(self.entities_set)
+        self.relations_list = _stable_list(self.relations_set)
+        self.entities_num, self.relations_num = len(self.entities_set), len(self.relations_set)
+        self.relation_triples_num = self.local_relation_triples_num = len(self.relation_triples_set)
+        self.generate_relation_triple_dict()
+        self.parse_relations()
+
+    def generate_relation_triple_dict(self):
+        self.rt_dict = _group((h, (r, t)) for h, r, t in self.local_relation_triples_list)
+        self.hr_dict = _group((t, (h, r)) for h, r, t in self.local_relation_triples_list)
+
+    def parse_relations(self):
+        self.entity_relations_dict = _group((h, r) for h, r, _ in self.local_relation_triples_list)
+
+    # -- attribute side --
+    def set_attributes(self, attribute_triples):
+        self.attribute_triples_set = self.local_attribute_triples_set = set(attribute_triples)
+        self.attribute_triples_list = self.local_attribute_triples_list = _stable_list(self.attribute_triples_set)
+        _, self.attributes_set, _ = parse_triples(self.attribute_triples_set)
+        self.attributes_list = _stable_list(self.attributes_set)
+        self.attributes_num = len(self.attributes_set)
+        self.attribute_triples_num = self.local_attribute_triples_num = len(self.attribute_triples_set)
+        self.generate_attribute_triple_dict()
+        self.parse_attributes()
+
+    def generate_attribute_triple_dict(self):
+        self.av_dict = _group((h, (a, v)) for h, a, v in self.local_attribute_triples_list)
+
+    def parse_attributes(self):
+        self.entity_attributes_dict = _group((h, a) for h, a, _ in self.local_attribute_triples_list)
+
+    def set_id_dict(self, entities_id_dict, relations_id_dict, attributes_id_dict):
+        self.entities_id_dict = entities_id_dict
+        self.relations_id_dict = relations_id_dict
+        self.attributes_id_dict = attributes_id_dict
+
+    # -- supervision --
+    def add_sup_relation_triples(self, sup_triples):
+        self.sup_relation_triples_set = set(sup_triples)
+        self.sup_relation_triples_list = _stable_list(self.sup_relation_triples_set)
+        self.relation_triples_set |= self.sup_relation_triples_set          # in place: the alias grows too
+        self.relation_triples_list = _stable_list(self.relation_triples_set)
+        self.relation_triples_num = len(self.relation_triples_list)
+
+    def add_sup_attribute_triples(self, sup_triples):
+        self.sup_attribute_triples_set = set(sup_triples)
+        self.sup_attribute_triples_list = _stable_list(self.sup_attribute_triples_set)
+        self.attribute_triples_set |= self.sup_attribute_triples_set
+        self.attribute_triples_list = _stable_list(self.attribute_triples_set)
+        self.attribute_triples_num = len(self.attribute_triples_list)
+
+    # -- packed views for the device side (id-space KGs only) --
+    @staticmethod
+    def _pack(triples) -> np.ndarray:
+        return np.asarray(triples, dtype=np.int32).reshape(-1, 3)
+
+    @property
+    def relation_triples_array(self) -> np.ndarray:
+        """int32 [n,3] (h, r, t) of the local (pre-supervision) relation triples, list order."""
+        return self._pack(self.local_relation_triples_list)
+
+    @property
+    def sup_relation_triples_array(self) -> np.ndarray:
+        return self._pack(self.sup_relation_triples_list or [])
+
+    @property
+    def known_relation_triples_array(self) -> np.ndarray:
+        """Everything the sampler must not emit as a negative: local + supervision triples."""
+        return self._pack(_stable_list(self.local_relation_triples_set))
+
+
+class KGs:
+    """The aligned pair in id space plus link splits (code/base/kgs.py:5-76)."""
+
+    def __init__(self, kg1: KG, kg2: KG, train_links, valid_links, test_links=None, mode="mapping", ordered=True):
+        assign = generate_sharing_id if mode == "sharing" else generate_mapping_id
+        pre = (lambda links: (links,)) if mode == "sharing" else (lambda links: ())
+        ent_ids1, ent_ids2 = assign(*pre(train_links), kg1.relation_triples_set, kg1.entities_set,
+                                    kg2.relation_triples_set, kg2.entities_set, ordered=ordered)
+        rel_ids1, rel_ids2 = assign(*pre([]), kg1.relation_triples_set, kg1.relations_set,
+                                    kg2.relation_triples_set, kg2.relations_set, ordered=ordered)
+        attr_ids1, attr_ids2 = assign(*pre([]), kg1.attribute_triples_set, kg1.attributes_set,
+                                      kg2.attribute_triples_set, kg2.attributes_set, ordered=ordered)
+        self.uri_kg1, self.uri_kg2 = kg1, kg2
+        id_kgs = []
+        for kg, e, r, a in ((kg1, ent_ids1, rel_ids1, attr_ids1), (kg2, ent_ids2, rel_ids2, attr_ids2)):
+            k = KG(uris_relation_triple_2ids(kg.relation_triples_set, e, r),
+                   uris_attribute_triple_2ids(kg.attribute_triples_set, e, a))
+            k.set_id_dict(e, r, a)
+            id_kgs.append(k)
+        self.kg1, self.kg2 = id_kgs
+
+        self.uri_train_links, self.uri_valid_links = train_links, valid_links
+        self.train_links = uris_pair_2ids(train_links, ent_ids1, ent_ids2)
+        self.valid_links = uris_pair_2ids(valid_links, ent_ids1, ent_ids2)
+        self.uri_test_links = test_links
+        self.test_links = uris_pair_2ids(test_links, ent_ids1, ent_ids2) if test_links is not None else []
+        for split in ("train", "valid", "test"):
+            links = getattr(self, split + "_links")
+            if len(set(links)) != len(links):
+                raise ValueError(f"duplicate pairs in {split}_links")
+            setattr(self, split + "_entities1", [a for a, _ in links])
+            setattr(self, split + "_entities2", [b for _, b in links])
+
+        if mode == "swapping":
+            s1, s2 = generate_sup_relation_triples(self.train_links, self.kg1.rt_dict, self.kg1.hr_dict,
+                                                   self.kg2.rt_dict, self.kg2.hr_dict)
+            self.kg1.add_sup_relation_triples(s1)
+            self.kg2.add_sup_relation_triples(s2)
+            s1, s2 = generate_sup_attribute_triples(self.train_links, self.kg1.av_dict, self.kg2.av_dict)
+            self.kg1.add_sup_attribute_triples(s1)
+            self.kg2.add_sup_attribute_triples(s2)
+
+        self.useful_entities_list1 = self.train_entities1 + self.valid_entities1 + self.test_entities1
+        self.useful_entities_list2 = self.train_entities2 + self.valid_entities2 + self.test_entities2
+        self.entities_num = len(self.kg1.entities_set | self.kg2.entities_set)
+        self.relations_num = len(self.kg1.relations_set | self.kg2.relations_set)
+        self.attributes_num = len(self.kg1.attributes_set | self.kg2.attributes_set)
+
+
+def read_kgs_from_folder(training_data_folder, division, mode, ordered):
+    """The dataset layout of the reference's README (README.md:10-20; code/base/kgs.py:79-92)."""
+    f = training_data_folder
+    r1, _, _ = read_relation_triples(f + "rel_triples_1")
+    r2, _, _ = read_relation_triples(f + "rel_triples_2")
+    a1, _, _ = read_attribute_triples(f + "attr_triples_1")
+    a2, _, _ = read_attribute_triples(f + "attr_triples_2")
+    links = [read_links(f + division + name) for name in ("train_links", "valid_links", "test_links")]
+    return _build(r1, r2, a1, a2, *links, mode=mode, ordered=ordered)
+
+
+def read_kgs_from_files(kg1_relation_triples, kg2_relation_triples, kg1_attribute_triples, kg2_attribute_triples,
+                        train_links, valid_links, test_links, mode):
+    return _build(kg1_relation_triples, kg2_relation_triples, kg1_attribute_triples, kg2_attribute_triples, train_links,
+                  valid_links, test_links, mode=mode, ordered=True)
+
+
+def _build(r1, r2, a1, a2, train_links, valid_links, test_links, mode, ordered):
+    uri1, uri2 = _UriKG(r1, a1), _UriKG(r2, a2)
+    return KGs(uri1, uri2, train_links, valid_links, test_links=test_links, mode=mode, ordered=ordered)
+
+
+class _UriKG(KG):
+    """URI-space KG that keeps file order for its element sets so that unordered id assignment is deterministic."""
+
+    def set_relations(self, relation_triples):
+        super().set_relations(relation_triples)
+        order = _OrderedSet()
+        rels = _OrderedSet()
+        for h, r, t in relation_triples:
+            order.add(h)
+            order.add(t)
+            rels.add(r)
+        self.entities_set, self.relations_set = order, rels
+
+    def set_attributes(self, attribute_triples):
+        super().set_attributes(attribute_triples)
+        attrs = _OrderedSet()
+        for _, a, _ in attribute_triples:
+            attrs.add(a)
+        self.attributes_set = attrs

@@ -141,3 +141,100 @@ def synthetic_args(**over):
              seed=0)
     d.update(over)
     return ARGs(d)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# a dataset *folder* in the reference's on-disk layout (README.md:10-20), for the reader / DataModel tests and demos
+# ----------------------------------------------------------------------------------------------------------------
+_WORDS = ("amber basalt cedar delta ember fjord garnet harbor indigo jasper kestrel lagoon marble nectar onyx prairie "
+          "quartz raven sierra tundra umber valley willow xenon yarrow zephyr atlas bridge canyon dune estuary forest "
+          "glacier heath island jungle knoll ledge meadow north oasis peak quarry ridge summit terrace upland vale "
+          "wharf yard zenith").split()
+
+
+def write_dataset_folder(folder, n_pairs=60, n_extra=8, n_rel=6, n_attr=7, seed=11, division="631/", word_dim=300,
+                         triples_per_entity=3.0):
+    """Writes rel_triples_{1,2}, attr_triples_{1,2}, entity_local_name_{1,2}, predicate_local_name_{1,2},
+    <division>{train,valid,test}_links and a text word-vector file into `folder` (created).  Two KGs over `n_pairs`
+    aligned entities (+ `n_extra` unaligned each) with partly matching predicate names, typed / language-tagged /
+    multi-field literal values and a few rare attributes, so every branch of the readers is exercised.  Deterministic
+    in `seed`.  Returns the path of the word-vector file."""
+    import os
+    rng = np.random.default_rng(seed)
+    folder = folder if folder.endswith("/") else folder + "/"
+    os.makedirs(folder + division, exist_ok=True)
+    n = n_pairs + n_extra
+    names = []
+    for i in range(n_pairs):
+        w = rng.choice(len(_WORDS), size=2, replace=False)
+        names.append(f"{_WORDS[w[0]].capitalize()}_{_WORDS[w[1]]}" + ("_(place)" if i % 7 == 0 else ""))
+
+    def ent(k, i):
+        return f"http://kg{k}.example.org/resource/E{i}"
+
+    rel_names = [f"{_WORDS[(3 * j) % len(_WORDS)]}Of" for j in range(n_rel)]
+    attr_names = [f"{_WORDS[(5 * j + 1) % len(_WORDS)]}Value" for j in range(n_attr)]
+    word_file = folder + "wiki-news-300d-tiny.vec"
+    for k in (1, 2):
+        # relations: the first n_rel-2 share names across KGs (one with a typo), the rest differ
+        rels = {j: f"http://kg{k}.example.org/ontology/{rel_names[j] if j < n_rel - 2 else rel_names[j] + str(k) * 3}"
+                for j in range(n_rel)}
+        attrs = {j: f"http://kg{k}.example.org/property/{attr_names[j] if j < n_attr - 2 else 'x' * k + attr_names[j]}"
+                 for j in range(n_attr)}
+        if k == 2:
+            rels[0] = rels[0][:-1] + "f"                                  # near-identical name
+        n_tri = int(n * triples_per_entity)
+        with open(folder + f"rel_triples_{k}", "w", encoding="utf8") as f:
+            seen = set()
+            for i in range(n):                                           # every entity occurs at least once
+                t = (i, int(rng.integers(n_rel)), int((i + 1 + rng.integers(n - 1)) % n))
+                seen.add(t)
+            while len(seen) < n_tri:
+                seen.add((int(rng.integers(n)), int(rng.integers(n_rel)), int(rng.integers(n))))
+            for (h, r, t) in sorted(seen):
+                f.write(f"{ent(k, h)}\t{rels[r]}\t{ent(k, t)} \n" if (h + t) % 5 == 0 else f"{ent(k, h)}\t{rels[r]}\t{ent(k, t)}\n")
+        with open(folder + f"attr_triples_{k}", "w", encoding="utf8") as f:
+            for i in range(n):
+                for _ in range(int(rng.integers(1, 5))):
+                    a = int(rng.integers(n_attr - 1))                    # the last attribute stays rare (< 10 triples)
+                    style = int(rng.integers(5))
+                    w = rng.choice(len(_WORDS), size=2, replace=False)
+                    if style == 0:
+                        v = f'"{_WORDS[w[0]]} {_WORDS[w[1]]}"@en'
+                    elif style == 1:
+                        v = f'"{int(rng.integers(1, 3000))}.{int(rng.integers(10))}"^^<http://www.w3.org/2001/XMLSchema#double>'
+                    elif style == 2:
+                        v = f'{_WORDS[w[0]]}_{_WORDS[w[1]]}-(north)\t{_WORDS[w[1]]}\t.'
+                    elif style == 3:
+                        v = f'http://kg{k}.example.org/resource/E{int(rng.integers(n))}'
+                    else:
+                        v = f'"{_WORDS[w[0]]}, {_WORDS[w[1]]}/zzunlisted{int(rng.integers(4))}" .'
+                    f.write(f"{ent(k, i)}\t{attrs[a]}\t{v}\n")
+            f.write(f"{ent(k, 0)}\t{attrs[n_attr - 1]}\t\"rare value\"@en\n")
+            f.write(f"{ent(k, 1)}\tshort line\n")
+        with open(folder + f"entity_local_name_{k}", "w", encoding="utf8") as f:
+            for i in range(n):
+                if i < n_pairs:
+                    nm = names[i] if (k == 1 or i % 5) else names[i].replace("_", "_the_", 1)
+                else:
+                    nm = f"{_WORDS[int(rng.integers(len(_WORDS)))]}_{k}{i}"
+                if not (k == 2 and i == n - 1):                          # one entity without a local-name line
+                    f.write(f"{ent(k, i)}\t{nm}\n")
+        with open(folder + f"predicate_local_name_{k}", "w", encoding="utf8") as f:
+            for j in range(n_rel):
+                f.write(f"{rels[j]}\t{rels[j].rsplit('/', 1)[1]}\n")
+            for j in range(n_attr):
+                f.write(f"{attrs[j]}\t{attrs[j].rsplit('/', 1)[1]}\n")
+    order = rng.permutation(n_pairs)
+    n_tr, n_va = int(n_pairs * 0.3), int(n_pairs * 0.1)
+    for name, sel in (("train_links", order[:n_tr]), ("valid_links", order[n_tr:n_tr + n_va]), ("test_links", order[n_tr + n_va:])):
+        with open(folder + division + name, "w", encoding="utf8") as f:
+            for i in sel:
+                f.write(f"{ent(1, int(i))}\t{ent(2, int(i))}\n")
+    with open(word_file, "w", encoding="utf-8") as f:
+        f.write(f"{len(_WORDS)} {word_dim}\n")
+        for w in _WORDS + ["the", "place", "north"]:
+            vec = rng.standard_normal(word_dim) * 0.3
+            f.write(w + " " + " ".join(f"{x:.5f}" for x in vec) + "\n")
+            f.write(w.capitalize() + " " + " ".join(f"{x:.5f}" for x in vec * 0.9) + "\n")
+    return word_file

@@ -77,3 +77,109 @@ def save_embeddings(folder, kgs, ent_embeds, nv_ent_embeds, rv_ent_embeds, av_en
                            ("kg1_attr_ids", kgs.kg1, "attributes_id_dict"), ("kg2_attr_ids", kgs.kg2, "attributes_id_dict")):
         dict2file(folder + name, getattr(kg, attr, None))
     print("Embeddings saved!")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# text-side inputs of the literal view (host-side data preparation, no kernels)
+# ----------------------------------------------------------------------------------------------------------------
+def read_word2vec(file_path, vector_dimension=300):
+    """Text word-vector file, `word v1 ... vD` separated by single spaces; lines with another field count (e.g. the
+    `count dim` header) are skipped (code/utils.py:94-105)."""
+    word2vec = {}
+    with open(file_path, "r", encoding="utf-8") as f:
+        for line in f:
+            p = line.rstrip("\n").split(" ")
+            if len(p) == vector_dimension + 1:
+                word2vec[p[0]] = np.asarray(p[1:], dtype=np.float64).astype(np.float32)
+    return word2vec
+
+
+def read_local_name_file(file_path, entities_set):
+    """`uri \\t local name`: a trailing "(...)" qualifier is cut at the first '(' and '_' becomes ' '; entities
+    without a line get '' (code/utils.py:117-137).  Every line must name an entity of the set."""
+    names = {}
+    with open(file_path, "r", encoding="utf-8") as f:
+        for no, line in enumerate(f, 1):
+            p = line.rstrip("\n").split("\t")
+            if len(p) != 2:
+                raise ValueError(f"{file_path}:{no}: expected 2 tab-separated fields")
+            ln = p[1].split("(")[0] if p[1].endswith(")") else p[1]
+            names[p[0]] = ln.replace("_", " ")
+    for e in entities_set:
+        names.setdefault(e, "")
+    if len(names) != len(entities_set):
+        raise ValueError(f"{file_path}: names for {len(names) - len(entities_set)} entities that are not in the KG")
+    return names
+
+
+def read_local_name(folder_path, entities_set_1, entities_set_2):
+    names = read_local_name_file(folder_path + "entity_local_name_1", entities_set_1)
+    names.update(read_local_name_file(folder_path + "entity_local_name_2", entities_set_2))
+    return names
+
+
+def is_number(s):
+    """code/utils.py:276-290: float()-parsable or a single numeric unicode character."""
+    try:
+        float(s)
+        return True
+    except ValueError:
+        pass
+    try:
+        import unicodedata
+        unicodedata.numeric(s)
+        return True
+    except (TypeError, ValueError):
+        return False
+
+
+_DROP = str.maketrans("", "", ".(),\"")
+_SPACE = str.maketrans("_-/", "   ")
+
+
+def clear_attribute_triples(attribute_triples):
+    """Literal clean-up before encoding (code/utils.py:233-273): keep attributes with >= 10 triples; cut typed /
+    @en suffixes; delete . ( ) , " and turn _ - / into spaces; drop values that still contain 'http'.
+    Returns (triples, numeric literals, string literals) -- the literal lists classify the value after the suffix
+    cut and before the character clean-up, dropped triples included, as the reference does."""
+    triples = set(attribute_triples)
+    freq = {}
+    for _, a, _ in triples:
+        freq[a] = freq.get(a, 0) + 1
+    kept, numbers, strings = [], [], []
+    for e, a, v in sorted(triples, key=repr):
+        if freq[a] < 10:
+            continue
+        cut = v.find('"^^')
+        if cut >= 0:
+            v = v[:cut]
+        if v.endswith('"@en'):
+            v = v[:v.index('"@en')]
+        (numbers if is_number(v) else strings).append(v)
+        v = v.translate(_DROP).translate(_SPACE)
+        if "http" not in v:
+            kept.append((e, a, v))
+    return kept, numbers, strings
+
+
+class CharHashEmbedder:
+    """Vectors for words missing from the word2vec file.  The reference trains gensim character embeddings on the
+    unlisted words and averages them per word (code/utils.py:140-172, code/literal_encoder.py:147-156); gensim is
+    not a dependency here and that training is itself unseeded, so this stand-in gives every character a fixed
+    pseudo-random unit-variance vector (seeded by its code point) and returns the mean over the word's characters.
+    Same shape of information (character bag), deterministic, no training."""
+
+    def __init__(self, vector_dimension=300, scale=0.1):
+        self.dim, self.scale, self._cache = int(vector_dimension), float(scale), {}
+
+    def _char(self, ch):
+        v = self._cache.get(ch)
+        if v is None:
+            v = np.random.default_rng(ord(ch)).standard_normal(self.dim).astype(np.float32) * self.scale
+            self._cache[ch] = v
+        return v
+
+    def __call__(self, word):
+        if not word:
+            return None
+        return np.mean([self._char(c) for c in word], axis=0)

@@ -319,6 +319,101 @@ def eval_fixture(ref_alignment, out):
         out[pre + "rest"] = np.array(sorted(rest_a), dtype=np.int64)
 
 
+def _py_ratio(a, b):
+    """Independent statement of python-Levenshtein's `ratio` (edit distance with substitution cost 2, normalised by
+    the summed lengths) -- plain O(len^2) DP, used only as the stand-in the reference module calls here."""
+    la, lb = len(a), len(b)
+    if la + lb == 0:
+        return 1.0
+    prev = list(range(lb + 1))
+    for i in range(1, la + 1):
+        cur = [i] + [0] * lb
+        for j in range(1, lb + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (0 if a[i - 1] == b[j - 1] else 2))
+        prev = cur
+    return (la + lb - prev[lb]) / (la + lb)
+
+
+def data_fixture(ref_kgs, ref_utils, ref_pa, out_json):
+    """Runs the reference's readers / id assignment / KG containers / literal clean-up / predicate alignment on the
+    folder `multike_amd.synthetic.write_dataset_folder` writes (deterministic) and stores what they return."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from multike_amd.synthetic import write_dataset_folder
+    folder = tempfile.mkdtemp() + "/"
+    write_dataset_folder(folder)
+    sys.modules["Levenshtein"].ratio = _py_ratio
+    res = {"writer": {"seed": 11, "n_pairs": 60}}
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        for mode in ("swapping", "mapping", "sharing"):
+            k = ref_kgs.read_kgs_from_folder(folder, "631/", mode, True)
+            e = {"ent_ids1": k.kg1.entities_id_dict, "ent_ids2": k.kg2.entities_id_dict,
+                 "rel_ids1": k.kg1.relations_id_dict, "rel_ids2": k.kg2.relations_id_dict,
+                 "attr_ids1": k.kg1.attributes_id_dict, "attr_ids2": k.kg2.attributes_id_dict,
+                 "train_links": k.train_links, "valid_links": k.valid_links, "test_links": k.test_links,
+                 "entities_num": k.entities_num, "relations_num": k.relations_num, "attributes_num": k.attributes_num}
+            for i, kg in ((1, k.kg1), (2, k.kg2)):
+                e[f"local_rel{i}"] = sorted(kg.local_relation_triples_list)
+                e[f"local_set_size{i}"] = len(kg.local_relation_triples_set)
+                e[f"rel_num{i}"] = [kg.relation_triples_num, kg.local_relation_triples_num,
+                                    kg.attribute_triples_num, kg.local_attribute_triples_num]
+                e[f"sup_rel{i}"] = sorted(kg.sup_relation_triples_list or [])
+                e[f"sup_attr{i}"] = sorted(kg.sup_attribute_triples_list or [])
+                e[f"local_attr{i}"] = sorted(kg.local_attribute_triples_list)
+            res[mode] = e
+        # unordered: only layout facts are reproducible (hash order)
+        k0 = ref_kgs.read_kgs_from_folder(folder, "631/", "swapping", False)
+        res["unordered"] = {"n1": k0.kg1.entities_num, "n2": k0.kg2.entities_num,
+                            "ids1_range": [min(k0.kg1.entities_id_dict.values()), max(k0.kg1.entities_id_dict.values())],
+                            "ids2_range": [min(k0.kg2.entities_id_dict.values()), max(k0.kg2.entities_id_dict.values())],
+                            "sup_rel": [len(k0.kg1.sup_relation_triples_list), len(k0.kg2.sup_relation_triples_list)]}
+        k = ref_kgs.read_kgs_from_folder(folder, "631/", "swapping", True)
+        cl = {}
+        for i, kg in ((1, k.kg1), (2, k.kg2)):
+            t, num, st = ref_utils.clear_attribute_triples(kg.local_attribute_triples_list)
+            cl[f"triples{i}"] = sorted(t)
+            cl[f"numbers{i}"] = sorted(num)
+            cl[f"strings{i}"] = sorted(st)
+        res["clear_attribute_triples"] = cl
+        res["local_names"] = ref_utils.read_local_name(folder, set(k.kg1.entities_id_dict), set(k.kg2.entities_id_dict))
+        res["is_number"] = {s: bool(ref_utils.is_number(s)) for s in ("12", "1e5", "-3.5", "abc", "\u00bd", "", "12a", "nan")}
+        w2v = ref_utils.read_word2vec(folder + "wiki-news-300d-tiny.vec")
+        res["word2vec"] = {"n": len(w2v), "amber_head": [float(x) for x in w2v["amber"][:4]]}
+        args = types.SimpleNamespace(training_data=folder, predicate_init_sim=0.9, predicate_soft_sim=0.85)
+        pam = ref_pa.PredicateAlignModel(k, args)
+        emb_rng = np.random.default_rng(5)
+
+        def snap(p):
+            return {"relation_alignment_set": sorted(p.relation_alignment_set),
+                    "attribute_alignment_set": sorted(p.attribute_alignment_set),
+                    "relation_latent": sorted([a, b, s] for (a, b), s in p.relation_latent_match_pairs_similarity_dict_init.items()),
+                    "attribute_latent": sorted([a, b, s] for (a, b), s in p.attribute_latent_match_pairs_similarity_dict_init.items()),
+                    "sup_rel1": sorted(p.sup_relation_alignment_triples1), "sup_rel2": sorted(p.sup_relation_alignment_triples2),
+                    "sup_attr1": sorted(p.sup_attribute_alignment_triples1), "sup_attr2": sorted(p.sup_attribute_alignment_triples2),
+                    "rel_w1": sorted(p.relation_triples_w_weights1), "attr_w2": sorted(p.attribute_triples_w_weights2),
+                    "train_relations1": sorted(p.train_relations1), "train_attributes2": sorted(p.train_attributes2)}
+        pa = {"init": snap(pam)}
+        rel_embed = emb_rng.standard_normal((k.relations_num, 8))
+        attr_embed = emb_rng.standard_normal((k.attributes_num, 8))
+        # make matched predicates close so that the refresh keeps some and drops others
+        for (p1, p2, _) in sorted(pam.relation_alignment_set_init)[:3]:
+            rel_embed[k.kg2.relations_id_dict[p2]] = rel_embed[k.kg1.relations_id_dict[p1]] + 0.05
+        for (p1, p2, _) in sorted(pam.attribute_alignment_set_init)[:2]:
+            attr_embed[k.kg2.attributes_id_dict[p2]] = attr_embed[k.kg1.attributes_id_dict[p1]] + 0.05
+        pam.update_predicate_alignment(rel_embed)
+        pam.update_predicate_alignment(attr_embed, predicate_type="attribute")
+        pa["rel_embed"] = rel_embed.tolist()
+        pa["attr_embed"] = attr_embed.tolist()
+        pa["refreshed"] = snap(pam)
+        pa["ratios"] = [[a, b, ref_pa.Levenshtein.ratio(a, b)] for a, b in
+                        (("Hello world!", "Holly grail!"), ("kitten", "sitting"), ("", ""), ("abc", ""), ("amberOf", "amberOf"))]
+        res["predicate_alignment"] = pa
+    out_json.update(res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -348,6 +443,10 @@ def main():
     host_fixture(ref_utils, js)
     with open(os.path.join(HERE, "sampler_golden.json"), "w") as f:
         json.dump(js, f, separators=(",", ":"))
+    dj = {}
+    data_fixture(importlib.import_module("base.kgs"), ref_utils, importlib.import_module("predicate_alignment"), dj)
+    with open(os.path.join(HERE, "data_golden.json"), "w") as f:
+        json.dump(dj, f, separators=(",", ":"), sort_keys=True)
     print("wrote", sorted(os.listdir(HERE)))
 
 

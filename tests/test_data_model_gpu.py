@@ -1,0 +1,67 @@
+"""Dataset folder -> DataModel -> PredicateAlignModel -> driver.run(): the reference's run_ITC.py / run_SSL.py flow
+(code/run_ITC.py:14-21) on a folder in the reference's on-disk layout, end to end on the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(folder, word_file, **over):
+    from multike_amd.synthetic import synthetic_args
+    return synthetic_args(training_data=folder, output=folder + "out/", word2vec_path=word_file, dataset_division="631/",
+                          encoder_epoch=3, encoder_active="tanh", encoder_normalize=True, retrain_literal_embeds=False,
+                          literal_normalize=True, dim=16, batch_size=120, attribute_batch_size=100, entity_batch_size=64,
+                          neg_triple_num=4, learning_rate=0.01, max_epoch=4, shared_learning_max_epoch=2, start_valid=2,
+                          eval_freq=2, start_predicate_soft_alignment=1, truncated_freq=2, truncated_epsilon=0.9,
+                          is_save=True, **over)
+
+
+def test_data_model_tables(tmp_path):
+    from multike_amd.data_model import LITERAL_EMBEDDINGS_FILE, DataModel
+    from multike_amd.synthetic import write_dataset_folder
+    folder = str(tmp_path) + "/"
+    wf = write_dataset_folder(folder)
+    args = _args(folder, wf)
+    data = DataModel(args)
+    kgs = data.kgs
+    n = kgs.entities_num
+    assert data.local_name_vectors.shape == (n, args.dim) and data.value_vectors.shape[1] == args.dim
+    norms = np.linalg.norm(data.local_name_vectors, axis=1)
+    assert np.all((np.abs(norms - 1) < 1e-6) | (norms == 0))
+    # attribute triples are now (entity id, attribute id, value id) with ids inside the value table
+    for kg in (kgs.kg1, kgs.kg2):
+        assert kg.local_attribute_triples_num > 0
+        vmax = max(v for _, _, v in kg.local_attribute_triples_list)
+        assert vmax < data.value_vectors.shape[0]
+        assert all(isinstance(v, int) for _, _, v in kg.sup_attribute_triples_list)
+    # aligned entities carry (nearly) the same local name -> their name vectors are each other's nearest neighbours
+    t1, t2 = np.array(kgs.test_entities1), np.array(kgs.test_entities2)
+    sim = data.local_name_vectors[t1] @ data.local_name_vectors[t2].T
+    assert (sim.argmax(1) == np.arange(len(t1))).mean() > 0.7
+    # the cache is written and a second DataModel loads it instead of re-training
+    assert os.path.exists(folder + LITERAL_EMBEDDINGS_FILE)
+    again = DataModel(args)
+    np.testing.assert_array_equal(again.local_name_vectors, data.local_name_vectors)
+    np.testing.assert_array_equal(again.value_vectors, data.value_vectors)
+    assert again.kgs.kg1.local_attribute_triples_list == kgs.kg1.local_attribute_triples_list
+
+
+@pytest.mark.parametrize("method", ["ITC", "SSL"])
+def test_run_from_folder(tmp_path, method):
+    from multike_amd.run import main
+    from multike_amd.synthetic import write_dataset_folder
+    folder = str(tmp_path) + "/"
+    wf = write_dataset_folder(folder, n_pairs=150, n_extra=10)
+    args = _args(folder, wf)
+    cfg = tmp_path / "args.json"
+    cfg.write_text(json.dumps(vars(args)))
+    res = main(["--method", method, "--training_data", folder.rstrip("/"), "--args", str(cfg), "--set", "max_epoch=4"])
+    assert {"nv", "rv", "av", "final"} <= set(res) and all(np.isfinite(v) for v in res.values())
+    assert res["nv"] > 0.5
+    outs = []
+    for root, _, files in os.walk(folder + "out/"):
+        outs += files
+    assert {"ent_embeds.npy", "rv_ent_embeds.npy", "rel_embeds.npy", "attr_embeds.npy", "kg1_ent_ids", "kg2_rel_ids"} <= set(outs)
