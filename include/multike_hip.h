@@ -370,34 +370,41 @@ int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int s
  *     the conv stack; W / bias follow.
  *   Pipeline of one step (all enqueue-only):
  *     mke_attr_conv_fwd   : gather attribute (table flag) + literal rows, BN affine, 2 x conv+tanh, width l2-norm -> flat [n][4*dim]
- *     (library GEMM)      : zpre = flat @ W
+ *     (library GEMM)      : zpre = flat @ W        (mke_attr_step: [flat, 1] @ [W; bias] -- W and bias are adjacent in the pack)
  *     mke_attr_tail_z     : z = tanh(zpre + bias) in place; per-block partial sums of z^2
  *     mke_attr_tail_loss  : out = z / ||z||_F (whole batch); loss = scale * sum w log(1+exp(||h-out||^2)); scatter of the
  *                           entity-row gradient; gout = dL/dout; per-block partials of sum gout.z
- *     mke_attr_tail_bwd   : gout <- dL/dzpre (through the batch-global normalisation and tanh), in place
- *     (library GEMMs)     : dW = flat^T @ dzpre ; dflat = dzpre @ W^T ; dbias = column sums
+ *     mke_attr_tail_bwd   : gout <- dL/dzpre (through the batch-global normalisation and tanh), in place; dbias += column sums
+ *     (library GEMMs)     : dW = flat^T @ dzpre ; dflat = dzpre @ W^T
  *     mke_attr_conv_bwd   : recomputes the conv stack, back-propagates it, scatters the attribute-row gradient and
  *                           accumulates the conv / BN parameter gradients into grad_params (atomic)
  *     mke_dense_update    : Adagrad / SGD over the packed parameter buffer (consumes = zeroes the gradient)
  * ------------------------------------------------------------------------------------------------ */
 #define MKE_CNN_CONV_PARAMS(dim) (2 * (dim) + 52)
 #define MKE_CNN_PARAMS(dim) (MKE_CNN_CONV_PARAMS(dim) + 4 * (dim) * (dim) + (dim))
+#define MKE_CNN_WORKSPACE_FLOATS(dim) (32 * (2 * (dim) + 64))
 int mke_attr_conv_fwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table, int lit_stride,
                       int dim, const int32_t* ia, const int32_t* iv, int64_t n, const float* params, float* flat,
+                      int flat_stride /* even, >= 4*dim; when > 4*dim, flat[t][4*dim] = 1 (bias column: [flat,1] @ [W;bias]) */,
                       void* stream);
 int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table, int lit_stride,
                       int dim, const int32_t* ia, const int32_t* iv, int64_t n, const float* params, const float* dflat,
-                      float* grad_params, float* grad_attr /*nullable*/, int32_t* touched_attr, int32_t tag, void* stream);
-int mke_attr_tail_z(float* z /* in: zpre, out: z */, const float* bias, int64_t n, int dim,
+                      float* grad_params, float* grad_attr /*nullable*/, int32_t* touched_attr, int32_t tag,
+                      float* workspace /* nullable: MKE_CNN_WORKSPACE_FLOATS(dim) floats, all-zero before the first call;
+                                          left all-zero by every call.  Without it every block accumulates straight into
+                                          grad_params: same result, ~3x slower at 5000 triples */,
+                      void* stream);
+int mke_attr_tail_z(float* z /* in: zpre, out: z */, const float* bias /* nullable: already in zpre */, int64_t n, int dim,
                     double* sumsq_partials /* [MKE_LOSS_PARTIALS] */, void* stream);
 int mke_attr_tail_loss(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
                        int ent_normalize, const int32_t* ih, const float* weights /*nullable*/, float scale, int64_t n,
                        int dim, float* gout /* [n][dim] */, double* dot_partials, float* grad_ent /*nullable*/,
                        int32_t* touched_ent, int32_t tag, double* loss_partials, void* stream);
 int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials, int64_t n,
-                      int dim, void* stream);
+                      int dim, float* grad_bias /* nullable: += column sums of dL/dzpre (the dense layer's bias gradient) */,
+                      void* stream);
 /* The whole pipeline above as ONE native call (the dense layer's three products run on mke_gemm_f32):
- * conv_fwd -> GEMM -> tail_z -> tail_loss -> tail_bwd -> bias gradient -> GEMM (dW, split-K) -> GEMM (dflat) -> conv_bwd
+ * conv_fwd -> GEMM -> tail_z -> tail_loss -> tail_bwd -> GEMM ([dW; dbias], split-K) -> GEMM (dflat) -> conv_bwd
  * -> [update != 0] row updates of the entity / attribute tables and the dense update of the packed parameters.
  * ent_grad / attr_grad NULL = that table is constant.  param_grads must be all-zero on entry (the dense update restores
  * it; with update == 0 the caller inspects and clears it).  scratch: mke_attr_scratch_floats(n, dim) floats.
@@ -412,6 +419,7 @@ typedef struct mke_attr_step_args {
   float* params; float* param_grads; float* param_acc /*nullable for SGD*/;
   float* scratch; double* partials;
   int optimizer; float lr; int32_t tag; int update;
+  float* workspace;   /* nullable: MKE_CNN_WORKSPACE_FLOATS(dim) floats, zero before first use, left zero (see mke_attr_conv_bwd) */
 } mke_attr_step_args;
 int64_t mke_attr_scratch_floats(int64_t n, int dim);
 int mke_attr_step(const mke_attr_step_args* args, void* stream);

@@ -43,7 +43,7 @@ class AttrStepArgs(C.Structure):
         ("ih", C.c_void_p), ("ia", C.c_void_p), ("iv", C.c_void_p), ("weights", C.c_void_p), ("n", C.c_int64),
         ("scale", C.c_float), ("params", C.c_void_p), ("param_grads", C.c_void_p), ("param_acc", C.c_void_p),
         ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
-        ("update", C.c_int),
+        ("update", C.c_int), ("workspace", C.c_void_p),
     ]
 
 
@@ -371,17 +371,25 @@ def attr_conv_fwd(attr, attr_normalize, lit, dim, ia, iv, params, flat):
     rc = lib().mke_attr_conv_fwd(_dev(attr, torch.float32, "attr_table"), C.c_int(attr.shape[1]), C.c_int(int(attr_normalize)),
                                  _dev(lit, torch.float32, "lit_table"), C.c_int(lit.shape[1]), C.c_int(dim),
                                  _dev(ia, torch.int32, "ia"), _dev(iv, torch.int32, "iv"), C.c_int64(ia.numel()),
-                                 _dev(params, torch.float32, "params"), _dev(flat, torch.float32, "flat"), _stream())
+                                 _dev(params, torch.float32, "params"), _dev(flat, torch.float32, "flat"),
+                                 C.c_int(flat.shape[1]), _stream())
     _check(rc, "mke_attr_conv_fwd")
 
 
-def attr_conv_bwd(attr, attr_normalize, lit, dim, ia, iv, params, dflat, grad_params, grad_attr, touched_attr, tag):
+def cnn_workspace_floats(dim: int) -> int:
+    """MKE_CNN_WORKSPACE_FLOATS(dim)"""
+    return 32 * (2 * dim + 64)
+
+
+def attr_conv_bwd(attr, attr_normalize, lit, dim, ia, iv, params, dflat, grad_params, grad_attr, touched_attr, tag,
+                  workspace=None):
     rc = lib().mke_attr_conv_bwd(_dev(attr, torch.float32, "attr_table"), C.c_int(attr.shape[1]), C.c_int(int(attr_normalize)),
                                  _dev(lit, torch.float32, "lit_table"), C.c_int(lit.shape[1]), C.c_int(dim),
                                  _dev(ia, torch.int32, "ia"), _dev(iv, torch.int32, "iv"), C.c_int64(ia.numel()),
                                  _dev(params, torch.float32, "params"), _dev(dflat, torch.float32, "dflat"),
                                  _dev(grad_params, torch.float32, "grad_params"), _dev(grad_attr, torch.float32, "grad_attr"),
-                                 _dev(touched_attr, torch.int32, "touched_attr"), C.c_int32(tag), _stream())
+                                 _dev(touched_attr, torch.int32, "touched_attr"), C.c_int32(tag),
+                                 _dev(workspace, torch.float32, "workspace"), _stream())
     _check(rc, "mke_attr_conv_bwd")
 
 
@@ -405,11 +413,11 @@ def attr_tail_loss(z, sumsq_partials, ent, ent_normalize, ih, weights, scale, go
     _check(rc, "mke_attr_tail_loss")
 
 
-def attr_tail_bwd(z, gout, sumsq_partials, dot_partials):
+def attr_tail_bwd(z, gout, sumsq_partials, dot_partials, grad_bias=None):
     n, dim = z.shape
     rc = lib().mke_attr_tail_bwd(_dev(z, torch.float32, "z"), _dev(gout, torch.float32, "gout"),
                                  _dev(sumsq_partials, torch.float64, "sumsq"), _dev(dot_partials, torch.float64, "dot"),
-                                 C.c_int64(n), C.c_int(dim), _stream())
+                                 C.c_int64(n), C.c_int(dim), _dev(grad_bias, torch.float32, "grad_bias"), _stream())
     _check(rc, "mke_attr_tail_bwd")
 
 

@@ -29,6 +29,7 @@ class AttrCNN:
         self.grads = torch.zeros_like(self.params)
         self.slots: dict[str, torch.Tensor] = {}
         self._scratch = None
+        self._workspace = None   # zero-invariant reduction workspace of mke_attr_conv_bwd
         self._partials = torch.zeros(8, 3 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
         self._ring = 0
         d = dim
@@ -110,5 +111,8 @@ class AttrCNN:
         a.param_acc = _lib.ptr(self.slot(opt_name), f32, "acc") if (adagrad and update) else None
         a.scratch, a.partials = _lib.ptr(self._scratch, f32, "scratch"), _lib.ptr(part, torch.float64, "partials")
         a.optimizer, a.lr, a.tag, a.update = _OPT[optimizer], float(lr), tag, int(update)
+        if self._workspace is None:
+            self._workspace = torch.zeros(_lib.cnn_workspace_floats(d), dtype=torch.float32, device=self.device)
+        a.workspace = _lib.ptr(self._workspace, f32, "workspace")
         _lib.attr_step(a)
         return part[:_lib.LOSS_PARTIALS]

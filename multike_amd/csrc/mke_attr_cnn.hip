@@ -18,6 +18,8 @@ namespace mke {
 
 #define CNN_BN_EPS 1e-3f
 #define CNN_NCONV 52  // K1 16 + b1 2 + K2 32 + b2 2
+#define CNN_WS_COPIES 32
+#define CNN_WS_STRIDE(d) (2 * (d) + 64)  // MKE_CNN_WORKSPACE_FLOATS(dim) = copies * stride
 
 __device__ __forceinline__ float wave_sum(float v) {
   v = sub16_sum(v);
@@ -36,12 +38,14 @@ struct ConvParams {
   const int32_t* __restrict__ iv;
   int64_t n;
   const float* __restrict__ params;  // packed: gamma[d] beta[d] K1[16] b1[2] K2[32] b2[2] ...
-  float* __restrict__ flat;          // fwd out [n][4d]
+  float* __restrict__ flat;          // fwd out [n][flat_stride]; column 4d = 1 when flat_stride > 4d
+  int flat_stride;
   const float* __restrict__ dflat;   // bwd in  [n][4d]
   float* __restrict__ gparams;       // bwd out, same packing, atomically accumulated
   float* __restrict__ gattr;         // bwd out: attribute-table gradient scratch (nullable)
   int32_t* __restrict__ tattr;
   int32_t tag;
+  float* __restrict__ ws;            // bwd: MKE_CNN_WORKSPACE_FLOATS(dim) zero-invariant floats (nullable)
 };
 
 // K1[kh][kw][0][f] at k1[(kh*4+kw)*2+f]; K2[kh][kw][c][f] at k2[((kh*4+kw)*2+c)*2+f]  (TF HWIO order)
@@ -52,7 +56,6 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   __shared__ float s_c1[MKE_BLOCK / 64][2][2][DP];
   __shared__ float s_d2[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
   __shared__ float s_d1[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
-  __shared__ float s_red[BWD ? CNN_NCONV : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int d = p.dim;
   const float bn_s = rsqrtf(1.0f + CNN_BN_EPS);
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       }
     if constexpr (!BWD) {
       if (live) {
-        float* o = p.flat + t * (int64_t)(4 * d);
+        float* o = p.flat + t * (int64_t)p.flat_stride;
+        if (lane == 0 && p.flat_stride > 4 * d) o[4 * d] = 1.0f;  // bias column: [flat, 1] @ [W; bias]
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
           const int w = lane + 64 * i;
@@ -311,34 +315,65 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 
   if constexpr (BWD) {
     // ---- block-reduce the parameter gradients, one atomic per block per scalar --------------------------------
-    if (threadIdx.x < CNN_NCONV) s_red[threadIdx.x] = 0.f;
-    __syncthreads();
+    // 16-lane sums stay in registers (DPP); the 16 quarter-wave leaders of the block park them in LDS and 52 threads
+    // add the 16 partials up.  (First version: 52 full wave reductions + LDS atomics per wave = 20 of the kernel's
+    // 45 us.)  gamma / beta are per width position: the four waves' vectors go through the (now free) x / c1 strips.
+    __shared__ float s_part[CNN_NCONV][17];
+    {
+      const int q = (lane >> 4) + 4 * wv;
+      const bool lead = (lane & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const float v = wave_sum(a_k1[i]); if (lane == 0) atomicAdd(&s_red[i], v); }
+      for (int i = 0; i < 16; ++i) { const float v = sub16_sum(a_k1[i]); if (lead) s_part[i][q] = v; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const float v = wave_sum(a_b1[i]); if (lane == 0) atomicAdd(&s_red[16 + i], v); }
+      for (int i = 0; i < 2; ++i) { const float v = sub16_sum(a_b1[i]); if (lead) s_part[16 + i][q] = v; }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { const float v = wave_sum(a_k2[i]); if (lane == 0) atomicAdd(&s_red[18 + i], v); }
+      for (int i = 0; i < 32; ++i) { const float v = sub16_sum(a_k2[i]); if (lead) s_part[18 + i][q] = v; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const float v = wave_sum(a_b2[i]); if (lane == 0) atomicAdd(&s_red[50 + i], v); }
-    // gamma / beta: reduce over the block's waves through the (now free) x strips
+      for (int i = 0; i < 2; ++i) { const float v = sub16_sum(a_b2[i]); if (lead) s_part[50 + i][q] = v; }
+    }
     float* gsum = &s_x[0][0][0];
     float* bsum = &s_c1[0][0][0][0];
     __syncthreads();
-    for (int w = threadIdx.x; w < 64 * WPL; w += MKE_BLOCK) { gsum[w] = 0.f; bsum[w] = 0.f; }
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      atomicAdd(&gsum[lane + 64 * i], a_gam[i]);
-      atomicAdd(&bsum[lane + 64 * i], a_bet[i]);
+      gsum[wv * 64 * WPL + lane + 64 * i] = a_gam[i];
+      bsum[wv * 64 * WPL + lane + 64 * i] = a_bet[i];
     }
     __syncthreads();
+    // Every block adding its 2d + 52 sums straight into grad_params is a chain of gridDim.x same-address atomics per
+    // scalar (measured: 45 of the kernel's 66 us at 1024 blocks).  With a workspace the blocks spread over
+    // CNN_WS_COPIES privatised copies (chain length gridDim.x / copies); whoever consumes the gradient next (the dense
+    // update, or k_cnn_ws_fold) adds the copies up and zeroes them.  (A last-block-done ticket was tried first: the
+    // ticket is itself a gridDim.x-long same-address chain and cost more than it saved, 95 us.)
+    float* dst = p.ws ? p.ws + (size_t)(blockIdx.x % CNN_WS_COPIES) * CNN_WS_STRIDE(d) : p.gparams;
     for (int w = threadIdx.x; w < d; w += MKE_BLOCK) {
-      atomic_add_f32(p.gparams + w, gsum[w]);
-      atomic_add_f32(p.gparams + d + w, bsum[w]);
+      float g = 0.f, b = 0.f;
+#pragma unroll
+      for (int k = 0; k < MKE_BLOCK / 64; ++k) { g += gsum[k * 64 * WPL + w]; b += bsum[k * 64 * WPL + w]; }
+      atomic_add_f32(dst + w, g);
+      atomic_add_f32(dst + d + w, b);
     }
-    if (threadIdx.x < CNN_NCONV) atomic_add_f32(p.gparams + 2 * d + threadIdx.x, s_red[threadIdx.x]);
+    if (threadIdx.x < CNN_NCONV) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += s_part[threadIdx.x][k];
+      atomic_add_f32(dst + 2 * d + threadIdx.x, v);
+    }
   }
+}
+
+// grad_params[i] += sum over the CNN_WS_COPIES privatised copies, copies zeroed (the standalone entry's epilogue; inside
+// mke_attr_step the dense update does this itself)
+__global__ __launch_bounds__(MKE_BLOCK) void k_cnn_ws_fold(float* __restrict__ ws, float* __restrict__ gparams, int np, int stride) {
+  const int i = blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (i >= np) return;
+  float v = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < CNN_WS_COPIES; ++c) {
+    v += ws[(size_t)c * stride + i];
+    ws[(size_t)c * stride + i] = 0.f;
+  }
+  gparams[i] += v;
 }
 
 // ---- tail: z = tanh(zpre + bias), partial sums of z^2 -------------------------------------------------------------
@@ -347,7 +382,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_z(float* __restrict__ z
   const int64_t total = n * dim;
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    const float v = tanhf(z[i] + bias[i % dim]);
+    const float v = tanhf(bias ? z[i] + bias[i % dim] : z[i]);
     z[i] = v;
     s = fmaf(v, v, s);
   }
@@ -456,10 +491,28 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_bwd(const float* __rest
   }
 }
 
+// out[j] += sum_i x[i][j]: each block folds its rows, one atomic per column per block (standalone bias gradient; inside
+// mke_attr_step the bias is a row of the extended weight matrix and its gradient a row of dW)
+__global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restrict__ x, int64_t n, int dim, float* __restrict__ out) {
+  for (int j = threadIdx.x; j < dim; j += MKE_BLOCK) {
+    float s = 0.f;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) s += x[i * dim + j];
+    atomic_add_f32(out + j, s);
+  }
+}
+
 __global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(float* __restrict__ w, float* __restrict__ acc, float* __restrict__ g,
-                                                            int64_t n, int optimizer, float lr) {
+                                                            int64_t n, int optimizer, float lr, float* __restrict__ ws, int ws_n,
+                                                            int ws_stride) {
   for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    const float gv = g[i];
+    float gv = g[i];
+    if (ws && i < ws_n) {  // the first ws_n gradients also live in CNN_WS_COPIES privatised copies (k_attr_conv<.,true>)
+#pragma unroll 8
+      for (int c = 0; c < CNN_WS_COPIES; ++c) {
+        gv += ws[(size_t)c * ws_stride + i];
+        ws[(size_t)c * ws_stride + i] = 0.f;
+      }
+    }
     g[i] = 0.f;
     if (optimizer == MKE_OPT_ADAGRAD) {
       const float a = fmaf(gv, gv, acc[i]);
@@ -468,15 +521,6 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(float* __restrict__ 
     } else {
       w[i] -= lr * gv;
     }
-  }
-}
-
-// out[j] += sum_i x[i][j]  (bias gradient of the dense layer): each block folds its rows, one atomic per column per block
-__global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restrict__ x, int64_t n, int dim, float* __restrict__ out) {
-  for (int j = threadIdx.x; j < dim; j += MKE_BLOCK) {
-    float s = 0.f;
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) s += x[i * dim + j];
-    atomic_add_f32(out + j, s);
   }
 }
 
@@ -503,25 +547,46 @@ static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   return check_launch("k_attr_conv");
 }
 
+static int ws_fold(float* ws, float* gparams, int dim, hipStream_t st) {
+  const int np = 2 * dim + CNN_NCONV;
+  hipLaunchKernelGGL(k_cnn_ws_fold, dim3((np + MKE_BLOCK - 1) / MKE_BLOCK), dim3(MKE_BLOCK), 0, st, ws, gparams, np, CNN_WS_STRIDE(dim));
+  return check_launch("k_cnn_ws_fold");
+}
+
+static int dense_update_impl(float* param, float* acc, float* grad, int64_t n, int optimizer, float lr, float* ws, int ws_n,
+                             int ws_stride, hipStream_t st) {
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!param || !grad) { set_error("mke_dense_update: NULL pointer"); return MKE_E_NULL; }
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
+  int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, param, acc, grad, n, optimizer, lr, ws, ws_n,
+                     ws_stride);
+  return check_launch("k_dense_update");
+}
+
 }  // namespace mke
 
 extern "C" int mke_attr_conv_fwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table,
                                  int lit_stride, int dim, const int32_t* ia, const int32_t* iv, int64_t n,
-                                 const float* params, float* flat, void* stream) {
+                                 const float* params, float* flat, int flat_stride, void* stream) {
   using namespace mke;
   if (n < 0 || dim <= 0 || dim > MKE_MAX_STRIDE || attr_stride < dim || lit_stride < dim) { set_error("mke_attr_conv_fwd: bad n/dim/stride"); return MKE_E_SHAPE; }
   if (n == 0) return MKE_OK;
   if (!attr_table || !lit_table || !ia || !iv || !params || !flat) { set_error("mke_attr_conv_fwd: NULL pointer"); return MKE_E_NULL; }
+  if (flat_stride < 4 * dim || (flat_stride & 1)) { set_error("mke_attr_conv_fwd: flat_stride must be even and >= 4*dim"); return MKE_E_SHAPE; }
   ConvParams p{};
   p.attr = attr_table; p.attr_stride = attr_stride; p.attr_norm = attr_normalize; p.lit = lit_table; p.lit_stride = lit_stride;
-  p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.flat = flat;
+  p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.flat = flat; p.flat_stride = flat_stride;
   return conv_dispatch(p, false, (hipStream_t)stream);
 }
 
 extern "C" int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int attr_normalize, const float* lit_table,
                                  int lit_stride, int dim, const int32_t* ia, const int32_t* iv, int64_t n,
                                  const float* params, const float* dflat, float* grad_params, float* grad_attr,
-                                 int32_t* touched_attr, int32_t tag, void* stream) {
+                                 int32_t* touched_attr, int32_t tag, float* workspace, void* stream) {
   using namespace mke;
   if (n < 0 || dim <= 0 || dim > MKE_MAX_STRIDE || attr_stride < dim || lit_stride < dim) { set_error("mke_attr_conv_bwd: bad n/dim/stride"); return MKE_E_SHAPE; }
   if (n == 0) return MKE_OK;
@@ -530,14 +595,16 @@ extern "C" int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int a
   ConvParams p{};
   p.attr = attr_table; p.attr_stride = attr_stride; p.attr_norm = attr_normalize; p.lit = lit_table; p.lit_stride = lit_stride;
   p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.dflat = dflat; p.gparams = grad_params;
-  p.gattr = grad_attr; p.tattr = touched_attr; p.tag = tag;
-  return conv_dispatch(p, true, (hipStream_t)stream);
+  p.gattr = grad_attr; p.tattr = touched_attr; p.tag = tag; p.ws = workspace;
+  int rc = conv_dispatch(p, true, (hipStream_t)stream);
+  if (rc || !workspace) return rc;
+  return ws_fold(workspace, grad_params, dim, (hipStream_t)stream);
 }
 
 extern "C" int mke_attr_tail_z(float* z, const float* bias, int64_t n, int dim, double* sumsq_partials, void* stream) {
   using namespace mke;
   if (n < 0 || dim <= 0) { set_error("bad n/dim"); return MKE_E_SHAPE; }
-  if (!z || !bias || !sumsq_partials) { set_error("mke_attr_tail_z: NULL pointer"); return MKE_E_NULL; }
+  if (!z || !sumsq_partials) { set_error("mke_attr_tail_z: NULL pointer"); return MKE_E_NULL; }
   hipLaunchKernelGGL(k_attr_tail_z, dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, bias, n, dim,
                      sumsq_partials);
   return check_launch("k_attr_tail_z");
@@ -563,32 +630,28 @@ extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, 
 }
 
 extern "C" int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials,
-                                 int64_t n, int dim, void* stream) {
+                                 int64_t n, int dim, float* grad_bias, void* stream) {
   using namespace mke;
   if (n < 0 || dim <= 0) { set_error("bad n/dim"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
   if (!z || !gout || !sumsq_partials || !dot_partials) { set_error("mke_attr_tail_bwd: NULL pointer"); return MKE_E_NULL; }
-  hipLaunchKernelGGL(k_attr_tail_bwd, dim3(1024), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, gout, sumsq_partials,
+  int64_t blocks = (n * dim + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
+  blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 1024));
+  hipLaunchKernelGGL(k_attr_tail_bwd, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, gout, sumsq_partials,
                      dot_partials, n, dim);
-  return check_launch("k_attr_tail_bwd");
+  int rc = check_launch("k_attr_tail_bwd");
+  if (rc || !grad_bias) return rc;
+  hipLaunchKernelGGL(k_colsum_add, dim3(64), dim3(MKE_BLOCK), 0, (hipStream_t)stream, gout, n, dim, grad_bias);
+  return check_launch("k_colsum_add");
 }
 
 extern "C" int mke_dense_update(float* param, float* acc, float* grad, int64_t n, int optimizer, float lr, void* stream) {
-  using namespace mke;
-  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
-  if (n == 0) return MKE_OK;
-  if (!param || !grad) { set_error("mke_dense_update: NULL pointer"); return MKE_E_NULL; }
-  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
-  if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
-  int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, param, acc, grad, n,
-                     optimizer, lr);
-  return check_launch("k_dense_update");
+  return mke::dense_update_impl(param, acc, grad, n, optimizer, lr, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int64_t mke_attr_scratch_floats(int64_t n, int dim) {
   if (n < 0 || dim <= 0) return 0;
-  return n * (int64_t)dim * 10;  // flat n*4d | dflat n*4d | z n*d | gout n*d
+  return n * ((int64_t)dim * 10 + 4);  // flat n*(4d+4) | dflat n*4d | z n*d | gout n*d
 }
 
 extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
@@ -604,40 +667,47 @@ extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
   const int d = a->dim;
   const int64_t n = a->n;
   hipStream_t st = (hipStream_t)stream;
+  const int fs = 4 * d + 4;  // row stride of flat: column 4d is the constant 1 that carries the bias through the GEMMs
   float* flat = a->scratch;
-  float* dflat = flat + n * 4 * d;
+  float* dflat = flat + n * fs;
   float* z = dflat + n * 4 * d;
   float* gout = z + n * d;
   double* lossp = a->partials;
   double* ssq = a->partials + MKE_LOSS_PARTIALS;
   double* dot = a->partials + 2 * MKE_LOSS_PARTIALS;
   float* W = a->params + MKE_CNN_CONV_PARAMS(d);
-  float* bias = W + 4 * d * d;
-  float* gW = a->param_grads + MKE_CNN_CONV_PARAMS(d);
-  float* gbias = gW + 4 * d * d;
+  float* gW = a->param_grads + MKE_CNN_CONV_PARAMS(d);  // bias / its gradient are row 4d of W / gW (packed right behind)
   int rc;
   // forward: conv stack -> dense -> tanh -> batch-global normalisation -> loss
   if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
-                              a->params, flat, stream))) return rc;
-  if ((rc = launch_gemm_f32(flat, 4 * d, 1, W, d, 1, z, d, (int)n, d, 4 * d, 1, 0, st))) return rc;
-  if ((rc = mke_attr_tail_z(z, bias, n, d, ssq, stream))) return rc;
+                              a->params, flat, fs, stream))) return rc;
+  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st))) return rc;   // zpre = [flat, 1] [W; bias]
+  if ((rc = mke_attr_tail_z(z, nullptr, n, d, ssq, stream))) return rc;
   const bool upd = a->update != 0;
   if ((rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
   // backward
-  if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, stream))) return rc;   // gout = dL/dzpre
-  hipLaunchKernelGGL(k_colsum_add, dim3(128), dim3(MKE_BLOCK), 0, st, gout, n, d, gbias);
-  if ((rc = check_launch("k_colsum_add"))) return rc;
-  if ((rc = launch_gemm_f32(flat, 1, 4 * d, gout, d, 1, gW, d, 4 * d, d, (int)n, 32, 1, st))) return rc;   // dW = flat^T dz
+  if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre
+  if ((rc = launch_gemm_f32(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1, st))) return rc;   // [dW; dbias] = [flat, 1]^T dz
   if ((rc = launch_gemm_f32(gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st))) return rc;   // dflat = dz W^T
-  if ((rc = mke_attr_conv_bwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
-                              a->params, dflat, a->param_grads, a->attr_grad, a->attr_touched, a->tag, stream))) return rc;
+  {
+    if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
+    ConvParams p{};
+    p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
+    p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
+    p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
+    if ((rc = conv_dispatch(p, true, st))) return rc;
+  }
   if (upd) {
     if (a->ent_grad && (rc = mke_rows_update(a->ent_table, a->ent_acc, a->ent_grad, 1, a->ent_touched, a->tag, a->n_ent,
                                              a->ent_stride, d, a->ent_normalize, a->optimizer, a->lr, stream))) return rc;
     if (a->attr_grad && (rc = mke_rows_update(a->attr_table, a->attr_acc, a->attr_grad, 1, a->attr_touched, a->tag, a->n_attr,
                                               a->attr_stride, d, a->attr_normalize, a->optimizer, a->lr, stream))) return rc;
-    if ((rc = mke_dense_update(a->params, a->param_acc, a->param_grads, MKE_CNN_PARAMS(d), a->optimizer, a->lr, stream))) return rc;
+    // the dense update adds up the privatised copies of the conv / BN gradients itself
+    if ((rc = dense_update_impl(a->params, a->param_acc, a->param_grads, MKE_CNN_PARAMS(d), a->optimizer, a->lr, a->workspace,
+                                MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), st))) return rc;
+  } else if (a->workspace) {
+    if ((rc = ws_fold(a->workspace, a->param_grads, d, st))) return rc;
   }
   return MKE_OK;
 }

@@ -4,19 +4,20 @@ import sqlite3
 import sys
 
 
-def summarise(db, top=12):
+def summarise(db, top=12, by_grid=False):
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    q = (f"select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+    name = "s.kernel_name || ' grid ' || d.grid_size_x || 'x' || d.grid_size_y || 'x' || d.grid_size_z" if by_grid else "s.kernel_name"
+    q = (f"select {name}, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
          f"sum(d.end-d.start), max(s.arch_vgpr_count), max(s.sgpr_count) from {kd} d join {ks} s on d.kernel_id=s.id "
-         f"group by s.kernel_name order by 6 desc")
+         f"group by 1 order by 6 desc")
     rows = list(c.execute(q))
     tot = sum(r[5] for r in rows)
     out = ["| kernel | calls | avg us | min us | max us | % GPU time | vgpr | sgpr |", "|---|---|---|---|---|---|---|---|"]
     for r in rows[:top]:
-        out.append(f"| `{r[0][:80]}` | {r[1]} | {r[2] / 1e3:.2f} | {r[3] / 1e3:.2f} | {r[4] / 1e3:.2f} | "
+        out.append(f"| `{r[0][:80] if not by_grid else r[0][:60] + r[0][r[0].rindex(' grid '):]}` | {r[1]} | {r[2] / 1e3:.2f} | {r[3] / 1e3:.2f} | {r[4] / 1e3:.2f} | "
                    f"{100 * r[5] / tot:.1f} | {r[6]} | {r[7]} |")
     span = list(c.execute(f"select min(start), max(end) from {kd}"))[0]
     out.append("")
@@ -25,4 +26,4 @@ def summarise(db, top=12):
 
 
 if __name__ == "__main__":
-    print(summarise(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12))
+    print(summarise(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12, by_grid=len(sys.argv) > 3))
