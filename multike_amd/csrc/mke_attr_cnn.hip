@@ -369,10 +369,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_cnn_ws_fold(float* __restrict__ w
   if (i >= np) return;
   float v = 0.f;
 #pragma unroll 8
-  for (int c = 0; c < CNN_WS_COPIES; ++c) {
-    v += ws[(size_t)c * stride + i];
-    ws[(size_t)c * stride + i] = 0.f;
-  }
+  for (int c = 0; c < CNN_WS_COPIES; ++c) v += ws[(size_t)c * stride + i];
+  for (int c = 0; c < CNN_WS_COPIES; ++c) ws[(size_t)c * stride + i] = 0.f;
   gparams[i] += v;
 }
 
@@ -501,36 +499,21 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(float* __restrict__ w, float* __restrict__ acc, float* __restrict__ g,
-                                                            int64_t n, int optimizer, float lr, float* __restrict__ ws, int ws_n,
-                                                            int ws_stride) {
-  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    float gv = g[i];
-    if (ws && i < ws_n) {  // the first ws_n gradients also live in CNN_WS_COPIES privatised copies (k_attr_conv<.,true>)
-#pragma unroll 8
-      for (int c = 0; c < CNN_WS_COPIES; ++c) {
-        gv += ws[(size_t)c * ws_stride + i];
-        ws[(size_t)c * ws_stride + i] = 0.f;
-      }
-    }
-    g[i] = 0.f;
-    if (optimizer == MKE_OPT_ADAGRAD) {
-      const float a = fmaf(gv, gv, acc[i]);
-      acc[i] = a;
-      w[i] -= lr * gv / sqrtf(a);
-    } else {
-      w[i] -= lr * gv;
-    }
-  }
-}
+__global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(const DenseJob j) { dense_update_range(j, blockIdx.x, gridDim.x); }
 
 int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
-                    int M, int N, int K, int splits, int accumulate, hipStream_t st);
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials);
+int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
+                         int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
+                         const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,
+                         int acc1, hipStream_t st);
+int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
+                             float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   const int wpl = (p.dim + 63) / 64;
   int64_t blocks = (p.n + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096) blocks = 4096;  // one triple per wave up to 16K triples: no half-idle second pass
   if (blocks < 1) blocks = 1;
 #define MKE_CONV_CASE(W)                                                                                        \
   case W:                                                                                                       \
@@ -562,8 +545,8 @@ static int dense_update_impl(float* param, float* acc, float* grad, int64_t n, i
   if (optimizer == MKE_OPT_ADAGRAD && !acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
   int64_t blocks = (n + MKE_BLOCK - 1) / MKE_BLOCK;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, param, acc, grad, n, optimizer, lr, ws, ws_n,
-                     ws_stride);
+  DenseJob j{param, acc, grad, n, optimizer, lr, ws, ws_n, ws_stride, CNN_WS_COPIES};
+  hipLaunchKernelGGL(k_dense_update, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, j);
   return check_launch("k_dense_update");
 }
 
@@ -681,15 +664,16 @@ extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
   // forward: conv stack -> dense -> tanh -> batch-global normalisation -> loss
   if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
                               a->params, flat, fs, stream))) return rc;
-  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st))) return rc;   // zpre = [flat, 1] [W; bias]
-  if ((rc = mke_attr_tail_z(z, nullptr, n, d, ssq, stream))) return rc;
+  // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
+  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq))) return rc;
   const bool upd = a->update != 0;
   if ((rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
   // backward
   if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre
-  if ((rc = launch_gemm_f32(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1, st))) return rc;   // [dW; dbias] = [flat, 1]^T dz
-  if ((rc = launch_gemm_f32(gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st))) return rc;   // dflat = dz W^T
+  // [dW; dbias] = [flat, 1]^T dz (split-K, atomic)  and  dflat = dz W^T, one launch
+  if ((rc = launch_gemm_f32_pair(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1,
+                                 gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st))) return rc;
   {
     if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
     ConvParams p{};
@@ -699,13 +683,19 @@ extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
     if ((rc = conv_dispatch(p, true, st))) return rc;
   }
   if (upd) {
-    if (a->ent_grad && (rc = mke_rows_update(a->ent_table, a->ent_acc, a->ent_grad, 1, a->ent_touched, a->tag, a->n_ent,
-                                             a->ent_stride, d, a->ent_normalize, a->optimizer, a->lr, stream))) return rc;
-    if (a->attr_grad && (rc = mke_rows_update(a->attr_table, a->attr_acc, a->attr_grad, 1, a->attr_touched, a->tag, a->n_attr,
-                                              a->attr_stride, d, a->attr_normalize, a->optimizer, a->lr, stream))) return rc;
-    // the dense update adds up the privatised copies of the conv / BN gradients itself
-    if ((rc = dense_update_impl(a->params, a->param_acc, a->param_grads, MKE_CNN_PARAMS(d), a->optimizer, a->lr, a->workspace,
-                                MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), st))) return rc;
+    // one launch: entity rows, attribute rows, and (rider blocks) the dense update of the packed parameters, which also
+    // adds up the privatised copies of the conv / BN gradients
+    if (a->optimizer != MKE_OPT_ADAGRAD && a->optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", a->optimizer); return MKE_E_UNSUPPORTED; }
+    if (a->optimizer == MKE_OPT_ADAGRAD && (!a->param_acc || (a->ent_grad && !a->ent_acc) || (a->attr_grad && !a->attr_acc))) { set_error("mke_attr_step: Adagrad needs accumulators"); return MKE_E_NULL; }
+    if (a->ent_stride != a->attr_stride && a->ent_grad && a->attr_grad) { set_error("mke_attr_step: entity / attribute strides differ"); return MKE_E_SHAPE; }
+    mke_update_table tabs[2];
+    int nt = 0;
+    if (a->ent_grad) tabs[nt++] = mke_update_table{a->ent_table, a->ent_acc, a->ent_grad, a->ent_touched, a->n_ent, a->ent_normalize, 1, nullptr};
+    if (a->attr_grad) tabs[nt++] = mke_update_table{a->attr_table, a->attr_acc, a->attr_grad, a->attr_touched, a->n_attr, a->attr_normalize, 1, nullptr};
+    DenseJob dj{a->params, a->param_acc, a->param_grads, (int64_t)MKE_CNN_PARAMS(d), a->optimizer, a->lr, a->workspace,
+                MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), CNN_WS_COPIES};
+    if ((rc = launch_rows_update_multi(tabs, nt, a->tag, a->ent_grad ? a->ent_stride : a->attr_stride, d, a->optimizer, a->lr, st,
+                                       nullptr, &dj))) return rc;
   } else if (a->workspace) {
     if ((rc = ws_fold(a->workspace, a->param_grads, d, st))) return rc;
   }

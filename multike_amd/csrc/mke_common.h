@@ -98,6 +98,38 @@ __device__ __forceinline__ double block_sum_double(float v) {
   return tot;
 }
 
+// Dense Adagrad / SGD over n contiguous floats (the CNN's packed parameters), gradient consumed (zeroed).  The first
+// ws_n gradients may additionally live in ws_copies privatised copies (row stride ws_stride) left by k_attr_conv's
+// backward; they are added up and zeroed here.  Runs as its own kernel or as rider blocks of k_rows_update_multi.
+struct DenseJob {
+  float* w;
+  float* acc;
+  float* g;
+  int64_t n;
+  int optimizer;
+  float lr;
+  float* ws;
+  int ws_n, ws_stride, ws_copies;
+};
+__device__ __forceinline__ void dense_update_range(const DenseJob& j, int64_t block, int64_t n_blocks) {
+  for (int64_t i = block * MKE_BLOCK + threadIdx.x; i < j.n; i += n_blocks * MKE_BLOCK) {
+    float gv = j.g[i];
+    if (j.ws && i < j.ws_n) {  // all loads first (independent, in flight together), then the zeroing stores
+#pragma unroll 8
+      for (int c = 0; c < j.ws_copies; ++c) gv += j.ws[(size_t)c * j.ws_stride + i];
+      for (int c = 0; c < j.ws_copies; ++c) j.ws[(size_t)c * j.ws_stride + i] = 0.f;
+    }
+    j.g[i] = 0.f;
+    if (j.optimizer == MKE_OPT_ADAGRAD) {
+      const float a = fmaf(gv, gv, j.acc[i]);
+      j.acc[i] = a;
+      j.w[i] -= j.lr * gv / sqrtf(a);
+    } else {
+      j.w[i] -= j.lr * gv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG of the negative sampler.
 // ---------------------------------------------------------------------------------------------

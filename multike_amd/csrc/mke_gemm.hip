@@ -1,5 +1,4 @@
-// mke_gemm.hip — small dense f32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fma
-// chain), with arbitrary operand strides (so A^T / B^T need no copies) and optional split-K with atomic accumulation.
+// mke_gemm.hip — small dense f32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: plain f32 fma chains), with arbitrary operand strides (so A^T / B^T need no copies) and optional split-K with atomic accumulation.
 // It exists so that a whole attribute-view step (conv stack -> dense layer -> loss tail -> backward) can be enqueued by
 // ONE native call: the dense layer's three products are [n,4d]x[4d,d], [4d,n]x[n,d] and [n,d]x[d,4d] with n = 5000,
 // d = 75 — a few hundred MFLOP each, far below where a library call's launch + dispatch overhead is amortised.
@@ -24,6 +23,10 @@ struct GemmParams {
   int64_t ldc;
   int k_per_split;
   int atomic;  // != 0: C += (atomicAdd), else C = (only with a single split)
+  // epilogue (single split only): C = tanh(acc) and partials[block] = sum of C^2 over the block's tile; the blocks also
+  // zero partials[block + k * n_blocks] up to MKE_LOSS_PARTIALS so that a reader can add all of them up
+  double* partials;
+  int gx, gy, gz;  // this problem's grid (k_gemm_f32_batch decodes its linear block index with it)
 };
 
 #define GT 64
@@ -35,15 +38,18 @@ struct GemmParams {
 //   B n-contiguous (b_cs == 1):  (k, n) = (tid / 64 + e * 4,          tid % 64)     else  (tid % GK, tid / GK + e * (256 / GK))
 // Addresses are one 64-bit base per operand plus a constant step per element and per slab: 64-bit multiplies are
 // quarter rate on CDNA and, at GE of them per slab, were what the first version of this kernel spent its time on.
-__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32(const GemmParams p) {
+__device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, int bz) {
   constexpr int GE = GT * GK / MKE_BLOCK;
-  __shared__ float As[GT][GK + 1];
-  __shared__ float Bs[GK][GT + 1];
+  // both tiles k-contiguous with a 16-byte aligned row stride: a lane's operands for the 16 MFMAs of a slab are 16
+  // consecutive floats = 4 ds_read_b128 per operand, all issued before the first MFMA (the first version read one
+  // dword per operand per MFMA and, at one wave per SIMD, exposed the LDS latency 160 times per block)
+  __shared__ __attribute__((aligned(16))) float As[GT][GK + 4];
+  __shared__ __attribute__((aligned(16))) float Bt[GT][GK + 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const int k_lo = blockIdx.z * p.k_per_split;
+  const int m0 = by * GT, n0 = bx * GT;
+  const int k_lo = bz * p.k_per_split;
   const int k_hi = min(p.K, k_lo + p.k_per_split);
   const bool akf = p.a_cs == 1, bnf = p.b_cs == 1;
   const int a_m = akf ? tid / GK : tid % GT, a_k = akf ? tid % GK : tid / GT;
@@ -74,56 +80,120 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < GE; ++e) {
       As[a_m + e * a_dm][a_k + e * a_dk] = ra[e];
-      Bs[b_k + e * b_dk][b_n + e * b_dn] = rb[e];
+      Bt[b_n + e * b_dn][b_k + e * b_dk] = rb[e];
     }
     __syncthreads();
     if (k0 + GK < k_hi) fetch(k0 + GK);  // the next slab is in flight during the MFMAs below
-    const int kw = min(GK, k_hi - k0);
-    if (kw == GK) {
+    // lane (l31, half) feeds k = half * 16 + j at MFMA j: any assignment that covers the slab's 32 k exactly once is a
+    // valid K order; columns past the matrix / split edge are zero-filled, so short tail slabs need no special case
+    float4 av[GK / 8], bv[GK / 8];
 #pragma unroll
-      for (int kk = 0; kk < GK / 2; ++kk) {
-        const float a = As[wm * 32 + l31][2 * kk + half];
-        const float b = Bs[2 * kk + half][wn * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-    } else {
-      for (int kk = 0; kk < (kw + 1) / 2; ++kk) {  // short tail slab: the columns past kw are zero-filled
-        const float a = As[wm * 32 + l31][2 * kk + half];
-        const float b = Bs[2 * kk + half][wn * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
+    for (int q = 0; q < GK / 8; ++q) {
+      av[q] = *reinterpret_cast<const float4*>(&As[wm * 32 + l31][half * (GK / 2) + q * 4]);
+      bv[q] = *reinterpret_cast<const float4*>(&Bt[wn * 32 + l31][half * (GK / 2) + q * 4]);
+    }
+#pragma unroll
+    for (int q = 0; q < GK / 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
     }
     __syncthreads();
   }
   // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + l31;
+  float ssq = 0.f;
   if (col < p.N) {
     float* c = p.C + (int64_t)(m0 + wm * 32 + 4 * half) * p.ldc + col;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int dr = (reg & 3) + 8 * (reg >> 2);
       if (m0 + wm * 32 + 4 * half + dr < p.M) {
-        if (p.atomic) atomic_add_f32(c + dr * p.ldc, acc[reg]);
+        if (p.partials) {
+          const float v = tanhf(acc[reg]);
+          c[dr * p.ldc] = v;
+          ssq = fmaf(v, v, ssq);
+        } else if (p.atomic) atomic_add_f32(c + dr * p.ldc, acc[reg]);
         else c[dr * p.ldc] = acc[reg];
       }
     }
   }
+  if (p.partials) {  // block-uniform
+    const double tot = block_sum_double(ssq);
+    if (tid == 0) {
+      const int nb = p.gx * p.gy, b = by * p.gx + bx;
+      p.partials[b] = tot;
+      for (int k = b + nb; k < MKE_LOSS_PARTIALS; k += nb) p.partials[k] = 0.0;
+    }
+  }
 }
 
-int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
-                    int M, int N, int K, int splits, int accumulate, hipStream_t st) {
-  if (M <= 0 || N <= 0 || K <= 0) return MKE_OK;
-  if (splits < 1) splits = 1;
-  GemmParams p;
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32(const GemmParams p) { gemm_block(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// several independent products in one launch (one kernel floor instead of one per product, and their block counts add
+// up to fill the chip): block b belongs to the problem whose [first, first + gx*gy*gz) range contains it
+#define GEMM_BATCH_MAX 4
+struct GemmBatch {
+  GemmParams g[GEMM_BATCH_MAX];
+  int first[GEMM_BATCH_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32_batch(const GemmBatch b) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GEMM_BATCH_MAX; ++k)
+    if (k < b.n && (int)blockIdx.x >= b.first[k]) i = k;
+  const GemmParams& p = b.g[i];
+  int r = blockIdx.x - b.first[i];
+  const int bx = r % p.gx;
+  r /= p.gx;
+  gemm_block(p, bx, r % p.gy, r / p.gy);
+}
+
+static bool gemm_setup(GemmParams& p, const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
+                       int64_t ldc, int M, int N, int K, int splits, int accumulate, double* partials) {
+  if (M <= 0 || N <= 0 || K <= 0) return false;
+  if (splits < 1 || partials) splits = 1;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
   int kps = (K + splits - 1) / splits;
   kps = (kps + 3) / 4 * 4;
   p.k_per_split = kps;
   const int nz = (K + kps - 1) / kps;
   p.atomic = (accumulate || nz > 1) ? 1 : 0;
-  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, nz);
-  hipLaunchKernelGGL(k_gemm_f32, grid, dim3(MKE_BLOCK), 0, st, p);
+  p.partials = partials;
+  p.gx = (N + GT - 1) / GT; p.gy = (M + GT - 1) / GT; p.gz = nz;
+  return true;
+}
+
+int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials) {
+  GemmParams p;
+  if (!gemm_setup(p, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, M, N, K, splits, accumulate, tanh_sumsq_partials)) return MKE_OK;
+  if (tanh_sumsq_partials && p.gx * p.gy > MKE_LOSS_PARTIALS) { set_error("gemm epilogue: more than %d blocks", MKE_LOSS_PARTIALS); return MKE_E_SHAPE; }
+  hipLaunchKernelGGL(k_gemm_f32, dim3(p.gx, p.gy, p.gz), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_gemm_f32");
+}
+
+// two independent products in one launch (the attribute step's dW and dflat)
+int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
+                         int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
+                         const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,
+                         int acc1, hipStream_t st) {
+  GemmBatch b;
+  b.n = 0;
+  b.first[0] = 0;
+  if (gemm_setup(b.g[b.n], A0, a0_rs, a0_cs, B0, b0_rs, b0_cs, C0, ldc0, M0, N0, K0, splits0, acc0, nullptr)) {
+    b.first[b.n + 1] = b.first[b.n] + b.g[b.n].gx * b.g[b.n].gy * b.g[b.n].gz;
+    ++b.n;
+  }
+  if (gemm_setup(b.g[b.n], A1, a1_rs, a1_cs, B1, b1_rs, b1_cs, C1, ldc1, M1, N1, K1, splits1, acc1, nullptr)) {
+    b.first[b.n + 1] = b.first[b.n] + b.g[b.n].gx * b.g[b.n].gy * b.g[b.n].gz;
+    ++b.n;
+  }
+  if (b.n == 0) return MKE_OK;
+  hipLaunchKernelGGL(k_gemm_f32_batch, dim3(b.first[b.n]), dim3(MKE_BLOCK), 0, st, b);
+  return check_launch("k_gemm_f32_batch");
 }
 
 }  // namespace mke
@@ -138,5 +208,5 @@ extern "C" int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_
   if (ldc < N) { set_error("mke_gemm_f32: ldc < N"); return MKE_E_SHAPE; }
   if (splits > 1 && !accumulate) { set_error("mke_gemm_f32: split-K accumulates atomically: pass accumulate=1 and a zeroed (or to-be-added-to) C"); return MKE_E_SHAPE; }
   return launch_gemm_f32(A, a_row_stride, a_col_stride, B, b_row_stride, b_col_stride, C, ldc, M, N, K, splits, accumulate,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, nullptr);
 }

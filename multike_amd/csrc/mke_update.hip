@@ -120,11 +120,18 @@ struct MultiUpdateParams {
   // optional rider: reference counting of the next step in blocks [block_end[n_tables-1], gridDim.x)
   mke_count_job cj;
   int count_blocks;
+  // optional rider: dense parameter update in the blocks after those
+  DenseJob dj;
+  int dense_blocks;
 };
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
-  const int64_t upd_blocks = mp.block_end[mp.n_tables - 1];
+  const int64_t upd_blocks = mp.n_tables > 0 ? mp.block_end[mp.n_tables - 1] : 0;
+  if ((int64_t)blockIdx.x >= upd_blocks + mp.count_blocks) {  // rider blocks: dense parameter update
+    dense_update_range(mp.dj, (int64_t)blockIdx.x - upd_blocks - mp.count_blocks, mp.dense_blocks);
+    return;
+  }
   if ((int64_t)blockIdx.x >= upd_blocks) {  // rider blocks: count the next step's entity references
     const mke_count_job& c = mp.cj;
     const int64_t total = c.n_pos + c.n_neg;
@@ -157,10 +164,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
 static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : 16; }
 
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
-                             float lr, hipStream_t st, const mke_count_job* count = nullptr) {
+                             float lr, hipStream_t st, const mke_count_job* count = nullptr, const DenseJob* dense = nullptr) {
   MultiUpdateParams mp;
   mp.n_tables = n_tables;
   mp.count_blocks = 0;
+  mp.dense_blocks = 0;
+  mp.dj = DenseJob{};
   mp.cj = mke_count_job{};
   int64_t blocks = 0;
   for (int k = 0; k < n_tables; ++k) {
@@ -181,6 +190,13 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
     if (mp.cj.neg_per_pos < 1) mp.cj.neg_per_pos = 1;
     mp.count_blocks = (int)cb;
     blocks += cb;
+  }
+  if (dense && dense->n > 0) {
+    int64_t db = (dense->n + MKE_BLOCK - 1) / MKE_BLOCK;
+    if (db > 256) db = 256;
+    mp.dj = *dense;
+    mp.dense_blocks = (int)db;
+    blocks += db;
   }
   if (blocks == 0) return MKE_OK;
   const int fpl = stride / 16;
