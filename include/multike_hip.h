@@ -231,6 +231,15 @@ int mke_tripleset_query(
     const int32_t* h, const int32_t* r, const int32_t* t, int64_t n,
     const uint64_t* keys, uint64_t capacity, uint8_t* out, void* stream);
 
+/* random.sample(list, batch) for every step of an epoch in one launch -- the batching of the cross-KG inference and
+ * common-space loops (code/MultiKE_model.py:358,380,402,425,446: `batch` distinct list positions per step, steps
+ * independent).  out[s * batch + i] = pi_s(i), i < batch, s < n_steps, where pi_s is a keyed pseudo-random permutation of
+ * [0, n): 6-round Feistel network on the smallest domain 4^k >= n, cycle-walked into [0, n); round keys from
+ * Philox4x32-10(step, {0,1}, 0x5A4D504C, stream_id; seed).  Deterministic in (seed, stream_id, step, i);
+ * oracle/sampler_oracle.py:distinct_sample restates it. */
+int mke_sample_distinct(int64_t n, int batch, int n_steps, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                        int32_t* out /* [n_steps][batch] */, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (4) Loss ops over ALREADY GATHERED rows — the losses.py surface itself (forward + gradient w.r.t.
  *     every gathered row in one pass; rows are dense [n][ld] with ld >= dim, no padding rule).
@@ -324,6 +333,8 @@ typedef struct mke_relation_plan {
   int optimizer; float lr; float scale;
   double* loss_partials; int loss_ring;      /* device [loss_ring][MKE_LOSS_PARTIALS] */
   int32_t tag_base;
+  const float* pos_w;                        /* nullable: per-positive weights, epoch order like pos_* (weighted positives-only
+                                                loops, code/MultiKE_model.py:393-414); neg_per_pos == 0 runs positives only */
 } mke_relation_plan;
 
 int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);
@@ -423,6 +434,13 @@ typedef struct mke_attr_step_args {
 } mke_attr_step_args;
 int64_t mke_attr_scratch_floats(int64_t n, int dim);
 int mke_attr_step(const mke_attr_step_args* args, void* stream);
+/* n_steps consecutive mke_attr_step calls without a host round trip between them (the per-step loop of
+ * code/MultiKE_model.py:319-345,371-391,416-437 as one native call): step s uses positions [step_off[s], step_off[s+1])
+ * of args->ih / ia / iv / weights (epoch order), tag args->tag + s, and writes its loss partials to
+ * loss_ring[s % ring][MKE_LOSS_PARTIALS]; args->n is ignored, args->scratch must hold the largest step,
+ * args->partials is used as scratch.  step_off is a HOST array of n_steps + 1 offsets. */
+int mke_attr_steps(const mke_attr_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
+                   void* stream);
 
 /* dense Adagrad / SGD over n contiguous floats; grad is zeroed — tf.train.AdagradOptimizer on the CNN variables */
 int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,

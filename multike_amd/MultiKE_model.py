@@ -119,11 +119,13 @@ class _TripleList:
         self.w = (torch.as_tensor(np.asarray([t[3] for t in triples], dtype=np.float32), device=device)
                   if len(triples[0]) > 3 else None)
 
-    def sample(self, batch_size, gen):
-        """random.sample(list, batch_size): without replacement inside a batch (code/MultiKE_model.py:358)."""
-        idx = torch.randperm(self.n, generator=gen, device=self.device)[:batch_size]
-        cols = tuple(c[idx].contiguous() for c in self.cols)
-        return cols, (None if self.w is None else self.w[idx].contiguous())
+    def sample_epoch(self, batch_size, steps, seed, stream_id):
+        """`steps` x random.sample(list, batch_size) (code/MultiKE_model.py:358: distinct inside a step, steps
+        independent) in one sampler launch + one gather per column.  Returns (cols, w, idx) in epoch order."""
+        idx = _lib.sample_distinct(self.n, batch_size, steps, seed, stream_id, device=self.device).reshape(-1)
+        il = idx.long()
+        cols = tuple(c[il] for c in self.cols)
+        return cols, (None if self.w is None else self.w[il]), idx
 
 
 class MultiKE:
@@ -303,93 +305,113 @@ class MultiKE:
             self._attr_perm = [None, None]
         return self._attr1, self._attr2
 
+    def _attr_epoch_layout(self, n1, n2, b1, b2, steps):
+        """Epoch order of the attribute view: step s = [KG1 positions s*b1 .. , KG2 positions s*b2 ..] (code/base/batch.py
+        slicing, code/attr_batch.py).  -> (step_off host int64 [steps+1], dest1, dest2 device int64: where position p of
+        each KG's (shuffled) list lands in the concatenated epoch arrays)."""
+        key = (n1, n2, b1, b2, steps)
+        if getattr(self, "_attr_layout_key", None) != key:
+            c1 = np.clip(n1 - np.arange(steps) * b1, 0, b1) if b1 > 0 else np.zeros(steps, np.int64)
+            c2 = np.clip(n2 - np.arange(steps) * b2, 0, b2) if b2 > 0 else np.zeros(steps, np.int64)
+            off = np.zeros(steps + 1, dtype=np.int64)
+            off[1:] = np.cumsum(c1 + c2)
+            p1, p2 = np.arange(int(c1.sum())), np.arange(int(c2.sum()))
+            d1 = off[p1 // max(b1, 1)] + p1 % max(b1, 1) if len(p1) else p1
+            d2 = off[p2 // max(b2, 1)] + c1[p2 // max(b2, 1)] + p2 % max(b2, 1) if len(p2) else p2
+            self._attr_layout = (off, torch.as_tensor(d1, dtype=torch.int64, device=self.device),
+                                 torch.as_tensor(d2, dtype=torch.int64, device=self.device))
+            self._attr_layout_key = key
+        return self._attr_layout
+
     def train_attribute_view_1epo(self, epoch, triple_steps, steps_tasks, batch_queue, neighbors1, neighbors2):
-        """code/MultiKE_model.py:319-345: weighted positives only (neg_triples_num = 0, :331), CNN scorer."""
+        """code/MultiKE_model.py:319-345: weighted positives only (neg_triples_num = 0, :331), CNN scorer.  The epoch's
+        batches are laid out once on the device and all steps run inside one native call (`mke_attr_steps`)."""
         from .sampling import kg_batch_split
         start = time.time()
         l1, l2 = self._attr_lists()
         B = self.args.attribute_batch_size
         b1, b2 = kg_batch_split(l1.n, l2.n, B)
-        total = None
-        trained = 0
-        for step in range(triple_steps):
-            parts = []
-            for li, (lst, b) in enumerate(((l1, b1), (l2, b2))):
-                lo, hi = min(step * b, lst.n), min((step + 1) * b, lst.n)
-                if hi > lo:
-                    perm = self._attr_perm[li]
-                    sl = slice(lo, hi) if perm is None else perm[lo:hi]
-                    parts.append(tuple(c[sl] for c in lst.cols) + (lst.w[sl],))
-            if not parts:
-                continue
-            ih, ia, iv, w = (torch.cat([p[k] for p in parts]).contiguous() for k in range(4))
-            lp = self._attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds, ih, ia, iv, w,
-                                     scale=1.0, opt_name="attribute", lr=self.args.learning_rate,
-                                     optimizer=self.args.optimizer)
-            s = lp.sum()
-            total = s if total is None else total + s
-            trained += ih.numel()
-        epoch_loss = (float(total) if total is not None else 0.0) / max(trained, 1)
-        # random.shuffle of both weighted lists (:342-343): a device permutation applied at slicing time
+        off, d1, d2 = self._attr_epoch_layout(l1.n, l2.n, b1, b2, triple_steps)
+        total = int(off[-1])
+        epoch_loss = 0.0
+        if total > 0:
+            i32, f32 = torch.int32, torch.float32
+            cols = [torch.empty(total, dtype=i32, device=self.device) for _ in range(3)] + [torch.empty(total, dtype=f32, device=self.device)]
+            for li, (lst, dest) in enumerate(((l1, d1), (l2, d2))):
+                m = dest.numel()
+                if m == 0:
+                    continue
+                perm = self._attr_perm[li]
+                for k, src in enumerate(lst.cols + (lst.w,)):
+                    cols[k][dest] = src[:m] if perm is None else src[perm[:m]]
+            ring = self._attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds, cols[0], cols[1],
+                                        cols[2], cols[3], off, scale=1.0, opt_name="attribute", lr=self.args.learning_rate,
+                                        optimizer=self.args.optimizer)
+            epoch_loss = float(ring.sum()) / total
+        # random.shuffle of both weighted lists (:342-343): a device permutation applied when the epoch is laid out
         self._attr_perm = [torch.randperm(l.n, generator=self._gen, device=self.device) if l.n else None for l in (l1, l2)]
         print('epoch {} of att. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
         return epoch_loss
 
     # --- training for cross-kg identity inference ----------------------------------------------------------
-    def _positives_epoch(self, epoch, sup_triples, batch_size, step_fn, label):
+    def _next_sample_stream(self):
+        """(seed, stream id) of the next `mke_sample_distinct` launch: one stream id per call, in call order."""
+        self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+        return (int(getattr(self.args, "seed", 0)) & 0xFFFFFFFF, 0x4D4B45), self._sample_calls
+
+    def _positives_epoch(self, epoch, sup_triples, batch_size, run_fn, label):
         """Shared loop shape of code/MultiKE_model.py:349-437: steps = ceil(len / B); each step is
-        random.sample(sup_triples, B) (B = len if one step)."""
+        random.sample(sup_triples, B) (B = len if one step).  All steps of the epoch are sampled by one launch and run
+        inside one native call; `run_fn(cols, w, step_off)` returns the loss partials [steps, LOSS_PARTIALS]."""
         if len(sup_triples) == 0:
             return None
         start = time.time()
         lst = self._list(sup_triples)
         steps = int(math.ceil(lst.n / batch_size))
         bs = batch_size if steps > 1 else lst.n
-        total = None
-        for _ in range(steps):
-            cols, w = lst.sample(bs, self._gen)
-            s = step_fn(cols, w).sum()
-            total = s if total is None else total + s
-        epoch_loss = float(total) / (steps * bs)
+        seed, stream = self._next_sample_stream()
+        cols, w, idx = lst.sample_epoch(bs, steps, seed, stream)
+        self._last_sample = (seed, stream, lst.n, bs, steps)   # tests replay it with oracle.sampler_oracle.distinct_sample
+        ring = run_fn(cols, w, np.arange(steps + 1, dtype=np.int64) * bs)
+        epoch_loss = float(ring.sum()) / (steps * bs)
         print('epoch {} of {}, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, label, epoch_loss, time.time() - start))
         return epoch_loss
 
+    def _relation_positive_steps(self, g, cols, w, off):
+        from .runner import run_positive_steps
+        tag_base = self.engine.tag + 1
+        self.engine.tag += len(off) - 1
+        return run_positive_steps(self.rv_ent_embeds, self.rel_embeds, g["opt"], cols, w, off, tag_base,
+                                  lr=self.args.learning_rate, scale=g["scale"], optimizer=self.args.optimizer)
+
     def train_cross_kg_entity_inference_relation_view_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:349-369."""
-        g = self._ckge_rel
-        return self._positives_epoch(
-            epoch, sup_triples, self.args.batch_size,
-            lambda cols, w: self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, g["opt"], cols, None,
-                                                      lr=self.args.learning_rate, scale=g["scale"],
-                                                      optimizer=self.args.optimizer),
-            'cross-kg entity inference in rel. view')
+        return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
+                                     lambda cols, w, off: self._relation_positive_steps(self._ckge_rel, cols, None, off),
+                                     'cross-kg entity inference in rel. view')
 
     def train_cross_kg_entity_inference_attribute_view_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:371-391: 2 * sum log(1+exp(-conv))."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
-            lambda cols, w: self._ckge_attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
-                                                     cols[0], cols[1], cols[2], None, scale=2.0, opt_name="ckge_attr",
-                                                     lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            lambda cols, w, off: self._ckge_attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
+                                                           cols[0], cols[1], cols[2], None, off, scale=2.0, opt_name="ckge_attr",
+                                                           lr=self.args.learning_rate, optimizer=self.args.optimizer),
             'cross-kg entity inference in attr. view')
 
     def train_cross_kg_relation_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:393-414: weighted 4-tuples, x2."""
-        g = self._ckgp_rel
-        return self._positives_epoch(
-            epoch, sup_triples, self.args.batch_size,
-            lambda cols, w: self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, g["opt"], cols, None,
-                                                      lr=self.args.learning_rate, pos_w=w, scale=g["scale"],
-                                                      optimizer=self.args.optimizer),
-            'cross-kg relation inference in rel. view')
+        return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
+                                     lambda cols, w, off: self._relation_positive_steps(self._ckgp_rel, cols, w, off),
+                                     'cross-kg relation inference in rel. view')
 
     def train_cross_kg_attribute_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:416-437: weighted, not doubled."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
-            lambda cols, w: self._ckga_attr_cnn.step(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
-                                                     cols[0], cols[1], cols[2], w, scale=1.0, opt_name="ckga_attr",
-                                                     lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            lambda cols, w, off: self._ckga_attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
+                                                           cols[0], cols[1], cols[2], w, off, scale=1.0, opt_name="ckga_attr",
+                                                           lr=self.args.learning_rate, optimizer=self.args.optimizer),
             'cross-kg attribute inference in attr. view')
 
     # --- shared / common space ------------------------------------------------------------------------------
@@ -401,8 +423,11 @@ class MultiKE:
             self._lists[key] = t
         steps = int(math.ceil(len(entities) / batch_size))
         bs = batch_size if steps > 1 else len(entities)
-        for _ in range(steps):
-            yield t[torch.randperm(t.numel(), generator=self._gen, device=self.device)[:bs]].contiguous(), bs
+        seed, stream = self._next_sample_stream()
+        self._last_sample = (seed, stream, len(entities), bs, steps)
+        picked = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).long()]   # [steps, bs]
+        for s in range(steps):
+            yield picked[s], bs
 
     def train_shared_space_mapping_1epo(self, epoch, entities):
         """code/MultiKE_model.py:439-454 + graph :241-261 (SSL).  Three space_mapping_loss terms; the dense part is a

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -28,7 +29,8 @@ SYMBOLS = (
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
-    "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step",
+    "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
+    "mke_sample_distinct",
 )
 
 
@@ -75,7 +77,7 @@ class RelationPlanStruct(C.Structure):
         ("neg_h", C.c_void_p), ("neg_r", C.c_void_p), ("neg_t", C.c_void_p),
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("stream_id", C.c_uint32),
         ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float),
-        ("loss_partials", C.c_void_p), ("loss_ring", C.c_int), ("tag_base", C.c_int32),
+        ("loss_partials", C.c_void_p), ("loss_ring", C.c_int), ("tag_base", C.c_int32), ("pos_w", C.c_void_p),
     ]
 
 _lib = None
@@ -455,6 +457,24 @@ def gemm_f32(lhs, rhs, out, transpose_a=False, transpose_b=False, splits=1, accu
 
 def attr_scratch_floats(n: int, dim: int) -> int:
     return int(lib().mke_attr_scratch_floats(C.c_int64(n), C.c_int(dim)))
+
+
+def attr_steps(args: AttrStepArgs, step_off: np.ndarray, loss_ring: torch.Tensor):
+    """mke_attr_steps: `step_off` host int64 [n_steps + 1]; loss_ring float64 [ring, LOSS_PARTIALS] on the device."""
+    off = np.ascontiguousarray(step_off, dtype=np.int64)
+    rc = lib().mke_attr_steps(C.byref(args), off.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int(len(off) - 1),
+                              _dev(loss_ring, torch.float64, "loss_ring"), C.c_int(loss_ring.shape[0]), _stream())
+    _check(rc, "mke_attr_steps")
+
+
+def sample_distinct(n: int, batch: int, n_steps: int, seed=(0, 0), stream_id: int = 0, device="cuda") -> torch.Tensor:
+    """mke_sample_distinct -> int32 [n_steps, batch]: `batch` distinct positions of range(n) per step."""
+    out = torch.empty(n_steps, batch, dtype=torch.int32, device=device)
+    rc = lib().mke_sample_distinct(C.c_int64(n), C.c_int(batch), C.c_int(n_steps), C.c_uint32(seed[0] & 0xFFFFFFFF),
+                                   C.c_uint32(seed[1] & 0xFFFFFFFF), C.c_uint32(stream_id & 0xFFFFFFFF),
+                                   _dev(out, torch.int32, "out"), _stream())
+    _check(rc, "mke_sample_distinct")
+    return out
 
 
 def attr_step(args: AttrStepArgs):

@@ -74,21 +74,16 @@ class AttrCNN:
     def numpy_params(self) -> dict:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
 
-    # ------------------------------------------------------------------------------------------------
-    def step(self, eng, ent: EmbeddingTable, attr: EmbeddingTable, lit: EmbeddingTable, ih, ia, iv, weights=None,
-             scale: float = 1.0, opt_name: str = "attribute", lr: float = 0.001, optimizer: str = "Adagrad",
-             update: bool = True) -> torch.Tensor:
-        """loss + optimizer of one attribute-view graph:  scale * sum w * log(1 + exp(-conv(h, a, v))), as ONE native
-        call (`mke_attr_step`: conv stack, the dense layer's three products on the MFMA GEMM kernel, loss tail,
-        backward, row updates, dense update).  Returns the loss partials (`.sum()` is the loss).  With update=False the
-        gradients are left in `self.grads`, `ent.grad`, `attr.grad` for inspection."""
+    def _args(self, eng, ent, attr, lit, ih, ia, iv, weights, max_n, scale, opt_name, lr, optimizer, update, n_tags):
+        """Fill an mke_attr_step_args for a step (or a run of steps) of at most `max_n` triples; reserves n_tags tags."""
         if optimizer not in _OPT:
             raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
-        d, n = self.dim, int(ih.numel())
+        d, n = self.dim, int(max_n)
         need = _lib.attr_scratch_floats(n, d)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(max(need, 1), dtype=torch.float32, device=self.device)
         tag, _ = eng._next()
+        eng.tag += n_tags - 1
         part = self._partials[self._ring]
         self._ring = (self._ring + 1) % self._partials.shape[0]
         adagrad = optimizer == "Adagrad"
@@ -114,5 +109,31 @@ class AttrCNN:
         if self._workspace is None:
             self._workspace = torch.zeros(_lib.cnn_workspace_floats(d), dtype=torch.float32, device=self.device)
         a.workspace = _lib.ptr(self._workspace, f32, "workspace")
+        return a, part
+
+    def steps(self, eng, ent: EmbeddingTable, attr: EmbeddingTable, lit: EmbeddingTable, ih, ia, iv, weights, step_off,
+              scale: float = 1.0, opt_name: str = "attribute", lr: float = 0.001, optimizer: str = "Adagrad") -> torch.Tensor:
+        """`len(step_off) - 1` consecutive steps as ONE native call (`mke_attr_steps`): step s trains positions
+        [step_off[s], step_off[s+1]) of the epoch-ordered index arrays.  Returns the loss partials
+        [n_steps, LOSS_PARTIALS] (sum of row s = loss of step s)."""
+        off = np.ascontiguousarray(step_off, dtype=np.int64)
+        n_steps = len(off) - 1
+        ring = torch.zeros(max(1, n_steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
+        if n_steps <= 0:
+            return ring[:0]
+        a, _ = self._args(eng, ent, attr, lit, ih, ia, iv, weights, int(np.diff(off).max()), scale, opt_name, lr, optimizer,
+                          True, n_steps)
+        _lib.attr_steps(a, off, ring)
+        return ring
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, eng, ent: EmbeddingTable, attr: EmbeddingTable, lit: EmbeddingTable, ih, ia, iv, weights=None,
+             scale: float = 1.0, opt_name: str = "attribute", lr: float = 0.001, optimizer: str = "Adagrad",
+             update: bool = True) -> torch.Tensor:
+        """loss + optimizer of one attribute-view graph:  scale * sum w * log(1 + exp(-conv(h, a, v))), as ONE native
+        call (`mke_attr_step`: conv stack, the dense layer's three products on the MFMA GEMM kernel, loss tail,
+        backward, row updates, dense update).  Returns the loss partials (`.sum()` is the loss).  With update=False the
+        gradients are left in `self.grads`, `ent.grad`, `attr.grad` for inspection."""
+        a, part = self._args(eng, ent, attr, lit, ih, ia, iv, weights, int(ih.numel()), scale, opt_name, lr, optimizer, update, 1)
         _lib.attr_step(a)
         return part[:_lib.LOSS_PARTIALS]

@@ -637,13 +637,43 @@ extern "C" int64_t mke_attr_scratch_floats(int64_t n, int dim) {
   return n * ((int64_t)dim * 10 + 4);  // flat n*(4d+4) | dflat n*4d | z n*d | gout n*d
 }
 
+static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream);
+
 extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
+  if (!a) { mke::set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
+  if (!a->partials) { mke::set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
+  return attr_step_impl(a, a->partials, a->partials + MKE_LOSS_PARTIALS, a->partials + 2 * MKE_LOSS_PARTIALS, stream);
+}
+
+extern "C" int mke_attr_steps(const mke_attr_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
+                              void* stream) {
+  using namespace mke;
+  if (!args || !step_off || !loss_ring) { set_error("mke_attr_steps: NULL pointer"); return MKE_E_NULL; }
+  if (n_steps < 0 || ring < 1) { set_error("mke_attr_steps: bad n_steps/ring"); return MKE_E_SHAPE; }
+  if (!args->partials || !args->ih || !args->ia || !args->iv) { set_error("mke_attr_steps: NULL pointer in args"); return MKE_E_NULL; }
+  if ((int64_t)args->tag + n_steps >= 0x7FFFFFFFLL) { set_error("tag overflow"); return MKE_E_RANGE; }
+  for (int s = 0; s < n_steps; ++s) {
+    const int64_t lo = step_off[s], hi = step_off[s + 1];
+    if (lo < 0 || hi < lo) { set_error("mke_attr_steps: step_off must be non-decreasing"); return MKE_E_SHAPE; }
+    mke_attr_step_args a = *args;
+    a.ih += lo; a.ia += lo; a.iv += lo;
+    if (a.weights) a.weights += lo;
+    a.n = hi - lo;
+    a.tag = args->tag + s;
+    const int rc = attr_step_impl(&a, loss_ring + (int64_t)(s % ring) * MKE_LOSS_PARTIALS, args->partials + MKE_LOSS_PARTIALS,
+                                  args->partials + 2 * MKE_LOSS_PARTIALS, stream);
+    if (rc) return rc;
+  }
+  return MKE_OK;
+}
+
+static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream) {
   using namespace mke;
   if (!a) { set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
   if (a->n < 0 || a->dim <= 0) { set_error("mke_attr_step: bad n/dim"); return MKE_E_SHAPE; }
   if (!a->ent_table || !a->attr_table || !a->lit_table || !a->params || !a->param_grads || !a->scratch || !a->partials) { set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
   if (a->n == 0) {
-    hipError_t e = hipMemsetAsync(a->partials, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(lossp, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("mke_attr_step: memset failed"); return (int)e; }
     return MKE_OK;
   }
@@ -655,9 +685,6 @@ extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
   float* dflat = flat + n * fs;
   float* z = dflat + n * 4 * d;
   float* gout = z + n * d;
-  double* lossp = a->partials;
-  double* ssq = a->partials + MKE_LOSS_PARTIALS;
-  double* dot = a->partials + 2 * MKE_LOSS_PARTIALS;
   float* W = a->params + MKE_CNN_CONV_PARAMS(d);
   float* gW = a->param_grads + MKE_CNN_CONV_PARAMS(d);  // bias / its gradient are row 4d of W / gW (packed right behind)
   int rc;

@@ -75,7 +75,7 @@ static int run_overlapped(const mke_relation_plan* pl, int step_begin, int step_
     const int32_t tag = pl->tag_base + s;
     int32_t* refc = pl->ent_ref_count + (int64_t)b * pl->n_ent;
     RUN_MKE(mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
-                                       pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
+                                       pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
                                        pl->neg_h + no, pl->neg_r + no, pl->neg_t + no, nullptr, (hi - lo) * N, N, pl->scale,
                                        pl->ent_grad, pl->rel_grad, pl->rel_grad_copies, pl->ent_touched, pl->rel_touched, tag, refc,
                                        pl->ent_acc, pl->optimizer, pl->lr,
@@ -156,7 +156,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
     }
     counted_ahead = false;
     rc = mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
-                                    pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, nullptr, hi - lo,
+                                    pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
                                     N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
                                     nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies,
                                     pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,

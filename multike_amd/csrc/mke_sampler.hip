@@ -182,6 +182,46 @@ int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t*
   else hipLaunchKernelGGL((k_neg_sample<64>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_neg_sample");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// random.sample(list, batch) for every step of an epoch in one launch (code/MultiKE_model.py:358,380,402,425,446: the
+// cross-KG inference and common-space loops draw `batch` distinct list positions per step, independently per step).
+// out[s * batch + i] = pi_s(i), pi_s a keyed pseudo-random permutation of [0, n): a 6-round Feistel network over the
+// smallest even-width power-of-two domain >= n, cycle-walked back into [0, n) (Black & Rogaway 2002).  Distinct
+// inputs give distinct outputs by construction, so no dedupe pass and no n-sized shuffle per step is needed.
+// Round keys: Philox4x32-10 of (step, block 0/1, 0x5A4D504C, stream_id) under (seed_lo, seed_hi).
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t feistel_round_fn(uint32_t x, uint32_t key) {
+  x = x * 0x9E3779B1u + key;
+  x ^= x >> 15; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_sample_distinct(uint32_t n, int batch, int n_steps, uint32_t seed_lo, uint32_t seed_hi,
+                                                               uint32_t stream_id, int half_bits, int32_t* __restrict__ out) {
+  const int step = blockIdx.y;
+  const Philox4 ka = philox4x32_10((uint32_t)step, 0u, 0x5A4D504Cu, stream_id, seed_lo, seed_hi);
+  const Philox4 kb = philox4x32_10((uint32_t)step, 1u, 0x5A4D504Cu, stream_id, seed_lo, seed_hi);
+  const uint32_t keys[6] = {ka.v[0], ka.v[1], ka.v[2], ka.v[3], kb.v[0], kb.v[1]};
+  const uint32_t mask = (1u << half_bits) - 1u;
+  for (int i = blockIdx.x * MKE_BLOCK + threadIdx.x; i < batch; i += gridDim.x * MKE_BLOCK) {
+    uint32_t x = (uint32_t)i;
+    do {
+      uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const uint32_t t = l ^ (feistel_round_fn(r, keys[k]) & mask);
+        l = r;
+        r = t;
+      }
+      x = (l << half_bits) | r;
+    } while (x >= n);
+    out[(int64_t)step * batch + i] = (int32_t)x;
+  }
+}
+
 }  // namespace mke
 
 extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
@@ -229,4 +269,20 @@ extern "C" int mke_tripleset_query(const int32_t* h, const int32_t* r, const int
   hipLaunchKernelGGL(k_tripleset_query, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, h, r, t, n,
                      keys, capacity, out);
   return check_launch("k_tripleset_query");
+}
+
+extern "C" int mke_sample_distinct(int64_t n, int batch, int n_steps, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                                   int32_t* out, void* stream) {
+  using namespace mke;
+  if (n < 0 || batch < 0 || n_steps < 0 || n > 0x7FFFFFFFLL || (int64_t)batch > n) { set_error("mke_sample_distinct: need 0 <= batch <= n < 2^31 (n=%lld batch=%d)", (long long)n, batch); return MKE_E_SHAPE; }
+  if (batch == 0 || n_steps == 0) return MKE_OK;
+  if (!out) { set_error("mke_sample_distinct: NULL output"); return MKE_E_NULL; }
+  if (n_steps > 65535) { set_error("mke_sample_distinct: more than 65535 steps"); return MKE_E_SHAPE; }
+  int half = 1;
+  while ((1ll << (2 * half)) < n) ++half;   // domain 4^half >= n, < 4n
+  int bx = (batch + MKE_BLOCK - 1) / MKE_BLOCK;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(k_sample_distinct, dim3(bx, n_steps), dim3(MKE_BLOCK), 0, (hipStream_t)stream, (uint32_t)n, batch, n_steps, seed_lo,
+                     seed_hi, stream_id, half, out);
+  return check_launch("k_sample_distinct");
 }

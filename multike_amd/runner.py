@@ -173,3 +173,40 @@ class RelationViewRunner:
 
     def step_losses(self) -> torch.Tensor:
         return self.loss.sum(dim=1)
+
+
+def run_positive_steps(ent: EmbeddingTable, rel: EmbeddingTable, opt_name: str, cols, weights, step_off, tag_base: int,
+                       lr: float = 0.001, scale: float = 1.0, optimizer: str = "Adagrad") -> torch.Tensor:
+    """Positives-only relation-style steps (the cross-KG inference loops, code/MultiKE_model.py:349-369,393-414) as ONE
+    native call: step s scores positions [step_off[s], step_off[s+1]) of `cols` = (h, r, t) int32 (and `weights`),
+    then updates both tables; tag of step s = tag_base + s.  Returns the loss partials [n_steps, LOSS_PARTIALS]."""
+    if optimizer not in _OPT:
+        raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
+    if ent.stride != rel.stride or ent.dim != rel.dim:
+        raise _lib.MultiKEHipError("entity and relation tables must share dim/stride")
+    off = np.ascontiguousarray(step_off, dtype=np.int64)
+    steps = len(off) - 1
+    loss = torch.zeros(max(1, steps), _lib.LOSS_PARTIALS, dtype=torch.float64, device=ent.device)
+    if steps <= 0:
+        return loss[:0]
+    adagrad = optimizer == "Adagrad"
+    f32, i32 = torch.float32, torch.int32
+    p = _lib.RelationPlanStruct()
+    p.ent_table, p.n_ent, p.ent_normalize = _lib.ptr(ent.data, f32, "ent"), ent.n_rows, int(ent.normalize)
+    p.rel_table, p.n_rel, p.rel_normalize = _lib.ptr(rel.data, f32, "rel"), rel.n_rows, int(rel.normalize)
+    p.ent_acc = _lib.ptr(ent.slot(opt_name), f32, "acc") if adagrad else None
+    p.rel_acc = _lib.ptr(rel.slot(opt_name), f32, "acc") if adagrad else None
+    p.ent_grad, p.rel_grad, p.rel_grad_copies = _lib.ptr(ent.grad, f32, "g"), _lib.ptr(rel.grad, f32, "g"), rel.grad_copies
+    p.ent_touched, p.rel_touched = _lib.ptr(ent.touched, i32, "t"), _lib.ptr(rel.touched, i32, "t")
+    p.ent_ref_count, p.overlap, p.neg_chunk_capacity = None, 0, 0
+    p.stride, p.dim = ent.stride, ent.dim
+    p.pos_h, p.pos_r, p.pos_t = (_lib.ptr(c, i32, "pos") for c in cols)
+    p.pos_w = _lib.ptr(weights, f32, "pos_w") if weights is not None else None
+    p.pos_kg = None
+    p.step_off, p.n_steps = off.ctypes.data_as(C.POINTER(C.c_int64)), steps
+    p.neg_per_pos, p.max_try, p.sample_chunk, p.negatives_ready = 0, 0, 1, 0
+    p.neg_h = p.neg_r = p.neg_t = None
+    p.optimizer, p.lr, p.scale = _OPT[optimizer], lr, scale
+    p.loss_partials, p.loss_ring, p.tag_base = _lib.ptr(loss, torch.float64, "loss"), steps, tag_base
+    _lib.relation_steps(p, 0, steps)
+    return loss

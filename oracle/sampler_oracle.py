@@ -168,3 +168,41 @@ def philox_negatives(pos_h, pos_r, pos_t, want, n_all, ent_lo=0, ent_list=None, 
                 got += 1
         assert got == want
     return nh, nr, nt
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# random.sample(list, batch) per step as a keyed permutation (mke_sample_distinct).  The reference draws with
+# Python's `random.sample` (code/MultiKE_model.py:358,380,402,425,446); the property that matters -- `batch` DISTINCT
+# positions per step, steps independent, uniform -- is kept, the bit stream is this build's own (Philox-keyed Feistel
+# network with cycle walking), restated here for the bit-exact device test.
+# ----------------------------------------------------------------------------------------------------------------
+def distinct_sample(n, batch, n_steps, seed=(0, 0), stream_id=0):
+    """-> int32 [n_steps, batch]: out[s, i] = pi_s(i)."""
+    import numpy as np
+    assert 0 <= batch <= n < 2 ** 31
+    half = 1
+    while (1 << (2 * half)) < n:
+        half += 1
+    mask = (1 << half) - 1
+    out = np.zeros((n_steps, batch), dtype=np.int32)
+    for s in range(n_steps):
+        ka = philox4x32_10(s, 0, 0x5A4D504C, stream_id, seed[0], seed[1])
+        kb = philox4x32_10(s, 1, 0x5A4D504C, stream_id, seed[0], seed[1])
+        keys = [int(k) for k in (ka[0], ka[1], ka[2], ka[3], kb[0], kb[1])]
+        x = np.arange(batch, dtype=np.uint64)
+        todo = np.ones(batch, dtype=bool)
+        while todo.any():
+            l, r = x[todo] >> np.uint64(half), x[todo] & np.uint64(mask)
+            for k in keys:
+                f = r.copy()
+                f = (f * np.uint64(0x9E3779B1) + np.uint64(k)) & np.uint64(0xFFFFFFFF)
+                f ^= f >> np.uint64(15)
+                f = (f * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+                f ^= f >> np.uint64(13)
+                f = (f * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+                f ^= f >> np.uint64(16)
+                l, r = r, l ^ (f & np.uint64(mask))
+            x[todo] = (l << np.uint64(half)) | r
+            todo = x >= np.uint64(n)
+        out[s] = x.astype(np.int32)
+    return out

@@ -73,7 +73,7 @@ def test_itc_style_epochs_run_and_learn():
 
 
 def test_cross_kg_and_common_space_loops_match_oracle():
-    """Replays the device RNG to recover the batches the loops sampled, then checks losses and tables against the
+    """Replays the batch sampler to recover the batches the loops drew, then checks losses and tables against the
     float64 oracle: ckge_rel (x2), ckgp_rel (weighted, x2), common space (three alignment terms, ITC lr)."""
     m, data, args = _model()
     kgs, pam = data.kgs, data.predicate_align_model
@@ -85,13 +85,15 @@ def test_cross_kg_and_common_space_loops_match_oracle():
     E, R, ENT, AV = raw(m.rv_ent_embeds), raw(m.rel_embeds), raw(m.ent_embeds), raw(m.av_ent_embeds)
     NM = data.local_name_vectors.astype(np.float64)
     acc = lambda x: np.full_like(x, 0.1)
-    state = m._gen.get_state()
+    state = None
 
     def replay(n, bs, steps):
-        g = torch.Generator(device="cuda")
-        g.set_state(state)
-        out = [torch.randperm(n, generator=g, device="cuda")[:bs].cpu().numpy() for _ in range(steps)]
-        return out, g.get_state()
+        """The batches the loop just drew: its (seed, stream) through the sampler oracle (mke_sample_distinct is bit-exact
+        against it, tests/test_sampler_gpu.py)."""
+        from oracle.sampler_oracle import distinct_sample
+        seed, stream, n_, bs_, steps_ = m._last_sample
+        assert (n_, bs_, steps_) == (n, bs, steps)
+        return list(distinct_sample(n, bs, steps, seed, stream)), None
 
     # --- ckge_rel --------------------------------------------------------------------------------------
     got = m.train_cross_kg_entity_inference_relation_view_1epo(1, sup)

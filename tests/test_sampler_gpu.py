@@ -122,3 +122,30 @@ def test_argument_errors():
         sample_negatives(pos, KGSide(np.arange(5), None), 10)   # random.sample would raise ValueError
     with pytest.raises(_lib.MultiKEHipError, match="neg_per_pos"):
         sample_negatives(pos, KGSide(np.arange(500), None), 65)
+
+
+def test_sample_distinct_bit_exact_and_distinct():
+    """mke_sample_distinct (random.sample batching of the cross-KG / common-space loops) vs the oracle restatement,
+    plus the properties that define it: in range, distinct inside a step, a full permutation when batch == n,
+    steps differ, deterministic."""
+    from multike_amd import _lib
+    from oracle.sampler_oracle import distinct_sample
+    for n, b, steps, seed, stream in ((10, 10, 3, (1, 2), 3), (470_000, 5000, 5, (7, 0x4D4B45), 1), (7, 3, 5, (0, 0), 0),
+                                      (1, 1, 2, (5, 5), 9), (2 ** 20 + 1, 1000, 2, (123, 456), 77), (65_537, 4096, 3, (9, 9), 2)):
+        got = _lib.sample_distinct(n, b, steps, seed, stream).cpu().numpy()
+        want = distinct_sample(n, b, steps, seed, stream)
+        np.testing.assert_array_equal(got, want)
+        assert got.min() >= 0 and got.max() < n
+        assert all(len(set(row.tolist())) == b for row in got)
+        again = _lib.sample_distinct(n, b, steps, seed, stream).cpu().numpy()
+        np.testing.assert_array_equal(got, again)
+    full = _lib.sample_distinct(200_000, 200_000, 2, (3, 4), 5).cpu().numpy()
+    assert np.array_equal(np.sort(full[0]), np.arange(200_000)) and np.array_equal(np.sort(full[1]), np.arange(200_000))
+    assert (full[0] != full[1]).mean() > 0.99
+    # uniform: every position about equally likely over many steps (chi-square-ish bound)
+    many = _lib.sample_distinct(64, 8, 4000, (11, 12), 13).cpu().numpy()
+    cnt = np.bincount(many.ravel(), minlength=64)
+    assert abs(cnt - 500).max() < 5 * np.sqrt(500)
+    with pytest.raises(_lib.MultiKEHipError, match="batch <= n"):
+        _lib.sample_distinct(5, 6, 1)
+    assert _lib.sample_distinct(5, 0, 3).shape == (3, 0)
