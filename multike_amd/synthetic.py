@@ -153,12 +153,15 @@ _WORDS = ("amber basalt cedar delta ember fjord garnet harbor indigo jasper kest
 
 
 def write_dataset_folder(folder, n_pairs=60, n_extra=8, n_rel=6, n_attr=7, seed=11, division="631/", word_dim=300,
-                         triples_per_entity=3.0):
+                         triples_per_entity=3.0, shared_structure=0.0):
     """Writes rel_triples_{1,2}, attr_triples_{1,2}, entity_local_name_{1,2}, predicate_local_name_{1,2},
     <division>{train,valid,test}_links and a text word-vector file into `folder` (created).  Two KGs over `n_pairs`
     aligned entities (+ `n_extra` unaligned each) with partly matching predicate names, typed / language-tagged /
     multi-field literal values and a few rare attributes, so every branch of the readers is exercised.  Deterministic
-    in `seed`.  Returns the path of the word-vector file."""
+    in `seed`.  shared_structure = p > 0: KG2 is a noisy copy of KG1 -- each relation / attribute triple of KG1 is kept
+    with probability p (entity i <-> entity i, predicate j <-> predicate j) and the rest is random -- so that the
+    relation and attribute views have something to align on (p = 0: the two graphs are independent and only the names
+    carry signal).  Returns the path of the word-vector file."""
     import os
     rng = np.random.default_rng(seed)
     folder = folder if folder.endswith("/") else folder + "/"
@@ -186,16 +189,26 @@ def write_dataset_folder(folder, n_pairs=60, n_extra=8, n_rel=6, n_attr=7, seed=
         n_tri = int(n * triples_per_entity)
         with open(folder + f"rel_triples_{k}", "w", encoding="utf8") as f:
             seen = set()
+            if k == 2 and shared_structure > 0:
+                seen = {t for t in sorted(kg1_rel) if rng.random() < shared_structure}
             for i in range(n):                                           # every entity occurs at least once
                 t = (i, int(rng.integers(n_rel)), int((i + 1 + rng.integers(n - 1)) % n))
                 seen.add(t)
             while len(seen) < n_tri:
                 seen.add((int(rng.integers(n)), int(rng.integers(n_rel)), int(rng.integers(n))))
+            if k == 1:
+                kg1_rel = set(seen)
             for (h, r, t) in sorted(seen):
                 f.write(f"{ent(k, h)}\t{rels[r]}\t{ent(k, t)} \n" if (h + t) % 5 == 0 else f"{ent(k, h)}\t{rels[r]}\t{ent(k, t)}\n")
         with open(folder + f"attr_triples_{k}", "w", encoding="utf8") as f:
+            if k == 1:
+                kg1_attr = []
+            elif shared_structure > 0:
+                for (i, a, v) in kg1_attr:
+                    if rng.random() < shared_structure:
+                        f.write(f"{ent(k, i)}\t{attrs[a]}\t{v}\n")
             for i in range(n):
-                for _ in range(int(rng.integers(1, 5))):
+                for _ in range(int(rng.integers(1, 5)) if not (k == 2 and shared_structure > 0) else int(rng.integers(0, 2))):
                     a = int(rng.integers(n_attr - 1))                    # the last attribute stays rare (< 10 triples)
                     style = int(rng.integers(5))
                     w = rng.choice(len(_WORDS), size=2, replace=False)
@@ -210,6 +223,8 @@ def write_dataset_folder(folder, n_pairs=60, n_extra=8, n_rel=6, n_attr=7, seed=
                     else:
                         v = f'"{_WORDS[w[0]]}, {_WORDS[w[1]]}/zzunlisted{int(rng.integers(4))}" .'
                     f.write(f"{ent(k, i)}\t{attrs[a]}\t{v}\n")
+                    if k == 1:
+                        kg1_attr.append((i, a, v))
             f.write(f"{ent(k, 0)}\t{attrs[n_attr - 1]}\t\"rare value\"@en\n")
             f.write(f"{ent(k, 1)}\tshort line\n")
         with open(folder + f"entity_local_name_{k}", "w", encoding="utf8") as f:
