@@ -108,8 +108,11 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # a wedged collective must end the run with an error, not hold the node until the driver's limit
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
 
     from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
     from multike_amd.synthetic import SyntheticKGs

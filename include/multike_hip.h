@@ -217,6 +217,16 @@ int mke_neg_sample(
     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
     int32_t* neg_h, int32_t* neg_r, int32_t* neg_t,
     void* stream);
+/* Same, for positives that are NOT consecutive in the epoch order (a rank's share of every step of a sharded epoch,
+ * gathered into one array): pos_index[i] = epoch position of positive i (takes the place of i + pos_offset in the RNG
+ * counter), so a whole epoch of a rank's negatives is one launch and equals what per-step calls would have drawn. */
+int mke_neg_sample_at(
+    const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, const int32_t* pos_index,
+    const uint8_t* pos_kg /*nullable*/, const mke_kg_side* sides /* host, [2] */,
+    int neg_per_pos, int max_try,
+    uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+    int32_t* neg_h, int32_t* neg_r, int32_t* neg_t,
+    void* stream);
 
 /* Known-triple hash set.  key = h<<38 | t<<12 | r  (h,t < 2^26, r < 2^12); empty slot = ~0.
  * keys must be filled with 0xFF bytes by the caller before the first build call; capacity is a power

@@ -30,7 +30,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct",
+    "mke_sample_distinct", "mke_neg_sample_at",
 )
 
 
@@ -260,6 +260,19 @@ def neg_sample(pos, pos_offset, pos_kg, sides, neg_per_pos, max_try, seed, strea
         C.c_uint32(stream_id & 0xFFFFFFFF), _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"),
         _dev(nt, torch.int32, "neg_t"), _stream())
     _check(rc, "mke_neg_sample")
+
+
+def neg_sample_at(pos, pos_index, pos_kg, sides, neg_per_pos, max_try, seed, stream_id, neg_out):
+    """mke_neg_sample_at: like neg_sample, with an explicit int32 epoch position per positive."""
+    ph, pr, pt = pos
+    nh, nr, nt = neg_out
+    rc = lib().mke_neg_sample_at(
+        _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+        C.c_int64(ph.numel()), _dev(pos_index, torch.int32, "pos_index"), _dev(pos_kg, torch.uint8, "pos_kg"), sides,
+        C.c_int(neg_per_pos), C.c_int(max_try), C.c_uint32(seed[0] & 0xFFFFFFFF), C.c_uint32(seed[1] & 0xFFFFFFFF),
+        C.c_uint32(stream_id & 0xFFFFFFFF), _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"),
+        _dev(nt, torch.int32, "neg_t"), _stream())
+    _check(rc, "mke_neg_sample_at")
 
 
 def relation_steps(plan: RelationPlanStruct, step_begin: int, step_end: int):

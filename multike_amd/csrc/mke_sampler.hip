@@ -20,6 +20,7 @@ struct SampleParams {
   const int32_t* __restrict__ pt;
   const uint8_t* __restrict__ pos_kg;
   int64_t n_pos, pos_offset;
+  const int32_t* __restrict__ pos_index;  // nullable: epoch position of positive i (else pos_offset + i)
   int npp, max_try;
   mke_kg_side side[2];
   uint32_t seed_lo, seed_hi, sid;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) 
   const mke_kg_side& sd = p.side[kg];
   const uint32_t sid = p.sid + (uint32_t)kg;
   const uint64_t* __restrict__ keys = sd.known_keys;
-  const uint32_t gi = (uint32_t)(ii + p.pos_offset);
+  const uint32_t gi = p.pos_index ? (uint32_t)p.pos_index[ii] : (uint32_t)(ii + p.pos_offset);
   const int N = p.npp;
   const uint64_t gmask_all = GS == 64 ? ~0ull : (((1ull << (GS & 63)) - 1ull) << gbase);
   int collected = live ? 0 : N;
@@ -167,10 +168,11 @@ int validate_side(const mke_kg_side& sd, int neg_per_pos) {
 }
 
 int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, int64_t pos_offset,
+                      const int32_t* pos_index,
                       const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos, int max_try, uint32_t seed_lo,
                       uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h, int32_t* neg_r, int32_t* neg_t, hipStream_t st) {
   SampleParams p;
-  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.pos_kg = pos_kg; p.n_pos = n_pos; p.pos_offset = pos_offset;
+  p.ph = pos_h; p.pr = pos_r; p.pt = pos_t; p.pos_kg = pos_kg; p.n_pos = n_pos; p.pos_offset = pos_offset; p.pos_index = pos_index;
   p.npp = neg_per_pos; p.max_try = max_try;
   p.side[0] = sides[0];
   p.side[1] = pos_kg ? sides[1] : sides[0];
@@ -224,10 +226,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sample_distinct(uint32_t n, int b
 
 }  // namespace mke
 
-extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
-                              int64_t pos_offset, const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos,
-                              int max_try, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h,
-                              int32_t* neg_r, int32_t* neg_t, void* stream) {
+static int neg_sample_checked(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos, int64_t pos_offset,
+                              const int32_t* pos_index, const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos, int max_try,
+                              uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h, int32_t* neg_r, int32_t* neg_t,
+                              void* stream) {
   using namespace mke;
   if (n_pos < 0) { set_error("negative n_pos"); return MKE_E_SHAPE; }
   if (n_pos == 0 || neg_per_pos == 0) return MKE_OK;
@@ -238,8 +240,25 @@ extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const 
     const int rc = validate_side(sides[k], neg_per_pos);
     if (rc) return rc;
   }
-  return launch_neg_sample(pos_h, pos_r, pos_t, n_pos, pos_offset, pos_kg, sides, neg_per_pos, max_try, seed_lo, seed_hi,
+  return launch_neg_sample(pos_h, pos_r, pos_t, n_pos, pos_offset, pos_index, pos_kg, sides, neg_per_pos, max_try, seed_lo, seed_hi,
                            stream_id, neg_h, neg_r, neg_t, (hipStream_t)stream);
+}
+
+extern "C" int mke_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
+                              int64_t pos_offset, const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos,
+                              int max_try, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h,
+                              int32_t* neg_r, int32_t* neg_t, void* stream) {
+  return neg_sample_checked(pos_h, pos_r, pos_t, n_pos, pos_offset, nullptr, pos_kg, sides, neg_per_pos, max_try, seed_lo, seed_hi,
+                            stream_id, neg_h, neg_r, neg_t, stream);
+}
+
+extern "C" int mke_neg_sample_at(const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, int64_t n_pos,
+                                 const int32_t* pos_index, const uint8_t* pos_kg, const mke_kg_side* sides, int neg_per_pos,
+                                 int max_try, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id, int32_t* neg_h,
+                                 int32_t* neg_r, int32_t* neg_t, void* stream) {
+  if (n_pos > 0 && !pos_index) { mke::set_error("mke_neg_sample_at: NULL pos_index"); return MKE_E_NULL; }
+  return neg_sample_checked(pos_h, pos_r, pos_t, n_pos, 0, pos_index, pos_kg, sides, neg_per_pos, max_try, seed_lo, seed_hi,
+                            stream_id, neg_h, neg_r, neg_t, stream);
 }
 
 extern "C" int mke_tripleset_build(const int32_t* h, const int32_t* r, const int32_t* t, int64_t n, uint64_t* keys,

@@ -43,6 +43,10 @@ class HipBackend:
     def sample(self, pos, pos_offset, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
         _lib.neg_sample(pos, pos_offset, pos_kg, side_array(side1, side2), neg_per_pos, 10, seed, stream_id, out)
 
+    def sample_at(self, pos, pos_index, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
+        """Negatives of positives given by explicit epoch positions (a rank's share of a whole epoch): one launch."""
+        _lib.neg_sample_at(pos, pos_index, pos_kg, side_array(side1, side2), neg_per_pos, 10, seed, stream_id, out)
+
     def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
         _lib.rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity)
 
@@ -136,7 +140,15 @@ class ShardedRelationTrainer:
         self._nslot = nslot
         self._want2 = [torch.empty(G * C, **i32) for _ in range(nslot)]
         self._cidx2 = [[torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)] for _ in range(nslot)]
-        self._neg2 = [tuple(torch.empty(max_pos * neg_per_pos, **i32) for _ in range(3)) for _ in range(nslot)]
+        # this rank's share of every step of the epoch, as epoch positions: its negatives are sampled by ONE launch per
+        # epoch (a per-step sampler launch is latency-bound: 38 us for 5000 positives vs 3.5 us/step amortised)
+        sl = [self.my_slice(s) for s in range(self.steps)]
+        self._loc_off = np.zeros(self.steps + 1, dtype=np.int64)
+        self._loc_off[1:] = np.cumsum([e - a for a, e in sl])
+        idx = np.concatenate([np.arange(a, e, dtype=np.int32) for a, e in sl]) if self.steps else np.zeros(0, np.int32)
+        self._epoch_idx = torch.as_tensor(idx, device=dev)
+        self._neg_epoch = tuple(torch.empty(max(1, int(self._loc_off[-1]) * neg_per_pos), **i32) for _ in range(3))
+        self._neg_epoch_of = -1   # epoch whose negatives the buffers hold
         self._counts_last = torch.zeros(G, **i32)
         self.keep_stats = False  # tests switch this on (costs one tiny copy per step)
         self._cuda = self.device.type == "cuda" and self.lookahead > 0   # side-stream machinery only when pipelining
@@ -187,6 +199,10 @@ class ShardedRelationTrainer:
         a = min(hi, lo + self.rank * per)
         return a, min(hi, a + per)
 
+    def _step_neg(self, s: int):
+        lo, hi = int(self._loc_off[s]) * self.N, int(self._loc_off[s + 1]) * self.N
+        return tuple(x[lo:hi] for x in self._neg_epoch)
+
     def global_scored(self, i: int) -> int:
         s = i % self.steps
         return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
@@ -199,9 +215,13 @@ class ShardedRelationTrainer:
         a, e = self.my_slice(s)
         n_pos = e - a
         pos = (b.pos_h[a:e], b.pos_r[a:e], b.pos_t[a:e])
-        neg = tuple(x[:n_pos * N] for x in self._neg2[slot])
-        if n_pos and N:
-            be.sample(pos, a, b.pos_kg[a:e], b.side1, b.side2, N, b.rng_seed, b.rng_stream, neg)
+        if N and self._neg_epoch_of != i // self.steps:       # first plan of an epoch: sample the rank's whole share
+            il = self._epoch_idx.long()
+            if il.numel():
+                be.sample_at((b.pos_h[il], b.pos_r[il], b.pos_t[il]), self._epoch_idx, b.pos_kg[il], b.side1, b.side2, N,
+                             b.rng_seed, b.rng_stream, self._neg_epoch)
+            self._neg_epoch_of = i // self.steps
+        neg = self._step_neg(s)
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
         dist.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
@@ -247,7 +267,7 @@ class ShardedRelationTrainer:
         a, e = self.my_slice(s)
         n_pos = e - a
         pos_r = b.pos_r[a:e]
-        neg_r = self._neg2[slot][1][:n_pos * N]
+        neg_r = self._step_neg(s)[1]
         want = self._want2[slot]
         cidx = [self._cidx2[slot][k][:(n_pos if k < 2 else n_pos * N)] for k in range(4)]
         cur = torch.cuda.current_stream() if self._cuda else None

@@ -26,6 +26,22 @@ class OracleBackend:
                 for o, v in zip(out, (nh, nr, nt)):
                     o.numpy()[a * neg_per_pos:b * neg_per_pos] = v
 
+    def sample_at(self, pos, pos_index, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
+        """Explicit epoch positions: split into runs of consecutive positions (one per step slice) and sample each run
+        with the offset-based oracle -- the RNG is indexed by epoch position, so this is what one launch draws."""
+        import torch
+        idx = pos_index.numpy()
+        if len(idx) == 0:
+            return
+        kg = pos_kg.numpy().astype(np.int32)
+        brk = (np.diff(idx) != 1) | (np.diff(kg) < 0)          # position gap, or a new [KG1 | KG2] step begins
+        cuts = [0] + [int(k) + 1 for k in np.nonzero(brk)[0]] + [len(idx)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sub = tuple(torch.from_numpy(np.empty((b - a) * neg_per_pos, dtype=np.int32)) for _ in range(3))
+            self.sample(tuple(x[a:b] for x in pos), int(idx[a]), pos_kg[a:b], side1, side2, neg_per_pos, seed, stream_id, sub)
+            for o, v in zip(out, sub):
+                o.numpy()[a * neg_per_pos:b * neg_per_pos] = v.numpy()
+
     # ---- bookkeeping ops (numpy restatements of mke_rowset_build / _remap / mke_rows_gather_padded / _scatter_add) ----
     def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
         ids = np.concatenate([x.numpy() for x in streams])
