@@ -29,7 +29,6 @@ int check_launch(const char* what) {
 
 namespace mke {
 int g_score_splits = 0;
-int g_cnn_debug = 0;
 }
 
 extern "C" int mke_set_option(const char* name, int value, int* old_value) {
@@ -37,11 +36,6 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "score_splits")) {
     if (old_value) *old_value = mke::g_score_splits;
     mke::g_score_splits = value < 0 ? 0 : value;
-    return MKE_OK;
-  }
-  if (!strcmp(name, "cnn_debug")) {
-    if (old_value) *old_value = mke::g_cnn_debug;
-    mke::g_cnn_debug = value;
     return MKE_OK;
   }
   mke::set_error("mke_set_option: unknown option '%s'", name);
