@@ -50,6 +50,8 @@ extern "C" {
 /* optimizer kinds for mke_rows_update — code/MultiKE_model.py:15-25 get_optimizer */
 #define MKE_OPT_ADAGRAD 0 /* tf.train.AdagradOptimizer: acc += g*g; w -= lr*g/sqrt(acc); acc0 = 0.1, no eps */
 #define MKE_OPT_SGD 1     /* tf.train.GradientDescentOptimizer: w -= lr*g */
+#define MKE_OPT_ADAM 2     /* tf.train.AdamOptimizer     -- dense entry points only (mke_rows_update_dense, mke_dense_update_opt) */
+#define MKE_OPT_ADADELTA 3 /* tf.train.AdadeltaOptimizer -- dense entry points only */
 
 int mke_version(void);
 const char* mke_last_error(void);
@@ -451,6 +453,22 @@ int mke_attr_step(const mke_attr_step_args* args, void* stream);
  * args->partials is used as scratch.  step_off is a HOST array of n_steps + 1 offsets. */
 int mke_attr_steps(const mke_attr_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
                    void* stream);
+
+/* Adam / Adadelta (selectable through args.optimizer, code/MultiKE_model.py:15-25; TF1 defaults beta1 0.9, beta2 0.999,
+ * epsilon 1e-8, rho 0.95).  These rules move weights whose gradient is zero, and TF applies them to the whole variable
+ * (the gradient through tf.nn.l2_normalize(table, 1) is dense), so both entry points stream EVERY element: grad (consumed =
+ * zeroed), the parameter and two slot arrays of the same layout -- Adam: slot1 = m, slot2 = v (both start at 0), `step` =
+ * 1, 2, ... the number of this update;  Adadelta: slot1 = accum, slot2 = accum_update (both start at 0).  The row form
+ * applies the l2_normalize Jacobian first when `normalize` is set, exactly as mke_rows_update does. */
+typedef struct mke_optimizer {
+  int kind;          /* MKE_OPT_ADAM | MKE_OPT_ADADELTA */
+  float lr, beta1, beta2, epsilon, rho;
+  int64_t step;      /* Adam bias correction */
+} mke_optimizer;
+int mke_rows_update_dense(float* table, float* slot1, float* slot2, float* grad, int64_t n_rows, int stride, int dim,
+                          int normalize, const mke_optimizer* opt, void* stream);
+int mke_dense_update_opt(float* param, float* slot1, float* slot2, float* grad, int64_t n, const mke_optimizer* opt,
+                         void* stream);
 
 /* dense Adagrad / SGD over n contiguous floats; grad is zeroed — tf.train.AdagradOptimizer on the CNN variables */
 int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,

@@ -27,7 +27,8 @@ from .sampling import KGSide, KnownTripleSet, RelationBatcher
 from .tables import ADAGRAD_INIT_ACC, EmbeddingTable, StepEngine
 from .utils import generate_out_folder, save_embeddings
 
-_HIP_OPTS = ("Adagrad", "SGD")
+_HIP_OPTS = ("Adagrad", "SGD")            # touched-rows rules: fused / native multi-step paths
+_DENSE_OPTS = tuple(_lib.DENSE_OPTS)        # Adam, Adadelta: whole-variable kernels, step-wise loops
 
 
 class Optimizer:
@@ -38,8 +39,8 @@ class Optimizer:
 
 
 def get_optimizer(opt, learning_rate):
-    """code/MultiKE_model.py:15-25.  Adagrad (the reference's default, code/args.json:18) and SGD run on the HIP path;
-    Adadelta / Adam are accepted by name but not implemented (they are not touched-rows-equivalent)."""
+    """code/MultiKE_model.py:15-25.  Adagrad (the reference's default, code/args.json:18) and SGD run on the fused
+    touched-rows paths; Adadelta / Adam move zero-gradient weights too and run on whole-variable kernels."""
     if opt in ("Adagrad", "Adadelta", "Adam"):
         return Optimizer(opt, learning_rate)
     return Optimizer("SGD", learning_rate)
@@ -52,16 +53,31 @@ class DenseOptimizerState:
     def __init__(self, var_list, learning_rate, opt="SGD"):
         self.vars = list(var_list)
         self.opt = get_optimizer(opt, learning_rate)
-        if self.opt.kind not in _HIP_OPTS:
-            raise _lib.MultiKEHipError(f"optimizer {self.opt.kind!r} not supported (Adagrad, SGD)")
         self.acc = [torch.full_like(v, ADAGRAD_INIT_ACC) for v in self.vars]
+        self.s1 = [torch.zeros_like(v) for v in self.vars] if self.opt.kind in _DENSE_OPTS else None
+        self.s2 = [torch.zeros_like(v) for v in self.vars] if self.opt.kind in _DENSE_OPTS else None
+        self.step = 0
 
     @torch.no_grad()
     def apply(self, grads):
-        for v, a, g in zip(self.vars, self.acc, grads):
+        self.step += 1
+        lr = self.opt.learning_rate
+        for i, (v, a, g) in enumerate(zip(self.vars, self.acc, grads)):
             if g is None:
                 continue
-            if self.opt.kind == "Adagrad":
+            if self.opt.kind == "Adam":        # TF1 ApplyAdam, defaults
+                m, vv = self.s1[i], self.s2[i]
+                m.mul_(0.9).add_(g, alpha=0.1)
+                vv.mul_(0.999).add_(g * g, alpha=0.001)
+                lr_t = lr * math.sqrt(1.0 - 0.999 ** self.step) / (1.0 - 0.9 ** self.step)
+                v.sub_(lr_t * m / (torch.sqrt(vv) + 1e-8))
+            elif self.opt.kind == "Adadelta":  # TF1 ApplyAdadelta, defaults
+                acc, upd = self.s1[i], self.s2[i]
+                acc.mul_(0.95).add_(g * g, alpha=0.05)
+                u = torch.sqrt(upd + 1e-8) / torch.sqrt(acc + 1e-8) * g
+                v.sub_(lr * u)
+                upd.mul_(0.95).add_(u * u, alpha=0.05)
+            elif self.opt.kind == "Adagrad":
                 a.add_(g * g)
                 v.sub_(self.opt.learning_rate * g / torch.sqrt(a))
             else:
@@ -148,8 +164,8 @@ class MultiKE:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._lists: dict = {}
-        if self.args.optimizer not in _HIP_OPTS:
-            raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: only Adagrad and SGD run on the HIP path")
+        if self.args.optimizer not in _HIP_OPTS + _DENSE_OPTS:
+            raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: Adagrad, SGD, Adam or Adadelta")
 
     # ------------------------------------------------------------------------------------------------
     def _define_variables(self):
@@ -193,8 +209,9 @@ class MultiKE:
         self._rel_batcher = RelationBatcher(self.kg1.local_relation_triples_list, self.kg2.local_relation_triples_list,
                                             sides[0], sides[1], self.args.batch_size, self.args.neg_triple_num, device=dev,
                                             seed=int(getattr(self.args, "seed", 0)))
-        self._rel_runner = RelationViewRunner(self.rv_ent_embeds, self.rel_embeds, self._rel_batcher, "relation",
-                                              lr=self.args.learning_rate, optimizer=self.args.optimizer)
+        self._rel_runner = (RelationViewRunner(self.rv_ent_embeds, self.rel_embeds, self._rel_batcher, "relation",
+                                               lr=self.args.learning_rate, optimizer=self.args.optimizer)
+                            if self.args.optimizer not in _DENSE_OPTS else None)
         self._neighbor_ids = (None, None)
 
     def _define_attribute_view_graph(self):
@@ -286,11 +303,24 @@ class MultiKE:
         are produced and consumed on the device by the native step runner."""
         start = time.time()
         self._set_neighbours(neighbors1, neighbors2)
-        run = self._rel_runner
-        steps = min(triple_steps, run.steps)
-        run.run(0, steps)
-        trained = int(self._rel_batcher.off[steps])
-        epoch_loss = float(run.loss[:steps].sum()) / max(trained, 1)
+        run, b = self._rel_runner, self._rel_batcher
+        steps = min(triple_steps, b.steps)
+        trained = int(b.off[steps])
+        if run is not None:
+            run.run(0, steps)
+            epoch_loss = float(run.loss[:steps].sum()) / max(trained, 1)
+        else:   # Adam / Adadelta: step-wise (sampler launch -> fused score/gradient -> whole-table updates)
+            from .sampling import sample_negatives
+            N, total = b.neg_per_pos, None
+            for s_ in range(steps):
+                lo, hi = int(b.off[s_]), int(b.off[s_ + 1])
+                pos = (b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi])
+                neg = sample_negatives(pos, b.side1, N, seed=b.rng_seed, stream_id=b.rng_stream, pos_offset=lo, side1=b.side2,
+                                       pos_kg=b.pos_kg[lo:hi]) if N else None
+                lp = self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, "relation", pos, neg, N,
+                                               lr=self.args.learning_rate, optimizer=self.args.optimizer).sum()
+                total = lp if total is None else total + lp
+            epoch_loss = (float(total) if total is not None else 0.0) / max(trained, 1)
         self._rel_batcher.shuffle()  # random.shuffle of both positive lists (:314-315)
         print('epoch {} of rel. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
         return epoch_loss
@@ -344,9 +374,7 @@ class MultiKE:
                 perm = self._attr_perm[li]
                 for k, src in enumerate(lst.cols + (lst.w,)):
                     cols[k][dest] = src[:m] if perm is None else src[perm[:m]]
-            ring = self._attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds, cols[0], cols[1],
-                                        cols[2], cols[3], off, scale=1.0, opt_name="attribute", lr=self.args.learning_rate,
-                                        optimizer=self.args.optimizer)
+            ring = self._run_attr_steps(self._attr_cnn, cols[:3], cols[3], off, 1.0, "attribute")
             epoch_loss = float(ring.sum()) / total
         # random.shuffle of both weighted lists (:342-343): a device permutation applied when the epoch is laid out
         self._attr_perm = [torch.randperm(l.n, generator=self._gen, device=self.device) if l.n else None for l in (l1, l2)]
@@ -377,7 +405,29 @@ class MultiKE:
         print('epoch {} of {}, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, label, epoch_loss, time.time() - start))
         return epoch_loss
 
+    def _run_attr_steps(self, cnn, cols, w, off, scale, opt_name):
+        """All steps of an attribute-type epoch: one native call (Adagrad / SGD) or a step-wise loop (Adam / Adadelta)."""
+        a = self.args
+        tabs = (self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds)
+        if a.optimizer not in _DENSE_OPTS:
+            return cnn.steps(*tabs, cols[0], cols[1], cols[2], w, off, scale=scale, opt_name=opt_name, lr=a.learning_rate,
+                             optimizer=a.optimizer)
+        parts = []
+        for s_ in range(len(off) - 1):
+            lo, hi = int(off[s_]), int(off[s_ + 1])
+            parts.append(cnn.step(*tabs, cols[0][lo:hi], cols[1][lo:hi], cols[2][lo:hi], None if w is None else w[lo:hi],
+                                  scale=scale, opt_name=opt_name, lr=a.learning_rate, optimizer=a.optimizer).sum())
+        return torch.stack(parts) if parts else torch.zeros(0, dtype=torch.float64, device=self.device)
+
     def _relation_positive_steps(self, g, cols, w, off):
+        if self.args.optimizer in _DENSE_OPTS:
+            parts = []
+            for s_ in range(len(off) - 1):
+                lo, hi = int(off[s_]), int(off[s_ + 1])
+                parts.append(self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, g["opt"], tuple(c[lo:hi] for c in cols),
+                                                       None, lr=self.args.learning_rate, pos_w=None if w is None else w[lo:hi],
+                                                       scale=g["scale"], optimizer=self.args.optimizer).sum())
+            return torch.stack(parts) if parts else torch.zeros(0, dtype=torch.float64, device=self.device)
         from .runner import run_positive_steps
         tag_base = self.engine.tag + 1
         self.engine.tag += len(off) - 1
@@ -394,9 +444,7 @@ class MultiKE:
         """code/MultiKE_model.py:371-391: 2 * sum log(1+exp(-conv))."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
-            lambda cols, w, off: self._ckge_attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
-                                                           cols[0], cols[1], cols[2], None, off, scale=2.0, opt_name="ckge_attr",
-                                                           lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            lambda cols, w, off: self._run_attr_steps(self._ckge_attr_cnn, cols, None, off, 2.0, "ckge_attr"),
             'cross-kg entity inference in attr. view')
 
     def train_cross_kg_relation_inference_1epo(self, epoch, sup_triples):
@@ -409,9 +457,7 @@ class MultiKE:
         """code/MultiKE_model.py:416-437: weighted, not doubled."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
-            lambda cols, w, off: self._ckga_attr_cnn.steps(self.engine, self.av_ent_embeds, self.attr_embeds, self.literal_embeds,
-                                                           cols[0], cols[1], cols[2], w, off, scale=1.0, opt_name="ckga_attr",
-                                                           lr=self.args.learning_rate, optimizer=self.args.optimizer),
+            lambda cols, w, off: self._run_attr_steps(self._ckga_attr_cnn, cols, w, off, 1.0, "ckga_attr"),
             'cross-kg attribute inference in attr. view')
 
     # --- shared / common space ------------------------------------------------------------------------------

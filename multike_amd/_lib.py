@@ -18,7 +18,8 @@ SO_PATH = os.path.join(_HERE, "libmultike_hip.so")
 
 LOSS_PARTIALS = 2048  # MKE_LOSS_PARTIALS
 MAX_STRIDE = 320  # MKE_MAX_STRIDE
-OPT_ADAGRAD, OPT_SGD = 0, 1
+OPT_ADAGRAD, OPT_SGD, OPT_ADAM, OPT_ADADELTA = 0, 1, 2, 3
+DENSE_OPTS = {"Adam": OPT_ADAM, "Adadelta": OPT_ADADELTA}   # TF1 rules that move zero-gradient weights: whole-variable kernels
 _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
@@ -30,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt",
 )
 
 
@@ -47,6 +48,16 @@ class AttrStepArgs(C.Structure):
         ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
         ("update", C.c_int), ("workspace", C.c_void_p),
     ]
+
+
+class OptimizerStruct(C.Structure):
+    """mke_optimizer (TF1 defaults)"""
+    _fields_ = [("kind", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+                ("rho", C.c_float), ("step", C.c_int64)]
+
+
+def optimizer_struct(name: str, lr: float, step: int = 1) -> OptimizerStruct:
+    return OptimizerStruct(DENSE_OPTS[name], float(lr), 0.9, 0.999, 1e-8, 0.95, int(step))
 
 
 class KGSideStruct(C.Structure):
@@ -466,6 +477,23 @@ def gemm_f32(lhs, rhs, out, transpose_a=False, transpose_b=False, splits=1, accu
                             C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
                             C.c_int(splits), C.c_int(int(accumulate)), _stream())
     _check(rc, "mke_gemm_f32")
+
+
+def rows_update_dense(table, slot1, slot2, grad, dim, normalize, opt: OptimizerStruct):
+    """mke_rows_update_dense: Adam / Adadelta over EVERY row of the table (grad consumed)."""
+    rc = lib().mke_rows_update_dense(_dev(table, torch.float32, "table"), _dev(slot1, torch.float32, "slot1"),
+                                     _dev(slot2, torch.float32, "slot2"), _dev(grad, torch.float32, "grad"),
+                                     C.c_int64(table.shape[0]), C.c_int(table.shape[1]), C.c_int(dim), C.c_int(int(normalize)),
+                                     C.byref(opt), _stream())
+    _check(rc, "mke_rows_update_dense")
+
+
+def dense_update_opt(param, slot1, slot2, grad, opt: OptimizerStruct):
+    """mke_dense_update_opt: Adam / Adadelta over a flat parameter buffer (grad consumed)."""
+    rc = lib().mke_dense_update_opt(_dev(param, torch.float32, "param"), _dev(slot1, torch.float32, "slot1"),
+                                    _dev(slot2, torch.float32, "slot2"), _dev(grad, torch.float32, "grad"),
+                                    C.c_int64(param.numel()), C.byref(opt), _stream())
+    _check(rc, "mke_dense_update_opt")
 
 
 def attr_scratch_floats(n: int, dim: int) -> int:

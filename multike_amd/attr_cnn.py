@@ -29,6 +29,7 @@ class AttrCNN:
         self.grads = torch.zeros_like(self.params)
         self.slots: dict[str, torch.Tensor] = {}
         self._scratch = None
+        self._dense = {}         # optimizer name -> [slot1, slot2, step] of an Adam / Adadelta instance
         self._workspace = None   # zero-invariant reduction workspace of mke_attr_conv_bwd
         self._partials = torch.zeros(8, 3 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
         self._ring = 0
@@ -134,6 +135,18 @@ class AttrCNN:
         call (`mke_attr_step`: conv stack, the dense layer's three products on the MFMA GEMM kernel, loss tail,
         backward, row updates, dense update).  Returns the loss partials (`.sum()` is the loss).  With update=False the
         gradients are left in `self.grads`, `ent.grad`, `attr.grad` for inspection."""
+        if optimizer in _lib.DENSE_OPTS and update:
+            # Adam / Adadelta move every weight: run the fused forward + backward without its (touched-rows) update,
+            # then the whole-variable kernels over both tables and the packed parameters
+            a, part = self._args(eng, ent, attr, lit, ih, ia, iv, weights, int(ih.numel()), scale, opt_name, lr, "SGD", False, 1)
+            _lib.attr_step(a)
+            for tb in (ent, attr):
+                if tb.trainable:
+                    eng._apply(tb, opt_name, optimizer, lr, a.tag)
+            st = self._dense.setdefault(opt_name, [torch.zeros_like(self.params), torch.zeros_like(self.params), 0])
+            st[2] += 1
+            _lib.dense_update_opt(self.params, st[0], st[1], self.grads, _lib.optimizer_struct(optimizer, lr, st[2]))
+            return part[:_lib.LOSS_PARTIALS]
         a, part = self._args(eng, ent, attr, lit, ih, ia, iv, weights, int(ih.numel()), scale, opt_name, lr, optimizer, update, 1)
         _lib.attr_step(a)
         return part[:_lib.LOSS_PARTIALS]

@@ -35,8 +35,8 @@ class AutoEncoderModel:
             n = np.linalg.norm(x, axis=1, keepdims=True)
             x = x / np.where(n == 0, 1.0, n)
         self.word_vec_list = torch.as_tensor(x, device=self.device)
-        if self.args.optimizer not in _OPT:
-            raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: only Adagrad and SGD are built")
+        if self.args.optimizer not in _OPT and self.args.optimizer not in _lib.DENSE_OPTS:
+            raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: Adagrad, SGD, Adam or Adadelta")
         self._init_graph(seed)
 
     def _init_graph(self, seed):
@@ -107,6 +107,13 @@ class AutoEncoderModel:
         grads = torch.autograd.grad(loss, [leaves[k] for k in names])
         for k, g in zip(names, grads):
             self._gviews[k].copy_(g)
+        if self.args.optimizer in _lib.DENSE_OPTS:
+            if getattr(self, "_dense", None) is None:
+                self._dense = [torch.zeros_like(self.params), torch.zeros_like(self.params), 0]
+            self._dense[2] += 1
+            _lib.dense_update_opt(self.params, self._dense[0], self._dense[1], self.grads,
+                                  _lib.optimizer_struct(self.args.optimizer, float(self.args.learning_rate), self._dense[2]))
+            return loss.detach()
         opt = _OPT[self.args.optimizer]
         _lib.dense_update(self.params, self.acc if opt == _lib.OPT_ADAGRAD else None, self.grads, opt,
                           float(self.args.learning_rate))

@@ -71,6 +71,17 @@ class EmbeddingTable:
             self.slots[optimizer_name] = s
         return s
 
+    def dense_slots(self, optimizer_name: str):
+        """(slot1, slot2, step) of an Adam / Adadelta optimizer instance: two zero-initialised arrays (m, v / accum,
+        accum_update) and the number of the update about to be applied (1, 2, ...), advanced by this call."""
+        key = optimizer_name + "/dense"
+        st = self.slots.get(key)
+        if st is None:
+            st = [torch.zeros_like(self.data), torch.zeros_like(self.data), 0]
+            self.slots[key] = st
+        st[2] += 1
+        return st[0], st[1], st[2]
+
     # -- read paths --
     def lookup(self, idx: torch.Tensor | None = None) -> torch.Tensor:
         """embedding_lookup on the normalised view -> dense [n, dim] float32 (HIP gather kernel)."""
@@ -121,8 +132,13 @@ class StepEngine:
         return self.tag, slot
 
     def _apply(self, table: EmbeddingTable, opt_name: str, optimizer: str, lr: float, tag: int):
+        if optimizer in _lib.DENSE_OPTS:      # Adam / Adadelta: every row moves, touched or not
+            s1, s2, step = table.dense_slots(opt_name)
+            _lib.rows_update_dense(table.data, s1, s2, table.grad, table.dim, table.normalize,
+                                   _lib.optimizer_struct(optimizer, lr, step))
+            return
         if optimizer not in _OPT:
-            raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
+            raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported (Adagrad, SGD, Adam, Adadelta)")
         acc = table.slot(opt_name) if optimizer == "Adagrad" else None
         _lib.rows_update(table.data, acc, table.grad, table.touched, tag, table.dim, table.normalize, _OPT[optimizer], lr)
 

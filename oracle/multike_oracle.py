@@ -137,6 +137,31 @@ def adagrad_dense(var, acc, grad, lr):
     var -= var.dtype.type(lr) * grad / np.sqrt(acc)
 
 
+def adam_dense(var, m, v, grad, lr, step, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    """TF1 ApplyAdam on the whole variable (tf.train.AdamOptimizer defaults; `step` = 1, 2, ...):
+    lr_t = lr sqrt(1-b2^t)/(1-b1^t) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; var -= lr_t m / (sqrt(v) + eps).
+    Selectable through args.optimizer (code/MultiKE_model.py:15-25); a zero gradient still moves the weight."""
+    dt = var.dtype.type
+    lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    m *= dt(beta1)
+    m += dt(1.0 - beta1) * grad
+    v *= dt(beta2)
+    v += dt(1.0 - beta2) * grad * grad
+    var -= dt(lr_t) * m / (np.sqrt(v) + dt(epsilon))
+
+
+def adadelta_dense(var, accum, accum_update, grad, lr, rho=0.95, epsilon=1e-8):
+    """TF1 ApplyAdadelta (tf.train.AdadeltaOptimizer defaults): accum = rho accum + (1-rho) g^2 ;
+    u = sqrt(accum_update + eps) / sqrt(accum + eps) * g ; var -= lr u ; accum_update = rho accum_update + (1-rho) u^2."""
+    dt = var.dtype.type
+    accum *= dt(rho)
+    accum += dt(1.0 - rho) * grad * grad
+    u = np.sqrt(accum_update + dt(epsilon)) / np.sqrt(accum + dt(epsilon)) * grad
+    var -= dt(lr) * u
+    accum_update *= dt(rho)
+    accum_update += dt(1.0 - rho) * u * u
+
+
 def relation_view_step_dense(ent, rel, acc_ent, acc_rel, pos, neg, lr, pos_w=None, neg_w=None, scale=1.0,
                              ent_norm=True, rel_norm=True, update=True):
     """One `session.run([loss, optimizer])` of the relation-view graph, whole-table semantics.

@@ -167,3 +167,24 @@ def test_task_divide_and_split(sampler_golden):
         assert [list(x) for x in mo.task_divide(list(range(row["total"])), row["n"])] == row["tasks"]
     for row in sampler_golden["kg_batch_split"]:
         assert mo.kg_batch_split(row["n1"], row["n2"], row["batch"]) == (row["b1"], row["b2"])
+
+
+def test_dense_optimizer_oracles_agree_with_torch_optim():
+    """adam_dense / adadelta_dense restate TF1's ApplyAdam / ApplyAdadelta.  torch.optim.Adadelta is the same rule; torch's
+    Adam differs only in where epsilon sits (eps vs eps * sqrt(1 - b2^t)), invisible at |g| >> eps -- an independent
+    implementation to pin the restatement against (TensorFlow itself is not installable here)."""
+    import torch
+    from oracle import multike_oracle as mo
+    rng = np.random.default_rng(0)
+    w0 = rng.standard_normal(50)
+    for kind in ("Adam", "Adadelta"):
+        p = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+        opt = (torch.optim.Adam([p], lr=0.01, betas=(0.9, 0.999), eps=1e-8) if kind == "Adam"
+               else torch.optim.Adadelta([p], lr=0.5, rho=0.95, eps=1e-8))
+        W, s1, s2 = w0.copy(), np.zeros(50), np.zeros(50)
+        for step in range(1, 6):
+            g = rng.standard_normal(50) + 0.5
+            p.grad = torch.tensor(g)
+            opt.step()
+            (mo.adam_dense(W, s1, s2, g, 0.01, step) if kind == "Adam" else mo.adadelta_dense(W, s1, s2, g, 0.5))
+        np.testing.assert_allclose(W, p.detach().numpy(), rtol=(1e-5 if kind == "Adam" else 1e-12), atol=(1e-6 if kind == "Adam" else 0))
