@@ -21,11 +21,65 @@ from collections import Counter
 
 import numpy as np
 
-__all__ = ["KG", "KGs", "read_relation_triples", "read_attribute_triples", "read_links", "read_dict", "read_pair_ids",
+__all__ = ["KG", "KGs", "TripleArray", "read_relation_triples", "read_attribute_triples", "read_links", "read_dict", "read_pair_ids",
            "pair2file", "dict2file", "line2file", "sort_elements", "generate_mapping_id", "generate_sharing_id",
            "uris_list_2ids", "uris_pair_2ids", "uris_relation_triple_2ids", "uris_attribute_triple_2ids",
            "generate_sup_relation_triples", "generate_sup_attribute_triples", "read_kgs_from_folder",
            "read_kgs_from_files", "parse_triples"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# a list of id triples kept as columns
+# ----------------------------------------------------------------------------------------------------------------
+class TripleArray:
+    """A list of (h, p, t) or (h, p, t, w) id tuples stored as an int array [n, 3] (+ float64 weights): what the
+    reference builds as Python lists of tuples with per-element loops (code/predicate_alignment.py:17-44), here produced
+    and concatenated with array operations and uploaded to HBM without a per-tuple conversion.  Reads like the list it
+    replaces: len(), iteration / indexing yield tuples, `a + b` concatenates."""
+
+    __slots__ = ("cols", "w")
+
+    def __init__(self, cols, w=None):
+        self.cols = np.ascontiguousarray(cols, dtype=np.int64).reshape(-1, 3)
+        self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+        if self.w is not None and len(self.w) != len(self.cols):
+            raise ValueError("weights and triples differ in length")
+
+    def __len__(self):
+        return len(self.cols)
+
+    def _tuple(self, i):
+        h, p, t = self.cols[i].tolist()
+        return (h, p, t) if self.w is None else (h, p, t, float(self.w[i]))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return TripleArray(self.cols[i], None if self.w is None else self.w[i])
+        return self._tuple(i)
+
+    def __iter__(self):
+        rows = self.cols.tolist()
+        if self.w is None:
+            return (tuple(r) for r in rows)
+        return ((r[0], r[1], r[2], w) for r, w in zip(rows, self.w.tolist()))
+
+    def __add__(self, other):
+        if not isinstance(other, TripleArray):
+            other = TripleArray.from_tuples(other)
+        if (self.w is None) != (other.w is None) and len(self) and len(other):
+            raise ValueError("cannot concatenate weighted and unweighted triples")
+        w = None if (self.w is None and other.w is None) else np.concatenate(
+            [x.w if x.w is not None else np.zeros(0) for x in (self, other)])
+        return TripleArray(np.concatenate([self.cols, other.cols]), w)
+
+    __radd__ = lambda self, other: TripleArray.from_tuples(other) + self   # noqa: E731
+
+    @classmethod
+    def from_tuples(cls, triples):
+        triples = list(triples)
+        if not triples:
+            return cls(np.zeros((0, 3), dtype=np.int64))
+        return cls([t[:3] for t in triples], [t[3] for t in triples] if len(triples[0]) > 3 else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .base.kgs import TripleArray
+
 UNMATCHED_WEIGHT = 0.2
 
 
@@ -174,6 +176,39 @@ class PredicateAlignModel:
         self.update_relation_triples(self.relation_alignment_set)
         self.update_attribute_triples(self.attribute_alignment_set)
 
+    def _int_triples(self, kind, which):
+        """The KG's local triples as an int array [n, 3], or None when a column is not integral (attribute values are
+        still strings before DataModel has replaced them by value ids)."""
+        cache = self.__dict__.setdefault("_arr_cache", {})
+        lst = getattr(self.kgs.kg1 if which == 1 else self.kgs.kg2, f"local_{kind}_triples_list")
+        key = (kind, which)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not lst:
+            arr = None
+            if all(isinstance(x, (int, np.integer)) for x in (lst[0] if lst else (0, 0, 0))):
+                arr = np.asarray(lst, dtype=np.int64).reshape(-1, 3)
+            hit = (lst, arr)
+            cache[key] = hit
+        return hit[1]
+
+    def _refresh_arrays(self, kind, id_set, t1, t2):
+        """`generate_sup_predicate_triples` + `add_weights` (code/predicate_alignment.py:17-44) as array operations: a
+        look-up table per KG from predicate id to (matched predicate, weight)."""
+        out = {}
+        for which, t, own, other in ((1, t1, 0, 1), (2, t2, 1, 0)):
+            n_pred = int(t[:, 1].max()) + 1 if len(t) else 1
+            for link in id_set:
+                n_pred = max(n_pred, int(link[own]) + 1)
+            to = np.full(n_pred, -1, dtype=np.int64)
+            wt = np.zeros(n_pred, dtype=np.float64)
+            for link in id_set:
+                to[link[own]], wt[link[own]] = link[other], link[2]
+            p = t[:, 1]
+            hit = to[p] >= 0
+            out[f"sup{which}"] = TripleArray(np.stack([t[hit, 0], to[p[hit]], t[hit, 2]], axis=1), wt[p[hit]])
+            out[f"w{which}"] = TripleArray(t, np.where(hit, zoom_weight(wt[p], self.args.predicate_soft_sim), UNMATCHED_WEIGHT))
+        return out
+
     def _refresh(self, kind, alignment_set):
         kg1, kg2 = self.kgs.kg1, self.kgs.kg2
         ids1, ids2 = getattr(kg1, kind + "s_id_dict"), getattr(kg2, kind + "s_id_dict")
@@ -182,14 +217,35 @@ class PredicateAlignModel:
         setattr(self, f"{kind}_id_alignment_set", id_set)
         setattr(self, f"train_{kind}s1", [a for a, _, _ in id_set])
         setattr(self, f"train_{kind}s2", [b for _, b, _ in id_set])
+        a1, a2 = self._int_triples(kind, 1), self._int_triples(kind, 2)
+        if a1 is not None and a2 is not None:
+            link2dic(id_set)                                          # one-to-one check, as the reference asserts
+            r = self._refresh_arrays(kind, id_set, a1, a2)
+            setattr(self, f"sup_{kind}_alignment_triples1", r["sup1"])
+            setattr(self, f"sup_{kind}_alignment_triples2", r["sup2"])
+            setattr(self, f"{kind}_triples_w_weights1", r["w1"])
+            setattr(self, f"{kind}_triples_w_weights2", r["w2"])
+            self.__dict__.pop(f"_{kind}_wsets", None)                 # the set views are rebuilt on demand
+            return
         s1, s2 = generate_sup_predicate_triples(id_set, t1, t2)
         setattr(self, f"sup_{kind}_alignment_triples1", s1)
         setattr(self, f"sup_{kind}_alignment_triples2", s2)
         w1, w2, ws1, ws2 = add_weights(id_set, t1, t2, self.args.predicate_soft_sim)
         setattr(self, f"{kind}_triples_w_weights1", w1)
         setattr(self, f"{kind}_triples_w_weights2", w2)
-        setattr(self, f"{kind}_triples_w_weights_set1", ws1)
-        setattr(self, f"{kind}_triples_w_weights_set2", ws2)
+        self.__dict__[f"_{kind}_wsets"] = (ws1, ws2)
+
+    def _wset(self, kind, which):
+        sets = self.__dict__.get(f"_{kind}_wsets")
+        if sets is None:
+            sets = (set(getattr(self, f"{kind}_triples_w_weights1")), set(getattr(self, f"{kind}_triples_w_weights2")))
+            self.__dict__[f"_{kind}_wsets"] = sets
+        return sets[which - 1]
+
+    relation_triples_w_weights_set1 = property(lambda self: self._wset("relation", 1))
+    relation_triples_w_weights_set2 = property(lambda self: self._wset("relation", 2))
+    attribute_triples_w_weights_set1 = property(lambda self: self._wset("attribute", 1))
+    attribute_triples_w_weights_set2 = property(lambda self: self._wset("attribute", 2))
 
     def update_attribute_triples(self, attribute_alignment_set):
         self._refresh("attribute", attribute_alignment_set)
