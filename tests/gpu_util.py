@@ -2,8 +2,7 @@
 import numpy as np
 import torch
 
-from multike_amd import _lib
-from multike_amd.tables import EmbeddingTable, StepEngine
+from multike_amd.tables import EmbeddingTable
 
 
 def dev_i32(a):

@@ -45,7 +45,6 @@ def test_ranks_vs_oracle(n1, n2, d):
 
 def test_neighbour_table_matches_reference_definition():
     """top-k inner products per row, self included, unordered (code/base/batch.py:143-150)."""
-    import torch
     from multike_amd.base.batch import generate_neighbours, neighbour_table
     rng = np.random.default_rng(0)
     n, d, k = 700, 20, 15

@@ -1,6 +1,5 @@
 """The hand-written f32 MFMA GEMM (mke_gemm_f32) against float64 matmul: every operand orientation the attribute step
 uses, ragged sizes, split-K accumulation."""
-import numpy as np
 import pytest
 import torch
 

@@ -5,9 +5,8 @@ import math
 
 import numpy as np
 import pytest
-import torch
+import torch  # noqa: F401  (device presence is asserted by the gpu marker fixtures)
 
-from oracle import attr_cnn_oracle as ao
 from oracle import multike_oracle as mo
 
 pytestmark = pytest.mark.gpu

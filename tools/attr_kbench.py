@@ -1,7 +1,7 @@
 """Per-kernel timings of the attribute-view step pieces (B = 5000, dim 75): `python tools/attr_kbench.py`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from multike_amd import _lib
 
 d, B = 75, 5000

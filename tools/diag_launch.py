@@ -1,7 +1,7 @@
 """GPU diagnostic: where does the per-step wall time go?  (enqueue cost vs GPU time, null vs side stream)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from multike_amd import _lib
 from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
 from multike_amd.synthetic import SyntheticKGs

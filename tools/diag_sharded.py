@@ -1,7 +1,7 @@
 """GPU diagnostic: host enqueue cost vs wall time per step of the sharded trainer on one rank."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, torch.distributed as dist
+import torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from multike_amd.distributed import ShardedRelationTrainer

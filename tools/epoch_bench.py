@@ -2,7 +2,7 @@
 python tools/epoch_bench.py [n_ent] [epochs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from multike_amd.MultiKE_CSL import MultiKE_CV
 from multike_amd.synthetic import SyntheticData, synthetic_args
 

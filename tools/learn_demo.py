@@ -1,8 +1,7 @@
 """End-to-end sanity run: a synthetic dataset FOLDER whose two KGs share structure -> DataModel -> ITC training ->
 Hits@k per view over the epochs.  python tools/learn_demo.py [n_pairs] [epochs] [shared]"""
-import os, sys, tempfile, json, contextlib, io
+import os, sys, tempfile, contextlib, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from multike_amd.data_model import DataModel
 from multike_amd.MultiKE_CSL import MultiKE_CV
 from multike_amd.MultiKE_Late import test
