@@ -5,7 +5,6 @@ import math
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (device presence is asserted by the gpu marker fixtures)
 
 from oracle import multike_oracle as mo
 
