@@ -292,6 +292,28 @@ int mke_align_fwd_bwd(
     int32_t tag,
     double* loss_partials, void* stream);
 
+/* A whole epoch of common-space steps as one native call (the step loop of code/MultiKE_model.py:458-473 around the graph
+ * :225-239): per step every term runs mke_align_fwd_bwd on positions [step_off[s], step_off[s+1]) of ia / ib, then ONE
+ * update launch covers every trainable table.  Tables share stride/dim; a table with grad == NULL is constant (the name
+ * view).  loss_partials: [n_steps][n_terms][MKE_LOSS_PARTIALS]; tag of step s = tag_base + s. */
+#define MKE_ALIGN_MAX_TABLES 4
+#define MKE_ALIGN_MAX_TERMS 4
+typedef struct mke_align_table {
+  float* table; float* acc /*nullable for SGD / constant*/; float* grad /*NULL = constant*/; int32_t* touched;
+  int64_t n_rows; int normalize;
+} mke_align_table;
+typedef struct mke_align_term { int a, b; float weight; } mke_align_term;   /* indices into tables[] */
+typedef struct mke_align_plan {
+  mke_align_table tables[MKE_ALIGN_MAX_TABLES]; int n_tables;
+  mke_align_term terms[MKE_ALIGN_MAX_TERMS]; int n_terms;
+  int stride, dim;
+  const int32_t* ia; const int32_t* ib;          /* device, epoch order */
+  const int64_t* step_off; int n_steps;          /* HOST, n_steps + 1 offsets */
+  int optimizer; float lr; int32_t tag_base;
+  double* loss_partials;
+} mke_align_plan;
+int mke_align_steps(const mke_align_plan* plan, void* stream);
+
 /* Gather normalised rows into a dense [n][dim] matrix (the `.eval()` / embedding_lookup read path).
  * replaces: code/MultiKE_model.py:263-277 eval_kg*_ent_embeddings. */
 int mke_gather_rows(

@@ -466,12 +466,16 @@ class MultiKE:
             'cross-kg attribute inference in attr. view')
 
     # --- shared / common space ------------------------------------------------------------------------------
-    def _entity_batches(self, entities, batch_size):
+    def _entity_tensor(self, entities):
         key = ("ents", id(entities), len(entities))
         t = self._lists.get(key)
         if t is None:
             t = _dev_i32(entities, self.device)
             self._lists[key] = t
+        return t
+
+    def _entity_batches(self, entities, batch_size):
+        t = self._entity_tensor(entities)
         steps = int(math.ceil(len(entities) / batch_size))
         bs = batch_size if steps > 1 else len(entities)
         seed, stream = self._next_sample_stream()
@@ -511,6 +515,26 @@ class MultiKE:
         g = self._cross_name
         cvw = float(self.args.cv_weight)
         total, trained = None, 0
+        if self.args.optimizer not in _DENSE_OPTS and len(entities):
+            # all steps of the epoch in one native call: one sampler launch, one gather of the entity ids
+            from .runner import run_alignment_steps
+            t = self._entity_tensor(entities)
+            B = self.args.entity_batch_size
+            steps = int(math.ceil(len(entities) / B))
+            bs = B if steps > 1 else len(entities)
+            seed, stream = self._next_sample_stream()
+            self._last_sample = (seed, stream, len(entities), bs, steps)
+            idx = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).reshape(-1).long()]
+            tag_base = self.engine.tag + 1
+            self.engine.tag += steps
+            ring = run_alignment_steps([self.ent_embeds, self.name_embeds, self.rv_ent_embeds, self.av_ent_embeds],
+                                       [(0, 1, cvw * float(self.args.cv_name_weight)), (0, 2, cvw), (0, 3, cvw)], idx, idx,
+                                       np.arange(steps + 1, dtype=np.int64) * bs, g["opt"], tag_base, g["lr"],
+                                       optimizer=self.args.optimizer)
+            epoch_loss = float(ring.sum()) / cvw / (steps * bs) if cvw != 0 else 0.0
+            print('epoch {} of common space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
+                                                                                               time.time() - start))
+            return epoch_loss
         for idx, bs in self._entity_batches(entities, self.args.entity_batch_size):
             terms = [(self.ent_embeds, idx, self.name_embeds, idx, cvw * float(self.args.cv_name_weight)),
                      (self.ent_embeds, idx, self.rv_ent_embeds, idx, cvw),

@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps",
 )
 
 
@@ -48,6 +48,25 @@ class AttrStepArgs(C.Structure):
         ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
         ("update", C.c_int), ("workspace", C.c_void_p),
     ]
+
+
+class AlignTableStruct(C.Structure):
+    """mke_align_table"""
+    _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p), ("n_rows", C.c_int64),
+                ("normalize", C.c_int)]
+
+
+class AlignTermStruct(C.Structure):
+    """mke_align_term"""
+    _fields_ = [("a", C.c_int), ("b", C.c_int), ("weight", C.c_float)]
+
+
+class AlignPlanStruct(C.Structure):
+    """mke_align_plan"""
+    _fields_ = [("tables", AlignTableStruct * 4), ("n_tables", C.c_int), ("terms", AlignTermStruct * 4), ("n_terms", C.c_int),
+                ("stride", C.c_int), ("dim", C.c_int), ("ia", C.c_void_p), ("ib", C.c_void_p),
+                ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("optimizer", C.c_int), ("lr", C.c_float),
+                ("tag_base", C.c_int32), ("loss_partials", C.c_void_p)]
 
 
 class OptimizerStruct(C.Structure):
@@ -284,6 +303,11 @@ def neg_sample_at(pos, pos_index, pos_kg, sides, neg_per_pos, max_try, seed, str
         C.c_uint32(stream_id & 0xFFFFFFFF), _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"),
         _dev(nt, torch.int32, "neg_t"), _stream())
     _check(rc, "mke_neg_sample_at")
+
+
+def align_steps(plan: AlignPlanStruct):
+    rc = lib().mke_align_steps(C.byref(plan), _stream())
+    _check(rc, "mke_align_steps")
 
 
 def relation_steps(plan: RelationPlanStruct, step_begin: int, step_end: int):

@@ -235,6 +235,44 @@ extern "C" int mke_align_fwd_bwd(const float* table_a, int a_normalize, const fl
   return check_launch("k_align");
 }
 
+extern "C" int mke_align_steps(const mke_align_plan* pl, void* stream) {
+  using namespace mke;
+  if (!pl) { set_error("mke_align_steps: NULL plan"); return MKE_E_NULL; }
+  if (pl->n_tables < 1 || pl->n_tables > MKE_ALIGN_MAX_TABLES || pl->n_terms < 1 || pl->n_terms > MKE_ALIGN_MAX_TERMS) { set_error("mke_align_steps: bad table / term count"); return MKE_E_SHAPE; }
+  if (pl->n_steps < 0 || !pl->step_off || !pl->loss_partials) { set_error("mke_align_steps: NULL pointer or negative n_steps"); return MKE_E_NULL; }
+  if ((int64_t)pl->tag_base + pl->n_steps >= 0x7FFFFFFFLL) { set_error("tag overflow"); return MKE_E_RANGE; }
+  mke_update_table ut[MKE_ALIGN_MAX_TABLES];
+  int nu = 0;
+  for (int k = 0; k < pl->n_tables; ++k) {
+    const mke_align_table& t = pl->tables[k];
+    if (!t.table) { set_error("mke_align_steps: table %d is NULL", k); return MKE_E_NULL; }
+    if (t.grad) {
+      if (!t.touched) { set_error("mke_align_steps: table %d has no touched array", k); return MKE_E_NULL; }
+      ut[nu++] = mke_update_table{t.table, t.acc, t.grad, t.touched, t.n_rows, t.normalize, 1, nullptr};
+    }
+  }
+  for (int k = 0; k < pl->n_terms; ++k)
+    if (pl->terms[k].a < 0 || pl->terms[k].a >= pl->n_tables || pl->terms[k].b < 0 || pl->terms[k].b >= pl->n_tables) { set_error("mke_align_steps: term %d names a table outside [0,%d)", k, pl->n_tables); return MKE_E_RANGE; }
+  for (int s = 0; s < pl->n_steps; ++s) {
+    const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1];
+    if (lo < 0 || hi < lo) { set_error("mke_align_steps: step_off must be non-decreasing"); return MKE_E_SHAPE; }
+    const int32_t tag = pl->tag_base + s;
+    for (int k = 0; k < pl->n_terms; ++k) {
+      const mke_align_table& a = pl->tables[pl->terms[k].a];
+      const mke_align_table& b = pl->tables[pl->terms[k].b];
+      const int rc = mke_align_fwd_bwd(a.table, a.normalize, b.table, b.normalize, pl->stride, pl->dim, pl->ia ? pl->ia + lo : nullptr,
+                                       pl->ib ? pl->ib + lo : nullptr, hi - lo, pl->terms[k].weight, a.grad, a.touched, b.grad, b.touched,
+                                       tag, pl->loss_partials + ((int64_t)s * pl->n_terms + k) * MKE_LOSS_PARTIALS, stream);
+      if (rc) return rc;
+    }
+    if (nu) {
+      const int rc = mke_rows_update_multi(ut, nu, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, stream);
+      if (rc) return rc;
+    }
+  }
+  return MKE_OK;
+}
+
 extern "C" int mke_gather_rows(const float* table, int normalize, int stride, int dim, const int32_t* idx, int64_t n,
                                float* out, void* stream) {
   using namespace mke;

@@ -210,3 +210,40 @@ def run_positive_steps(ent: EmbeddingTable, rel: EmbeddingTable, opt_name: str, 
     p.loss_partials, p.loss_ring, p.tag_base = _lib.ptr(loss, torch.float64, "loss"), steps, tag_base
     _lib.relation_steps(p, 0, steps)
     return loss
+
+
+def run_alignment_steps(tables, terms, idx_a, idx_b, step_off, opt_name: str, tag_base: int, lr: float,
+                        optimizer: str = "Adagrad") -> torch.Tensor:
+    """A whole epoch of common-space steps as ONE native call (`mke_align_steps`; code/MultiKE_model.py:458-473).
+    tables: list of EmbeddingTable (constant tables are left untouched); terms: [(index_a, index_b, weight)].
+    Returns the loss partials [n_steps, n_terms, LOSS_PARTIALS]."""
+    if optimizer not in _OPT:
+        raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the native step loops (Adagrad, SGD)")
+    off = np.ascontiguousarray(step_off, dtype=np.int64)
+    steps = len(off) - 1
+    dev = tables[0].device
+    loss = torch.zeros(max(1, steps), len(terms), _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
+    if steps <= 0:
+        return loss[:0]
+    f32, i32 = torch.float32, torch.int32
+    p = _lib.AlignPlanStruct()
+    p.n_tables, p.n_terms = len(tables), len(terms)
+    for k, t in enumerate(tables):
+        if t.stride != tables[0].stride or t.dim != tables[0].dim:
+            raise _lib.MultiKEHipError("common-space tables must share dim/stride")
+        s = p.tables[k]
+        s.table, s.n_rows, s.normalize = _lib.ptr(t.data, f32, "table"), t.n_rows, int(t.normalize)
+        if t.trainable:
+            s.grad, s.touched = _lib.ptr(t.grad, f32, "grad"), _lib.ptr(t.touched, i32, "touched")
+            s.acc = _lib.ptr(t.slot(opt_name), f32, "acc") if optimizer == "Adagrad" else None
+        else:
+            s.grad = s.touched = s.acc = None
+    for k, (a, b, w) in enumerate(terms):
+        p.terms[k].a, p.terms[k].b, p.terms[k].weight = int(a), int(b), float(w)
+    p.stride, p.dim = tables[0].stride, tables[0].dim
+    p.ia, p.ib = _lib.ptr(idx_a, i32, "ia"), _lib.ptr(idx_b, i32, "ib")
+    p.step_off, p.n_steps = off.ctypes.data_as(C.POINTER(C.c_int64)), steps
+    p.optimizer, p.lr, p.tag_base = _OPT[optimizer], float(lr), int(tag_base)
+    p.loss_partials = _lib.ptr(loss, torch.float64, "loss")
+    _lib.align_steps(p)
+    return loss
