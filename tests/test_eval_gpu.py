@@ -61,3 +61,38 @@ def test_neighbour_table_matches_reference_definition():
     assert int(valid.sum()) == n
     dic = generate_neighbours(e, ids, k, 4)
     assert set(dic.keys()) == set(ids) and len(dic[ids[0]]) == k
+
+
+def test_neighbour_table_threshold_path_is_exact():
+    """Long rows, k = 2 %: the sample-threshold + compaction + short top-k path must return exactly the top-k set of a
+    full-width top-k (rows of clustered data so that similarities are far from uniform), including the fallback rows."""
+    import torch
+    from multike_amd import _lib
+    from multike_amd.base.batch import neighbour_table
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    n, d, k = 40_000, 32, 800
+    centers = torch.randn(50, d, device="cuda", generator=g)
+    e = centers[torch.randint(0, 50, (n,), device="cuda", generator=g)] + 0.7 * torch.randn(n, d, device="cuda", generator=g)
+    e = torch.nn.functional.normalize(e, dim=1)
+    ids = list(range(n))
+    table, valid = neighbour_table(e, ids, k, n)
+    assert int(valid.sum()) == n
+    rows = torch.arange(0, n, 97, device="cuda")
+    sim = e[rows] @ e.t()
+    ref = torch.topk(sim, k, dim=1).indices
+    kth = torch.topk(sim, k + 1, dim=1).values
+    for r in range(len(rows)):
+        got, exp = set(table[rows[r]].tolist()), set(ref[r].tolist())
+        assert len(got) == k
+        if float(kth[r, k - 1] - kth[r, k]) > 1e-6:        # no tie at the boundary
+            assert got == exp, (int(rows[r]), len(got - exp))
+    # the kernel itself: counts and hits against a mask
+    s = torch.randn(64, 10_000, device="cuda", generator=g)
+    tau = torch.full((64,), 1.5, device="cuda")
+    idx, cnt = _lib.select_above(s, tau, 1024)
+    m = s > 1.5
+    assert torch.equal(cnt.long(), m.sum(1))
+    for r in (0, 63):
+        assert set(idx[r, :int(cnt[r])].tolist()) == set(torch.nonzero(m[r]).reshape(-1).tolist())
+    idx2, cnt2 = _lib.select_above(s, torch.full((64,), -10.0, device="cuda"), 16)     # overflow: count reported, cap kept
+    assert int(cnt2.min()) == 10_000

@@ -38,5 +38,18 @@ torch.cuda.synchronize()
 print(f"MultiKE_CV.run(): {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
 print("test Hits@1:", {k_: round(float(v), 3) for k_, v in res.items()})
 log = buf.getvalue().splitlines()
+import re, collections
+agg = collections.OrderedDict()
+for l in log:
+    m = re.match(r"epoch \d+ of (.*?), avg\. loss: .*?time: ([0-9.]+)s", l)
+    if m:
+        agg[m.group(1)] = agg.get(m.group(1), 0.0) + float(m.group(2))
+    m = re.match(r"generating neighbors of .* costs ([0-9.]+) s", l)
+    if m:
+        agg["k-NN refresh"] = agg.get("k-NN refresh", 0.0) + float(m.group(1))
+    m = re.search(r"quick results: .*time = ([0-9.]+) s", l)
+    if m:
+        agg["valid/test ranking"] = agg.get("valid/test ranking", 0.0) + float(m.group(1))
+print("time by phase (s):", {k_: round(v, 2) for k_, v in agg.items()}, "| sum", round(sum(agg.values()), 2))
 print("epochs executed:", sum(1 for l in log if l.startswith("epoch ") and l.rstrip().endswith(":")), "| k-NN refreshes:", sum(1 for l in log if "neighbors of" in l))
 print("\n".join([l for l in log if "neighbors of" in l][:2]))
