@@ -24,7 +24,8 @@ import numpy as np
 __all__ = ["KG", "KGs", "TripleArray", "read_relation_triples", "read_attribute_triples", "read_links", "read_dict", "read_pair_ids",
            "pair2file", "dict2file", "line2file", "sort_elements", "generate_mapping_id", "generate_sharing_id",
            "uris_list_2ids", "uris_pair_2ids", "uris_relation_triple_2ids", "uris_attribute_triple_2ids",
-           "generate_sup_relation_triples", "generate_sup_attribute_triples", "read_kgs_from_folder",
+           "generate_sup_relation_triples", "generate_sup_attribute_triples", "swap_relation_triples", "swap_attribute_triples",
+           "read_kgs_from_folder",
            "read_kgs_from_files", "parse_triples"]
 
 
@@ -321,13 +322,36 @@ def _group(pairs):
     return out
 
 
+def swap_relation_triples(triples, link_map):
+    """'swapping' supervision of one KG in one pass over its triples (same set as `generate_sup_relation_triples` builds
+    from rt_dict / hr_dict, code/base/read.py:130-146): every triple whose head (tail) is a linked entity, re-stated with
+    the counterpart in that position."""
+    new = {(link_map[h], r, t) for h, r, t in triples if h in link_map}
+    new.update((h, r, link_map[t]) for h, r, t in triples if t in link_map)
+    return new
+
+
+def swap_attribute_triples(triples, link_map):
+    """code/base/read.py:149-164 in one pass."""
+    return {(link_map[h], a, v) for h, a, v in triples if h in link_map}
+
+
 class KG:
     """One knowledge graph, either in URI space or in id space (code/base/kg.py:10-143).
 
     `relation_triples_set` and `local_relation_triples_set` are the SAME set object, as in the reference
     (code/base/kg.py:58-61), so `add_sup_relation_triples` also grows the "local" set -- that is the set the
     negative sampler filters against -- while `local_relation_triples_list` / `_num` keep the
-    pre-supervision triples the relation view trains on."""
+    pre-supervision triples the relation view trains on.
+
+    Everything derivable from the two triple sets (the sorted lists, rt_dict / hr_dict / av_dict, the per-entity predicate
+    dicts) is computed on first access: the reference builds all of it eagerly for four KG objects per run (two of them the
+    URI-space KGs, whose dicts nothing reads), which at 100K entities per KG was 12 s of an 18 s load."""
+
+    _REL_DERIVED = ("relation_triples_list", "local_relation_triples_list", "entities_list", "relations_list", "rt_dict", "hr_dict",
+                    "entity_relations_dict")
+    _ATTR_DERIVED = ("attribute_triples_list", "local_attribute_triples_list", "attributes_list", "av_dict",
+                     "entity_attributes_dict")
 
     def __init__(self, relation_triples, attribute_triples, verbose=False):
         self.entities_id_dict = self.relations_id_dict = self.attributes_id_dict = None
@@ -338,6 +362,40 @@ class KG:
         if verbose:
             print(self.statistics())
 
+    def __getattr__(self, name):          # only reached when `name` is not set: the lazily derived attributes
+        if name == "local_relation_triples_list":
+            v = _stable_list(self.local_relation_triples_set)     # add_sup_* snapshots this before the alias grows
+        elif name == "relation_triples_list":
+            v = self.local_relation_triples_list if self.sup_relation_triples_set is None else _stable_list(self.relation_triples_set)
+        elif name == "local_attribute_triples_list":
+            v = _stable_list(self.local_attribute_triples_set)
+        elif name == "attribute_triples_list":
+            v = self.local_attribute_triples_list if self.sup_attribute_triples_set is None else _stable_list(self.attribute_triples_set)
+        elif name == "entities_list":
+            v = _stable_list(self.entities_set)
+        elif name == "relations_list":
+            v = _stable_list(self.relations_set)
+        elif name == "attributes_list":
+            v = _stable_list(self.attributes_set)
+        elif name == "rt_dict":
+            v = _group((h, (r, t)) for h, r, t in self.local_relation_triples_list)
+        elif name == "hr_dict":
+            v = _group((t, (h, r)) for h, r, t in self.local_relation_triples_list)
+        elif name == "entity_relations_dict":
+            v = _group((h, r) for h, r, _ in self.local_relation_triples_list)
+        elif name == "av_dict":
+            v = _group((h, (a, v_)) for h, a, v_ in self.local_attribute_triples_list)
+        elif name == "entity_attributes_dict":
+            v = _group((h, a) for h, a, _ in self.local_attribute_triples_list)
+        else:
+            raise AttributeError(name)
+        self.__dict__[name] = v
+        return v
+
+    def _forget(self, names):
+        for n in names:
+            self.__dict__.pop(n, None)
+
     def statistics(self) -> str:
         return (f"KG: {self.entities_num} entities, {self.relations_num} relations, {self.attributes_num} attributes, "
                 f"{self.relation_triples_num} relation triples ({self.local_relation_triples_num} local), "
@@ -345,40 +403,38 @@ class KG:
 
     # -- relation side --
     def set_relations(self, relation_triples):
+        self._forget(self._REL_DERIVED)
+        self.sup_relation_triples_set, self.sup_relation_triples_list = None, None
         self.relation_triples_set = self.local_relation_triples_set = set(relation_triples)
-        self.relation_triples_list = self.local_relation_triples_list = _stable_list(self.relation_triples_set)
         heads, self.relations_set, tails = parse_triples(self.relation_triples_set)
         self.entities_set = heads | tails
-        self.entities_list = _stable_list(self.entities_set)
-        self.relations_list = _stable_list(self.relations_set)
         self.entities_num, self.relations_num = len(self.entities_set), len(self.relations_set)
         self.relation_triples_num = self.local_relation_triples_num = len(self.relation_triples_set)
-        self.generate_relation_triple_dict()
-        self.parse_relations()
 
     def generate_relation_triple_dict(self):
-        self.rt_dict = _group((h, (r, t)) for h, r, t in self.local_relation_triples_list)
-        self.hr_dict = _group((t, (h, r)) for h, r, t in self.local_relation_triples_list)
+        self._forget(("rt_dict", "hr_dict"))
+        return self.rt_dict, self.hr_dict
 
     def parse_relations(self):
-        self.entity_relations_dict = _group((h, r) for h, r, _ in self.local_relation_triples_list)
+        self._forget(("entity_relations_dict",))
+        return self.entity_relations_dict
 
     # -- attribute side --
     def set_attributes(self, attribute_triples):
+        self._forget(self._ATTR_DERIVED)
+        self.sup_attribute_triples_set, self.sup_attribute_triples_list = None, None
         self.attribute_triples_set = self.local_attribute_triples_set = set(attribute_triples)
-        self.attribute_triples_list = self.local_attribute_triples_list = _stable_list(self.attribute_triples_set)
         _, self.attributes_set, _ = parse_triples(self.attribute_triples_set)
-        self.attributes_list = _stable_list(self.attributes_set)
         self.attributes_num = len(self.attributes_set)
         self.attribute_triples_num = self.local_attribute_triples_num = len(self.attribute_triples_set)
-        self.generate_attribute_triple_dict()
-        self.parse_attributes()
 
     def generate_attribute_triple_dict(self):
-        self.av_dict = _group((h, (a, v)) for h, a, v in self.local_attribute_triples_list)
+        self._forget(("av_dict",))
+        return self.av_dict
 
     def parse_attributes(self):
-        self.entity_attributes_dict = _group((h, a) for h, a, _ in self.local_attribute_triples_list)
+        self._forget(("entity_attributes_dict",))
+        return self.entity_attributes_dict
 
     def set_id_dict(self, entities_id_dict, relations_id_dict, attributes_id_dict):
         self.entities_id_dict = entities_id_dict
@@ -387,18 +443,20 @@ class KG:
 
     # -- supervision --
     def add_sup_relation_triples(self, sup_triples):
+        self.local_relation_triples_list                                   # snapshot of the pre-supervision triples
         self.sup_relation_triples_set = set(sup_triples)
         self.sup_relation_triples_list = _stable_list(self.sup_relation_triples_set)
         self.relation_triples_set |= self.sup_relation_triples_set          # in place: the alias grows too
-        self.relation_triples_list = _stable_list(self.relation_triples_set)
-        self.relation_triples_num = len(self.relation_triples_list)
+        self._forget(("relation_triples_list",))
+        self.relation_triples_num = len(self.relation_triples_set)
 
     def add_sup_attribute_triples(self, sup_triples):
+        self.local_attribute_triples_list
         self.sup_attribute_triples_set = set(sup_triples)
         self.sup_attribute_triples_list = _stable_list(self.sup_attribute_triples_set)
         self.attribute_triples_set |= self.sup_attribute_triples_set
-        self.attribute_triples_list = _stable_list(self.attribute_triples_set)
-        self.attribute_triples_num = len(self.attribute_triples_list)
+        self._forget(("attribute_triples_list",))
+        self.attribute_triples_num = len(self.attribute_triples_set)
 
     # -- packed views for the device side (id-space KGs only) --
     @staticmethod
@@ -454,13 +512,11 @@ class KGs:
             setattr(self, split + "_entities2", [b for _, b in links])
 
         if mode == "swapping":
-            s1, s2 = generate_sup_relation_triples(self.train_links, self.kg1.rt_dict, self.kg1.hr_dict,
-                                                   self.kg2.rt_dict, self.kg2.hr_dict)
-            self.kg1.add_sup_relation_triples(s1)
-            self.kg2.add_sup_relation_triples(s2)
-            s1, s2 = generate_sup_attribute_triples(self.train_links, self.kg1.av_dict, self.kg2.av_dict)
-            self.kg1.add_sup_attribute_triples(s1)
-            self.kg2.add_sup_attribute_triples(s2)
+            m12, m21 = dict(self.train_links), {b: a for a, b in self.train_links}
+            self.kg1.add_sup_relation_triples(swap_relation_triples(self.kg1.local_relation_triples_set, m12))
+            self.kg2.add_sup_relation_triples(swap_relation_triples(self.kg2.local_relation_triples_set, m21))
+            self.kg1.add_sup_attribute_triples(swap_attribute_triples(self.kg1.local_attribute_triples_set, m12))
+            self.kg2.add_sup_attribute_triples(swap_attribute_triples(self.kg2.local_attribute_triples_set, m21))
 
         self.useful_entities_list1 = self.train_entities1 + self.valid_entities1 + self.test_entities1
         self.useful_entities_list2 = self.train_entities2 + self.valid_entities2 + self.test_entities2

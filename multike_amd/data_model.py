@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-from .base.kgs import generate_sup_attribute_triples, read_kgs_from_folder
+from .base.kgs import read_kgs_from_folder, swap_attribute_triples
 from .utils import CharHashEmbedder, clear_attribute_triples, read_local_name, read_word2vec
 
 LITERAL_EMBEDDINGS_FILE = "literal_vectors.npy"
@@ -119,9 +119,9 @@ class DataModel:
         value_id = {v: i for i, v in enumerate(values_list)}
         for kg, side in zip((self.kgs.kg1, self.kgs.kg2), kept):
             kg.set_attributes({(h, a, value_id[v]) for (h, a, v) in side})
-        s1, s2 = generate_sup_attribute_triples(self.kgs.train_links, self.kgs.kg1.av_dict, self.kgs.kg2.av_dict)
-        self.kgs.kg1.add_sup_attribute_triples(s1)
-        self.kgs.kg2.add_sup_attribute_triples(s2)
+        m12, m21 = dict(self.kgs.train_links), {b: a for a, b in self.kgs.train_links}
+        self.kgs.kg1.add_sup_attribute_triples(swap_attribute_triples(self.kgs.kg1.local_attribute_triples_set, m12))
+        self.kgs.kg2.add_sup_attribute_triples(swap_attribute_triples(self.kgs.kg2.local_attribute_triples_set, m21))
         self.values_list = values_list
         vecs = np.asarray(self.literal_vectors_mat)[[self.literal_id_dic[v] for v in values_list]]
         self.value_vectors = l2_normalize_rows(vecs) if self.args.literal_normalize else vecs
