@@ -207,7 +207,8 @@ class MultiKE:
         dev = self.device
         sides = []
         for kg in (self.kg1, self.kg2):
-            known = np.asarray(sorted(kg.local_relation_triples_set), dtype=np.int32).reshape(-1, 3)
+            # membership only: the order in which the hash set is filled does not matter, so no sort
+            known = np.array(list(kg.local_relation_triples_set), dtype=np.int32).reshape(-1, 3)
             t = torch.as_tensor(known, device=dev)
             sides.append(KGSide(kg.entities_list,
                                 KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous()), device=dev))
