@@ -72,11 +72,47 @@ class HipBackend:
         _lib.rows_update_multi([t0, t1], tag, t0[0].shape[1], dim, _lib.OPT_ADAGRAD, lr)
 
 
+class TorchComm:
+    """The collectives of the sharded step, on torch.distributed (RCCL over xGMI on MI355X; gloo in the CPU tests)."""
+
+    def all_to_all_single(self, out, inp, group=None):
+        dist.all_to_all_single(out, inp, group=group)
+
+    def all_reduce(self, t, op=None):
+        dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
+
+    def all_gather(self, parts, mine):
+        dist.all_gather(parts, mine)
+
+
+class HostStagedComm(TorchComm):
+    """Test vehicle: the same collectives on device tensors through a CPU backend (gloo), staged over the host.  Lets two
+    ranks that SHARE one GPU exercise the device kernels of the sharded step with world_size 2 -- RCCL refuses two ranks
+    on one device, and a single-GPU box is all the test environment offers."""
+
+    def all_to_all_single(self, out, inp, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        dist.all_reduce(c) if op is None else dist.all_reduce(c, op=op)
+        t.copy_(c)
+
+    def all_gather(self, parts, mine):
+        cp = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        dist.all_gather(cp, mine.cpu())
+        for p, c in zip(parts, cp):
+            p.copy_(c)
+
+
 class ShardedRelationTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int,
                  world: int, seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32,
-                 lookahead: int | None = None):
+                 lookahead: int | None = None, comm=None):
         self.backend = backend or HipBackend()
+        self.comm = comm or TorchComm()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         self.rank, self.world, self.lr = rank, world, lr
         self.dim = ent0.shape[1]
@@ -187,7 +223,7 @@ class ShardedRelationTrainer:
             worst = max(worst, int(counts.max()))
         t = torch.tensor([worst], dtype=torch.int64, device=dev)
         if dist.is_initialized() and G > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.comm.all_reduce(t, op=dist.ReduceOp.MAX)
         worst = int(t)
         return int(min(max_local, c_bound, math.ceil(worst * slack) + 64)) if worst else c_bound
 
@@ -224,7 +260,7 @@ class ShardedRelationTrainer:
         neg = self._step_neg(s)
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
-        dist.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
+        self.comm.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
         if self.keep_stats:
             self._counts_last.copy_(self._counts)
         cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
@@ -277,7 +313,7 @@ class ShardedRelationTrainer:
                 cur.wait_event(self._plan_done[slot])
             # ---- requested rows: owner gathers raw rows, equal-split all-to-all back ---------------------------------
             be.gather_padded(self.ent, want, self._rows_out, self._cgrad)       # also clears the compact grad scratch
-            dist.all_to_all_single(self._rows_in, self._rows_out)
+            self.comm.all_to_all_single(self._rows_in, self._rows_out)
             # ---- local fused step on the compact row set --------------------------------------------------------
             self.tag += 1
             tag = self.tag
@@ -291,9 +327,9 @@ class ShardedRelationTrainer:
                 e1.record()
                 ev.append((e0, e1, n_pos * (1 + N)))
             # ---- gradient rows home; the owner reduces and updates each row once ---------------------------------
-            dist.all_to_all_single(self._ggot, self._cgrad)
+            self.comm.all_to_all_single(self._ggot, self._cgrad)
             # ---- replicated relation table: all-reduce the (tiny) dense gradient -----------------------------------
-            dist.all_reduce(self.rel_grad)
+            self.comm.all_reduce(self.rel_grad)
             be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
             # ---- one launch: identical relation update on every rank (touched=None: all rows) + this shard's rows
             be.update_pair((self.rel, self.rel_acc, self.rel_grad, None, True),
@@ -322,7 +358,7 @@ class ShardedRelationTrainer:
         mine = torch.zeros(pad, self.stride, dtype=self.ent.dtype, device=self.device)
         mine[:self.n_local] = self.ent
         parts = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(parts, mine)
+        self.comm.all_gather(parts, mine)
         full = torch.zeros(self.n_ent, self.dim, dtype=self.ent.dtype, device=self.device)
         for r in range(self.world):
             n = len(range(r, self.n_ent, self.world))
@@ -333,6 +369,6 @@ class ShardedRelationTrainer:
         if int(self._overflow.item()):
             raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded: results of this epoch are invalid")
         t = self.loss_ring.sum()
-        dist.all_reduce(t)
+        self.comm.all_reduce(t)
         self.loss_ring.zero_()
         return float(t)

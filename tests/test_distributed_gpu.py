@@ -53,3 +53,86 @@ def test_one_rank_sharded_equals_single_table_path(lookahead):
         assert float(tr.ent_grad.abs().max()) == 0.0
     finally:
         dist.destroy_process_group()
+
+
+# ---- two ranks sharing the one GPU: world_size-2 run of the DEVICE kernels (HipBackend) ------------------------------
+N_ENT2, N_REL2, DIM2, B2, NEG2, STEPS2, SEED2 = 3000, 20, 75, 300, 8, 7, 11
+
+
+def _two_rank_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
+        from multike_amd.synthetic import SyntheticKGs
+        torch.cuda.set_device(0)
+        kgs = SyntheticKGs(n_ent=N_ENT2, n_rel=N_REL2, seed=SEED2)
+        rng = np.random.default_rng(SEED2)
+        ent0 = mo.xavier_truncated_normal((N_ENT2, DIM2), rng)
+        rel0 = mo.xavier_truncated_normal((N_REL2, DIM2), rng)
+        tr = ShardedRelationTrainer(kgs, ent0, rel0, B2, NEG2, rank, world, seed=SEED2, lr=0.02, comm=HostStagedComm(), lookahead=0)
+        tr.keep_stats = True
+        stats = []
+        for i in range(STEPS2):
+            tr.step(i)
+            stats.append(tr.stats())
+        full = tr.gather_entity_table().cpu().numpy()
+        loss = tr.epoch_loss()
+        gmax = float(tr.ent_grad.abs().max())
+        if rank == 0:
+            ret.put((full, tr.rel[:, :DIM2].cpu().numpy().copy(), loss, stats, gmax))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_equal_single_process_oracle():
+    """world_size 2 with the HIP backend: both ranks run their kernels on cuda:0, the collectives are staged through gloo
+    (`HostStagedComm`) because RCCL refuses two ranks on one device.  Owner = id % 2, remote rows, gradient rows coming
+    home from another rank, per-epoch `mke_neg_sample_at`, relation all-reduce -- against the float64 dense oracle on the
+    same global batches."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as co
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss, stats, gmax = ret.get(timeout=480)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    kgs = SyntheticKGs(n_ent=N_ENT2, n_rel=N_REL2, seed=SEED2)
+    rng = np.random.default_rng(SEED2)
+    e = mo.xavier_truncated_normal((N_ENT2, DIM2), rng).astype(np.float32).astype(np.float64)
+    r = mo.xavier_truncated_normal((N_REL2, DIM2), rng).astype(np.float32).astype(np.float64)
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None, device="cpu"),
+                          KGSide(kgs.entities(1), None, device="cpu"), B2 * world, NEG2, device="cpu", seed=SEED2)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    ph, pr, pt = (x.numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+    tot = 0.0
+    assert STEPS2 <= bat.steps
+    for st in range(STEPS2):
+        lo, hi = int(bat.off[st]), int(bat.off[st + 1])
+        mid = lo + int(bat.cnt1[st])
+        parts = []
+        for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+            elo, ehi = kgs.ent_range[k]
+            parts.append(co.neg_sample(ph[a:b], pr[a:b], pt[a:b], NEG2, ehi - elo, ent_lo=elo, known=sets[k], seed=(SEED2, 0),
+                                       stream_id=k, pos_offset=a))
+        neg = [np.concatenate([parts[0][i], parts[1][i]]) for i in range(3)]
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, (ph[lo:hi], pr[lo:hi], pt[lo:hi]), neg, 0.02)
+        tot += L
+    np.testing.assert_allclose(loss, tot, rtol=2e-6)
+    np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
+    assert gmax == 0.0
+    assert all(x["remote_rows"] > 0 and x["overflow"] == 0 for x in stats)
