@@ -104,9 +104,19 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (multike_amd has no CPU path)"
+    # MKE_BENCH_COMM=staged: dry run of the multi-rank flow on fewer GPUs than ranks (ranks share devices, collectives go
+    # through gloo staged over the host).  Exercises launch / barrier / max-over-ranks / rank-0 output; its number is NOT a
+    # benchmark result and is labelled as such.
+    staged = os.environ.get("MKE_BENCH_COMM", "") == "staged"
+    if staged:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 and staged:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elif world > 1:
         import torch.distributed as dist
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -130,8 +140,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        from multike_amd.distributed import ShardedRelationTrainer
-        trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234)
+        from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
+        trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, comm=HostStagedComm() if staged else None)
         trainer.bat.shuffle()
         run_step = trainer.step
         n_steps_epoch = trainer.steps
@@ -216,7 +226,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     scored = sum(triples_of(i) for i in range(args.warmup, args.warmup + args.steps))
@@ -285,7 +295,8 @@ def main():
         out = {
             "metric": "scored triples/sec (pos+neg)", "value": value, "unit": "triples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not staged else "synthetic; DRY RUN: ranks share GPUs, collectives staged through the host (not a result)",
             "config": {"workload": "relation-view ITC train step (sampler + fused score/grad + Adagrad), "
                                    f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}"
                                    + (f" per GPU, entity rows sharded id%{world}" if sharded else ""),

@@ -41,3 +41,24 @@ def test_n1_line():
 def test_sharded_line_one_rank():
     d = _run(["--force-sharded"])
     assert d["n_gpus"] == 1 and d["roofline"]["achieved"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_launch_dry_run():
+    """The driver's N>1 launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with two
+    ranks sharing the one GPU and host-staged collectives (MKE_BENCH_COMM=staged): rendezvous, barriers, max over ranks,
+    one JSON line from rank 0 only, whole-job aggregate.  The number itself is not a result (and says so)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MKE_BENCH_COMM="staged")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "DRY RUN" in d["data"]
+    assert d["config"]["scored_per_step"] == 2 * d["config"]["batch"] * (1 + d["config"]["neg"])
+    assert abs(d["value"] - d["config"]["scored_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
+    assert "cpu_baseline" not in d
