@@ -28,6 +28,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The LDS strips of k_attr_conv are private to a wavefront: ordering its own LDS writes before its own later reads needs
+// no block barrier, only that the writes have been issued to the LDS (in-order per wave) and that the compiler does not
+// move the reads up.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct ConvParams {
   const float* __restrict__ attr;
   int attr_stride, attr_norm;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       }
       if (lane < 4) xs[h][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
     }
-    __syncthreads();
+    wave_lds_sync();
     // ---- conv1 ---------------------------------------------------------------------------------------------
     float c1[2][2][WPL];
 #pragma unroll
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) c1s[h][f][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
     }
-    __syncthreads();
+    wave_lds_sync();
     // ---- conv2 + width normalisation -----------------------------------------------------------------------
     float c2[2][2][WPL], nrm[2][2], ssq[2][2];
 #pragma unroll
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
           }
         }
       }
-      __syncthreads();  // LDS strips are rewritten by the next iteration
+      wave_lds_sync();  // LDS strips are rewritten by the next iteration
       continue;
     }
     if constexpr (BWD) {
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
           for (int f = 0; f < 2; ++f) d2s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
       }
-      __syncthreads();
+      wave_lds_sync();
       // ---- conv2 transposed -> dc1, tanh', parameter gradients of conv1 -----------------------------------
       float dp1[2][2][WPL];
 #pragma unroll
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
           for (int f = 0; f < 2; ++f) d1s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
       }
-      __syncthreads();
+      wave_lds_sync();
       // ---- conv1 transposed -> dx, batch-norm affine backward, attribute-row gradient ---------------------
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
@@ -309,10 +318,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         if (live && w < d && p.gattr) atomic_add_f32(p.gattr + (int64_t)ra * p.attr_stride + w, dx[0] * gam[i] * bn_s);
       }
       if (live && lane == 0 && p.gattr) p.tattr[ra] = p.tag;
-      __syncthreads();
+      wave_lds_sync();
     }
   }
 
+  __syncthreads();  // the strips are reused by the block-level reduction below
   if constexpr (BWD) {
     // ---- block-reduce the parameter gradients, one atomic per block per scalar --------------------------------
     // 16-lane sums stay in registers (DPP); the 16 quarter-wave leaders of the block park them in LDS and 52 threads
