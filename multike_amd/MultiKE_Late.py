@@ -115,17 +115,51 @@ class _ScheduledMultiKE(MultiKE):
         self._ckga_attr_triples = pam.sup_attribute_alignment_triples1 + pam.sup_attribute_alignment_triples2
 
     def _train_views(self, i):
-        """One epoch of the six view / cross-KG phases in the reference's order."""
+        """One epoch of the six view / cross-KG phases in the reference's order.
+
+        The relation group (relation view -> ckge-rel -> ckgp-rel: rv_ent_embeds, rel_embeds) and the attribute group
+        (attribute view -> ckge-attr -> ckga-attr: av_ent_embeds, attr_embeds, the CNNs) touch disjoint state, so they
+        commute; with `overlap_views` the two groups are enqueued on two HIP streams and meet again before common-space
+        learning.  Each group is a chain of small, launch-floor-dominated kernels that leaves most of the chip idle, and
+        nothing synchronises inside the epoch (the loss read-backs are deferred to the end), unlike the per-step overlap
+        schemes that were measured and rejected for the relation view alone."""
         a = self.args
         n1, n2 = self._neighbors
-        self.train_relation_view_1epo(i, self._rel_steps, self._rel_tasks, None, n1, n2)
-        self.train_cross_kg_entity_inference_relation_view_1epo(i, self._ckge_rel_triples)
-        if i > a.start_predicate_soft_alignment:
-            self.train_cross_kg_relation_inference_1epo(i, self._ckgp_rel_triples)
-        self.train_attribute_view_1epo(i, self._attr_steps, self._attr_tasks, None, n1, n2)
-        self.train_cross_kg_entity_inference_attribute_view_1epo(i, self._ckge_attr_triples)
-        if i > a.start_predicate_soft_alignment:
-            self.train_cross_kg_attribute_inference_1epo(i, self._ckga_attr_triples)
+        soft = i > a.start_predicate_soft_alignment
+
+        def relation_group():
+            self.train_relation_view_1epo(i, self._rel_steps, self._rel_tasks, None, n1, n2)
+            self.train_cross_kg_entity_inference_relation_view_1epo(i, self._ckge_rel_triples)
+            if soft:
+                self.train_cross_kg_relation_inference_1epo(i, self._ckgp_rel_triples)
+
+        def attribute_group():
+            self.train_attribute_view_1epo(i, self._attr_steps, self._attr_tasks, None, n1, n2)
+            self.train_cross_kg_entity_inference_attribute_view_1epo(i, self._ckge_attr_triples)
+            if soft:
+                self.train_cross_kg_attribute_inference_1epo(i, self._ckga_attr_triples)
+
+        if not getattr(self, "overlap_views", True) or a.optimizer not in ("Adagrad", "SGD"):
+            relation_group()
+            attribute_group()
+            return
+        import torch
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        self._defer_losses, self._pending = True, []
+        try:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                relation_group()
+            attribute_group()
+            main.wait_stream(side)
+        finally:
+            self._defer_losses = False
+        for p in self._pending:      # enqueue order = the reference's print order
+            p.finish()
+        self._pending = []
 
     def _update_predicate_alignment(self):
         """code/MultiKE_CSL.py:80-87 / code/MultiKE_Late.py:244-251 (host-side soft predicate alignment)."""

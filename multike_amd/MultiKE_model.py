@@ -149,6 +149,19 @@ class _TripleList:
         return cols, (None if self.w is None else self.w[il]), idx
 
 
+class _EpochLoss:
+    """The closing line of a `train_*_1epo` call, separated from the enqueueing of its kernels: reading the loss is the only
+    host synchronisation of an epoch, so the drivers can enqueue several independent phases before reading any of them."""
+
+    def __init__(self, text, epoch, value, denom, start, scale=1.0):
+        self.text, self.epoch, self.value, self.denom, self.start, self.scale = text, epoch, value, denom, start, scale
+
+    def finish(self):
+        loss = (float(self.value) if self.value is not None else 0.0) * self.scale / max(self.denom, 1)
+        print('epoch {} of {}, avg. loss: {:.4f}, time: {:.4f}s'.format(self.epoch, self.text, loss, time.time() - self.start))
+        return loss
+
+
 class MultiKE:
 
     def __check_args(self):
@@ -169,6 +182,8 @@ class MultiKE:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._lists: dict = {}
+        self._defer_losses = False      # drivers set it while they enqueue independent phases on two streams
+        self._pending: list = []
         if self.args.optimizer not in _HIP_OPTS + _DENSE_OPTS:
             raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: Adagrad, SGD, Adam or Adadelta")
 
@@ -303,6 +318,12 @@ class MultiKE:
                 valid[e] = 1
             side.set_neighbours(torch.as_tensor(table, device=self.device), torch.as_tensor(valid, device=self.device))
 
+    def _done(self, pending: _EpochLoss):
+        if self._defer_losses:
+            self._pending.append(pending)
+            return pending
+        return pending.finish()
+
     # --- training for multi-view embeddings ---------------------------------------------------------------
     def train_relation_view_1epo(self, epoch, triple_steps, steps_tasks, batch_queue, neighbors1, neighbors2):
         """code/MultiKE_model.py:291-317.  `steps_tasks` / `batch_queue` are accepted for driver compatibility; batches
@@ -310,11 +331,17 @@ class MultiKE:
         start = time.time()
         self._set_neighbours(neighbors1, neighbors2)
         run, b = self._rel_runner, self._rel_batcher
+        # the epoch buffers are re-created by every shuffle; they may have been allocated on another stream than the one
+        # this epoch runs on (the drivers run this phase on a side stream): tell the allocator, or the old buffers could
+        # be handed out again while this stream still reads them
+        cur = torch.cuda.current_stream()
+        for t_ in (b.pos_h, b.pos_r, b.pos_t, b.pos_kg):
+            t_.record_stream(cur)
         steps = min(triple_steps, b.steps)
         trained = int(b.off[steps])
         if run is not None:
             run.run(0, steps)
-            epoch_loss = float(run.loss[:steps].sum()) / max(trained, 1)
+            total = run.loss[:steps].sum()
         else:   # Adam / Adadelta: step-wise (sampler launch -> fused score/gradient -> whole-table updates)
             from .sampling import sample_negatives
             N, total = b.neg_per_pos, None
@@ -326,10 +353,8 @@ class MultiKE:
                 lp = self.engine.relation_step(self.rv_ent_embeds, self.rel_embeds, "relation", pos, neg, N,
                                                lr=self.args.learning_rate, optimizer=self.args.optimizer).sum()
                 total = lp if total is None else total + lp
-            epoch_loss = (float(total) if total is not None else 0.0) / max(trained, 1)
         self._rel_batcher.shuffle()  # random.shuffle of both positive lists (:314-315)
-        print('epoch {} of rel. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
-        return epoch_loss
+        return self._done(_EpochLoss('rel. view', epoch, total, trained, start))
 
     def _attr_lists(self):
         pam = self.predicate_align_model
@@ -369,7 +394,7 @@ class MultiKE:
         b1, b2 = kg_batch_split(l1.n, l2.n, B)
         off, d1, d2 = self._attr_epoch_layout(l1.n, l2.n, b1, b2, triple_steps)
         total = int(off[-1])
-        epoch_loss = 0.0
+        value = None
         if total > 0:
             i32, f32 = torch.int32, torch.float32
             cols = [torch.empty(total, dtype=i32, device=self.device) for _ in range(3)] + [torch.empty(total, dtype=f32, device=self.device)]
@@ -380,12 +405,10 @@ class MultiKE:
                 perm = self._attr_perm[li]
                 for k, src in enumerate(lst.cols + (lst.w,)):
                     cols[k][dest] = src[:m] if perm is None else src[perm[:m]]
-            ring = self._run_attr_steps(self._attr_cnn, cols[:3], cols[3], off, 1.0, "attribute")
-            epoch_loss = float(ring.sum()) / total
+            value = self._run_attr_steps(self._attr_cnn, cols[:3], cols[3], off, 1.0, "attribute").sum()
         # random.shuffle of both weighted lists (:342-343): a device permutation applied when the epoch is laid out
         self._attr_perm = [torch.randperm(l.n, generator=self._gen, device=self.device) if l.n else None for l in (l1, l2)]
-        print('epoch {} of att. view, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
-        return epoch_loss
+        return self._done(_EpochLoss('att. view', epoch, value, total, start))
 
     # --- training for cross-kg identity inference ----------------------------------------------------------
     def _next_sample_stream(self):
@@ -407,9 +430,7 @@ class MultiKE:
         cols, w, idx = lst.sample_epoch(bs, steps, seed, stream)
         self._last_sample = (seed, stream, lst.n, bs, steps)   # tests replay it with oracle.sampler_oracle.distinct_sample
         ring = run_fn(cols, w, np.arange(steps + 1, dtype=np.int64) * bs)
-        epoch_loss = float(ring.sum()) / (steps * bs)
-        print('epoch {} of {}, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, label, epoch_loss, time.time() - start))
-        return epoch_loss
+        return self._done(_EpochLoss(label, epoch, ring.sum(), steps * bs, start))
 
     def _run_attr_steps(self, cnn, cols, w, off, scale, opt_name):
         """All steps of an attribute-type epoch: one native call (Adagrad / SGD) or a step-wise loop (Adam / Adadelta)."""

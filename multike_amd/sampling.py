@@ -142,6 +142,13 @@ class RelationBatcher:
         self.pos_kg = torch.as_tensor(kg, device=self.device)  # fixed across epochs: only the contents shuffle
 
     def _materialise(self, perm1, perm2):
+        if self.device.type == "cuda":
+            # the lists are replaced below; if this epoch runs on another stream than the one they were allocated on
+            # (drivers run the relation group on a side stream), the allocator must not hand the old ones out again
+            # before this stream has read them
+            cur = torch.cuda.current_stream(self.device)
+            for t in (self.t1, self.t2):
+                t.record_stream(cur)
         t1 = self.t1 if perm1 is None else self.t1[perm1]
         t2 = self.t2 if perm2 is None else self.t2[perm2]
         allt = torch.cat([t1, t2], 0)[self._src]  # epoch order, step-contiguous

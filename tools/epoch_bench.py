@@ -23,6 +23,13 @@ phases = [("relation view", lambda i: m.train_relation_view_1epo(i, m._rel_steps
           ("ckga attribute", lambda i: m.train_cross_kg_attribute_inference_1epo(i, m._ckga_attr_triples)),
           ("common space", lambda i: m.train_common_space_learning_1epo(i, m._entity_list))]
 import contextlib, io
+for ov in (False, True):
+    m.overlap_views = ov
+    for i in range(1, 4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            m._train_views(i); m.train_common_space_learning_1epo(i, m._entity_list)
+        torch.cuda.synchronize(); print(f"driver epoch (overlap_views={ov}): {(time.perf_counter() - t0) * 1e3:.1f} ms")
 for i in range(1, epochs + 1):
     tot = 0.0
     line = []
