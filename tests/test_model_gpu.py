@@ -184,3 +184,45 @@ def test_drivers_run_end_to_end(mode):
     assert all(np.isfinite(v) for v in res.values())
     assert res["nv"] > 0.5                       # the name view alone aligns the synthetic pairs
     assert model._neighbors[0] is not None and model._rel_batcher.side1.cand_table is not None   # truncated mode active
+
+
+def test_two_stream_epochs_equal_single_stream_epochs():
+    """The drivers enqueue the relation group and the attribute group of an epoch on two streams (disjoint state).  Same
+    seeds => same batches => the tables after a few epochs must agree with the single-stream schedule up to fp32
+    atomic-order noise.  One model also alternates between the two schedules, the case in which a buffer allocated on one
+    stream is released while the other stream still reads it (caught once as a memory fault at C2 scale)."""
+    import contextlib
+    import io
+    from multike_amd.MultiKE_CSL import MultiKE_CV
+    from multike_amd.synthetic import SyntheticData, synthetic_args
+
+    def run(schedule):
+        data = SyntheticData(n_ent=40_000, n_rel=60, n_attr=40, n_values=5000, dim=32, seed=3)
+        args = synthetic_args(dim=32, batch_size=4000, attribute_batch_size=4000, entity_batch_size=4000, neg_triple_num=8,
+                              learning_rate=0.01, start_predicate_soft_alignment=0, neg_sampling="uniform")
+        m = MultiKE_CV(data, args, data.predicate_align_model)
+        m._prepare()
+        losses = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for i, ov in enumerate(schedule, 1):
+                m.overlap_views = ov
+                m._train_views(i)
+                losses.append(m.train_common_space_learning_1epo(i, m._entity_list))
+        torch.cuda.synchronize()
+        return m, losses
+
+    import torch
+    a, la = run([False] * 6)
+    a2, _ = run([False] * 6)          # same schedule twice: the run-to-run noise of fp32 atomics through six Adagrad epochs
+    b, lb = run([True] * 6)
+    c, lc = run([False, True, True, False, True, True])
+    names = ("rv_ent_embeds", "av_ent_embeds", "rel_embeds", "attr_embeds", "ent_embeds")
+    tab = lambda m, n: getattr(m, n).raw().cpu().numpy()
+    for other, lo in ((b, lb), (c, lc)):
+        np.testing.assert_allclose(lo, la, rtol=1e-4)
+        for name in names:
+            noise = np.abs(tab(a2, name) - tab(a, name))
+            diff = np.abs(tab(other, name) - tab(a, name))
+            # same statistics as two runs of one schedule (a stale or recycled buffer would move whole rows by O(0.1))
+            assert float(diff.mean()) <= 3.0 * float(noise.mean()) + 1e-8, (name, float(diff.mean()), float(noise.mean()))
+            assert float(diff.max()) <= 5e-3, (name, float(diff.max()), float(noise.max()))
