@@ -130,17 +130,11 @@ class SyntheticData:
 
 
 def synthetic_args(**over):
-    """The keys of code/args.json that the hot path reads, with the reference's defaults."""
-    from .utils import ARGs
-    d = dict(training_data="synthetic/", output="/tmp/multike_out/", alignment_module="swapping", dim=75,
-             learning_rate=0.001, optimizer="Adagrad", max_epoch=200, shared_learning_max_epoch=200, batch_size=5000,
-             entity_batch_size=5000, attribute_batch_size=5000, neg_triple_num=10, neg_sampling="truncated",
-             truncated_epsilon=0.98, truncated_freq=20, batch_threads_num=4, test_threads_num=8, start_valid=100,
-             eval_freq=10, top_k=[1, 5, 10, 50], orthogonal_weight=2, cv_name_weight=1, cv_weight=1,
-             start_predicate_soft_alignment=10, predicate_soft_sim=0.85, predicate_init_sim=0.90, ITC_learning_rate=0.004,
-             seed=0)
+    """`utils.default_args()` (the reference's hyper-parameters) pointed at synthetic data, plus a seed."""
+    from .utils import default_args
+    d = dict(training_data="synthetic/", output="/tmp/multike_out/", seed=0)
     d.update(over)
-    return ARGs(d)
+    return default_args(**d)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -25,6 +25,30 @@ def load_args(file_path):
     return ARGs(args_dict)
 
 
+def default_args(**over):
+    """The hyper-parameters the reference ships in code/args.json (:1-52), grouped by what reads them; paths are left
+    empty.  `load_args(file)` on a user's own JSON file overrides any subset of them."""
+    d = dict(
+        # data
+        training_data="", output="output/results/", word2vec_path="", dataset_division="631/", alignment_module="swapping",
+        # literal auto-encoder (code/literal_encoder.py)
+        encoder_epoch=100, encoder_active="thah", encoder_normalize=True, retrain_literal_embeds=False, literal_normalize=True,
+        # embeddings and optimisation
+        dim=75, optimizer="Adagrad", learning_rate=0.001, relation_learning_rate=0.005, ITC_learning_rate=0.004,
+        max_epoch=200, shared_learning_max_epoch=200, batch_size=5000, entity_batch_size=5000, attribute_batch_size=5000,
+        # negative sampling
+        neg_triple_num=10, neg_sampling="truncated", truncated_epsilon=0.98, truncated_freq=20,
+        # host-side worker counts of the reference (accepted, unused: batches are produced on the device)
+        batch_threads_num=4, test_threads_num=8,
+        # validation / early stopping
+        start_valid=100, eval_freq=10, stop_metric="mrr", top_k=[1, 5, 10, 50], is_save=True,
+        # view combination and predicate soft alignment
+        orthogonal_weight=2, cv_name_weight=1, cv_weight=1, start_predicate_soft_alignment=10, predicate_soft_sim=0.85,
+        predicate_init_sim=0.90)
+    d.update(over)
+    return ARGs(d)
+
+
 def task_divide(idx, n):
     """code/utils.py:35-49: n-1 chunks of total//n and a last chunk with the remainder; degenerate cases
     return a single task."""
