@@ -59,7 +59,7 @@ def test_one_rank_sharded_equals_single_table_path(lookahead):
 N_ENT2, N_REL2, DIM2, B2, NEG2, STEPS2, SEED2 = 3000, 20, 75, 300, 8, 7, 11
 
 
-def _two_rank_worker(rank, world, port, ret):
+def _two_rank_worker(rank, world, port, ret, lookahead=0):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,7 +72,7 @@ def _two_rank_worker(rank, world, port, ret):
         rng = np.random.default_rng(SEED2)
         ent0 = mo.xavier_truncated_normal((N_ENT2, DIM2), rng)
         rel0 = mo.xavier_truncated_normal((N_REL2, DIM2), rng)
-        tr = ShardedRelationTrainer(kgs, ent0, rel0, B2, NEG2, rank, world, seed=SEED2, lr=0.02, comm=HostStagedComm(), lookahead=0)
+        tr = ShardedRelationTrainer(kgs, ent0, rel0, B2, NEG2, rank, world, seed=SEED2, lr=0.02, comm=HostStagedComm(), lookahead=lookahead)
         tr.keep_stats = True
         stats = []
         for i in range(STEPS2):
@@ -88,11 +88,13 @@ def _two_rank_worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_equal_single_process_oracle():
+@pytest.mark.parametrize("lookahead", [0, 2])
+def test_two_ranks_on_one_gpu_equal_single_process_oracle(lookahead):
     """world_size 2 with the HIP backend: both ranks run their kernels on cuda:0, the collectives are staged through gloo
     (`HostStagedComm`) because RCCL refuses two ranks on one device.  Owner = id % 2, remote rows, gradient rows coming
     home from another rank, per-epoch `mke_neg_sample_at`, relation all-reduce -- against the float64 dense oracle on the
-    same global batches."""
+    same global batches.  lookahead = 2: the plan half of each step (row set, id exchange, remap) runs two steps ahead on
+    its own stream and process group."""
     import socket
     import torch.multiprocessing as mp
     from oracle import c_oracle as co
@@ -102,7 +104,7 @@ def test_two_ranks_on_one_gpu_equal_single_process_oracle():
     world = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, lookahead)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, stats, gmax = ret.get(timeout=480)
