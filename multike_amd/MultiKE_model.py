@@ -289,13 +289,24 @@ class MultiKE:
                         self.av_ent_embeds.eval(), self.rel_embeds.eval(), self.attr_embeds.eval())
 
     # --- helpers ----------------------------------------------------------------------------------------------
-    def _list(self, triples) -> _TripleList:
-        key = id(triples)
+    _CACHE_MAX = 24
+
+    def _cached(self, key_obj, build):
+        """Device mirror of a host list, cached per list OBJECT.  The entry keeps a reference to the list, so its id()
+        cannot be recycled for a different list while the entry lives (the predicate lists are re-created every ten
+        epochs); the cache is bounded, oldest entry out."""
+        key = id(key_obj)
         hit = self._lists.get(key)
-        if hit is None or hit[0] != len(triples):
-            hit = (len(triples), _TripleList(triples, self.device))
+        if hit is None or hit[0] is not key_obj or hit[1] != len(key_obj):
+            hit = (key_obj, len(key_obj), build(key_obj))
+            self._lists.pop(key, None)
             self._lists[key] = hit
-        return hit[1]
+            while len(self._lists) > self._CACHE_MAX:
+                self._lists.pop(next(iter(self._lists)))
+        return hit[2]
+
+    def _list(self, triples) -> _TripleList:
+        return self._cached(triples, lambda t: _TripleList(t, self.device))
 
     def _set_neighbours(self, neighbors1, neighbors2):
         """Truncated-sampling dicts {entity: [k neighbours]} (code/base/batch.py:119-150) -> device candidate tables."""
@@ -358,11 +369,12 @@ class MultiKE:
 
     def _attr_lists(self):
         pam = self.predicate_align_model
-        key = (id(pam.attribute_triples_w_weights1), id(pam.attribute_triples_w_weights2))
-        if getattr(self, "_attr_key", None) != key:
-            self._attr_key = key
-            self._attr1 = _TripleList(pam.attribute_triples_w_weights1, self.device)
-            self._attr2 = _TripleList(pam.attribute_triples_w_weights2, self.device)
+        w1, w2 = pam.attribute_triples_w_weights1, pam.attribute_triples_w_weights2
+        held = getattr(self, "_attr_key", None)          # the list objects themselves: ids alone could be recycled
+        if held is None or held[0] is not w1 or held[1] is not w2:
+            self._attr_key = (w1, w2)
+            self._attr1 = _TripleList(w1, self.device)
+            self._attr2 = _TripleList(w2, self.device)
             self._attr_perm = [None, None]
         return self._attr1, self._attr2
 
@@ -489,12 +501,7 @@ class MultiKE:
 
     # --- shared / common space ------------------------------------------------------------------------------
     def _entity_tensor(self, entities):
-        key = ("ents", id(entities), len(entities))
-        t = self._lists.get(key)
-        if t is None:
-            t = _dev_i32(entities, self.device)
-            self._lists[key] = t
-        return t
+        return self._cached(entities, lambda e: _dev_i32(e, self.device))
 
     def _entity_batches(self, entities, batch_size):
         t = self._entity_tensor(entities)
