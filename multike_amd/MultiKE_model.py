@@ -310,10 +310,10 @@ class MultiKE:
 
     def _set_neighbours(self, neighbors1, neighbors2):
         """Truncated-sampling dicts {entity: [k neighbours]} (code/base/batch.py:119-150) -> device candidate tables."""
-        ids = (id(neighbors1), id(neighbors2))
-        if ids == self._neighbor_ids:
+        held = self._neighbor_ids            # the objects last installed (held, so that their ids cannot be recycled)
+        if held[0] is neighbors1 and held[1] is neighbors2 and getattr(self, "_neighbours_installed", False):
             return
-        self._neighbor_ids = ids
+        self._neighbor_ids, self._neighbours_installed = (neighbors1, neighbors2), True
         for side, nb in ((self._rel_batcher.side1, neighbors1), (self._rel_batcher.side2, neighbors2)):
             if nb is None or (isinstance(nb, dict) and not nb):
                 side.set_neighbours(None, None)
