@@ -15,21 +15,34 @@ import torch
 from ..sampling import KGSide, KnownTripleSet, kg_batch_split, sample_negatives
 
 _cache: dict = {}
+_CACHE_MAX = 16
 _call_counter = [0]
 
 
+def _cached(objs, extra, build):
+    """Device-side mirror of host containers, cached per container OBJECT: the entry holds the objects, so an id() cannot
+    be recycled for another container while the entry lives; bounded, oldest entry out."""
+    key = tuple(id(o) for o in objs) + tuple(extra)
+    hit = _cache.get(key)
+    if hit is None or any(a is not b for a, b in zip(hit[0], objs)):
+        hit = (tuple(objs), build())
+        _cache.pop(key, None)
+        _cache[key] = hit
+        while len(_cache) > _CACHE_MAX:
+            _cache.pop(next(iter(_cache)))
+    return hit[1]
+
+
 def _known(triples_set, device):
-    key = ("known", id(triples_set), len(triples_set))
-    if key not in _cache:
-        arr = np.asarray(sorted(triples_set), dtype=np.int32).reshape(-1, 3)
+    def build():
+        arr = np.array(list(triples_set), dtype=np.int32).reshape(-1, 3)
         t = torch.as_tensor(arr, device=device)
-        _cache[key] = KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
-    return _cache[key]
+        return KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
+    return _cached((triples_set,), ("known", len(triples_set)), build)
 
 
 def _side(entities_list, triples_set, neighbor, device):
-    key = ("side", id(entities_list), len(entities_list), id(triples_set), id(neighbor))
-    if key not in _cache:
+    def build():
         side = KGSide(entities_list, _known(triples_set, device) if triples_set is not None else None, device=device)
         if neighbor:
             n_total = max(max(entities_list), max(neighbor)) + 1
@@ -40,8 +53,8 @@ def _side(entities_list, triples_set, neighbor, device):
                 table[e] = np.asarray(lst[:k], dtype=np.int32)
                 valid[e] = 1
             side.set_neighbours(torch.as_tensor(table, device=device), torch.as_tensor(valid, device=device))
-        _cache[key] = side
-    return _cache[key]
+        return side
+    return _cached((entities_list, triples_set, neighbor), ("side", len(entities_list)), build)
 
 
 def generate_pos_triples(triples, batch_size, step, is_fixed_size=False):
