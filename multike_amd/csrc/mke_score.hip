@@ -244,7 +244,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                   for (int k = 0; k < FPL; ++k) {
                     const float a = fmaf(g[k], g[k], A[u][k]);
                     ap[k * 16] = a;
-                    wp[k * 16] = C[u][k] - p.lr * g[k] / sqrtf(a);
+                    wp[k * 16] = C[u][k] - p.lr * g[k] * adagrad_scale(a);
                   }
                 } else {
 #pragma unroll

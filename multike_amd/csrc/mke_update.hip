@@ -75,7 +75,7 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 #pragma unroll
     for (int k = 0; k < FPL; ++k) {
       a[k] = fmaf(g[k], g[k], a[k]);
-      w[k] -= p.lr * g[k] / sqrtf(a[k]);
+      w[k] -= p.lr * g[k] * adagrad_scale(a[k]);
     }
 #pragma unroll
     for (int k = 0; k < FPL; ++k) ap[k * 16] = a[k];
