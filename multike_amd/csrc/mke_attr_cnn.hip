@@ -88,13 +88,20 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     bet[i] = w < d ? beta[w] : 0.f;
   }
   // parameter-gradient accumulators (BWD)
-  float a_k1[BWD ? 16 : 1], a_k2[BWD ? 32 : 1], a_b1[2], a_b2[2], a_gam[WPL], a_bet[WPL];
+  // The 52 conv-parameter gradients are NOT kept in registers: each is reduced over its quarter-wave as soon as it is
+  // formed and added to the quarter's own LDS slot (s_part).  48 + 4 long-lived accumulators pushed the backward kernel to
+  // 208 unified registers = 2 waves per SIMD = three rounds of waves for 5000 triples.
+  __shared__ float s_part[BWD ? CNN_NCONV : 1][17];
+  const int pq = (lane >> 4) + 4 * wv;
+  const bool plead = (lane & 15) == 0;
+  auto park = [&](int idx, float v) {
+    v = sub16_sum(v);
+    if (plead) atomicAdd(&s_part[idx][pq], v);   // the slot belongs to this quarter-wave: no contention
+  };
+  float a_gam[WPL], a_bet[WPL];
   if constexpr (BWD) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_k1[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) a_k2[i] = 0.f;
-    a_b1[0] = a_b1[1] = a_b2[0] = a_b2[1] = 0.f;
+    for (int i = threadIdx.x; i < CNN_NCONV * 17; i += MKE_BLOCK) (&s_part[0][0])[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < WPL; ++i) a_gam[i] = a_bet[i] = 0.f;
   }
@@ -248,15 +255,29 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
             const float dc2 = ssq[h][f] > MKE_L2_EPS ? nrm[h][f] * (dy[h][f][i] - y * dot[h][f]) : nrm[h][f] * dy[h][f][i];
             dp2[h][f][i] = (w < d) ? dc2 * (1.0f - c2[h][f][i] * c2[h][f][i]) : 0.f;
             d2s[h][f][w + 2] = dp2[h][f][i];  // index w+2 <-> width w
-            a_b2[f] += dp2[h][f][i];
-#pragma unroll
-            for (int kh = 0; kh + h < 2; ++kh)
-#pragma unroll
-              for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                  a_k2[((kh * 4 + kw) * 2 + c) * 2 + f] = fmaf(dp2[h][f][i], c1s[h + kh][c][w + kw], a_k2[((kh * 4 + kw) * 2 + c) * 2 + f]);
           }
+      }
+      // parameter gradients of conv2, one scalar at a time: db2[f] = sum dp2[.][f][.],
+      // dK2[kh][kw][c][f] = sum_{h, w} dp2[h][f][w] * c1[h + kh][c][w + kw - 1]
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) v += dp2[0][f][i] + dp2[1][f][i];
+        park(50 + f, v);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              float a = 0.f;
+#pragma unroll
+              for (int h = 0; h + kh < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < WPL; ++i) a = fmaf(dp2[h][f][i], c1s[h + kh][c][lane + 64 * i + kw], a);
+              park(18 + ((kh * 4 + kw) * 2 + c) * 2 + f, a);
+            }
       }
       if (lane < 4) {
 #pragma unroll
@@ -283,11 +304,25 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
                 for (int f = 0; f < 2; ++f) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], d2s[hh - kh][f][w + 3 - kw], acc);
             dp1[hh][c][i] = (w < d) ? acc * (1.0f - c1[hh][c][i] * c1[hh][c][i]) : 0.f;
             d1s[hh][c][w + 2] = dp1[hh][c][i];
-            a_b1[c] += dp1[hh][c][i];
+          }
+      }
+      // parameter gradients of conv1: db1[c], dK1[kh][kw][0][c] = sum_{h, w} dp1[h][c][w] * x[h + kh][w + kw - 1]
 #pragma unroll
-            for (int kh = 0; kh + hh < 2; ++kh)
+      for (int c = 0; c < 2; ++c) {
+        float v = 0.f;
 #pragma unroll
-              for (int kw = 0; kw < 4; ++kw) a_k1[(kh * 4 + kw) * 2 + c] = fmaf(dp1[hh][c][i], xs[hh + kh][w + kw], a_k1[(kh * 4 + kw) * 2 + c]);
+        for (int i = 0; i < WPL; ++i) v += dp1[0][c][i] + dp1[1][c][i];
+        park(16 + c, v);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw) {
+            float a = 0.f;
+#pragma unroll
+            for (int hh = 0; hh + kh < 2; ++hh)
+#pragma unroll
+              for (int i = 0; i < WPL; ++i) a = fmaf(dp1[hh][c][i], xs[hh + kh][lane + 64 * i + kw], a);
+            park((kh * 4 + kw) * 2 + c, a);
           }
       }
       if (lane < 4) {
@@ -325,22 +360,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   __syncthreads();  // the strips are reused by the block-level reduction below
   if constexpr (BWD) {
     // ---- block-reduce the parameter gradients, one atomic per block per scalar --------------------------------
-    // 16-lane sums stay in registers (DPP); the 16 quarter-wave leaders of the block park them in LDS and 52 threads
-    // add the 16 partials up.  (First version: 52 full wave reductions + LDS atomics per wave = 20 of the kernel's
-    // 45 us.)  gamma / beta are per width position: the four waves' vectors go through the (now free) x / c1 strips.
-    __shared__ float s_part[CNN_NCONV][17];
-    {
-      const int q = (lane >> 4) + 4 * wv;
-      const bool lead = (lane & 15) == 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float v = sub16_sum(a_k1[i]); if (lead) s_part[i][q] = v; }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { const float v = sub16_sum(a_b1[i]); if (lead) s_part[16 + i][q] = v; }
-#pragma unroll
-      for (int i = 0; i < 32; ++i) { const float v = sub16_sum(a_k2[i]); if (lead) s_part[18 + i][q] = v; }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { const float v = sub16_sum(a_b2[i]); if (lead) s_part[50 + i][q] = v; }
-    }
+    // the 16 quarter-wave slots of every scalar were filled during the loop (`park`); 52 threads add them up.  (First
+    // version: 52 full wave reductions + LDS atomics per wave = 20 of the kernel's 45 us.)  gamma / beta are per width
+    // position: the four waves' vectors go through the (now free) x / c1 strips.
     float* gsum = &s_x[0][0][0];
     float* bsum = &s_c1[0][0][0][0];
     __syncthreads();
