@@ -15,7 +15,7 @@
 namespace mke {
 
 #ifndef MKE_SCORE_U
-#define MKE_SCORE_U 4
+#define MKE_SCORE_U 2
 #endif
 extern int g_score_splits;  // mke_set_option("score_splits")
 
@@ -121,9 +121,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       l2_normalize_row<FPL>(H, p.ent_norm);
       l2_normalize_row<FPL>(R, p.rel_norm);
       l2_normalize_row<FPL>(T, p.ent_norm);
-      float gH[FPL], gR[FPL], gT[FPL];  // gT holds the NEGATED t-gradient (sum of c*d)
+      float gH[FPL], gT[FPL];  // gT holds the NEGATED t-gradient (sum of c*d)
+      float gP[FPL];           // the positive's own c*d (quarter 0 of slice 0, else 0): gR = gH + gT - gP at the flush
+      float HR[FPL], RT[FPL];  // h + r and r - t of the positive: a negative's difference is one fma from them
 #pragma unroll
-      for (int k = 0; k < FPL; ++k) gH[k] = gR[k] = gT[k] = 0.f;
+      for (int k = 0; k < FPL; ++k) {
+        gH[k] = gT[k] = gP[k] = 0.f;
+        HR[k] = H[k] + R[k];
+        RT[k] = R[k] - T[k];
+      }
 
       if (s == 0 && q == 0) {  // the positive itself
         const float w = p.pw ? p.pw[g] : 1.0f;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         float x = 0.f;
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
-          d[k] = (H[k] + R[k]) - T[k];
+          d[k] = HR[k] - T[k];
           x = fmaf(d[k], d[k], x);
         }
         x = sub16_sum(x);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
           const float gd = c * d[k];
-          gH[k] += gd; gR[k] += gd; gT[k] += gd;
+          gH[k] += gd; gT[k] += gd; gP[k] = gd;
         }
       }
 
@@ -196,28 +202,29 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
               for (int k = 0; k < FPL; ++k) ss = fmaf(C[u][k], C[u][k], ss);
               cinv = rsqrtf(fmaxf(sub16_sum(ss), MKE_L2_EPS));
             }
+            // corrupt head: d = c^ + (r - t);  corrupt tail: d = (h + r) - c^   ->   d = base + (+-cinv) * C
             float d[FPL];
             float y = 0.f;
+            const float sc = sideH[u] ? cinv : -cinv;
 #pragma unroll
             for (int k = 0; k < FPL; ++k) {
-              const float cn = C[u][k] * cinv;
-              const float hh = sideH[u] ? cn : H[k];
-              const float tt = sideH[u] ? T[k] : cn;
-              d[k] = (hh + R[k]) - tt;
+              d[k] = fmaf(sc, C[u][k], sideH[u] ? RT[k] : HR[k]);
               y = fmaf(d[k], d[k], y);
             }
             y = sub16_sum(y);
-            loss += w[u] * softplus_f(-y);
+            // y >= 0: with t = exp(-y), softplus(-y) = log(1 + t) and sigmoid(-y) = t / (1 + t): one exp for both
+            const float t_ = __expf(-y);
+            const float s1 = 1.0f + t_;
+            loss += w[u] * __logf(s1);
             if (bwd) {
-              const float c = -2.0f * w[u] * p.scale * sigmoid_f(-y);
-              const float toH = sideH[u] ? 0.f : 1.f;
-              const float toT = sideH[u] ? 1.f : 0.f;
+              const float c = -2.0f * w[u] * p.scale * t_ * __builtin_amdgcn_rcpf(s1);
+              const float cH = sideH[u] ? 0.f : c;   // a corrupted tail leaves the positive's head in the triple, and vice versa
+              const float cT = sideH[u] ? c : 0.f;
 #pragma unroll
               for (int k = 0; k < FPL; ++k) {
+                gH[k] = fmaf(cH, d[k], gH[k]);
+                gT[k] = fmaf(cT, d[k], gT[k]);
                 d[k] *= c;
-                gR[k] += d[k];
-                gH[k] = fmaf(toH, d[k], gH[k]);
-                gT[k] = fmaf(toT, d[k], gT[k]);
               }
               bool in_place = false;
               if constexpr (X) in_place = cnt[u] == 1;
@@ -226,13 +233,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                 const float sg = sideH[u] ? 1.0f : -1.0f;
                 float g[FPL];
                 if (p.ent_norm) {
+                  // g = (ghat - what (what . ghat)) / |w| with ghat = sg * d, what = C * cinv
                   float dot = 0.f;
 #pragma unroll
-                  for (int k = 0; k < FPL; ++k) dot = fmaf(C[u][k] * cinv, sg * d[k], dot);
-                  dot = sub16_sum(dot);
-                  const float coef = cinv < 0.99e6f ? dot * cinv : 0.f;  // sum w^2 > eps  <=>  cinv < rsqrt(eps) = 1e6
+                  for (int k = 0; k < FPL; ++k) dot = fmaf(C[u][k], d[k], dot);
+                  dot = sub16_sum(dot) * (sg * cinv);
+                  const float a1 = sg * cinv;
+                  const float a2 = cinv < 0.99e6f ? -dot * cinv * cinv : 0.f;  // sum w^2 > eps  <=>  cinv < rsqrt(eps) = 1e6
 #pragma unroll
-                  for (int k = 0; k < FPL; ++k) g[k] = (sg * d[k] - C[u][k] * coef) * cinv;
+                  for (int k = 0; k < FPL; ++k) g[k] = fmaf(a2, C[u][k], a1 * d[k]);
                 } else {
 #pragma unroll
                   for (int k = 0; k < FPL; ++k) g[k] = sg * d[k];
@@ -274,8 +283,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 
       if (bwd) {
         // reduce the shared rows' gradients over the four quarter-waves (all lanes converge here)
+        // every negative's c*d went into exactly one of gH / gT and the positive's into both: the relation row's gradient
+        // is their sum minus the positive's term once
+        float gR[FPL];
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
+          gR[k] = (gH[k] + gT[k]) - gP[k];
           gH[k] += __shfl_xor(gH[k], 16, 64); gH[k] += __shfl_xor(gH[k], 32, 64);
           gR[k] += __shfl_xor(gR[k], 16, 64); gR[k] += __shfl_xor(gR[k], 32, 64);
           gT[k] += __shfl_xor(gT[k], 16, 64); gT[k] += __shfl_xor(gT[k], 32, 64);
@@ -387,7 +400,10 @@ static int score_impl(
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;
   MKE_DISPATCH_FPL(fpl, {
-    constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);  // corrupt rows in flight per quarter-wave
+    // corrupt rows in flight per quarter-wave.  2, not 4, at FPL <= 5: with the accumulator rows of the exclusive-row path
+    // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
+    // latency than the two extra gathers in flight did (41.9 -> 40.2 us at the C2 shape)
+    constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);
     if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
     else hipLaunchKernelGGL((k_triple_score<FPL, U, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
   });
