@@ -492,6 +492,36 @@ int mke_rows_update_dense(float* table, float* slot1, float* slot2, float* grad,
 int mke_dense_update_opt(float* param, float* slot1, float* slot2, float* grad, int64_t n, const mke_optimizer* opt,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Space-mapping step of the SSL driver (code/losses.py:53-63; graph code/MultiKE_model.py:241-261; loop :439-454):
+ *     loss = sum_k [ sum (F - l2n(V_k[idx] @ M_k))^2 + orthogonal_weight * ||M_k M_k^T - I||^2 + norm_w * ||M_k||^2 ]
+ *   F = rows idx of the shared table (trainable, normalise-on-read), V_k = rows idx of view k's table (constant here),
+ *   l2n = tf.nn.l2_normalize with no axis (the whole [n, dim] batch), M = [n_views][dim][dim] packed, row-major.
+ *   One call = forward, backward, the row update of the shared table and the dense update of the matrices (update != 0).
+ *   gM must be all-zero on entry (the dense update restores it; with update == 0 the caller reads and clears it).
+ *   scratch: mke_mapping_scratch_floats(n, dim) floats.  partials: double[2 * MKE_LOSS_PARTIALS] scratch.
+ *   loss_partials: double[(MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS], overwritten: one block per view (map loss) and one
+ *   for the orthogonality + norm terms; the loss is the sum of all of it.  dim <= 88.
+ * ------------------------------------------------------------------------------------------------ */
+#define MKE_MAPPING_MAX_VIEWS 3
+typedef struct mke_mapping_view { const float* table; int normalize; } mke_mapping_view;
+typedef struct mke_mapping_step_args {
+  float* ent_table; int64_t n_ent; int ent_normalize; float* ent_acc; float* ent_grad /*NULL = constant*/; int32_t* ent_touched;
+  mke_mapping_view views[MKE_MAPPING_MAX_VIEWS]; int n_views;
+  int stride, dim;
+  const int32_t* idx; int64_t n;
+  float* M; float* gM; float* accM /*nullable for SGD*/;
+  float orthogonal_weight, norm_w;
+  float* scratch; double* partials;
+  int optimizer; float lr; int32_t tag; int update;
+} mke_mapping_step_args;
+int64_t mke_mapping_scratch_floats(int64_t n, int dim);
+int mke_mapping_step(const mke_mapping_step_args* args, double* loss_partials, void* stream);
+/* n_steps consecutive steps: step s uses idx[step_off[s] .. step_off[s+1]) (step_off: HOST array), tag args->tag + s, and writes
+ * its loss partials to loss_ring[s % ring][(MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS]; args->n is ignored. */
+int mke_mapping_steps(const mke_mapping_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
+                      void* stream);
+
 /* dense Adagrad / SGD over n contiguous floats; grad is zeroed — tf.train.AdagradOptimizer on the CNN variables */
 int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad, int64_t n, int optimizer, float lr,
                      void* stream);

@@ -514,11 +514,36 @@ class MultiKE:
             yield picked[s], bs
 
     def train_shared_space_mapping_1epo(self, epoch, entities):
-        """code/MultiKE_model.py:439-454 + graph :241-261 (SSL).  Three space_mapping_loss terms; the dense part is a
-        75x75 GEMM (torch / rocBLAS); the `ent_embeds` rows are updated through the HIP scatter + row update."""
+        """code/MultiKE_model.py:439-454 + graph :241-261 (SSL).  Three space_mapping_loss terms.  Adagrad / SGD: one native
+        call per epoch.  Adam / Adadelta (or dim > 88): step-wise through the differentiable `losses.space_mapping_loss`."""
         start = time.time()
         st = self._shared_comb
         total, trained = None, 0
+        if self.args.optimizer not in _DENSE_OPTS and self.args.dim <= 88 and len(entities):
+            # native path: every step of the epoch inside one call (`mke_mapping_steps`): MFMA GEMMs for V M and V^T dP, the
+            # batch-wide normalisation as two partial-sum passes, one launch for the row update + the three matrices
+            from .runner import SpaceMappingState, run_space_mapping_steps
+            if getattr(self, "_map_state", None) is None:
+                self._map_state = SpaceMappingState(st.vars, self.device)
+                for k, name in enumerate(("nv_mapping", "rv_mapping", "av_mapping")):   # the matrices now live in the pack
+                    setattr(self, name, self._map_state.M[k])
+                st.vars = [self._map_state.M[k] for k in range(3)]
+            t = self._entity_tensor(entities)
+            B = self.args.entity_batch_size
+            steps = int(math.ceil(len(entities) / B))
+            bs = B if steps > 1 else len(entities)
+            seed, stream = self._next_sample_stream()
+            self._last_sample = (seed, stream, len(entities), bs, steps)
+            idx = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).reshape(-1).long()]
+            tag_base = self.engine.tag + 1
+            self.engine.tag += steps
+            ring = run_space_mapping_steps(self._map_state, self.ent_embeds, [self.name_embeds, self.rv_ent_embeds, self.av_ent_embeds],
+                                           idx, np.arange(steps + 1, dtype=np.int64) * bs, "shared_comb", tag_base,
+                                           self.args.learning_rate, self.args.orthogonal_weight, optimizer=self.args.optimizer)
+            epoch_loss = float(ring.sum()) / (steps * bs)
+            print('epoch {} of shared space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
+                                                                                               time.time() - start))
+            return epoch_loss
         for idx, bs in self._entity_batches(entities, self.args.entity_batch_size):
             final = self.ent_embeds.lookup(idx).requires_grad_(True)
             views = (self.name_embeds.lookup(idx), self.rv_ent_embeds.lookup(idx), self.av_ent_embeds.lookup(idx))

@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_select_above",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_select_above", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
 )
 
 
@@ -67,6 +67,20 @@ class AlignPlanStruct(C.Structure):
                 ("stride", C.c_int), ("dim", C.c_int), ("ia", C.c_void_p), ("ib", C.c_void_p),
                 ("step_off", C.POINTER(C.c_int64)), ("n_steps", C.c_int), ("optimizer", C.c_int), ("lr", C.c_float),
                 ("tag_base", C.c_int32), ("loss_partials", C.c_void_p)]
+
+
+class MappingViewStruct(C.Structure):
+    """mke_mapping_view"""
+    _fields_ = [("table", C.c_void_p), ("normalize", C.c_int)]
+
+
+class MappingStepArgs(C.Structure):
+    """mke_mapping_step_args"""
+    _fields_ = [("ent_table", C.c_void_p), ("n_ent", C.c_int64), ("ent_normalize", C.c_int), ("ent_acc", C.c_void_p),
+                ("ent_grad", C.c_void_p), ("ent_touched", C.c_void_p), ("views", MappingViewStruct * 3), ("n_views", C.c_int),
+                ("stride", C.c_int), ("dim", C.c_int), ("idx", C.c_void_p), ("n", C.c_int64), ("M", C.c_void_p), ("gM", C.c_void_p),
+                ("accM", C.c_void_p), ("orthogonal_weight", C.c_float), ("norm_w", C.c_float), ("scratch", C.c_void_p),
+                ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32), ("update", C.c_int)]
 
 
 class OptimizerStruct(C.Structure):
@@ -131,6 +145,7 @@ def lib():
         for name in SYMBOLS[2:]:
             getattr(L, name).restype = C.c_int
         L.mke_attr_scratch_floats.restype = C.c_int64
+        L.mke_mapping_scratch_floats.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -317,6 +332,23 @@ def select_above(sim: torch.Tensor, tau: torch.Tensor, cap: int):
                                 _dev(cnt, torch.int32, "count"), _stream())
     _check(rc, "mke_select_above")
     return idx, cnt
+
+
+def mapping_scratch_floats(n: int, dim: int) -> int:
+    return int(lib().mke_mapping_scratch_floats(C.c_int64(n), C.c_int(dim)))
+
+
+def mapping_step(args: MappingStepArgs, loss_partials: torch.Tensor):
+    rc = lib().mke_mapping_step(C.byref(args), _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_mapping_step")
+
+
+def mapping_steps(args: MappingStepArgs, step_off: np.ndarray, loss_ring: torch.Tensor):
+    """loss_ring: float64 [ring, 4, LOSS_PARTIALS]."""
+    off = np.ascontiguousarray(step_off, dtype=np.int64)
+    rc = lib().mke_mapping_steps(C.byref(args), off.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int(len(off) - 1),
+                                 _dev(loss_ring, torch.float64, "loss_ring"), C.c_int(loss_ring.shape[0]), _stream())
+    _check(rc, "mke_mapping_steps")
 
 
 def align_steps(plan: AlignPlanStruct):

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restric
 __global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(const DenseJob j) { dense_update_range(j, blockIdx.x, gridDim.x); }
 
 int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
-                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials);
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain);
 int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
                          int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
                          const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,
@@ -724,7 +724,7 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
                               a->params, flat, fs, stream))) return rc;
   // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
-  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq))) return rc;
+  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq, 0))) return rc;
   const bool upd = a->update != 0;
   if ((rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;

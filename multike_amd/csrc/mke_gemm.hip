@@ -26,6 +26,7 @@ struct GemmParams {
   // epilogue (single split only): C = tanh(acc) and partials[block] = sum of C^2 over the block's tile; the blocks also
   // zero partials[block + k * n_blocks] up to MKE_LOSS_PARTIALS so that a reader can add all of them up
   double* partials;
+  int epi_plain;  // with partials: store acc itself (no tanh) and the per-block sums of its squares
   int gx, gy, gz;  // this problem's grid (k_gemm_f32_batch decodes its linear block index with it)
 };
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, 
       const int dr = (reg & 3) + 8 * (reg >> 2);
       if (m0 + wm * 32 + 4 * half + dr < p.M) {
         if (p.partials) {
-          const float v = tanhf(acc[reg]);
+          const float v = p.epi_plain ? acc[reg] : tanhf(acc[reg]);
           c[dr * p.ldc] = v;
           ssq = fmaf(v, v, ssq);
         } else if (p.atomic) atomic_add_f32(c + dr * p.ldc, acc[reg]);
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32_batch(const GemmBatch b)
 }
 
 static bool gemm_setup(GemmParams& p, const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C,
-                       int64_t ldc, int M, int N, int K, int splits, int accumulate, double* partials) {
+                       int64_t ldc, int M, int N, int K, int splits, int accumulate, double* partials, int epi_plain = 0) {
   if (M <= 0 || N <= 0 || K <= 0) return false;
   if (splits < 1 || partials) splits = 1;
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
@@ -162,14 +163,15 @@ static bool gemm_setup(GemmParams& p, const float* A, int64_t a_rs, int64_t a_cs
   const int nz = (K + kps - 1) / kps;
   p.atomic = (accumulate || nz > 1) ? 1 : 0;
   p.partials = partials;
+  p.epi_plain = epi_plain;
   p.gx = (N + GT - 1) / GT; p.gy = (M + GT - 1) / GT; p.gz = nz;
   return true;
 }
 
 int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
-                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials) {
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain) {
   GemmParams p;
-  if (!gemm_setup(p, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, M, N, K, splits, accumulate, tanh_sumsq_partials)) return MKE_OK;
+  if (!gemm_setup(p, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, M, N, K, splits, accumulate, tanh_sumsq_partials, epi_plain)) return MKE_OK;
   if (tanh_sumsq_partials && p.gx * p.gy > MKE_LOSS_PARTIALS) { set_error("gemm epilogue: more than %d blocks", MKE_LOSS_PARTIALS); return MKE_E_SHAPE; }
   hipLaunchKernelGGL(k_gemm_f32, dim3(p.gx, p.gy, p.gz), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_gemm_f32");
@@ -208,5 +210,5 @@ extern "C" int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_
   if (ldc < N) { set_error("mke_gemm_f32: ldc < N"); return MKE_E_SHAPE; }
   if (splits > 1 && !accumulate) { set_error("mke_gemm_f32: split-K accumulates atomically: pass accumulate=1 and a zeroed (or to-be-added-to) C"); return MKE_E_SHAPE; }
   return launch_gemm_f32(A, a_row_stride, a_col_stride, B, b_row_stride, b_col_stride, C, ldc, M, N, K, splits, accumulate,
-                         (hipStream_t)stream, nullptr);
+                         (hipStream_t)stream, nullptr, 0);
 }

@@ -247,3 +247,56 @@ def run_alignment_steps(tables, terms, idx_a, idx_b, step_off, opt_name: str, ta
     p.loss_partials = _lib.ptr(loss, torch.float64, "loss")
     _lib.align_steps(p)
     return loss
+
+
+class SpaceMappingState:
+    """The three mapping matrices of the SSL driver's space-mapping graph (code/MultiKE_model.py:241-261), packed
+    [n_views, d, d] with their gradient scratch and Adagrad accumulator, plus the scratch of the native step."""
+
+    def __init__(self, matrices, device):
+        self.n_views, self.dim = len(matrices), matrices[0].shape[0]
+        self.M = torch.stack([m.detach().to(device=device, dtype=torch.float32) for m in matrices]).contiguous()
+        self.gM = torch.zeros_like(self.M)
+        self.accM = torch.full_like(self.M, 0.1)                 # tf.train.AdagradOptimizer initial accumulator
+        self.partials = torch.zeros(2 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=device)
+        self._scratch = None
+
+    def scratch(self, n):
+        need = _lib.mapping_scratch_floats(n, self.dim)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(max(need, 1), dtype=torch.float32, device=self.M.device)
+        return self._scratch
+
+
+def run_space_mapping_steps(state: SpaceMappingState, ent: EmbeddingTable, views, idx, step_off, opt_name: str, tag_base: int,
+                            lr: float, orthogonal_weight: float, optimizer: str = "Adagrad", norm_w: float = 0.0001,
+                            update: bool = True) -> torch.Tensor:
+    """A whole epoch of space-mapping steps as ONE native call (`mke_mapping_steps`).  `views`: the EmbeddingTables mapped
+    onto the shared table `ent` (constants here).  Returns the loss partials [n_steps, 4, LOSS_PARTIALS]."""
+    if optimizer not in _OPT:
+        raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the native step loops (Adagrad, SGD)")
+    off = np.ascontiguousarray(step_off, dtype=np.int64)
+    steps = len(off) - 1
+    ring = torch.zeros(max(1, steps), 4, _lib.LOSS_PARTIALS, dtype=torch.float64, device=ent.device)
+    if steps <= 0:
+        return ring[:0]
+    f32, i32 = torch.float32, torch.int32
+    a = _lib.MappingStepArgs()
+    a.ent_table, a.n_ent, a.ent_normalize = _lib.ptr(ent.data, f32, "ent"), ent.n_rows, int(ent.normalize)
+    a.ent_acc = _lib.ptr(ent.slot(opt_name), f32, "acc") if optimizer == "Adagrad" else None
+    a.ent_grad, a.ent_touched = _lib.ptr(ent.grad, f32, "grad"), _lib.ptr(ent.touched, i32, "touched")
+    a.n_views = len(views)
+    for k, t in enumerate(views):
+        if t.stride != ent.stride or t.dim != ent.dim:
+            raise _lib.MultiKEHipError("space-mapping tables must share dim/stride")
+        a.views[k].table, a.views[k].normalize = _lib.ptr(t.data, f32, "view"), int(t.normalize)
+    a.stride, a.dim = ent.stride, ent.dim
+    a.idx, a.n = _lib.ptr(idx, i32, "idx"), int(np.diff(off).max())
+    a.M, a.gM = _lib.ptr(state.M, f32, "M"), _lib.ptr(state.gM, f32, "gM")
+    a.accM = _lib.ptr(state.accM, f32, "accM") if optimizer == "Adagrad" else None
+    a.orthogonal_weight, a.norm_w = float(orthogonal_weight), float(norm_w)
+    a.scratch = _lib.ptr(state.scratch(int(np.diff(off).max())), f32, "scratch")
+    a.partials = _lib.ptr(state.partials, torch.float64, "partials")
+    a.optimizer, a.lr, a.tag, a.update = _OPT[optimizer], float(lr), int(tag_base), int(update)
+    _lib.mapping_steps(a, off, ring)
+    return ring

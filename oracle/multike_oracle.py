@@ -200,6 +200,46 @@ def relation_view_step_dense(ent, rel, acc_ent, acc_rel, pos, neg, lr, pos_w=Non
     return loss, ghat_ent, ghat_rel
 
 
+def space_mapping_grads(view_rows, shared_rows, mapping, orthogonal_weight, norm_w=0.0001):
+    """Closed-form gradients of `space_mapping_loss` (code/losses.py:53-63) w.r.t. the gathered shared rows and the
+    mapping matrix.  Returns (loss, g_shared [B,d], g_mapping [d,d])."""
+    d = mapping.shape[0]
+    P = view_rows @ mapping
+    S = np.sum(P * P)
+    inv = 1.0 / np.sqrt(max(S, L2_EPS))
+    out = P * inv
+    diff = shared_rows - out
+    g_out = -2.0 * diff
+    dP = inv * (g_out - out * np.sum(g_out * out)) if S > L2_EPS else inv * g_out
+    Q = mapping @ mapping.T - np.eye(d, dtype=mapping.dtype)
+    gM = view_rows.T @ dP + orthogonal_weight * 4.0 * (Q @ mapping) + norm_w * 2.0 * mapping
+    loss = np.sum(diff * diff) + orthogonal_weight * np.sum(Q * Q) + norm_w * np.sum(mapping * mapping)
+    return loss, 2.0 * diff, gM
+
+
+def space_mapping_step_dense(ent, acc_ent, views, mappings, acc_mappings, idx, lr, orthogonal_weight, ent_norm=True, norm_w=0.0001):
+    """One `session.run([shared_comb_loss, shared_comb_optimizer])` (code/MultiKE_model.py:241-261,:447-451) with dense-table
+    semantics: `views` = [(table, read_through_l2_normalize)] (constants here), `mappings` / `acc_mappings` lists of [d,d]
+    arrays and `ent` / `acc_ent` are updated in place (TF1 Adagrad).  Returns the loss."""
+    E = l2_normalize_rows(ent) if ent_norm else ent
+    F = E[idx]
+    total = 0.0
+    gF = np.zeros_like(F)
+    gMs = []
+    for (table, norm), M in zip(views, mappings):
+        V = (l2_normalize_rows(table) if norm else table)[idx]
+        loss, g_shared, gM = space_mapping_grads(V, F, M, orthogonal_weight, norm_w)
+        total += loss
+        gF += g_shared
+        gMs.append(gM)
+    ge = np.zeros_like(ent)
+    np.add.at(ge, idx, gF)
+    adagrad_dense(ent, acc_ent, l2_normalize_rows_backward(ent, ge) if ent_norm else ge, lr)
+    for M, a, g in zip(mappings, acc_mappings, gMs):
+        adagrad_dense(M, a, g, lr)
+    return total
+
+
 def alignment_step_dense(table_a, table_b, acc_a, acc_b, ia, ib, lr, weight=1.0, a_norm=True, b_norm=True,
                          update=True):
     """One alignment term  weight * sum ||A^[ia] - B^[ib]||^2  with dense-table semantics

@@ -188,3 +188,23 @@ def test_dense_optimizer_oracles_agree_with_torch_optim():
             opt.step()
             (mo.adam_dense(W, s1, s2, g, 0.01, step) if kind == "Adam" else mo.adadelta_dense(W, s1, s2, g, 0.5))
         np.testing.assert_allclose(W, p.detach().numpy(), rtol=(1e-5 if kind == "Adam" else 1e-12), atol=(1e-6 if kind == "Adam" else 0))
+
+
+def test_space_mapping_gradients_against_autograd():
+    """oracle.space_mapping_grads (closed form) vs torch autograd on the loss restatement that is pinned to the reference's
+    code/losses.py:53-63 by the golden fixture."""
+    import torch
+    from oracle import multike_oracle as mo
+    rng = np.random.default_rng(1)
+    B, d, ow = 40, 9, 2.0
+    V, F, M = rng.standard_normal((B, d)), rng.standard_normal((B, d)) * 0.1, rng.standard_normal((d, d)) * 0.4
+    loss, gF, gM = mo.space_mapping_grads(V, F, M, ow)
+    np.testing.assert_allclose(loss, mo.space_mapping_loss(V, F, M, np.eye(d), ow), rtol=1e-13)
+    tV, tF, tM = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (V, F, M))
+    P = tV @ tM
+    P = P / torch.sqrt(torch.clamp_min((P * P).sum(), 1e-12))
+    L = ((tF - P) ** 2).sum() + ow * ((tM @ tM.T - torch.eye(d, dtype=torch.float64)) ** 2).sum() + 1e-4 * (tM * tM).sum()
+    L.backward()
+    np.testing.assert_allclose(loss, float(L), rtol=1e-13)
+    np.testing.assert_allclose(gF, tF.grad.numpy(), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gM, tM.grad.numpy(), rtol=1e-10, atol=1e-12)
