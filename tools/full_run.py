@@ -1,22 +1,24 @@
-"""The reference's run_ITC.py flow at DBP-WD-100K scale on a synthetic dataset folder, timed phase by phase.
-python tools/full_run.py [n_pairs] [max_epoch]"""
+"""The reference's run_ITC.py / run_SSL.py flow at DBP-WD-100K scale on a synthetic dataset folder, timed phase by phase.
+python tools/full_run.py [n_pairs] [max_epoch] [ITC|SSL]"""
 import os, sys, tempfile, time, contextlib, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multike_amd.data_model import DataModel
 from multike_amd.MultiKE_CSL import MultiKE_CV
+from multike_amd.MultiKE_Late import MultiKE_Late
 from multike_amd.predicate_alignment import PredicateAlignModel
 from multike_amd.synthetic import synthetic_args, write_dataset_folder
 import torch
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+method = sys.argv[3] if len(sys.argv) > 3 else "ITC"
 folder = tempfile.mkdtemp() + "/"
 t = time.time()
 wf = write_dataset_folder(folder, n_pairs=n_pairs, n_extra=n_pairs // 20, n_rel=300, n_attr=300, triples_per_entity=4.4, shared_structure=0.8)
 print(f"folder written in {time.time() - t:.1f}s")
 args = synthetic_args(training_data=folder, output=folder + "out/", word2vec_path=wf, dataset_division="631/", encoder_epoch=100,
                       encoder_active="tanh", encoder_normalize=True, retrain_literal_embeds=False, literal_normalize=True, is_save=True,
-                      max_epoch=epochs, start_valid=100, eval_freq=10)
+                      max_epoch=epochs, shared_learning_max_epoch=epochs, start_valid=100, eval_freq=10)
 quiet = contextlib.redirect_stdout(io.StringIO())
 t = time.time()
 with quiet:
@@ -32,10 +34,10 @@ print(f"DataModel {t_data:.1f}s (entities {k.entities_num}, relation triples {k.
 t = time.time()
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
-    model = MultiKE_CV(data, args, pam)
+    model = (MultiKE_CV if method == "ITC" else MultiKE_Late)(data, args, pam)
     res = model.run()
 torch.cuda.synchronize()
-print(f"MultiKE_CV.run(): {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
+print(f"{type(model).__name__}.run(): {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
 print("test Hits@1:", {k_: round(float(v), 3) for k_, v in res.items()})
 log = buf.getvalue().splitlines()
 import re, collections
