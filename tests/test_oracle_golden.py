@@ -205,6 +205,6 @@ def test_space_mapping_gradients_against_autograd():
     P = P / torch.sqrt(torch.clamp_min((P * P).sum(), 1e-12))
     L = ((tF - P) ** 2).sum() + ow * ((tM @ tM.T - torch.eye(d, dtype=torch.float64)) ** 2).sum() + 1e-4 * (tM * tM).sum()
     L.backward()
-    np.testing.assert_allclose(loss, float(L), rtol=1e-13)
+    np.testing.assert_allclose(loss, float(L.detach()), rtol=1e-13)
     np.testing.assert_allclose(gF, tF.grad.numpy(), rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(gM, tM.grad.numpy(), rtol=1e-10, atol=1e-12)
