@@ -114,14 +114,16 @@ def read_relation_triples(file_path):
     triples, entities, relations = _OrderedSet(), _OrderedSet(), _OrderedSet()
     if file_path is None:
         return triples, entities, relations
-    for no, p in _fields(file_path):
-        if len(p) != 3:
-            raise ValueError(f"{file_path}:{no}: expected 3 tab-separated fields, got {len(p)}")
-        h, r, t = (x.strip() for x in p)
-        triples.add((h, r, t))
-        entities.add(h)
-        entities.add(t)
-        relations.add(r)
+    with open(file_path, "r", encoding="utf8") as f:
+        for no, line in enumerate(f, 1):
+            p = line.rstrip("\n").split("\t")
+            if len(p) != 3:
+                raise ValueError(f"{file_path}:{no}: expected 3 tab-separated fields, got {len(p)}")
+            h, r, t = p[0].strip(), p[1].strip(), p[2].strip()
+            triples[(h, r, t)] = None          # _OrderedSet is a dict: plain stores, no method call per line
+            entities[h] = None
+            entities[t] = None
+            relations[r] = None
     return triples, entities, relations
 
 
@@ -139,9 +141,9 @@ def read_attribute_triples(file_path):
             head, attr = p[0].strip(), p[1].strip()
             value = " ".join([p[2].strip()] + [x.strip() for x in p[3:]]) if len(p) > 3 else p[2].strip()
             value = value.strip().rstrip(".").strip()
-            triples.add((head, attr, value))
-            entities.add(head)
-            attributes.add(attr)
+            triples[(head, attr, value)] = None
+            entities[head] = None
+            attributes[attr] = None
     return triples, entities, attributes
 
 
@@ -264,12 +266,18 @@ def uris_pair_2ids(uris, ids1, ids2):
 
 
 def uris_relation_triple_2ids(uris, ent_ids, rel_ids):
-    return [(_need(h, ent_ids, "entity"), _need(r, rel_ids, "relation"), _need(t, ent_ids, "entity")) for h, r, t in uris]
+    try:
+        return [(ent_ids[h], rel_ids[r], ent_ids[t]) for h, r, t in uris]
+    except KeyError:      # slow pass only to name the offender
+        return [(_need(h, ent_ids, "entity"), _need(r, rel_ids, "relation"), _need(t, ent_ids, "entity")) for h, r, t in uris]
 
 
 def uris_attribute_triple_2ids(uris, ent_ids, attr_ids):
     """Heads must be entities of the relation graph; the value stays a string (code/base/read.py:120-127)."""
-    return [(_need(h, ent_ids, "entity (attribute-triple head)"), _need(a, attr_ids, "attribute"), v) for h, a, v in uris]
+    try:
+        return [(ent_ids[h], attr_ids[a], v) for h, a, v in uris]
+    except KeyError:
+        return [(_need(h, ent_ids, "entity (attribute-triple head)"), _need(a, attr_ids, "attribute"), v) for h, a, v in uris]
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -548,21 +556,31 @@ def _build(r1, r2, a1, a2, train_links, valid_links, test_links, mode, ordered):
 
 
 class _UriKG(KG):
-    """URI-space KG that keeps file order for its element sets so that unordered id assignment is deterministic."""
+    """URI-space KG that keeps file order for its element sets so that unordered id assignment is deterministic.  One pass
+    per triple list; none of the derived lists / dicts of `KG` is ever needed for it."""
 
     def set_relations(self, relation_triples):
-        super().set_relations(relation_triples)
-        order = _OrderedSet()
-        rels = _OrderedSet()
+        self._forget(self._REL_DERIVED)
+        self.sup_relation_triples_set, self.sup_relation_triples_list = None, None
+        self.relation_triples_set = self.local_relation_triples_set = (
+            relation_triples if isinstance(relation_triples, _OrderedSet) else set(relation_triples))
+        ents, rels = _OrderedSet(), _OrderedSet()
         for h, r, t in relation_triples:
-            order.add(h)
-            order.add(t)
-            rels.add(r)
-        self.entities_set, self.relations_set = order, rels
+            ents[h] = None
+            ents[t] = None
+            rels[r] = None
+        self.entities_set, self.relations_set = ents, rels
+        self.entities_num, self.relations_num = len(ents), len(rels)
+        self.relation_triples_num = self.local_relation_triples_num = len(self.relation_triples_set)
 
     def set_attributes(self, attribute_triples):
-        super().set_attributes(attribute_triples)
+        self._forget(self._ATTR_DERIVED)
+        self.sup_attribute_triples_set, self.sup_attribute_triples_list = None, None
+        self.attribute_triples_set = self.local_attribute_triples_set = (
+            attribute_triples if isinstance(attribute_triples, _OrderedSet) else set(attribute_triples))
         attrs = _OrderedSet()
         for _, a, _ in attribute_triples:
-            attrs.add(a)
+            attrs[a] = None
         self.attributes_set = attrs
+        self.attributes_num = len(attrs)
+        self.attribute_triples_num = self.local_attribute_triples_num = len(self.attribute_triples_set)
