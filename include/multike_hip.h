@@ -165,6 +165,14 @@ typedef struct mke_update_table {
   int normalize;
   int grad_copies; /* grad is [grad_copies][n_rows][stride] */
   int32_t* ref_count; /* nullable: reset to 0 for every visited row (exclusive-row fast path bookkeeping) */
+  /* Owner side of the sharded step (section 7): when slot_of != NULL the row's gradient is not taken from grad/touched
+   * (both may be NULL) but summed, in rank order, from the rows the ranks sent back: for every g with
+   * s = slot_of[row * n_ranks + g] >= 0, ghat += src_rows[g * capacity + s][:].  Rows without a slot are not visited;
+   * the slots a visit consumed are reset to -1.  One pass replaces scatter-add + touched-row update. */
+  const float* src_rows;
+  int32_t* slot_of;
+  int n_ranks;
+  int64_t capacity;
 } mke_update_table;
 int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                           int optimizer, float lr, void* stream);
@@ -384,7 +392,10 @@ int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_e
  *     dirty and are cleared by mke_rowset_remap.  *overflow is set to 1 when a segment is full (result invalid).
  *     Slot order inside a segment is unspecified.
  *   mke_rowset_remap: for up to four streams, out_s[i] = id_map[ids_s[i]] and flags[ids_s[i]] = 0; optionally
- *     re-initialises a req / counts pair for the next build (req[:] = -1, counts[:] = 0).
+ *     re-initialises a req / counts pair for the next build (req[:] = -1, counts[:] = 0); and, when want != NULL
+ *     (the [n_ranks][capacity] local rows the other ranks asked this owner for, -1 = pad), inverts it for the owner's
+ *     reduce-and-update launch: slot_of[row * n_ranks + g] = slot of `row` in rank g's segment.  slot_of is
+ *     [n_local_rows * n_ranks], all -1 on entry by invariant (mke_rows_update_multi resets what it consumes).
  *   mke_rows_gather_padded: out[i][:] = idx[i] >= 0 ? table[idx[i]][:] : 0   (raw padded rows, no normalisation);
  *     when zero_rows != NULL, zero_rows[i][:] = 0 as well (clears the compact gradient scratch in the same pass).
  *   mke_rows_scatter_add: grad[idx[i]][:] += rows[i][:] (atomic), touched[idx[i]] = tag, for idx[i] >= 0; when
@@ -396,7 +407,8 @@ int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* ids1, int64
 int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, const int32_t* ids1, int32_t* out1, int64_t n1,
                      const int32_t* ids2, int32_t* out2, int64_t n2, const int32_t* ids3, int32_t* out3, int64_t n3,
                      const int32_t* id_map, int32_t* flags, int32_t* reset_req /*nullable*/, int64_t reset_req_len,
-                     int32_t* reset_counts /*nullable*/, int n_counts, void* stream);
+                     int32_t* reset_counts /*nullable*/, int n_counts,
+                     const int32_t* want /*nullable*/, int32_t* slot_of, int n_ranks, int capacity, void* stream);
 int mke_rows_gather_padded(const float* table, int stride, const int32_t* idx, int64_t n, float* out,
                            float* zero_rows /*nullable*/, void* stream);
 int mke_rows_scatter_add(const int32_t* idx, const float* rows, int64_t n, int stride, int dim, float* grad,

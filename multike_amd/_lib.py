@@ -103,7 +103,8 @@ class KGSideStruct(C.Structure):
 class UpdateTableStruct(C.Structure):
     """mke_update_table"""
     _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p),
-                ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int), ("ref_count", C.c_void_p)]
+                ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int), ("ref_count", C.c_void_p),
+                ("src_rows", C.c_void_p), ("slot_of", C.c_void_p), ("n_ranks", C.c_int), ("capacity", C.c_int64)]
 
 
 class RelationPlanStruct(C.Structure):
@@ -277,9 +278,23 @@ def ptr(t: torch.Tensor | None, dtype, name: str) -> int | None:
 
 
 def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
-    """tables: list of (data, acc, grad, touched, normalize[, ref_count])."""
+    """tables: list of (data, acc, grad, touched, normalize[, ref_count]); or, for the owner side of the sharded
+    step, a dict(table=, acc=, normalize=, src_rows=, slot_of=, n_ranks=, capacity=) (mke_update_table.slot_of)."""
     arr = (UpdateTableStruct * len(tables))()
     for k, tpl in enumerate(tables):
+        if isinstance(tpl, dict):
+            arr[k].table = ptr(tpl["table"], torch.float32, "table")
+            arr[k].acc = ptr(tpl["acc"], torch.float32, "acc")
+            arr[k].n_rows = tpl["table"].shape[0]
+            arr[k].normalize = int(tpl["normalize"])
+            arr[k].grad_copies = 1
+            arr[k].src_rows = ptr(tpl["src_rows"], torch.float32, "src_rows")
+            arr[k].slot_of = ptr(tpl["slot_of"], torch.int32, "slot_of")
+            arr[k].n_ranks = int(tpl["n_ranks"])
+            arr[k].capacity = int(tpl["capacity"])
+            if tpl["slot_of"].numel() < arr[k].n_rows * arr[k].n_ranks or tpl["src_rows"].shape[0] < arr[k].n_ranks * arr[k].capacity:
+                raise ValueError("slot_of / src_rows are smaller than n_rows * n_ranks / n_ranks * capacity")
+            continue
         data, acc, grad, touched, normalize = tpl[:5]
         arr[k].ref_count = ptr(tpl[5], torch.int32, "ref_count") if len(tpl) > 5 and tpl[5] is not None else None
         arr[k].table = ptr(data, torch.float32, "table")
@@ -426,7 +441,8 @@ def rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacit
     _check(rc, "mke_rowset_build")
 
 
-def rowset_remap(streams, outs, id_map, flags, reset_req=None, reset_counts=None):
+def rowset_remap(streams, outs, id_map, flags, reset_req=None, reset_counts=None, want=None, slot_of=None, n_ranks=0,
+                 capacity=0):
     args = []
     for k in range(4):
         t = streams[k] if k < len(streams) else None
@@ -435,7 +451,9 @@ def rowset_remap(streams, outs, id_map, flags, reset_req=None, reset_counts=None
     rc = lib().mke_rowset_remap(*args, _dev(id_map, torch.int32, "id_map"), _dev(flags, torch.int32, "flags"),
                                 _dev(reset_req, torch.int32, "reset_req"), C.c_int64(0 if reset_req is None else reset_req.numel()),
                                 _dev(reset_counts, torch.int32, "reset_counts"),
-                                C.c_int(0 if reset_counts is None else reset_counts.numel()), _stream())
+                                C.c_int(0 if reset_counts is None else reset_counts.numel()),
+                                _dev(want, torch.int32, "want"), _dev(slot_of, torch.int32, "slot_of"), C.c_int(n_ranks),
+                                C.c_int(capacity), _stream())
     _check(rc, "mke_rowset_remap")
 
 

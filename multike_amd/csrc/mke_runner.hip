@@ -114,7 +114,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
   if (N > 0 && (!pl->neg_h || !pl->neg_r || !pl->neg_t)) { set_error("NULL negative scratch"); return MKE_E_NULL; }
   if ((int64_t)pl->tag_base + step_end >= 0x7FFFFFFFLL) { set_error("tag overflow"); return MKE_E_RANGE; }
 
-  mke_update_table ut[2];
+  mke_update_table ut[2] = {};
   ut[0].table = pl->rel_table; ut[0].acc = pl->rel_acc; ut[0].grad = pl->rel_grad; ut[0].touched = pl->rel_touched;
   ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies; ut[0].ref_count = nullptr;
   ut[1].table = pl->ent_table; ut[1].acc = pl->ent_acc; ut[1].grad = pl->ent_grad; ut[1].touched = pl->ent_touched;

@@ -35,33 +35,43 @@ __device__ __forceinline__ int32_t stream_at(const RowsetParams& p, int64_t i) {
   return -1;
 }
 
+// Each thread claims ROWSET_IPT ids per pass: their first-touch atomics are in flight together, and a block issues ONE
+// global atomic per owner for MKE_BLOCK * ROWSET_IPT ids — the per-owner counters are same-address atomic chains
+// (~20-45 ns per link), so the number of blocks x passes is what bounds this kernel, not the id traffic.
+#define ROWSET_IPT 4
 __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_build(const RowsetParams p) {
   __shared__ int s_cnt[MKE_MAX_RANKS];
   __shared__ int s_base[MKE_MAX_RANKS];
-  const int64_t stride = (int64_t)gridDim.x * MKE_BLOCK;
-  for (int64_t base = (int64_t)blockIdx.x * MKE_BLOCK; base < p.total; base += stride) {  // block-uniform trip count
+  const int64_t per_pass = (int64_t)MKE_BLOCK * ROWSET_IPT;
+  const int64_t stride = (int64_t)gridDim.x * per_pass;
+  for (int64_t base = (int64_t)blockIdx.x * per_pass; base < p.total; base += stride) {  // block-uniform trip count
     if (threadIdx.x < p.G) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t i = base + threadIdx.x;
-    int id = -1, owner = 0, local = 0;
-    bool first = false;
-    if (i < p.total) {
-      id = stream_at(p, i);
-      first = atomicExch(&p.flags[id], 1) == 0;
-      owner = id % p.G;
-      if (first) local = atomicAdd(&s_cnt[owner], 1);
+    int id[ROWSET_IPT], local[ROWSET_IPT];
+    bool first[ROWSET_IPT];
+#pragma unroll
+    for (int k = 0; k < ROWSET_IPT; ++k) {
+      const int64_t i = base + k * MKE_BLOCK + threadIdx.x;
+      id[k] = i < p.total ? stream_at(p, i) : -1;
     }
+#pragma unroll
+    for (int k = 0; k < ROWSET_IPT; ++k) first[k] = id[k] >= 0 && atomicExch(&p.flags[id[k]], 1) == 0;
+#pragma unroll
+    for (int k = 0; k < ROWSET_IPT; ++k) local[k] = first[k] ? atomicAdd(&s_cnt[id[k] % p.G], 1) : 0;
     __syncthreads();
     if (threadIdx.x < p.G) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&p.counts[threadIdx.x], s_cnt[threadIdx.x]) : 0;
     __syncthreads();
-    if (first) {
-      const int slot = s_base[owner] + local;
+#pragma unroll
+    for (int k = 0; k < ROWSET_IPT; ++k) {
+      if (!first[k]) continue;
+      const int owner = id[k] % p.G;
+      const int slot = s_base[owner] + local[k];
       if (slot < p.C) {
-        p.req[(int64_t)owner * p.C + slot] = id / p.G;
-        p.id_map[id] = owner * p.C + slot;
+        p.req[(int64_t)owner * p.C + slot] = id[k] / p.G;
+        p.id_map[id[k]] = owner * p.C + slot;
       } else {
         *p.overflow = 1;
-        p.id_map[id] = owner * p.C;  // keep indices in range; the step's result is invalid and flagged
+        p.id_map[id[k]] = owner * p.C;  // keep indices in range; the step's result is invalid and flagged
       }
     }
   }
@@ -78,6 +88,10 @@ struct RemapParams {
   int64_t reset_req_len;
   int32_t* reset_counts;  // nullable
   int n_counts;
+  const int32_t* want;    // nullable: [G][C] local rows the other ranks requested (-1 = pad) ...
+  int32_t* slot_of;       // ... inverted into slot_of[row * G + g] = slot (entries of rows nobody wants stay -1)
+  int G;
+  int64_t C;
 };
 
 __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p) {
@@ -85,6 +99,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p)
   if (p.reset_req)
     for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.reset_req_len; i += (int64_t)gridDim.x * MKE_BLOCK)
       p.reset_req[i] = -1;
+  if (p.want)
+    for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.G * p.C; i += (int64_t)gridDim.x * MKE_BLOCK) {
+      const int row = p.want[i];
+      if (row >= 0) p.slot_of[(int64_t)row * p.G + i / p.C] = (int32_t)(i % p.C);
+    }
   for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < p.total; i += (int64_t)gridDim.x * MKE_BLOCK) {
     int64_t k = i;
     int s = 0;
@@ -172,7 +191,8 @@ extern "C" int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* 
 extern "C" int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, const int32_t* ids1, int32_t* out1, int64_t n1,
                                 const int32_t* ids2, int32_t* out2, int64_t n2, const int32_t* ids3, int32_t* out3, int64_t n3,
                                 const int32_t* id_map, int32_t* flags, int32_t* reset_req, int64_t reset_req_len,
-                                int32_t* reset_counts, int n_counts, void* stream) {
+                                int32_t* reset_counts, int n_counts, const int32_t* want, int32_t* slot_of, int n_ranks,
+                                int capacity, void* stream) {
   using namespace mke;
   RemapParams p;
   p.reset_req = reset_req; p.reset_req_len = reset_req ? reset_req_len : 0; p.reset_counts = reset_counts;
@@ -187,10 +207,14 @@ extern "C" int mke_rowset_remap(const int32_t* ids0, int32_t* out0, int64_t n0, 
     if (p.len[s] > 0 && (!p.ids[s] || !p.out[s])) { set_error("NULL stream %d", s); return MKE_E_NULL; }
     p.total += p.len[s];
   }
-  if (p.total == 0 && !reset_req && !reset_counts) return MKE_OK;
+  if (want && (!slot_of || n_ranks < 1 || n_ranks > MKE_MAX_RANKS || capacity < 1)) { set_error("mke_rowset_remap: bad inversion arguments"); return MKE_E_SHAPE; }
+  p.want = want; p.slot_of = slot_of; p.G = n_ranks; p.C = capacity;
+  if (p.total == 0 && !reset_req && !reset_counts && !want) return MKE_OK;
   if (p.total > 0 && (!id_map || !flags)) { set_error("mke_rowset_remap: NULL pointer"); return MKE_E_NULL; }
   p.id_map = id_map; p.flags = flags;
-  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(p.total > p.reset_req_len ? p.total : p.reset_req_len, MKE_BLOCK)), dim3(MKE_BLOCK), 0,
+  int64_t work = p.total > p.reset_req_len ? p.total : p.reset_req_len;
+  if (want && (int64_t)n_ranks * capacity > work) work = (int64_t)n_ranks * capacity;
+  hipLaunchKernelGGL(k_rowset_remap, dim3(blocks_for(work, MKE_BLOCK)), dim3(MKE_BLOCK), 0,
                      (hipStream_t)stream, p);
   return check_launch("k_rowset_remap");
 }

@@ -27,6 +27,11 @@ struct UpdateParams {
   int normalize, optimizer;
   float lr;
   int chunk;  // rows per wavefront: 16, or 4 for small dense tables (every quarter-wave gets its own row at once)
+  // owner side of the sharded step: gradient = sum over ranks of the returned rows (mke_update_table.slot_of)
+  const float* __restrict__ src_rows;
+  int32_t* __restrict__ slot_of;
+  int n_ranks;
+  int64_t capacity;
 };
 
 template <int FPL>
@@ -34,8 +39,23 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
   float* gp = p.grad + row * (int64_t)p.stride + j;
   float* wp = p.table + row * (int64_t)p.stride + j;
   float g[FPL], w[FPL], a[FPL];
+  if (p.slot_of) {  // rank-ordered sum of the rows sent back for this row (deterministic, no atomics)
+    int32_t* so = p.slot_of + row * (int64_t)p.n_ranks;
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) g[k] = gp[k * 16];
+    for (int k = 0; k < FPL; ++k) g[k] = 0.f;
+    for (int r = 0; r < p.n_ranks; ++r) {
+      const int s = so[r];  // uniform over the quarter-wave
+      if (s >= 0) {
+        const float* src = p.src_rows + ((int64_t)r * p.capacity + s) * p.stride + j;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) g[k] += src[k * 16];
+      }
+    }
+    for (int r = j; r < p.n_ranks; r += 16) so[r] = -1;
+  } else {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) g[k] = gp[k * 16];
+  }
   if (p.copies > 1) {  // privatised gradient: sum (and consume) the other copies
     const int64_t ce = p.n_rows * (int64_t)p.stride;
     for (int c = 1; c < p.copies; ++c) {
@@ -52,8 +72,10 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 #pragma unroll
     for (int k = 0; k < FPL; ++k) a[k] = ap[k * 16];
   }
+  if (!p.slot_of) {
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) gp[k * 16] = 0.f;  // consume: restore the all-zero invariant
+    for (int k = 0; k < FPL; ++k) gp[k * 16] = 0.f;  // consume: restore the all-zero invariant
+  }
   if (p.refcount && j == 0) p.refcount[row] = 0;
 
   if (p.normalize) {
@@ -95,7 +117,15 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
   const int64_t base = wave * p.chunk;
   if (base >= p.n_rows) return;  // wave-uniform
   const int64_t r = base + (j & (p.chunk - 1));
-  const bool mine = (r < p.n_rows) && (p.touched == nullptr || p.touched[r] == p.tag);
+  bool mine = r < p.n_rows;
+  if (mine && p.slot_of) {
+    const int32_t* so = p.slot_of + r * (int64_t)p.n_ranks;
+    int any = -1;
+    for (int g = 0; g < p.n_ranks; ++g) any = max(any, so[g]);
+    mine = any >= 0;
+  } else if (mine) {
+    mine = p.touched == nullptr || p.touched[r] == p.tag;
+  }
   const uint32_t m = (uint32_t)(__ballot(mine) & ((1ull << p.chunk) - 1ull));  // the quarters hold the same flags
   const int total = __popc(m);
   for (int round = 0; round * 4 < total; ++round) {
@@ -178,6 +208,8 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
     p.table = tables[k].table; p.acc = tables[k].acc; p.grad = tables[k].grad; p.touched = tables[k].touched;
     p.copies = tables[k].grad_copies < 1 ? 1 : tables[k].grad_copies;
     p.refcount = tables[k].ref_count;
+    p.src_rows = tables[k].src_rows; p.slot_of = tables[k].slot_of; p.n_ranks = tables[k].n_ranks; p.capacity = tables[k].capacity;
+    if (p.slot_of) p.copies = 1;
     p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
     p.optimizer = optimizer; p.lr = lr; p.chunk = chunk_for(tables[k].n_rows);
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
@@ -224,6 +256,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   UpdateParams p;
   p.table = table; p.acc = acc; p.grad = grad; p.copies = grad_copies < 1 ? 1 : grad_copies; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
   p.refcount = nullptr;
+  p.src_rows = nullptr; p.slot_of = nullptr; p.n_ranks = 0; p.capacity = 0;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
   p.chunk = n_rows <= 16384 ? 4 : 16;
   const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * p.chunk;
@@ -257,7 +290,11 @@ extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n
   if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
   if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim: stride=%d dim=%d", stride, dim); return MKE_E_SHAPE; }
   for (int k = 0; k < n_tables; ++k) {
-    if (!tables[k].table || !tables[k].grad) { set_error("table %d: NULL table/grad", k); return MKE_E_NULL; }
+    if (!tables[k].table || (!tables[k].grad && !tables[k].slot_of)) { set_error("table %d: NULL table/grad", k); return MKE_E_NULL; }
+    if (tables[k].slot_of && (!tables[k].src_rows || tables[k].n_ranks < 1 || tables[k].n_ranks > 64 || tables[k].capacity < 1)) {
+      set_error("table %d: slot_of needs src_rows, 1 <= n_ranks <= 64 and capacity >= 1", k);
+      return MKE_E_SHAPE;
+    }
     if (optimizer == MKE_OPT_ADAGRAD && !tables[k].acc) { set_error("table %d: Adagrad needs an accumulator", k); return MKE_E_NULL; }
     if (tables[k].n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
   }

@@ -50,8 +50,9 @@ class HipBackend:
     def rowset_build(self, streams, flags, counts, req, id_map, overflow, n_ranks, capacity):
         _lib.rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity)
 
-    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None):
-        _lib.rowset_remap(streams, outs, id_map, flags, reset_req, reset_counts)
+    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None, want=None, slot_of=None,
+                     n_ranks=0, capacity=0):
+        _lib.rowset_remap(streams, outs, id_map, flags, reset_req, reset_counts, want, slot_of, n_ranks, capacity)
 
     def gather_padded(self, table, idx, out, zero_rows=None):
         _lib.rows_gather_padded(table, idx, out, zero_rows)
@@ -70,6 +71,12 @@ class HipBackend:
     def update_pair(self, t0, t1, tag, dim, lr):
         """One launch over two tables; each t = (table, acc, grad, touched, normalize); touched may be None."""
         _lib.rows_update_multi([t0, t1], tag, t0[0].shape[1], dim, _lib.OPT_ADAGRAD, lr)
+
+    def reduce_update(self, rel, shard, tag, dim, lr):
+        """One launch: the replicated table rel = (table, acc, grad, None, normalize), every row; and the owner's
+        reduce-and-update of its shard = dict(table, acc, normalize, src_rows, slot_of, n_ranks, capacity): each row
+        some rank sent a gradient for sums its contributions in rank order and is updated once."""
+        _lib.rows_update_multi([rel, shard], tag, rel[0].shape[1], dim, _lib.OPT_ADAGRAD, lr)
 
 
 class TorchComm:
@@ -126,8 +133,6 @@ class ShardedRelationTrainer:
         self.ent = torch.zeros(self.n_local, st, dtype=dtype, device=dev)
         self.ent[:, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
         self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)
-        self.ent_grad = torch.zeros_like(self.ent)
-        self.ent_touched = torch.zeros(self.n_local, dtype=torch.int32, device=dev)
         # --- replicated relation state ------------------------------------------------------------
         self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
         self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
@@ -158,7 +163,7 @@ class ShardedRelationTrainer:
         self._id_map = torch.zeros(self.n_ent, **i32)                            # global id -> compact row
         self._counts = torch.zeros(G, **i32)
         self._overflow = torch.zeros(1, **i32)
-        self._req = torch.full((G * C,), -1, **i32)                              # re-initialised by scatter_add each step
+        self._req = torch.full((G * C,), -1, **i32)                              # re-initialised by rowset_remap each step
         self._rows_out = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._rows_in = torch.empty(G * C, st, dtype=dtype, device=dev)
         self._cgrad = torch.zeros(G * C, st, dtype=dtype, device=dev)
@@ -175,6 +180,8 @@ class ShardedRelationTrainer:
         nslot = self.lookahead + 1
         self._nslot = nslot
         self._want2 = [torch.empty(G * C, **i32) for _ in range(nslot)]
+        # want inverted per local row (slot_of[row * G + g]); all -1 between steps: the update launch resets what it reads
+        self._slot_of = [torch.full((max(1, self.n_local) * G,), -1, **i32) for _ in range(nslot)]
         self._cidx2 = [[torch.empty(max_pos * (1 if k < 2 else neg_per_pos), **i32) for k in range(4)] for _ in range(nslot)]
         # this rank's share of every step of the epoch, as epoch positions: its negatives are sampled by ONE launch per
         # epoch (a per-step sampler launch is latency-bound: 38 us for 5000 positives vs 3.5 us/step amortised)
@@ -195,6 +202,7 @@ class ShardedRelationTrainer:
             self._main_done_valid = [False] * nslot
         self._plan_group = dist.new_group() if (dist.is_initialized() and G > 1 and self.lookahead > 0) else None
         self._planned = -1    # plans of global steps <= this index have been enqueued
+        self._stepped = -1    # main steps <= this index have been enqueued
         self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
 
     def _calibrate_capacity(self, c_bound: int, max_local: int, probe_steps: int = 3, slack: float = 1.15) -> int:
@@ -264,8 +272,10 @@ class ShardedRelationTrainer:
         if self.keep_stats:
             self._counts_last.copy_(self._counts)
         cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
-        # remap also re-initialises req / counts for the next build (they are consumed: the id exchange is enqueued)
-        be.rowset_remap(streams, cidx, self._id_map, self._flags, self._req, self._counts)
+        # remap also re-initialises req / counts for the next build (they are consumed: the id exchange is enqueued) and
+        # inverts the requests this owner received, for its reduce-and-update launch
+        be.rowset_remap(streams, cidx, self._id_map, self._flags, self._req, self._counts, self._want2[slot],
+                        self._slot_of[slot], G, C)
 
     def _enqueue_plan(self, i: int):
         """Plans are issued strictly in step order; the epoch shuffle happens right before the first plan of the next
@@ -330,20 +340,32 @@ class ShardedRelationTrainer:
             self.comm.all_to_all_single(self._ggot, self._cgrad)
             # ---- replicated relation table: all-reduce the (tiny) dense gradient -----------------------------------
             self.comm.all_reduce(self.rel_grad)
-            be.scatter_add(want, self._ggot, self.dim, self.ent_grad, self.ent_touched, tag)
-            # ---- one launch: identical relation update on every rank (touched=None: all rows) + this shard's rows
-            be.update_pair((self.rel, self.rel_acc, self.rel_grad, None, True),
-                           (self.ent, self.ent_acc, self.ent_grad, self.ent_touched, True), tag, self.dim, self.lr)
+            # ---- one launch: identical relation update on every rank (touched=None: all rows) + this shard's rows, each
+            #      summing what the ranks sent for it (no scatter pass, no dense gradient scratch on the owner)
+            be.reduce_update((self.rel, self.rel_acc, self.rel_grad, None, True),
+                             dict(table=self.ent, acc=self.ent_acc, normalize=True, src_rows=self._ggot,
+                                  slot_of=self._slot_of[slot], n_ranks=G, capacity=C), tag, self.dim, self.lr)
             if self._cuda:
                 self._main_done[slot].record(cur)
                 self._main_done_valid[slot] = True
         finally:
             if self._cuda:
                 _lib.pin_stream(old)
+        self._stepped = i
         # ---- look ahead: this step is enqueued, so the next epoch's plans may start if we are at the boundary --------
         nxt_limit = i + 1 + self.lookahead if i + 1 < epoch_end else i + 1
         while self._planned < min(nxt_limit, (epoch_end if i + 1 < epoch_end else epoch_end + self.steps) - 1):
             self._enqueue_plan(self._planned + 1)
+
+    def pending_slots(self) -> int:
+        """Synchronising invariant check: request slots the owner should have consumed and has not (0 between steps).
+        Plans enqueued ahead of the last executed step legitimately hold theirs."""
+        ahead = {p % self._nslot for p in range(self._stepped + 1, self._planned + 1)}
+        bad = 0
+        for k, so in enumerate(self._slot_of):
+            expect = int((self._want2[k] >= 0).sum()) if k in ahead else 0
+            bad += abs(int((so >= 0).sum()) - expect)
+        return bad
 
     def stats(self) -> dict:
         """Synchronising debug view of the last step's row set."""

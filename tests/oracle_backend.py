@@ -59,7 +59,8 @@ class OracleBackend:
                 im[i] = o * capacity
             cnt[o] += 1
 
-    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None):
+    def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None, want=None, slot_of=None,
+                     n_ranks=0, capacity=0):
         for ids, out in zip(streams, outs):
             i = ids.numpy()
             out.numpy()[:] = id_map.numpy()[i]
@@ -68,6 +69,28 @@ class OracleBackend:
             reset_req.numpy()[:] = -1
         if reset_counts is not None:
             reset_counts.numpy()[:] = 0
+        if want is not None:
+            w, so = want.numpy(), slot_of.numpy()
+            k = np.nonzero(w >= 0)[0]
+            so[w[k].astype(np.int64) * n_ranks + k // capacity] = k % capacity
+
+    def reduce_update(self, rel, shard, tag, dim, lr):
+        """mke_rows_update_multi with a slot_of table: rank-ordered sum of the returned rows, one update per row."""
+        table, acc, grad, touched, normalize = rel
+        self.update(table, acc, grad, touched, tag, dim, normalize, lr)
+        G, C = shard["n_ranks"], shard["capacity"]
+        ent, so, src = shard["table"], shard["slot_of"].numpy(), shard["src_rows"].numpy()
+        n = ent.shape[0]
+        so2 = so[:n * G].reshape(n, G)
+        g = np.zeros((n, src.shape[1]), dtype=src.dtype)
+        for r in range(G):
+            rows = np.nonzero(so2[:, r] >= 0)[0]
+            g[rows] += src[r * C + so2[rows, r]]
+        hit = (so2 >= 0).any(axis=1)
+        so2[hit] = -1
+        import torch
+        touched = torch.from_numpy(np.where(hit, tag, 0).astype(np.int32))
+        self.update(ent, shard["acc"], torch.from_numpy(g), touched, tag, dim, shard["normalize"], lr)
 
     def update_pair(self, t0, t1, tag, dim, lr):
         for (table, acc, grad, touched, normalize) in (t0, t1):

@@ -47,7 +47,7 @@ def _worker(rank, world, port, ret):
         full = tr.gather_entity_table().numpy()
         loss = tr.epoch_loss()
         if rank == 0:
-            ret.put((full, tr.rel[:, :DIM].numpy().copy(), loss, stats, tr.ent_grad.abs().max().item()))
+            ret.put((full, tr.rel[:, :DIM].numpy().copy(), loss, stats, float(tr.pending_slots())))
     finally:
         dist.destroy_process_group()
 
@@ -92,7 +92,7 @@ def test_sharded_equals_single_process_oracle():
     np.testing.assert_allclose(full, e, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(rel, r, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(loss, tot, rtol=1e-12)
-    assert gmax == 0.0                                   # owner consumed every gradient row
+    assert gmax == 0.0                                   # owner consumed every request slot
     assert all(st["remote_rows"] > 0 and st["overflow"] == 0 and st["unique_rows"] <= world * st["capacity"] for st in stats)
 
 

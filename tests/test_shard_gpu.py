@@ -73,3 +73,46 @@ def test_rowset_overflow_is_flagged():
     req = torch.full((2 * 10,), -1, **i32)
     _lib.rowset_build([ids], flags, counts, req, id_map, overflow, 2, 10)
     assert int(overflow) == 1 and int(id_map.max()) < 20
+
+
+@pytest.mark.parametrize("G,n_local,C,dim", [(1, 3000, 1500, 75), (8, 2500, 900, 75), (3, 700, 700, 20), (16, 64, 40, 256)])
+def test_owner_reduce_update_equals_scatter_then_update(G, n_local, C, dim):
+    """mke_rowset_remap's inversion + mke_rows_update_multi(slot_of) == mke_rows_scatter_add + touched-row update:
+    each owner row sums what the G ranks sent for it and is updated once; slots are consumed (reset to -1)."""
+    from multike_amd import _lib
+    from multike_amd.tables import ADAGRAD_INIT_ACC
+    rng = np.random.default_rng(G * 1000 + n_local)
+    stride = _lib.stride_for(dim)
+    want_np = np.full((G, C), -1, np.int32)
+    for g in range(G):                                     # every rank asks for a distinct subset of the local rows
+        k = int(rng.integers(0, min(C, n_local) + 1))
+        want_np[g, rng.permutation(C)[:k]] = rng.permutation(n_local)[:k]
+    want = torch.as_tensor(want_np.reshape(-1), device="cuda")
+    rows = torch.randn(G * C, stride, device="cuda") * 0.1
+    rows[:, dim:] = 0
+    rows[want < 0] = 0
+    t0 = torch.randn(n_local, stride, device="cuda")
+    t0[:, dim:] = 0
+    i32 = dict(dtype=torch.int32, device="cuda")
+    # --- two-kernel path
+    ta, aa = t0.clone(), torch.full_like(t0, ADAGRAD_INIT_ACC)
+    grad, touched = torch.zeros_like(t0), torch.zeros(n_local, **i32)
+    _lib.rows_scatter_add(want, rows, dim, grad, touched, 5)
+    _lib.rows_update(ta, aa, grad, touched, 5, dim, True, _lib.OPT_ADAGRAD, 0.05)
+    # --- inverted requests, one launch
+    slot_of = torch.full((n_local * G,), -1, **i32)
+    _lib.rowset_remap([], [], None, None, None, None, want, slot_of, G, C)
+    so = slot_of.cpu().numpy().reshape(n_local, G)
+    for g in range(G):
+        k = np.nonzero(want_np[g] >= 0)[0]
+        assert np.array_equal(so[want_np[g, k], g], k)
+    assert int((so >= 0).sum()) == int((want_np >= 0).sum())
+    tb, ab = t0.clone(), torch.full_like(t0, ADAGRAD_INIT_ACC)
+    _lib.rows_update_multi([dict(table=tb, acc=ab, normalize=True, src_rows=rows, slot_of=slot_of, n_ranks=G, capacity=C)],
+                           5, stride, dim, _lib.OPT_ADAGRAD, 0.05)
+    assert int((slot_of != -1).sum()) == 0
+    hit = np.zeros(n_local, bool)
+    hit[want_np[want_np >= 0]] = True
+    assert np.array_equal(tb.cpu().numpy()[~hit], t0.cpu().numpy()[~hit])        # rows nobody asked for: bit-identical
+    np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=2e-5, atol=2e-6)   # summation order differs
+    np.testing.assert_allclose(ab.cpu().numpy(), aa.cpu().numpy(), rtol=2e-5, atol=2e-6)
