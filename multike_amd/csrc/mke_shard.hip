@@ -183,7 +183,7 @@ extern "C" int mke_rowset_build(const int32_t* ids0, int64_t n0, const int32_t* 
   if (p.total == 0) return MKE_OK;
   p.flags = flags; p.counts = counts; p.req = req; p.id_map = id_map; p.overflow = overflow; p.G = n_ranks; p.C = capacity;
   // few, fat blocks: one global atomic per (block iteration, owner) on n_ranks counters
-  hipLaunchKernelGGL(k_rowset_build, dim3(blocks_for(p.total, MKE_BLOCK * 4) > 512 ? 512 : blocks_for(p.total, MKE_BLOCK * 4)),
+  hipLaunchKernelGGL(k_rowset_build, dim3(blocks_for(p.total, MKE_BLOCK * ROWSET_IPT) > 512 ? 512 : blocks_for(p.total, MKE_BLOCK * ROWSET_IPT)),
                      dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   return check_launch("k_rowset_build");
 }
