@@ -382,6 +382,38 @@ typedef struct mke_relation_plan {
 int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (6c) Truncated-sampling k-NN refresh without the similarity matrix.
+ *
+ * replaces: `generate_neighbours` / `find_neighbours` at code/base/batch.py:119-150 (sim = E . E^T over one KG's useful
+ *           entities, per row the k largest columns via argpartition, self included, unordered).
+ *
+ *   mke_sim_select: for rows [row_lo, row_hi) of emb ([n_cols][ld] float32, row-normalised by the caller, columns
+ *     dim..kpad zero, kpad a multiple of 16) against ALL n_cols rows: every column j with emb[i] . emb[j] > tau[i - row_lo]
+ *     is appended to row i's candidate list, similarity alongside.  The columns are split into n_seg contiguous ranges;
+ *     range s of row i owns cand[i - row_lo][s][0 .. seg_cap) and seg_count[i - row_lo][s] (the number
+ *     of hits, which may exceed seg_cap: only the first seg_cap are stored).  Inside a segment the candidates are in
+ *     column order.  n_seg <= 16, n_seg * seg_cap <= 4096.  The similarity is an f32 MFMA fma chain over k.
+ *   mke_topk_rows: per row of a short list (n_seg segments of seg_cap slots, seg_count valid entries each; NULL
+ *     seg_count = all slots valid): the exact k largest values.  out_idx[row][0..k) = their idx entries (NULL idx = the
+ *     slot number), mapped through id_map when given, in list order; ties at the k-th value are broken by list order.
+ *     out_kth[row] = the k-th largest value.  status[row] = 0 ok, 1 = fewer than k entries, 2 = a segment overflowed
+ *     (seg_count > seg_cap); for status != 0 out_idx[row] is not written and out_kth[row] = -3e38.
+ *   mke_topk_candidates: the same over mke_sim_select's (column, similarity) pairs.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mke_candidate {
+  int32_t idx;
+  float sim;
+} mke_candidate;
+int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols, int64_t row_lo, int64_t row_hi, const float* tau,
+                   int n_seg, int seg_cap, mke_candidate* cand, int32_t* seg_count, void* stream);
+int mke_topk_candidates(const mke_candidate* cand, const int32_t* seg_count, int64_t rows, int n_seg, int seg_cap, int k,
+                        const int32_t* id_map /*nullable*/, int32_t* out_idx /*nullable*/, float* out_kth /*nullable*/,
+                        int32_t* status /*nullable*/, void* stream);
+int mke_topk_rows(const float* vals, const int32_t* idx /*nullable*/, const int32_t* seg_count /*nullable*/, int64_t rows,
+                  int n_seg, int seg_cap, int k, const int32_t* id_map /*nullable*/, int32_t* out_idx /*nullable*/,
+                  float* out_kth /*nullable*/, int32_t* status /*nullable*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (7) Bookkeeping of the entity-row sharded (multi-GPU) step.  New design — the reference has no multi-device
  *     code.  Entity rows are owned by rank id % n_ranks (local row id / n_ranks).  Everything
  *     is fixed-capacity so that the exchanges are equal-split all-to-alls with no host synchronisation.

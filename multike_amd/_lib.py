@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_select_above", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_select_above", "mke_sim_select", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
 )
 
 
@@ -347,6 +347,53 @@ def select_above(sim: torch.Tensor, tau: torch.Tensor, cap: int):
                                 _dev(cnt, torch.int32, "count"), _stream())
     _check(rc, "mke_select_above")
     return idx, cnt
+
+
+def sim_select(emb: torch.Tensor, kpad: int, row_lo: int, row_hi: int, tau: torch.Tensor, n_seg: int, seg_cap: int):
+    """mke_sim_select -> (cand int32 [rows, n_seg, seg_cap, 2] = (column, similarity bits) pairs, seg_count int32 [rows, n_seg])."""
+    if emb.dim() != 2 or emb.stride(1) != 1 or emb.dtype != torch.float32:
+        raise MultiKEHipError("sim_select: emb must be a row-major float32 matrix")
+    rows = row_hi - row_lo
+    if tau.numel() != rows:
+        raise MultiKEHipError("sim_select: one threshold per row")
+    cand = torch.empty(rows, n_seg, seg_cap, 2, dtype=torch.int32, device=emb.device)
+    cnt = torch.empty(rows, n_seg, dtype=torch.int32, device=emb.device)
+    rc = lib().mke_sim_select(C.c_void_p(emb.data_ptr()), C.c_int(emb.stride(0)), C.c_int(kpad), C.c_int64(emb.shape[0]),
+                              C.c_int64(row_lo), C.c_int64(row_hi), _dev(tau, torch.float32, "tau"), C.c_int(n_seg),
+                              C.c_int(seg_cap), _dev(cand, torch.int32, "cand"), _dev(cnt, torch.int32, "seg_count"), _stream())
+    _check(rc, "mke_sim_select")
+    return cand, cnt
+
+
+def topk_candidates(cand: torch.Tensor, seg_count: torch.Tensor, k: int, id_map=None):
+    """mke_topk_candidates over sim_select's pairs -> (out_idx int32 [rows, k], status int32 [rows])."""
+    rows, n_seg, seg_cap, _ = cand.shape
+    out = torch.empty(rows, k, dtype=torch.int32, device=cand.device)
+    status = torch.empty(rows, dtype=torch.int32, device=cand.device)
+    rc = lib().mke_topk_candidates(_dev(cand, torch.int32, "cand"), _dev(seg_count, torch.int32, "seg_count"), C.c_int64(rows),
+                                   C.c_int(n_seg), C.c_int(seg_cap), C.c_int(k), _dev(id_map, torch.int32, "id_map"),
+                                   _dev(out, torch.int32, "out_idx"), C.c_void_p(0), _dev(status, torch.int32, "status"), _stream())
+    _check(rc, "mke_topk_candidates")
+    return out, status
+
+
+def topk_rows(vals: torch.Tensor, k: int, idx=None, seg_count=None, id_map=None, want_idx=True, want_kth=False):
+    """mke_topk_rows over vals [rows, n_seg, seg_cap] (or [rows, seg_cap]) -> (out_idx int32 [rows, k] | None,
+    kth float32 [rows] | None, status int32 [rows])."""
+    if vals.dim() == 2:
+        vals = vals.unsqueeze(1)
+    if not vals.is_contiguous():
+        raise MultiKEHipError("topk_rows: vals must be contiguous")
+    rows, n_seg, seg_cap = vals.shape
+    out = torch.empty(rows, k, dtype=torch.int32, device=vals.device) if want_idx else None
+    kth = torch.empty(rows, dtype=torch.float32, device=vals.device) if want_kth else None
+    status = torch.empty(rows, dtype=torch.int32, device=vals.device)
+    rc = lib().mke_topk_rows(_dev(vals, torch.float32, "vals"), _dev(idx, torch.int32, "idx"),
+                             _dev(seg_count, torch.int32, "seg_count"), C.c_int64(rows), C.c_int(n_seg), C.c_int(seg_cap),
+                             C.c_int(k), _dev(id_map, torch.int32, "id_map"), _dev(out, torch.int32, "out_idx"),
+                             _dev(kth, torch.float32, "out_kth"), _dev(status, torch.int32, "status"), _stream())
+    _check(rc, "mke_topk_rows")
+    return out, kth, status
 
 
 def mapping_scratch_floats(n: int, dim: int) -> int:

@@ -107,41 +107,64 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     """Truncated-sampling k-NN refresh on the device (code/base/batch.py:119-150): inner product of the (already
     row-normalised) relation-view rows of one KG's useful entities, top `neighbors_num` per row INCLUDING the entity
     itself, unordered.  Returns (cand_table [n_ent_total, k] int32, cand_valid [n_ent_total] uint8) for
-    `KGSide.set_neighbours`.  The similarity block and the top-k selection are library ops (rocBLAS GEMM, torch.topk)."""
+    `KGSide.set_neighbours`.
+
+    When k is a small share of a long row the n x n similarity matrix is never built: a per-row threshold a bit below
+    the k-th largest value is estimated from a fixed column sample (small library GEMM + `mke_topk_rows`),
+    `mke_sim_select` computes the similarities tile by tile on the matrix cores and keeps only the ~1.4 k columns above
+    the threshold, `mke_topk_rows` takes the exact top k of that short list.  The few rows whose estimate came out too
+    tight (fewer than k hits) or too loose (a segment overflowed) are redone at full width (library GEMM + torch.topk,
+    which is also the path of short rows).  The result is the exact top-k set."""
+    from .. import _lib
     e = (entity_embeds.to(device).float() if isinstance(entity_embeds, torch.Tensor)
          else torch.as_tensor(np.asarray(entity_embeds), dtype=torch.float32, device=device))
     ids = torch.as_tensor(np.asarray(entity_list), dtype=torch.int64, device=device)
-    n = e.shape[0]
+    n, d = e.shape
     k = int(neighbors_num)
     table = torch.zeros(n_ent_total, k, dtype=torch.int32, device=device)
     valid = torch.zeros(n_ent_total, dtype=torch.uint8, device=device)
-    # Full-width torch.topk over n columns costs 3x the GEMM.  When k is a small share of a long row: estimate a per-row
-    # threshold a bit below the k-th largest value from a column sample, compact the columns above it on the device
-    # (mke_select_above, ~1.4 k per row), run the exact top-k on that short list; the few rows whose estimate came out too
-    # tight (fewer than k hits) or too loose (more than `cap`) take the full-width path.  The result is the exact top-k set.
     n_samp, cap = 4096, _pow2_at_least(int(1.4 * k) + 64)
-    short = n >= 8 * n_samp and cap * 4 <= n
-    if short:
-        from .. import _lib
-        g = torch.Generator(device="cpu")
-        g.manual_seed(12345)
-        samp = torch.randperm(n, generator=g)[:n_samp].to(device)
-        m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
-    for lo in range(0, n, block_rows):
-        sim = e[lo:lo + block_rows] @ e.t()
-        if not short:
-            idx = torch.topk(sim, k, dim=1, sorted=False).indices
-        else:
-            tau = torch.topk(sim[:, samp], m, dim=1, sorted=False).values.min(dim=1).values
-            cidx, cnt = _lib.select_above(sim, tau, cap)
-            pos = torch.arange(cap, device=device)[None, :]
-            live = pos < cnt[:, None]
-            csim = torch.where(live, sim.gather(1, cidx.clamp(0, n - 1).long() * live), torch.full((), -3.0e38, device=device))
-            idx = cidx.long().gather(1, torch.topk(csim, k, dim=1, sorted=False).indices)
-            bad = torch.nonzero((cnt < k) | (cnt > cap)).reshape(-1)
-            if bad.numel():
-                idx[bad] = torch.topk(sim[bad], k, dim=1, sorted=False).indices
-        table[ids[lo:lo + block_rows]] = ids[idx].to(torch.int32)
+    short = n >= 8 * n_samp and cap * 4 <= n and cap <= 4096 and d <= 256
+
+    def full_width(rows):
+        return torch.topk(e[rows] @ e.t(), k, dim=1, sorted=False).indices
+
+    if not short:
+        for lo in range(0, n, block_rows):
+            table[ids[lo:lo + block_rows]] = ids[full_width(slice(lo, lo + block_rows))].to(torch.int32)
+        valid[ids] = 1
+        return table, valid
+
+    kpad = _lib.stride_for(d)
+    ep = torch.zeros(n, kpad, dtype=torch.float32, device=device)
+    ep[:, :d] = e
+    ids32 = ids.to(torch.int32)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(12345)
+    samp = torch.randperm(n, generator=g)[:n_samp].to(device)
+    es_t = e[samp].t().contiguous()
+    m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
+    chunk = 131072                                        # rows per launch: bounds the candidate buffers (8 * cap bytes per row)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        # enough (row block, column segment) work items to fill the chip several times over, segments of >= 4096 columns
+        n_seg = 1
+        while n_seg < 8 and ((hi - lo + 127) // 128) * n_seg < 6144 and n // (2 * n_seg) >= 4096:
+            n_seg *= 2
+        tau = torch.empty(hi - lo, dtype=torch.float32, device=device)
+        for a in range(lo, hi, 16384):                    # sample similarities: [rows, 4096] library GEMM blocks
+            b = min(hi, a + 16384)
+            _, kth, _ = _lib.topk_rows(e[a:b] @ es_t, m, want_idx=False, want_kth=True)
+            tau[a - lo:b - lo] = kth
+        cand, cnt = _lib.sim_select(ep, kpad, lo, hi, tau, n_seg, cap // n_seg)
+        out, status = _lib.topk_candidates(cand, cnt, k, id_map=ids32)
+        table[ids[lo:hi]] = out
+        bad = torch.nonzero(status).reshape(-1)
+        if bad.numel():
+            rows = bad + lo
+            for a in range(0, rows.numel(), block_rows):
+                r = rows[a:a + block_rows]
+                table[ids[r]] = ids[full_width(r)].to(torch.int32)
     valid[ids] = 1
     return table, valid
 

@@ -1,0 +1,388 @@
+// mke_knn.hip — truncated-sampling k-NN refresh without the similarity matrix (gfx950).
+//
+// What it computes = code/base/batch.py:119-150 (`generate_neighbours` / `find_neighbours`): for every useful entity of
+// one KG the k = 2 % columns of `sim = E . E^T` (already row-normalised relation-view rows, so cosine) with the largest
+// values, the entity itself included, as an unordered set.  The reference materialises the n x n matrix and
+// argpartitions every row; at n = 100K that is 40 GB written and read back.  Here:
+//
+//   k_sim_select   the similarity tile never leaves the registers: a block owns 128 rows (4 wavefronts x one 32-row strip
+//                  held as MFMA A operands in VGPRs), streams 64-column tiles of E (64 consecutive rows = one contiguous
+//                  copy) through LDS, multiplies with v_mfma_f32_32x32x2_f32 (plain f32 fma chains) and, in the
+//                  epilogue, appends the columns whose similarity exceeds the row's threshold tau to the row's candidate
+//                  list: a ballot per accumulator register gives every hit its slot (the 32 lanes of a half-wave hold 32
+//                  columns of ONE row), so a row's candidates of one block are written in column order with no atomics.
+//                  The columns are split over gridDim.y segments (a row-owner block sweeping all columns alone would
+//                  leave a 2x tail: 782 blocks on 768 slots); segment s of a row has its own counter and seg_cap slots.
+//   k_topk_rows    exact k-th largest of a short list held in LDS (<= 4096 values: the candidates of a row, or a row of
+//                  sample similarities when only the threshold is wanted): 4-pass byte-wise radix select on the
+//                  order-preserving integer image of the floats, then an ordered compaction (block scan) of the values
+//                  above the k-th plus the first ties — the output is deterministic and in candidate (= column) order.
+//
+// The threshold of a row is the m-th largest of its similarities to a fixed column sample (caller: a small library GEMM
+// + k_topk_rows), chosen so that ~1.4 k columns pass; a row whose estimate came out too tight (< k hits) or whose
+// segment overflowed is flagged and redone by the caller at full width.  The result is the exact top-k set.
+#include "mke_common.h"
+
+namespace mke {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KNN_BM 128  // rows per block
+#define KNN_BN_FOR(KS) ((KS) <= 13 ? 64 : 32)  // columns per tile (LDS: BN x (kpad + 4) floats must stay under 64 KB)
+#define KNN_MAX_LIST 4096
+
+struct SimSelectParams {
+  const float* __restrict__ emb;  // [n][ld], columns >= dim zero up to kpad
+  int ld;
+  int n_cols;             // columns = rows 0..n_cols-1 of emb
+  int row_lo, row_hi;     // rows handled by this launch
+  const float* __restrict__ tau;  // [row_hi - row_lo]
+  int n_seg, seg_cap, tiles_per_seg;
+  mke_candidate* __restrict__ cand;  // [rows][n_seg][seg_cap] (column, similarity) pairs: one 8-byte store per hit
+  int32_t* __restrict__ seg_count;   // [rows][n_seg]
+};
+
+template <int KS>  // kpad / 16
+__global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams p) {
+  constexpr int KP = KS * 16;
+  constexpr int KNN_BN = KNN_BN_FOR(KS);
+  constexpr int NQ = KNN_BN * KP / (4 * MKE_BLOCK);  // float4 per thread per tile
+  static_assert(KNN_BN * KP % (4 * MKE_BLOCK) == 0, "tile must split evenly into float4 per thread");
+  constexpr int NBUF = 2 * KNN_BN * (KP + 4) * 4 <= 65536 ? 2 : 1;  // double-buffered tiles: one barrier per tile
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][KNN_BN][KP + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int strip0 = p.row_lo + blockIdx.x * KNN_BM + wv * 32;
+  // A operands: MFMA j of slab s multiplies k = s*16 + half*8 + j (lanes 0-31 feed the even, 32-63 the odd k of a 32x32x2)
+  float a[KS * 8];
+  {
+    const int r = strip0 + l31;
+    const bool ok = r < p.row_hi;
+    const float* ap = p.emb + (int64_t)(ok ? r : p.row_lo) * p.ld + half * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 x = ok ? *reinterpret_cast<const float4*>(ap + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 y = ok ? *reinterpret_cast<const float4*>(ap + s * 16 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a[s * 8 + 0] = x.x; a[s * 8 + 1] = x.y; a[s * 8 + 2] = x.z; a[s * 8 + 3] = x.w;
+      a[s * 8 + 4] = y.x; a[s * 8 + 5] = y.y; a[s * 8 + 6] = y.z; a[s * 8 + 7] = y.w;
+    }
+  }
+  // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float tauR[16];
+  int cnt[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int r = strip0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+    tauR[reg] = r < p.row_hi ? p.tau[r - p.row_lo] : 3.0e38f;
+    cnt[reg] = 0;
+  }
+  const int seg = blockIdx.y;
+  const int ntiles = (p.n_cols + KNN_BN - 1) / KNN_BN;
+  const int t0 = seg * p.tiles_per_seg;
+  const int t1 = min(ntiles, t0 + p.tiles_per_seg);
+  const unsigned lt = (1u << l31) - 1u;
+  // global -> registers -> LDS staging of a tile: 64 rows x KP floats, KS float4 per thread
+  float4 pre[NQ];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = (tid + q * MKE_BLOCK) * 4;
+      const int c = e / KP, k = e % KP;
+      const int col = t * KNN_BN + c;
+      pre[q] = col < p.n_cols ? *reinterpret_cast<const float4*>(p.emb + (int64_t)col * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = (tid + q * MKE_BLOCK) * 4;
+      *reinterpret_cast<float4*>(&Bs[buf][e / KP][e % KP]) = pre[q];
+    }
+  };
+  // candidate slot of (row of accumulator register reg, position) as a 32-bit element offset
+  const int row_stride = p.n_seg * p.seg_cap;
+  const int base0 = ((strip0 - p.row_lo + 4 * half) * p.n_seg + seg) * p.seg_cap;
+  if (t0 < t1) {
+    fetch(t0);
+    stage(0);
+  }
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) % NBUF;
+    if (t + 1 < t1) fetch(t + 1);  // in flight during the MFMAs below
+#pragma unroll
+    for (int cg = 0; cg < KNN_BN / 32; ++cg) {
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const float* bp = &Bs[buf][cg * 32 + l31][half * 8];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(bp + s * 16);
+        const float4 y = *reinterpret_cast<const float4*>(bp + s * 16 + 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 0], x.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 1], x.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 2], x.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 3], x.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 4], y.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 5], y.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 6], y.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 7], y.w, acc, 0, 0, 0);
+      }
+      const int col = t * KNN_BN + cg * 32 + l31;
+      const bool col_ok = col < p.n_cols;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const bool hit = col_ok && acc[reg] > tauR[reg];
+        const uint64_t m = __ballot(hit);
+        if (m == 0) continue;  // wave-uniform
+        const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
+        const int pos = cnt[reg] + __popc(mh & lt);
+        if (hit && pos < p.seg_cap) {
+          mke_candidate c;
+          c.idx = col;
+          c.sim = acc[reg];
+          p.cand[base0 + ((reg & 3) + 8 * (reg >> 2)) * row_stride + pos] = c;
+        }
+        cnt[reg] += __popc(mh);
+      }
+    }
+    if (NBUF == 1) __syncthreads();  // every wave is done reading the only buffer
+    if (t + 1 < t1) stage((t + 1 - t0) % NBUF);
+    __syncthreads();
+  }
+  if (l31 == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = strip0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+      if (r < p.row_hi) p.seg_count[(int64_t)(r - p.row_lo) * p.n_seg + seg] = cnt[reg];
+    }
+  }
+}
+
+// order-preserving integer image of a float: larger float <=> larger unsigned
+__device__ __forceinline__ unsigned float_key(float v) {
+  unsigned u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0u;  // -0 and +0 compare equal as floats: one key
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+struct TopkParams {
+  const mke_candidate* __restrict__ cand;  // [rows][n_seg][seg_cap] pairs; or NULL and:
+  const float* __restrict__ vals;     // [rows][n_seg][seg_cap]
+  const int32_t* __restrict__ idx;    // nullable: same shape; NULL => the position in the list is the index
+  const int32_t* __restrict__ seg_count;  // nullable: [rows][n_seg] valid entries per segment; NULL => seg_cap each
+  int n_seg, seg_cap, k;
+  const int32_t* __restrict__ id_map;  // nullable: out = id_map[index]
+  int32_t* __restrict__ out_idx;       // nullable: [rows][k]
+  float* __restrict__ out_kth;         // nullable: [rows] k-th largest value
+  int32_t* __restrict__ status;        // nullable: [rows] 0 ok, 1 fewer than k entries, 2 a segment overflowed
+};
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_topk_rows(const TopkParams p) {
+  static_assert(MKE_BLOCK == 256, "one histogram bin per thread");
+  __shared__ unsigned s_key[KNN_MAX_LIST];
+  __shared__ int s_idx[KNN_MAX_LIST];
+  __shared__ int s_hist[MKE_BLOCK / 64][256];
+  __shared__ unsigned s_red[8];
+  __shared__ int s_off[17];
+  __shared__ int s_wave[MKE_BLOCK / 64];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need, s_bad;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int tot = 0, bad = 0;
+    for (int s = 0; s < p.n_seg; ++s) {
+      int c = p.seg_count ? p.seg_count[row * p.n_seg + s] : p.seg_cap;
+      if (c > p.seg_cap) { bad = 2; c = p.seg_cap; }
+      s_off[s] = tot;
+      tot += c;
+    }
+    s_off[p.n_seg] = tot;
+    if (!bad && tot < p.k) bad = 1;
+    s_bad = bad;
+  }
+  __syncthreads();
+  if (s_bad) {  // block-uniform
+    if (tid == 0) {
+      if (p.status) p.status[row] = s_bad;
+      if (p.out_kth) p.out_kth[row] = -3.0e38f;
+    }
+    return;
+  }
+  const int total = s_off[p.n_seg];
+  for (int s = 0; s < p.n_seg; ++s) {
+    const int n = s_off[s + 1] - s_off[s];
+    const int64_t base = (row * p.n_seg + s) * (int64_t)p.seg_cap;
+    if (p.cand) {
+      for (int i = tid; i < n; i += MKE_BLOCK) {
+        const mke_candidate c = p.cand[base + i];
+        s_key[s_off[s] + i] = float_key(c.sim);
+        s_idx[s_off[s] + i] = c.idx;
+      }
+    } else {
+      for (int i = tid; i < n; i += MKE_BLOCK) {
+        s_key[s_off[s] + i] = float_key(p.vals[base + i]);
+        s_idx[s_off[s] + i] = p.idx ? p.idx[base + i] : s * p.seg_cap + i;
+      }
+    }
+  }
+  // The keys of one list share their leading bits (similarities above a threshold: same sign, one or two exponents), and
+  // a byte-wise pass over shared bits would pile every LDS atomic onto one bin: find the highest bit in which the largest
+  // and the smallest key differ and select on the bits below it only.
+  unsigned kmin = 0xFFFFFFFFu, kmax = 0u;
+  for (int i = tid; i < total; i += MKE_BLOCK) {
+    const unsigned kx = s_key[i];
+    kmin = min(kmin, kx);
+    kmax = max(kmax, kx);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, off, 64));
+    kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, off, 64));
+  }
+  const int lane = tid & 63, wv = tid >> 6;
+  if (lane == 0) { s_red[wv] = kmin; s_red[4 + wv] = kmax; }
+  __syncthreads();
+  kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+  kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+  int hi = kmin == kmax ? 0 : 32 - __clz(kmin ^ kmax);  // number of low bits still undecided
+  if (tid == 0) { s_prefix = hi >= 32 ? 0u : (kmax >> hi) << hi; s_need = p.k; }
+  __syncthreads();
+  // radix select on the undecided bits, most significant digit first; a private histogram per wavefront (4x fewer
+  // collisions), bins summed and scanned from the top by all 256 threads
+  while (hi > 0) {
+    const int w = min(8, hi), shift = hi - w;
+#pragma unroll
+    for (int q = 0; q < MKE_BLOCK / 64; ++q) s_hist[q][tid] = 0;
+    __syncthreads();
+    const unsigned pre = s_prefix;
+    const int need = s_need;
+    for (int i = tid; i < total; i += MKE_BLOCK) {
+      const unsigned kx = s_key[i];
+      if (hi >= 32 || (kx >> hi) == (pre >> hi)) atomicAdd(&s_hist[wv][(kx >> shift) & ((1u << w) - 1u)], 1);
+    }
+    __syncthreads();
+    // thread t owns digit 255 - t: inclusive scan from the largest digit down
+    const int dgt = 255 - tid;
+    const int h = s_hist[0][dgt] + s_hist[1][dgt] + s_hist[2][dgt] + s_hist[3][dgt];
+    int incl = h;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    for (int q = 0; q < wv; ++q) incl += s_wave[q];
+    if (incl >= need && incl - h < need) {  // exactly one thread: the digit where the count from the top reaches `need`
+      s_prefix = pre | ((unsigned)dgt << shift);
+      s_need = need - (incl - h);
+    }
+    hi = shift;
+    __syncthreads();
+  }
+  const unsigned kth = s_prefix;
+  const int ties = s_need;  // how many of the keys equal to kth belong to the top k
+  if (tid == 0) {
+    if (p.out_kth) p.out_kth[row] = key_float(kth);
+    if (p.status) p.status[row] = 0;
+  }
+  if (!p.out_idx) return;
+  // ordered compaction: thread t owns a contiguous run; packed (greater | equal << 16) counts scanned over the block
+  const int per = (total + MKE_BLOCK - 1) / MKE_BLOCK;
+  const int lo = min(total, tid * per), up = min(total, lo + per);
+  int mine = 0;
+  for (int i = lo; i < up; ++i) {
+    const unsigned kx = s_key[i];
+    mine += (kx > kth ? 1 : 0) + (kx == kth ? 65536 : 0);
+  }
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();  // s_wave is reused
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  int before = incl - mine;
+  for (int w = 0; w < wv; ++w) before += s_wave[w];
+  int gt = before & 0xFFFF, eq = before >> 16;
+  int32_t* o = p.out_idx + row * (int64_t)p.k;
+  for (int i = lo; i < up; ++i) {
+    const unsigned kx = s_key[i];
+    if (kx > kth || (kx == kth && eq < ties)) {
+      const int id = s_idx[i];
+      o[gt + min(eq, ties)] = p.id_map ? p.id_map[id] : id;
+    }
+    gt += kx > kth ? 1 : 0;
+    eq += kx == kth ? 1 : 0;
+  }
+}
+
+}  // namespace mke
+
+extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols, int64_t row_lo, int64_t row_hi, const float* tau,
+                              int n_seg, int seg_cap, mke_candidate* cand, int32_t* seg_count, void* stream) {
+  using namespace mke;
+  if (n_cols < 0 || row_lo < 0 || row_hi < row_lo || row_hi > n_cols || n_cols > 0x7FFFFF00LL) { set_error("mke_sim_select: bad row/column range"); return MKE_E_SHAPE; }
+  if (row_hi == row_lo) return MKE_OK;
+  if (!emb || !tau || !cand || !seg_count) { set_error("mke_sim_select: NULL pointer"); return MKE_E_NULL; }
+  if (kpad <= 0 || kpad % 16 != 0 || kpad > MKE_MAX_STRIDE || ld < kpad || ld % 4 != 0) { set_error("mke_sim_select: kpad must be a multiple of 16 <= %d and <= ld (ld a multiple of 4)", MKE_MAX_STRIDE); return MKE_E_SHAPE; }
+  if (n_seg < 1 || n_seg > 16 || seg_cap < 1 || (int64_t)n_seg * seg_cap > KNN_MAX_LIST) { set_error("mke_sim_select: need 1 <= n_seg <= 16 and n_seg * seg_cap <= %d", KNN_MAX_LIST); return MKE_E_SHAPE; }
+  if ((row_hi - row_lo + KNN_BM) * (int64_t)n_seg * seg_cap > 0x7FFFFFFFLL) { set_error("mke_sim_select: more than 2^31 candidate slots in one launch (split the row range)"); return MKE_E_RANGE; }
+  SimSelectParams p;
+  p.emb = emb; p.ld = ld; p.n_cols = (int)n_cols; p.row_lo = (int)row_lo; p.row_hi = (int)row_hi; p.tau = tau;
+  p.n_seg = n_seg; p.seg_cap = seg_cap;
+  const int bn = KNN_BN_FOR(kpad / 16);
+  const int ntiles = (int)((n_cols + bn - 1) / bn);
+  p.tiles_per_seg = (ntiles + n_seg - 1) / n_seg;
+  p.cand = cand; p.seg_count = seg_count;
+  dim3 grid((unsigned)((row_hi - row_lo + KNN_BM - 1) / KNN_BM), (unsigned)n_seg);
+  hipStream_t st = (hipStream_t)stream;
+#define KNN_CASE(K)                                                                 \
+  case K:                                                                           \
+    hipLaunchKernelGGL((k_sim_select<K / 16>), grid, dim3(MKE_BLOCK), 0, st, p);     \
+    break;
+  switch (kpad) {
+    KNN_CASE(16) KNN_CASE(32) KNN_CASE(48) KNN_CASE(64) KNN_CASE(80) KNN_CASE(96) KNN_CASE(112) KNN_CASE(128) KNN_CASE(160)
+    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256)
+    default:
+      set_error("mke_sim_select: unsupported kpad %d", kpad);
+      return MKE_E_UNSUPPORTED;
+  }
+#undef KNN_CASE
+  return check_launch("k_sim_select");
+}
+
+static int topk_launch(const mke_candidate* cand, const float* vals, const int32_t* idx, const int32_t* seg_count, int64_t rows,
+                       int n_seg, int seg_cap, int k, const int32_t* id_map, int32_t* out_idx, float* out_kth, int32_t* status,
+                       void* stream, const char* who) {
+  using namespace mke;
+  if (rows < 0 || rows > 0x7FFFFFFFLL) { set_error("%s: bad row count", who); return MKE_E_SHAPE; }
+  if (rows == 0) return MKE_OK;
+  if ((!vals && !cand) || (!out_idx && !out_kth)) { set_error("%s: NULL pointer", who); return MKE_E_NULL; }
+  if (n_seg < 1 || n_seg > 16 || seg_cap < 1 || (int64_t)n_seg * seg_cap > KNN_MAX_LIST || k < 1 || k > n_seg * seg_cap) {
+    set_error("%s: need 1 <= n_seg <= 16, n_seg * seg_cap <= %d and 1 <= k <= n_seg * seg_cap", who, KNN_MAX_LIST);
+    return MKE_E_SHAPE;
+  }
+  TopkParams p;
+  p.cand = cand; p.vals = vals; p.idx = idx; p.seg_count = seg_count; p.n_seg = n_seg; p.seg_cap = seg_cap; p.k = k; p.id_map = id_map;
+  p.out_idx = out_idx; p.out_kth = out_kth; p.status = status;
+  hipLaunchKernelGGL(k_topk_rows, dim3((unsigned)rows), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  return check_launch("k_topk_rows");
+}
+
+extern "C" int mke_topk_rows(const float* vals, const int32_t* idx, const int32_t* seg_count, int64_t rows, int n_seg, int seg_cap,
+                             int k, const int32_t* id_map, int32_t* out_idx, float* out_kth, int32_t* status, void* stream) {
+  return topk_launch(nullptr, vals, idx, seg_count, rows, n_seg, seg_cap, k, id_map, out_idx, out_kth, status, stream, "mke_topk_rows");
+}
+
+extern "C" int mke_topk_candidates(const mke_candidate* cand, const int32_t* seg_count, int64_t rows, int n_seg, int seg_cap, int k,
+                                   const int32_t* id_map, int32_t* out_idx, float* out_kth, int32_t* status, void* stream) {
+  return topk_launch(cand, nullptr, nullptr, seg_count, rows, n_seg, seg_cap, k, id_map, out_idx, out_kth, status, stream,
+                     "mke_topk_candidates");
+}

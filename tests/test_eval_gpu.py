@@ -96,3 +96,86 @@ def test_neighbour_table_threshold_path_is_exact():
         assert set(idx[r, :int(cnt[r])].tolist()) == set(torch.nonzero(m[r]).reshape(-1).tolist())
     idx2, cnt2 = _lib.select_above(s, torch.full((64,), -10.0, device="cuda"), 16)     # overflow: count reported, cap kept
     assert int(cnt2.min()) == 10_000
+
+
+@pytest.mark.parametrize("rows,n_seg,seg_cap,k", [(37, 1, 4096, 123), (64, 4, 512, 700), (5, 8, 64, 1), (9, 2, 100, 200)])
+def test_topk_rows_exact_with_ties_and_status(rows, n_seg, seg_cap, k):
+    """mke_topk_rows: the k largest of a segmented short list, ties at the k-th value broken by list order, output in
+    list order, k-th value reported; short / overflowed rows flagged."""
+    import torch
+    from multike_amd import _lib
+    g = torch.Generator(device="cuda"); g.manual_seed(rows * 7 + k)
+    vals = torch.randn(rows, n_seg, seg_cap, device="cuda", generator=g)
+    vals = torch.round(vals * 8) / 8                      # plenty of exact ties
+    idx = torch.randint(0, 1 << 30, (rows, n_seg, seg_cap), device="cuda", generator=g, dtype=torch.int32)
+    cnt = torch.randint(max(1, seg_cap // 2), seg_cap + 1, (rows, n_seg), device="cuda", generator=g, dtype=torch.int32)
+    cnt[0] = seg_cap
+    if rows > 3:
+        cnt[1, 0] = seg_cap + 5                           # overflow -> status 2
+        cnt[2] = 0                                        # nothing -> status 1
+    out, kth, status = _lib.topk_rows(vals, k, idx=idx, seg_count=cnt, want_kth=True)
+    st = status.cpu().numpy()
+    for r in range(rows):
+        c = cnt[r].cpu().numpy()
+        if (c > seg_cap).any():
+            assert st[r] == 2
+            continue
+        lst_v = np.concatenate([vals[r, s, :c[s]].cpu().numpy() for s in range(n_seg)])
+        lst_i = np.concatenate([idx[r, s, :c[s]].cpu().numpy() for s in range(n_seg)])
+        if len(lst_v) < k:
+            assert st[r] == 1
+            continue
+        assert st[r] == 0
+        kv = np.sort(lst_v)[::-1][k - 1]
+        assert float(kth[r]) == float(kv)
+        take = lst_v > kv
+        ties = np.nonzero(lst_v == kv)[0][:k - int(take.sum())]
+        take[ties] = True
+        assert np.array_equal(out[r].cpu().numpy(), lst_i[take])
+    # plain list (no idx, no counts): positions, and the threshold-only mode
+    v2 = torch.randn(11, 4096, device="cuda", generator=g)
+    out2, kth2, st2 = _lib.topk_rows(v2, 50, want_kth=True)
+    ref = torch.topk(v2, 50, dim=1)
+    assert int(st2.abs().sum()) == 0 and torch.equal(kth2, ref.values[:, -1])
+    assert torch.equal(out2.long().sort(dim=1).values, ref.indices.sort(dim=1).values)
+    _, kth3, _ = _lib.topk_rows(v2, 50, want_idx=False, want_kth=True)
+    assert torch.equal(kth3, kth2)
+
+
+@pytest.mark.parametrize("n,d,lo,hi,n_seg", [(5000, 75, 0, 5000, 4), (3333, 20, 1000, 1777, 1), (9000, 256, 128, 1000, 2),
+                                              (700, 100, 0, 700, 8)])
+def test_sim_select_candidates(n, d, lo, hi, n_seg):
+    """mke_sim_select: per row the columns with similarity above the row's threshold, per column segment, in column
+    order, with their similarities (f32 MFMA chain vs a float64 product: 1e-5 band around the threshold)."""
+    import torch
+    from multike_amd import _lib
+    g = torch.Generator(device="cuda"); g.manual_seed(n + d)
+    e = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    kpad = _lib.stride_for(d)
+    ep = torch.zeros(n, kpad, device="cuda")
+    ep[:, :d] = e
+    sim = (e[lo:hi].double() @ e.double().t())
+    tau = sim.float().quantile(0.97, dim=1).contiguous()
+    seg_cap = 512 // n_seg
+    cand, cnt = _lib.sim_select(ep, kpad, lo, hi, tau, n_seg, seg_cap)
+    cidx, csim = cand[..., 0].contiguous(), cand[..., 1].contiguous().view(torch.float32)
+    bn = 64 if kpad <= 208 else 32
+    tiles = (n + bn - 1) // bn
+    per = (tiles + n_seg - 1) // n_seg * bn
+    cidx, csim, cnt = cidx.cpu().numpy(), csim.cpu().numpy(), cnt.cpu().numpy()
+    sim_np, tau_np = sim.cpu().numpy(), tau.cpu().numpy().astype(np.float64)
+    for r in list(range(0, hi - lo, 37)) + [hi - lo - 1]:
+        for s in range(n_seg):
+            a, b = s * per, min(n, (s + 1) * per)
+            if a >= b:
+                assert cnt[r, s] == 0
+                continue
+            sure = np.nonzero(sim_np[r, a:b] > tau_np[r] + 1e-5)[0] + a
+            maybe = np.nonzero(sim_np[r, a:b] > tau_np[r] - 1e-5)[0] + a
+            c = int(cnt[r, s])
+            assert len(sure) <= c <= len(maybe)
+            got = cidx[r, s, :min(c, seg_cap)]
+            assert np.all(np.diff(got) > 0)                                   # column order, no duplicates
+            if c <= seg_cap:
+                assert set(sure.tolist()) <= set(got.tolist()) <= set(maybe.tolist())
+            np.testing.assert_allclose(csim[r, s, :len(got)], sim_np[r, got], rtol=0, atol=2e-6)
