@@ -586,14 +586,6 @@ int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad,
 int mke_align_rank(const float* emb1, int ld1, const float* emb2_t, int64_t ld2t, int kpad, int64_t n1, int64_t n2,
                    int32_t* rank, uint64_t* best, void* stream);
 
-/* Candidate selection for the truncated-sampling k-NN refresh (code/base/batch.py:119-150; the similarity block itself is a
- * plain library GEMM): for every row of sim [rows][ld], the column indices with sim > tau[row], compacted in arbitrary
- * order into out_idx[row][0 .. min(count, cap)); out_count[row] = number of hits (may exceed cap).  The caller picks tau
- * slightly below the k-th largest value (estimated from a column sample) and finishes with an exact top-k on the short
- * candidate list. */
-int mke_select_above(const float* sim, int64_t rows, int64_t cols, int64_t ld, const float* tau, int cap,
-                     int32_t* out_idx /* [rows][cap] */, int32_t* out_count /* [rows] */, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * (10) Small dense f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) with arbitrary operand strides:
  *        C[M][N] (=|+=) A[M][K] . B[K][N],  A(i,k) = A[i*a_row_stride + k*a_col_stride], likewise B.

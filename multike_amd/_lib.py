@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_select_above", "mke_sim_select", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
 )
 
 
@@ -335,18 +335,7 @@ def neg_sample_at(pos, pos_index, pos_kg, sides, neg_per_pos, max_try, seed, str
     _check(rc, "mke_neg_sample_at")
 
 
-def select_above(sim: torch.Tensor, tau: torch.Tensor, cap: int):
-    """mke_select_above -> (idx int32 [rows, cap] (first min(count, cap) entries valid), count int32 [rows])."""
-    rows, cols = sim.shape
-    if sim.stride(1) != 1:
-        raise MultiKEHipError("select_above: sim must be row-major")
-    idx = torch.empty(rows, cap, dtype=torch.int32, device=sim.device)
-    cnt = torch.empty(rows, dtype=torch.int32, device=sim.device)
-    rc = lib().mke_select_above(C.c_void_p(sim.data_ptr()), C.c_int64(rows), C.c_int64(cols), C.c_int64(sim.stride(0)),
-                                _dev(tau, torch.float32, "tau"), C.c_int(cap), _dev(idx, torch.int32, "idx"),
-                                _dev(cnt, torch.int32, "count"), _stream())
-    _check(rc, "mke_select_above")
-    return idx, cnt
+SIM_SELECT_KPADS = (16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 208, 256)   # instantiations of k_sim_select
 
 
 def sim_select(emb: torch.Tensor, kpad: int, row_lo: int, row_hi: int, tau: torch.Tensor, n_seg: int, seg_cap: int):

@@ -135,7 +135,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         valid[ids] = 1
         return table, valid
 
-    kpad = _lib.stride_for(d)
+    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
     ep = torch.zeros(n, kpad, dtype=torch.float32, device=device)
     ep[:, :d] = e
     ids32 = ids.to(torch.int32)

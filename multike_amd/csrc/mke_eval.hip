@@ -139,59 +139,3 @@ extern "C" int mke_align_rank(const float* emb1, int ld1, const float* emb2_t, i
 #undef EV_CASE
   return check_launch("k_align_rank");
 }
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Candidate selection of the truncated-sampling k-NN refresh (code/base/batch.py:143-150: argpartition of every row of
-// the similarity block for its k = 2 % largest entries).  A full-width top-k over 100K columns costs 3x the GEMM that
-// produced the block; instead the caller estimates a per-row threshold just below the k-th largest value from a column
-// sample, this kernel compacts the columns above it (about 1.4 k of them) and the exact top-k runs on that short list.
-// One block per row; ballot-compacted appends through one LDS counter.  count[row] may exceed cap (the caller then
-// falls back to the full-width path for that row) -- only the first cap hits are stored.
-// ---------------------------------------------------------------------------------------------------------------
-namespace mke {
-__global__ __launch_bounds__(MKE_BLOCK) void k_select_above(const float* __restrict__ sim, int64_t cols, int64_t ld,
-                                                            const float* __restrict__ tau, int cap, int32_t* __restrict__ out_idx,
-                                                            int32_t* __restrict__ out_count) {
-  __shared__ int s_n;
-  const int64_t row = blockIdx.x;
-  const float* __restrict__ r = sim + row * ld;
-  int32_t* __restrict__ o = out_idx + row * (int64_t)cap;
-  const float t = tau[row];
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  for (int64_t c0 = 0; c0 < cols; c0 += 2 * MKE_BLOCK) {   // block-uniform trip count; two independent loads per thread
-    const int64_t ca = c0 + threadIdx.x, cb = ca + MKE_BLOCK;
-    const float va = ca < cols ? r[ca] : t, vb = cb < cols ? r[cb] : t;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bool hit = (h ? vb : va) > t;
-      const uint64_t m = __ballot(hit);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (hit) {
-          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < cap) o[pos] = (int32_t)(h ? cb : ca);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) out_count[row] = s_n;
-}
-}  // namespace mke
-
-extern "C" int mke_select_above(const float* sim, int64_t rows, int64_t cols, int64_t ld, const float* tau, int cap,
-                                int32_t* out_idx, int32_t* out_count, void* stream) {
-  using namespace mke;
-  if (rows < 0 || cols < 0 || ld < cols || cap < 1) { set_error("mke_select_above: bad shape"); return MKE_E_SHAPE; }
-  if (rows == 0) return MKE_OK;
-  if (!sim || !tau || !out_idx || !out_count) { set_error("mke_select_above: NULL pointer"); return MKE_E_NULL; }
-  if (cols > 0x7FFFFFFFLL || rows > 0x7FFFFFFFLL) { set_error("mke_select_above: more than 2^31 rows / columns"); return MKE_E_RANGE; }
-  hipLaunchKernelGGL(k_select_above, dim3((unsigned)rows), dim3(MKE_BLOCK), 0, (hipStream_t)stream, sim, cols, ld, tau, cap, out_idx,
-                     out_count);
-  return check_launch("k_select_above");
-}

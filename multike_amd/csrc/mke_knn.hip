@@ -110,28 +110,35 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) % NBUF;
     if (t + 1 < t1) fetch(t + 1);  // in flight during the MFMAs below
+    f32x16 acc[KNN_BN / 32];
 #pragma unroll
     for (int cg = 0; cg < KNN_BN / 32; ++cg) {
-      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc[cg] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const float* bp = &Bs[buf][cg * 32 + l31][half * 8];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const float4 x = *reinterpret_cast<const float4*>(bp + s * 16);
         const float4 y = *reinterpret_cast<const float4*>(bp + s * 16 + 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 0], x.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 1], x.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 2], x.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 3], x.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 4], y.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 5], y.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 6], y.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 7], y.w, acc, 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 0], x.x, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 1], x.y, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 2], x.z, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 3], x.w, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 4], y.x, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 5], y.y, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 6], y.z, acc[cg], 0, 0, 0);
+        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 7], y.w, acc[cg], 0, 0, 0);
       }
+    }
+    // The next tile goes to LDS BEFORE the candidate stores are issued: loads and stores share one in-order counter
+    // (vmcnt), so waiting for the prefetched tile after the epilogue would also wait for every store's round trip.
+    if (NBUF == 2 && t + 1 < t1) stage((t + 1 - t0) % NBUF);
+#pragma unroll
+    for (int cg = 0; cg < KNN_BN / 32; ++cg) {
       const int col = t * KNN_BN + cg * 32 + l31;
       const bool col_ok = col < p.n_cols;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const bool hit = col_ok && acc[reg] > tauR[reg];
+        const bool hit = col_ok && acc[cg][reg] > tauR[reg];
         const uint64_t m = __ballot(hit);
         if (m == 0) continue;  // wave-uniform
         const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
@@ -139,14 +146,16 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
         if (hit && pos < p.seg_cap) {
           mke_candidate c;
           c.idx = col;
-          c.sim = acc[reg];
+          c.sim = acc[cg][reg];
           p.cand[base0 + ((reg & 3) + 8 * (reg >> 2)) * row_stride + pos] = c;
         }
         cnt[reg] += __popc(mh);
       }
     }
-    if (NBUF == 1) __syncthreads();  // every wave is done reading the only buffer
-    if (t + 1 < t1) stage((t + 1 - t0) % NBUF);
+    if (NBUF == 1) {
+      __syncthreads();  // every wave is done reading the only buffer
+      if (t + 1 < t1) stage(0);
+    }
     __syncthreads();
   }
   if (l31 == 0) {
