@@ -291,7 +291,9 @@ def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
     # hub rows sum hundreds of fp32 contributions (atomic order free): absolute tolerance ~1e-4 of a typical weight
     np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=3e-3, atol=1e-6)   # sum of g^2 on hub rows
+    # accumulator = sum of g^2 where a hub row's g is itself a cancelling sum of hundreds of fp32 terms in atomic order:
+    # single elements land a few 1e-3 off in about one run out of 25
+    np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=1e-2, atol=1e-6)
     assert int(E.refcount.abs().sum()) == 0 and float(E.grad.abs().max()) == 0.0
     # and the two paths agree with each other
     E2, R2 = make_tables(ent, rel)
