@@ -137,7 +137,7 @@ def test_topk_rows_exact_with_ties_and_status(rows, n_seg, seg_cap, k):
 
 
 @pytest.mark.parametrize("n,d,lo,hi,n_seg", [(5000, 75, 0, 5000, 4), (3333, 20, 1000, 1777, 1), (9000, 256, 128, 1000, 2),
-                                              (700, 100, 0, 700, 8)])
+                                              (700, 100, 0, 700, 8), (2500, 120, 300, 2500, 2), (1500, 200, 0, 1500, 1)])
 def test_sim_select_candidates(n, d, lo, hi, n_seg):
     """mke_sim_select: per row the columns with similarity above the row's threshold, per column segment, in column
     order, with their similarities (f32 MFMA chain vs a float64 product: 1e-5 band around the threshold)."""
@@ -145,7 +145,7 @@ def test_sim_select_candidates(n, d, lo, hi, n_seg):
     from multike_amd import _lib
     g = torch.Generator(device="cuda"); g.manual_seed(n + d)
     e = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
-    kpad = _lib.stride_for(d)
+    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
     ep = torch.zeros(n, kpad, device="cuda")
     ep[:, :d] = e
     sim = (e[lo:hi].double() @ e.double().t())
