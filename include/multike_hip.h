@@ -577,13 +577,13 @@ int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad,
  * replaces: code/base/similarity.py:30-34 (sim = E1 . E2^T) + code/base/alignment.py:141-163 calculate_rank
  *           (argsort / argpartition per row, gold located by position) as used by greedy_alignment (:8-79).
  *
- *   emb1   : [n1][ld1], columns [dim, kpad) zero.           emb2_t : [kpad][ld2t] = E2 TRANSPOSED, columns >= n2 zero,
- *   ld2t >= round_up(max(n1, n2), 32).  Gold column of row i is i (so n2 >= n1).
+ *   emb1 : [n1][ld1], emb2 : [n2][ld2], both row-major with columns [dim, kpad) zero, kpad a multiple of 16, ld1 and
+ *   ld2 multiples of 4 (16-byte rows).  Gold column of row i is i (so n2 >= n1).
  *   rank[i] += #{j < n2 : sim[i][j] > sim[i][i]}  (rank zeroed by the caller);
  *   best[i]  = max over j of (ordered(sim[i][j]) << 32 | 0xFFFFFFFF - j)  (best zeroed by the caller; arg-max column =
  *              0xFFFFFFFF - low word, lowest column on ties).
  * ------------------------------------------------------------------------------------------------ */
-int mke_align_rank(const float* emb1, int ld1, const float* emb2_t, int64_t ld2t, int kpad, int64_t n1, int64_t n2,
+int mke_align_rank(const float* emb1, int ld1, const float* emb2, int ld2, int kpad, int64_t n1, int64_t n2,
                    int32_t* rank, uint64_t* best, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -27,15 +27,14 @@ def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
     n2 = b.shape[0]
     if n2 < n1:
         raise _lib.MultiKEHipError("greedy_alignment: gold column = row index needs len(embed2) >= len(embed1)")
-    kpad = _lib.stride_for(d)
+    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
     ap = torch.zeros(n1, kpad, dtype=torch.float32, device=device)
     ap[:, :d] = a
-    n2p = (max(n1, n2) + 31) // 32 * 32
-    bt = torch.zeros(kpad, n2p, dtype=torch.float32, device=device)
-    bt[:d, :n2] = b.t()
+    bp = torch.zeros(n2, kpad, dtype=torch.float32, device=device)
+    bp[:, :d] = b
     rank = torch.zeros(n1, dtype=torch.int32, device=device)
     best = torch.zeros(n1, dtype=torch.int64, device=device)
-    _lib.align_rank(ap, bt, kpad, n1, n2, rank, best)
+    _lib.align_rank(ap, bp, kpad, n1, n2, rank, best)
     col = 0xFFFFFFFF - (best & 0xFFFFFFFF)
     return rank.long(), col
 

@@ -21,14 +21,10 @@
 // The threshold of a row is the m-th largest of its similarities to a fixed column sample (caller: a small library GEMM
 // + k_topk_rows), chosen so that ~1.4 k columns pass; a row whose estimate came out too tight (< k hits) or whose
 // segment overflowed is flagged and redone by the caller at full width.  The result is the exact top-k set.
-#include "mke_common.h"
+#include "mke_simtile.h"
 
 namespace mke {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define KNN_BM 128  // rows per block
-#define KNN_BN_FOR(KS) ((KS) <= 13 ? 64 : 32)  // columns per tile (LDS: BN x (kpad + 4) floats must stay under 64 KB)
 #define KNN_MAX_LIST 4096
 
 struct SimSelectParams {
@@ -44,30 +40,15 @@ struct SimSelectParams {
 
 template <int KS>  // kpad / 16
 __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams p) {
-  constexpr int KP = KS * 16;
-  constexpr int KNN_BN = KNN_BN_FOR(KS);
-  constexpr int NQ = KNN_BN * KP / (4 * MKE_BLOCK);  // float4 per thread per tile
-  static_assert(KNN_BN * KP % (4 * MKE_BLOCK) == 0, "tile must split evenly into float4 per thread");
-  constexpr int NBUF = 2 * KNN_BN * (KP + 4) * 4 <= 65536 ? 2 : 1;  // double-buffered tiles: one barrier per tile
-  __shared__ __attribute__((aligned(16))) float Bs[NBUF][KNN_BN][KP + 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int strip0 = p.row_lo + blockIdx.x * KNN_BM + wv * 32;
-  // A operands: MFMA j of slab s multiplies k = s*16 + half*8 + j (lanes 0-31 feed the even, 32-63 the odd k of a 32x32x2)
+  const int strip0 = p.row_lo + blockIdx.x * SIMT_BM + wv * 32;
   float a[KS * 8];
   {
     const int r = strip0 + l31;
     const bool ok = r < p.row_hi;
-    const float* ap = p.emb + (int64_t)(ok ? r : p.row_lo) * p.ld + half * 8;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 x = ok ? *reinterpret_cast<const float4*>(ap + s * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 y = ok ? *reinterpret_cast<const float4*>(ap + s * 16 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      a[s * 8 + 0] = x.x; a[s * 8 + 1] = x.y; a[s * 8 + 2] = x.z; a[s * 8 + 3] = x.w;
-      a[s * 8 + 4] = y.x; a[s * 8 + 5] = y.y; a[s * 8 + 6] = y.z; a[s * 8 + 7] = y.w;
-    }
+    simt_load_fragment<KS>(p.emb + (int64_t)(ok ? r : p.row_lo) * p.ld, ok, half, a);
   }
-  // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float tauR[16];
   int cnt[16];
 #pragma unroll
@@ -77,87 +58,30 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
     cnt[reg] = 0;
   }
   const int seg = blockIdx.y;
-  const int ntiles = (p.n_cols + KNN_BN - 1) / KNN_BN;
+  const int ntiles = (p.n_cols + SIMT_BN_FOR(KS) - 1) / SIMT_BN_FOR(KS);
   const int t0 = seg * p.tiles_per_seg;
   const int t1 = min(ntiles, t0 + p.tiles_per_seg);
   const unsigned lt = (1u << l31) - 1u;
-  // global -> registers -> LDS staging of a tile: 64 rows x KP floats, KS float4 per thread
-  float4 pre[NQ];
-  auto fetch = [&](int t) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int e = (tid + q * MKE_BLOCK) * 4;
-      const int c = e / KP, k = e % KP;
-      const int col = t * KNN_BN + c;
-      pre[q] = col < p.n_cols ? *reinterpret_cast<const float4*>(p.emb + (int64_t)col * p.ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int e = (tid + q * MKE_BLOCK) * 4;
-      *reinterpret_cast<float4*>(&Bs[buf][e / KP][e % KP]) = pre[q];
-    }
-  };
   // candidate slot of (row of accumulator register reg, position) as a 32-bit element offset
   const int row_stride = p.n_seg * p.seg_cap;
   const int base0 = ((strip0 - p.row_lo + 4 * half) * p.n_seg + seg) * p.seg_cap;
-  if (t0 < t1) {
-    fetch(t0);
-    stage(0);
-  }
-  __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) % NBUF;
-    if (t + 1 < t1) fetch(t + 1);  // in flight during the MFMAs below
-    f32x16 acc[KNN_BN / 32];
+  simt_sweep<KS>(a, p.emb, p.ld, p.n_cols, t0, t1, [&](const f32x16& acc, int col, bool col_ok) {
 #pragma unroll
-    for (int cg = 0; cg < KNN_BN / 32; ++cg) {
-      acc[cg] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      const float* bp = &Bs[buf][cg * 32 + l31][half * 8];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const float4 x = *reinterpret_cast<const float4*>(bp + s * 16);
-        const float4 y = *reinterpret_cast<const float4*>(bp + s * 16 + 4);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 0], x.x, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 1], x.y, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 2], x.z, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 3], x.w, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 4], y.x, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 5], y.y, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 6], y.z, acc[cg], 0, 0, 0);
-        acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 7], y.w, acc[cg], 0, 0, 0);
+    for (int reg = 0; reg < 16; ++reg) {
+      const bool hit = col_ok && acc[reg] > tauR[reg];
+      const uint64_t m = __ballot(hit);
+      if (m == 0) continue;  // wave-uniform
+      const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;  // the 32 lanes of a half hold 32 columns of ONE row
+      const int pos = cnt[reg] + __popc(mh & lt);
+      if (hit && pos < p.seg_cap) {
+        mke_candidate c;
+        c.idx = col;
+        c.sim = acc[reg];
+        p.cand[base0 + ((reg & 3) + 8 * (reg >> 2)) * row_stride + pos] = c;
       }
+      cnt[reg] += __popc(mh);
     }
-    // The next tile goes to LDS BEFORE the candidate stores are issued: loads and stores share one in-order counter
-    // (vmcnt), so waiting for the prefetched tile after the epilogue would also wait for every store's round trip.
-    if (NBUF == 2 && t + 1 < t1) stage((t + 1 - t0) % NBUF);
-#pragma unroll
-    for (int cg = 0; cg < KNN_BN / 32; ++cg) {
-      const int col = t * KNN_BN + cg * 32 + l31;
-      const bool col_ok = col < p.n_cols;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const bool hit = col_ok && acc[cg][reg] > tauR[reg];
-        const uint64_t m = __ballot(hit);
-        if (m == 0) continue;  // wave-uniform
-        const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
-        const int pos = cnt[reg] + __popc(mh & lt);
-        if (hit && pos < p.seg_cap) {
-          mke_candidate c;
-          c.idx = col;
-          c.sim = acc[cg][reg];
-          p.cand[base0 + ((reg & 3) + 8 * (reg >> 2)) * row_stride + pos] = c;
-        }
-        cnt[reg] += __popc(mh);
-      }
-    }
-    if (NBUF == 1) {
-      __syncthreads();  // every wave is done reading the only buffer
-      if (t + 1 < t1) stage(0);
-    }
-    __syncthreads();
-  }
+  });
   if (l31 == 0) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -346,15 +270,15 @@ extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols
   if (!emb || !tau || !cand || !seg_count) { set_error("mke_sim_select: NULL pointer"); return MKE_E_NULL; }
   if (kpad <= 0 || kpad % 16 != 0 || kpad > MKE_MAX_STRIDE || ld < kpad || ld % 4 != 0) { set_error("mke_sim_select: kpad must be a multiple of 16 <= %d and <= ld (ld a multiple of 4)", MKE_MAX_STRIDE); return MKE_E_SHAPE; }
   if (n_seg < 1 || n_seg > 16 || seg_cap < 1 || (int64_t)n_seg * seg_cap > KNN_MAX_LIST) { set_error("mke_sim_select: need 1 <= n_seg <= 16 and n_seg * seg_cap <= %d", KNN_MAX_LIST); return MKE_E_SHAPE; }
-  if ((row_hi - row_lo + KNN_BM) * (int64_t)n_seg * seg_cap > 0x7FFFFFFFLL) { set_error("mke_sim_select: more than 2^31 candidate slots in one launch (split the row range)"); return MKE_E_RANGE; }
+  if ((row_hi - row_lo + SIMT_BM) * (int64_t)n_seg * seg_cap > 0x7FFFFFFFLL) { set_error("mke_sim_select: more than 2^31 candidate slots in one launch (split the row range)"); return MKE_E_RANGE; }
   SimSelectParams p;
   p.emb = emb; p.ld = ld; p.n_cols = (int)n_cols; p.row_lo = (int)row_lo; p.row_hi = (int)row_hi; p.tau = tau;
   p.n_seg = n_seg; p.seg_cap = seg_cap;
-  const int bn = KNN_BN_FOR(kpad / 16);
+  const int bn = SIMT_BN_FOR(kpad / 16);
   const int ntiles = (int)((n_cols + bn - 1) / bn);
   p.tiles_per_seg = (ntiles + n_seg - 1) / n_seg;
   p.cand = cand; p.seg_count = seg_count;
-  dim3 grid((unsigned)((row_hi - row_lo + KNN_BM - 1) / KNN_BM), (unsigned)n_seg);
+  dim3 grid((unsigned)((row_hi - row_lo + SIMT_BM - 1) / SIMT_BM), (unsigned)n_seg);
   hipStream_t st = (hipStream_t)stream;
 #define KNN_CASE(K)                                                                 \
   case K:                                                                           \
