@@ -34,12 +34,14 @@ struct UpdateParams {
   int64_t capacity;
 };
 
-template <int FPL>
+// SHARD: the owner side of the sharded step (gradient gathered through slot_of); a compile-time switch so that the
+// single-GPU step does not carry its registers and branches
+template <int FPL, bool SHARD>
 __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t row, int j) {
   float* gp = p.grad + row * (int64_t)p.stride + j;
   float* wp = p.table + row * (int64_t)p.stride + j;
   float g[FPL], w[FPL], a[FPL];
-  if (p.slot_of) {  // rank-ordered sum of the rows sent back for this row (deterministic, no atomics)
+  if (SHARD && p.slot_of) {  // rank-ordered sum of the rows sent back for this row (deterministic, no atomics)
     int32_t* so = p.slot_of + row * (int64_t)p.n_ranks;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) g[k] = 0.f;
@@ -72,7 +74,7 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 #pragma unroll
     for (int k = 0; k < FPL; ++k) a[k] = ap[k * 16];
   }
-  if (!p.slot_of) {
+  if (!(SHARD && p.slot_of)) {
 #pragma unroll
     for (int k = 0; k < FPL; ++k) gp[k * 16] = 0.f;  // consume: restore the all-zero invariant
   }
@@ -112,13 +114,13 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 // One wavefront, one 16-row chunk: ballot the flags, deal the set bits round-robin to the four quarter-waves.  Every
 // quarter looks up ITS row of the round (the (4*round + q)-th set bit) so that the four row visits of a round execute
 // together in one instruction stream — a branch per set bit would serialise them.
-template <int FPL>
+template <int FPL, bool SHARD>
 __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, int j, int q) {
   const int64_t base = wave * p.chunk;
   if (base >= p.n_rows) return;  // wave-uniform
   const int64_t r = base + (j & (p.chunk - 1));
   bool mine = r < p.n_rows;
-  if (mine && p.slot_of) {
+  if (SHARD && mine && p.slot_of) {
     const int32_t* so = p.slot_of + r * (int64_t)p.n_ranks;
     int any = -1;
     for (int g = 0; g < p.n_ranks; ++g) any = max(any, so[g]);
@@ -132,7 +134,7 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
     const int target = round * 4 + q;
     uint32_t t = m;
     for (int k = 0; k < target; ++k) t &= t - 1;  // drop the `target` lowest set bits (<= 15 iterations)
-    if (target < total) update_one_row<FPL>(p, base + __builtin_ctz(t), j);
+    if (target < total) update_one_row<FPL, SHARD>(p, base + __builtin_ctz(t), j);
   }
 }
 
@@ -140,7 +142,7 @@ template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update(const UpdateParams p) {
   const int j = threadIdx.x & 15;
   const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
-  walk_chunk<FPL>(p, wave, j, (threadIdx.x & 63) >> 4);
+  walk_chunk<FPL, false>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
 struct MultiUpdateParams {
@@ -155,7 +157,7 @@ struct MultiUpdateParams {
   int dense_blocks;
 };
 
-template <int FPL>
+template <int FPL, bool SHARD>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
   const int64_t upd_blocks = mp.n_tables > 0 ? mp.block_end[mp.n_tables - 1] : 0;
   if ((int64_t)blockIdx.x >= upd_blocks + mp.count_blocks) {  // rider blocks: dense parameter update
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   const UpdateParams& p = mp.t[ti];
   const int j = threadIdx.x & 15;
   const int64_t wave = (((int64_t)blockIdx.x - first) * MKE_BLOCK + threadIdx.x) >> 6;
-  walk_chunk<FPL>(p, wave, j, (threadIdx.x & 63) >> 4);
+  walk_chunk<FPL, SHARD>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
 static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : 16; }
@@ -232,9 +234,13 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
   }
   if (blocks == 0) return MKE_OK;
   const int fpl = stride / 16;
-  MKE_DISPATCH_FPL(fpl, {
-    hipLaunchKernelGGL((k_rows_update_multi<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp);
-  });
+  bool shard = false;
+  for (int k = 0; k < n_tables; ++k) shard = shard || tables[k].slot_of != nullptr;
+  if (shard) {
+    MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_rows_update_multi<FPL, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp); });
+  } else {
+    MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_rows_update_multi<FPL, false>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp); });
+  }
   return check_launch("k_rows_update_multi");
 }
 
