@@ -393,6 +393,8 @@ int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_e
  *     range s of row i owns cand[i - row_lo][s][0 .. seg_cap) and seg_count[i - row_lo][s] (the number
  *     of hits, which may exceed seg_cap: only the first seg_cap are stored).  Inside a segment the candidates are in
  *     column order.  n_seg <= 16, n_seg * seg_cap <= 4096.  The similarity is an f32 MFMA fma chain over k.
+ *   mke_sim_sample: out[i - row_lo][c] = emb[i] . samp[c] for rows [row_lo, row_hi) and the n_samp rows of samp (same padding
+ *     as emb): the similarities the thresholds are estimated from, made of the same fma chains as mke_sim_select's.
  *   mke_topk_rows: per row of a short list (n_seg segments of seg_cap slots, seg_count valid entries each; NULL
  *     seg_count = all slots valid): the exact k largest values.  out_idx[row][0..k) = their idx entries (NULL idx = the
  *     slot number), mapped through id_map when given, in list order; ties at the k-th value are broken by list order.
@@ -406,6 +408,8 @@ typedef struct mke_candidate {
 } mke_candidate;
 int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols, int64_t row_lo, int64_t row_hi, const float* tau,
                    int n_seg, int seg_cap, mke_candidate* cand, int32_t* seg_count, void* stream);
+int mke_sim_sample(const float* emb, int ld, int kpad, int64_t n_rows, int64_t row_lo, int64_t row_hi, const float* samp,
+                   int ld_samp, int n_samp, float* out /* [row_hi - row_lo][n_samp] */, void* stream);
 int mke_topk_candidates(const mke_candidate* cand, const int32_t* seg_count, int64_t rows, int n_seg, int seg_cap, int k,
                         const int32_t* id_map /*nullable*/, int32_t* out_idx /*nullable*/, float* out_kth /*nullable*/,
                         int32_t* status /*nullable*/, void* stream);

@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
 )
 
 
@@ -352,6 +352,16 @@ def sim_select(emb: torch.Tensor, kpad: int, row_lo: int, row_hi: int, tau: torc
                               C.c_int(seg_cap), _dev(cand, torch.int32, "cand"), _dev(cnt, torch.int32, "seg_count"), _stream())
     _check(rc, "mke_sim_select")
     return cand, cnt
+
+
+def sim_sample(emb: torch.Tensor, kpad: int, row_lo: int, row_hi: int, samp: torch.Tensor):
+    """mke_sim_sample -> float32 [row_hi - row_lo, n_samp] similarities of the rows to the sample rows."""
+    out = torch.empty(row_hi - row_lo, samp.shape[0], dtype=torch.float32, device=emb.device)
+    rc = lib().mke_sim_sample(_dev(emb, torch.float32, "emb"), C.c_int(emb.stride(0)), C.c_int(kpad), C.c_int64(emb.shape[0]),
+                              C.c_int64(row_lo), C.c_int64(row_hi), _dev(samp, torch.float32, "samp"), C.c_int(samp.stride(0)),
+                              C.c_int(samp.shape[0]), _dev(out, torch.float32, "out"), _stream())
+    _check(rc, "mke_sim_sample")
+    return out
 
 
 def topk_candidates(cand: torch.Tensor, seg_count: torch.Tensor, k: int, id_map=None):

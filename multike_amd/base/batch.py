@@ -110,7 +110,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     `KGSide.set_neighbours`.
 
     When k is a small share of a long row the n x n similarity matrix is never built: a per-row threshold a bit below
-    the k-th largest value is estimated from a fixed column sample (small library GEMM + `mke_topk_rows`),
+    the k-th largest value is estimated from a fixed column sample (`mke_sim_sample` + `mke_topk_rows`),
     `mke_sim_select` computes the similarities tile by tile on the matrix cores and keeps only the ~1.4 k columns above
     the threshold, `mke_topk_rows` takes the exact top k of that short list.  The few rows whose estimate came out too
     tight (fewer than k hits) or too loose (a segment overflowed) are redone at full width (library GEMM + torch.topk,
@@ -147,7 +147,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     ep[:, :d] = e
     ids32 = ids.to(torch.int32)
     samp = torch.randperm(n, generator=g)[:n_samp].to(device)
-    es_t = e[samp].t().contiguous()
+    es = ep[samp].contiguous()
     m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
     chunk = 131072                                        # rows per launch: bounds the candidate buffers (8 * cap bytes per row)
     for lo in range(0, n, chunk):
@@ -157,9 +157,9 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         while n_seg < 8 and ((hi - lo + 127) // 128) * n_seg < 6144 and n // (2 * n_seg) >= 4096:
             n_seg *= 2
         tau = torch.empty(hi - lo, dtype=torch.float32, device=device)
-        for a in range(lo, hi, 16384):                    # sample similarities: [rows, 4096] library GEMM blocks
+        for a in range(lo, hi, 16384):                    # sample similarities, [16384, 4096] at a time
             b = min(hi, a + 16384)
-            _, kth, _ = _lib.topk_rows(e[a:b] @ es_t, m, want_idx=False, want_kth=True)
+            _, kth, _ = _lib.topk_rows(_lib.sim_sample(ep, kpad, a, b, es), m, want_idx=False, want_kth=True)
             tau[a - lo:b - lo] = kth
         cand, cnt = _lib.sim_select(ep, kpad, lo, hi, tau, n_seg, cap // n_seg)
         out, status = _lib.topk_candidates(cand, cnt, k, id_map=ids32)

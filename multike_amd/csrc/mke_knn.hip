@@ -91,6 +91,43 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
   }
 }
 
+// Similarities of rows [row_lo, row_hi) to a short list of sample rows, written out ([rows][n_samp]): the input of the
+// threshold estimate.  Same sweep, same fma chains as k_sim_select, so the thresholds are taken from numbers the main
+// pass would reproduce bit for bit — and the refresh does not depend on a library GEMM's choice of algorithm.
+struct SimSampleParams {
+  const float* __restrict__ emb;   // [n][ld]
+  int ld;
+  int row_lo, row_hi;
+  const float* __restrict__ samp;  // [n_samp][ld_s] sample rows (same padding as emb)
+  int ld_s, n_samp;
+  int tiles_per_chunk;
+  float* __restrict__ out;  // [row_hi - row_lo][n_samp]
+};
+
+template <int KS>
+__global__ __launch_bounds__(MKE_BLOCK) void k_sim_sample(const SimSampleParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int strip0 = p.row_lo + blockIdx.x * SIMT_BM + wv * 32;
+  float a[KS * 8];
+  {
+    const int r = strip0 + l31;
+    const bool ok = r < p.row_hi;
+    simt_load_fragment<KS>(p.emb + (int64_t)(ok ? r : p.row_lo) * p.ld, ok, half, a);
+  }
+  const int ntiles = (p.n_samp + SIMT_BN_FOR(KS) - 1) / SIMT_BN_FOR(KS);
+  const int t0 = blockIdx.y * p.tiles_per_chunk;
+  const int t1 = min(ntiles, t0 + p.tiles_per_chunk);
+  float* o = p.out + (int64_t)(strip0 - p.row_lo + 4 * half) * p.n_samp;
+  simt_sweep<KS>(a, p.samp, p.ld_s, p.n_samp, t0, t1, [&](const f32x16& acc, int col, bool col_ok) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int dr = (reg & 3) + 8 * (reg >> 2);
+      if (col_ok && strip0 + 4 * half + dr < p.row_hi) o[(int64_t)dr * p.n_samp + col] = acc[reg];
+    }
+  });
+}
+
 // order-preserving integer image of a float: larger float <=> larger unsigned
 __device__ __forceinline__ unsigned float_key(float v) {
   unsigned u = __float_as_uint(v);
@@ -293,6 +330,39 @@ extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols
   }
 #undef KNN_CASE
   return check_launch("k_sim_select");
+}
+
+extern "C" int mke_sim_sample(const float* emb, int ld, int kpad, int64_t n_rows, int64_t row_lo, int64_t row_hi, const float* samp,
+                              int ld_samp, int n_samp, float* out, void* stream) {
+  using namespace mke;
+  if (n_rows < 0 || row_lo < 0 || row_hi < row_lo || row_hi > n_rows || n_rows > 0x7FFFFF00LL || n_samp < 1) { set_error("mke_sim_sample: bad row range / sample size"); return MKE_E_SHAPE; }
+  if (row_hi == row_lo) return MKE_OK;
+  if (!emb || !samp || !out) { set_error("mke_sim_sample: NULL pointer"); return MKE_E_NULL; }
+  if (kpad <= 0 || kpad % 16 != 0 || kpad > MKE_MAX_STRIDE || ld < kpad || ld_samp < kpad || ld % 4 != 0 || ld_samp % 4 != 0) { set_error("mke_sim_sample: kpad must be a multiple of 16 <= %d and <= ld, ld_samp (multiples of 4)", MKE_MAX_STRIDE); return MKE_E_SHAPE; }
+  SimSampleParams p;
+  p.emb = emb; p.ld = ld; p.row_lo = (int)row_lo; p.row_hi = (int)row_hi; p.samp = samp; p.ld_s = ld_samp; p.n_samp = n_samp; p.out = out;
+  const int bn = SIMT_BN_FOR(kpad / 16);
+  const int ntiles = (n_samp + bn - 1) / bn;
+  const int row_blocks = (int)((row_hi - row_lo + SIMT_BM - 1) / SIMT_BM);
+  int chunks = (4096 + row_blocks - 1) / row_blocks;
+  if (chunks > (ntiles + 7) / 8) chunks = (ntiles + 7) / 8;
+  if (chunks < 1) chunks = 1;
+  p.tiles_per_chunk = (ntiles + chunks - 1) / chunks;
+  dim3 grid((unsigned)row_blocks, (unsigned)((ntiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk));
+  hipStream_t st = (hipStream_t)stream;
+#define KNN_CASE(K)                                                                 \
+  case K:                                                                           \
+    hipLaunchKernelGGL((k_sim_sample<K / 16>), grid, dim3(MKE_BLOCK), 0, st, p);     \
+    break;
+  switch (kpad) {
+    KNN_CASE(16) KNN_CASE(32) KNN_CASE(48) KNN_CASE(64) KNN_CASE(80) KNN_CASE(96) KNN_CASE(112) KNN_CASE(128) KNN_CASE(160)
+    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256)
+    default:
+      set_error("mke_sim_sample: unsupported kpad %d", kpad);
+      return MKE_E_UNSUPPORTED;
+  }
+#undef KNN_CASE
+  return check_launch("k_sim_sample");
 }
 
 static int topk_launch(const mke_candidate* cand, const float* vals, const int32_t* idx, const int32_t* seg_count, int64_t rows,

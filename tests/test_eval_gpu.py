@@ -173,3 +173,27 @@ def test_sim_select_candidates(n, d, lo, hi, n_seg):
             if c <= seg_cap:
                 assert set(sure.tolist()) <= set(got.tolist()) <= set(maybe.tolist())
             np.testing.assert_allclose(csim[r, s, :len(got)], sim_np[r, got], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("n,d,lo,hi,ns", [(3000, 75, 0, 3000, 4096), (1000, 20, 100, 777, 100), (900, 256, 0, 900, 65), (500, 120, 0, 500, 64)])
+def test_sim_sample_matches_product_and_select(n, d, lo, hi, ns):
+    """mke_sim_sample = rows x sample-rows similarities (float64 product within 2e-6), and bit-identical to what
+    mke_sim_select computes for the same (row, column) pairs (same fma chains)."""
+    import torch
+    from multike_amd import _lib
+    g = torch.Generator(device="cuda"); g.manual_seed(n + ns)
+    e = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
+    ep = torch.zeros(n, kpad, device="cuda")
+    ep[:, :d] = e
+    cols = torch.randint(0, n, (ns,), device="cuda", generator=g)
+    out = _lib.sim_sample(ep, kpad, lo, hi, ep[cols].contiguous())
+    ref = e[lo:hi].double() @ e[cols].double().t()
+    assert out.shape == (hi - lo, ns)
+    assert float((out.double() - ref).abs().max()) < 2e-6
+    # the main pass reproduces these numbers exactly: select everything (tau = -2) in one segment, compare by column
+    if n <= 1000:
+        cand, cnt = _lib.sim_select(ep, kpad, lo, hi, torch.full((hi - lo,), -2.0, device="cuda"), 1, 1024)
+        assert int(cnt.min()) == n and int(cnt.max()) == n
+        sims = cand[:, 0, :n, 1].contiguous().view(torch.float32)           # column order = column index
+        assert torch.equal(sims[:, cols], out)
