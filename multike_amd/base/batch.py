@@ -149,7 +149,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     samp = torch.randperm(n, generator=g)[:n_samp].to(device)
     es = ep[samp].contiguous()
     m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
-    chunk = 131072                                        # rows per launch: bounds the candidate buffers (8 * cap bytes per row)
+    chunk = (1 << 29) // cap - 128                        # rows per launch: 2^29 candidate slots (8 bytes each) at most
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
         # enough (row block, column segment) work items to fill the chip several times over, segments of >= 4096 columns

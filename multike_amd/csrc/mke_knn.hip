@@ -62,14 +62,17 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
   const int t0 = seg * p.tiles_per_seg;
   const int t1 = min(ntiles, t0 + p.tiles_per_seg);
   const unsigned lt = (1u << l31) - 1u;
-  // candidate slot of (row of accumulator register reg, position) as a 32-bit element offset
-  const int row_stride = p.n_seg * p.seg_cap;
-  const int base0 = ((strip0 - p.row_lo + 4 * half) * p.n_seg + seg) * p.seg_cap;
+  // candidate slot of (row of accumulator register reg, position) as a 32-bit BYTE offset from p.cand (the launcher
+  // bounds the slot count of a launch to 2^29): the store then takes the scalar base + a 32-bit vector offset
+  const unsigned row_stride_b = (unsigned)(p.n_seg * p.seg_cap) * 8u;
+  const unsigned base0_b = (unsigned)(((strip0 - p.row_lo + 4 * half) * p.n_seg + seg) * p.seg_cap) * 8u;
+  char* const cand_b = reinterpret_cast<char*>(p.cand);
   simt_sweep<KS>(a, p.emb, p.ld, p.n_cols, t0, t1, [&](const f32x16& acc, int col, bool col_ok) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const bool hit = col_ok && acc[reg] > tauR[reg];
-      const uint64_t m = __ballot(hit);
+      const float v = col_ok ? acc[reg] : -3.0e38f;  // one select, so that the compare's mask IS the ballot
+      const bool hit = v > tauR[reg];
+      const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
       if (m == 0) continue;  // wave-uniform
       const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;  // the 32 lanes of a half hold 32 columns of ONE row
       const int pos = cnt[reg] + __popc(mh & lt);
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_sim_select(const SimSelectParams 
         mke_candidate c;
         c.idx = col;
         c.sim = acc[reg];
-        p.cand[base0 + ((reg & 3) + 8 * (reg >> 2)) * row_stride + pos] = c;
+        *reinterpret_cast<mke_candidate*>(cand_b + (base0_b + (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride_b + (unsigned)pos * 8u)) = c;
       }
       cnt[reg] += __popc(mh);
     }
@@ -307,7 +310,7 @@ extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols
   if (!emb || !tau || !cand || !seg_count) { set_error("mke_sim_select: NULL pointer"); return MKE_E_NULL; }
   if (kpad <= 0 || kpad % 16 != 0 || kpad > MKE_MAX_STRIDE || ld < kpad || ld % 4 != 0) { set_error("mke_sim_select: kpad must be a multiple of 16 <= %d and <= ld (ld a multiple of 4)", MKE_MAX_STRIDE); return MKE_E_SHAPE; }
   if (n_seg < 1 || n_seg > 16 || seg_cap < 1 || (int64_t)n_seg * seg_cap > KNN_MAX_LIST) { set_error("mke_sim_select: need 1 <= n_seg <= 16 and n_seg * seg_cap <= %d", KNN_MAX_LIST); return MKE_E_SHAPE; }
-  if ((row_hi - row_lo + SIMT_BM) * (int64_t)n_seg * seg_cap > 0x7FFFFFFFLL) { set_error("mke_sim_select: more than 2^31 candidate slots in one launch (split the row range)"); return MKE_E_RANGE; }
+  if ((row_hi - row_lo + SIMT_BM) * (int64_t)n_seg * seg_cap > 0x1FFFFFFFLL) { set_error("mke_sim_select: more than 2^29 candidate slots in one launch (split the row range)"); return MKE_E_RANGE; }
   SimSelectParams p;
   p.emb = emb; p.ld = ld; p.n_cols = (int)n_cols; p.row_lo = (int)row_lo; p.row_hi = (int)row_hi; p.tau = tau;
   p.n_seg = n_seg; p.seg_cap = seg_cap;
