@@ -116,23 +116,36 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_remap(const RemapParams p)
   }
 }
 
-// pure row copy: 16 bytes per lane (a quarter-wave moves 256 contiguous bytes per instruction)
+// pure row copy, one float4 per lane: a block pass covers 256 / (stride / 4) whole rows (12 rows of 320 bytes: 240 of the
+// 256 lanes busy; a lane-per-row-quarter mapping leaves 44 of 64 lanes idle on its second pass), four independent
+// rows in flight per thread
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_gather_padded(const float* __restrict__ table, int stride,
                                                                   const int32_t* __restrict__ idx, int64_t n,
                                                                   float* __restrict__ out, float* __restrict__ zero_rows) {
-  const int j = threadIdx.x & 15;
-  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
-  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  const int q = stride >> 2;        // float4 per row (<= 256 / 4)
+  const int rpb = MKE_BLOCK / q;    // rows per block pass
+  const int r = threadIdx.x / q, c = threadIdx.x - r * q;
+  if (r >= rpb) return;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t i = sub0; i < n; i += nsub) {
-    const int row = idx[i];
-    const float* src = table + (int64_t)(row >= 0 ? row : 0) * stride;
-    float* o = out + i * (int64_t)stride;
-    float* zr = zero_rows ? zero_rows + i * (int64_t)stride : nullptr;
-    for (int c = 4 * j; c < stride; c += 64) {
-      const float4 v = row >= 0 ? *reinterpret_cast<const float4*>(src + c) : z;
-      *reinterpret_cast<float4*>(o + c) = v;
-      if (zr) *reinterpret_cast<float4*>(zr + c) = z;
+  const int64_t step = (int64_t)gridDim.x * rpb;
+  for (int64_t i0 = (int64_t)blockIdx.x * rpb + r; i0 < n; i0 += 4 * step) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * step;
+      v[u] = z;
+      if (i < n) {
+        const int row = idx[i];
+        if (row >= 0) v[u] = *reinterpret_cast<const float4*>(table + (int64_t)row * stride + 4 * c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * step;
+      if (i < n) {
+        *reinterpret_cast<float4*>(out + i * stride + 4 * c) = v[u];
+        if (zero_rows) *reinterpret_cast<float4*>(zero_rows + i * stride + 4 * c) = z;
+      }
     }
   }
 }
@@ -226,7 +239,7 @@ extern "C" int mke_rows_gather_padded(const float* table, int stride, const int3
   if (n == 0) return MKE_OK;
   if (!table || !idx || !out) { set_error("mke_rows_gather_padded: NULL pointer"); return MKE_E_NULL; }
   if (stride <= 0 || stride % 16 != 0 || stride > MKE_MAX_STRIDE) { set_error("bad stride %d", stride); return MKE_E_SHAPE; }
-  hipLaunchKernelGGL(k_rows_gather_padded, dim3(blocks_for(n, MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_rows_gather_padded, dim3(blocks_for(n, (MKE_BLOCK / (stride / 4)) * 4)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
                      table, stride, idx, n, out, zero_rows);
   return check_launch("k_rows_gather_padded");
 }
