@@ -111,7 +111,7 @@ struct AlignParams {
 };
 
 template <int FPL>
-__global__ __launch_bounds__(MKE_BLOCK) void k_align(const AlignParams p) {
+__device__ __forceinline__ void align_block(const AlignParams& p) {
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
@@ -145,6 +145,16 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align(const AlignParams p) {
   const double tot = block_sum_double(j == 0 ? loss : 0.f);
   if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)p.weight;
 }
+
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_align(const AlignParams p) { align_block<FPL>(p); }
+
+// all terms of one common-space step in one launch (blockIdx.y = term): one kernel floor instead of one per term
+struct AlignBatch {
+  AlignParams t[MKE_ALIGN_MAX_TERMS];
+};
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_align_batch(const AlignBatch b) { align_block<FPL>(b.t[blockIdx.y]); }
 
 // ---- normalised gather into a dense matrix -------------------------------------------------------
 template <int FPL>
@@ -241,6 +251,7 @@ extern "C" int mke_align_steps(const mke_align_plan* pl, void* stream) {
   if (pl->n_tables < 1 || pl->n_tables > MKE_ALIGN_MAX_TABLES || pl->n_terms < 1 || pl->n_terms > MKE_ALIGN_MAX_TERMS) { set_error("mke_align_steps: bad table / term count"); return MKE_E_SHAPE; }
   if (pl->n_steps < 0 || !pl->step_off || !pl->loss_partials) { set_error("mke_align_steps: NULL pointer or negative n_steps"); return MKE_E_NULL; }
   if ((int64_t)pl->tag_base + pl->n_steps >= 0x7FFFFFFFLL) { set_error("tag overflow"); return MKE_E_RANGE; }
+  if (pl->stride <= 0 || pl->stride % 16 != 0 || pl->dim <= 0 || pl->dim > pl->stride || pl->stride > MKE_MAX_STRIDE) { set_error("mke_align_steps: bad stride/dim"); return MKE_E_SHAPE; }
   mke_update_table ut[MKE_ALIGN_MAX_TABLES];
   int nu = 0;
   for (int k = 0; k < pl->n_tables; ++k) {
@@ -257,12 +268,23 @@ extern "C" int mke_align_steps(const mke_align_plan* pl, void* stream) {
     const int64_t lo = pl->step_off[s], hi = pl->step_off[s + 1];
     if (lo < 0 || hi < lo) { set_error("mke_align_steps: step_off must be non-decreasing"); return MKE_E_SHAPE; }
     const int32_t tag = pl->tag_base + s;
+    if (hi > lo && (!pl->ia || !pl->ib)) { set_error("mke_align_steps: NULL index stream"); return MKE_E_NULL; }
+    AlignBatch ab;
     for (int k = 0; k < pl->n_terms; ++k) {
       const mke_align_table& a = pl->tables[pl->terms[k].a];
       const mke_align_table& b = pl->tables[pl->terms[k].b];
-      const int rc = mke_align_fwd_bwd(a.table, a.normalize, b.table, b.normalize, pl->stride, pl->dim, pl->ia ? pl->ia + lo : nullptr,
-                                       pl->ib ? pl->ib + lo : nullptr, hi - lo, pl->terms[k].weight, a.grad, a.touched, b.grad, b.touched,
-                                       tag, pl->loss_partials + ((int64_t)s * pl->n_terms + k) * MKE_LOSS_PARTIALS, stream);
+      AlignParams& q = ab.t[k];
+      q.ta = a.table; q.tb = b.table; q.a_norm = a.normalize; q.b_norm = b.normalize; q.stride = pl->stride; q.dim = pl->dim;
+      q.ia = pl->ia ? pl->ia + lo : nullptr; q.ib = pl->ib ? pl->ib + lo : nullptr; q.n = hi - lo; q.weight = pl->terms[k].weight;
+      q.ga = a.grad; q.toa = a.touched; q.gb = b.grad; q.tob = b.touched; q.tag = tag;
+      q.lossp = pl->loss_partials + ((int64_t)s * pl->n_terms + k) * MKE_LOSS_PARTIALS;
+    }
+    {
+      const int fpl = pl->stride / 16;
+      MKE_DISPATCH_FPL(fpl, {
+        hipLaunchKernelGGL((k_align_batch<FPL>), dim3(MKE_LOSS_PARTIALS, pl->n_terms), dim3(MKE_BLOCK), 0, (hipStream_t)stream, ab);
+      });
+      const int rc = check_launch("k_align_batch");
       if (rc) return rc;
     }
     if (nu) {
