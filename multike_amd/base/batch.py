@@ -103,7 +103,8 @@ def generate_relation_triple_batch_queue(triple_list1, triple_list2, triple_set1
                                                      neg_triples_num))
 
 
-def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, device="cuda", block_rows=4096):
+def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, device="cuda", block_rows=4096,
+                    rows_per_launch=None):
     """Truncated-sampling k-NN refresh on the device (code/base/batch.py:119-150): inner product of the (already
     row-normalised) relation-view rows of one KG's useful entities, top `neighbors_num` per row INCLUDING the entity
     itself, unordered.  Returns (cand_table [n_ent_total, k] int32, cand_valid [n_ent_total] uint8) for
@@ -150,6 +151,8 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     es = ep[samp].contiguous()
     m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
     chunk = (1 << 29) // cap - 128                        # rows per launch: 2^29 candidate slots (8 bytes each) at most
+    if rows_per_launch:
+        chunk = min(chunk, int(rows_per_launch))
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
         # enough (row block, column segment) work items to fill the chip several times over, segments of >= 4096 columns

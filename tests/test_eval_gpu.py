@@ -79,6 +79,8 @@ def test_neighbour_table_threshold_path_is_exact():
     assert int(valid.sum()) == n
     table2, _ = neighbour_table(e, ids, k, n)
     assert torch.equal(table, table2)                      # same input, same table (order included)
+    table3, _ = neighbour_table(e, ids, k, n, rows_per_launch=16_384)
+    assert torch.equal(table, table3)                      # several row ranges per refresh (KGs beyond 2^29 / cap rows)
     tol = 3e-6                                             # the kernel's f32 fma chain vs the float64 reference
     for lo in range(0, n, 10_000):                         # EVERY row
         sim = e[lo:lo + 10_000].double() @ e.double().t()
