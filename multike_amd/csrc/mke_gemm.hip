@@ -130,6 +130,78 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, 
   }
 }
 
+// Tall-and-skinny products with the fused epilogue (the attribute step's [5000 x 301] x [301 x 75] and the mapping step's
+// [5000 x 75] x [75 x 75]): 64 x 64 tiles give 158 blocks of one wave per SIMD, each walking the whole K through LDS with a
+// barrier pair per slab — 17 us for 0.23 GFLOP.  Here a block owns 16 rows x all N (<= 96) columns and its four wavefronts
+// split K: every operand a wave needs (<= 20 k-steps of 4: one A scalar and up to six B scalars each) is requested up
+// front, straight from global memory (B is L2-resident), multiplied with v_mfma_f32_16x16x4_f32, and the four partial
+// products meet once in LDS.  313 blocks for M = 5000, no barrier inside the K loop: 10.5 us for the attribute step's
+// product (forcing all 120 loads of a wave ahead of its first MFMA with a scheduling barrier: 12.8 us; guarded instead of
+// clamped loads or run-time tile counts: 44-61 us of register shuffling).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// NCT = column tiles of 16 (N <= 16 NCT), KS = k-steps of 4 per wavefront (K <= 16 KS): compile-time, so that the operand
+// arrays stay in registers and the MFMA sequence is straight-line code.  Loads are unconditional from clamped addresses
+// (a guarded load makes the compiler wait for each one before its select): a k-step past K gets a = 0, so whatever b
+// holds there multiplies to nothing; columns past N and rows past M are computed from valid memory and never stored.
+template <int NCT, int KS>
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
+  __shared__ float s_part[MKE_BLOCK / 64][NCT][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int k0 = 4 * KS * wv + kq;  // this lane's first k
+  const int row = min(m0 + r16, p.M - 1);
+  const float* ap = p.A + (int64_t)row * p.a_rs;
+  int bcol[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) bcol[c] = min(16 * c + r16, p.N - 1);
+  float a[KS], b[KS][NCT];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int kc = min(k0 + 4 * i, p.K - 1);
+    a[i] = ap[kc];
+    const float* bp = p.B + (int64_t)kc * p.b_rs;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) b[i][c] = bp[bcol[c]];
+  }
+  f32x4 acc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const float ai = (k0 + 4 * i < p.K) ? a[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b[i][c], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_part[wv][c][r][lane] = acc[c][r];
+  __syncthreads();
+  // wave w finishes column tiles w, w + 4: C/D map of the 16x16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
+  float ssq = 0.f;
+  for (int c = wv; c < NCT; c += MKE_BLOCK / 64) {
+    const int col = 16 * c + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s_part[0][c][r][lane] + s_part[1][c][r][lane] + s_part[2][c][r][lane] + s_part[3][c][r][lane];
+      const int orow = m0 + 4 * kq + r;
+      if (col < p.N && orow < p.M) {
+        if (!p.epi_plain) v = tanhf(v);
+        p.C[(int64_t)orow * p.ldc + col] = v;
+        ssq = fmaf(v, v, ssq);
+      }
+    }
+  }
+  const double tot = block_sum_double(ssq);
+  if (tid == 0) {
+    const int nb = gridDim.x, bi = blockIdx.x;
+    p.partials[bi] = tot;
+    for (int k = bi + nb; k < MKE_LOSS_PARTIALS; k += nb) p.partials[k] = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32(const GemmParams p) { gemm_block(p, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // several independent products in one launch (one kernel floor instead of one per product, and their block counts add
@@ -172,6 +244,14 @@ int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, 
                     int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain) {
   GemmParams p;
   if (!gemm_setup(p, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, M, N, K, splits, accumulate, tanh_sumsq_partials, epi_plain)) return MKE_OK;
+  // tall and skinny with the fused epilogue: K split over the four wavefronts of a 16-row block (see k_gemm_tall)
+  if (tanh_sumsq_partials && a_cs == 1 && b_cs == 1 && N <= 80 && K <= 320 && M >= 1024 && (M + 15) / 16 <= MKE_LOSS_PARTIALS) {
+    const dim3 grid((M + 15) / 16);
+    if (K <= 80) hipLaunchKernelGGL((k_gemm_tall<5, 5>), grid, dim3(MKE_BLOCK), 0, st, p);
+    else if (K <= 160) hipLaunchKernelGGL((k_gemm_tall<5, 10>), grid, dim3(MKE_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_tall<5, 20>), grid, dim3(MKE_BLOCK), 0, st, p);
+    return check_launch("k_gemm_tall");
+  }
   if (tanh_sumsq_partials && p.gx * p.gy > MKE_LOSS_PARTIALS) { set_error("gemm epilogue: more than %d blocks", MKE_LOSS_PARTIALS); return MKE_E_SHAPE; }
   hipLaunchKernelGGL(k_gemm_f32, dim3(p.gx, p.gy, p.gz), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_gemm_f32");
