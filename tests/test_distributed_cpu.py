@@ -22,10 +22,10 @@ def _free_port():
     return p
 
 
-N_ENT, N_REL, DIM, B, NEG, STEPS, SEED = 600, 12, 20, 64, 5, 4, 7
+N_REL, DIM, B, NEG, STEPS, SEED = 12, 20, 64, 5, 4, 7
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, N_ENT):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,12 +53,14 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_equals_single_process_oracle():
-    world = 2
+@pytest.mark.parametrize("world,N_ENT", [(2, 600), (3, 602)])
+def test_sharded_equals_single_process_oracle(world, N_ENT):
+    """world 3 with 602 entities: shards of unequal size (201 / 201 / 200 rows), KG id ranges that do not fall on shard
+    boundaries."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, N_ENT)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, stats, gmax = ret.get(timeout=240)
