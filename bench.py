@@ -10,9 +10,13 @@ code/MultiKE_model.py:304-310).  Workload at N=1: BASELINE.json configs[1] shape
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
+    python bench.py --config c5        # BASELINE.json configs[4] per-GPU shape (|E|=2M, |R|=2K, dim=256, neg=64): the
+                                       # HBM-resident size (2 GB table; C2's 192 MB working set sits in the Infinity Cache)
+
 Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,25 +29,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 streaming copy reaches on this part (same guide)
+
+# SURVEY.md §8(d) shapes.  c2 = the shape BASELINE.json's metric is quoted on (configs[1], DBP-WD-like); c5 = configs[4]'s
+# per-GPU shape.
+CONFIGS = {
+    "c2": dict(n_ent=200_000, n_rel=550, dim=75, neg=25, batch=5000, label="C2-synth"),
+    "c5": dict(n_ent=2_000_000, n_rel=2000, dim=256, neg=64, batch=5000, label="C5-synth"),
+}
+KERNEL_SOURCES = ("mke_score.hip", "mke_update.hip", "mke_common.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the two kernels of the step: a committed PMC figure is only quoted for the build it
+    was collected on (profiles/r02_pmc_<config>.json carries the hash)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "multike_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=920)  # five synthetic epochs of 184 steps
+    ap.add_argument("--steps", type=int, default=920)  # five synthetic epochs of 184 steps at c2
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n-ent", type=int, default=200_000)
-    ap.add_argument("--n-rel", type=int, default=550)
-    ap.add_argument("--dim", type=int, default=75)
-    ap.add_argument("--neg", type=int, default=25)
-    ap.add_argument("--batch", type=int, default=5000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--n-ent", type=int, default=None)
+    ap.add_argument("--n-rel", type=int, default=None)
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--neg", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-variants", action="store_true", help="skip the reference-default-shape side lines (N=10, truncated)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of each cpu_baseline leg")
     ap.add_argument("--sample-chunk", type=int, default=0, help="steps sampled per sampler launch (0 = whole epoch)")
     ap.add_argument("--rel-grad-copies", type=int, default=1, help="privatised copies of the relation gradient scratch")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded multi-GPU path even at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=60)
-    return ap.parse_args()
+    ap.add_argument("--cpu-steps", type=int, default=60, help="upper bound of steps per cpu_baseline leg")
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    for k in ("n_ent", "n_rel", "dim", "neg", "batch"):
+        if getattr(a, k) is None:
+            setattr(a, k, cfg[k])
+        elif getattr(a, k) != cfg[k]:
+            a.custom = True
+    a.label = cfg["label"] if not getattr(a, "custom", False) else "custom"
+    return a
 
 
 def b_alg(dim):
@@ -52,22 +86,31 @@ def b_alg(dim):
 
 
 def cpu_baseline(args, kgs, ent, rel):
-    """The oracle's C restatement (oracle/mke_oracle.c) timed on this box's host cores, 1 thread, on a bounded
-    sample of the same workload: `cpu_steps` steps (sampler + step, touched-rows update)."""
+    """The oracle's C restatement (oracle/mke_oracle.c: Philox sampler + mko_relation_step_mt_f32) timed on this box's
+    host cores on a bounded sample of the same workload: sampler + step with the touched-rows update, OpenMP over
+    positives / triples / row ranges with every core the process may run on; the same on 1 thread; and the
+    reference-faithful dense cost model (whole-table normalise + dense Jacobian / Adagrad, what the TF graph does every
+    step) on all cores.  Each leg stops after --cpu-seconds or --cpu-steps."""
     from oracle import c_oracle as co
     from oracle import multike_oracle as mo
     d, N, B = args.dim, args.neg, args.batch
     t1, t2 = kgs.triples
     b1, b2 = mo.kg_batch_split(len(t1), len(t2), B)
     sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in (t1, t2)]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    n_steps_epoch = int(np.ceil((len(t1) + len(t2)) / B))
     out = {}
-    for dense, steps in ((False, args.cpu_steps), (True, max(2, args.cpu_steps // 5))):
+    for name, dense, threads in (("all", False, cores), ("one", False, 1), ("dense", True, cores)):
         e, r = ent.copy(), rel.copy()
         a, b = np.full_like(e, 0.1), np.full_like(r, 0.1)
-        orc = co.RelationStepOracle(e.shape[0], r.shape[0], d, np.float32, dense=dense)
-        scored = 0
-        t0 = time.perf_counter()
-        for s in range(steps):
+        orc = co.RelationStepBaselineMT(e.shape[0], r.shape[0], d, dense=dense, threads=threads)
+        co.set_threads(threads)
+        scored, steps, dt = 0, 0, 0.0
+        for s in range(min(args.cpu_steps, n_steps_epoch) + 1):
+            t0 = time.perf_counter()
             pos_parts, neg_parts = [], []
             for k, (t, bs) in enumerate(((t1, b1), (t2, b2))):
                 p = t[s * bs:(s + 1) * bs]
@@ -78,19 +121,90 @@ def cpu_baseline(args, kgs, ent, rel):
             pos = [np.concatenate([pos_parts[0][:, i], pos_parts[1][:, i]]) for i in range(3)]
             neg = [np.concatenate([neg_parts[0][i], neg_parts[1][i]]) for i in range(3)]
             orc.step(e, r, a, b, pos, neg, 0.001)
+            if s == 0:
+                continue  # first step: page faults of the scratch, OpenMP thread start-up
+            dt += time.perf_counter() - t0
             scored += len(pos[0]) * (1 + N)
-        dt = time.perf_counter() - t0
-        out["dense" if dense else "sparse"] = (scored / dt, steps, dt)
-    v, steps, dt = out["sparse"]
+            steps += 1
+            if dt > args.cpu_seconds:
+                break
+        co.set_threads(1)
+        out[name] = (scored / dt, steps, dt)
+        del orc, e, a
+    v, steps, dt = out["all"]
+    v1, s1, dt1 = out["one"]
     vd, dsteps, ddt = out["dense"]
     return {
-        "value": v, "unit": "scored triples/s", "cores": 1, "kind": "port",
+        "value": v, "unit": "scored triples/s", "cores": cores, "kind": "port",
         "sample": f"{steps} steps of the same workload ({dt:.1f}s): C restatement of sampler + relation-view step, "
-                  f"touched-rows update, fp32, 1 thread",
+                  f"touched-rows update, fp32, OpenMP on {cores} threads",
+        "one_thread_value": v1, "one_thread_sample": f"{s1} steps ({dt1:.1f}s), 1 thread",
         "dense_semantics_value": vd,
-        "dense_semantics_sample": f"{dsteps} steps ({ddt:.1f}s) with the reference's whole-table normalise + dense "
-                                  f"Jacobian/Adagrad cost model",
+        "dense_semantics_sample": f"{dsteps} steps ({ddt:.1f}s) on {cores} threads: the same step plus the reference graph's "
+                                  f"whole-table normalise and dense Jacobian/Adagrad passes over all {ent.shape[0]} rows",
     }
+
+
+def reference_default_variants(args, kgs, ent0, rel0, sides):
+    """Side lines (the headline stays the shape BASELINE.json's metric is quoted on): the reference's DEFAULT
+    configuration (code/args.json:25-28) — neg_triple_num 10, and neg_sampling "truncated": candidates drawn from each
+    entity's 2000 nearest neighbours (k = int(0.02 |E_kg|), code/MultiKE_CSL.py:89-102) instead of the whole KG.  Same
+    tables, same KGs, fresh optimizer slots; the k-NN table is built by the product's own refresh (base/batch.neighbour_table)
+    from the current relation-view rows and is NOT inside the timed region (the reference refreshes it every 20 epochs)."""
+    from multike_amd.base.batch import neighbour_table
+    from multike_amd.runner import RelationViewRunner
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.tables import EmbeddingTable
+    d, B, N = args.dim, args.batch, 10
+    out = []
+    for name, truncated in (("neg=10 uniform", False), ("neg=10 truncated k=2000 (reference default)", True)):
+        E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", values=ent0)
+        R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=rel0)
+        vs = [KGSide(kgs.entities(k), sides[k].known) for k in (0, 1)]
+        knn_ms = None
+        if truncated:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in (0, 1):
+                ids = torch.as_tensor(kgs.entities(k), device="cuda")
+                kk = int((1 - 0.98) * len(ids))
+                tab, valid = neighbour_table(E.lookup(ids.to(torch.int32)), kgs.entities(k), kk, kgs.entities_num)
+                vs[k].set_neighbours(tab, valid)
+            torch.cuda.synchronize()
+            knn_ms = (time.perf_counter() - t0) * 1e3
+        bat = RelationBatcher(kgs.triples[0], kgs.triples[1], vs[0], vs[1], B, N, seed=1234)
+        runner = RelationViewRunner(E, R, bat, "relation", lr=0.001)
+        runner.run()                                   # warm-up epoch
+        torch.cuda.synchronize()
+        n_ep = max(1, min(args.steps, 368) // bat.steps)
+        t0 = time.perf_counter()
+        for e in range(n_ep):
+            bat.shuffle()
+            runner.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        scored = n_ep * int(bat.off[-1]) * (1 + N)
+        row = {"name": name, "value": scored / dt, "unit": "triples/s", "steps": n_ep * bat.steps,
+               "ms_per_step": dt / (n_ep * bat.steps) * 1e3, "scored_per_step": B * (1 + N)}
+        if knn_ms is not None:
+            row["knn_refresh_ms_untimed"] = knn_ms
+        out.append(row)
+        del runner, bat, E, R, vs
+    return out
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per launch of k_triple_score from the committed rocprofv3 PMC passes (tools/pmc_passes.sh ->
+    profiles/r02_pmc_<config>.json), quoted only when the file was collected on THIS build of the kernels (source hash)
+    and on this workload; None otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r02_pmc_{args.config}.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("kernel_source_sha") != kernel_source_hash() or getattr(args, "custom", False):
+            return None
+        return int(pmc["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -255,19 +369,19 @@ def main():
         avg_ms = float(ms.mean())
         med_ms = float(np.median(ms))
         achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
-        traffic = None  # PMC bytes per launch of this kernel: collected by separate rocprofv3 --pmc passes
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-                pmc = json.load(f)
-            if pmc["workload"] == f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}":
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = pmc_traffic(args)  # PMC bytes per launch of this kernel (separate rocprofv3 --pmc passes), or None
         roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "median_launch_us": med_ms * 1e3, "launches_timed": int(len(ms)),
                     "alg_bytes_per_triple": b_alg(d),
-                    "triples_per_launch": float(tr.mean())}
+                    "triples_per_launch": float(tr.mean()),
+                    # the same launch priced in the bytes the memory side actually moved (PMC), against the spec peak
+                    # and against what a streaming copy achieves on this part
+                    "achieved_counter": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9,
+                    "frac_counter_of_achievable": None if traffic is None else
+                    traffic / (avg_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS,
+                    "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                    "kernel_source_sha": kernel_source_hash()}
         # second kernel of the step, reported beside it: rows left to it (referenced more than once in the step) x 6 row
         # streams (grad, w, acc read; 0, w, acc written); rows referenced once were updated inside k_triple_score
         touched_rows = int((E.touched == ev_upd[-1][2]).sum()) + int((R.touched == ev_upd[-1][2]).sum())
@@ -276,6 +390,10 @@ def main():
         roofline["update_kernel"] = {"kernel": "k_rows_update_multi", "avg_launch_us": float(ums.mean()) * 1e3,
                                      "touched_rows_last_step": touched_rows, "bytes_per_launch": upd_bytes,
                                      "achieved": upd_bytes / (float(ums.mean()) * 1e-3) / 1e9, "unit": "GB/s"}
+
+    variants = None
+    if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False):
+        variants = reference_default_variants(args, kgs, ent0, rel0, sides)
 
     if sharded:
         # same instrumentation on the sharded path: events around this rank's score-kernel launches (extra steps)
@@ -286,10 +404,12 @@ def main():
         ms = np.array([a.elapsed_time(b) for a, b, _ in trainer.score_events])
         tr = np.array([n for _, _, n in trainer.score_events])
         trainer.score_events = None
+        shard_info = trainer.check()   # raises when any step's row set overflowed the exchange capacity (results invalid)
         achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
         roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": float(ms.mean()) * 1e3,
-                    "alg_bytes_per_triple": b_alg(d), "triples_per_launch": float(tr.mean()), "scope": "per GPU (rank 0)"}
+                    "alg_bytes_per_triple": b_alg(d), "triples_per_launch": float(tr.mean()), "scope": "per GPU (rank 0)",
+                    "exchange": shard_info}
 
     if rank == 0:
         out = {
@@ -297,13 +417,15 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not staged else "synthetic; DRY RUN: ranks share GPUs, collectives staged through the host (not a result)",
-            "config": {"workload": "relation-view ITC train step (sampler + fused score/grad + Adagrad), "
-                                   f"C2-synth |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} batch={B}"
-                                   + (f" per GPU, entity rows sharded id%{world}" if sharded else ""),
+            "config": {"workload": f"relation-view train step, {args.label} |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} "
+                                   f"batch={B}" + (f"/GPU, rows sharded id%{world}" if sharded else ""),
+                       "step": "on-device negative sampling + fused gather/score/loss/gradient + Jacobian/Adagrad row update",
                        "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,
                        "scored_per_step": B * (1 + N) * world, "steps_per_epoch": n_steps_epoch},
             "roofline": roofline,
         }
+        if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False):
+            out["variants"] = variants
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)
         print(json.dumps(out), flush=True)

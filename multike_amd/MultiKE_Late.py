@@ -179,7 +179,13 @@ class _ScheduledMultiKE(MultiKE):
         assert 0.0 < a.truncated_epsilon < 1.0
         out = []
         for kg, useful in ((kgs.kg1, kgs.useful_entities_list1), (kgs.kg2, kgs.useful_entities_list2)):
-            k = max(int((1 - a.truncated_epsilon) * kg.entities_num), a.neg_triple_num)
+            k = int((1 - a.truncated_epsilon) * kg.entities_num)
+            # the reference's random.sample(candidates, neg_triple_num) raises ValueError on a shorter list
+            # (code/base/batch.py:96-99); say so before the kernels see it
+            if k < a.neg_triple_num or k > len(useful):
+                raise ValueError(f"truncated sampling: {k} neighbours per entity (int((1 - truncated_epsilon) * "
+                                 f"{kg.entities_num})) must be >= neg_triple_num ({a.neg_triple_num}) and <= the "
+                                 f"{len(useful)} useful entities of the KG")
             emb = self.rv_ent_embeds.lookup(self._ids(useful))
             out.append(neighbour_table(emb, useful, k, kgs.entities_num, device=self.device))
         self._neighbors = tuple(out)

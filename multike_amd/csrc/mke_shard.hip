@@ -22,7 +22,7 @@ struct RowsetParams {
   int32_t* counts;   // [G] 0 on entry
   int32_t* req;      // [G][C] pre-filled with -1
   int32_t* id_map;   // [n_ent]
-  int32_t* overflow; // [1] set to 1 when an owner's segment is full
+  int32_t* overflow; // [1] set to 1 when an owner's segment is full (those ids map to the pad row G*C)
   int G, C;
 };
 
@@ -70,8 +70,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rowset_build(const RowsetParams p
         p.req[(int64_t)owner * p.C + slot] = id[k] / p.G;
         p.id_map[id[k]] = owner * p.C + slot;
       } else {
+        // the owner's segment is full: the id goes to the PAD row behind the compact row set (index G*C: an all-zero row
+        // on the reading side, a gradient row nobody collects on the writing side), so no other entity's row is read or
+        // updated in its place; the step's result is incomplete and flagged
         *p.overflow = 1;
-        p.id_map[id[k]] = owner * p.C;  // keep indices in range; the step's result is invalid and flagged
+        p.id_map[id[k]] = p.G * p.C;
       }
     }
   }

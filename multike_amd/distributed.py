@@ -165,10 +165,15 @@ class ShardedRelationTrainer:
         self._overflow = torch.zeros(1, **i32)
         self._req = torch.full((G * C,), -1, **i32)                              # re-initialised by rowset_remap each step
         self._rows_out = torch.empty(G * C, st, dtype=dtype, device=dev)
-        self._rows_in = torch.empty(G * C, st, dtype=dtype, device=dev)
-        self._cgrad = torch.zeros(G * C, st, dtype=dtype, device=dev)
+        # compact row set + one PAD row (index G*C): ids that overflowed an owner's segment read this all-zero row and
+        # add their gradient to a row nobody collects (mke_rowset_build), instead of aliasing another entity's slot
+        self._rows_in_all = torch.zeros(G * C + 1, st, dtype=dtype, device=dev)
+        self._rows_in = self._rows_in_all[:G * C]
+        self._cgrad_all = torch.zeros(G * C + 1, st, dtype=dtype, device=dev)
+        self._cgrad = self._cgrad_all[:G * C]
         self._ggot = torch.empty(G * C, st, dtype=dtype, device=dev)
-        self._ctouched = torch.zeros(G * C, **i32)
+        self._ctouched = torch.zeros(G * C + 1, **i32)
+        self._max_rows = torch.zeros(1, **i32)                                   # largest per-owner request count seen
         # --- plan phase (sampler -> row-set build -> id exchange -> remap) is table-independent: it runs one step
         #     ahead on its own stream + communicator, double-buffered, off the critical path of the step ----------
         # plans may be enqueued `lookahead` steps ahead of their use on a side stream with their own communicator.
@@ -269,6 +274,7 @@ class ShardedRelationTrainer:
         streams = [pos[0], pos[2], neg[0], neg[2]]
         be.rowset_build(streams, self._flags, self._counts, self._req, self._id_map, self._overflow, G, C)
         self.comm.all_to_all_single(self._want2[slot], self._req, group=self._plan_group)
+        torch.maximum(self._max_rows, self._counts.max().reshape(1), out=self._max_rows)
         if self.keep_stats:
             self._counts_last.copy_(self._counts)
         cidx = [self._cidx2[slot][k][:streams[k].numel()] for k in range(4)]
@@ -331,8 +337,8 @@ class ShardedRelationTrainer:
             if ev is not None:                                # bench instrumentation: HIP events around the score kernel
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            be.score(self._rows_in, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
-                     self._cgrad, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
+            be.score(self._rows_in_all, True, self.rel, True, self.dim, (cidx[0], pos_r, cidx[1]), (cidx[2], neg_r, cidx[3]), N,
+                     self._cgrad_all, self.rel_grad, self._ctouched, self.rel_touched, tag, self.loss_ring[s])
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1, n_pos * (1 + N)))
@@ -387,9 +393,23 @@ class ShardedRelationTrainer:
             full[r::self.world] = parts[r][:n, :self.dim]
         return full
 
+    def check(self) -> dict:
+        """Synchronising: raise if ANY rank's row set overflowed the exchange capacity since the last check (the steps
+        concerned dropped the overflowing rows' contributions: their results are invalid); returns the capacity and the
+        largest per-owner request count any rank has seen.  Call it before results are used (bench.py: after the timed
+        region; training: `epoch_loss` calls it every epoch)."""
+        t = torch.stack([self._overflow[0].to(torch.int64), self._max_rows[0].to(torch.int64)])
+        if dist.is_initialized() and self.world > 1:
+            self.comm.all_reduce(t, op=dist.ReduceOp.MAX)
+        over, worst = int(t[0]), int(t[1])
+        self._overflow.zero_()
+        if over:
+            raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded (largest request seen: > {self.C}): the "
+                                       f"steps since the last check dropped rows; rebuild the trainer with a larger capacity")
+        return {"capacity_rows_per_owner": self.C, "max_rows_per_owner_seen": worst}
+
     def epoch_loss(self) -> float:
-        if int(self._overflow.item()):
-            raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded: results of this epoch are invalid")
+        self.check()
         t = self.loss_ring.sum()
         self.comm.all_reduce(t)
         self.loss_ring.zero_()

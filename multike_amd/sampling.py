@@ -27,12 +27,14 @@ class KnownTripleSet:
     """Open-addressing hash set of packed (h, r, t) keys in HBM — the `all_triples_set` membership test of
     code/base/batch.py:109."""
 
-    MAX_ENT, MAX_REL = 1 << 26, 1 << 12
+    # packed key = h<<38 | t<<12 | r (26 + 26 + 12 bits).  The largest entity id is excluded so that no triple packs to the
+    # all-ones word, which is the EMPTY marker of the open-addressing table (MKE_EMPTY_KEY)
+    MAX_ENT, MAX_REL = (1 << 26) - 1, 1 << 12
 
     def __init__(self, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor):
         n = h.numel()
         if n and (int(h.max()) >= self.MAX_ENT or int(t.max()) >= self.MAX_ENT or int(r.max()) >= self.MAX_REL):
-            raise _lib.MultiKEHipError("entity id >= 2^26 or relation id >= 2^12 does not fit the packed triple key")
+            raise _lib.MultiKEHipError("entity id >= 2^26 - 1 or relation id >= 2^12 does not fit the packed triple key")
         cap = 1
         while cap < 2 * n + 2:
             cap *= 2

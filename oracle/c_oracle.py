@@ -29,7 +29,9 @@ def lib():
         for suf in ("f32", "f64"):
             fn = getattr(_lib, "mko_relation_step_" + suf)
             fn.restype = C.c_double
+            getattr(_lib, "mko_relation_step_mt_" + suf).restype = C.c_double
         _lib.mko_neg_sample.restype = C.c_int
+        _lib.mko_set_threads.restype = None
         _lib.mko_set_insert.restype = None
     return _lib
 
@@ -70,6 +72,40 @@ class RelationStepOracle:
                        C.c_int(int(rel_norm)), C.c_int(int(self.dense)), C.c_int(int(update)), _p(self.g_ent),
                        _p(self.g_rel), _p(self.mark_ent), _p(self.mark_rel), _p(self.list_ent), _p(self.list_rel),
                        _p(self.norm_ent), _p(self.norm_rel))
+
+
+def set_threads(n: int):
+    """Threads of mko_neg_sample (the sampled negatives do not depend on it)."""
+    lib().mko_set_threads(C.c_int(int(n)))
+
+
+class RelationStepBaselineMT:
+    """bench.py's `cpu_baseline` leg: the OpenMP step (mko_relation_step_mt_f32), touched-rows or dense cost model.
+    Not a parity checker (a row's gradient is summed in thread-schedule order)."""
+
+    def __init__(self, n_ent, n_rel, dim, dense=False, threads=1):
+        f = np.float32
+        self.n_ent, self.n_rel, self.dim, self.dense, self.threads = n_ent, n_rel, dim, dense, int(threads)
+        self.g_ent, self.g_rel = np.zeros((n_ent, dim), f), np.zeros((n_rel, dim), f)
+        self.mark_ent, self.mark_rel = np.zeros(n_ent, np.uint8), np.zeros(n_rel, np.uint8)
+        self.inv_ent, self.inv_rel = np.ones(n_ent, f), np.ones(n_rel, f)
+        self.norm_ent = np.zeros((n_ent, dim), f) if dense else None
+        self.norm_rel = np.zeros((n_rel, dim), f) if dense else None
+        self.gtrip = None
+        self.fn = lib().mko_relation_step_mt_f32
+
+    def step(self, ent, rel, acc_ent, acc_rel, pos, neg, lr):
+        for a in (ent, rel, acc_ent, acc_rel):
+            assert a.dtype == np.float32 and a.flags.c_contiguous
+        ph, pr, pt = (np.ascontiguousarray(a, np.int32) for a in pos)
+        nh, nr, nt = (np.ascontiguousarray(a, np.int32) for a in neg)
+        if self.gtrip is None or self.gtrip.shape[0] < len(ph) + len(nh):
+            self.gtrip = np.zeros((len(ph) + len(nh), self.dim), np.float32)
+        return self.fn(_p(ent), _p(rel), _p(acc_ent), _p(acc_rel), C.c_int64(self.n_ent), C.c_int64(self.n_rel),
+                       C.c_int(self.dim), _p(ph), _p(pr), _p(pt), C.c_int64(len(ph)), _p(nh), _p(nr), _p(nt),
+                       C.c_int64(len(nh)), C.c_double(lr), C.c_int(int(self.dense)), _p(self.g_ent), _p(self.g_rel),
+                       _p(self.mark_ent), _p(self.mark_rel), _p(self.inv_ent), _p(self.inv_rel), _p(self.norm_ent),
+                       _p(self.norm_rel), _p(self.gtrip), C.c_int(self.threads))
 
 
 class TripleSet:

@@ -15,6 +15,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MKO_L2_EPS 1e-12
 #define MKO_MAX_DIM 512
@@ -62,6 +65,11 @@ static inline uint64_t mix64(uint64_t x) {
   return x;
 }
 
+/* threads used by mko_neg_sample (positives are independent; the output does not depend on it).  1 unless bench.py's
+ * cpu_baseline leg raises it. */
+static int mko_threads = 1;
+void mko_set_threads(int n) { mko_threads = n > 0 ? n : 1; }
+
 /* known-triple set: open addressing; keys pre-filled with 0xFF by the caller */
 void mko_set_insert(const int32_t* h, const int32_t* r, const int32_t* t, int64_t n, uint64_t* keys, uint64_t cap) {
   for (int64_t i = 0; i < n; ++i) {
@@ -84,9 +92,10 @@ int mko_neg_sample(const int32_t* ph, const int32_t* pr, const int32_t* pt, int6
                    int max_try, const int32_t* ent_list, int32_t ent_lo, int32_t n_all, const int32_t* cand_table,
                    const uint8_t* cand_valid, int32_t cand_k, const uint64_t* keys, uint64_t cap, uint32_t k0,
                    uint32_t k1, uint32_t sid, int32_t* nh, int32_t* nr, int32_t* nt) {
-  uint32_t fin[64];
   if (want > 64) return -1;
+#pragma omp parallel for schedule(static) num_threads(mko_threads > 0 ? mko_threads : 1)
   for (int64_t i = 0; i < n_pos; ++i) {
+    uint32_t fin[64];
     const int32_t h = ph[i], r = pr[i], t = pt[i];
     const uint32_t gi = (uint32_t)(i + pos_offset);
     int got = 0;

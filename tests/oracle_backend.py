@@ -56,7 +56,7 @@ class OracleBackend:
                 im[i] = o * capacity + cnt[o]
             else:
                 overflow.numpy()[0] = 1
-                im[i] = o * capacity
+                im[i] = n_ranks * capacity          # the pad row behind the compact row set
             cnt[o] += 1
 
     def rowset_remap(self, streams, outs, id_map, flags, reset_req=None, reset_counts=None, want=None, slot_of=None,

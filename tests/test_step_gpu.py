@@ -256,6 +256,63 @@ def test_wide_rows_many_negatives_vs_c_oracle():
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
 
 
+def test_full_size_c5_step_vs_compact_f64_oracle():
+    """BASELINE configs[4] per-GPU shape at FULL size: |E|=2M, |R|=2000, dim=256, N=64, P=5000 (T=325K scored triples, a
+    2 GB table: the HBM-resident shape).  The float64 C oracle runs on the COMPACTED problem — the ~300K rows the two
+    steps touch, renumbered — which is the same function: untouched rows take no part in a step and stay bit-identical
+    (asserted on the device table).  Plus the size-independent properties: gradient scratch consumed, reference counts
+    back to zero, loss additivity over a split of the batch."""
+    from gpu_util import make_tables
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    n_ent, n_rel, d, N, P = 2_000_000, 2000, 256, 64, 5000
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, triples_per_entity=1.0, seed=5)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    sigma = float(np.sqrt(2.6 / (n_ent + d)))
+    E = EmbeddingTable(n_ent, d, "ent", trainable=False)
+    E.trainable = True
+    E.data[:, :d] = torch.randn(n_ent, d, device="cuda", generator=g).clamp_(-2, 2) * sigma
+    R = EmbeddingTable(n_rel, d, "rel", values=mo.xavier_truncated_normal((n_rel, d), np.random.default_rng(6)))
+    eng = StepEngine()
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None), KGSide(kgs.entities(1), None), P, N,
+                          seed=2)
+    steps = [bat.batch(s) for s in (0, 7)]
+    used = torch.unique(torch.cat([x.long() for pos, neg in steps for x in (pos[0], pos[2], neg[0], neg[2])]))
+    remap = torch.full((n_ent,), -1, dtype=torch.int64, device="cuda")
+    remap[used] = torch.arange(used.numel(), device="cuda")
+    e64 = E.raw()[used].double().cpu().numpy()
+    r64 = R.raw().double().cpu().numpy()
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    orc = co.RelationStepOracle(len(e64), n_rel, d, np.float64)
+    before = E.data.clone()
+    for pos, neg in steps:
+        lp = eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, lr=0.001)
+        cp = (remap[pos[0].long()].cpu().numpy(), pos[1].cpu().numpy(), remap[pos[2].long()].cpu().numpy())
+        cn = (remap[neg[0].long()].cpu().numpy(), neg[1].cpu().numpy(), remap[neg[2].long()].cpu().numpy())
+        L = orc.step(e64, r64, a64, b64, cp, cn, 0.001)
+        np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(E.raw()[used].cpu().numpy(), e64, rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(E.slot("relation")[used][:, :d].cpu().numpy(), a64, rtol=1e-3, atol=1e-7)
+    mask = torch.ones(n_ent, dtype=torch.bool, device="cuda")
+    mask[used] = False
+    assert torch.equal(E.data[mask], before[mask])                      # 1.7M untouched rows: bit-identical
+    assert float(E.slot("relation")[mask].min()) == float(E.slot("relation")[mask].max()) == np.float32(0.1)
+    assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+    assert int(E.refcount.abs().sum()) == 0
+    del before
+    pos, neg = bat.batch(3)
+    h = pos[0].numel() // 2
+    full = float(eng.relation_step(E, R, "relation", pos, neg, neg_per_pos=N, update=False).sum())
+    parts = float(eng.relation_step(E, R, "relation", tuple(x[:h] for x in pos), tuple(x[:h * N] for x in neg), neg_per_pos=N,
+                                    update=False).sum()) + \
+        float(eng.relation_step(E, R, "relation", tuple(x[h:] for x in pos), tuple(x[h * N:] for x in neg), neg_per_pos=N,
+                                update=False).sum())
+    np.testing.assert_allclose(full, parts, rtol=1e-6)
+
+
 @pytest.mark.parametrize("n_ent,P,N", [(300, 400, 25), (5000, 2000, 10)])
 def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
     """Few entities, many references: almost every row is referenced many times, some exactly once, the same corrupt
