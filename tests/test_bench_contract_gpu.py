@@ -34,7 +34,11 @@ def test_n1_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["peak"] == 8000.0 and r["alg_bytes_per_triple"] == 12 + 24 * d["config"]["dim"]
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["one_thread_value"] > 0 and c["dense_semantics_value"] > 0
+    v = d["variants"]                 # the reference's default shape (code/args.json:25-28) as side lines
+    assert [x["scored_per_step"] for x in v] == [d["config"]["batch"] * 11] * 2 and all(x["value"] > 50e6 for x in v)
+    assert r["kernel_source_sha"] and (r["traffic"] is None or r["achieved_counter"] > 0)
     assert d["value"] > 50e6          # north_star floor: >= 50 M scored triples/s on one MI355X
 
 

@@ -13,3 +13,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $root
 python tools/pmc_to_json.py $cfg gpurun_out/pmc_${cfg}_FETCH_SIZE gpurun_out/pmc_${cfg}_WRITE_SIZE gpurun_out/pmc_${cfg}_FETCH_SIZE.log
+rm -rf gpurun_out/pmc_${cfg}_FETCH_SIZE gpurun_out/pmc_${cfg}_WRITE_SIZE

@@ -7,3 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/$name -o p -- python "$@" > $root/gpurun_out/$name.log 2>&1
 cd $root
 python tools/rocpd_summary.py $(find gpurun_out/$name -name "*.db" | head -1) $top g
+rm -rf gpurun_out/$name   # the raw database is tens of MB; gpurun merges back at most 64 MiB
