@@ -600,6 +600,46 @@ int mke_align_rank(const float* emb1, int ld1, const float* emb2, int ld2, int k
 int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_stride, const float* B, int64_t b_row_stride,
                  int64_t b_col_stride, float* C, int64_t ldc, int M, int N, int K, int splits, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (12) Literal auto-encoder: training steps and the final encoding as native calls on the
+ *      hand-written f32 MFMA GEMMs with fused epilogues (mke_autoenc.hip, mke_gemm.hip).
+ *
+ * replaces: AutoEncoderModel's graph and training loop, code/literal_encoder.py:41-112 (`_init_graph`, `encoder`,
+ *           `decoder`, `train_one_epoch`: session.run([loss, optimizer]) per batch) and `encoder_multi_batches` (:114-144).
+ *
+ *   dims[0..n_layers] = input width, hidden widths, code width; the decoder mirrors them.  Parameters are ONE packed
+ *   float buffer; tensor t (t < n_layers: encoder layer t; t >= n_layers: decoder layer t - n_layers) has its weight
+ *   [in][out] row-major at params + w_off[t] and its bias [out] at params + b_off[t]; offsets must be multiples of 4
+ *   floats (pad with zeros: a pad entry has a zero gradient for ever).  grads is all-zero on entry and on exit when
+ *   update != 0 (the update consumes it); acc is the Adagrad accumulator (filled with 0.1 by the caller, TF1 default).
+ *   act: 0 none (what the shipped "thah" selects, :75-78), 1 tanh, 2 sigmoid.  normalize: tf.nn.l2_normalize over the
+ *   WHOLE code matrix of the batch (:65-66).
+ *   mke_ae_train_steps: rows [0, n_rows) of x in batches of batch_rows (the last may be short); loss_out[b] (device
+ *   double) = mean((decoded - x)^2) of batch b.  scratch: mke_ae_scratch_floats(plan, min(batch_rows, n_rows)) floats;
+ *   partials: double[3 * MKE_LOSS_PARTIALS], all-zero on entry and on exit; scalars: float[4].
+ * ------------------------------------------------------------------------------------------------ */
+#define MKE_AE_MAX_LAYERS 4
+typedef struct mke_ae_plan {
+  int n_layers;
+  int dims[MKE_AE_MAX_LAYERS + 1];
+  int act, normalize;
+  float* params; float* grads; float* acc /*nullable for SGD*/;
+  int64_t n_params;
+  int64_t w_off[2 * MKE_AE_MAX_LAYERS], b_off[2 * MKE_AE_MAX_LAYERS];
+  int optimizer; float lr; int update;
+  float* scratch; int64_t scratch_floats;
+  double* partials; float* scalars;
+} mke_ae_plan;
+int64_t mke_ae_scratch_floats(const mke_ae_plan* plan, int64_t rows);
+int mke_ae_train_steps(const mke_ae_plan* plan, const float* x, int64_t n_rows, int64_t ldx, int64_t batch_rows,
+                       double* loss_out /* device [ceil(n_rows / batch_rows)] */, void* stream);
+/* out [n_rows][ld_out] = encoder(x): code/literal_encoder.py:114-144 (no normalisation of input or output) */
+int mke_ae_encode(const mke_ae_plan* plan, const float* x, int64_t n_rows, int64_t ldx, float* out, int64_t ld_out, void* stream);
+/* one dense layer, out [M][ld_out] = act(x [M][ldx] @ w [K][ldw] + b [N]) (b nullable): the `encoder` / `decoder` methods of
+ * code/literal_encoder.py:71-91 on arbitrary inputs */
+int mke_dense_layer_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b /*nullable*/, int act, float* out,
+                        int64_t ld_out, int M, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

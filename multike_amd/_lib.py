@@ -32,7 +32,10 @@ SYMBOLS = (
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
+    "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
 )
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+AE_MAX_LAYERS = 4
 
 
 class AttrStepArgs(C.Structure):
@@ -81,6 +84,15 @@ class MappingStepArgs(C.Structure):
                 ("stride", C.c_int), ("dim", C.c_int), ("idx", C.c_void_p), ("n", C.c_int64), ("M", C.c_void_p), ("gM", C.c_void_p),
                 ("accM", C.c_void_p), ("orthogonal_weight", C.c_float), ("norm_w", C.c_float), ("scratch", C.c_void_p),
                 ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32), ("update", C.c_int)]
+
+
+class AEPlanStruct(C.Structure):
+    """mke_ae_plan"""
+    _fields_ = [("n_layers", C.c_int), ("dims", C.c_int * 5), ("act", C.c_int), ("normalize", C.c_int),
+                ("params", C.c_void_p), ("grads", C.c_void_p), ("acc", C.c_void_p), ("n_params", C.c_int64),
+                ("w_off", C.c_int64 * 8), ("b_off", C.c_int64 * 8), ("optimizer", C.c_int), ("lr", C.c_float),
+                ("update", C.c_int), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64), ("partials", C.c_void_p),
+                ("scalars", C.c_void_p)]
 
 
 class OptimizerStruct(C.Structure):
@@ -147,6 +159,7 @@ def lib():
             getattr(L, name).restype = C.c_int
         L.mke_attr_scratch_floats.restype = C.c_int64
         L.mke_mapping_scratch_floats.restype = C.c_int64
+        L.mke_ae_scratch_floats.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -586,6 +599,39 @@ def dense_update(param, acc, grad, optimizer, lr):
                                 _dev(grad, torch.float32, "grad"), C.c_int64(param.numel()), C.c_int(optimizer), C.c_float(lr),
                                 _stream())
     _check(rc, "mke_dense_update")
+
+
+def ae_scratch_floats(plan: AEPlanStruct, rows: int) -> int:
+    n = lib().mke_ae_scratch_floats(C.byref(plan), C.c_int64(rows))
+    if n < 0:
+        raise MultiKEHipError("mke_ae_scratch_floats: bad plan")
+    return int(n)
+
+
+def ae_train_steps(plan: AEPlanStruct, x: torch.Tensor, batch_rows: int, loss_out: torch.Tensor):
+    """mke_ae_train_steps over the rows of x (float32 [n, ldx] CUDA, row-major); loss_out: float64 [n_batches]."""
+    rc = lib().mke_ae_train_steps(C.byref(plan), _dev(x, torch.float32, "x"), C.c_int64(x.shape[0]), C.c_int64(x.stride(0)),
+                                  C.c_int64(batch_rows), _dev(loss_out, torch.float64, "loss_out"), _stream())
+    _check(rc, "mke_ae_train_steps")
+
+
+def ae_encode(plan: AEPlanStruct, x: torch.Tensor, out: torch.Tensor):
+    rc = lib().mke_ae_encode(C.byref(plan), _dev(x, torch.float32, "x"), C.c_int64(x.shape[0]), C.c_int64(x.stride(0)),
+                             _dev(out, torch.float32, "out"), C.c_int64(out.stride(0)), _stream())
+    _check(rc, "mke_ae_encode")
+
+
+def dense_layer_fwd(x: torch.Tensor, w: torch.Tensor, b, act: int, out: torch.Tensor):
+    """out = act(x @ w + b) on the hand-written MFMA GEMM (bias / activation in its epilogue)."""
+    M, K = x.shape
+    K2, N = w.shape
+    if K != K2 or tuple(out.shape) != (M, N) or x.stride(1) != 1 or w.stride(1) != 1 or out.stride(1) != 1:
+        raise MultiKEHipError(f"dense_layer_fwd: shapes {tuple(x.shape)} x {tuple(w.shape)} -> {tuple(out.shape)} (row-major)")
+    rc = lib().mke_dense_layer_fwd(_dev(x, torch.float32, "x"), C.c_int64(x.stride(0)), _dev(w, torch.float32, "w"),
+                                   C.c_int64(w.stride(0)), _dev(b, torch.float32, "b"), C.c_int(act),
+                                   _dev(out, torch.float32, "out"), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
+                                   _stream())
+    _check(rc, "mke_dense_layer_fwd")
 
 
 def align_rank(emb1, emb2, kpad, n1, n2, rank, best):

@@ -8,7 +8,7 @@
 // current one is multiplied.  Measured on MI355X for the attribute step's products (n = 5000, d = 75): 15.9 / 13.0 /
 // 9.1 us (was 44 / 31 / 14 us with 16-wide slabs, no prefetch and per-element 64-bit address arithmetic); slab widths
 // 16..128 are within 15 % of each other, i.e. the rest is occupancy (158..395 blocks on 256 CUs), not the slab size.
-#include "mke_common.h"
+#include "mke_gemm.h"
 
 namespace mke {
 
@@ -28,7 +28,55 @@ struct GemmParams {
   double* partials;
   int epi_plain;  // with partials: store acc itself (no tanh) and the per-block sums of its squares
   int gx, gy, gz;  // this problem's grid (k_gemm_f32_batch decodes its linear block index with it)
+  int ext;         // != 0: the GemmEpilogue below replaces the partials / epi_plain epilogue
+  GemmEpilogue e;
 };
+
+// Extended epilogue (mke_gemm.h) for one wavefront's 32 x 32 accumulator whose top-left element is (row0, col0) of C.
+// C/D map of the 32x32 MFMA forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void gemm_epilogue_ext(const GemmEpilogue& e, const f32x16& acc, float* __restrict__ C, int64_t ldc,
+                                                  int M, int N, int row0, int col0, int lane, int atomic, int block_linear) {
+  const int half = lane >> 5, col = col0 + (lane & 31);
+  const float alpha = e.alpha ? *e.alpha : 1.0f;
+  float ssq = 0.f, dot = 0.f, csum = 0.f;
+  if (col < N) {
+    const float bias = e.bias ? e.bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = row0 + 4 * half + (reg & 3) + 8 * (reg >> 2);
+      if (row < M) {
+        float v = fmaf(alpha, acc[reg], bias);
+        if (atomic) { atomic_add_f32(C + (int64_t)row * ldc + col, v); continue; }
+        v = act_fwd(v, e.act);
+        if (e.target) {
+          const float d = v - e.target[(int64_t)row * e.ld_target + col];
+          ssq = fmaf(d, d, ssq);
+          v = e.target_scale * d * act_grad_from_output(v, e.act);
+        } else if (e.sumsq) {
+          ssq = fmaf(v, v, ssq);
+        }
+        if (e.dact_y) v *= act_grad_from_output(e.dact_y[(int64_t)row * e.ld_dact + col], e.dact_act);
+        if (e.dot_with) dot = fmaf(v, e.dot_with[(int64_t)row * e.ld_dot + col], dot);
+        C[(int64_t)row * ldc + col] = v;
+        csum += v;
+      }
+    }
+  }
+  if (atomic) return;
+  if (e.colsum) {
+    csum += __shfl_xor(csum, 32, 64);
+    if (half == 0 && col < N) atomic_add_f32(e.colsum + col, csum);
+  }
+  if (e.sumsq) {  // block-uniform
+    const double tot = block_sum_double(ssq);
+    if (threadIdx.x == 0) atomic_add_f64(e.sumsq + (block_linear % MKE_LOSS_PARTIALS), tot);
+  }
+  if (e.dot) {
+    __syncthreads();
+    const double tot = block_sum_double(dot);
+    if (threadIdx.x == 0) atomic_add_f64(e.dot + (block_linear % MKE_LOSS_PARTIALS), tot);
+  }
+}
 
 #define GT 64
 #define GK 32
@@ -101,6 +149,10 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
     }
     __syncthreads();
+  }
+  if (p.ext) {
+    gemm_epilogue_ext(p.e, acc, p.C, p.ldc, p.M, p.N, m0 + wm * 32, n0 + wn * 32, lane, p.atomic, (bz * p.gy + by) * p.gx + bx);
+    return;
   }
   // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + l31;
@@ -236,6 +288,8 @@ static bool gemm_setup(GemmParams& p, const float* A, int64_t a_rs, int64_t a_cs
   p.atomic = (accumulate || nz > 1) ? 1 : 0;
   p.partials = partials;
   p.epi_plain = epi_plain;
+  p.ext = 0;
+  p.e = GemmEpilogue{};
   p.gx = (N + GT - 1) / GT; p.gy = (M + GT - 1) / GT; p.gz = nz;
   return true;
 }
@@ -278,6 +332,147 @@ int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const fl
   return check_launch("k_gemm_f32_batch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large dense products (the literal auto-encoder: M = 5000, K / N up to 1500; code/literal_encoder.py:63-91).
+// Same 64 x 64 block tile / one 32 x 32 accumulator per wavefront as gemm_block — at the f32 MFMA rate (64 cycles per
+// v_mfma_f32_32x32x2_f32 per SIMD) a 32 x 32 wave tile needs only 8 bytes of LDS per lane per MFMA, and 64 x 64 blocks
+// quantise well on 256 CUs (5000 x 1024: 1264 blocks = 4.94 per CU) — but every global access is a 16-byte load along the
+// operand's contiguous dimension (gemm_block's dword loads: 16 per thread and slab = as many vector-memory cycles as the
+// slab's MFMAs take; here 4), the LDS image keeps the operand's own orientation (k-contiguous: fragments by ds_read_b128;
+// m / n-contiguous: by conflict-free ds_read_b32), and the block -> tile map gives every XCD a contiguous band of row
+// tiles so that an A row tile is fetched through ONE L2 instead of eight.
+//   A_KC: A[m * lda + k]   (!A_KC: A[k * lda + m])      B_KC: B[n * ldb + k]   (!B_KC: B[k * ldb + n])
+struct GemmVParams {
+  const float* __restrict__ A;
+  const float* __restrict__ B;
+  float* __restrict__ C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int k_per_split, atomic;
+  int gx, gy, gz;
+  GemmEpilogue e;
+};
+
+#define GV_SK 36  // row stride (floats) of a k-contiguous 64 x 32 image
+#define GV_SM 68  // row stride of an m/n-contiguous 32 x 64 image
+
+template <bool KC>
+__device__ __forceinline__ void gv_fetch(const float* __restrict__ base, int64_t ld, int dim_mn, int mn0, int k0, int k_hi, int K,
+                                         int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    int mn, k;
+    if (KC) { mn = mn0 + (tid >> 3) + 32 * e; k = k0 + 4 * (tid & 7); }
+    else    { k = k0 + (tid >> 4) + 16 * e;   mn = mn0 + 4 * (tid & 15); }
+    const bool live = k < k_hi;                       // whole float4 in or out: K, k_per_split (and dim_mn if !KC) are multiples of 4
+    const int kc = min(k, K - (KC ? 4 : 1)), mc = min(mn, dim_mn - (KC ? 1 : 4));   // clamped: rows / columns past the edge are never stored
+    const float4 v = *reinterpret_cast<const float4*>(KC ? base + (int64_t)mc * ld + kc : base + (int64_t)kc * ld + mc);
+    r[e] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void gv_stage(float* __restrict__ s, int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (KC) *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * e) * GV_SK + 4 * (tid & 7)) = r[e];
+    else    *reinterpret_cast<float4*>(s + ((tid >> 4) + 16 * e) * GV_SM + 4 * (tid & 15)) = r[e];
+  }
+}
+// the 16 operand values of one lane for the slab's 16 MFMAs: k = 16 * half + j
+template <bool KC>
+__device__ __forceinline__ void gv_frag(const float* __restrict__ s, int w32, int l31, int half, float (&f)[16]) {
+  if (KC) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(s + (w32 + l31) * GV_SK + half * 16 + 4 * q);
+      f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = s[(half * 16 + j) * GV_SM + w32 + l31];
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_vec(const GemmVParams p) {
+  __shared__ __attribute__((aligned(16))) float sA[64 * GV_SK];
+  __shared__ __attribute__((aligned(16))) float sB[64 * GV_SK];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, half = lane >> 5, l31 = lane & 31;
+  // block -> (row tile, column tile, K split): XCD x (= block % 8, observed dispatch order) gets a contiguous range of tiles
+  const int nb = p.gx * p.gy;
+  const int bz = blockIdx.x / nb, t = blockIdx.x - bz * nb;
+  const int per = nb >> 3, rem = nb & 7, xcd = t & 7, idx = t >> 3;
+  const int L = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  const int by = L / p.gx, bx = L - by * p.gx;
+  const int m0 = by * 64, n0 = bx * 64;
+  const int k_lo = bz * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float4 ra[2], rb[2];
+  gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k_lo, k_hi, p.K, tid, ra);
+  gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k_lo, k_hi, p.K, tid, rb);
+  for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+    gv_stage<A_KC>(sA, tid, ra);
+    gv_stage<B_KC>(sB, tid, rb);
+    __syncthreads();
+    if (k0 + 32 < k_hi) {  // the next slab is in flight during the MFMAs below
+      gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k0 + 32, k_hi, p.K, tid, ra);
+      gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k0 + 32, k_hi, p.K, tid, rb);
+    }
+    float fa[16], fb[16];
+    gv_frag<A_KC>(sA, wm * 32, l31, half, fa);
+    gv_frag<B_KC>(sB, wn * 32, l31, half, fb);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  gemm_epilogue_ext(p.e, acc, p.C, p.ldc, p.M, p.N, m0 + wm * 32, n0 + wn * 32, lane, p.atomic, blockIdx.x);
+}
+
+int launch_gemm_f32_ex(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
+                       int M, int N, int K, int splits, int accumulate, hipStream_t st, const GemmEpilogue* epi) {
+  if (M <= 0 || N <= 0 || K <= 0) return MKE_OK;
+  GemmEpilogue e = epi ? *epi : GemmEpilogue{};
+  const bool single_only = e.bias || e.act != MKE_ACT_NONE || e.dact_y || e.target || e.sumsq || e.dot || e.colsum;
+  const int gx = (N + 63) / 64, gy = (M + 63) / 64;
+  if (splits <= 0) {  // enough blocks for ~4 per CU, slices of >= 128 k
+    splits = 1;
+    if (!single_only) {
+      const int want = (4 * 256 + gx * gy - 1) / (gx * gy);
+      splits = max(1, min(want, K / 128));
+    }
+  }
+  if (single_only && (splits > 1 || accumulate)) { set_error("gemm epilogue needs a single K split and a plain store"); return MKE_E_SHAPE; }
+  if ((e.target && !e.sumsq) || (e.dot_with && !e.dot)) { set_error("gemm epilogue: target needs sumsq, dot_with needs dot"); return MKE_E_NULL; }
+  int kps = (K + splits - 1) / splits;
+  kps = (kps + 31) / 32 * 32;
+  const int gz = (K + kps - 1) / kps;
+  const int atomic = (accumulate || gz > 1) ? 1 : 0;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  const bool a_kc = a_cs == 1, a_mc = a_rs == 1 && !a_kc, b_nc = b_cs == 1, b_kc = b_rs == 1 && !b_nc;
+  const bool vec = (a_kc || a_mc) && (b_nc || b_kc) && al16(A) && al16(B) && K % 4 == 0 && K >= 4 &&
+                   (a_kc ? a_rs % 4 == 0 : (a_cs % 4 == 0 && M % 4 == 0 && M >= 4)) &&
+                   (b_kc ? b_cs % 4 == 0 : (b_rs % 4 == 0 && N % 4 == 0 && N >= 4));
+  if (vec) {
+    GemmVParams p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = a_kc ? a_rs : a_cs; p.ldb = b_kc ? b_cs : b_rs; p.ldc = ldc;
+    p.k_per_split = kps; p.atomic = atomic; p.gx = gx; p.gy = gy; p.gz = gz; p.e = e;
+    const dim3 grid((unsigned)(gx * gy * gz));
+    if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm_vec<true, true>), grid, dim3(MKE_BLOCK), 0, st, p);
+    else if (a_kc) hipLaunchKernelGGL((k_gemm_vec<true, false>), grid, dim3(MKE_BLOCK), 0, st, p);
+    else if (b_kc) hipLaunchKernelGGL((k_gemm_vec<false, true>), grid, dim3(MKE_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_vec<false, false>), grid, dim3(MKE_BLOCK), 0, st, p);
+    return check_launch("k_gemm_vec");
+  }
+  GemmParams p;  // any strides / alignment: the dword-load kernel with the same epilogue
+  gemm_setup(p, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, M, N, K, gz, accumulate, nullptr);
+  p.ext = 1;
+  p.e = e;
+  hipLaunchKernelGGL(k_gemm_f32, dim3(p.gx, p.gy, p.gz), dim3(MKE_BLOCK), 0, st, p);
+  return check_launch("k_gemm_f32");
+}
+
 }  // namespace mke
 
 extern "C" int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_stride, const float* B, int64_t b_row_stride,
@@ -289,6 +484,6 @@ extern "C" int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_
   if (!A || !B || !C) { set_error("mke_gemm_f32: NULL pointer"); return MKE_E_NULL; }
   if (ldc < N) { set_error("mke_gemm_f32: ldc < N"); return MKE_E_SHAPE; }
   if (splits > 1 && !accumulate) { set_error("mke_gemm_f32: split-K accumulates atomically: pass accumulate=1 and a zeroed (or to-be-added-to) C"); return MKE_E_SHAPE; }
-  return launch_gemm_f32(A, a_row_stride, a_col_stride, B, b_row_stride, b_col_stride, C, ldc, M, N, K, splits, accumulate,
-                         (hipStream_t)stream, nullptr, 0);
+  return launch_gemm_f32_ex(A, a_row_stride, a_col_stride, B, b_row_stride, b_col_stride, C, ldc, M, N, K, splits < 1 ? 1 : splits,
+                            accumulate, (hipStream_t)stream, nullptr);
 }

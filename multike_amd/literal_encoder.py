@@ -3,9 +3,10 @@ dense literal auto-encoder that produces the `[#literals, dim]` value vectors of
 runs once; §8 row M1).
 
 This is the one GEMM-shaped part of the system: 1500 -> 1024 -> 512 -> dim -> 512 -> 1024 -> 1500 on 5000-row batches
-(~126 GFLOP per training step).  They are plain dense GEMMs, so they go to the library (rocBLAS / hipBLASLt through
-torch: fp32 on the matrix cores); the optimizer step over the packed parameter buffer is the HIP `mke_dense_update`
-kernel (TF1 Adagrad: acc0 = 0.1, no epsilon).  Parameters live in ONE packed float32 buffer, like the CNN's.
+(~126 GFLOP per training step).  Forward, hand-derived backward and the optimizer step of a whole epoch are ONE native
+call (`mke_ae_train_steps`): every product runs on the hand-written f32 MFMA GEMM of `csrc/mke_gemm.hip` with the layer's
+bias / activation / loss / normalisation partial sums / bias-gradient column sums fused into its epilogue — no
+torch.autograd, no library GEMM.  Parameters live in ONE packed float32 buffer (tensor starts padded to 16 bytes).
 """
 from __future__ import annotations
 
@@ -40,29 +41,64 @@ class AutoEncoderModel:
         self._init_graph(seed)
 
     def _init_graph(self, seed):
-        """code/literal_encoder.py:41-61: every weight and bias ~ N(0, 1) (tf.random_normal_initializer)."""
+        """code/literal_encoder.py:41-61: every weight and bias ~ N(0, 1) (tf.random_normal_initializer).  Packed
+        buffer: encoder_h0 | encoder_b0 | ... | decoder_h0 | decoder_b0 | ..., each tensor's start padded to a multiple of
+        4 floats (pad entries are zero and have a zero gradient for ever)."""
         hds, n = self.hidden_dimensions, self.layer_num
+        if n > _lib.AE_MAX_LAYERS:
+            raise _lib.MultiKEHipError(f"at most {_lib.AE_MAX_LAYERS} encoder layers")
         shapes = []
         for i in range(n):
             shapes += [(f"encoder_h{i}", (hds[i], hds[i + 1])), (f"encoder_b{i}", (hds[i + 1],))]
         for i in range(n):
             j = n - i
             shapes += [(f"decoder_h{i}", (hds[j], hds[j - 1])), (f"decoder_b{i}", (hds[j - 1],))]
-        total = sum(int(np.prod(s)) for _, s in shapes)
+        offs, o = {}, 0
+        for name, shape in shapes:
+            offs[name] = o
+            o += (int(np.prod(shape)) + 3) // 4 * 4
+        total = o
         g = torch.Generator(device="cpu")
         if seed is not None:
             g.manual_seed(int(seed))
-        self.params = torch.randn(total, generator=g).to(self.device)
+        host = torch.zeros(total)
+        for name, shape in shapes:
+            k = int(np.prod(shape))
+            host[offs[name]:offs[name] + k] = torch.randn(k, generator=g)
+        self.params = host.to(self.device)
         self.grads = torch.zeros_like(self.params)
         self.acc = torch.full_like(self.params, ADAGRAD_INIT_ACC)
         self.weights, self.biases, self._gviews = {}, {}, {}
-        o = 0
         for name, shape in shapes:
             k = int(np.prod(shape))
-            view = self.params[o:o + k].view(shape).requires_grad_(False)
+            view = self.params[offs[name]:offs[name] + k].view(shape)
             (self.weights if "_h" in name else self.biases)[name] = view
-            self._gviews[name] = self.grads[o:o + k].view(shape)
-            o += k
+            self._gviews[name] = self.grads[offs[name]:offs[name] + k].view(shape)
+        # native plan
+        p = _lib.AEPlanStruct()
+        p.n_layers = n
+        for i, w in enumerate(hds):
+            p.dims[i] = int(w)
+        p.act = {"sigmoid": _lib.ACT_SIGMOID, "tanh": _lib.ACT_TANH}.get(self.args.encoder_active, _lib.ACT_NONE)  # :75-78
+        p.normalize = int(bool(self.args.encoder_normalize))
+        f32 = torch.float32
+        p.params, p.grads, p.acc = (_lib.ptr(t, f32, "ae") for t in (self.params, self.grads, self.acc))
+        p.n_params = total
+        for i in range(n):
+            p.w_off[i], p.b_off[i] = offs[f"encoder_h{i}"], offs[f"encoder_b{i}"]
+            p.w_off[n + i], p.b_off[n + i] = offs[f"decoder_h{i}"], offs[f"decoder_b{i}"]
+        self._partials = torch.zeros(3 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
+        self._scalars = torch.zeros(4, dtype=f32, device=self.device)
+        p.partials, p.scalars = _lib.ptr(self._partials, torch.float64, "partials"), _lib.ptr(self._scalars, f32, "scalars")
+        self._plan, self._scratch = p, None
+        self._dense = None
+
+    def _ensure_scratch(self, rows: int):
+        need = _lib.ae_scratch_floats(self._plan, rows)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=self.device)
+        self._plan.scratch = _lib.ptr(self._scratch, torch.float32, "scratch")
+        self._plan.scratch_floats = self._scratch.numel()
 
     def set_params(self, p: dict):
         for k, v in p.items():
@@ -71,68 +107,62 @@ class AutoEncoderModel:
     def numpy_params(self) -> dict:
         return {k: v.detach().cpu().numpy().copy() for k, v in {**self.weights, **self.biases}.items()}
 
-    def _act(self, x):
-        if self.args.encoder_active == 'sigmoid':
-            return torch.sigmoid(x)
-        if self.args.encoder_active == 'tanh':
-            return torch.tanh(x)
-        return x  # any other string (the shipped "thah") selects no activation (:75-78)
+    def _layer(self, x, w, b):
+        out = torch.empty(x.shape[0], w.shape[1], dtype=torch.float32, device=self.device)
+        if x.shape[0]:
+            _lib.dense_layer_fwd(x.contiguous(), w, b, self._plan.act, out)
+        return out
 
-    def encoder(self, input_data, W=None, B=None):
-        W, B = W or self.weights, B or self.biases
+    def encoder(self, input_data):
+        """code/literal_encoder.py:71-80 on an arbitrary [n, input_dimension] device tensor."""
         h = input_data
         for i in range(self.layer_num):
-            h = self._act(torch.addmm(B[f"encoder_b{i}"], h, W[f"encoder_h{i}"]))
+            h = self._layer(h, self.weights[f"encoder_h{i}"], self.biases[f"encoder_b{i}"])
         return h
 
-    def decoder(self, input_data, W=None, B=None):
-        W, B = W or self.weights, B or self.biases
+    def decoder(self, input_data):
+        """code/literal_encoder.py:82-91."""
         h = input_data
         for i in range(self.layer_num):
-            h = self._act(torch.addmm(B[f"decoder_b{i}"], h, W[f"decoder_h{i}"]))
+            h = self._layer(h, self.weights[f"decoder_h{i}"], self.biases[f"decoder_b{i}"])
         return h
+
+    def train_steps(self, x: torch.Tensor, batch_rows: int) -> torch.Tensor:
+        """loss + optimizer over the rows of x in batches of batch_rows (code/literal_encoder.py:63-69,98-107) as one
+        native call; returns the per-batch losses (float64, device).  Adam / Adadelta: the native call leaves the gradients
+        and the whole-variable update kernel follows, batch by batch."""
+        p = self._plan
+        n_b = (x.shape[0] + batch_rows - 1) // batch_rows
+        losses = torch.zeros(max(1, n_b), dtype=torch.float64, device=self.device)
+        if x.shape[0] == 0:
+            return losses[:0]
+        self._ensure_scratch(min(batch_rows, x.shape[0]))
+        p.lr = float(self.args.learning_rate)
+        if self.args.optimizer in _lib.DENSE_OPTS:
+            if self._dense is None:
+                self._dense = [torch.zeros_like(self.params), torch.zeros_like(self.params), 0]
+            p.optimizer, p.update = _lib.OPT_SGD, 0
+            for b in range(n_b):
+                _lib.ae_train_steps(p, x[b * batch_rows:(b + 1) * batch_rows], batch_rows, losses[b:b + 1])
+                self._dense[2] += 1
+                _lib.dense_update_opt(self.params, self._dense[0], self._dense[1], self.grads,
+                                      _lib.optimizer_struct(self.args.optimizer, p.lr, self._dense[2]))
+            return losses[:n_b]
+        p.optimizer, p.update = _OPT[self.args.optimizer], 1
+        _lib.ae_train_steps(p, x, batch_rows, losses)
+        return losses[:n_b]
 
     def train_step(self, batch: torch.Tensor) -> torch.Tensor:
-        """loss + optimizer of one batch (code/literal_encoder.py:63-69): library GEMMs forward and backward, HIP
-        update over the packed parameters."""
-        leaves = {k: v.detach().requires_grad_(True) for k, v in {**self.weights, **self.biases}.items()}
-        W = {k: v for k, v in leaves.items() if "_h" in k}
-        B = {k: v for k, v in leaves.items() if "_b" in k}
-        code = self.encoder(batch, W, B)
-        if self.args.encoder_normalize:  # tf.nn.l2_normalize with no axis: the whole matrix (:65-66)
-            code = code * torch.rsqrt(torch.clamp_min(torch.sum(code * code), 1e-12))
-        dec = self.decoder(code, W, B)
-        loss = torch.mean(torch.square(dec - batch))
-        names = list(leaves)
-        grads = torch.autograd.grad(loss, [leaves[k] for k in names])
-        for k, g in zip(names, grads):
-            self._gviews[k].copy_(g)
-        if self.args.optimizer in _lib.DENSE_OPTS:
-            if getattr(self, "_dense", None) is None:
-                self._dense = [torch.zeros_like(self.params), torch.zeros_like(self.params), 0]
-            self._dense[2] += 1
-            _lib.dense_update_opt(self.params, self._dense[0], self._dense[1], self.grads,
-                                  _lib.optimizer_struct(self.args.optimizer, float(self.args.learning_rate), self._dense[2]))
-            return loss.detach()
-        opt = _OPT[self.args.optimizer]
-        _lib.dense_update(self.params, self.acc if opt == _lib.OPT_ADAGRAD else None, self.grads, opt,
-                          float(self.args.learning_rate))
-        return loss.detach()
+        """One batch (code/literal_encoder.py:63-69); returns its loss as a device scalar."""
+        return self.train_steps(batch, max(1, batch.shape[0]))[0]
 
     def train_one_epoch(self, epoch):
         """code/literal_encoder.py:93-112.  `num_batch = L // batch_size + 1`, so the last slice is empty when L is a
         multiple of the batch size; TF would feed it and produce a NaN loss — it is skipped here.  The printed value
         keeps the reference's `loss_sum += batch_size` (:108)."""
         start_time = time.time()
-        bs = self.args.batch_size
-        L = self.word_vec_list.shape[0]
-        loss_sum = torch.zeros((), device=self.device)
-        for i in range(L // bs + 1):
-            batch = self.word_vec_list[i * bs:(i + 1) * bs]
-            if batch.shape[0] == 0:
-                continue
-            loss_sum = loss_sum + self.train_step(batch)
-        loss_sum = float(loss_sum) + self.args.batch_size
+        losses = self.train_steps(self.word_vec_list, self.args.batch_size)
+        loss_sum = float(losses.sum()) + self.args.batch_size
         print('epoch {} of literal encoder, loss: {:.4f}, time: {:.4f}s'.format(epoch, loss_sum, time.time() - start_time))
         return loss_sum
 
@@ -143,8 +173,11 @@ class AutoEncoderModel:
         x = torch.as_tensor(np.reshape(np.asarray(input_data, dtype=np.float32), [len(input_data), self.input_dimension]),
                             device=self.device)
         bs = self.args.batch_size
-        out = [self.encoder(x[i:i + bs]) for i in range(0, x.shape[0], bs)]
-        res = torch.cat(out, 0).double().cpu().numpy() if out else np.zeros((0, self.args.dim))
+        code = torch.empty(x.shape[0], self.hidden_dimensions[-1], dtype=torch.float32, device=self.device)
+        for i in range(0, x.shape[0], bs):
+            self._ensure_scratch(min(bs, x.shape[0] - i))
+            _lib.ae_encode(self._plan, x[i:i + bs], code[i:i + bs])
+        res = code.double().cpu().numpy() if x.shape[0] else np.zeros((0, self.args.dim))
         print("encoded literal embeddings", res.shape)
         return res
 

@@ -9,7 +9,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,ta,tb,splits", [(5000, 75, 300, False, False, 1), (300, 75, 5000, True, False, 32),
                                                 (5000, 300, 75, False, True, 1), (1, 1, 1, False, False, 1),
                                                 (65, 33, 17, True, True, 1), (128, 64, 64, False, False, 4),
-                                                (37, 300, 1024, True, False, 7)])
+                                                (37, 300, 1024, True, False, 7),
+                                                # 16-byte-load kernel (k_gemm_vec), the four operand layouts, ragged M / N / K edges
+                                                (5000, 1024, 1500, False, False, 1), (1500, 1024, 5000, True, False, 4),
+                                                (5000, 1024, 512, False, True, 1), (516, 260, 1028, True, True, 3),
+                                                (68, 72, 36, False, False, 1), (4, 4, 4, True, True, 1)])
 def test_matches_float64(M, N, K, ta, tb, splits):
     from multike_amd import _lib
     g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)

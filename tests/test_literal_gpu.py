@@ -1,4 +1,6 @@
-"""GPU parity of the literal auto-encoder (library GEMMs + HIP optimizer step) against the float64 oracle."""
+"""GPU parity of the literal auto-encoder (native steps on the hand-written MFMA GEMMs with fused epilogues + HIP
+optimizer step) against the float64 oracle (oracle/literal_oracle.py: hand-derived gradients, pinned to torch autograd in
+tests/test_oracle_literal.py)."""
 import numpy as np
 import pytest
 
@@ -54,3 +56,73 @@ def test_literal_encoder_pipeline():
                           encoder_epoch=3)
     enc = LiteralEncoder(lits, w2v, args, tokens_max_len=5, word2vec_dimension=12)
     assert enc.encoded_literal_vector.shape == (58, 6) and np.all(np.isfinite(enc.encoded_literal_vector))
+
+
+@pytest.mark.parametrize("dims,L,active,normalize", [([128, 64, 32, 16], 256, "thah", True),     # every product on the 16-byte path
+                                                     ([128, 64, 32, 16], 256, "tanh", True),
+                                                     ([128, 64, 32, 16], 256, "sigmoid", False),
+                                                     ([150, 70, 33, 9], 77, "tanh", True),        # ragged: dword-load kernel
+                                                     ([64, 20], 300, "thah", True),                # one layer
+                                                     ([96, 64, 48, 32, 12], 130, "sigmoid", True)])  # four layers
+def test_native_gradients_vs_oracle(dims, L, active, normalize):
+    """Gradients of ONE batch left in the packed buffer by mke_ae_train_steps(update = 0): every weight and bias against
+    the float64 oracle; loss; the zero-invariant scratch (partials) restored."""
+    import torch
+    from multike_amd import _lib
+    from multike_amd.literal_encoder import AutoEncoderModel
+    from multike_amd.synthetic import synthetic_args
+    rng = np.random.default_rng(len(dims) * 1000 + L)
+    n = len(dims) - 1
+    x = rng.standard_normal((L, dims[0])).astype(np.float32)
+    args = synthetic_args(dim=dims[-1], batch_size=L, learning_rate=0.05, encoder_active=active, encoder_normalize=normalize,
+                          encoder_epoch=1)
+    m = AutoEncoderModel(x, args, input_dimension=dims[0], hidden_dimensions=dims[1:])
+    p = lo.init_params(dims, rng)
+    for k in p:
+        p[k] *= 0.3
+    m.set_params(p)
+    xin = m.word_vec_list                                   # row-normalised when encoder_normalize (as the model feeds it)
+    x64 = xin.double().cpu().numpy()
+    loss, g = lo.loss_and_grads(p, x64, n, active, normalize)
+    m._ensure_scratch(L)
+    m._plan.optimizer, m._plan.update, m._plan.lr = _lib.OPT_SGD, 0, 0.0
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    _lib.ae_train_steps(m._plan, xin, L, out)
+    np.testing.assert_allclose(float(out[0]), loss, rtol=2e-5)
+    for k in g:
+        got = m._gviews[k].cpu().numpy()
+        scale = np.abs(g[k]).max() + 1e-30
+        assert np.abs(got - g[k]).max() / scale < 2e-4, (k, np.abs(got - g[k]).max() / scale)
+    assert float(m._partials.abs().max()) == 0.0
+    # pad entries of the packed buffer never receive a gradient
+    used = torch.zeros_like(m.grads, dtype=torch.bool)
+    for k, v in m._gviews.items():
+        off = (v.data_ptr() - m.grads.data_ptr()) // 4
+        used[off:off + v.numel()] = True
+    assert float(m.grads[~used].abs().sum()) == 0.0
+
+
+def test_full_shape_step_runs_and_learns():
+    """The reference's shape (code/literal_encoder.py:26-31: 1500 -> 1024 -> 512 -> 75, batches of 5000): a few native
+    epochs on 10,300 literals (2 full batches + a short one) lower the loss; the encoding has the right shape."""
+    import torch
+    from multike_amd.literal_encoder import AutoEncoderModel
+    from multike_amd.synthetic import synthetic_args
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    base = torch.randn(40, 1500, generator=g)
+    x = (base[torch.randint(0, 40, (10300,), generator=g)] + 0.05 * torch.randn(10300, 1500, generator=g)).numpy()
+    args = synthetic_args(dim=75, batch_size=5000, learning_rate=0.01, encoder_active="thah", encoder_normalize=True, encoder_epoch=4)
+    m = AutoEncoderModel(x.reshape(10300, 5, 300), args, seed=3)
+    with torch.no_grad():
+        m.params.mul_(0.02)                                  # N(0,1) weights at width 1500 overflow nothing but learn slowly
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = m.train_one_epoch(1)
+        for e in range(2, 6):
+            last = m.train_one_epoch(e)
+    assert np.isfinite(first) and np.isfinite(last) and last < first
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = m.encoder_multi_batches(x[:6000].reshape(6000, 5, 300))
+    assert enc.shape == (6000, 75) and enc.dtype == np.float64 and np.all(np.isfinite(enc))
+    ref = m.encoder(torch.as_tensor(x[:64], device="cuda")).double().cpu().numpy()
+    np.testing.assert_allclose(enc[:64], ref, rtol=1e-6, atol=1e-6)
