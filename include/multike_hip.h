@@ -609,8 +609,9 @@ int mke_gemm_f32(const float* A, int64_t a_row_stride, int64_t a_col_stride, con
  *
  *   dims[0..n_layers] = input width, hidden widths, code width; the decoder mirrors them.  Parameters are ONE packed
  *   float buffer; tensor t (t < n_layers: encoder layer t; t >= n_layers: decoder layer t - n_layers) has its weight
- *   [in][out] row-major at params + w_off[t] and its bias [out] at params + b_off[t]; offsets must be multiples of 4
- *   floats (pad with zeros: a pad entry has a zero gradient for ever).  grads is all-zero on entry and on exit when
+ *   [in][out] row-major WITH ROW STRIDE (out + 3) & ~3 at params + w_off[t] and its bias [out] at params + b_off[t];
+ *   offsets must be multiples of 4 floats (pad entries are zero and have a zero gradient for ever), so that every
+ *   operand of every product is readable with aligned 16-byte loads.  grads is all-zero on entry and on exit when
  *   update != 0 (the update consumes it); acc is the Adagrad accumulator (filled with 0.1 by the caller, TF1 default).
  *   act: 0 none (what the shipped "thah" selects, :75-78), 1 tanh, 2 sigmoid.  normalize: tf.nn.l2_normalize over the
  *   WHOLE code matrix of the batch (:65-66).

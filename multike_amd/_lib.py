@@ -627,9 +627,12 @@ def dense_layer_fwd(x: torch.Tensor, w: torch.Tensor, b, act: int, out: torch.Te
     K2, N = w.shape
     if K != K2 or tuple(out.shape) != (M, N) or x.stride(1) != 1 or w.stride(1) != 1 or out.stride(1) != 1:
         raise MultiKEHipError(f"dense_layer_fwd: shapes {tuple(x.shape)} x {tuple(w.shape)} -> {tuple(out.shape)} (row-major)")
-    rc = lib().mke_dense_layer_fwd(_dev(x, torch.float32, "x"), C.c_int64(x.stride(0)), _dev(w, torch.float32, "w"),
+    for t, nm in ((x, "x"), (w, "w"), (out, "out")):       # row-major with any row stride (padded rows are not "contiguous")
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise MultiKEHipError(f"dense_layer_fwd: {nm} must be a float32 CUDA tensor")
+    rc = lib().mke_dense_layer_fwd(C.c_void_p(x.data_ptr()), C.c_int64(x.stride(0)), C.c_void_p(w.data_ptr()),
                                    C.c_int64(w.stride(0)), _dev(b, torch.float32, "b"), C.c_int(act),
-                                   _dev(out, torch.float32, "out"), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
+                                   C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)), C.c_int(M), C.c_int(N), C.c_int(K),
                                    _stream())
     _check(rc, "mke_dense_layer_fwd")
 

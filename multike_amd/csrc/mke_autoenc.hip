@@ -47,15 +47,16 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_ae_scalar(double* __restrict__ pa
 
 // Backward through out = code * inv, inv = rsqrt(max(S, eps)), S = sum code^2 over the whole batch, then through the
 // code layer's activation:  dcode = inv * dcn - code * inv^3 * D  (D = sum dcn . code; the second term only when S > eps),
-// dz = dcode * act'(code).  A block owns 64 rows; thread = column; one atomic per column and block for the bias gradient.
+// dz = dcode * act'(code).  A block owns 16 rows (two 8-row strips x 128 columns); one atomic per column and strip for the bias gradient.
 __global__ __launch_bounds__(MKE_BLOCK) void k_ae_norm_bwd(const float* __restrict__ dcn, const float* __restrict__ code,
                                                            float* __restrict__ dz, int64_t ld, int M, int d, int act,
                                                            int normalize, const float* __restrict__ scal,
                                                            float* __restrict__ colsum) {
   const float inv = normalize ? scal[0] : 1.0f;
   const float coef = (normalize && scal[1] > MKE_L2_EPS) ? inv * inv * inv * scal[2] : 0.f;
-  const int r0 = blockIdx.x * 64, r1 = min(M, r0 + 64);
-  for (int c = threadIdx.x; c < d; c += MKE_BLOCK) {
+  // 16 rows per block; threads = (row half, column): two 8-row strips of up to 128 columns per pass
+  const int r0 = blockIdx.x * 16 + (threadIdx.x >> 7) * 8, r1 = min(M, r0 + 8);
+  for (int c = threadIdx.x & 127; c < d; c += 128) {
     float cs = 0.f;
     for (int r = r0; r < r1; ++r) {
       const float y = code[(int64_t)r * ld + c];
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_ae_norm_bwd(const float* __restri
       dz[(int64_t)r * ld + c] = v;
       cs += v;
     }
-    atomic_add_f32(colsum + c, cs);
+    if (r0 < r1) atomic_add_f32(colsum + c, cs);
   }
 }
 
@@ -132,7 +133,7 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
       e.bias = pl->params + pl->b_off[i];
       e.act = act;
       if (i == n - 1 && pl->normalize) e.sumsq = P_ssq;
-      AE_RUN(launch_gemm_f32_ex(H[i], ldH(i), 1, pl->params + pl->w_off[i], d[i + 1], 1, H[i + 1], ldH(i + 1), M, d[i + 1], d[i], 1, 0, st, &e));
+      AE_RUN(launch_gemm_f32_ex(H[i], ldH(i), 1, pl->params + pl->w_off[i], pad4(d[i + 1]), 1, H[i + 1], ldH(i + 1), M, d[i + 1], d[i], 1, 0, st, &e));
     }
     if (pl->normalize) hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_ssq, scal, 0, 1.0, (double*)nullptr);   // scal[0] = 1 / ||code||
     // ---- forward: decoder (layer j maps width d[n-j] -> d[n-j-1]) ----
@@ -146,7 +147,7 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
         e.sumsq = P_loss;
         e.colsum = pl->grads + pl->b_off[n + j];
       }
-      AE_RUN(launch_gemm_f32_ex(D[j], j == 0 ? ldH(n) : ldD(j), 1, pl->params + pl->w_off[n + j], d[n - j - 1], 1, D[j + 1], ldD(j + 1), M,
+      AE_RUN(launch_gemm_f32_ex(D[j], j == 0 ? ldH(n) : ldD(j), 1, pl->params + pl->w_off[n + j], pad4(d[n - j - 1]), 1, D[j + 1], ldD(j + 1), M,
                                 d[n - j - 1], d[n - j], 1, 0, st, &e));
     }
     hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_loss, scal, 2, (double)M * (double)d[0], loss_out + batch_i);
@@ -161,7 +162,7 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
       {  // dW_j = D[j]^T dz  (x inv for the first decoder layer: its input was the normalised code)
         GemmEpilogue e;
         if (j == 0 && pl->normalize) e.alpha = scal;
-        AE_RUN(launch_gemm_f32_ex(D[j], 1, j == 0 ? ldH(n) : ldD(j), dz, ld_dz, 1, pl->grads + pl->w_off[n + j], dout, din, dout, M, 0, 1, st, &e));
+        AE_RUN(launch_gemm_f32_ex(D[j], 1, j == 0 ? ldH(n) : ldD(j), dz, ld_dz, 1, pl->grads + pl->w_off[n + j], pad4(dout), din, dout, M, 0, 1, st, &e));
       }
       if (j > 0) {  // dZ_{j-1} = (dz W_j^T) * act'(D[j]);  column sums -> bias gradient of decoder layer j-1
         GemmEpilogue e;
@@ -169,29 +170,29 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
         e.dact_y = D[j]; e.ld_dact = ldD(j);
         e.colsum = pl->grads + pl->b_off[n + j - 1];
         float* out = G[gsel]; gsel ^= 1;
-        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, Win, 1, dout, out, pad4(din), M, din, dout, 1, 0, st, &e));
+        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, Win, 1, pad4(dout), out, pad4(din), M, din, dout, 1, 0, st, &e));
         dz = out; ld_dz = pad4(din);
       } else {      // gradient w.r.t. the normalised code, and sum dcn . code for the normalisation's backward
         GemmEpilogue e;
         if (pl->normalize) { e.dot_with = H[n]; e.ld_dot = ldH(n); e.dot = P_dot; }
-        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, Win, 1, dout, dcn, pad4(din), M, din, dout, 1, 0, st, &e));
+        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, Win, 1, pad4(dout), dcn, pad4(din), M, din, dout, 1, 0, st, &e));
       }
     }
     if (pl->normalize) hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_dot, scal, 1, 1.0, (double*)nullptr);
-    hipLaunchKernelGGL(k_ae_norm_bwd, dim3((M + 63) / 64), dim3(MKE_BLOCK), 0, st, dcn, H[n], dzc, pad4(d[n]), M, d[n], act, pl->normalize,
+    hipLaunchKernelGGL(k_ae_norm_bwd, dim3((M + 15) / 16), dim3(MKE_BLOCK), 0, st, dcn, H[n], dzc, pad4(d[n]), M, d[n], act, pl->normalize,
                        scal, pl->grads + pl->b_off[n - 1]);
     // ---- backward: encoder ----
     dz = dzc; ld_dz = pad4(d[n]);
     for (int i = n - 1; i >= 0; --i) {
       const int din = d[i], dout = d[i + 1];
-      AE_RUN(launch_gemm_f32_ex(H[i], 1, ldH(i), dz, ld_dz, 1, pl->grads + pl->w_off[i], dout, din, dout, M, 0, 1, st, nullptr));
+      AE_RUN(launch_gemm_f32_ex(H[i], 1, ldH(i), dz, ld_dz, 1, pl->grads + pl->w_off[i], pad4(dout), din, dout, M, 0, 1, st, nullptr));
       if (i > 0) {
         GemmEpilogue e;
         e.dact_act = act;
         e.dact_y = H[i]; e.ld_dact = ldH(i);
         e.colsum = pl->grads + pl->b_off[i - 1];
         float* out = G[gsel]; gsel ^= 1;
-        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, pl->params + pl->w_off[i], 1, dout, out, pad4(din), M, din, dout, 1, 0, st, &e));
+        AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, pl->params + pl->w_off[i], 1, pad4(dout), out, pad4(din), M, din, dout, 1, 0, st, &e));
         dz = out; ld_dz = pad4(din);
       }
     }
@@ -224,7 +225,7 @@ extern "C" int mke_ae_encode(const mke_ae_plan* pl, const float* x, int64_t n_ro
     GemmEpilogue e;
     e.bias = pl->params + pl->b_off[i];
     e.act = pl->act;
-    const int rc = launch_gemm_f32_ex(in, ld_in, 1, pl->params + pl->w_off[i], d[i + 1], 1, o, ld_o, M, d[i + 1], d[i], 1, 0, (hipStream_t)stream, &e);
+    const int rc = launch_gemm_f32_ex(in, ld_in, 1, pl->params + pl->w_off[i], pad4(d[i + 1]), 1, o, ld_o, M, d[i + 1], d[i], 1, 0, (hipStream_t)stream, &e);
     if (rc) return rc;
     in = o; ld_in = ld_o;
   }

@@ -359,15 +359,25 @@ struct GemmVParams {
 template <bool KC>
 __device__ __forceinline__ void gv_fetch(const float* __restrict__ base, int64_t ld, int dim_mn, int mn0, int k0, int k_hi, int K,
                                          int tid, float4 (&r)[2]) {
+  // Every access is one aligned 16-byte load along the contiguous dimension; the caller guarantees that the contiguous
+  // extent rounded up to 4 fits in ld, so a float4 that straddles the logical edge still reads the row's own padding.
+  // What must contribute nothing is zeroed by K position: whole float4s past k_hi, and — k-contiguous operands with
+  // K % 4 != 0 — the components past K of the last one.  Rows / columns past the M / N edge are clamped to valid memory
+  // and never stored.
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     int mn, k;
     if (KC) { mn = mn0 + (tid >> 3) + 32 * e; k = k0 + 4 * (tid & 7); }
     else    { k = k0 + (tid >> 4) + 16 * e;   mn = mn0 + 4 * (tid & 15); }
-    const bool live = k < k_hi;                       // whole float4 in or out: K, k_per_split (and dim_mn if !KC) are multiples of 4
-    const int kc = min(k, K - (KC ? 4 : 1)), mc = min(mn, dim_mn - (KC ? 1 : 4));   // clamped: rows / columns past the edge are never stored
-    const float4 v = *reinterpret_cast<const float4*>(KC ? base + (int64_t)mc * ld + kc : base + (int64_t)kc * ld + mc);
-    r[e] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int kpad = (K + 3) & ~3, mpad = (dim_mn + 3) & ~3;
+    const int kc = min(k, (KC ? kpad - 4 : K - 1)), mc = min(mn, (KC ? dim_mn - 1 : mpad - 4));
+    float4 v = *reinterpret_cast<const float4*>(KC ? base + (int64_t)mc * ld + kc : base + (int64_t)kc * ld + mc);
+    if (KC) {
+      v.x = k < k_hi ? v.x : 0.f; v.y = k + 1 < k_hi ? v.y : 0.f; v.z = k + 2 < k_hi ? v.z : 0.f; v.w = k + 3 < k_hi ? v.w : 0.f;
+    } else if (k >= k_hi) {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    r[e] = v;
   }
 }
 template <bool KC>
@@ -395,6 +405,11 @@ __device__ __forceinline__ void gv_frag(const float* __restrict__ s, int w32, in
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_vec(const GemmVParams p) {
+  // ONE LDS image per operand and two barriers per slab: double-buffering the images (one barrier per slab) measured
+  // SLOWER (5000 x 1024 x 1500: 191 vs 174 us) — 37 KB of LDS and 73 registers leave 4 waves per SIMD instead of 8, and
+  // it is the number of co-resident blocks that keeps the matrix pipe fed across the barriers.  Raising the wave priority
+  // around the 16-MFMA burst (s_setprio 2 ... 0) also measured slower (190 vs 175 us).  PMC: the matrix pipe is busy 74 %
+  // of the kernel's cycles at an effective clock of 1.84 GHz under this load (profiles/r02_gemm.md).
   __shared__ __attribute__((aligned(16))) float sA[64 * GV_SK];
   __shared__ __attribute__((aligned(16))) float sB[64 * GV_SK];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -450,9 +465,11 @@ int launch_gemm_f32_ex(const float* A, int64_t a_rs, int64_t a_cs, const float* 
   const int atomic = (accumulate || gz > 1) ? 1 : 0;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   const bool a_kc = a_cs == 1, a_mc = a_rs == 1 && !a_kc, b_nc = b_cs == 1, b_kc = b_rs == 1 && !b_nc;
-  const bool vec = (a_kc || a_mc) && (b_nc || b_kc) && al16(A) && al16(B) && K % 4 == 0 && K >= 4 &&
-                   (a_kc ? a_rs % 4 == 0 : (a_cs % 4 == 0 && M % 4 == 0 && M >= 4)) &&
-                   (b_kc ? b_cs % 4 == 0 : (b_rs % 4 == 0 && N % 4 == 0 && N >= 4));
+  // 16-byte loads: base and leading dimension 16-byte aligned, and the contiguous extent rounded up to 4 inside the row
+  auto p4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
+  const bool vec = (a_kc || a_mc) && (b_nc || b_kc) && al16(A) && al16(B) &&
+                   (a_kc ? (a_rs % 4 == 0 && p4(K) <= a_rs) : (a_cs % 4 == 0 && p4(M) <= a_cs)) &&
+                   (b_kc ? (b_cs % 4 == 0 && p4(K) <= b_cs) : (b_rs % 4 == 0 && p4(N) <= b_rs));
   if (vec) {
     GemmVParams p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;

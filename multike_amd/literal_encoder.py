@@ -53,27 +53,32 @@ class AutoEncoderModel:
         for i in range(n):
             j = n - i
             shapes += [(f"decoder_h{i}", (hds[j], hds[j - 1])), (f"decoder_b{i}", (hds[j - 1],))]
+        pad4 = lambda v: (int(v) + 3) // 4 * 4
         offs, o = {}, 0
-        for name, shape in shapes:
+        for name, shape in shapes:              # weight [in][out] stored with row stride pad4(out); bias [out]
             offs[name] = o
-            o += (int(np.prod(shape)) + 3) // 4 * 4
+            o += shape[0] * pad4(shape[1]) if len(shape) == 2 else pad4(shape[0])
         total = o
         g = torch.Generator(device="cpu")
         if seed is not None:
             g.manual_seed(int(seed))
         host = torch.zeros(total)
-        for name, shape in shapes:
-            k = int(np.prod(shape))
-            host[offs[name]:offs[name] + k] = torch.randn(k, generator=g)
         self.params = host.to(self.device)
         self.grads = torch.zeros_like(self.params)
         self.acc = torch.full_like(self.params, ADAGRAD_INIT_ACC)
         self.weights, self.biases, self._gviews = {}, {}, {}
+
+        def view_of(buf, name, shape):
+            if len(shape) == 2:
+                ld = pad4(shape[1])
+                return buf[offs[name]:offs[name] + shape[0] * ld].view(shape[0], ld)[:, :shape[1]]
+            return buf[offs[name]:offs[name] + shape[0]]
+
         for name, shape in shapes:
-            k = int(np.prod(shape))
-            view = self.params[offs[name]:offs[name] + k].view(shape)
+            view = view_of(self.params, name, shape)
+            view.copy_(torch.randn(shape, generator=g).to(self.device))
             (self.weights if "_h" in name else self.biases)[name] = view
-            self._gviews[name] = self.grads[offs[name]:offs[name] + k].view(shape)
+            self._gviews[name] = view_of(self.grads, name, shape)
         # native plan
         p = _lib.AEPlanStruct()
         p.n_layers = n
@@ -108,9 +113,12 @@ class AutoEncoderModel:
         return {k: v.detach().cpu().numpy().copy() for k, v in {**self.weights, **self.biases}.items()}
 
     def _layer(self, x, w, b):
-        out = torch.empty(x.shape[0], w.shape[1], dtype=torch.float32, device=self.device)
+        ld = (w.shape[1] + 3) // 4 * 4           # row stride a multiple of 16 bytes: the 16-byte-load kernel applies
+        out = torch.empty(x.shape[0], ld, dtype=torch.float32, device=self.device)[:, :w.shape[1]]
         if x.shape[0]:
-            _lib.dense_layer_fwd(x.contiguous(), w, b, self._plan.act, out)
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            _lib.dense_layer_fwd(x, w, b, self._plan.act, out)
         return out
 
     def encoder(self, input_data):

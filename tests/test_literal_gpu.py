@@ -95,11 +95,9 @@ def test_native_gradients_vs_oracle(dims, L, active, normalize):
         assert np.abs(got - g[k]).max() / scale < 2e-4, (k, np.abs(got - g[k]).max() / scale)
     assert float(m._partials.abs().max()) == 0.0
     # pad entries of the packed buffer never receive a gradient
-    used = torch.zeros_like(m.grads, dtype=torch.bool)
-    for k, v in m._gviews.items():
-        off = (v.data_ptr() - m.grads.data_ptr()) // 4
-        used[off:off + v.numel()] = True
-    assert float(m.grads[~used].abs().sum()) == 0.0
+    total = float(m.grads.abs().sum())
+    named = sum(float(v.abs().sum()) for v in m._gviews.values())
+    assert abs(total - named) <= 1e-6 * max(1.0, total)
 
 
 def test_full_shape_step_runs_and_learns():

@@ -30,14 +30,18 @@ g = torch.Generator(device="cuda"); g.manual_seed(0)
 print("| product | M | N | K | ours us | ours TF/s | % of 157 | library us | library TF/s |")
 print("|---|---|---|---|---|---|---|---|---|")
 for name, m, n, k, ta, tb in SHAPES:
-    a = torch.randn((k, m) if ta else (m, k), device="cuda", generator=g)
-    b = torch.randn((n, k) if tb else (k, n), device="cuda", generator=g)
-    out = torch.zeros(m, n, device="cuda")
+    # rows padded to 16 bytes, as the auto-encoder stores its weights and activations (mke_ae_plan)
+    p4 = lambda v: (v + 3) // 4 * 4
+    mk = lambda r, c: torch.randn(r, p4(c), device="cuda", generator=g)[:, :c]
+    a = mk(k, m) if ta else mk(m, k)
+    b = mk(n, k) if tb else mk(k, n)
+    out = torch.zeros(m, p4(n), device="cuda")[:, :n]
     A, B = (a.t() if ta else a), (b.t() if tb else b)
     fl = 2.0 * m * n * k
     splits = int(os.environ.get("SPLITS", "1")) if not ta else max(1, min(64, (256 * 4) // (((m + 63) // 64) * ((n + 63) // 64))))
     t_ours = timeit(lambda: _lib.gemm_f32(a, b, out, transpose_a=ta, transpose_b=tb, splits=splits, accumulate=splits > 1))
-    t_lib = timeit(lambda: torch.matmul(A, B, out=out))
+    Ac, Bc, outc = A.contiguous(), B.contiguous(), torch.zeros(m, n, device="cuda")
+    t_lib = timeit(lambda: torch.matmul(Ac, Bc, out=outc))
     ref = A.double() @ B.double()
     out.zero_(); _lib.gemm_f32(a, b, out, transpose_a=ta, transpose_b=tb, splits=splits, accumulate=splits > 1)
     err = float((out.double() - ref).abs().max() / ref.abs().max())
