@@ -641,6 +641,50 @@ int mke_ae_encode(const mke_ae_plan* plan, const float* x, int64_t n_rows, int64
 int mke_dense_layer_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b /*nullable*/, int act, float* out,
                         int64_t ld_out, int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (13) Multi-GPU relation-view step, "owner computes" form (mke_oc.hip; new design, the reference is
+ *      single-device).  Entity rows are sharded id % n_ranks (local row = id / n_ranks); the relation table is replicated.
+ *      A global step = n_pos positives in the reference's epoch order; rank g is HOME of positives [g*per, (g+1)*per).
+ *      Instead of moving entity rows to the triples, each rank scores the negatives whose corrupted entity it owns; what
+ *      crosses the links per positive p is HR_p = h^ + r^ (built by the owner of h), RT_p = r^ - t^ (built by the owner of
+ *      t) and the gradients w.r.t. them.  Per step, on every rank:
+ *          mke_oc_bases  -> all-gather of the send blocks (mke_oc_count meanwhile) -> mke_oc_score -> reduce-scatter of
+ *          g_all -> mke_oc_apply -> all-reduce of rel_grad -> mke_rows_update_multi(relation table, shard)
+ *      Block of rank o (mke_oc_block_floats floats): [capacity] HR vectors (slot order) | [capacity] RT vectors.
+ *      codes: the negatives as (corrupt entity << 1) | corrupted-head, packed by every home rank for its own positives
+ *      (mke_oc_pack_codes; table-independent, exchanged once per epoch); the codes of home rank g's positives of this step
+ *      are codes[code_off[g] + j * neg_per_pos + n] (j-th positive of its slice).
+ *      slot_h[i] / slot_t[i]: slot of positive i's HR / RT vector in its owner's block (i-th positive of the step; any
+ *      numbering the ranks agree on); own_h / own_t: the positives whose head / tail this rank owns, in slot order.
+ *      g_all: [n_ranks][2 * capacity][stride] — every slot is overwritten each step; gv: this rank's block after the
+ *      reduce-scatter.  ref_count (nullable): zero-invariant counters of the exclusive-row fast path (a corrupt row
+ *      referenced once in the whole global step is updated in place by mke_oc_score).  Same arithmetic as
+ *      mke_triple_score_fwd_bwd_x; both tables are read through l2_normalize (the relation view's tables).
+ * ------------------------------------------------------------------------------------------------ */
+#define MKE_OC_MAX_RANKS 16
+typedef struct mke_oc_step {
+  float* ent; float* ent_acc /*nullable: SGD*/; float* ent_grad; int32_t* ent_touched; int32_t* ref_count /*nullable*/;
+  int64_t n_local;
+  const float* rel; float* rel_grad; int rel_grad_copies; int32_t* rel_touched; int64_t n_rel;
+  int stride, dim, rank, n_ranks;
+  const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t;   /* [n_pos], GLOBAL entity ids */
+  int64_t n_pos, per;
+  const int32_t* slot_h; const int32_t* slot_t;                       /* [n_pos] */
+  const int32_t* own_h; int64_t n_own_h; const int32_t* own_t; int64_t n_own_t;
+  int neg_per_pos; int64_t capacity;
+  const int32_t* codes; int64_t code_off[MKE_OC_MAX_RANKS];
+  int optimizer; float lr, scale; int32_t tag;
+} mke_oc_step;
+int64_t mke_oc_block_floats(int64_t capacity, int stride);
+/* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output */
+int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, const int32_t* neg_t, int64_t n_pos, int neg_per_pos,
+                      int32_t* codes, void* stream);
+int mke_oc_bases(const mke_oc_step* step, float* send_block, void* stream);
+int mke_oc_count(const mke_oc_step* step, void* stream);
+int mke_oc_score(const mke_oc_step* step, const float* v_all, int64_t block_floats, float* g_all,
+                 double* loss_partials /* [MKE_LOSS_PARTIALS] */, void* stream);
+int mke_oc_apply(const mke_oc_step* step, const float* gv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ SYMBOLS = (
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
+    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -84,6 +85,19 @@ class MappingStepArgs(C.Structure):
                 ("stride", C.c_int), ("dim", C.c_int), ("idx", C.c_void_p), ("n", C.c_int64), ("M", C.c_void_p), ("gM", C.c_void_p),
                 ("accM", C.c_void_p), ("orthogonal_weight", C.c_float), ("norm_w", C.c_float), ("scratch", C.c_void_p),
                 ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32), ("update", C.c_int)]
+
+
+class OcStepStruct(C.Structure):
+    """mke_oc_step"""
+    _fields_ = [("ent", C.c_void_p), ("ent_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("ent_touched", C.c_void_p),
+                ("ref_count", C.c_void_p), ("n_local", C.c_int64),
+                ("rel", C.c_void_p), ("rel_grad", C.c_void_p), ("rel_grad_copies", C.c_int), ("rel_touched", C.c_void_p),
+                ("n_rel", C.c_int64), ("stride", C.c_int), ("dim", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int),
+                ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("n_pos", C.c_int64), ("per", C.c_int64),
+                ("slot_h", C.c_void_p), ("slot_t", C.c_void_p), ("own_h", C.c_void_p), ("n_own_h", C.c_int64),
+                ("own_t", C.c_void_p), ("n_own_t", C.c_int64), ("neg_per_pos", C.c_int), ("capacity", C.c_int64),
+                ("codes", C.c_void_p), ("code_off", C.c_int64 * 16),
+                ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32)]
 
 
 class AEPlanStruct(C.Structure):
@@ -160,6 +174,7 @@ def lib():
         L.mke_attr_scratch_floats.restype = C.c_int64
         L.mke_mapping_scratch_floats.restype = C.c_int64
         L.mke_ae_scratch_floats.restype = C.c_int64
+        L.mke_oc_block_floats.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -599,6 +614,38 @@ def dense_update(param, acc, grad, optimizer, lr):
                                 _dev(grad, torch.float32, "grad"), C.c_int64(param.numel()), C.c_int(optimizer), C.c_float(lr),
                                 _stream())
     _check(rc, "mke_dense_update")
+
+
+def oc_block_floats(capacity: int, stride: int) -> int:
+    return int(lib().mke_oc_block_floats(C.c_int64(capacity), C.c_int(stride)))
+
+
+def oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos: int, codes):
+    rc = lib().mke_oc_pack_codes(_dev(pos_h, torch.int32, "pos_h"), _dev(neg_h, torch.int32, "neg_h"),
+                                 _dev(neg_t, torch.int32, "neg_t"), C.c_int64(pos_h.numel()), C.c_int(neg_per_pos),
+                                 _dev(codes, torch.int32, "codes"), _stream())
+    _check(rc, "mke_oc_pack_codes")
+
+
+def oc_bases(step: OcStepStruct, send_block):
+    rc = lib().mke_oc_bases(C.byref(step), _dev(send_block, torch.float32, "send_block"), _stream())
+    _check(rc, "mke_oc_bases")
+
+
+def oc_count(step: OcStepStruct):
+    rc = lib().mke_oc_count(C.byref(step), _stream())
+    _check(rc, "mke_oc_count")
+
+
+def oc_score(step: OcStepStruct, v_all, block_floats: int, g_all, loss_partials):
+    rc = lib().mke_oc_score(C.byref(step), _dev(v_all, torch.float32, "v_all"), C.c_int64(block_floats),
+                            _dev(g_all, torch.float32, "g_all"), _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+    _check(rc, "mke_oc_score")
+
+
+def oc_apply(step: OcStepStruct, gv):
+    rc = lib().mke_oc_apply(C.byref(step), _dev(gv, torch.float32, "gv"), _stream())
+    _check(rc, "mke_oc_apply")
 
 
 def ae_scratch_floats(plan: AEPlanStruct, rows: int) -> int:

@@ -1,0 +1,374 @@
+// mke_oc.hip — "owner computes" kernels of the entity-row sharded (multi-GPU) relation-view step (gfx950).
+//
+// New design (the reference has no multi-device code).  Entity rows are sharded id % G.  Moving rows to
+// the triples costs one row in and one gradient row out per (corrupted) negative; here the NEGATIVES move to the rows:
+// a negative of positive (h, r, t) differs from it in one entity c, and its score needs only c's row and one of two
+// vectors of the positive,
+//       corrupted head:  d = c^ + (r^ - t^) = c^ + RT_p          corrupted tail:  d = (h^ + r^) - c^ = HR_p - c^ ,
+// so per global step every rank
+//   (0) per EPOCH (table-independent): every rank packs the negatives of its own positives as (corrupt entity, side) codes
+//                    (k_oc_pack_codes); one all-gather per epoch gives every rank the codes of all negatives;
+//   (1) k_oc_bases : builds HR_p for the positives whose head it owns and RT_p for those whose tail it owns (relation
+//                    table replicated: no row leaves its owner);
+//   ... all-gather of the blocks: every rank now holds HR / RT of ALL G x P positives ...
+//   (2) k_oc_count : reference counts of its own rows over the whole global step (exclusive-row fast path; needs only the
+//                    codes, so it runs while the all-gather is on the wire);
+//   (3) k_oc_score : one wavefront per positive of the GLOBAL step scores the negatives whose corrupt entity THIS rank
+//                    owns — the corrupt row is local: updated in place when referenced once, else scattered into the
+//                    local gradient scratch — and writes its partial dL/dHR_p, dL/dRT_p into the slot the vector came
+//                    from; the positive's own term is added by its home rank;
+//   ... reduce-scatter of the gradient vectors: the owner of h_p receives sum dL/dHR_p, the owner of t_p sum dL/dRT_p ...
+//   (4) k_oc_apply : adds them to the head / tail rows' gradient (local) and to the replicated relation gradient;
+//   ... all-reduce of the relation gradient; mke_rows_update_multi on the shard + the relation table (every row is
+//       updated once per step from the sum of all its contributions: dense-Adagrad-equivalent).
+// Per rank and step that is 2 vectors out and 2 gradient vectors back per positive instead of N rows + N gradient rows:
+// (G-1)/G * 2 * 2 * P * stride * 4 bytes against (G-1)/G * 2 * P * (N + 2) * stride * 4 — 13.5x less at N = 25, and no
+// row-set construction, id exchange or remap.  Same arithmetic as the fused single-GPU kernel (mke_score.hip).
+#include "mke_common.h"
+
+namespace mke {
+
+struct OcParams {
+  mke_oc_step s;
+  float* send;          // k_oc_bases: this rank's block
+  const float* v_all;   // [G][block_floats]
+  int64_t block_floats; // 2 C stride
+  float* g_all;         // [G][2 C stride]
+  const float* gv;      // [2 C stride]
+  double* lossp;
+};
+
+// codes of the negatives of home rank g's positives of this part: [n_mine_g][neg_per_pos]
+__device__ __forceinline__ const int32_t* oc_codes(const OcParams& p, int g) { return p.s.codes + p.s.code_off[g]; }
+
+// (corrupt entity << 1) | corrupted-head, one per negative; a negative equal to its positive counts as a corrupted tail
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_pack_codes(const int32_t* __restrict__ pos_h, const int32_t* __restrict__ neg_h,
+                                                             const int32_t* __restrict__ neg_t, int64_t n_pos, int neg_per_pos,
+                                                             int32_t* __restrict__ codes) {
+  const int64_t total = n_pos * neg_per_pos;
+  for (int64_t e = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * MKE_BLOCK) {
+    const int nh = neg_h[e], nt = neg_t[e];
+    codes[e] = nh != pos_h[e / neg_per_pos] ? ((nh << 1) | 1) : (nt << 1);
+  }
+}
+
+// quarter-wave per owned slot (HR slots, then RT slots)
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_bases(const OcParams p) {
+  const mke_oc_step& s = p.s;
+  const int j = threadIdx.x & 15;
+  const int64_t sub = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  if (sub >= s.n_own_h + s.n_own_t) return;
+  const bool is_h = sub < s.n_own_h;
+  const int64_t k = is_h ? sub : sub - s.n_own_h;
+  const int32_t pos = is_h ? s.own_h[k] : s.own_t[k];
+  const int e = is_h ? s.pos_h[pos] : s.pos_t[pos];
+  float E[FPL], R[FPL];
+  load_row<FPL>(s.ent, e / s.n_ranks, s.stride, j, E);
+  load_row<FPL>(s.rel, s.pos_r[pos], s.stride, j, R);
+  l2_normalize_row<FPL>(E, true);
+  l2_normalize_row<FPL>(R, true);
+  float* o = p.send + ((is_h ? 0 : s.capacity) + k) * (int64_t)s.stride + j;
+#pragma unroll
+  for (int q = 0; q < FPL; ++q) o[q * 16] = is_h ? E[q] + R[q] : R[q] - E[q];
+}
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) {
+  const mke_oc_step& s = p.s;
+  const int64_t n_codes = s.n_pos * s.neg_per_pos;
+  const int64_t total = n_codes + s.n_own_h + s.n_own_t;
+  for (int64_t e = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * MKE_BLOCK) {
+    if (e < n_codes) {
+      const int64_t i = e / s.neg_per_pos;
+      const int g = (int)(i / s.per);
+      const int c = oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)] >> 1;
+      if (c % s.n_ranks == s.rank) atomicAdd(&s.ref_count[c / s.n_ranks], 1);
+    } else {
+      const int64_t k = e - n_codes;
+      const int ent = k < s.n_own_h ? s.pos_h[s.own_h[k]] : s.pos_t[s.own_t[k - s.n_own_h]];
+      atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
+    }
+  }
+}
+
+// One wavefront per positive of the global step.  Lane l holds the code of negative l (neg_per_pos <= 64); the negatives
+// this rank owns are dealt round-robin to the four quarter-waves (the (4 round + q)-th set bit of the ballot), U of them
+// in flight per quarter.
+template <int FPL, int U>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
+  const mke_oc_step& s = p.s;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
+  const int G = s.n_ranks, N = s.neg_per_pos;
+  const int64_t C = s.capacity;
+  float loss = 0.f;
+  for (int64_t i = wave0; i < s.n_pos; i += nwaves) {
+    const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
+    const int home = (int)(i / s.per);
+    const int64_t slot_h = (int64_t)(ph % G) * p.block_floats + (int64_t)s.slot_h[i] * s.stride;
+    const int64_t slot_t = (int64_t)(pt % G) * p.block_floats + (C + s.slot_t[i]) * s.stride;
+    float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
+    load_row<FPL>(p.v_all + slot_h, 0, s.stride, j, HR);
+    load_row<FPL>(p.v_all + slot_t, 0, s.stride, j, RT);
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
+    int code = 0;
+    if (lane < N) code = oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane];
+    const bool mine = lane < N && ((code >> 1) % G) == s.rank;
+    const uint64_t mask = __ballot(mine);
+    const int total = __popcll(mask);
+
+    if (home == s.rank && q == 0) {  // the positive itself: d = h^ + r^ - t^ = HR + RT - r^
+      float R[FPL];
+      load_row<FPL>(s.rel, pr, s.stride, j, R);
+      l2_normalize_row<FPL>(R, true);
+      float d[FPL];
+      float x = 0.f;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        d[k] = (HR[k] + RT[k]) - R[k];
+        x = fmaf(d[k], d[k], x);
+      }
+      x = sub16_sum(x);
+      loss += softplus_f(x);
+      const float c = 2.0f * s.scale * sigmoid_f(x);
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        d[k] *= c;
+        gHR[k] += d[k];   // -> head row +g, relation row +g
+        gRT[k] += d[k];   // -> relation row +g, tail row -g;  the relation row's surplus g is taken back here:
+      }
+      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
+      atomic_add_row<FPL>(grel, pr, s.stride, s.dim, j, d, -1.0f);
+      if (j == 0) s.rel_touched[pr] = s.tag;
+    }
+
+    for (int base = 0; base < total; base += 4 * U) {
+      int e[U], cnt[U];
+      bool live[U], sideH[U];
+      float Cr[U][FPL], A[U][FPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int target = base + 4 * u + q;
+        live[u] = target < total;
+        uint64_t t = mask;
+        for (int k = 0; k < target && t; ++k) t &= t - 1;   // drop the `target` lowest set bits
+        const int src = live[u] ? __builtin_ctzll(t) : 0;
+        const int cd = __shfl(code, src, 64);
+        sideH[u] = cd & 1;
+        e[u] = (cd >> 1) / G;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cnt[u] = 0;
+        if (live[u]) {
+          load_row<FPL>(s.ent, e[u], s.stride, j, Cr[u]);
+          cnt[u] = s.ref_count ? s.ref_count[e[u]] : 0;
+          if (s.ref_count && s.ent_acc) load_row<FPL>(s.ent_acc, e[u], s.stride, j, A[u]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) Cr[u][k] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) ss = fmaf(Cr[u][k], Cr[u][k], ss);
+        const float cinv = rsqrtf(fmaxf(sub16_sum(ss), MKE_L2_EPS));
+        float d[FPL];
+        float y = 0.f;
+        const float sc = sideH[u] ? cinv : -cinv;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) {
+          d[k] = fmaf(sc, Cr[u][k], sideH[u] ? RT[k] : HR[k]);
+          y = fmaf(d[k], d[k], y);
+        }
+        y = sub16_sum(y);
+        const float t_ = __expf(-y);
+        const float s1 = 1.0f + t_;
+        loss += __logf(s1);
+        const float c = -2.0f * s.scale * t_ * __builtin_amdgcn_rcpf(s1);
+        const float cHR = sideH[u] ? 0.f : c, cRT = sideH[u] ? c : 0.f;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) {
+          gHR[k] = fmaf(cHR, d[k], gHR[k]);
+          gRT[k] = fmaf(cRT, d[k], gRT[k]);
+          d[k] *= c;
+        }
+        const float sg = sideH[u] ? 1.0f : -1.0f;
+        if (s.ref_count && cnt[u] == 1) {  // the only reference to this row in the whole global step: finish it here
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) dot = fmaf(Cr[u][k], d[k], dot);
+          dot = sub16_sum(dot) * (sg * cinv);
+          const float a1 = sg * cinv;
+          const float a2 = cinv < 0.99e6f ? -dot * cinv * cinv : 0.f;
+          float g[FPL];
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) g[k] = fmaf(a2, Cr[u][k], a1 * d[k]);
+          float* wp = s.ent + (int64_t)e[u] * s.stride + j;
+          if (s.optimizer == MKE_OPT_ADAGRAD) {
+            float* ap = s.ent_acc + (int64_t)e[u] * s.stride + j;
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+              const float a = fmaf(g[k], g[k], A[u][k]);
+              ap[k * 16] = a;
+              wp[k * 16] = Cr[u][k] - s.lr * g[k] * adagrad_scale(a);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) wp[k * 16] = Cr[u][k] - s.lr * g[k];
+          }
+          if (j == 0) s.ref_count[e[u]] = 0;
+        } else {
+          atomic_add_row<FPL>(s.ent_grad, e[u], s.stride, s.dim, j, d, sg);
+          if (j == 0) s.ent_touched[e[u]] = s.tag;
+        }
+      }
+    }
+
+    // partial gradient vectors of this positive (zero when this rank owns none of its negatives): quarter 0 -> HR slot,
+    // quarter 1 -> RT slot.  Every slot of g_all is written by exactly one wavefront per step: no atomics, no clearing.
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      gHR[k] += __shfl_xor(gHR[k], 16, 64); gHR[k] += __shfl_xor(gHR[k], 32, 64);
+      gRT[k] += __shfl_xor(gRT[k], 16, 64); gRT[k] += __shfl_xor(gRT[k], 32, 64);
+    }
+    if (q < 2) {
+      const int64_t gb = 2 * C * (int64_t)s.stride;
+      float* o = p.g_all + (q == 0 ? (int64_t)(ph % G) * gb + (int64_t)s.slot_h[i] * s.stride
+                                   : (int64_t)(pt % G) * gb + (C + s.slot_t[i]) * s.stride) + j;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) o[k * 16] = q == 0 ? gHR[k] : gRT[k];
+    }
+  }
+  const double tot = block_sum_double(j == 0 ? loss : 0.f);
+  if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)s.scale;
+}
+
+// quarter-wave per owned slot: the summed gradient vector goes to the head (+) / tail (-) row's gradient and to the
+// relation row's
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
+  const mke_oc_step& s = p.s;
+  const int j = threadIdx.x & 15;
+  const int64_t sub = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  if (sub >= s.n_own_h + s.n_own_t) return;
+  const bool is_h = sub < s.n_own_h;
+  const int64_t k = is_h ? sub : sub - s.n_own_h;
+  const int32_t pos = is_h ? s.own_h[k] : s.own_t[k];
+  const int row = (is_h ? s.pos_h[pos] : s.pos_t[pos]) / s.n_ranks;
+  const int r = s.pos_r[pos];
+  float v[FPL];
+  load_row<FPL>(p.gv, (is_h ? 0 : s.capacity) + k, s.stride, j, v);
+  atomic_add_row<FPL>(s.ent_grad, row, s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
+  float* grel = s.rel_grad + (sub % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
+  atomic_add_row<FPL>(grel, r, s.stride, s.dim, j, v, 1.0f);
+  if (j == 0) {
+    s.ent_touched[row] = s.tag;
+    s.rel_touched[r] = s.tag;
+  }
+}
+
+static int oc_check(const mke_oc_step* s, const char* who) {
+  if (!s) { set_error("%s: NULL step", who); return MKE_E_NULL; }
+  if (s->n_ranks < 1 || s->n_ranks > MKE_OC_MAX_RANKS || s->rank < 0 || s->rank >= s->n_ranks) { set_error("%s: bad rank / n_ranks", who); return MKE_E_SHAPE; }
+  if (s->stride <= 0 || s->stride % 16 != 0 || s->dim <= 0 || s->dim > s->stride || s->stride > MKE_MAX_STRIDE) { set_error("%s: bad stride/dim", who); return MKE_E_SHAPE; }
+  if (s->n_pos < 0 || s->per < 1 || s->per * s->n_ranks < s->n_pos || s->neg_per_pos < 0 || s->neg_per_pos > 64) { set_error("%s: bad n_pos / per / neg_per_pos (<= 64)", who); return MKE_E_SHAPE; }
+  if (s->n_own_h < 0 || s->n_own_t < 0 || s->n_own_h > s->capacity || s->n_own_t > s->capacity) { set_error("%s: owned vectors exceed the capacity", who); return MKE_E_SHAPE; }
+  if (s->rel_grad_copies < 1 || s->rel_grad_copies > 64) { set_error("%s: rel_grad_copies must be in [1,64]", who); return MKE_E_SHAPE; }
+  if (s->n_pos > 0 && (!s->pos_h || !s->pos_r || !s->pos_t || !s->slot_h || !s->slot_t)) { set_error("%s: NULL positive / slot stream", who); return MKE_E_NULL; }
+  if (s->n_pos * s->neg_per_pos > 0 && !s->codes) { set_error("%s: NULL negative codes", who); return MKE_E_NULL; }
+  if ((s->n_own_h > 0 && !s->own_h) || (s->n_own_t > 0 && !s->own_t)) { set_error("%s: NULL owned-slot list", who); return MKE_E_NULL; }
+  if (!s->ent || !s->rel) { set_error("%s: NULL table", who); return MKE_E_NULL; }
+  if (s->optimizer != MKE_OPT_ADAGRAD && s->optimizer != MKE_OPT_SGD) { set_error("%s: Adagrad or SGD", who); return MKE_E_UNSUPPORTED; }
+  return MKE_OK;
+}
+
+static inline unsigned oc_blocks(int64_t n, int per_block, int64_t cap) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace mke
+
+extern "C" int64_t mke_oc_block_floats(int64_t capacity, int stride) {
+  if (capacity < 0 || stride < 0) return -1;
+  return 2 * capacity * stride;
+}
+
+extern "C" int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, const int32_t* neg_t, int64_t n_pos, int neg_per_pos,
+                                 int32_t* codes, void* stream) {
+  using namespace mke;
+  if (n_pos < 0 || neg_per_pos < 0) { set_error("mke_oc_pack_codes: negative count"); return MKE_E_SHAPE; }
+  if (n_pos * neg_per_pos == 0) return MKE_OK;
+  if (!pos_h || !neg_h || !neg_t || !codes) { set_error("mke_oc_pack_codes: NULL pointer"); return MKE_E_NULL; }
+  hipLaunchKernelGGL(k_oc_pack_codes, dim3(oc_blocks(n_pos * neg_per_pos, MKE_BLOCK, 4096)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
+                     pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
+  return check_launch("k_oc_pack_codes");
+}
+
+extern "C" int mke_oc_bases(const mke_oc_step* s, float* send_block, void* stream) {
+  using namespace mke;
+  int rc = oc_check(s, "mke_oc_bases");
+  if (rc) return rc;
+  if (!send_block) { set_error("mke_oc_bases: NULL send block"); return MKE_E_NULL; }
+  OcParams p{};
+  p.s = *s; p.send = send_block;
+  const int64_t subs = s->n_own_h + s->n_own_t;
+  if (subs == 0) return MKE_OK;
+  const int fpl = s->stride / 16;
+  MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_bases<FPL>), dim3((unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); });
+  return check_launch("k_oc_bases");
+}
+
+extern "C" int mke_oc_count(const mke_oc_step* s, void* stream) {
+  using namespace mke;
+  int rc = oc_check(s, "mke_oc_count");
+  if (rc) return rc;
+  if (!s->ref_count) return MKE_OK;
+  const int64_t total = s->n_pos * s->neg_per_pos + s->n_own_h + s->n_own_t;
+  if (total == 0) return MKE_OK;
+  OcParams p{};
+  p.s = *s;
+  hipLaunchKernelGGL(k_oc_count, dim3(oc_blocks(total, MKE_BLOCK, 2048)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  return check_launch("k_oc_count");
+}
+
+extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t block_floats, float* g_all, double* loss_partials,
+                            void* stream) {
+  using namespace mke;
+  int rc = oc_check(s, "mke_oc_score");
+  if (rc) return rc;
+  if (!v_all || !g_all || !loss_partials || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_score: NULL pointer"); return MKE_E_NULL; }
+  if (s->ref_count && s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_score: the exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  OcParams p{};
+  p.s = *s; p.v_all = v_all; p.block_floats = block_floats; p.g_all = g_all; p.lossp = loss_partials;
+  const int fpl = s->stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    constexpr int U = FPL <= 5 ? 2 : 1;
+    hipLaunchKernelGGL((k_oc_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  });
+  return check_launch("k_oc_score");
+}
+
+extern "C" int mke_oc_apply(const mke_oc_step* s, const float* gv, void* stream) {
+  using namespace mke;
+  int rc = oc_check(s, "mke_oc_apply");
+  if (rc) return rc;
+  const int64_t subs = s->n_own_h + s->n_own_t;
+  if (subs == 0) return MKE_OK;
+  if (!gv || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_apply: NULL pointer"); return MKE_E_NULL; }
+  OcParams p{};
+  p.s = *s; p.gv = gv;
+  const int fpl = s->stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_oc_apply<FPL>), dim3((unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  });
+  return check_launch("k_oc_apply");
+}

@@ -1,0 +1,417 @@
+"""Entity-row sharded relation-view training, "owner computes" form (RCCL over xGMI on MI355X).
+
+The reference has no multi-device code; this is new design.  One process per GPU.
+  * entity table + its Adagrad slot + gradient scratch are row-sharded by  id % world  (local row = id // world);
+  * the relation table is replicated;
+  * a global step is `world` x batch_size positives in the reference's epoch order; rank g is HOME of the g-th
+    contiguous slice and samples its negatives (Philox stream indexed by the GLOBAL epoch position: the negatives of a
+    positive do not depend on the world size);
+  * rows never leave their owner.  A negative differs from its positive (h, r, t) in one entity c and its score needs only
+    c's row and one of two vectors of the positive — HR_p = h^ + r^ (corrupted tail: d = HR_p - c^) or RT_p = r^ - t^
+    (corrupted head: d = c^ + RT_p) — so the NEGATIVES go to the rows.  Per global step:
+        owner of h_p builds HR_p, owner of t_p builds RT_p;  own negatives packed as (entity, side) codes   [mke_oc_bases]
+        ALL-GATHER of the blocks (2 vectors per positive + 4 bytes per negative)
+        reference counts of the own rows over the whole global step                                        [mke_oc_count]
+        every rank scores, for ALL world x batch positives, the negatives whose corrupt entity it owns: corrupt-row
+        gradient applied locally (in place when referenced once, else scattered), partial dL/dHR_p, dL/dRT_p written into
+        the slot the vector came from; the home rank adds the positive's own term                          [mke_oc_score]
+        REDUCE-SCATTER of the gradient vectors (same layout): the owner of h_p / t_p receives the sum
+        head / tail rows' and relation rows' gradient from it                                              [mke_oc_apply]
+        ALL-REDUCE of the relation gradient;  one update of every touched shard row and relation row  [mke_rows_update_multi]
+    i.e. every row is updated once per step from the sum of all its contributions (dense-Adagrad-equivalent, SURVEY.md
+    §8e "semantics note").  Slots are assigned per epoch from the (replicated) epoch order, so capacity is known exactly
+    before the epoch starts: nothing can overflow mid-epoch.
+Bytes per rank and step over the links: (G-1)/G * 2 * (2 P stride 4 + 4 P N) against (G-1)/G * 2 * P (N + 2) stride 4 of a
+row exchange — 12x less at N = 25 / dim 75, 30x less at N = 64 / dim 256 (DESIGN.md §5 has the latency model).
+
+`chunks` > 1 splits the global step's positives into that many parts whose all-gather / reduce-scatter run on the
+communicator's own stream while the previous / next part is scored (split-batch pipelining; the single update at the end
+sees every part's gradients, so the result is the same function).
+
+The compute steps go through a backend object: `OcHipBackend` (the product, HIP kernels) — tests inject a CPU backend
+built on the oracle to exercise this logic under `gloo`.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .sampling import KGSide, KnownTripleSet, RelationBatcher, side_array
+from .tables import ADAGRAD_INIT_ACC
+
+
+@dataclass
+class OcStep:
+    """One part of a global step as the backends see it (tensors on the trainer's device)."""
+    pos_h: torch.Tensor
+    pos_r: torch.Tensor
+    pos_t: torch.Tensor
+    per: int
+    slot_h: torch.Tensor
+    slot_t: torch.Tensor
+    own_h: torch.Tensor
+    own_t: torch.Tensor
+    tag: int
+    codes: torch.Tensor = None      # the epoch's negative codes of every rank, [world][codes_per_rank]
+    code_off: tuple = ()            # per home rank: offset of its codes of this part inside `codes`
+
+
+class OcHipBackend:
+    """Product backend: every compute step is a HIP kernel of libmultike_hip.so (mke_oc.hip, mke_update.hip)."""
+
+    device_type = "cuda"
+
+    def make_known(self, h, r, t):
+        return KnownTripleSet(h, r, t)
+
+    def sample_at(self, pos, pos_index, pos_kg, side1, side2, neg_per_pos, seed, stream_id, out):
+        _lib.neg_sample_at(pos, pos_index, pos_kg, side_array(side1, side2), neg_per_pos, 10, seed, stream_id, out)
+
+    def block_elems(self, capacity, stride):
+        return _lib.oc_block_floats(capacity, stride)
+
+    def pack_codes(self, pos_h, neg_h, neg_t, neg_per_pos, codes):
+        _lib.oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos, codes)
+
+    def _struct(self, tr: "OwnerComputesTrainer", st: OcStep):
+        f32, i32 = torch.float32, torch.int32
+        s = _lib.OcStepStruct()
+        s.ent, s.ent_acc = _lib.ptr(tr.ent, f32, "ent"), _lib.ptr(tr.ent_acc, f32, "acc")
+        s.ent_grad, s.ent_touched = _lib.ptr(tr.ent_grad, f32, "grad"), _lib.ptr(tr.ent_touched, i32, "touched")
+        s.ref_count = _lib.ptr(tr.ref_count, i32, "ref_count") if tr.ref_count is not None else None
+        s.n_local = tr.n_local
+        s.rel, s.rel_grad, s.rel_grad_copies = _lib.ptr(tr.rel, f32, "rel"), _lib.ptr(tr.rel_grad, f32, "rel_grad"), 1
+        s.rel_touched, s.n_rel = _lib.ptr(tr.rel_touched, i32, "rel_touched"), tr.rel.shape[0]
+        s.stride, s.dim, s.rank, s.n_ranks = tr.stride, tr.dim, tr.rank, tr.world
+        s.pos_h, s.pos_r, s.pos_t = (_lib.ptr(x, i32, "pos") for x in (st.pos_h, st.pos_r, st.pos_t))
+        s.n_pos, s.per = st.pos_h.numel(), st.per
+        s.slot_h, s.slot_t = _lib.ptr(st.slot_h, i32, "slot"), _lib.ptr(st.slot_t, i32, "slot")
+        s.own_h, s.n_own_h = _lib.ptr(st.own_h, i32, "own"), st.own_h.numel()
+        s.own_t, s.n_own_t = _lib.ptr(st.own_t, i32, "own"), st.own_t.numel()
+        s.neg_per_pos, s.capacity = tr.N, tr.C
+        s.codes = _lib.ptr(st.codes, i32, "codes")
+        for g, o in enumerate(st.code_off):
+            s.code_off[g] = int(o)
+        s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, 1.0, st.tag
+        return s
+
+    def bases(self, tr, st, send):
+        _lib.oc_bases(self._struct(tr, st), send)
+
+    def count(self, tr, st):
+        _lib.oc_count(self._struct(tr, st))
+
+    def score(self, tr, st, v_all, g_all, loss_partials):
+        _lib.oc_score(self._struct(tr, st), v_all, tr.block, g_all, loss_partials)
+
+    def apply(self, tr, st, gv):
+        _lib.oc_apply(self._struct(tr, st), gv)
+
+    def update(self, tr, tag):
+        # relation table: EVERY row (touched = None) — after the all-reduce a row may carry a gradient no local triple touched
+        _lib.rows_update_multi([(tr.rel, tr.rel_acc, tr.rel_grad, None, True),
+                                (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched, True, tr.ref_count)],
+                               tag, tr.stride, tr.dim, _lib.OPT_ADAGRAD, tr.lr)
+
+
+class OcComm:
+    """The three collectives of the step on torch.distributed (RCCL over xGMI on MI355X; gloo in the CPU tests).
+    `async_op` returns a work handle whose wait() orders the CURRENT stream after the collective."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_gather(self, out, mine, async_op=False):
+        return dist.all_gather_into_tensor(out, mine, group=self.group, async_op=async_op)
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        return dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=async_op)
+
+    def all_reduce(self, t, op=None):
+        dist.all_reduce(t, group=self.group) if op is None else dist.all_reduce(t, op=op, group=self.group)
+
+    def all_gather_list(self, parts, mine):
+        dist.all_gather(parts, mine, group=self.group)
+
+
+class OcGlooComm(OcComm):
+    """gloo has no reduce-scatter: all-reduce the whole buffer and keep this rank's block (CPU tests only)."""
+
+    def all_gather(self, out, mine, async_op=False):
+        w = dist.get_world_size(self.group)
+        dist.all_gather(list(out.view(w, -1).unbind(0)), mine.reshape(-1), group=self.group)
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        w, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+        tmp = inp.clone()
+        dist.all_reduce(tmp, group=self.group)
+        out.copy_(tmp.view(w, -1)[r].view_as(out))
+
+
+class OcHostStagedComm(OcGlooComm):
+    """Test vehicle: the same collectives on DEVICE tensors through gloo, staged over the host.  Lets two ranks that SHARE
+    one GPU run the device kernels with world_size 2 (RCCL refuses two ranks on one device)."""
+
+    def all_gather(self, out, mine, async_op=False):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        super().all_gather(o, mine.cpu())
+        out.copy_(o)
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        super().reduce_scatter(o, inp.cpu())
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        super().all_reduce(c, op)
+        t.copy_(c)
+
+    def all_gather_list(self, parts, mine):
+        cp = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        dist.all_gather(cp, mine.cpu(), group=self.group)
+        for p, c in zip(parts, cp):
+            p.copy_(c)
+
+
+class OwnerComputesTrainer:
+    def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
+                 seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
+                 exclusive_rows: bool = True, chunks: int = 1):
+        self.backend = backend or OcHipBackend()
+        self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
+        if comm is None:
+            comm = OcComm() if (self.device.type == "cuda" or not dist.is_initialized()) else OcGlooComm()
+        self.comm = comm
+        self.rank, self.world, self.lr = rank, world, float(lr)
+        self.dim = ent0.shape[1]
+        self.stride = _lib.stride_for(self.dim)
+        self.N = int(neg_per_pos)
+        if not 0 < self.N <= 64:
+            raise _lib.MultiKEHipError("the sharded relation view needs 1..64 negatives per positive")
+        self.n_ent = ent0.shape[0]
+        self.batch_size = int(batch_size)
+        self.chunks = max(1, int(chunks))
+        dev, st = self.device, self.stride
+        i32 = dict(dtype=torch.int32, device=dev)
+        # --- row-sharded entity state ---------------------------------------------------------------
+        mine = np.arange(rank, self.n_ent, world)
+        self.n_local = len(mine)
+        self.ent = torch.zeros(max(1, self.n_local), st, dtype=dtype, device=dev)
+        self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
+        self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)
+        self.ent_grad = torch.zeros_like(self.ent)
+        self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
+        self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
+        # --- replicated relation state --------------------------------------------------------------
+        self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
+        self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
+        self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
+        self.rel_grad = torch.zeros_like(self.rel)
+        self.rel_touched = torch.zeros(rel0.shape[0], **i32)
+        # --- global epoch order (identical on every rank: same seed) ----------------------------------
+        sides = []
+        for k in (0, 1):
+            t = torch.as_tensor(np.asarray(kgs.triples[k], dtype=np.int32), device=dev)
+            known = self.backend.make_known(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
+            sides.append(KGSide(kgs.entities(k), known, device=dev))
+        self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
+                                   device=dev, seed=seed)
+        self.steps = self.bat.steps
+        self.tag = 0
+        self.loss_ring = torch.zeros(max(1, self.steps) * self.chunks, _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
+        self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
+        self.C = 0
+        self._dtype = dtype
+        self._planned_epoch = -1
+        self._stepped = -1
+        self._plan_epoch()
+
+    # ------------------------------------------------------------------------------------------------
+    def parts_of_step(self, s: int):
+        """[(lo, hi)] epoch-position ranges of the `chunks` parts of global step s (contiguous, ceil split; empty parts
+        are dropped)."""
+        lo, hi = int(self.bat.off[s]), int(self.bat.off[s + 1])
+        if hi <= lo:
+            return []
+        size = int(math.ceil((hi - lo) / self.chunks))
+        return [(a, min(hi, a + size)) for a in range(lo, hi, size)]
+
+    def my_slice(self, lo: int, hi: int):
+        """(per, a, e): positives per home rank in [lo, hi) and this rank's contiguous share [a, e)."""
+        per = max(1, int(math.ceil((hi - lo) / self.world)))
+        a = min(hi, lo + self.rank * per)
+        return per, a, min(hi, a + per)
+
+    def _plan_epoch(self):
+        """Everything of an epoch that does not depend on the tables: this rank's negatives (one sampler launch), the
+        slot of every positive's HR / RT vector in its owner's block, the lists of owned positives per part, and the exact
+        capacity the epoch needs.  Integer work on the replicated epoch order: identical on every rank."""
+        b, G, dev = self.bat, self.world, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        parts = [(s, lo, hi) for s in range(self.steps) for (lo, hi) in self.parts_of_step(s)]
+        self._parts = parts
+        n_all = int(b.off[-1]) if self.steps else 0
+        # -- own negatives of the whole epoch (one sampler launch), packed as codes, all-gathered once ------------------
+        def slice_of(g, lo, hi):
+            per = max(1, int(math.ceil((hi - lo) / G)))
+            a = min(hi, lo + g * per)
+            return per, a, min(hi, a + per)
+        sl = [self.my_slice(lo, hi) for (_, lo, hi) in parts]
+        loc_off = np.zeros((G, len(parts) + 1), dtype=np.int64)     # every rank's prefix of slice sizes (all ranks agree)
+        for g in range(G):
+            loc_off[g, 1:] = np.cumsum([e - a for (_, a, e) in (slice_of(g, lo, hi) for (_, lo, hi) in parts)]) if parts else 0
+        self._loc_off = loc_off
+        idx = np.concatenate([np.arange(a, e, dtype=np.int32) for (_, a, e) in sl]) if parts else np.zeros(0, np.int32)
+        eidx = torch.as_tensor(idx, device=dev)
+        n_loc = int(loc_off[self.rank, -1])
+        per_rank = max(1, int(loc_off[:, -1].max()) * self.N)      # codes per rank in the gathered buffer (padded to the largest)
+        self._codes_per_rank = per_rank
+        mine = torch.zeros(per_rank, **i32)
+        if n_loc:
+            il = eidx.long()
+            neg = tuple(torch.empty(n_loc * self.N, **i32) for _ in range(3))
+            ph = b.pos_h[il]
+            self.backend.sample_at((ph, b.pos_r[il], b.pos_t[il]), eidx, b.pos_kg[il], b.side1, b.side2, self.N,
+                                   b.rng_seed, b.rng_stream, neg)
+            self.backend.pack_codes(ph, neg[0], neg[2], self.N, mine[:n_loc * self.N])
+        if G == 1:
+            self._codes = mine
+        else:
+            self._codes = torch.empty(G * per_rank, **i32)
+            self.comm.all_gather(self._codes, mine)
+        # -- slots: rank of a positive among the positives of its part whose head (tail) has the same owner ---------
+        part_id = torch.zeros(max(1, n_all), dtype=torch.int64, device=dev)
+        for k, (_, lo, hi) in enumerate(parts):
+            part_id[lo:hi] = k
+        self._slot, self._own, self._own_off = [], [], []
+        worst = 0
+        for ids in (b.pos_h, b.pos_t):
+            if n_all == 0:
+                self._slot.append(torch.zeros(1, **i32)); self._own.append(torch.zeros(1, **i32))
+                self._own_off.append(np.zeros(len(parts) + 1, dtype=np.int64))
+                continue
+            key = part_id[:n_all] * G + (ids[:n_all].long() % G)
+            order = torch.argsort(key, stable=True)
+            ks = key[order]
+            counts = torch.bincount(ks, minlength=len(parts) * G)
+            start = torch.cumsum(counts, 0) - counts
+            slot = torch.empty(n_all, dtype=torch.int64, device=dev)
+            slot[order] = torch.arange(n_all, device=dev) - start[ks]
+            self._slot.append(slot.to(torch.int32))
+            cnt = counts.view(len(parts), G).cpu().numpy()
+            worst = max(worst, int(cnt.max()))
+            # owned positives (as positions inside their part), in slot order, for every part: the sorted order restricted
+            # to this rank's keys is exactly that
+            mine = ks % G == self.rank
+            own_pos = order[mine]
+            lo_of = torch.as_tensor(np.array([lo for (_, lo, _) in parts], dtype=np.int64), device=dev)
+            self._own.append((own_pos - lo_of[part_id[own_pos]]).to(torch.int32))
+            off = np.zeros(len(parts) + 1, dtype=np.int64)
+            off[1:] = np.cumsum(cnt[:, self.rank])
+            self._own_off.append(off)
+        # -- capacity: exact for this epoch, buffers only ever grow ----------------------------------------
+        need = max(worst, 1)
+        if need > self.C:
+            self.C = int(need * 1.05) + 16
+            self.block = int(self.backend.block_elems(self.C, self.stride))
+            gb = 2 * self.C * self.stride
+            mk = lambda n: torch.zeros(n, dtype=self._dtype, device=dev)
+            self._send = [mk(self.block) for _ in range(self.chunks)]
+            self._v_all = [self._send[c] if G == 1 else mk(G * self.block) for c in range(self.chunks)]
+            self._g_all = [mk(G * gb) for _ in range(self.chunks)]
+            self._gv = [self._g_all[c] if G == 1 else mk(gb) for c in range(self.chunks)]
+        self._planned_epoch = b.epoch
+
+    def global_scored(self, i: int) -> int:
+        s = i % self.steps
+        return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
+
+    def _part_step(self, k: int, tag: int) -> OcStep:
+        _, lo, hi = self._parts[k]
+        b = self.bat
+        per, _, _ = self.my_slice(lo, hi)
+        oh, ot = self._own_off[0], self._own_off[1]
+        code_off = tuple(g * self._codes_per_rank + int(self._loc_off[g, k]) * self.N for g in range(self.world))
+        return OcStep(b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi], per, self._slot[0][lo:hi], self._slot[1][lo:hi],
+                      self._own[0][oh[k]:oh[k + 1]], self._own[1][ot[k]:ot[k + 1]], tag, self._codes, code_off)
+
+    def step(self, i: int):
+        """Global step i (steps must be issued in order)."""
+        s = i % self.steps
+        if s == 0 and i > 0:
+            self.bat.shuffle()                               # random.shuffle of both lists at the epoch boundary
+            self._plan_epoch()
+        be, G, cm = self.backend, self.world, self.comm
+        ks = [k for k, (ps, _, _) in enumerate(self._parts) if ps == s]
+        self.tag += 1
+        tag = self.tag
+        pipelined = len(ks) > 1 and G > 1 and self.device.type == "cuda"
+        sts, works = [], {}
+        # ---- HR / RT vectors of every part, all-gathered (asynchronously when pipelining) -------------------------
+        for c, k in enumerate(ks):
+            st = self._part_step(k, tag)
+            sts.append(st)
+            be.bases(self, st, self._send[c])
+            if G > 1:
+                works[("ag", c)] = cm.all_gather(self._v_all[c], self._send[c], async_op=pipelined)
+        # ---- reference counts over the WHOLE global step (all parts) before any part is scored: they need only the
+        #      epoch's codes, so this runs while the all-gathers are on the wire ----------------------------------
+        if self.ref_count is not None:
+            for st in sts:
+                be.count(self, st)
+        # ---- score part c while part c+1's all-gather / part c-1's reduce-scatter are on the wire ------------------
+        for c, (k, st) in enumerate(zip(ks, sts)):
+            if works.get(("ag", c)) is not None:
+                works[("ag", c)].wait()
+            ev = self.score_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            be.score(self, st, self._v_all[c], self._g_all[c], self.loss_ring[s * self.chunks + c])
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1, st.pos_h.numel() * (1 + self.N) // G))
+            if G > 1:
+                works[("rs", c)] = cm.reduce_scatter(self._gv[c], self._g_all[c], async_op=pipelined)
+        for c, st in enumerate(sts):
+            if works.get(("rs", c)) is not None:
+                works[("rs", c)].wait()
+            be.apply(self, st, self._gv[c])
+        # ---- replicated relation table: all-reduce the (small) dense gradient; one update of everything ---------------
+        if G > 1:
+            cm.all_reduce(self.rel_grad)
+        be.update(self, tag)
+        self._stepped = i
+
+    # ------------------------------------------------------------------------------------------------
+    def check(self) -> dict:
+        """Capacity is fixed per epoch from the data before the epoch runs (`_plan_epoch`): nothing to flag."""
+        return {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks}
+
+    def gather_entity_table(self) -> torch.Tensor:
+        """Reassemble the full [n_ent, dim] raw table on every rank (tests / checkpoint)."""
+        pad = int(math.ceil(self.n_ent / self.world))
+        mine = torch.zeros(pad, self.stride, dtype=self.ent.dtype, device=self.device)
+        mine[:self.n_local] = self.ent[:self.n_local]
+        if self.world == 1:
+            return mine[:self.n_local, :self.dim].clone()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.comm.all_gather_list(parts, mine)
+        full = torch.zeros(self.n_ent, self.dim, dtype=self.ent.dtype, device=self.device)
+        for r in range(self.world):
+            n = len(range(r, self.n_ent, self.world))
+            full[r::self.world] = parts[r][:n, :self.dim]
+        return full
+
+    def epoch_loss(self) -> float:
+        t = self.loss_ring.sum()
+        if self.world > 1:
+            self.comm.all_reduce(t)
+        self.loss_ring.zero_()
+        return float(t)

@@ -138,3 +138,138 @@ class OracleBackend:
         a[rows] += gg * gg
         w[rows] -= lr * gg / np.sqrt(a[rows])
         g[rows] = 0
+
+
+class OcOracleBackend(OracleBackend):
+    """NumPy restatement of the owner-computes kernels (mke_oc.hip: pack_codes / bases / count / score / apply) and of the
+    row update, float64 — the CPU backend of `multike_amd.distributed_oc.OwnerComputesTrainer` under gloo.  Same block
+    layout as the device: [capacity] HR vectors | [capacity] RT vectors, rows of `stride` elements."""
+
+    EPS = 1e-12
+
+    def block_elems(self, capacity, stride):
+        return 2 * capacity * stride
+
+    def pack_codes(self, pos_h, neg_h, neg_t, neg_per_pos, codes):
+        ph = np.repeat(pos_h.numpy(), neg_per_pos)
+        nh, nt = neg_h.numpy(), neg_t.numpy()
+        codes.numpy()[:] = np.where(nh != ph, (nh << 1) | 1, nt << 1)
+
+    @classmethod
+    def _nrm(cls, x):
+        return x / np.sqrt(np.maximum((x * x).sum(-1, keepdims=True), cls.EPS))
+
+    def bases(self, tr, st, send):
+        G, C, S, d = tr.world, tr.C, tr.stride, tr.dim
+        ent, rel = tr.ent.numpy()[:, :d], tr.rel.numpy()[:, :d]
+        out = send.numpy().reshape(2 * C, S)
+        ph, pr, pt = st.pos_h.numpy(), st.pos_r.numpy(), st.pos_t.numpy()
+        oh, ot = st.own_h.numpy(), st.own_t.numpy()
+        out[:len(oh), :d] = self._nrm(ent[ph[oh] // G]) + self._nrm(rel[pr[oh]])
+        out[C:C + len(ot), :d] = self._nrm(rel[pr[ot]]) - self._nrm(ent[pt[ot] // G])
+
+    def _codes_of(self, tr, st):
+        """[n_pos, N] codes of the part, assembled from every home rank's run."""
+        n, N = st.pos_h.numel(), tr.N
+        cd = st.codes.numpy()
+        out = np.zeros((n, N), dtype=np.int64)
+        for g, off in enumerate(st.code_off):
+            a, e = g * st.per, min(n, (g + 1) * st.per)
+            if e > a:
+                out[a:e] = cd[off:off + (e - a) * N].reshape(e - a, N)
+        return out
+
+    def count(self, tr, st):
+        G = tr.world
+        rc = tr.ref_count.numpy()
+        c = self._codes_of(tr, st).reshape(-1) >> 1
+        np.add.at(rc, c[c % G == tr.rank] // G, 1)
+        np.add.at(rc, st.pos_h.numpy()[st.own_h.numpy()] // G, 1)
+        np.add.at(rc, st.pos_t.numpy()[st.own_t.numpy()] // G, 1)
+
+    def _row_update(self, w, a, g, lr):
+        """Jacobian of the normalisation + Adagrad on one raw row (in place)."""
+        s = float((w * w).sum())
+        inv = 1.0 / np.sqrt(max(s, self.EPS))
+        gg = (g - w * ((w * g).sum() * inv * inv if s > self.EPS else 0.0)) * inv
+        a += gg * gg
+        w -= lr * gg / np.sqrt(a)
+
+    def score(self, tr, st, v_all, g_all, loss_partials):
+        G, C, S, d, N, rank = tr.world, tr.C, tr.stride, tr.dim, tr.N, tr.rank
+        V = v_all.numpy().reshape(G, 2 * C, S)
+        Gout = g_all.numpy().reshape(G, 2 * C, S)
+        ent, acc, eg = tr.ent.numpy(), tr.ent_acc.numpy(), tr.ent_grad.numpy()
+        rel, rg = tr.rel.numpy(), tr.rel_grad.numpy()
+        te, trl = tr.ent_touched.numpy(), tr.rel_touched.numpy()
+        rc = tr.ref_count.numpy() if tr.ref_count is not None else None
+        ph, pr, pt = st.pos_h.numpy(), st.pos_r.numpy(), st.pos_t.numpy()
+        sh, stt = st.slot_h.numpy(), st.slot_t.numpy()
+        codes = self._codes_of(tr, st)
+        loss = 0.0
+        for i in range(len(ph)):
+            HR, RT = V[ph[i] % G, sh[i], :d], V[pt[i] % G, C + stt[i], :d]
+            gHR, gRT = np.zeros(d), np.zeros(d)
+            if i // st.per == rank:
+                dv = HR + RT - self._nrm(rel[pr[i], :d])
+                x = float(dv @ dv)
+                loss += np.log1p(np.exp(x))
+                g = 2.0 / (1.0 + np.exp(-x)) * dv
+                gHR += g
+                gRT += g
+                rg[pr[i], :d] -= g
+                trl[pr[i]] = st.tag
+            for cd in codes[i]:
+                c, head = int(cd) >> 1, int(cd) & 1
+                if c % G != rank:
+                    continue
+                row = c // G
+                ch = self._nrm(ent[row, :d])
+                dv = ch + RT if head else HR - ch
+                y = float(dv @ dv)
+                loss += np.log1p(np.exp(-y))
+                g = -2.0 / (1.0 + np.exp(y)) * dv
+                if head:
+                    gRT += g
+                else:
+                    gHR += g
+                gc = g if head else -g
+                if rc is not None and rc[row] == 1:
+                    self._row_update(ent[row, :d], acc[row, :d], gc, tr.lr)
+                    rc[row] = 0
+                else:
+                    eg[row, :d] += gc
+                    te[row] = st.tag
+            Gout[ph[i] % G, sh[i], :] = 0
+            Gout[pt[i] % G, C + stt[i], :] = 0
+            Gout[ph[i] % G, sh[i], :d] = gHR
+            Gout[pt[i] % G, C + stt[i], :d] = gRT
+        lp = loss_partials.numpy()
+        lp[:] = 0
+        lp[0] = loss
+
+    def apply(self, tr, st, gv):
+        G, C, S, d = tr.world, tr.C, tr.stride, tr.dim
+        g = gv.numpy().reshape(2 * C, S)
+        eg, rg = tr.ent_grad.numpy(), tr.rel_grad.numpy()
+        te, trl = tr.ent_touched.numpy(), tr.rel_touched.numpy()
+        ph, pr, pt = st.pos_h.numpy(), st.pos_r.numpy(), st.pos_t.numpy()
+        for k, pos in enumerate(st.own_h.numpy()):
+            eg[ph[pos] // G, :d] += g[k, :d]
+            rg[pr[pos], :d] += g[k, :d]
+            te[ph[pos] // G] = trl[pr[pos]] = st.tag
+        for k, pos in enumerate(st.own_t.numpy()):
+            eg[pt[pos] // G, :d] -= g[C + k, :d]
+            rg[pr[pos], :d] += g[C + k, :d]
+            te[pt[pos] // G] = trl[pr[pos]] = st.tag
+
+    def update(self, tr, tag):
+        d = tr.dim
+        # relation table: every row (after the all-reduce a row may carry a gradient no local triple touched)
+        for w, a, g, t in ((tr.rel, tr.rel_acc, tr.rel_grad, None), (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched)):
+            wn, an, gn = w.numpy(), a.numpy(), g.numpy()
+            for row in (range(len(wn)) if t is None else np.nonzero(t.numpy() == tag)[0]):
+                self._row_update(wn[row, :d], an[row, :d], gn[row, :d].copy(), tr.lr)
+                gn[row] = 0
+                if w is tr.ent and tr.ref_count is not None:
+                    tr.ref_count.numpy()[row] = 0

@@ -46,7 +46,8 @@ def test_struct_layouts_match_header():
     from multike_amd import _lib
     h = _header()
     for cname, st in (("mke_kg_side", _lib.KGSideStruct), ("mke_update_table", _lib.UpdateTableStruct),
-                      ("mke_relation_plan", _lib.RelationPlanStruct)):
+                      ("mke_relation_plan", _lib.RelationPlanStruct), ("mke_oc_step", _lib.OcStepStruct),
+                      ("mke_ae_plan", _lib.AEPlanStruct)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), h, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -55,7 +56,7 @@ def test_struct_layouts_match_header():
             if not decl:
                 continue
             for part in decl.split(","):
-                names.append(re.search(r"(\w+)\s*(?:\[\d+\])?$", part.strip()).group(1))
+                names.append(re.search(r"(\w+)\s*(?:\[[^\]]*\])?$", part.strip()).group(1))
         assert names == [f[0] for f in st._fields_], (cname, names)
 
 

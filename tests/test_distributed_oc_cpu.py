@@ -1,0 +1,137 @@
+"""world_size 2 / 3 gloo runs of the owner-computes sharded trainer (multike_amd/distributed_oc.py) with the oracle as the
+compute backend: slots, per-epoch code exchange, ownership filtering, the all-gather / reduce-scatter / all-reduce
+sequence, split-batch chunks and the epoch boundary.  The sharded result must equal a single-process dense float64
+oracle run on the same global batches (every row updated once per step from the sum of all its contributions)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import c_oracle as co
+from oracle import multike_oracle as mo
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+N_REL, DIM, B, NEG, SEED = 12, 20, 64, 5, 7
+
+
+def _worker(rank, world, port, ret, n_ent, steps, chunks, excl):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OwnerComputesTrainer
+        from multike_amd.synthetic import SyntheticKGs
+        from oracle_backend import OcOracleBackend
+        kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+        rng = np.random.default_rng(SEED)
+        ent0 = mo.xavier_truncated_normal((n_ent, DIM), rng).astype(np.float64)
+        rel0 = mo.xavier_truncated_normal((N_REL, DIM), rng).astype(np.float64)
+        tr = OwnerComputesTrainer(kgs, ent0, rel0, B, NEG, rank, world, seed=SEED, lr=0.05, backend=OcOracleBackend(),
+                                  device="cpu", dtype=torch.float64, chunks=chunks, exclusive_rows=excl)
+        for i in range(steps):
+            tr.step(i)
+        full = tr.gather_entity_table().numpy()
+        assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0   # scratch consumed
+        assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
+        loss = tr.epoch_loss()
+        if rank == 0:
+            ret.put((full, tr.rel[:, :DIM].numpy().copy(), loss, tr.steps, tr.check()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(world, n_ent, steps):
+    """Single process, dense float64 oracle, same global batches (world * B positives per step), crossing epochs."""
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+    rng = np.random.default_rng(SEED)
+    e = mo.xavier_truncated_normal((n_ent, DIM), rng).astype(np.float64)
+    r = mo.xavier_truncated_normal((N_REL, DIM), rng).astype(np.float64)
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None, device="cpu"),
+                          KGSide(kgs.entities(1), None, device="cpu"), B * world, NEG, device="cpu", seed=SEED)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    losses = []
+    for i in range(steps):
+        s = i % bat.steps
+        if s == 0 and i > 0:
+            bat.shuffle()
+        ph, pr, pt = (x.numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        mid = lo + int(bat.cnt1[s])
+        parts = []
+        for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+            elo, ehi = kgs.ent_range[k]
+            parts.append(co.neg_sample(ph[a:b], pr[a:b], pt[a:b], NEG, ehi - elo, ent_lo=elo, known=sets[k], seed=bat.rng_seed,
+                                       stream_id=bat.rng_stream + k, pos_offset=a))
+        neg = [np.concatenate([parts[0][j], parts[1][j]]) for j in range(3)]
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, (ph[lo:hi], pr[lo:hi], pt[lo:hi]), neg, 0.05)
+        losses.append(L)
+    return e, r, losses, bat.steps
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n_ent,chunks,excl", [(2, 600, 1, True), (3, 602, 1, True), (2, 600, 3, True), (2, 600, 2, False)])
+def test_owner_computes_equals_single_process_oracle(world, n_ent, chunks, excl):
+    """world 3 with 602 entities: shards of unequal size, KG id ranges that do not fall on shard boundaries, ragged slices;
+    chunks 2 / 3: split-batch parts; steps run past the epoch boundary (shuffle + re-plan)."""
+    ref_e, ref_r, ref_losses, steps_per_epoch = _reference(world, n_ent, 1)   # steps per epoch only
+    steps = steps_per_epoch + 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n_ent, steps, chunks, excl)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss, tsteps, info = ret.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    e, r, losses, _ = _reference(world, n_ent, steps)
+    assert tsteps == steps_per_epoch
+    np.testing.assert_allclose(full, e, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rel, r, rtol=1e-9, atol=1e-12)
+    # the loss ring holds one slot per step of an epoch: steps 0 and 1 were overwritten by the second epoch's first two
+    np.testing.assert_allclose(loss, sum(losses[2:]), rtol=1e-11)
+    assert info["chunks"] == chunks and info["capacity_vectors_per_owner"] >= B * world // world // 2
+
+
+def test_parts_and_slices_partition_every_global_step():
+    """Parts are disjoint, ordered and cover each global step; rank slices partition each part — ragged last steps too."""
+    from multike_amd.distributed_oc import OwnerComputesTrainer
+
+    class Fake:
+        pass
+    for world in (2, 3, 8):
+        for chunks in (1, 2, 3):
+            t = Fake()
+            t.bat = Fake()
+            t.bat.off = np.array([0, 40, 80, 97, 97])
+            t.world, t.chunks = world, chunks
+            for s in range(4):
+                parts = OwnerComputesTrainer.parts_of_step(t, s)
+                cur = t.bat.off[s]
+                for lo, hi in parts:
+                    assert lo == cur and hi > lo
+                    c2 = lo
+                    for rank in range(world):
+                        t.rank = rank
+                        per, a, e = OwnerComputesTrainer.my_slice(t, lo, hi)
+                        assert a == min(c2, hi) and a <= e <= hi and e - a <= per
+                        c2 = e
+                    assert c2 == hi
+                    cur = hi
+                assert cur == t.bat.off[s + 1]

@@ -1,0 +1,148 @@
+"""The owner-computes sharded trainer with the HIP kernels (mke_oc.hip): one rank (no collectives: every entity is local),
+and two ranks SHARING the one GPU the test boxes have (collectives staged through gloo, `OcHostStagedComm`, because RCCL
+refuses two ranks on one device) — against the float64 dense oracle on the same global batches.  The exchange logic itself
+(slots, codes, chunks, epoch boundary) is covered under gloo in tests/test_distributed_oc_cpu.py; what is left unexercised
+is RCCL's own transport at G > 1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import multike_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+N_ENT, N_REL, DIM, B, NEG, SEED = 3000, 20, 75, 300, 8, 11
+
+
+def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+    rng = np.random.default_rng(SEED)
+    e = mo.xavier_truncated_normal((n_ent, dim), rng).astype(np.float32).astype(np.float64)
+    r = mo.xavier_truncated_normal((N_REL, dim), rng).astype(np.float32).astype(np.float64)
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None, device="cpu"),
+                          KGSide(kgs.entities(1), None, device="cpu"), b * world, neg, device="cpu", seed=SEED)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    losses = []
+    for i in range(steps):
+        s = i % bat.steps
+        if s == 0 and i > 0:
+            bat.shuffle()
+        ph, pr, pt = (x.numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        mid = lo + int(bat.cnt1[s])
+        parts = []
+        for k, (a, c) in enumerate(((lo, mid), (mid, hi))):
+            elo, ehi = kgs.ent_range[k]
+            parts.append(co.neg_sample(ph[a:c], pr[a:c], pt[a:c], neg, ehi - elo, ent_lo=elo, known=sets[k], seed=bat.rng_seed,
+                                       stream_id=bat.rng_stream + k, pos_offset=a))
+        nn = [np.concatenate([parts[0][j], parts[1][j]]) for j in range(3)]
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, (ph[lo:hi], pr[lo:hi], pt[lo:hi]), nn, 0.02)
+        losses.append(L)
+    return e, r, losses, bat.steps
+
+
+def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
+    from multike_amd.distributed_oc import OwnerComputesTrainer
+    from multike_amd.synthetic import SyntheticKGs
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+    rng = np.random.default_rng(SEED)
+    ent0 = mo.xavier_truncated_normal((n_ent, dim), rng)
+    rel0 = mo.xavier_truncated_normal((N_REL, dim), rng)
+    return OwnerComputesTrainer(kgs, ent0, rel0, b, neg, rank, world, seed=SEED, lr=0.02, comm=comm, chunks=chunks,
+                                exclusive_rows=excl)
+
+
+@pytest.mark.parametrize("chunks,excl,dim,neg", [(1, True, 75, 8), (2, True, 75, 25), (1, False, 75, 8), (1, True, 256, 64),
+                                                  (3, True, 20, 1)])
+def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg):
+    """G = 1: every vector / code / gradient slot is local; the kernels alone against the oracle, past an epoch boundary."""
+    n_ent = 3000 if dim < 256 else 1200
+    _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
+    steps = spe + 2
+    tr = _make(0, 1, chunks=chunks, excl=excl, n_ent=n_ent, dim=dim, neg=neg)
+    for i in range(steps):
+        tr.step(i)
+    e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses[2:]), rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+    assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
+    assert float(tr.ent[:, dim:].abs().max()) == 0.0 if tr.stride > dim else True
+
+
+def _two_rank_worker(rank, world, port, ret, chunks, steps):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OcHostStagedComm
+        torch.cuda.set_device(0)
+        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks)
+        for i in range(steps):
+            tr.step(i)
+        full = tr.gather_entity_table().cpu().numpy()
+        ok = float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+        loss = tr.epoch_loss()
+        if rank == 0:
+            ret.put((full, tr.rel[:, :DIM].cpu().numpy().copy(), loss, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks):
+    """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
+    negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world, steps = 2, 7
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss, ok = ret.get(timeout=480)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    e, r, losses, spe = _reference(world, steps)
+    assert steps <= spe and ok
+    np.testing.assert_allclose(loss, sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
+
+
+def test_one_rank_rccl_collectives_run():
+    """1-rank RCCL group: the trainer's own communicator class (all_gather_into_tensor / reduce_scatter_tensor / all_reduce)
+    is importable and the G = 1 short-cuts leave it untouched."""
+    import torch.distributed as dist
+    from multike_amd.distributed_oc import OcComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("MASTER_PORT", "29655")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cm = OcComm()
+        a = torch.arange(8, dtype=torch.float32, device="cuda")
+        o = torch.empty(8, device="cuda")
+        cm.all_gather(o, a)
+        assert torch.equal(o, a)
+        cm.reduce_scatter(o, a)
+        assert torch.equal(o, a)
+        w = cm.all_gather(o, a, async_op=True)
+        w.wait()
+        cm.all_reduce(a)
+        tr = _make(0, 1, comm=cm)
+        tr.step(0)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
