@@ -302,9 +302,18 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
-        trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, comm=HostStagedComm() if staged else None)
-        trainer.bat.shuffle()
+        # MKE_SHARD_MODE=oc (default): owner-computes step (multike_amd/distributed_oc.py: the negatives go to the rows, 2
+        # vectors per positive cross the links); =rowfetch: round 1's row-exchange step (multike_amd/distributed.py)
+        shard_mode = os.environ.get("MKE_SHARD_MODE", "oc")
+        if shard_mode == "rowfetch":
+            from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
+            trainer = ShardedRelationTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, comm=HostStagedComm() if staged else None)
+            trainer.bat.shuffle()
+        else:
+            from multike_amd.distributed_oc import OcHostStagedComm, OwnerComputesTrainer
+            chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 else "1"))
+            trainer = OwnerComputesTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, chunks=chunks,
+                                           comm=OcHostStagedComm() if staged else None)
         run_step = trainer.step
         n_steps_epoch = trainer.steps
         triples_of = trainer.global_scored

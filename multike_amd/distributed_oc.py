@@ -9,9 +9,10 @@ The reference has no multi-device code; this is new design.  One process per GPU
   * rows never leave their owner.  A negative differs from its positive (h, r, t) in one entity c and its score needs only
     c's row and one of two vectors of the positive — HR_p = h^ + r^ (corrupted tail: d = HR_p - c^) or RT_p = r^ - t^
     (corrupted head: d = c^ + RT_p) — so the NEGATIVES go to the rows.  Per global step:
-        owner of h_p builds HR_p, owner of t_p builds RT_p;  own negatives packed as (entity, side) codes   [mke_oc_bases]
-        ALL-GATHER of the blocks (2 vectors per positive + 4 bytes per negative)
-        reference counts of the own rows over the whole global step                                        [mke_oc_count]
+        (once per epoch: every rank packs its own positives' negatives as (entity, side) codes; one all-gather of them)
+        owner of h_p builds HR_p, owner of t_p builds RT_p                                                  [mke_oc_bases]
+        ALL-GATHER of the blocks (2 vectors per positive)
+        reference counts of the own rows over the whole global step (needs only the codes)                 [mke_oc_count]
         every rank scores, for ALL world x batch positives, the negatives whose corrupt entity it owns: corrupt-row
         gradient applied locally (in place when referenced once, else scattered), partial dL/dHR_p, dL/dRT_p written into
         the slot the vector came from; the home rank adds the positive's own term                          [mke_oc_score]
@@ -59,6 +60,7 @@ class OcStep:
     tag: int
     codes: torch.Tensor = None      # the epoch's negative codes of every rank, [world][codes_per_rank]
     code_off: tuple = ()            # per home rank: offset of its codes of this part inside `codes`
+    native: object = None           # backend-private cache (the ctypes mke_oc_step of the HIP backend)
 
 
 class OcHipBackend:
@@ -100,17 +102,25 @@ class OcHipBackend:
         s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, 1.0, st.tag
         return s
 
+    def _cached(self, tr, st):
+        """The part's mke_oc_step is built once per epoch (st.native) and only re-tagged per step."""
+        s = st.native
+        if s is None:
+            s = st.native = self._struct(tr, st)
+        s.tag = st.tag
+        return s
+
     def bases(self, tr, st, send):
-        _lib.oc_bases(self._struct(tr, st), send)
+        _lib.oc_bases(self._cached(tr, st), send)
 
     def count(self, tr, st):
-        _lib.oc_count(self._struct(tr, st))
+        _lib.oc_count(self._cached(tr, st))
 
     def score(self, tr, st, v_all, g_all, loss_partials):
-        _lib.oc_score(self._struct(tr, st), v_all, tr.block, g_all, loss_partials)
+        _lib.oc_score(self._cached(tr, st), v_all, tr.block, g_all, loss_partials)
 
     def apply(self, tr, st, gv):
-        _lib.oc_apply(self._struct(tr, st), gv)
+        _lib.oc_apply(self._cached(tr, st), gv)
 
     def update(self, tr, tag):
         # relation table: EVERY row (touched = None) — after the all-reduce a row may carry a gradient no local triple touched
@@ -327,12 +337,24 @@ class OwnerComputesTrainer:
             self._g_all = [mk(G * gb) for _ in range(self.chunks)]
             self._gv = [self._g_all[c] if G == 1 else mk(gb) for c in range(self.chunks)]
         self._planned_epoch = b.epoch
+        self._st_cache = {}
+        self._parts_of = {}
+        for k, (ps, _, _) in enumerate(parts):
+            self._parts_of.setdefault(ps, []).append(k)
 
     def global_scored(self, i: int) -> int:
         s = i % self.steps
         return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
 
     def _part_step(self, k: int, tag: int) -> OcStep:
+        st = self._st_cache.get(k)
+        if st is not None:
+            st.tag = tag
+            return st
+        st = self._st_cache[k] = self._build_part_step(k, tag)
+        return st
+
+    def _build_part_step(self, k: int, tag: int) -> OcStep:
         _, lo, hi = self._parts[k]
         b = self.bat
         per, _, _ = self.my_slice(lo, hi)
@@ -348,7 +370,7 @@ class OwnerComputesTrainer:
             self.bat.shuffle()                               # random.shuffle of both lists at the epoch boundary
             self._plan_epoch()
         be, G, cm = self.backend, self.world, self.comm
-        ks = [k for k, (ps, _, _) in enumerate(self._parts) if ps == s]
+        ks = self._parts_of.get(s, [])
         self.tag += 1
         tag = self.tag
         pipelined = len(ks) > 1 and G > 1 and self.device.type == "cuda"
