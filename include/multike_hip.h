@@ -665,7 +665,8 @@ int mke_dense_layer_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw
 typedef struct mke_oc_step {
   float* ent; float* ent_acc /*nullable: SGD*/; float* ent_grad; int32_t* ent_touched; int32_t* ref_count /*nullable*/;
   int64_t n_local;
-  const float* rel; float* rel_grad; int rel_grad_copies; int32_t* rel_touched; int64_t n_rel;
+  const float* rel; float* rel_acc /*mke_oc_run's update only*/; float* rel_grad; int rel_grad_copies; int32_t* rel_touched;
+  int64_t n_rel;
   int stride, dim, rank, n_ranks;
   const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t;   /* [n_pos], GLOBAL entity ids */
   int64_t n_pos, per;
@@ -684,6 +685,14 @@ int mke_oc_count(const mke_oc_step* step, void* stream);
 int mke_oc_score(const mke_oc_step* step, const float* v_all, int64_t block_floats, float* g_all,
                  double* loss_partials /* [MKE_LOSS_PARTIALS] */, void* stream);
 int mke_oc_apply(const mke_oc_step* step, const float* gv, void* stream);
+/* the phases selected by the bit mask, in the order above, in one call (what lies between two collectives): */
+#define MKE_OC_BASES 1
+#define MKE_OC_COUNT 2
+#define MKE_OC_SCORE 4
+#define MKE_OC_APPLY 8
+#define MKE_OC_UPDATE 16   /* mke_rows_update_multi: relation table (every row) + the shard's touched rows */
+int mke_oc_run(const mke_oc_step* step, int phases, float* send_block, const float* v_all, int64_t block_floats, float* g_all,
+               const float* gv, double* loss_partials, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ SYMBOLS = (
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
-    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply",
+    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -91,7 +91,7 @@ class OcStepStruct(C.Structure):
     """mke_oc_step"""
     _fields_ = [("ent", C.c_void_p), ("ent_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("ent_touched", C.c_void_p),
                 ("ref_count", C.c_void_p), ("n_local", C.c_int64),
-                ("rel", C.c_void_p), ("rel_grad", C.c_void_p), ("rel_grad_copies", C.c_int), ("rel_touched", C.c_void_p),
+                ("rel", C.c_void_p), ("rel_acc", C.c_void_p), ("rel_grad", C.c_void_p), ("rel_grad_copies", C.c_int), ("rel_touched", C.c_void_p),
                 ("n_rel", C.c_int64), ("stride", C.c_int), ("dim", C.c_int), ("rank", C.c_int), ("n_ranks", C.c_int),
                 ("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("n_pos", C.c_int64), ("per", C.c_int64),
                 ("slot_h", C.c_void_p), ("slot_t", C.c_void_p), ("own_h", C.c_void_p), ("n_own_h", C.c_int64),
@@ -646,6 +646,16 @@ def oc_score(step: OcStepStruct, v_all, block_floats: int, g_all, loss_partials)
 def oc_apply(step: OcStepStruct, gv):
     rc = lib().mke_oc_apply(C.byref(step), _dev(gv, torch.float32, "gv"), _stream())
     _check(rc, "mke_oc_apply")
+
+
+OC_BASES, OC_COUNT, OC_SCORE, OC_APPLY, OC_UPDATE = 1, 2, 4, 8, 16
+
+
+def oc_run(step: OcStepStruct, phases: int, send, v_all, block_floats: int, g_all, gv, loss_partials):
+    """mke_oc_run with RAW device addresses (ints / None) — the caller validated the tensors once per epoch."""
+    rc = lib().mke_oc_run(C.byref(step), C.c_int(phases), C.c_void_p(send), C.c_void_p(v_all), C.c_int64(block_floats),
+                          C.c_void_p(g_all), C.c_void_p(gv), C.c_void_p(loss_partials), _stream())
+    _check(rc, "mke_oc_run")
 
 
 def ae_scratch_floats(plan: AEPlanStruct, rows: int) -> int:

@@ -372,3 +372,32 @@ extern "C" int mke_oc_apply(const mke_oc_step* s, const float* gv, void* stream)
   });
   return check_launch("k_oc_apply");
 }
+
+namespace mke {
+int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
+                             float lr, hipStream_t st, const mke_count_job* count, const struct DenseJob* dense);
+}
+
+// Several phases of one part's step in ONE call (host overhead: the step is 5 launches of 5-50 us each): bit 0 bases, 1 count,
+// 2 score, 3 apply, 4 the row update (relation table: every row; shard: touched rows).  What lies between two collectives
+// goes into one call: single rank: 31;  G > 1: 1 | all-gather | 6 | reduce-scatter | 8 | all-reduce | 16.
+extern "C" int mke_oc_run(const mke_oc_step* s, int phases, float* send_block, const float* v_all, int64_t block_floats, float* g_all,
+                          const float* gv, double* loss_partials, void* stream) {
+  using namespace mke;
+  int rc = MKE_OK;
+  if ((phases & MKE_OC_BASES) && (rc = mke_oc_bases(s, send_block, stream))) return rc;
+  if ((phases & MKE_OC_COUNT) && (rc = mke_oc_count(s, stream))) return rc;
+  if ((phases & MKE_OC_SCORE) && (rc = mke_oc_score(s, v_all, block_floats, g_all, loss_partials, stream))) return rc;
+  if ((phases & MKE_OC_APPLY) && (rc = mke_oc_apply(s, gv, stream))) return rc;
+  if (phases & MKE_OC_UPDATE) {
+    if ((rc = oc_check(s, "mke_oc_run"))) return rc;
+    if (s->optimizer == MKE_OPT_ADAGRAD && (!s->ent_acc || !s->rel_acc)) { set_error("mke_oc_run: Adagrad needs ent_acc and rel_acc"); return MKE_E_NULL; }
+    mke_update_table ut[2] = {};
+    ut[0].table = const_cast<float*>(s->rel); ut[0].acc = s->rel_acc; ut[0].grad = s->rel_grad; ut[0].touched = nullptr;
+    ut[0].n_rows = s->n_rel; ut[0].normalize = 1; ut[0].grad_copies = s->rel_grad_copies;
+    ut[1].table = s->ent; ut[1].acc = s->ent_acc; ut[1].grad = s->ent_grad; ut[1].touched = s->ent_touched;
+    ut[1].n_rows = s->n_local; ut[1].normalize = 1; ut[1].grad_copies = 1; ut[1].ref_count = s->ref_count;
+    if ((rc = launch_rows_update_multi(ut, 2, s->tag, s->stride, s->dim, s->optimizer, s->lr, (hipStream_t)stream, nullptr, nullptr))) return rc;
+  }
+  return MKE_OK;
+}

@@ -35,6 +35,7 @@ built on the oracle to exercise this logic under `gloo`.
 from __future__ import annotations
 
 import math
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
@@ -88,6 +89,7 @@ class OcHipBackend:
         s.ref_count = _lib.ptr(tr.ref_count, i32, "ref_count") if tr.ref_count is not None else None
         s.n_local = tr.n_local
         s.rel, s.rel_grad, s.rel_grad_copies = _lib.ptr(tr.rel, f32, "rel"), _lib.ptr(tr.rel_grad, f32, "rel_grad"), 1
+        s.rel_acc = _lib.ptr(tr.rel_acc, f32, "rel_acc")
         s.rel_touched, s.n_rel = _lib.ptr(tr.rel_touched, i32, "rel_touched"), tr.rel.shape[0]
         s.stride, s.dim, s.rank, s.n_ranks = tr.stride, tr.dim, tr.rank, tr.world
         s.pos_h, s.pos_r, s.pos_t = (_lib.ptr(x, i32, "pos") for x in (st.pos_h, st.pos_r, st.pos_t))
@@ -110,6 +112,40 @@ class OcHipBackend:
         s.tag = st.tag
         return s
 
+    def prepare_epoch(self, tr):
+        """One mke_oc_step per part of the epoch, from raw device addresses (the epoch buffers are persistent: positives,
+        slots, owned lists keep their addresses; only the owned-list offsets change from epoch to epoch) — no tensor
+        slicing and no struct building on the step path."""
+        i32 = torch.int32
+        b = tr.bat
+        if not tr._parts:
+            self._steps = []
+            return
+        oh, ot = _lib.ptr(tr._own[0], i32, "own"), _lib.ptr(tr._own[1], i32, "own")
+        key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts))
+        if getattr(self, "_steps_key", None) != key:      # first epoch, or a buffer was re-allocated: build the static part
+            base = self._struct(tr, tr._build_part_step(0, 0))
+            ph, pr, pt = (_lib.ptr(x, i32, "pos") for x in (b.pos_h, b.pos_r, b.pos_t))
+            sh, stt = _lib.ptr(tr._slot[0], i32, "slot"), _lib.ptr(tr._slot[1], i32, "slot")
+            out = []
+            for k, (_, lo, hi) in enumerate(tr._parts):
+                s = _lib.OcStepStruct()
+                C.memmove(C.byref(s), C.byref(base), C.sizeof(s))
+                s.pos_h, s.pos_r, s.pos_t = ph + 4 * lo, pr + 4 * lo, pt + 4 * lo
+                s.slot_h, s.slot_t = sh + 4 * lo, stt + 4 * lo
+                s.n_pos = hi - lo
+                s.per = max(1, -(-(hi - lo) // tr.world))
+                for g in range(tr.world):
+                    s.code_off[g] = g * tr._codes_per_rank + int(tr._loc_off[g, k]) * tr.N
+                out.append(s)
+            self._steps, self._steps_key = out, key
+            self._ring = tr.loss_ring.data_ptr()
+            self._ring_stride = tr.loss_ring.shape[1] * 8
+        offh, offt = (x.tolist() for x in tr._own_off)
+        for k, s in enumerate(self._steps):
+            s.own_h, s.n_own_h = oh + 4 * offh[k], offh[k + 1] - offh[k]
+            s.own_t, s.n_own_t = ot + 4 * offt[k], offt[k + 1] - offt[k]
+
     def bases(self, tr, st, send):
         _lib.oc_bases(self._cached(tr, st), send)
 
@@ -127,6 +163,17 @@ class OcHipBackend:
         _lib.rows_update_multi([(tr.rel, tr.rel_acc, tr.rel_grad, None, True),
                                 (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched, True, tr.ref_count)],
                                tag, tr.stride, tr.dim, _lib.OPT_ADAGRAD, tr.lr)
+
+    def run(self, tr, k, tag, phases, c, loss_slot):
+        """The phases of `phases` (OC_* bit mask) of part k (chunk buffers c) in ONE native call; buffers by raw address
+        (validated when they were allocated)."""
+        a = tr._addr[c]
+        s = self._steps[k]
+        s.tag = tag
+        _lib.oc_run(s, phases, a[0], a[1], tr.block, a[2], a[3], self._ring + loss_slot * self._ring_stride)
+
+
+BASES, COUNT, SCORE, APPLY, UPDATE = _lib.OC_BASES, _lib.OC_COUNT, _lib.OC_SCORE, _lib.OC_APPLY, _lib.OC_UPDATE
 
 
 class OcComm:
@@ -240,6 +287,8 @@ class OwnerComputesTrainer:
         self._dtype = dtype
         self._planned_epoch = -1
         self._stepped = -1
+        self._parts = None
+        self._persistent = {}
         self._plan_epoch()
 
     # ------------------------------------------------------------------------------------------------
@@ -258,47 +307,66 @@ class OwnerComputesTrainer:
         a = min(hi, lo + self.rank * per)
         return per, a, min(hi, a + per)
 
-    def _plan_epoch(self):
-        """Everything of an epoch that does not depend on the tables: this rank's negatives (one sampler launch), the
-        slot of every positive's HR / RT vector in its owner's block, the lists of owned positives per part, and the exact
-        capacity the epoch needs.  Integer work on the replicated epoch order: identical on every rank."""
+    def _layout(self):
+        """What depends only on the sizes of the epoch (fixed across epochs: a shuffle permutes contents, not the step /
+        part / slice boundaries): parts, every rank's slice of every part, this rank's epoch positions, part ids."""
         b, G, dev = self.bat, self.world, self.device
-        i32 = dict(dtype=torch.int32, device=dev)
         parts = [(s, lo, hi) for s in range(self.steps) for (lo, hi) in self.parts_of_step(s)]
         self._parts = parts
-        n_all = int(b.off[-1]) if self.steps else 0
-        # -- own negatives of the whole epoch (one sampler launch), packed as codes, all-gathered once ------------------
-        def slice_of(g, lo, hi):
-            per = max(1, int(math.ceil((hi - lo) / G)))
-            a = min(hi, lo + g * per)
-            return per, a, min(hi, a + per)
-        sl = [self.my_slice(lo, hi) for (_, lo, hi) in parts]
+        self._n_all = int(b.off[-1]) if self.steps else 0
+        lo = np.array([p[1] for p in parts], dtype=np.int64)
+        hi = np.array([p[2] for p in parts], dtype=np.int64)
+        per = np.maximum(1, -(-(hi - lo) // G))
         loc_off = np.zeros((G, len(parts) + 1), dtype=np.int64)     # every rank's prefix of slice sizes (all ranks agree)
         for g in range(G):
-            loc_off[g, 1:] = np.cumsum([e - a for (_, a, e) in (slice_of(g, lo, hi) for (_, lo, hi) in parts)]) if parts else 0
+            a = np.minimum(hi, lo + g * per)
+            e = np.minimum(hi, a + per)
+            loc_off[g, 1:] = np.cumsum(e - a)
+            if g == self.rank:
+                mine_a, mine_n = a, e - a
         self._loc_off = loc_off
-        idx = np.concatenate([np.arange(a, e, dtype=np.int32) for (_, a, e) in sl]) if parts else np.zeros(0, np.int32)
-        eidx = torch.as_tensor(idx, device=dev)
-        n_loc = int(loc_off[self.rank, -1])
-        per_rank = max(1, int(loc_off[:, -1].max()) * self.N)      # codes per rank in the gathered buffer (padded to the largest)
-        self._codes_per_rank = per_rank
-        mine = torch.zeros(per_rank, **i32)
+        if len(parts):
+            rep = np.repeat(mine_a - np.concatenate([[0], np.cumsum(mine_n)[:-1]]), mine_n)
+            idx = (np.arange(int(mine_n.sum()), dtype=np.int64) + rep).astype(np.int32)
+        else:
+            idx = np.zeros(0, np.int32)
+        self._eidx = torch.as_tensor(idx, device=dev)
+        self._eidx_long = self._eidx.long()
+        self._codes_per_rank = max(1, int(loc_off[:, -1].max()) * self.N)   # per rank in the gathered buffer (padded to the largest)
+        self._part_id = torch.repeat_interleave(torch.arange(len(parts), device=dev), torch.as_tensor(hi - lo, device=dev)) \
+            if len(parts) else torch.zeros(0, dtype=torch.int64, device=dev)
+        self._lo_of = torch.as_tensor(lo, device=dev)
+        self._parts_of = {}
+        for k, (ps, _, _) in enumerate(parts):
+            self._parts_of.setdefault(ps, []).append(k)
+
+    def _plan_epoch(self):
+        """Everything of an epoch that does not depend on the tables: this rank's negatives (one sampler launch) packed as
+        codes and all-gathered, the slot of every positive's HR / RT vector in its owner's block, the lists of owned
+        positives per part, and the exact capacity the epoch needs.  Integer work on the replicated epoch order: identical
+        on every rank."""
+        b, G, dev = self.bat, self.world, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        if getattr(self, "_parts", None) is None:
+            self._layout()
+        parts, n_all = self._parts, self._n_all
+        part_id = self._part_id
+        # -- own negatives of the whole epoch (one sampler launch), packed as codes, all-gathered once ------------------
+        n_loc = int(self._loc_off[self.rank, -1])
+        mine = self._persist(("codes_mine",), torch.zeros(0, **i32), self._codes_per_rank)
         if n_loc:
-            il = eidx.long()
+            il = self._eidx_long
             neg = tuple(torch.empty(n_loc * self.N, **i32) for _ in range(3))
             ph = b.pos_h[il]
-            self.backend.sample_at((ph, b.pos_r[il], b.pos_t[il]), eidx, b.pos_kg[il], b.side1, b.side2, self.N,
+            self.backend.sample_at((ph, b.pos_r[il], b.pos_t[il]), self._eidx, b.pos_kg[il], b.side1, b.side2, self.N,
                                    b.rng_seed, b.rng_stream, neg)
             self.backend.pack_codes(ph, neg[0], neg[2], self.N, mine[:n_loc * self.N])
         if G == 1:
             self._codes = mine
         else:
-            self._codes = torch.empty(G * per_rank, **i32)
+            self._codes = self._persist(("codes_all",), torch.zeros(0, **i32), G * self._codes_per_rank)
             self.comm.all_gather(self._codes, mine)
         # -- slots: rank of a positive among the positives of its part whose head (tail) has the same owner ---------
-        part_id = torch.zeros(max(1, n_all), dtype=torch.int64, device=dev)
-        for k, (_, lo, hi) in enumerate(parts):
-            part_id[lo:hi] = k
         self._slot, self._own, self._own_off = [], [], []
         worst = 0
         for ids in (b.pos_h, b.pos_t):
@@ -306,22 +374,21 @@ class OwnerComputesTrainer:
                 self._slot.append(torch.zeros(1, **i32)); self._own.append(torch.zeros(1, **i32))
                 self._own_off.append(np.zeros(len(parts) + 1, dtype=np.int64))
                 continue
-            key = part_id[:n_all] * G + (ids[:n_all].long() % G)
+            key = part_id * G + (ids[:n_all].long() % G)
             order = torch.argsort(key, stable=True)
             ks = key[order]
             counts = torch.bincount(ks, minlength=len(parts) * G)
             start = torch.cumsum(counts, 0) - counts
             slot = torch.empty(n_all, dtype=torch.int64, device=dev)
             slot[order] = torch.arange(n_all, device=dev) - start[ks]
-            self._slot.append(slot.to(torch.int32))
+            self._slot.append(self._persist(("slot", len(self._slot)), slot.to(torch.int32), n_all))
             cnt = counts.view(len(parts), G).cpu().numpy()
             worst = max(worst, int(cnt.max()))
             # owned positives (as positions inside their part), in slot order, for every part: the sorted order restricted
             # to this rank's keys is exactly that
             mine = ks % G == self.rank
             own_pos = order[mine]
-            lo_of = torch.as_tensor(np.array([lo for (_, lo, _) in parts], dtype=np.int64), device=dev)
-            self._own.append((own_pos - lo_of[part_id[own_pos]]).to(torch.int32))
+            self._own.append(self._persist(("own", len(self._own)), (own_pos - self._lo_of[part_id[own_pos]]).to(torch.int32), n_all))
             off = np.zeros(len(parts) + 1, dtype=np.int64)
             off[1:] = np.cumsum(cnt[:, self.rank])
             self._own_off.append(off)
@@ -336,11 +403,20 @@ class OwnerComputesTrainer:
             self._v_all = [self._send[c] if G == 1 else mk(G * self.block) for c in range(self.chunks)]
             self._g_all = [mk(G * gb) for _ in range(self.chunks)]
             self._gv = [self._g_all[c] if G == 1 else mk(gb) for c in range(self.chunks)]
+            self._addr = [tuple(t.data_ptr() for t in (self._send[c], self._v_all[c], self._g_all[c], self._gv[c]))
+                          for c in range(self.chunks)]
         self._planned_epoch = b.epoch
         self._st_cache = {}
-        self._parts_of = {}
-        for k, (ps, _, _) in enumerate(parts):
-            self._parts_of.setdefault(ps, []).append(k)
+        if hasattr(self.backend, "prepare_epoch"):
+            self.backend.prepare_epoch(self)
+
+    def _persist(self, key, value, capacity):
+        """Epoch buffers keep their device addresses across epochs (the native step descriptors point into them)."""
+        buf = self._persistent.get(key)
+        if buf is None or buf.numel() < max(capacity, value.numel(), 1):
+            buf = self._persistent[key] = torch.zeros(max(capacity, value.numel(), 1), dtype=value.dtype, device=value.device)
+        buf[:value.numel()].copy_(value)
+        return buf
 
     def global_scored(self, i: int) -> int:
         s = i % self.steps
@@ -373,42 +449,58 @@ class OwnerComputesTrainer:
         ks = self._parts_of.get(s, [])
         self.tag += 1
         tag = self.tag
-        pipelined = len(ks) > 1 and G > 1 and self.device.type == "cuda"
-        sts, works = [], {}
+        ev = self.score_events
+        slot0 = s * self.chunks
+        if G == 1:  # every row is local: no collective between the phases
+            last = len(ks) - 1
+            if last == 0 and ev is None:
+                be.run(self, ks[0], tag, BASES | COUNT | SCORE | APPLY | UPDATE, 0, slot0)
+            else:
+                for c, k in enumerate(ks):
+                    be.run(self, k, tag, BASES | COUNT, c, slot0 + c)       # counts of ALL parts before any is scored
+                for c, k in enumerate(ks):
+                    if ev is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    be.run(self, k, tag, SCORE, c, slot0 + c)
+                    if ev is not None:
+                        e1.record()
+                        ev.append((e0, e1, (self._parts[k][2] - self._parts[k][1]) * (1 + self.N)))
+                for c, k in enumerate(ks):
+                    be.run(self, k, tag, APPLY | (UPDATE if c == last else 0), c, slot0 + c)
+            self._stepped = i
+            return
+        pipelined = len(ks) > 1 and self.device.type == "cuda"
+        works = {}
         # ---- HR / RT vectors of every part, all-gathered (asynchronously when pipelining) -------------------------
         for c, k in enumerate(ks):
-            st = self._part_step(k, tag)
-            sts.append(st)
-            be.bases(self, st, self._send[c])
-            if G > 1:
-                works[("ag", c)] = cm.all_gather(self._v_all[c], self._send[c], async_op=pipelined)
+            be.run(self, k, tag, BASES, c, slot0 + c)
+            works[("ag", c)] = cm.all_gather(self._v_all[c], self._send[c], async_op=pipelined)
         # ---- reference counts over the WHOLE global step (all parts) before any part is scored: they need only the
         #      epoch's codes, so this runs while the all-gathers are on the wire ----------------------------------
         if self.ref_count is not None:
-            for st in sts:
-                be.count(self, st)
+            for c, k in enumerate(ks):
+                be.run(self, k, tag, COUNT, c, slot0 + c)
         # ---- score part c while part c+1's all-gather / part c-1's reduce-scatter are on the wire ------------------
-        for c, (k, st) in enumerate(zip(ks, sts)):
+        for c, k in enumerate(ks):
             if works.get(("ag", c)) is not None:
                 works[("ag", c)].wait()
-            ev = self.score_events
             if ev is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            be.score(self, st, self._v_all[c], self._g_all[c], self.loss_ring[s * self.chunks + c])
+            be.run(self, k, tag, SCORE, c, slot0 + c)
             if ev is not None:
                 e1.record()
-                ev.append((e0, e1, st.pos_h.numel() * (1 + self.N) // G))
-            if G > 1:
-                works[("rs", c)] = cm.reduce_scatter(self._gv[c], self._g_all[c], async_op=pipelined)
-        for c, st in enumerate(sts):
+                ev.append((e0, e1, (self._parts[k][2] - self._parts[k][1]) * (1 + self.N) // G))
+            works[("rs", c)] = cm.reduce_scatter(self._gv[c], self._g_all[c], async_op=pipelined)
+        for c, k in enumerate(ks):
             if works.get(("rs", c)) is not None:
                 works[("rs", c)].wait()
-            be.apply(self, st, self._gv[c])
+            be.run(self, k, tag, APPLY, c, slot0 + c)
         # ---- replicated relation table: all-reduce the (small) dense gradient; one update of everything ---------------
-        if G > 1:
-            cm.all_reduce(self.rel_grad)
-        be.update(self, tag)
+        cm.all_reduce(self.rel_grad)
+        if ks:
+            be.run(self, ks[-1], tag, UPDATE, 0, slot0)
         self._stepped = i
 
     # ------------------------------------------------------------------------------------------------

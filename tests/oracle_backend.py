@@ -273,3 +273,17 @@ class OcOracleBackend(OracleBackend):
                 gn[row] = 0
                 if w is tr.ent and tr.ref_count is not None:
                     tr.ref_count.numpy()[row] = 0
+
+    def run(self, tr, k, tag, phases, c, loss_slot):
+        from multike_amd.distributed_oc import APPLY, BASES, COUNT, SCORE, UPDATE
+        st = tr._part_step(k, tag)
+        if phases & BASES:
+            self.bases(tr, st, tr._send[c])
+        if phases & COUNT and tr.ref_count is not None:
+            self.count(tr, st)
+        if phases & SCORE:
+            self.score(tr, st, tr._v_all[c], tr._g_all[c], tr.loss_ring[loss_slot])
+        if phases & APPLY:
+            self.apply(tr, st, tr._gv[c])
+        if phases & UPDATE:
+            self.update(tr, tag)
