@@ -516,6 +516,19 @@ typedef struct mke_attr_step_args {
 } mke_attr_step_args;
 int64_t mke_attr_scratch_floats(int64_t n, int dim);
 int mke_attr_step(const mke_attr_step_args* args, void* stream);
+/* The same step cut into phases for data-parallel training over ranks (each rank trains the triples whose head entity it
+ * owns): the batch-wide l2_normalize (code/MultiKE_model.py:60) couples the ranks through two scalars and the replicated
+ * parameters through their gradients, so between the phases the caller all-reduces
+ *   partials[MKE_LOSS_PARTIALS ..)    (sum z^2)  after MKE_ATTR_FWD,   partials[2 MKE_LOSS_PARTIALS ..) (sum g.z) after MKE_ATTR_TAIL
+ *   (replace each array by [global sum, 0, 0, ...]; the consuming kernel adds the entries up),
+ *   param_grads and attr_grad after MKE_ATTR_BWD (then MKE_ATTR_UPD with attr_touched = NULL: every attribute row).
+ * n == 0 is legal (a rank owning none of the step's triples contributes zero sums). */
+#define MKE_ATTR_FWD 1
+#define MKE_ATTR_TAIL 2
+#define MKE_ATTR_BWD 4
+#define MKE_ATTR_UPD 8
+#define MKE_ATTR_ALL 15
+int mke_attr_step_phases(const mke_attr_step_args* args, int phases, void* stream);
 /* n_steps consecutive mke_attr_step calls without a host round trip between them (the per-step loop of
  * code/MultiKE_model.py:319-345,371-391,416-437 as one native call): step s uses positions [step_off[s], step_off[s+1])
  * of args->ih / ia / iv / weights (epoch order), tag args->tag + s, and writes its loss partials to

@@ -30,7 +30,7 @@ SYMBOLS = (
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
-    "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps",
+    "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
@@ -757,6 +757,14 @@ def sample_distinct(n: int, batch: int, n_steps: int, seed=(0, 0), stream_id: in
                                    _dev(out, torch.int32, "out"), _stream())
     _check(rc, "mke_sample_distinct")
     return out
+
+
+ATTR_FWD, ATTR_TAIL, ATTR_BWD, ATTR_UPD = 1, 2, 4, 8
+
+
+def attr_step_phases(args: AttrStepArgs, phases: int):
+    rc = lib().mke_attr_step_phases(C.byref(args), C.c_int(phases), _stream())
+    _check(rc, "mke_attr_step_phases")
 
 
 def attr_step(args: AttrStepArgs):

@@ -669,12 +669,26 @@ extern "C" int64_t mke_attr_scratch_floats(int64_t n, int dim) {
   return n * ((int64_t)dim * 10 + 4);  // flat n*(4d+4) | dflat n*4d | z n*d | gout n*d
 }
 
-static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream);
+static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream, int phases);
 
 extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
   if (!a) { mke::set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
   if (!a->partials) { mke::set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
-  return attr_step_impl(a, a->partials, a->partials + MKE_LOSS_PARTIALS, a->partials + 2 * MKE_LOSS_PARTIALS, stream);
+  return attr_step_impl(a, a->partials, a->partials + MKE_LOSS_PARTIALS, a->partials + 2 * MKE_LOSS_PARTIALS, stream, MKE_ATTR_ALL);
+}
+
+// The same step in phases (bit mask), for the data-parallel attribute view (multike_amd/distributed_views.py): the
+// batch-wide normalisation couples the ranks through two scalars, so the caller all-reduces
+//   args->partials[MKE_LOSS_PARTIALS ...)      (sum z^2)  between MKE_ATTR_FWD and MKE_ATTR_TAIL,
+//   args->partials[2 MKE_LOSS_PARTIALS ...)    (sum g.z)  between MKE_ATTR_TAIL and MKE_ATTR_BWD
+// (replace each array by [global sum, 0, 0, ...]: the consuming kernel adds the entries up itself), and the parameter /
+// attribute-table gradients between MKE_ATTR_BWD and MKE_ATTR_UPD.
+extern "C" int mke_attr_step_phases(const mke_attr_step_args* a, int phases, void* stream) {
+  using namespace mke;
+  if (!a) { set_error("mke_attr_step_phases: NULL args"); return MKE_E_NULL; }
+  if (phases <= 0 || phases > MKE_ATTR_ALL) { set_error("mke_attr_step_phases: bad phase mask"); return MKE_E_SHAPE; }
+  if (!a->partials) { set_error("mke_attr_step_phases: NULL partials"); return MKE_E_NULL; }
+  return attr_step_impl(a, a->partials, a->partials + MKE_LOSS_PARTIALS, a->partials + 2 * MKE_LOSS_PARTIALS, stream, phases);
 }
 
 extern "C" int mke_attr_steps(const mke_attr_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
@@ -693,21 +707,30 @@ extern "C" int mke_attr_steps(const mke_attr_step_args* args, const int64_t* ste
     a.n = hi - lo;
     a.tag = args->tag + s;
     const int rc = attr_step_impl(&a, loss_ring + (int64_t)(s % ring) * MKE_LOSS_PARTIALS, args->partials + MKE_LOSS_PARTIALS,
-                                  args->partials + 2 * MKE_LOSS_PARTIALS, stream);
+                                  args->partials + 2 * MKE_LOSS_PARTIALS, stream, MKE_ATTR_ALL);
     if (rc) return rc;
   }
   return MKE_OK;
 }
 
-static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream) {
+static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream, int phases) {
   using namespace mke;
   if (!a) { set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
   if (a->n < 0 || a->dim <= 0) { set_error("mke_attr_step: bad n/dim"); return MKE_E_SHAPE; }
   if (!a->ent_table || !a->attr_table || !a->lit_table || !a->params || !a->param_grads || !a->scratch || !a->partials) { set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
-  if (a->n == 0) {
+  if (a->n == 0 && phases == MKE_ATTR_ALL) {
     hipError_t e = hipMemsetAsync(lossp, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("mke_attr_step: memset failed"); return (int)e; }
     return MKE_OK;
+  }
+  if (a->n == 0) {  // a rank that owns none of the step's triples still takes part in the reductions: its sums are zero
+    hipError_t e = hipSuccess;
+    if (phases & MKE_ATTR_FWD) e = hipMemsetAsync(ssq, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
+    if (e == hipSuccess && (phases & MKE_ATTR_TAIL)) e = hipMemsetAsync(lossp, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
+    if (e == hipSuccess && (phases & MKE_ATTR_TAIL)) e = hipMemsetAsync(dot, 0, sizeof(double) * MKE_LOSS_PARTIALS, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("mke_attr_step: memset failed"); return (int)e; }
+    phases &= MKE_ATTR_UPD;
+    if (!phases) return MKE_OK;
   }
   const int d = a->dim;
   const int64_t n = a->n;
@@ -721,14 +744,18 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   float* gW = a->param_grads + MKE_CNN_CONV_PARAMS(d);  // bias / its gradient are row 4d of W / gW (packed right behind)
   int rc;
   // forward: conv stack -> dense -> tanh -> batch-global normalisation -> loss
-  if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
-                              a->params, flat, fs, stream))) return rc;
-  // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
-  if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq, 0))) return rc;
-  const bool upd = a->update != 0;
-  if ((rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
+  if (phases & MKE_ATTR_FWD) {
+    if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
+                                a->params, flat, fs, stream))) return rc;
+    // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
+    if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq, 0))) return rc;
+  }
+  const bool upd = a->update != 0 && (phases & MKE_ATTR_UPD);
+  if ((phases & MKE_ATTR_TAIL) &&
+      (rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
   // backward
+  if (phases & MKE_ATTR_BWD) {
   if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre
   // [dW; dbias] = [flat, 1]^T dz (split-K, atomic)  and  dflat = dz W^T, one launch
   if ((rc = launch_gemm_f32_pair(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1,
@@ -740,6 +767,8 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
     p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
     p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
     if ((rc = conv_dispatch(p, true, st))) return rc;
+  }
+  if (!upd && a->workspace && (rc = ws_fold(a->workspace, a->param_grads, d, st))) return rc;   // gradients complete in param_grads
   }
   if (upd) {
     // one launch: entity rows, attribute rows, and (rider blocks) the dense update of the packed parameters, which also
@@ -755,8 +784,6 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
                 MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), CNN_WS_COPIES};
     if ((rc = launch_rows_update_multi(tabs, nt, a->tag, a->ent_grad ? a->ent_stride : a->attr_stride, d, a->optimizer, a->lr, st,
                                        nullptr, &dj))) return rc;
-  } else if (a->workspace) {
-    if ((rc = ws_fold(a->workspace, a->param_grads, d, st))) return rc;
   }
   return MKE_OK;
 }

@@ -77,7 +77,7 @@ def forward(p, hs, as_, vs):
     ssq = np.sum(c2 * c2, axis=2, keepdims=True)                   # over width, per (b,h,c)
     n = 1.0 / np.sqrt(np.maximum(ssq, L2_EPS))
     y = c2 * n
-    flat = y.reshape(y.shape[0], -1)                               # index h*2d + w*2 + c
+    flat = y.reshape(y.shape[0], y.shape[1] * y.shape[2] * y.shape[3])   # index h*2d + w*2 + c (explicit: B may be 0)
     zpre = flat @ p["W"] + p["bias"]
     z = np.tanh(zpre)
     S = np.sum(z * z)
@@ -90,23 +90,30 @@ def forward(p, hs, as_, vs):
     return score, cache
 
 
-def loss_and_grads(p, hs, as_, vs, ws=None, scale=1.0):
-    """loss = scale * sum w * log(1+exp(-score)); returns (loss, grads) with grads for every parameter plus
-    'hs' (gradient w.r.t. the normalised entity rows) and 'as' (w.r.t. the attribute rows)."""
-    score, c = forward(p, hs, as_, vs)
-    x = -score
+def dp_tail(c, hs, ws, scale, S_global):
+    """Loss tail on a PART of a batch whose batch-wide sum of z^2 is S_global (data-parallel evaluation: the part's own
+    contribution is c["S"]).  Returns (loss of the part, g_h, g_out, T_part = sum g_out . out over the part)."""
+    inv = 1.0 / np.sqrt(max(S_global, L2_EPS))
+    out = c["z"] * inv
+    diff = hs - out
+    x = np.sum(diff * diff, axis=1)
     w = np.ones_like(x) if ws is None else ws.astype(x.dtype)
     loss = scale * np.sum(w * np.logaddexp(0.0, x))
     coef = scale * w / (1.0 + np.exp(-x))                          # dL/dx
-    g_h = 2.0 * coef[:, None] * c["diff"]
+    g_h = 2.0 * coef[:, None] * diff
     g_out = -g_h
-    if c["S"] > L2_EPS:
-        T = np.sum(g_out * c["out"])
-        dz = c["inv"] * (g_out - c["out"] * T)
+    return loss, g_h, g_out, float(np.sum(g_out * out)), dict(inv=inv, out=out)
+
+
+def dp_backward(p, c, t, g_out, S_global, T_global):
+    """Backward of the part from g_out, given the batch-wide scalars.  Returns the parameter gradients of the part (they
+    add up over the parts) and 'as' (gradient w.r.t. the part's attribute rows)."""
+    if S_global > L2_EPS:
+        dz = t["inv"] * (g_out - t["out"] * T_global)
     else:
-        dz = c["inv"] * g_out
+        dz = t["inv"] * g_out
     dzpre = dz * (1.0 - c["z"] ** 2)
-    g = {"W": c["flat"].T @ dzpre, "bias": dzpre.sum(0), "hs": g_h}
+    g = {"W": c["flat"].T @ dzpre, "bias": dzpre.sum(0)}
     dflat = dzpre @ p["W"].T
     dy = dflat.reshape(c["y"].shape)
     dot = np.sum(dy * c["y"], axis=2, keepdims=True)
@@ -119,6 +126,16 @@ def loss_and_grads(p, hs, as_, vs, ws=None, scale=1.0):
     g["gamma"] = np.sum(dx * c["raw"] * c["s"], axis=(0, 1))
     g["beta"] = np.sum(dx, axis=(0, 1))
     g["as"] = dx[:, 0, :] * (p["gamma"] * c["s"])
+    return g
+
+
+def loss_and_grads(p, hs, as_, vs, ws=None, scale=1.0):
+    """loss = scale * sum w * log(1+exp(-score)); returns (loss, grads) with grads for every parameter plus
+    'hs' (gradient w.r.t. the normalised entity rows) and 'as' (w.r.t. the attribute rows)."""
+    _, c = forward(p, hs, as_, vs)
+    loss, g_h, g_out, T, t = dp_tail(c, hs, ws, scale, c["S"])
+    g = dp_backward(p, c, t, g_out, c["S"], T)
+    g["hs"] = g_h
     return loss, g
 
 

@@ -310,3 +310,18 @@ def xavier_truncated_normal(shape, rng: np.random.Generator, dtype=np.float32):
         x[bad] = rng.standard_normal(size=int(bad.sum()))
         bad = np.abs(x) > 2.0
     return (x * sigma).astype(dtype)
+
+
+def common_space_step_dense(ent, name, rv, av, acc_ent, acc_rv, acc_av, idx, lr, cv_name_weight=1.0, cv_weight=1.0):
+    """One common-space learning step (code/MultiKE_model.py:225-239): loss = cv_name_weight * align(ent, name) +
+    align(ent, rv) + align(ent, av) over the entities idx; the optimizer minimises cv_weight * loss in ONE step (ent gets the
+    sum of its three gradients).  name is a constant read as-is (:88); the others are read through l2_normalize.  Tables and
+    accumulators are updated in place; returns cv_weight * loss."""
+    w = cv_weight
+    l1, g_e1, _ = alignment_step_dense(ent, name, None, None, idx, idx, lr, w * cv_name_weight, True, False, update=False)
+    l2, g_e2, g_rv = alignment_step_dense(ent, rv, None, None, idx, idx, lr, w, True, True, update=False)
+    l3, g_e3, g_av = alignment_step_dense(ent, av, None, None, idx, idx, lr, w, True, True, update=False)
+    adagrad_dense(ent, acc_ent, l2_normalize_rows_backward(ent, g_e1 + g_e2 + g_e3), lr)
+    adagrad_dense(rv, acc_rv, l2_normalize_rows_backward(rv, g_rv), lr)
+    adagrad_dense(av, acc_av, l2_normalize_rows_backward(av, g_av), lr)
+    return l1 + l2 + l3

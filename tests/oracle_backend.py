@@ -287,3 +287,85 @@ class OcOracleBackend(OracleBackend):
             self.apply(tr, st, tr._gv[c])
         if phases & UPDATE:
             self.update(tr, tag)
+
+
+# ---- NumPy backends of multike_amd/distributed_views.py (float64) ------------------------------------------------------
+class OracleAttrBackend:
+    device_type = "cpu"
+
+    def __init__(self, view, ent_shard, attr0, lit, cnn_params):
+        from oracle import attr_cnn_oracle as ao
+        self.ao = ao
+        self.ent = np.array(ent_shard, dtype=np.float64)
+        self.attr, self.lit = np.array(attr0, dtype=np.float64), np.array(lit, dtype=np.float64)
+        self.p = {k: np.array(v, dtype=np.float64) for k, v in cnn_params.items()}
+        self.acc_p = {k: np.full_like(v, 0.1) for k, v in self.p.items()}
+        self.acc_ent, self.acc_attr = np.full_like(self.ent, 0.1), np.full_like(self.attr, 0.1)
+        self.loss = 0.0
+
+    def forward(self, view, lh, ia, iv, w, scale):
+        import torch
+        self.lh, self.ia, self.w, self.scale = lh, np.asarray(ia, dtype=np.int64), w, scale
+        self.hs = mo.l2_normalize_rows(self.ent)[lh] if len(self.ent) else np.zeros((0, view.dim))
+        _, self.c = self.ao.forward(self.p, self.hs, self.attr[self.ia], self.lit[np.asarray(iv, dtype=np.int64)])
+        return torch.tensor([self.c["S"]], dtype=torch.float64)
+
+    def tail(self, view, S):
+        import torch
+        self.S = float(S)
+        loss, self.g_h, self.g_out, T, self.t = self.ao.dp_tail(self.c, self.hs, self.w, self.scale, self.S)
+        self.loss += loss
+        return torch.tensor([T], dtype=torch.float64)
+
+    def backward(self, view, T):
+        import torch
+        g = self.ao.dp_backward(self.p, self.c, self.t, self.g_out, self.S, float(T))
+        self.ge = np.zeros_like(self.ent)
+        np.add.at(self.ge, self.lh, self.g_h)
+        self.ga = np.zeros_like(self.attr)
+        np.add.at(self.ga, self.ia, g["as"])
+        self.flat = np.concatenate([g[k].reshape(-1) for k in self.ao.PARAM_NAMES])
+        return [torch.from_numpy(self.flat), torch.from_numpy(self.ga)]
+
+    def update(self, view):
+        mo.adagrad_dense(self.ent, self.acc_ent, mo.l2_normalize_rows_backward(self.ent, self.ge), view.lr)
+        mo.adagrad_dense(self.attr, self.acc_attr, self.ga, view.lr)
+        o = 0
+        for k in self.ao.PARAM_NAMES:
+            n = self.p[k].size
+            mo.adagrad_dense(self.p[k], self.acc_p[k], self.flat[o:o + n].reshape(self.p[k].shape), view.lr)
+            o += n
+
+    def take_loss(self):
+        import torch
+        v = torch.tensor([self.loss], dtype=torch.float64)
+        self.loss = 0.0
+        return v
+
+    def tables(self):
+        return self.ent, self.attr, self.p
+
+
+class OracleCommonSpaceBackend:
+    device_type = "cpu"
+
+    def __init__(self, view, shards):
+        self.t = {k: np.array(v, dtype=np.float64) for k, v in shards.items()}
+        self.acc = {k: np.full_like(self.t[k], 0.1) for k in ("ent", "rv", "av")}
+        self.loss = 0.0
+
+    def step(self, view, rows):
+        if len(rows) == 0:
+            return
+        t, a = self.t, self.acc
+        self.loss += mo.common_space_step_dense(t["ent"], t["name"], t["rv"], t["av"], a["ent"], a["rv"], a["av"], rows, view.lr,
+                                                view.cv_name_weight, view.cv_weight)
+
+    def take_loss(self):
+        import torch
+        v = torch.tensor([self.loss], dtype=torch.float64)
+        self.loss = 0.0
+        return v
+
+    def tables(self):
+        return {k: self.t[k] for k in ("ent", "rv", "av")}

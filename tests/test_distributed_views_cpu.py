@@ -1,0 +1,141 @@
+"""world_size-2 gloo runs of the sharded attribute view and the sharded common-space step
+(multike_amd/distributed_views.py) with NumPy backends built on the oracle: ownership by head entity, the two scalar
+all-reduces of the batch-wide l2_normalize (code/MultiKE_model.py:60), the all-reduce of the replicated parameters'
+gradients, a rank that owns none of a step's triples — against a single-process dense oracle on the same global batches."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import attr_cnn_oracle as ao
+from oracle import multike_oracle as mo
+
+N_ENT, N_ATTR, N_LIT, DIM, B, STEPS, SEED = 61, 9, 40, 12, 50, 4, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _attr_data():
+    rng = np.random.default_rng(SEED)
+    ent = mo.xavier_truncated_normal((N_ENT, DIM), rng).astype(np.float64)
+    attr = mo.xavier_truncated_normal((N_ATTR, DIM), rng).astype(np.float64)
+    lit = rng.standard_normal((N_LIT, DIM))
+    lit /= np.linalg.norm(lit, axis=1, keepdims=True)
+    P = ao.init_params(DIM, rng)
+    P["bias"] = 0.05 * rng.standard_normal(DIM)
+    batches = []
+    for s in range(STEPS):
+        ih = rng.integers(0, N_ENT, B)
+        if s == 2:
+            ih = 2 * rng.integers(0, N_ENT // 2, 7)            # only even heads: rank 1 of 2 owns nothing in this step
+        n = len(ih)
+        batches.append((ih, rng.integers(0, N_ATTR, n), rng.integers(0, N_LIT, n), rng.uniform(0.2, 1.0, n)))
+    return ent, attr, lit, P, batches
+
+
+def _attr_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import ShardedAttributeView
+        from oracle_backend import OracleAttrBackend
+        ent, attr, lit, P, batches = _attr_data()
+        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.05, backend_cls=OracleAttrBackend)
+        for (ih, ia, iv, w) in batches:
+            v.step(ih, ia, iv, w, scale=2.0)
+        loss = v.epoch_loss()
+        full, a, p = v.gather()
+        if rank == 0:
+            ret.put((full, a, p, loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_attribute_view_equals_single_process_oracle(world):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_attr_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, a, p, loss = ret.get(timeout=240)
+    for q in procs:
+        q.join(60)
+        assert q.exitcode == 0
+    ent, attr, lit, P, batches = _attr_data()
+    acc = {k: np.full_like(x, 0.1) for k, x in P.items()}
+    ae, aa = np.full_like(ent, 0.1), np.full_like(attr, 0.1)
+    tot = 0.0
+    for (ih, ia, iv, w) in batches:
+        L, _ = ao.attribute_step_dense(P, acc, ent, attr, lit, ae, aa, ih, ia, iv, w, 2.0, 0.05)
+        tot += L
+    np.testing.assert_allclose(loss, tot, rtol=1e-11)
+    np.testing.assert_allclose(full, ent, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a, attr, rtol=1e-9, atol=1e-12)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(p[k], P[k], rtol=1e-8, atol=1e-12, err_msg=k)
+
+
+def _cs_data():
+    rng = np.random.default_rng(SEED + 1)
+    mk = lambda: mo.xavier_truncated_normal((N_ENT, DIM), rng).astype(np.float64)
+    ent, rv, av = mk(), mk(), mk()
+    name = rng.standard_normal((N_ENT, DIM))
+    name /= np.linalg.norm(name, axis=1, keepdims=True)
+    name[5] = 0.0                                             # an entity without a name vector
+    batches = [rng.choice(N_ENT, 23, replace=False) for _ in range(STEPS)]
+    return ent, name, rv, av, batches
+
+
+def _cs_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import ShardedCommonSpace
+        from oracle_backend import OracleCommonSpaceBackend
+        ent, name, rv, av, batches = _cs_data()
+        v = ShardedCommonSpace(ent, name, rv, av, rank, world, lr=0.05, cv_name_weight=0.7, cv_weight=1.3,
+                               backend_cls=OracleCommonSpaceBackend)
+        for ids in batches:
+            v.step(ids)
+        loss = v.epoch_loss()
+        out = v.gather()
+        if rank == 0:
+            ret.put((out, loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_common_space_equals_single_process_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cs_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, loss = ret.get(timeout=240)
+    for q in procs:
+        q.join(60)
+        assert q.exitcode == 0
+    ent, name, rv, av, batches = _cs_data()
+    accs = [np.full_like(ent, 0.1) for _ in range(3)]
+    tot = sum(mo.common_space_step_dense(ent, name, rv, av, accs[0], accs[1], accs[2], ids, 0.05, 0.7, 1.3) for ids in batches)
+    np.testing.assert_allclose(loss, tot, rtol=1e-12)
+    for k, ref in (("ent", ent), ("rv", rv), ("av", av)):
+        np.testing.assert_allclose(out[k], ref, rtol=1e-10, atol=1e-13, err_msg=k)

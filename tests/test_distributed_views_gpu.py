@@ -1,0 +1,132 @@
+"""The sharded attribute view / common-space step with the HIP kernels (mke_attr_step_phases, mke_align_*): two ranks
+SHARING the one GPU of the test box (collectives staged through gloo) against the float64 dense oracle on the same global
+batches; the exchange logic itself is covered under gloo in tests/test_distributed_views_cpu.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attr_cnn_oracle as ao
+from oracle import multike_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+N_ENT, N_ATTR, N_LIT, DIM, B, STEPS, SEED = 900, 40, 300, 75, 700, 3, 5
+
+
+def _attr_data():
+    rng = np.random.default_rng(SEED)
+    ent = mo.xavier_truncated_normal((N_ENT, DIM), rng)
+    attr = mo.xavier_truncated_normal((N_ATTR, DIM), rng)
+    lit = rng.standard_normal((N_LIT, DIM)).astype(np.float32)
+    lit /= np.linalg.norm(lit, axis=1, keepdims=True)
+    P = ao.init_params(DIM, rng)
+    P["bias"] = 0.05 * rng.standard_normal(DIM)
+    batches = []
+    for s in range(STEPS):
+        ih = rng.integers(0, N_ENT, B)
+        if s == 1:
+            ih = 2 * rng.integers(0, N_ENT // 2, 64)           # rank 1 of 2 owns none of this step's triples
+        n = len(ih)
+        batches.append((ih, rng.integers(0, N_ATTR, n), rng.integers(0, N_LIT, n), rng.uniform(0.2, 1.0, n)))
+    return ent, attr, lit, P, batches
+
+
+def _attr_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import HostStagedViewComm, ShardedAttributeView
+        torch.cuda.set_device(0)
+        ent, attr, lit, P, batches = _attr_data()
+        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.01, comm=HostStagedViewComm())
+        for (ih, ia, iv, w) in batches:
+            v.step(ih, ia, iv, w, scale=2.0)
+        loss = v.epoch_loss()
+        full, a, p = v.gather()
+        ok = float(v.backend.cnn.grads.abs().max()) == 0.0 and float(v.backend.attr.grad.abs().max()) == 0.0 and \
+            float(v.backend.ent.grad.abs().max()) == 0.0
+        if rank == 0:
+            ret.put((full, a, p, loss, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker, world=2):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = ret.get(timeout=480)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_attribute_view_equals_dense_oracle():
+    full, a, p, loss, ok = _run(_attr_worker)
+    ent, attr, lit, P, batches = _attr_data()
+    p64 = {k: v.astype(np.float64) for k, v in P.items()}
+    acc = {k: np.full_like(v, 0.1) for k, v in p64.items()}
+    e64, a64, l64 = ent.astype(np.float64), attr.astype(np.float64), lit.astype(np.float64)
+    ae, aa = np.full_like(e64, 0.1), np.full_like(a64, 0.1)
+    tot = 0.0
+    for (ih, ia, iv, w) in batches:
+        L, _ = ao.attribute_step_dense(p64, acc, e64, a64, l64, ae, aa, ih, ia, iv, w.astype(np.float32).astype(np.float64), 2.0, 0.01)
+        tot += L
+    assert ok
+    np.testing.assert_allclose(loss, tot, rtol=1e-5)
+    np.testing.assert_allclose(full, e64, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(a, a64, rtol=2e-3, atol=2e-5)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(p[k], p64[k], rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+def _cs_data():
+    rng = np.random.default_rng(SEED + 1)
+    mk = lambda: mo.xavier_truncated_normal((N_ENT, DIM), rng)
+    ent, rv, av = mk(), mk(), mk()
+    name = rng.standard_normal((N_ENT, DIM)).astype(np.float32)
+    name /= np.linalg.norm(name, axis=1, keepdims=True)
+    batches = [rng.choice(N_ENT, 400, replace=False) for _ in range(STEPS)]
+    return ent, name, rv, av, batches
+
+
+def _cs_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import HostStagedViewComm, ShardedCommonSpace
+        torch.cuda.set_device(0)
+        ent, name, rv, av, batches = _cs_data()
+        v = ShardedCommonSpace(ent, name, rv, av, rank, world, lr=0.02, cv_name_weight=0.7, cv_weight=1.3, comm=HostStagedViewComm())
+        for ids in batches:
+            v.step(ids)
+        loss = v.epoch_loss()
+        out = v.gather()
+        if rank == 0:
+            ret.put((out, loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_common_space_equals_dense_oracle():
+    out, loss = _run(_cs_worker)
+    ent, name, rv, av, batches = (x.astype(np.float64) if isinstance(x, np.ndarray) else x for x in _cs_data())
+    accs = [np.full_like(ent, 0.1) for _ in range(3)]
+    tot = sum(mo.common_space_step_dense(ent, name, rv, av, accs[0], accs[1], accs[2], ids, 0.02, 0.7, 1.3) for ids in batches)
+    np.testing.assert_allclose(loss, tot, rtol=2e-6)
+    for k, ref in (("ent", ent), ("rv", rv), ("av", av)):
+        np.testing.assert_allclose(out[k], ref, rtol=2e-4, atol=2e-6, err_msg=k)
