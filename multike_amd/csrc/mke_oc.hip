@@ -144,20 +144,22 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
       if (j == 0) s.rel_touched[pr] = s.tag;
     }
 
+    // quarter q takes the q-th, (q+4)-th, ... set bit of the ballot: a running copy of the mask with the bits already
+    // dealt removed (4 bit-clears per negative instead of a scan from bit 0)
+    uint64_t rest = mask;
+    for (int k = 0; k < q; ++k) rest &= rest - 1;
     for (int base = 0; base < total; base += 4 * U) {
       int e[U], cnt[U];
       bool live[U], sideH[U];
       float Cr[U][FPL], A[U][FPL];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int target = base + 4 * u + q;
-        live[u] = target < total;
-        uint64_t t = mask;
-        for (int k = 0; k < target && t; ++k) t &= t - 1;   // drop the `target` lowest set bits
-        const int src = live[u] ? __builtin_ctzll(t) : 0;
+        live[u] = rest != 0;
+        const int src = live[u] ? __builtin_ctzll(rest) : 0;
         const int cd = __shfl(code, src, 64);
         sideH[u] = cd & 1;
         e[u] = (cd >> 1) / G;
+        rest &= rest - 1; rest &= rest - 1; rest &= rest - 1; rest &= rest - 1;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
