@@ -58,6 +58,10 @@ const char* mke_last_error(void);
 
 /* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
  *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
+ *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
+ *                     kernels themselves are selected by which entry point is called)
+ *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per
+ *                     half; default 12, 0 = never) — the reference's default of 10 negatives fills a whole wavefront badly
  * Returns the previous value through *old_value when it is not NULL. */
 int mke_set_option(const char* name, int value, int* old_value);
 
@@ -115,6 +119,23 @@ int mke_triple_score_fwd_bwd(
  *     ref_count[e] == 1 is applied in place on (ent_table, ent_acc) with (optimizer, lr) and ref_count[e] is reset to 0;
  *     every other row goes through grad_ent / touched_ent as in (1).  mke_rows_update* reset ref_count for the rows they
  *     visit when given the array (mke_update_table.ref_count / the ref_count argument), restoring the invariant. */
+/* Deterministic mode (parity / debugging; SURVEY.md §7 "hard parts"): the same step with every gradient-row contribution
+ * STORED into a slot of its own instead of added atomically — slot ((g * (neg_per_pos + 1) + n) * 3 + c) for contribution c
+ * (0 head, 1 relation, 2 tail row) of triple n of group g (n = neg_per_pos: the group's pre-reduced flush), key
+ * (is_relation << 40) | row — then summed per row in slot order:
+ *     fill stage_keys with 0x7F bytes -> mke_triple_score_fwd_bwd_det -> stable sort of the keys (-> sorted_keys, order)
+ *     -> mke_stage_reduce -> mke_rows_update_multi as usual.
+ * stage_rows: [stage_slots][stride] floats, stage_slots >= 3 * n_pos * (neg_per_pos + 1) (ungrouped: 3 * (n_pos + n_neg)).
+ * Results are bit-identical from run to run; rows referenced once are still updated in place (one contribution: no order). */
+int mke_triple_score_fwd_bwd_det(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+    int32_t* ref_count /*nullable*/, float* ent_acc, int optimizer, float lr, float* stage_rows, int64_t* stage_keys,
+    int64_t stage_slots, double* loss_partials, void* stream);
+int mke_stage_reduce(const float* stage_rows, const int64_t* sorted_keys, const int64_t* order, int64_t n_slots, int stride,
+                     float* grad_ent, float* grad_rel, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, void* stream);
 int mke_count_entity_refs(const int32_t* pos_h, const int32_t* pos_t, int64_t n_pos, const int32_t* neg_h,
                           const int32_t* neg_t, int64_t n_neg, int neg_per_pos, int32_t* ref_count, void* stream);
 int mke_triple_score_fwd_bwd_x(

@@ -25,7 +25,7 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
     "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_triple_score_fwd_bwd_x",
-    "mke_count_entity_refs", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
+    "mke_count_entity_refs", "mke_triple_score_fwd_bwd_det", "mke_stage_reduce", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
@@ -232,6 +232,39 @@ def set_option(name: str, value: int) -> int:
     old = C.c_int(0)
     _check(lib().mke_set_option(name.encode(), C.c_int(value), C.byref(old)), "mke_set_option")
     return old.value
+
+
+def triple_score_fwd_bwd_det(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale, grad_ent,
+                             grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, stage_rows, stage_keys,
+                             loss_partials):
+    ph, pr, pt = pos
+    nh, nr, nt = neg if neg is not None else (None, None, None)
+    i32, f32 = torch.int32, torch.float32
+    rc = lib().mke_triple_score_fwd_bwd_det(
+        _dev(ent, f32, "ent"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)), _dev(rel, f32, "rel"), C.c_int64(rel.shape[0]),
+        C.c_int(int(rel_normalize)), C.c_int(ent.shape[1]), C.c_int(dim), _dev(ph, i32, "ph"), _dev(pr, i32, "pr"), _dev(pt, i32, "pt"),
+        _dev(pos_w, f32, "pos_w"), C.c_int64(ph.numel()), _dev(nh, i32, "nh"), _dev(nr, i32, "nr"), _dev(nt, i32, "nt"),
+        _dev(neg_w, f32, "neg_w"), C.c_int64(0 if nh is None else nh.numel()), C.c_int(neg_per_pos), C.c_float(scale),
+        _dev(grad_ent, f32, "grad_ent"), _dev(grad_rel, f32, "grad_rel"), _dev(touched_ent, i32, "touched"),
+        _dev(touched_rel, i32, "touched"), C.c_int32(tag), _dev(ref_count, i32, "ref_count"), _dev(ent_acc, f32, "acc"),
+        C.c_int(optimizer), C.c_float(lr), _dev(stage_rows, f32, "stage_rows"), _dev(stage_keys, torch.int64, "stage_keys"),
+        C.c_int64(stage_keys.numel()), _dev(loss_partials, torch.float64, "loss"), _stream())
+    _check(rc, "mke_triple_score_fwd_bwd_det")
+
+
+def stage_reduce(stage_rows, sorted_keys, order, grad_ent, grad_rel, touched_ent, touched_rel, tag):
+    rc = lib().mke_stage_reduce(_dev(stage_rows, torch.float32, "stage_rows"), _dev(sorted_keys, torch.int64, "keys"),
+                                _dev(order, torch.int64, "order"), C.c_int64(sorted_keys.numel()), C.c_int(stage_rows.shape[1]),
+                                _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"),
+                                _dev(touched_ent, torch.int32, "touched"), _dev(touched_rel, torch.int32, "touched"), C.c_int32(tag),
+                                _stream())
+    _check(rc, "mke_stage_reduce")
+
+
+def get_option(name: str) -> int:
+    old = set_option(name, 0)
+    set_option(name, old)
+    return old
 
 
 def triple_score_fwd_bwd(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale,

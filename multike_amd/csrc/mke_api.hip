@@ -29,6 +29,8 @@ int check_launch(const char* what) {
 
 namespace mke {
 int g_score_splits = 0;
+int g_score_half_max = 12;   // groups of <= 12 negatives: two groups per wavefront (mke_score.hip)
+int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
 }
 
 extern "C" int mke_set_option(const char* name, int value, int* old_value) {
@@ -36,6 +38,16 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "score_splits")) {
     if (old_value) *old_value = mke::g_score_splits;
     mke::g_score_splits = value < 0 ? 0 : value;
+    return MKE_OK;
+  }
+  if (!strcmp(name, "score_half_groups")) {
+    if (old_value) *old_value = mke::g_score_half_max;
+    mke::g_score_half_max = value < 0 ? 0 : (value > 32 ? 32 : value);
+    return MKE_OK;
+  }
+  if (!strcmp(name, "deterministic")) {
+    if (old_value) *old_value = mke::g_deterministic;
+    mke::g_deterministic = value != 0;
     return MKE_OK;
   }
   mke::set_error("mke_set_option: unknown option '%s'", name);

@@ -17,7 +17,8 @@ namespace mke {
 #ifndef MKE_SCORE_U
 #define MKE_SCORE_U 2
 #endif
-extern int g_score_splits;  // mke_set_option("score_splits")
+extern int g_score_splits;    // mke_set_option("score_splits")
+extern int g_score_half_max;  // mke_set_option("score_half_groups"): largest neg_per_pos scored two groups per wavefront (0 = off)
 
 struct ScoreParams {
   const float* __restrict__ ent;
@@ -51,12 +52,35 @@ struct ScoreParams {
   float* __restrict__ ent_acc;  // nullable (SGD)
   int optimizer;
   float lr;
+  // deterministic mode (nullable): every gradient-row contribution is STORED into its own slot instead of added
+  // atomically; mke_stage_reduce sums a row's slots in slot order afterwards
+  float* __restrict__ stage_rows;   // [slots][stride]
+  int64_t* __restrict__ stage_keys; // [slots]: (is_relation << 40) | row; untouched slots keep the caller's fill value
 };
+
+#define MKE_STAGE_REL (1ll << 40)
+// slot of contribution c (0 head row, 1 relation row, 2 tail row) of triple n of group g (n == npp: the group's flush)
+__device__ __forceinline__ int64_t stage_slot(int64_t g, int npp, int n, int c) { return ((g * (npp + 1) + n) * 3 + c); }
+
+// one gradient-row contribution: atomic add + touched flag, or (deterministic mode) a plain store into its slot
+template <int FPL>
+__device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, float* __restrict__ table_grad, int32_t* __restrict__ touched,
+                                         int row, int64_t slot, int j, const float (&v)[FPL], float sgn) {
+  if (p.stage_keys) {
+    float* o = p.stage_rows + slot * p.stride + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) o[k * 16] = sgn * v[k];
+    if (j == 0) p.stage_keys[slot] = (is_rel ? MKE_STAGE_REL : 0ll) | (int64_t)row;
+  } else {
+    atomic_add_row<FPL>(table_grad, row, p.stride, p.dim, j, v, sgn);
+    if (j == 0) touched[row] = p.tag;
+  }
+}
 
 // One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
 template <int FPL>
 __device__ __forceinline__ float independent_triple(const ScoreParams& p, float* __restrict__ grel, int j, int h, int r,
-                                                    int t, float w, float sign) {
+                                                    int t, float w, float sign, int64_t slot0) {
   float H[FPL], R[FPL], T[FPL];
   load_row<FPL>(p.ent, h, p.stride, j, H);
   load_row<FPL>(p.rel, r, p.stride, j, R);
@@ -77,14 +101,9 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
     const float c = 2.0f * sign * w * p.scale * sigmoid_f(z);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) H[k] *= c;
-    atomic_add_row<FPL>(p.gent, h, p.stride, p.dim, j, H, 1.0f);
-    atomic_add_row<FPL>(grel, r, p.stride, p.dim, j, H, 1.0f);
-    atomic_add_row<FPL>(p.gent, t, p.stride, p.dim, j, H, -1.0f);
-    if (j == 0) {
-      p.tent[h] = p.tag;
-      p.tent[t] = p.tag;
-      p.trel[r] = p.tag;
-    }
+    emit_row<FPL>(p, false, p.gent, p.tent, h, slot0, j, H, 1.0f);
+    emit_row<FPL>(p, true, grel, p.trel, r, slot0 + 1, j, H, 1.0f);
+    emit_row<FPL>(p, false, p.gent, p.tent, t, slot0 + 2, j, H, -1.0f);
   }
   return l;
 }
@@ -95,11 +114,17 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // butterfly steps and flush them with ONE scatter of three rows (quarter 0 -> head row, 1 -> relation row,
 // 2 -> tail row).  Lanes of one wave-instruction therefore never add to the same address (measured on
 // MI355X: S quarter-waves of one wave adding to the same rows cost ~15-25 us per extra S at this shape).
-template <int FPL, int U, bool X>  // X: exclusive-row fast path compiled in
+// QPG (quarter-waves per group): 4 = the wavefront owns one group; 2 = each HALF of the wavefront owns a group of its own
+// (short groups: with the reference's default 10 negatives a whole wavefront leaves a third of its quarter-wave slots
+// idle in the last round and pays the positive's three row loads per 11 triples instead of per 22).
+template <int FPL, int U, bool X, int QPG>  // X: exclusive-row fast path compiled in
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
-  const int q = lane >> 4;
+  const int q4 = lane >> 4;
+  constexpr int GPW = 4 / QPG;             // groups per wavefront
+  const int sub = QPG == 4 ? 0 : (q4 >> 1);  // which group of the wavefront this lane works for
+  const int q = QPG == 4 ? q4 : (q4 & 1);    // quarter-wave index inside the group
   const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
   const bool bwd = p.gent != nullptr;
@@ -107,9 +132,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 
   const int npp = p.npp;
   if (npp > 0) {
-    const int S = p.splits;  // wavefronts sharing one group's negatives
-    const int64_t nwork = p.n_pos * S;
-    for (int64_t wk = wave0; wk < nwork; wk += nwaves) {
+    const int S = p.splits;  // wavefronts sharing one group's negatives (1 when QPG == 2)
+    const int64_t nitems = p.n_pos * S;
+    const int64_t nwork = (nitems + GPW - 1) / GPW;
+    for (int64_t wv = wave0; wv < nwork; wv += nwaves) {
+      const int64_t wk_raw = wv * GPW + sub;
+      const bool active = wk_raw < nitems;       // the second half of the last wavefront may have no group
+      const int64_t wk = active ? wk_raw : 0;
       const int64_t g = wk % p.n_pos;  // slices of one group are n_pos work items apart: different CUs
       const int s = (int)(wk / p.n_pos);
       float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
@@ -131,7 +160,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         RT[k] = R[k] - T[k];
       }
 
-      if (s == 0 && q == 0) {  // the positive itself
+      if (s == 0 && q == 0 && active) {  // the positive itself
         const float w = p.pw ? p.pw[g] : 1.0f;
         float d[FPL];
         float x = 0.f;
@@ -153,10 +182,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       // this wave's slice of the group's negatives; quarter q takes n_lo+q, n_lo+q+4, ...
       const int per = (npp + S - 1) / S;
       const int n_lo = s * per;
-      const int n_hi = min(npp, n_lo + per);
+      const int n_hi = active ? min(npp, n_lo + per) : n_lo;
       const int64_t nbase = g * (int64_t)npp;
       bool any_slow = false;
-      for (int n0 = n_lo + q; n0 < n_hi; n0 += 4 * U) {
+      for (int n0 = n_lo + q; n0 < n_hi; n0 += QPG * U) {
         int e[U], cnt[U];
         bool fast[U], sideH[U];
         float w[U];
@@ -165,7 +194,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         // phase 1: ids
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int n = n0 + 4 * u;
+          const int n = n0 + QPG * u;
           const bool live = n < n_hi;
           const int64_t idx = nbase + (live ? n : n_lo);
           const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
@@ -261,8 +290,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                 }
                 if (j == 0) p.refcount[e[u]] = 0;
               } else {
-                atomic_add_row<FPL>(p.gent, e[u], p.stride, p.dim, j, d, sideH[u] ? 1.0f : -1.0f);
-                if (j == 0) p.tent[e[u]] = p.tag;
+                emit_row<FPL>(p, false, p.gent, p.tent, e[u], stage_slot(g, npp, n0 + QPG * u, sideH[u] ? 0 : 2), j, d,
+                              sideH[u] ? 1.0f : -1.0f);
               }
             }
           }
@@ -273,36 +302,48 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         // rare: negatives that are not "the positive with exactly one entity replaced" (both sides or the
         // relation differ, or the negative equals the positive) are scored as independent triples
 #pragma unroll 1
-        for (int n = n_lo + q; n < n_hi; n += 4) {
+        for (int n = n_lo + q; n < n_hi; n += QPG) {
           const int64_t idx = nbase + n;
           const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
           if (!((nr == pr) && ((nh != ph) != (nt != pt))))
-            loss += independent_triple<FPL>(p, grel, j, nh, nr, nt, p.nw ? p.nw[idx] : 1.0f, -1.0f);
+            loss += independent_triple<FPL>(p, grel, j, nh, nr, nt, p.nw ? p.nw[idx] : 1.0f, -1.0f, stage_slot(g, npp, n, 0));
         }
       }
 
       if (bwd) {
-        // reduce the shared rows' gradients over the four quarter-waves (all lanes converge here)
+        // reduce the shared rows' gradients over the group's quarter-waves (all lanes converge here)
         // every negative's c*d went into exactly one of gH / gT and the positive's into both: the relation row's gradient
         // is their sum minus the positive's term once
         float gR[FPL];
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
           gR[k] = (gH[k] + gT[k]) - gP[k];
-          gH[k] += __shfl_xor(gH[k], 16, 64); gH[k] += __shfl_xor(gH[k], 32, 64);
-          gR[k] += __shfl_xor(gR[k], 16, 64); gR[k] += __shfl_xor(gR[k], 32, 64);
-          gT[k] += __shfl_xor(gT[k], 16, 64); gT[k] += __shfl_xor(gT[k], 32, 64);
+          gH[k] += __shfl_xor(gH[k], 16, 64);
+          gR[k] += __shfl_xor(gR[k], 16, 64);
+          gT[k] += __shfl_xor(gT[k], 16, 64);
+          if (QPG == 4) {
+            gH[k] += __shfl_xor(gH[k], 32, 64);
+            gR[k] += __shfl_xor(gR[k], 32, 64);
+            gT[k] += __shfl_xor(gT[k], 32, 64);
+          }
         }
-        if (s == 0 || n_lo < n_hi) {
-          // one scatter instruction stream covers the three rows: quarter 0 -> h, 1 -> r, 2 -> t
-          float v[FPL];
+        if (active && (s == 0 || n_lo < n_hi)) {
+          if (QPG == 4) {
+            // one scatter instruction stream covers the three rows: quarter 0 -> h, 1 -> r, 2 -> t
+            float v[FPL];
 #pragma unroll
-          for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : (q == 1 ? gR[k] : -gT[k]);
-          float* __restrict__ base = q == 1 ? grel : p.gent;
-          const int row = q == 0 ? ph : (q == 1 ? pr : pt);
-          if (q < 3) {
-            atomic_add_row<FPL>(base, row, p.stride, p.dim, j, v, 1.0f);
-            if (j == 0) (q == 1 ? p.trel : p.tent)[row] = p.tag;
+            for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : (q == 1 ? gR[k] : -gT[k]);
+            float* __restrict__ base = q == 1 ? grel : p.gent;
+            const int row = q == 0 ? ph : (q == 1 ? pr : pt);
+            if (q < 3) emit_row<FPL>(p, q == 1, base, q == 1 ? p.trel : p.tent, row, stage_slot(g, npp, npp, q), j, v, 1.0f);
+          } else {
+            // two quarter-waves per group: quarter 0 -> h, quarter 1 -> t, then quarter 0 -> r
+            float v[FPL];
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : -gT[k];
+            const int row = q == 0 ? ph : pt;
+            emit_row<FPL>(p, false, p.gent, p.tent, row, stage_slot(g, npp, npp, q == 0 ? 0 : 2), j, v, 1.0f);
+            if (q == 0) emit_row<FPL>(p, true, grel, p.trel, pr, stage_slot(g, npp, npp, 1), j, gR, 1.0f);
           }
         }
       }
@@ -314,10 +355,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
     for (int64_t i = sub0; i < p.n_pos + p.n_neg; i += nsub) {
       float* __restrict__ grel = bwd ? p.grel + (i % p.grel_copies) * p.grel_copy_elems : nullptr;
       if (i < p.n_pos) {
-        loss += independent_triple<FPL>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f);
+        loss += independent_triple<FPL>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f, i * 3);
       } else {
         const int64_t n = i - p.n_pos;
-        loss += independent_triple<FPL>(p, grel, j, p.nh[n], p.nr[n], p.nt[n], p.nw ? p.nw[n] : 1.0f, -1.0f);
+        loss += independent_triple<FPL>(p, grel, j, p.nh[n], p.nr[n], p.nt[n], p.nw ? p.nw[n] : 1.0f, -1.0f, i * 3);
       }
     }
   }
@@ -353,7 +394,8 @@ static int score_impl(
     const float* pos_w, int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t,
     const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
     int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream,
-    int32_t* ref_count, float* ent_w, float* ent_acc, int optimizer, float lr) {
+    int32_t* ref_count, float* ent_w, float* ent_acc, int optimizer, float lr, float* stage_rows = nullptr,
+    int64_t* stage_keys = nullptr, int64_t stage_slots = 0) {
   using namespace mke;
   if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
   if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
@@ -389,6 +431,12 @@ static int score_impl(
     if (s > neg_per_pos) s = neg_per_pos;
     splits = (int)s;
   }
+  if (stage_keys) {  // deterministic mode: one flush per group (its slot), every contribution has a slot of its own
+    splits = 1;
+    const int64_t need = (neg_per_pos > 0 ? n_pos * (neg_per_pos + 1) : n_pos + n_neg) * 3;
+    if (!stage_rows || !grad_ent || need > stage_slots) { set_error("deterministic mode: %lld staging slots needed, %lld given", (long long)need, (long long)stage_slots); return MKE_E_SHAPE; }
+  }
+  p.stage_rows = stage_rows; p.stage_keys = stage_keys;
   p.splits = splits;
   p.scale = scale;
   p.gent = grad_ent; p.grel = grad_rel; p.grel_copies = grad_rel_copies < 1 ? 1 : grad_rel_copies;
@@ -404,8 +452,15 @@ static int score_impl(
     // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
     // latency than the two extra gathers in flight did (41.9 -> 40.2 us at the C2 shape)
     constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);
-    if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
-    else hipLaunchKernelGGL((k_triple_score<FPL, U, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+    // short groups: two groups per wavefront (mke_set_option("score_half_groups", 0) switches it off)
+    const bool half = neg_per_pos > 0 && neg_per_pos <= g_score_half_max && splits == 1;
+    if (half) {
+      if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+    } else {
+      if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+    }
   });
   return check_launch("k_triple_score");
 }
@@ -436,6 +491,75 @@ extern "C" int mke_triple_score_fwd_bwd_x(
                     n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
                     touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
                     optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Deterministic mode: contributions were stored one per slot (emit_row); `order` = stable argsort of the slot keys, so the
+// contributions of one row are adjacent and in slot order.  One quarter-wave per segment head sums its segment front to
+// back and stores the row's gradient (the scratch is all-zero by invariant, so a store is an add).
+namespace mke {
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_stage_reduce(const float* __restrict__ stage_rows, const int64_t* __restrict__ keys,
+                                                            const int64_t* __restrict__ order, int64_t n, int stride,
+                                                            float* __restrict__ gent, float* __restrict__ grel,
+                                                            int32_t* __restrict__ tent, int32_t* __restrict__ trel, int32_t tag) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  for (int64_t i = sub0; i < n; i += nsub) {
+    const int64_t key = keys[i];
+    if (key >= (1ll << 41) || (i > 0 && keys[i - 1] == key)) continue;   // unused slot, or not the head of its segment
+    double acc[FPL];   // a hub row's gradient is a cancelling sum of hundreds of fp32 terms: summed in double, rounded once
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) acc[k] = 0.0;
+    for (int64_t m = i; m < n && keys[m] == key; ++m) {
+      const float* src = stage_rows + order[m] * stride + j;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) acc[k] += (double)src[k * 16];
+    }
+    const bool is_rel = (key & MKE_STAGE_REL) != 0;
+    const int64_t row = key & (MKE_STAGE_REL - 1);
+    float* o = (is_rel ? grel : gent) + row * stride + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) o[k * 16] = (float)acc[k];
+    if (j == 0) (is_rel ? trel : tent)[row] = tag;
+  }
+}
+}  // namespace mke
+
+extern "C" int mke_triple_score_fwd_bwd_det(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+    int32_t* ref_count, float* ent_acc, int optimizer, float lr, float* stage_rows, int64_t* stage_keys, int64_t stage_slots,
+    double* loss_partials, void* stream) {
+  using namespace mke;
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (ref_count && optimizer == MKE_OPT_ADAGRAD && !ent_acc) { set_error("exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  if (!stage_rows || !stage_keys) { set_error("mke_triple_score_fwd_bwd_det: NULL staging buffers"); return MKE_E_NULL; }
+  return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
+                    n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, 1, touched_ent, touched_rel, tag,
+                    loss_partials, stream, ref_count, ent_table, optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr,
+                    stage_rows, stage_keys, stage_slots);
+}
+
+extern "C" int mke_stage_reduce(const float* stage_rows, const int64_t* sorted_keys, const int64_t* order, int64_t n_slots, int stride,
+                                float* grad_ent, float* grad_rel, int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+                                void* stream) {
+  using namespace mke;
+  if (n_slots < 0) { set_error("mke_stage_reduce: negative count"); return MKE_E_SHAPE; }
+  if (n_slots == 0) return MKE_OK;
+  if (!stage_rows || !sorted_keys || !order || !grad_ent || !grad_rel || !touched_ent || !touched_rel) { set_error("mke_stage_reduce: NULL pointer"); return MKE_E_NULL; }
+  if (stride <= 0 || stride % 16 != 0 || stride > MKE_MAX_STRIDE) { set_error("mke_stage_reduce: bad stride %d", stride); return MKE_E_SHAPE; }
+  int64_t blocks = (n_slots + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK;
+  if (blocks > 4096) blocks = 4096;
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_stage_reduce<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, stage_rows, sorted_keys,
+                       order, n_slots, stride, grad_ent, grad_rel, touched_ent, touched_rel, tag);
+  });
+  return check_launch("k_stage_reduce");
 }
 
 extern "C" int mke_count_entity_refs(const int32_t* pos_h, const int32_t* pos_t, int64_t n_pos, const int32_t* neg_h,

@@ -93,6 +93,19 @@ class RelationViewRunner:
         """Enqueue steps [step_begin, step_end) of the current epoch (default: all).  A call with step_begin == 0
         starts a new epoch (fresh tag range); other calls continue the current one."""
         step_end = self.steps if step_end is None else step_end
+        if _lib.get_option("deterministic"):
+            # parity / debugging mode: step by step through StepEngine's deterministic path (fixed-order gradient sums)
+            from .tables import StepEngine
+            if getattr(self, "_det_engine", None) is None:
+                self._det_engine = StepEngine(self.ent.device, loss_ring=max(2, self.steps))
+                self._det_engine.tag = 1 << 29
+            for s in range(step_begin, step_end):
+                pos, neg = self.bat.batch(s)
+                lp = self._det_engine.relation_step(self.ent, self.rel, self.opt_name, pos, neg if self.bat.neg_per_pos else None,
+                                                    neg_per_pos=self.bat.neg_per_pos, lr=self.lr, scale=self.scale,
+                                                    optimizer=self.optimizer, exclusive_rows=self.exclusive_rows)
+                self.loss[s].copy_(lp)
+            return
         if step_begin == 0 or self._epoch_tag_base is None:
             self._epoch_tag_base = self.tag
             self.tag += self.steps

@@ -148,6 +148,9 @@ class StepEngine:
         """loss + optimizer of a relation-view style graph (a1/a2/a3).  Returns the loss partials (a view into the
         ring; `.sum()` is the loss) without synchronising.  With grouped negatives the exclusive-row fast path is
         used (rows referenced once in the step are updated by the scoring quarter-wave itself)."""
+        if update and optimizer in _OPT and _lib.get_option("deterministic"):
+            return self._relation_step_deterministic(ent, rel, opt_name, pos, neg, neg_per_pos, lr, pos_w, neg_w, scale,
+                                                     optimizer, exclusive_rows)
         tag, lp = self._next()
         if update and exclusive_rows and neg is not None and neg_per_pos > 0 and optimizer in _OPT:
             _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], neg_per_pos, ent.refcount)
@@ -166,6 +169,42 @@ class StepEngine:
         if update:
             self._apply(ent, opt_name, optimizer, lr, tag)
             self._apply(rel, opt_name, optimizer, lr, tag)
+        return lp
+
+    def _relation_step_deterministic(self, ent, rel, opt_name, pos, neg, neg_per_pos, lr, pos_w, neg_w, scale, optimizer,
+                                     exclusive_rows):
+        """`mke_set_option("deterministic", 1)`: every gradient-row contribution is stored into a slot of its own
+        (mke_triple_score_fwd_bwd_det), a stable sort of the slot keys brings a row's contributions together in slot
+        order, mke_stage_reduce sums them front to back: bit-identical results from run to run, and hub rows whose
+        gradient is a cancelling sum of hundreds of terms are summed in ONE order (the atomic path's order changes from
+        run to run).  Rows referenced once are still finished in place (one contribution: no order to fix)."""
+        tag, lp = self._next()
+        n_pos = pos[0].numel()
+        n_neg = 0 if neg is None else neg[0].numel()
+        slots = 3 * (n_pos * (neg_per_pos + 1) if neg_per_pos > 0 else n_pos + n_neg)
+        st = getattr(self, "_stage", None)
+        if st is None or st[0].shape[0] < slots or st[0].shape[1] != ent.stride:
+            st = self._stage = (torch.empty(max(slots, 1), ent.stride, dtype=torch.float32, device=self.device),
+                                torch.empty(max(slots, 1), dtype=torch.int64, device=self.device))
+        rows, keys = st[0][:max(slots, 1)], st[1][:max(slots, 1)]
+        keys.fill_(0x7F7F7F7F7F7F7F7F)
+        adagrad = optimizer == "Adagrad"
+        acc = ent.slot(opt_name) if adagrad else None
+        refc = None
+        if exclusive_rows and neg is not None and neg_per_pos > 0:
+            _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], neg_per_pos, ent.refcount)
+            refc = ent.refcount
+        grel = rel.grad if rel.grad.dim() == 2 else rel.grad[0]
+        _lib.triple_score_fwd_bwd_det(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
+                                      neg_per_pos, scale, ent.grad, grel, ent.touched, rel.touched, tag, refc, acc,
+                                      _OPT[optimizer], lr, rows, keys, lp)
+        sorted_keys, order = torch.sort(keys, stable=True)
+        _lib.stage_reduce(rows, sorted_keys, order, ent.grad, grel, ent.touched, rel.touched, tag)
+        _lib.rows_update_multi([(rel.data, rel.slot(opt_name) if adagrad else None, rel.grad, rel.touched, rel.normalize),
+                                (ent.data, acc, ent.grad, ent.touched, ent.normalize, ent.refcount if refc is not None else None)]
+                               if refc is not None else
+                               [(rel.data, rel.slot(opt_name) if adagrad else None, rel.grad, rel.touched, rel.normalize),
+                                (ent.data, acc, ent.grad, ent.touched, ent.normalize)], tag, ent.stride, ent.dim, _OPT[optimizer], lr)
         return lp
 
     def alignment_step(self, terms, opt_name: str, lr: float, optimizer="Adagrad") -> torch.Tensor:

@@ -72,7 +72,11 @@ def test_rowset_overflow_is_flagged():
     flags, id_map, counts, overflow = torch.zeros(100, **i32), torch.zeros(100, **i32), torch.zeros(2, **i32), torch.zeros(1, **i32)
     req = torch.full((2 * 10,), -1, **i32)
     _lib.rowset_build([ids], flags, counts, req, id_map, overflow, 2, 10)
-    assert int(overflow) == 1 and int(id_map.max()) < 20
+    # ids beyond an owner's capacity go to the PAD row behind the compact row set (index G*C), never to another entity's slot
+    m = id_map.cpu().numpy()
+    assert int(overflow) == 1 and int(m.max()) == 20 and int((m == 20).sum()) == 80
+    real = np.sort(m[m < 20])
+    assert np.array_equal(real, np.arange(20))                      # the 20 slots that exist are each used exactly once
 
 
 @pytest.mark.parametrize("G,n_local,C,dim", [(1, 3000, 1500, 75), (8, 2500, 900, 75), (3, 700, 700, 20), (16, 64, 40, 256)])

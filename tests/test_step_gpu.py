@@ -140,6 +140,94 @@ def test_variants(variant):
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=ROW_RTOL, atol=ROW_ATOL)
 
 
+@pytest.mark.parametrize("P,N,half", [(333, 10, 12), (333, 10, 0), (1, 3, 12), (64, 12, 12), (77, 1, 12)])
+def test_two_groups_per_wavefront_equals_one(P, N, half):
+    """Short groups are scored two per wavefront (each half owns a group; `score_half_groups`): same losses and tables as
+    the one-group-per-wavefront form and as the oracle, odd group counts (the last wavefront's second half idle) included."""
+    from gpu_util import dev_i32, grouped_batch, make_tables
+    from multike_amd import _lib
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(P * 100 + N)
+    d, n_ent, n_rel = 75, 4000, 13
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    pos, neg = grouped_batch(rng, n_ent, n_rel, P, N)
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    old_s = _lib.set_option("score_splits", 1)
+    old_h = _lib.set_option("score_half_groups", half)
+    try:
+        E, R = make_tables(ent, rel)
+        eng = StepEngine()
+        for step in range(2):
+            L, _, _ = mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01)
+            lp = eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg),
+                                   neg_per_pos=N, lr=0.01)
+            np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+        np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=ROW_RTOL, atol=ROW_ATOL)
+        np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=2e-6)
+        assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0 and int(E.refcount.abs().sum()) == 0
+    finally:
+        _lib.set_option("score_splits", old_s)
+        _lib.set_option("score_half_groups", old_h)
+
+
+@pytest.mark.parametrize("n_ent,P,N,excl", [(300, 400, 25, True), (300, 400, 25, False), (5000, 2000, 10, True), (200, 300, 0, True)])
+def test_deterministic_mode_hub_rows(n_ent, P, N, excl):
+    """`mke_set_option("deterministic", 1)`: fixed-order gradient sums.  On the heavy-collision (Zipf) batches whose hub
+    rows sum hundreds of cancelling fp32 terms: (1) two runs are BIT-identical (tables, accumulators, losses), (2) rows agree
+    with the float64 oracle to 1e-4 and the accumulator to 1e-3 on EVERY run (the atomic path's accumulator check is 1e-2
+    because single elements land a few 1e-3 off in about one run out of 25; what is left here — 2 elements of 375,000 at
+    5e-4 — is the fp32 Jacobian (g - w^(w^.g)) / |w| of rows whose gradient is nearly parallel to the row, not the sum)."""
+    from gpu_util import dev_i32, make_tables
+    from multike_amd import _lib
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(n_ent + P)
+    d, n_rel = 75, 7
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    pr_ = 1.0 / np.arange(1, n_ent + 1)
+    pr_ /= pr_.sum()
+    ph, pt = rng.choice(n_ent, P, p=pr_), rng.choice(n_ent, P, p=pr_)
+    prl = rng.integers(0, n_rel, P)
+    M = max(N, 1)
+    nh, nt, nr = np.repeat(ph, M), np.repeat(pt, M), np.repeat(prl, M)
+    side = rng.integers(0, 2, P * M).astype(bool)
+    c = rng.integers(0, n_ent, P * M)
+    nh, nt = np.where(side, c, nh), np.where(side, nt, c)
+    nh[3], nt[3] = rng.integers(0, n_ent, 2)                       # an irregular negative (independent-triple path)
+    pos = tuple(a.astype(np.int32) for a in (ph, prl, pt))
+    neg = tuple(a.astype(np.int32) for a in (nh, nr, nt)) if N else None
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    losses64 = [mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01)[0] for _ in range(2)]
+    old = _lib.set_option("deterministic", 1)
+    try:
+        runs = []
+        for rep in range(2):
+            E, R = make_tables(ent, rel)
+            eng = StepEngine()
+            ls = []
+            for step in range(2):
+                lp = eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos),
+                                       None if neg is None else tuple(dev_i32(a) for a in neg), neg_per_pos=N, lr=0.01,
+                                       exclusive_rows=excl)
+                ls.append(lp.clone())
+            runs.append((E.data.clone(), R.data.clone(), E.slot("relation").clone(), R.slot("relation").clone(), torch.stack(ls)))
+            assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+            assert E._refcount is None or int(E.refcount.abs().sum()) == 0
+        for x, y in zip(*runs):
+            assert torch.equal(x, y)                               # bit-identical from run to run
+        E_data, R_data, E_acc, R_acc, ls = runs[0]
+        np.testing.assert_allclose(ls.sum(1).cpu().numpy(), losses64, rtol=LOSS_RTOL)
+        np.testing.assert_allclose(E_data[:, :d].cpu().numpy(), e64, rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(R_data[:, :d].cpu().numpy(), r64, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(E_acc[:, :d].cpu().numpy(), a64, rtol=1e-3, atol=1e-6)
+        assert np.mean(np.abs(E_acc[:, :d].cpu().numpy() - a64) > 1e-4 * np.abs(a64) + 1e-6) < 1e-5
+    finally:
+        _lib.set_option("deterministic", old)
+
+
 def test_edge_cases():
     from gpu_util import dev_i32, make_tables
     from multike_amd import _lib
