@@ -58,6 +58,7 @@ const char* mke_last_error(void);
 
 /* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
  *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
+ *   "update_chunk"  : rows per wavefront of the row-update kernels on large tables: 0 = by table size (default), 16, 64
  *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
  *                     kernels themselves are selected by which entry point is called)
  *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per

@@ -176,6 +176,11 @@ def lib():
         L.mke_ae_scratch_floats.restype = C.c_int64
         L.mke_oc_block_floats.restype = C.c_int64
         _lib = L
+        # MKE_OPTIONS="name=value,name=value": mke_set_option calls applied at load (performance knobs for experiments)
+        for kv in filter(None, os.environ.get("MKE_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            if L.mke_set_option(k.strip().encode(), C.c_int(int(v)), None):
+                raise MultiKEHipError(f"MKE_OPTIONS: {L.mke_last_error().decode()}")
     return _lib
 
 

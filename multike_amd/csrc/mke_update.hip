@@ -118,7 +118,9 @@ template <int FPL, bool SHARD>
 __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, int j, int q) {
   const int64_t base = wave * p.chunk;
   if (base >= p.n_rows) return;  // wave-uniform
-  const int64_t r = base + (j & (p.chunk - 1));
+  // chunk <= 16: the four quarter-waves hold the same flags (lane j <-> row base + j); chunk == 64: one flag per lane
+  const int lane = q * 16 + j;
+  const int64_t r = base + (p.chunk == 64 ? lane : (j & (p.chunk - 1)));
   bool mine = r < p.n_rows;
   if (SHARD && mine && p.slot_of) {
     const int32_t* so = p.slot_of + r * (int64_t)p.n_ranks;
@@ -128,13 +130,13 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
   } else if (mine) {
     mine = p.touched == nullptr || p.touched[r] == p.tag;
   }
-  const uint32_t m = (uint32_t)(__ballot(mine) & ((1ull << p.chunk) - 1ull));  // the quarters hold the same flags
-  const int total = __popc(m);
-  for (int round = 0; round * 4 < total; ++round) {
-    const int target = round * 4 + q;
-    uint32_t t = m;
-    for (int k = 0; k < target; ++k) t &= t - 1;  // drop the `target` lowest set bits (<= 15 iterations)
-    if (target < total) update_one_row<FPL, SHARD>(p, base + __builtin_ctz(t), j);
+  uint64_t m = __ballot(mine);
+  if (p.chunk < 64) m &= (1ull << p.chunk) - 1ull;
+  // quarter q takes the q-th, (q+4)-th, ... set bit: a running copy of the mask with the bits already dealt removed
+  for (int k = 0; k < q; ++k) m &= m - 1;
+  while (__ballot(m != 0)) {   // wave-uniform trip count: the quarters visit their rows of a round together
+    if (m) update_one_row<FPL, SHARD>(p, base + __builtin_ctzll(m), j);
+    m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
   }
 }
 
@@ -193,7 +195,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   walk_chunk<FPL, SHARD>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
-static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : 16; }
+extern int g_update_chunk;  // mke_set_option("update_chunk"): rows per wavefront for large tables (16 or 64)
+// 4 rows for small dense tables (every quarter-wave gets a row at once); 16 for tables where a step touches a good share of the
+// rows (C2: 17 % of 200K: 2.8 flags set per 16); 64 (one flag per lane) for large tables touched sparsely (C5: 1.7 % of 2M rows —
+// a quarter as many wavefronts, each still finding about one row: 77 -> 59 us).  "update_chunk" = 16 / 64 forces one.
+static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : (g_update_chunk ? g_update_chunk : (n_rows > 500000 ? 64 : 16)); }
 
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count = nullptr, const DenseJob* dense = nullptr) {
@@ -264,7 +270,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   p.refcount = nullptr;
   p.src_rows = nullptr; p.slot_of = nullptr; p.n_ranks = 0; p.capacity = 0;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
-  p.chunk = n_rows <= 16384 ? 4 : 16;
+  p.chunk = chunk_for(n_rows);
   const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * p.chunk;
   const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
   hipStream_t st = (hipStream_t)stream;

@@ -13,7 +13,9 @@ ap.add_argument("--n-ent", type=int, default=200_000); ap.add_argument("--n-rel"
 ap.add_argument("--dim", type=int, default=75); ap.add_argument("--neg", type=int, default=25)
 ap.add_argument("--batch", type=int, default=5000); ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--splits", type=str, default="0,1,2,3,4,5"); ap.add_argument("--copies", type=int, default=1); ap.add_argument("--zipf", type=float, default=0.0)
+ap.add_argument("--update-chunk", type=int, default=0)
 a = ap.parse_args()
+_lib.set_option("update_chunk", a.update_chunk)
 kgs = SyntheticKGs(n_ent=a.n_ent, n_rel=a.n_rel, zipf=a.zipf)
 d, N = a.dim, a.neg
 E = EmbeddingTable(kgs.entities_num, d, "e", seed=1); R = EmbeddingTable(kgs.relations_num, d, "r", seed=2, grad_copies=a.copies)
