@@ -212,7 +212,48 @@ def reference_default_variants(args, kgs, ent0, rel0, sides):
             row["knn_refresh_ms_untimed"] = knn_ms
         out.append(row)
         del runner, bat, E, R, vs
+    out.append(attribute_step_variant(args))
     return out
+
+
+def attribute_step_variant(args):
+    """Side line: one attribute-view step (code/MultiKE_model.py:134-151 + conv :34-63) at the same batch size — the other
+    half of an ITC epoch's GPU time.  Bytes per triple (algorithmic): 3 row gathers (entity, attribute, literal) + 2 gradient
+    rows (entity, attribute) + 4 ids/weight = 5 * 4 * dim + 16; flops per triple: 2 * (4 dim * dim dense + 7.2K conv MACs)
+    forward, ~3x that with the backward.  The step is 7 dependent launches of 7-20 us at this size: it is bound by kernel
+    floors and latency, not by HBM or the matrix pipe — the roofline block says how far below both it sits."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    d, B = args.dim, args.batch
+    n_ent, n_attr, n_lit = args.n_ent, 600, 100_000
+    E = EmbeddingTable(n_ent, d, "av_ent_embeds", seed=1)
+    A = EmbeddingTable(n_attr, d, "attr_embeds", normalize=False, seed=2)
+    lit = torch.nn.functional.normalize(torch.randn(n_lit, d, generator=torch.Generator().manual_seed(0)), dim=1).numpy()
+    L = EmbeddingTable(n_lit, d, "literal_embeds", normalize=False, trainable=False, values=lit)
+    cnn, eng = AttrCNN(d, seed=3), StepEngine()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    n_steps = 120
+    ih = torch.randint(0, n_ent, (n_steps * B,), device="cuda", generator=g, dtype=torch.int32)
+    ia = torch.randint(0, n_attr, (n_steps * B,), device="cuda", generator=g, dtype=torch.int32)
+    iv = torch.randint(0, n_lit, (n_steps * B,), device="cuda", generator=g, dtype=torch.int32)
+    w = torch.rand(n_steps * B, device="cuda", generator=g)
+    off = np.arange(n_steps + 1, dtype=np.int64) * B
+    cnn.steps(eng, E, A, L, ih, ia, iv, w, off[:11])          # warm-up: 10 steps, one native call
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cnn.steps(eng, E, A, L, ih, ia, iv, w, off)               # the epoch loop as ONE native call (mke_attr_steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    bytes_per = 5 * 4 * d + 16
+    flops_per = 3 * 2 * (4 * d * d + 7200)
+    return {"name": "attribute-view step (CNN scorer, fwd + bwd + updates)", "value": B / dt, "unit": "attribute triples/s",
+            "steps": n_steps, "ms_per_step": dt * 1e3, "scored_per_step": B,
+            "roofline": {"bound": "launch floors / latency (7 dependent launches per step)",
+                         "alg_bytes_per_triple": bytes_per, "achieved_GBps": B * bytes_per / dt / 1e9,
+                         "frac_hbm": B * bytes_per / dt / 1e9 / HBM_PEAK_GBS,
+                         "flops_per_triple": flops_per, "achieved_TFLOPs": B * flops_per / dt / 1e12,
+                         "frac_f32_matrix_peak": B * flops_per / dt / 1e12 / 157.3}}
 
 
 def host_threads():
