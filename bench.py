@@ -353,8 +353,11 @@ def main():
         else:
             from multike_amd.distributed_oc import OcHostStagedComm, OwnerComputesTrainer
             chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 else "1"))
+            # MKE_SHARD_PEER=1: peer-mapped blocks read / written directly by the score kernel instead of the all-gather /
+            # reduce-scatter (opt-in: exercised with two ranks on one GPU only)
             trainer = OwnerComputesTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, chunks=chunks,
-                                           comm=OcHostStagedComm() if staged else None)
+                                           comm=OcHostStagedComm() if staged else None,
+                                           peer_direct=os.environ.get("MKE_SHARD_PEER", "0") == "1")
         run_step = trainer.step
         n_steps_epoch = trainer.steps
         triples_of = trainer.global_scored

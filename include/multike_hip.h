@@ -710,6 +710,12 @@ typedef struct mke_oc_step {
   int neg_per_pos; int64_t capacity;
   const int32_t* codes; int64_t code_off[MKE_OC_MAX_RANKS];
   int optimizer; float lr, scale; int32_t tag;
+  /* peer-direct mode (n_peers == n_ranks; 0 = the blocks are exchanged by collectives): peer_v[o] = rank o's SEND block,
+   * peer_g[o] = this rank's slice [2 * capacity][stride] of rank o's gradient inbox — both mapped into this process
+   * (hipIpc): mke_oc_score reads the vectors and writes its partial gradient vectors straight over xGMI, mke_oc_apply sums
+   * the n_ranks slices of its own inbox in rank order.  The caller places a cross-GPU barrier after mke_oc_bases and after
+   * mke_oc_score. */
+  int n_peers; const float* peer_v[MKE_OC_MAX_RANKS]; float* peer_g[MKE_OC_MAX_RANKS];
 } mke_oc_step;
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output */

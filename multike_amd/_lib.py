@@ -97,7 +97,8 @@ class OcStepStruct(C.Structure):
                 ("slot_h", C.c_void_p), ("slot_t", C.c_void_p), ("own_h", C.c_void_p), ("n_own_h", C.c_int64),
                 ("own_t", C.c_void_p), ("n_own_t", C.c_int64), ("neg_per_pos", C.c_int), ("capacity", C.c_int64),
                 ("codes", C.c_void_p), ("code_off", C.c_int64 * 16),
-                ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32)]
+                ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32),
+                ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16)]
 
 
 class AEPlanStruct(C.Structure):

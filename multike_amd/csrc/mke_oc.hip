@@ -106,11 +106,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   for (int64_t i = wave0; i < s.n_pos; i += nwaves) {
     const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
     const int home = (int)(i / s.per);
-    const int64_t slot_h = (int64_t)(ph % G) * p.block_floats + (int64_t)s.slot_h[i] * s.stride;
-    const int64_t slot_t = (int64_t)(pt % G) * p.block_floats + (C + s.slot_t[i]) * s.stride;
+    // the vectors' home: this rank's all-gathered copy, or (peer-direct) the owner's own send block over xGMI
+    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * s.stride;
+    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * s.stride;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
-    load_row<FPL>(p.v_all + slot_h, 0, s.stride, j, HR);
-    load_row<FPL>(p.v_all + slot_t, 0, s.stride, j, RT);
+    load_row<FPL>(vh, 0, s.stride, j, HR);
+    load_row<FPL>(vt, 0, s.stride, j, RT);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
     int code = 0;
@@ -241,8 +242,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     }
     if (q < 2) {
       const int64_t gb = 2 * C * (int64_t)s.stride;
-      float* o = p.g_all + (q == 0 ? (int64_t)(ph % G) * gb + (int64_t)s.slot_h[i] * s.stride
-                                   : (int64_t)(pt % G) * gb + (C + s.slot_t[i]) * s.stride) + j;
+      const int own = q == 0 ? ph % G : pt % G;
+      float* o = (s.n_peers ? s.peer_g[own] : p.g_all + (int64_t)own * gb) +
+                 (q == 0 ? (int64_t)s.slot_h[i] : C + s.slot_t[i]) * s.stride + j;
 #pragma unroll
       for (int k = 0; k < FPL; ++k) o[k * 16] = q == 0 ? gHR[k] : gRT[k];
     }
@@ -266,6 +268,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
   const int r = s.pos_r[pos];
   float v[FPL];
   load_row<FPL>(p.gv, (is_h ? 0 : s.capacity) + k, s.stride, j, v);
+  if (s.n_peers) {  // peer-direct: gv is this rank's inbox [n_ranks][2 C][stride]; sum the writers' slices in rank order
+    const int64_t gb = 2 * s.capacity * (int64_t)s.stride;
+    for (int r = 1; r < s.n_ranks; ++r) {
+      float w[FPL];
+      load_row<FPL>(p.gv + r * gb, (is_h ? 0 : s.capacity) + k, s.stride, j, w);
+#pragma unroll
+      for (int c = 0; c < FPL; ++c) v[c] += w[c];
+    }
+  }
   atomic_add_row<FPL>(s.ent_grad, row, s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
   float* grel = s.rel_grad + (sub % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
   atomic_add_row<FPL>(grel, r, s.stride, s.dim, j, v, 1.0f);
@@ -284,6 +295,9 @@ static int oc_check(const mke_oc_step* s, const char* who) {
   if (s->rel_grad_copies < 1 || s->rel_grad_copies > 64) { set_error("%s: rel_grad_copies must be in [1,64]", who); return MKE_E_SHAPE; }
   if (s->n_pos > 0 && (!s->pos_h || !s->pos_r || !s->pos_t || !s->slot_h || !s->slot_t)) { set_error("%s: NULL positive / slot stream", who); return MKE_E_NULL; }
   if (s->n_pos * s->neg_per_pos > 0 && !s->codes) { set_error("%s: NULL negative codes", who); return MKE_E_NULL; }
+  if (s->n_peers != 0 && s->n_peers != s->n_ranks) { set_error("%s: n_peers must be 0 or n_ranks", who); return MKE_E_SHAPE; }
+  for (int g = 0; g < s->n_peers; ++g)
+    if (!s->peer_v[g] || !s->peer_g[g]) { set_error("%s: NULL peer block %d", who, g); return MKE_E_NULL; }
   if ((s->n_own_h > 0 && !s->own_h) || (s->n_own_t > 0 && !s->own_t)) { set_error("%s: NULL owned-slot list", who); return MKE_E_NULL; }
   if (!s->ent || !s->rel) { set_error("%s: NULL table", who); return MKE_E_NULL; }
   if (s->optimizer != MKE_OPT_ADAGRAD && s->optimizer != MKE_OPT_SGD) { set_error("%s: Adagrad or SGD", who); return MKE_E_UNSUPPORTED; }
@@ -347,7 +361,7 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   using namespace mke;
   int rc = oc_check(s, "mke_oc_score");
   if (rc) return rc;
-  if (!v_all || !g_all || !loss_partials || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_score: NULL pointer"); return MKE_E_NULL; }
+  if ((!s->n_peers && (!v_all || !g_all)) || !loss_partials || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_score: NULL pointer"); return MKE_E_NULL; }
   if (s->ref_count && s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_score: the exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
   OcParams p{};
   p.s = *s; p.v_all = v_all; p.block_floats = block_floats; p.g_all = g_all; p.lossp = loss_partials;

@@ -102,6 +102,13 @@ class OcHipBackend:
         for g, o in enumerate(st.code_off):
             s.code_off[g] = int(o)
         s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, 1.0, st.tag
+        s.n_peers = 0
+        if tr.peer_direct and tr.world > 1:   # peer-mapped blocks (chunk 0: peer-direct runs unchunked)
+            gb = 2 * tr.C * tr.stride * 4
+            s.n_peers = tr.world
+            for g in range(tr.world):
+                s.peer_v[g] = tr._peer_send[g].data_ptr()
+                s.peer_g[g] = tr._peer_inbox[g].data_ptr() + tr.rank * gb
         return s
 
     def _cached(self, tr, st):
@@ -122,7 +129,8 @@ class OcHipBackend:
             self._steps = []
             return
         oh, ot = _lib.ptr(tr._own[0], i32, "own"), _lib.ptr(tr._own[1], i32, "own")
-        key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts))
+        key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts),
+               tr._peer_send[0].data_ptr() if tr.peer_direct and tr.world > 1 else 0)
         if getattr(self, "_steps_key", None) != key:      # first epoch, or a buffer was re-allocated: build the static part
             base = self._struct(tr, tr._build_part_step(0, 0))
             ph, pr, pt = (_lib.ptr(x, i32, "pos") for x in (b.pos_h, b.pos_r, b.pos_t))
@@ -195,6 +203,16 @@ class OcComm:
     def all_gather_list(self, parts, mine):
         dist.all_gather(parts, mine, group=self.group)
 
+    def barrier(self, token):
+        """Stream-ordered cross-rank barrier (peer-direct mode): a one-element all-reduce — every rank's stream passes it only
+        after every rank's stream has reached it; the host is not blocked."""
+        dist.all_reduce(token, group=self.group)
+
+    def all_gather_object(self, obj):
+        out = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
 
 class OcGlooComm(OcComm):
     """gloo has no reduce-scatter: all-reduce the whole buffer and keep this rank's block (CPU tests only)."""
@@ -235,11 +253,15 @@ class OcHostStagedComm(OcGlooComm):
         for p, c in zip(parts, cp):
             p.copy_(c)
 
+    def barrier(self, token):
+        torch.cuda.synchronize()           # gloo orders hosts, not streams
+        dist.barrier(group=self.group)
+
 
 class OwnerComputesTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
-                 exclusive_rows: bool = True, chunks: int = 1):
+                 exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False):
         self.backend = backend or OcHipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         if comm is None:
@@ -254,6 +276,12 @@ class OwnerComputesTrainer:
         self.n_ent = ent0.shape[0]
         self.batch_size = int(batch_size)
         self.chunks = max(1, int(chunks))
+        # peer-direct (opt-in): no all-gather / reduce-scatter — every rank maps the other ranks' send blocks and gradient
+        # inboxes (IPC handles exchanged once) and mke_oc_score reads / writes them straight over xGMI; two stream-ordered
+        # barriers per step.  Correct by construction and tested with two ranks on one GPU; not measured on several.
+        self.peer_direct = bool(peer_direct) and world > 1
+        if self.peer_direct:
+            self.chunks = 1
         dev, st = self.device, self.stride
         i32 = dict(dtype=torch.int32, device=dev)
         # --- row-sharded entity state ---------------------------------------------------------------
@@ -403,12 +431,31 @@ class OwnerComputesTrainer:
             self._v_all = [self._send[c] if G == 1 else mk(G * self.block) for c in range(self.chunks)]
             self._g_all = [mk(G * gb) for _ in range(self.chunks)]
             self._gv = [self._g_all[c] if G == 1 else mk(gb) for c in range(self.chunks)]
+            if self.peer_direct:
+                self._map_peers(gb)
             self._addr = [tuple(t.data_ptr() for t in (self._send[c], self._v_all[c], self._g_all[c], self._gv[c]))
                           for c in range(self.chunks)]
         self._planned_epoch = b.epoch
         self._st_cache = {}
         if hasattr(self.backend, "prepare_epoch"):
             self.backend.prepare_epoch(self)
+
+    def _map_peers(self, gb):
+        """Exchange IPC handles of this rank's send block and gradient inbox ([world][2 C][stride]: one slice per writer) and
+        map every peer's (torch's CUDA-IPC tensor reductions: hipIpcGetMemHandle / hipIpcOpenMemHandle underneath)."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        G = self.world
+        self._inbox = torch.zeros(G * gb, dtype=self._dtype, device=self.device)
+        self._gv = [self._inbox]
+        self._v_all = [self._send[0]]                      # unused in peer mode (kept non-null for the address table)
+        self._g_all = [self._inbox]
+        mine = (reduce_tensor(self._send[0]), reduce_tensor(self._inbox))
+        every = self.comm.all_gather_object(mine)
+        self._peer_send, self._peer_inbox = [], []
+        for g, ((f1, a1), (f2, a2)) in enumerate(every):
+            self._peer_send.append(self._send[0] if g == self.rank else f1(*a1))
+            self._peer_inbox.append(self._inbox if g == self.rank else f2(*a2))
+        self._bar = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def _persist(self, key, value, capacity):
         """Epoch buffers keep their device addresses across epochs (the native step descriptors point into them)."""
@@ -468,6 +515,18 @@ class OwnerComputesTrainer:
                         ev.append((e0, e1, (self._parts[k][2] - self._parts[k][1]) * (1 + self.N)))
                 for c, k in enumerate(ks):
                     be.run(self, k, tag, APPLY | (UPDATE if c == last else 0), c, slot0 + c)
+            self._stepped = i
+            return
+        if self.peer_direct:
+            for k in ks:
+                be.run(self, k, tag, BASES | COUNT, 0, slot0)
+                cm.barrier(self._bar)                        # every rank's vectors are in its send block
+                be.run(self, k, tag, SCORE, 0, slot0)        # reads peers' blocks, writes its slice of peers' inboxes
+                cm.barrier(self._bar)                        # every writer's slice of every inbox is complete
+                be.run(self, k, tag, APPLY, 0, slot0)
+            cm.all_reduce(self.rel_grad)
+            if ks:
+                be.run(self, ks[-1], tag, UPDATE, 0, slot0)
             self._stepped = i
             return
         pipelined = len(ks) > 1 and self.device.type == "cuda"

@@ -48,7 +48,7 @@ def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
     return e, r, losses, bat.steps
 
 
-def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
+def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, peer=False):
     from multike_amd.distributed_oc import OwnerComputesTrainer
     from multike_amd.synthetic import SyntheticKGs
     kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
@@ -56,7 +56,7 @@ def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg
     ent0 = mo.xavier_truncated_normal((n_ent, dim), rng)
     rel0 = mo.xavier_truncated_normal((N_REL, dim), rng)
     return OwnerComputesTrainer(kgs, ent0, rel0, b, neg, rank, world, seed=SEED, lr=0.02, comm=comm, chunks=chunks,
-                                exclusive_rows=excl)
+                                exclusive_rows=excl, peer_direct=peer)
 
 
 @pytest.mark.parametrize("chunks,excl,dim,neg", [(1, True, 75, 8), (2, True, 75, 25), (1, False, 75, 8), (1, True, 256, 64),
@@ -116,7 +116,7 @@ def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), R.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def _two_rank_worker(rank, world, port, ret, chunks, steps):
+def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -124,7 +124,7 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps):
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
-        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks)
+        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer)
         for i in range(steps):
             tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
@@ -137,8 +137,8 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks", [1, 2])
-def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks):
+@pytest.mark.parametrize("chunks,peer", [(1, False), (2, False), (1, True)])
+def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer):
     """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
     negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
     import torch.multiprocessing as mp
@@ -146,7 +146,9 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks):
     world, steps = 2, 7
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps)) for r in range(world)]
+    # peer = True: no all-gather / reduce-scatter — each process maps the other's send block and gradient inbox (IPC) and the
+    # score kernel reads / writes them directly
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, ok = ret.get(timeout=480)
