@@ -9,7 +9,7 @@ The reference has no multi-device code; this is new design.  One process per GPU
   * rows never leave their owner.  A negative differs from its positive (h, r, t) in one entity c and its score needs only
     c's row and one of two vectors of the positive — HR_p = h^ + r^ (corrupted tail: d = HR_p - c^) or RT_p = r^ - t^
     (corrupted head: d = c^ + RT_p) — so the NEGATIVES go to the rows.  Per global step:
-        (once per epoch: every rank packs its own positives' negatives as (entity, side) codes; one all-gather of them)
+        (once per epoch, prefetched on a side stream: every rank draws ALL negatives itself and packs them as (entity, side) codes)
         owner of h_p builds HR_p, owner of t_p builds RT_p                                                  [mke_oc_bases]
         ALL-GATHER of the blocks (2 vectors per positive)
         reference counts of the own rows over the whole global step (needs only the codes)                 [mke_oc_count]
@@ -131,7 +131,10 @@ class OcHipBackend:
         oh, ot = _lib.ptr(tr._own[0], i32, "own"), _lib.ptr(tr._own[1], i32, "own")
         key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts),
                tr._peer_send[0].data_ptr() if tr.peer_direct and tr.world > 1 else 0)
-        if getattr(self, "_steps_key", None) != key:      # first epoch, or a buffer was re-allocated: build the static part
+        cache = self.__dict__.setdefault("_tables", {})
+        if key in cache:                                  # the two epoch buffer sets alternate: one table each
+            self._steps = cache[key]
+        else:                                             # first use of this buffer set, or a buffer was re-allocated
             base = self._struct(tr, tr._build_part_step(0, 0))
             ph, pr, pt = (_lib.ptr(x, i32, "pos") for x in (b.pos_h, b.pos_r, b.pos_t))
             sh, stt = _lib.ptr(tr._slot[0], i32, "slot"), _lib.ptr(tr._slot[1], i32, "slot")
@@ -144,9 +147,11 @@ class OcHipBackend:
                 s.n_pos = hi - lo
                 s.per = max(1, -(-(hi - lo) // tr.world))
                 for g in range(tr.world):
-                    s.code_off[g] = g * tr._codes_per_rank + int(tr._loc_off[g, k]) * tr.N
+                    s.code_off[g] = (lo + g * int(s.per)) * tr.N      # codes are laid out by epoch position
                 out.append(s)
-            self._steps, self._steps_key = out, key
+            if len(cache) > 4:
+                cache.clear()
+            self._steps = cache[key] = out
             self._ring = tr.loss_ring.data_ptr()
             self._ring_stride = tr.loss_ring.shape[1] * 8
         offh, offt = (x.tolist() for x in tr._own_off)
@@ -261,7 +266,7 @@ class OcHostStagedComm(OcGlooComm):
 class OwnerComputesTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
-                 exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False):
+                 exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True):
         self.backend = backend or OcHipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         if comm is None:
@@ -279,6 +284,7 @@ class OwnerComputesTrainer:
         # peer-direct (opt-in): no all-gather / reduce-scatter — every rank maps the other ranks' send blocks and gradient
         # inboxes (IPC handles exchanged once) and mke_oc_score reads / writes them straight over xGMI; two stream-ordered
         # barriers per step.  Correct by construction and tested with two ranks on one GPU; not measured on several.
+        self.prefetch = bool(prefetch)
         self.peer_direct = bool(peer_direct) and world > 1
         if self.peer_direct:
             self.chunks = 1
@@ -345,22 +351,7 @@ class OwnerComputesTrainer:
         lo = np.array([p[1] for p in parts], dtype=np.int64)
         hi = np.array([p[2] for p in parts], dtype=np.int64)
         per = np.maximum(1, -(-(hi - lo) // G))
-        loc_off = np.zeros((G, len(parts) + 1), dtype=np.int64)     # every rank's prefix of slice sizes (all ranks agree)
-        for g in range(G):
-            a = np.minimum(hi, lo + g * per)
-            e = np.minimum(hi, a + per)
-            loc_off[g, 1:] = np.cumsum(e - a)
-            if g == self.rank:
-                mine_a, mine_n = a, e - a
-        self._loc_off = loc_off
-        if len(parts):
-            rep = np.repeat(mine_a - np.concatenate([[0], np.cumsum(mine_n)[:-1]]), mine_n)
-            idx = (np.arange(int(mine_n.sum()), dtype=np.int64) + rep).astype(np.int32)
-        else:
-            idx = np.zeros(0, np.int32)
-        self._eidx = torch.as_tensor(idx, device=dev)
-        self._eidx_long = self._eidx.long()
-        self._codes_per_rank = max(1, int(loc_off[:, -1].max()) * self.N)   # per rank in the gathered buffer (padded to the largest)
+        self._all_idx = torch.arange(self._n_all, dtype=torch.int32, device=dev)
         self._part_id = torch.repeat_interleave(torch.arange(len(parts), device=dev), torch.as_tensor(hi - lo, device=dev)) \
             if len(parts) else torch.zeros(0, dtype=torch.int64, device=dev)
         self._lo_of = torch.as_tensor(lo, device=dev)
@@ -368,39 +359,29 @@ class OwnerComputesTrainer:
         for k, (ps, _, _) in enumerate(parts):
             self._parts_of.setdefault(ps, []).append(k)
 
-    def _plan_epoch(self):
-        """Everything of an epoch that does not depend on the tables: this rank's negatives (one sampler launch) packed as
-        codes and all-gathered, the slot of every positive's HR / RT vector in its owner's block, the lists of owned
-        positives per part, and the exact capacity the epoch needs.  Integer work on the replicated epoch order: identical
-        on every rank."""
-        b, G, dev = self.bat, self.world, self.device
+    # ---- per-epoch plan: table-independent, so the NEXT epoch's is computed on a side stream while this epoch trains -----
+    def _compute_plan(self, pos, rng_stream, bs):
+        """Device work only (no host synchronisation), into buffer set `bs`: the negatives of EVERY positive of the epoch
+        (one sampler launch — every rank draws all of them itself: the Philox stream is a function of the epoch position,
+        so the ranks agree without exchanging a byte) packed as codes; the slot of every positive's HR / RT vector in its
+        owner's block; the owned positives per part in slot order; per (part, owner) counts, copied to pinned host memory
+        asynchronously."""
+        b, G, dev, N = self.bat, self.world, self.device, self.N
         i32 = dict(dtype=torch.int32, device=dev)
-        if getattr(self, "_parts", None) is None:
-            self._layout()
-        parts, n_all = self._parts, self._n_all
-        part_id = self._part_id
-        # -- own negatives of the whole epoch (one sampler launch), packed as codes, all-gathered once ------------------
-        n_loc = int(self._loc_off[self.rank, -1])
-        mine = self._persist(("codes_mine",), torch.zeros(0, **i32), self._codes_per_rank)
-        if n_loc:
-            il = self._eidx_long
-            neg = tuple(torch.empty(n_loc * self.N, **i32) for _ in range(3))
-            ph = b.pos_h[il]
-            self.backend.sample_at((ph, b.pos_r[il], b.pos_t[il]), self._eidx, b.pos_kg[il], b.side1, b.side2, self.N,
-                                   b.rng_seed, b.rng_stream, neg)
-            self.backend.pack_codes(ph, neg[0], neg[2], self.N, mine[:n_loc * self.N])
-        if G == 1:
-            self._codes = mine
-        else:
-            self._codes = self._persist(("codes_all",), torch.zeros(0, **i32), G * self._codes_per_rank)
-            self.comm.all_gather(self._codes, mine)
-        # -- slots: rank of a positive among the positives of its part whose head (tail) has the same owner ---------
-        self._slot, self._own, self._own_off = [], [], []
-        worst = 0
-        for ids in (b.pos_h, b.pos_t):
+        ph, pr, pt = pos
+        n_all, parts, part_id = self._n_all, self._parts, self._part_id
+        plan = {"bs": bs}
+        codes = self._persist(("codes", bs), torch.zeros(0, **i32), max(1, n_all * N))
+        if n_all:
+            neg = tuple(torch.empty(n_all * N, **i32) for _ in range(3))
+            self.backend.sample_at((ph[:n_all], pr[:n_all], pt[:n_all]), self._all_idx, b.pos_kg[:n_all], b.side1, b.side2, N,
+                                   b.rng_seed, rng_stream, neg)
+            self.backend.pack_codes(ph[:n_all], neg[0], neg[2], N, codes[:n_all * N])
+        plan["codes"] = codes
+        plan["slot"], plan["own"], plan["cnt_dev"] = [], [], []
+        for x, ids in enumerate((ph, pt)):
             if n_all == 0:
-                self._slot.append(torch.zeros(1, **i32)); self._own.append(torch.zeros(1, **i32))
-                self._own_off.append(np.zeros(len(parts) + 1, dtype=np.int64))
+                plan["slot"].append(torch.zeros(1, **i32)); plan["own"].append(torch.zeros(1, **i32))
                 continue
             key = part_id * G + (ids[:n_all].long() % G)
             order = torch.argsort(key, stable=True)
@@ -409,16 +390,41 @@ class OwnerComputesTrainer:
             start = torch.cumsum(counts, 0) - counts
             slot = torch.empty(n_all, dtype=torch.int64, device=dev)
             slot[order] = torch.arange(n_all, device=dev) - start[ks]
-            self._slot.append(self._persist(("slot", len(self._slot)), slot.to(torch.int32), n_all))
-            cnt = counts.view(len(parts), G).cpu().numpy()
-            worst = max(worst, int(cnt.max()))
+            plan["slot"].append(self._persist(("slot", x, bs), slot.to(torch.int32), n_all))
             # owned positives (as positions inside their part), in slot order, for every part: the sorted order restricted
             # to this rank's keys is exactly that
-            mine = ks % G == self.rank
-            own_pos = order[mine]
-            self._own.append(self._persist(("own", len(self._own)), (own_pos - self._lo_of[part_id[own_pos]]).to(torch.int32), n_all))
+            own_pos = order[ks % G == self.rank]
+            plan["own"].append(self._persist(("own", x, bs), (own_pos - self._lo_of[part_id[own_pos]]).to(torch.int32), n_all))
+            plan["cnt_dev"].append(counts)
+        if n_all:
+            c = torch.stack(plan["cnt_dev"]).to(torch.int64)
+            host = self._persistent.get(("cnt_host", bs))
+            if host is None or host.shape != c.shape:
+                host = torch.empty(c.shape, dtype=torch.int64, pin_memory=dev.type == "cuda")
+                self._persistent[("cnt_host", bs)] = host
+            host.copy_(c, non_blocking=True)
+            plan["cnt_host"] = host
+        if dev.type == "cuda":
+            plan["event"] = torch.cuda.Event()
+            plan["event"].record()
+        return plan
+
+    def _finish_plan(self, plan):
+        """Make a computed plan the current one: wait for its counts (the only host synchronisation of an epoch), size the
+        exchange blocks exactly, rebuild the native step descriptors."""
+        G, dev = self.world, self.device
+        if "event" in plan:
+            plan["event"].synchronize()
+        parts = self._parts
+        self._codes, self._slot, self._own = plan["codes"], plan["slot"], plan["own"]
+        self._own_off = []
+        worst = 0
+        for x in range(2):
             off = np.zeros(len(parts) + 1, dtype=np.int64)
-            off[1:] = np.cumsum(cnt[:, self.rank])
+            if self._n_all:
+                cnt = plan["cnt_host"][x].numpy().reshape(len(parts), G)
+                worst = max(worst, int(cnt.max()))
+                off[1:] = np.cumsum(cnt[:, self.rank])
             self._own_off.append(off)
         # -- capacity: exact for this epoch, buffers only ever grow ----------------------------------------
         need = max(worst, 1)
@@ -435,10 +441,52 @@ class OwnerComputesTrainer:
                 self._map_peers(gb)
             self._addr = [tuple(t.data_ptr() for t in (self._send[c], self._v_all[c], self._g_all[c], self._gv[c]))
                           for c in range(self.chunks)]
-        self._planned_epoch = b.epoch
+        self._planned_epoch = self.bat.epoch
+        self._plan_bs = plan["bs"]
         self._st_cache = {}
         if hasattr(self.backend, "prepare_epoch"):
             self.backend.prepare_epoch(self)
+
+    def _plan_epoch(self):
+        """Plan of the CURRENT epoch order, in line (construction, or an epoch boundary without a prefetched plan)."""
+        if getattr(self, "_parts", None) is None:
+            self._layout()
+        b = self.bat
+        self._finish_plan(self._compute_plan((b.pos_h, b.pos_r, b.pos_t), b.rng_stream, 0))
+        self._next_plan = None
+
+    def _prefetch_next_epoch(self):
+        """Draw the next epoch's permutation into the batcher's alternate buffers and compute its plan on a side stream (the
+        sampler, two sorts): by the time the epoch ends it is waiting in the other buffer set."""
+        b = self.bat
+        staged = b.stage_next_epoch()                           # randperm + gather on the current stream (tiny)
+        nxt = ((b.epoch + 1) * 2) & 0xFFFFFFFF
+        bs = 1 - getattr(self, "_plan_bs", 0)
+        if self.device.type != "cuda":
+            self._next_plan = self._compute_plan(staged, nxt, bs)
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            old = _lib.pin_stream(self._side.cuda_stream)
+            try:
+                self._next_plan = self._compute_plan(staged, nxt, bs)
+            finally:
+                _lib.pin_stream(old)
+
+    def _advance_epoch(self):
+        """Epoch boundary: random.shuffle of both positive lists (code/MultiKE_model.py:314-315) + the new epoch's plan."""
+        if getattr(self, "_next_plan", None) is not None:
+            plan, self._next_plan = self._next_plan, None
+            if "event" in plan:
+                torch.cuda.current_stream().wait_event(plan["event"])
+            self.bat.commit_staged()
+            self._finish_plan(plan)
+        else:
+            self.bat.shuffle()
+            self._plan_epoch()
 
     def _map_peers(self, gb):
         """Exchange IPC handles of this rank's send block and gradient inbox ([world][2 C][stride]: one slice per writer) and
@@ -482,7 +530,7 @@ class OwnerComputesTrainer:
         b = self.bat
         per, _, _ = self.my_slice(lo, hi)
         oh, ot = self._own_off[0], self._own_off[1]
-        code_off = tuple(g * self._codes_per_rank + int(self._loc_off[g, k]) * self.N for g in range(self.world))
+        code_off = tuple((lo + g * per) * self.N for g in range(self.world))   # codes are laid out by epoch position
         return OcStep(b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi], per, self._slot[0][lo:hi], self._slot[1][lo:hi],
                       self._own[0][oh[k]:oh[k + 1]], self._own[1][ot[k]:ot[k + 1]], tag, self._codes, code_off)
 
@@ -490,8 +538,9 @@ class OwnerComputesTrainer:
         """Global step i (steps must be issued in order)."""
         s = i % self.steps
         if s == 0 and i > 0:
-            self.bat.shuffle()                               # random.shuffle of both lists at the epoch boundary
-            self._plan_epoch()
+            self._advance_epoch()
+        if s == 0 and self.prefetch:
+            self._prefetch_next_epoch()                      # the next epoch's plan overlaps this epoch's steps
         be, G, cm = self.backend, self.world, self.comm
         ks = self._parts_of.get(s, [])
         self.tag += 1
