@@ -357,13 +357,13 @@ struct GemmVParams {
 #define GV_SM 68  // row stride of an m/n-contiguous 32 x 64 image
 
 template <bool KC>
-__device__ __forceinline__ void gv_fetch(const float* __restrict__ base, int64_t ld, int dim_mn, int mn0, int k0, int k_hi, int K,
-                                         int tid, float4 (&r)[2]) {
+__device__ __forceinline__ void gv_fetch(const float* __restrict__ base, int64_t ld, int dim_mn, int mn0, int k0, int K, int tid,
+                                         float4 (&r)[2]) {
   // Every access is one aligned 16-byte load along the contiguous dimension; the caller guarantees that the contiguous
   // extent rounded up to 4 fits in ld, so a float4 that straddles the logical edge still reads the row's own padding.
-  // What must contribute nothing is zeroed by K position: whole float4s past k_hi, and — k-contiguous operands with
-  // K % 4 != 0 — the components past K of the last one.  Rows / columns past the M / N edge are clamped to valid memory
-  // and never stored.
+  // Rows / columns past the M / N edge are clamped to valid memory and never stored.  NOTHING is computed on the loaded
+  // values here: they are only consumed by gv_stage one iteration later, so the wait for them can sit behind the slab's
+  // MFMAs (a zero-fill select right after the load pinned the wait in front of them: 175 -> 150 us at 5000 x 1024 x 1500).
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     int mn, k;
@@ -371,17 +371,46 @@ __device__ __forceinline__ void gv_fetch(const float* __restrict__ base, int64_t
     else    { k = k0 + (tid >> 4) + 16 * e;   mn = mn0 + 4 * (tid & 15); }
     const int kpad = (K + 3) & ~3, mpad = (dim_mn + 3) & ~3;
     const int kc = min(k, (KC ? kpad - 4 : K - 1)), mc = min(mn, (KC ? dim_mn - 1 : mpad - 4));
-    float4 v = *reinterpret_cast<const float4*>(KC ? base + (int64_t)mc * ld + kc : base + (int64_t)kc * ld + mc);
-    if (KC) {
-      v.x = k < k_hi ? v.x : 0.f; v.y = k + 1 < k_hi ? v.y : 0.f; v.z = k + 2 < k_hi ? v.z : 0.f; v.w = k + 3 < k_hi ? v.w : 0.f;
-    } else if (k >= k_hi) {
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    r[e] = v;
+    r[e] = *reinterpret_cast<const float4*>(KC ? base + (int64_t)mc * ld + kc : base + (int64_t)kc * ld + mc);
   }
 }
+// the two addresses a thread loads from in the slab starting at k0 (rows / columns clamped once: they do not depend on k)
 template <bool KC>
-__device__ __forceinline__ void gv_stage(float* __restrict__ s, int tid, const float4 (&r)[2]) {
+__device__ __forceinline__ void gv_ptrs(const float* __restrict__ base, int64_t ld, int dim_mn, int mn0, int k0, int tid,
+                                        const float* (&q)[2]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (KC) q[e] = base + (int64_t)min(mn0 + (tid >> 3) + 32 * e, dim_mn - 1) * ld + (k0 + 4 * (tid & 7));
+    else    q[e] = base + (int64_t)(k0 + (tid >> 4) + 16 * e) * ld + min(mn0 + 4 * (tid & 15), ((dim_mn + 3) & ~3) - 4);
+  }
+}
+// interior slabs (wholly inside [0, K)): plain loads from the running pointers, which then advance by one slab — no
+// 64-bit multiply, no clamp in the loop (quarter-rate 64-bit address arithmetic per load cost 8 us of 167 here)
+template <bool KC>
+__device__ __forceinline__ void gv_fetch_fast(const float* (&q)[2], int64_t slab_step, float4 (&r)[2]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    r[e] = *reinterpret_cast<const float4*>(q[e]);
+    q[e] += slab_step;
+  }
+}
+
+// registers -> LDS image; on the slab that crosses the K edge (k_hi) what must contribute nothing is zeroed first: whole
+// float4s past k_hi, and — k-contiguous operands with K % 4 != 0 — the components past it
+template <bool KC>
+__device__ __forceinline__ void gv_stage(float* __restrict__ s, int tid, float4 (&r)[2], int k0, int k_hi) {
+  if (k0 + 32 > k_hi) {  // block-uniform
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = KC ? k0 + 4 * (tid & 7) : k0 + (tid >> 4) + 16 * e;
+      if (KC) {
+        r[e].x = k < k_hi ? r[e].x : 0.f; r[e].y = k + 1 < k_hi ? r[e].y : 0.f;
+        r[e].z = k + 2 < k_hi ? r[e].z : 0.f; r[e].w = k + 3 < k_hi ? r[e].w : 0.f;
+      } else if (k >= k_hi) {
+        r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     if (KC) *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * e) * GV_SK + 4 * (tid & 7)) = r[e];
@@ -409,7 +438,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_vec(const GemmVParams p) {
   // SLOWER (5000 x 1024 x 1500: 191 vs 174 us) — 37 KB of LDS and 73 registers leave 4 waves per SIMD instead of 8, and
   // it is the number of co-resident blocks that keeps the matrix pipe fed across the barriers.  Raising the wave priority
   // around the 16-MFMA burst (s_setprio 2 ... 0) also measured slower (190 vs 175 us).  PMC: the matrix pipe is busy 74 %
-  // of the kernel's cycles at an effective clock of 1.84 GHz under this load (profiles/r02_gemm.md).
+  // of the kernel's cycles at an effective clock of 1.84 GHz under this load (profiles/r02_ae_step.md).  Ablations (wrong
+  // results, timing only): without the second barrier 173 us, without the LDS fragment reads 175 us, without the global
+  // loads of the loop 143 us — but that variant also multiplies constant operands, and on this part a lower-toggle
+  // operand stream clocks higher (MI355X_MICROARCH.md, DVFS), so it bounds the load path's share from above.
   __shared__ __attribute__((aligned(16))) float sA[64 * GV_SK];
   __shared__ __attribute__((aligned(16))) float sB[64 * GV_SK];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -424,15 +456,25 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_vec(const GemmVParams p) {
   const int k_lo = bz * p.k_per_split, k_hi = min(p.K, k_lo + p.k_per_split);
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float4 ra[2], rb[2];
-  gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k_lo, k_hi, p.K, tid, ra);
-  gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k_lo, k_hi, p.K, tid, rb);
+  const float* qa[2];
+  const float* qb[2];
+  gv_ptrs<A_KC>(p.A, p.lda, p.M, m0, k_lo + 32, tid, qa);   // running pointers: the slab AFTER the first
+  gv_ptrs<B_KC>(p.B, p.ldb, p.N, n0, k_lo + 32, tid, qb);
+  const int64_t a_step = A_KC ? 32 : 32 * p.lda, b_step = B_KC ? 32 : 32 * p.ldb;
+  gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k_lo, p.K, tid, ra);
+  gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k_lo, p.K, tid, rb);
   for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
-    gv_stage<A_KC>(sA, tid, ra);
-    gv_stage<B_KC>(sB, tid, rb);
+    gv_stage<A_KC>(sA, tid, ra, k0, k_hi);
+    gv_stage<B_KC>(sB, tid, rb, k0, k_hi);
     __syncthreads();
     if (k0 + 32 < k_hi) {  // the next slab is in flight during the MFMAs below
-      gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k0 + 32, k_hi, p.K, tid, ra);
-      gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k0 + 32, k_hi, p.K, tid, rb);
+      if (k0 + 64 <= p.K) {   // wholly inside the matrix (block-uniform)
+        gv_fetch_fast<A_KC>(qa, a_step, ra);
+        gv_fetch_fast<B_KC>(qb, b_step, rb);
+      } else {                // the slab that crosses the K edge: clamped addresses
+        gv_fetch<A_KC>(p.A, p.lda, p.M, m0, k0 + 32, p.K, tid, ra);
+        gv_fetch<B_KC>(p.B, p.ldb, p.N, n0, k0 + 32, p.K, tid, rb);
+      }
     }
     float fa[16], fb[16];
     gv_frag<A_KC>(sA, wm * 32, l31, half, fa);
