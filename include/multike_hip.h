@@ -618,12 +618,14 @@ int mke_dense_update(float* param, float* acc /*nullable for SGD*/, float* grad,
  *
  *   emb1 : [n1][ld1], emb2 : [n2][ld2], both row-major with columns [dim, kpad) zero, kpad a multiple of 16, ld1 and
  *   ld2 multiples of 4 (16-byte rows).  Gold column of row i is i (so n2 >= n1).
- *   rank[i] += #{j < n2 : sim[i][j] > sim[i][i]}  (rank zeroed by the caller);
+ *   rank[i] += #{j < n2 : sim[i][j] > sim[i][i]}  (rank zeroed by the caller); with `ties` also the columns that tie with
+ *   the gold (the reference's argsort puts the gold at an arbitrary place among them: the host reports the mid-rank);
  *   best[i]  = max over j of (ordered(sim[i][j]) << 32 | 0xFFFFFFFF - j)  (best zeroed by the caller; arg-max column =
  *              0xFFFFFFFF - low word, lowest column on ties).
  * ------------------------------------------------------------------------------------------------ */
 int mke_align_rank(const float* emb1, int ld1, const float* emb2, int ld2, int kpad, int64_t n1, int64_t n2,
-                   int32_t* rank, uint64_t* best, void* stream);
+                   int32_t* rank, int32_t* ties /* nullable: ties[i] += #{j : sim[i][j] == sim[i][i]} (j = i included) */,
+                   uint64_t* best, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (10) Small dense f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32) with arbitrary operand strides:

@@ -733,11 +733,12 @@ def dense_layer_fwd(x: torch.Tensor, w: torch.Tensor, b, act: int, out: torch.Te
     _check(rc, "mke_dense_layer_fwd")
 
 
-def align_rank(emb1, emb2, kpad, n1, n2, rank, best):
+def align_rank(emb1, emb2, kpad, n1, n2, rank, best, ties=None):
     """mke_align_rank over row-major padded emb1 [n1, ld1] / emb2 [n2, ld2]."""
     rc = lib().mke_align_rank(_dev(emb1, torch.float32, "emb1"), C.c_int(emb1.shape[1]), _dev(emb2, torch.float32, "emb2"),
                               C.c_int(emb2.shape[1]), C.c_int(kpad), C.c_int64(n1), C.c_int64(n2),
-                              _dev(rank, torch.int32, "rank"), _dev(best, torch.int64, "best"), _stream())
+                              _dev(rank, torch.int32, "rank"), _dev(ties, torch.int32, "ties"), _dev(best, torch.int64, "best"),
+                              _stream())
     _check(rc, "mke_align_rank")
 
 

@@ -21,7 +21,11 @@ def _prep(x, device, normalize):
 
 
 def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
-    """(rank [n1] int64, best [n1] int64): rank_i = #{j: sim_ij > sim_ii}; best_i = argmax_j sim_ij."""
+    """(rank [n1] float64, best [n1] int64): rank_i = #{j: sim_ij > sim_ii} + (#{j: sim_ij == sim_ii} - 1) / 2; best_i =
+    argmax_j sim_ij.  Ties: the reference's argsort / argpartition leaves the gold at an arbitrary position among the columns
+    that tie with it (code/base/alignment.py:152-160); the MID-rank is reported here, so degenerate inputs — a zero name
+    vector has similarity 0 to every column, duplicated embeddings — do not count as Hits@1 (counting only strictly
+    greater columns would resolve every tie in the gold's favour).  Without ties this is the reference's rank exactly."""
     a, b = _prep(embed1, device, normalize), _prep(embed2, device, normalize)
     n1, d = a.shape
     n2 = b.shape[0]
@@ -33,10 +37,11 @@ def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
     bp = torch.zeros(n2, kpad, dtype=torch.float32, device=device)
     bp[:, :d] = b
     rank = torch.zeros(n1, dtype=torch.int32, device=device)
+    ties = torch.zeros(n1, dtype=torch.int32, device=device)
     best = torch.zeros(n1, dtype=torch.int64, device=device)
-    _lib.align_rank(ap, bp, kpad, n1, n2, rank, best)
+    _lib.align_rank(ap, bp, kpad, n1, n2, rank, best, ties)
     col = 0xFFFFFFFF - (best & 0xFFFFFFFF)
-    return rank.long(), col
+    return rank.double() + (ties.double() - 1.0).clamp_min(0.0) * 0.5, col
 
 
 def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
@@ -53,8 +58,8 @@ def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csl
     num = rank.numel()
     hits = np.array([float((rank < k).sum()) for k in top_k]) / num * 100
     hits = np.round(hits, 3)
-    mr = float((rank + 1).double().mean())
-    mrr = float((1.0 / (rank + 1).double()).mean())
+    mr = float((rank + 1).mean())
+    mrr = float((1.0 / (rank + 1)).mean())
     alignment_rest = set(zip(range(num), best.cpu().tolist()))
     cost = time.time() - t
     if accurate:

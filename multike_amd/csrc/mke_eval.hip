@@ -24,10 +24,11 @@ struct AlignRankParams {
   int n1, n2;
   int tiles_per_chunk;
   int32_t* __restrict__ rank;
+  int32_t* __restrict__ ties;   // nullable: #{ j : sim[i][j] == sim[i][i] } including j = i
   unsigned long long* __restrict__ best;
 };
 
-template <int KS>  // kpad / 16
+template <int KS, bool TIES>  // kpad / 16; TIES: also count the columns that tie with the gold
 __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams p) {
   __shared__ float s_gold[MKE_BLOCK / 64][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -54,10 +55,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams 
     for (int reg = 0; reg < 16; ++reg) gold[reg] = s_gold[wv][(reg & 3) + 8 * (reg >> 2) + 4 * half];
   }
   int cnt[16];
+  int eq[TIES ? 16 : 1];
   float bestv[16];
   int bestc[16];
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) { cnt[reg] = 0; bestv[reg] = -3.0e38f; bestc[reg] = 0; }
+  for (int reg = 0; reg < 16; ++reg) { cnt[reg] = 0; bestv[reg] = -3.0e38f; bestc[reg] = 0; if (TIES) eq[reg] = 0; }
   const int ntiles = (p.n2 + SIMT_BN_FOR(KS) - 1) / SIMT_BN_FOR(KS);
   const int t0 = blockIdx.y * p.tiles_per_chunk;
   const int t1 = min(ntiles, t0 + p.tiles_per_chunk);
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams 
     for (int reg = 0; reg < 16; ++reg) {
       const float s = acc[reg];
       cnt[reg] += (col_ok && s > gold[reg]) ? 1 : 0;
+      if (TIES) eq[reg] += (col_ok && s == gold[reg]) ? 1 : 0;
       if (col_ok && s > bestv[reg]) { bestv[reg] = s; bestc[reg] = col; }  // columns ascend: the lowest column wins a tie
     }
   });
@@ -73,11 +76,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams 
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     int c = cnt[reg];
+    int ce = TIES ? eq[reg] : 0;
     float bv = bestv[reg];
     int bc = bestc[reg];
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) {
       c += __shfl_xor(c, off, 64);
+      if (TIES) ce += __shfl_xor(ce, off, 64);
       const float ov = __shfl_xor(bv, off, 64);
       const int oc = __shfl_xor(bc, off, 64);
       if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams 
     const int row = strip0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
     if (l31 == 0 && row < p.n1 && t0 < t1) {
       atomicAdd(&p.rank[row], c);
+      if (TIES) atomicAdd(&p.ties[row], ce);
       // order-preserving key: similarity (monotone uint) in the high word, lowest column wins ties
       unsigned u = __float_as_uint(bv);
       u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_align_rank(const AlignRankParams 
 }  // namespace mke
 
 extern "C" int mke_align_rank(const float* emb1, int ld1, const float* emb2, int ld2, int kpad, int64_t n1, int64_t n2,
-                              int32_t* rank, uint64_t* best, void* stream) {
+                              int32_t* rank, int32_t* ties, uint64_t* best, void* stream) {
   using namespace mke;
   if (n1 < 0 || n2 < 0 || n1 > 0x7FFFFF00 || n2 > 0x7FFFFF00) { set_error("bad n1/n2"); return MKE_E_SHAPE; }
   if (n1 == 0) return MKE_OK;
@@ -108,7 +114,7 @@ extern "C" int mke_align_rank(const float* emb1, int ld1, const float* emb2, int
   }
   if (n2 < n1) { set_error("gold column = row index needs n2 >= n1"); return MKE_E_SHAPE; }
   AlignRankParams p;
-  p.emb1 = emb1; p.ld1 = ld1; p.emb2 = emb2; p.ld2 = ld2; p.n1 = (int)n1; p.n2 = (int)n2; p.rank = rank;
+  p.emb1 = emb1; p.ld1 = ld1; p.emb2 = emb2; p.ld2 = ld2; p.n1 = (int)n1; p.n2 = (int)n2; p.rank = rank; p.ties = ties;
   p.best = (unsigned long long*)best;
   const int bn = SIMT_BN_FOR(kpad / 16);
   const int ntiles = (int)((n2 + bn - 1) / bn);
@@ -122,7 +128,8 @@ extern "C" int mke_align_rank(const float* emb1, int ld1, const float* emb2, int
   hipStream_t st = (hipStream_t)stream;
 #define EV_CASE(K)                                                                \
   case K:                                                                         \
-    hipLaunchKernelGGL((k_align_rank<K / 16>), grid, dim3(MKE_BLOCK), 0, st, p);   \
+    if (ties) hipLaunchKernelGGL((k_align_rank<K / 16, true>), grid, dim3(MKE_BLOCK), 0, st, p);   \
+    else hipLaunchKernelGGL((k_align_rank<K / 16, false>), grid, dim3(MKE_BLOCK), 0, st, p);       \
     break;
   switch (kpad) {
     EV_CASE(16) EV_CASE(32) EV_CASE(48) EV_CASE(64) EV_CASE(80) EV_CASE(96) EV_CASE(112) EV_CASE(128) EV_CASE(160)

@@ -21,7 +21,8 @@ extern int g_score_splits;    // mke_set_option("score_splits")
 extern int g_score_half_max;  // mke_set_option("score_half_groups"): largest neg_per_pos scored two groups per wavefront (0 = off)
 
 struct ScoreParams {
-  const float* __restrict__ ent;
+  const float* ent;   // NOT __restrict__: ent_w below aliases it (in-place update of rows referenced once; such a row is never
+                      // read again in the launch, but the compiler must not be told the two pointers cannot alias)
   const float* __restrict__ rel;
   int ent_norm, rel_norm;
   int stride, dim;
@@ -48,7 +49,7 @@ struct ScoreParams {
   double* __restrict__ lossp;
   // exclusive-row fast path (nullable refcount = disabled)
   int32_t* __restrict__ refcount;
-  float* __restrict__ ent_w;    // writable alias of ent
+  float* ent_w;                 // writable alias of ent
   float* __restrict__ ent_acc;  // nullable (SGD)
   int optimizer;
   float lr;

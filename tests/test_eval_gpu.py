@@ -43,6 +43,28 @@ def test_ranks_vs_oracle(n1, n2, d):
     assert int(rank0.max()) == 0 and np.array_equal(best0.cpu().numpy(), np.arange(n1))
 
 
+def test_ties_are_ranked_at_mid_rank():
+    """The reference's argsort leaves the gold at an arbitrary place among the columns that tie with it; the evaluator
+    reports the mid-rank: a zero row (similarity 0 to every column) lands in the middle, not at Hits@1; a duplicated gold
+    column shares ranks 0 and 1."""
+    from multike_amd.base.alignment import alignment_ranks, greedy_alignment
+    rng = np.random.default_rng(5)
+    n, d = 200, 75
+    e2 = rng.standard_normal((n, d)).astype(np.float32)
+    e1 = e2.copy()
+    e1[7] = 0.0                                   # no name vector: sim = 0 against all n columns
+    e2[11] = e2[10]                               # column 11 duplicates column 10: row 10's gold ties with column 11
+    rank, _ = alignment_ranks(e1, e2)
+    r = rank.cpu().numpy()
+    assert r[7] == (n - 1) / 2.0                  # n columns tie (the gold among them): mid-rank
+    assert r[10] == 0.5                           # two columns tie for the first place
+    assert r[3] == 0.0
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, hits1, mr, mrr = greedy_alignment(e1, e2, [1, 10], 1, "inner", True, 0, True)
+    assert hits1 < 100.0
+
+
 def test_neighbour_table_matches_reference_definition():
     """top-k inner products per row, self included, unordered (code/base/batch.py:143-150)."""
     from multike_amd.base.batch import generate_neighbours, neighbour_table
