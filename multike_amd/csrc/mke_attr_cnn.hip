@@ -12,7 +12,7 @@
 // the batch-norm affine, scatters the attribute-row gradient with atomics and block-reduces the parameter gradients.
 // The batch-global normalisation needs two batch-wide sums (sum z^2, sum g.z): kernels write per-block partials
 // and the next kernel's blocks add them up themselves — no extra reduction launches, no host round trip.
-#include "mke_gemm.h"
+#include "mke_common.h"
 
 namespace mke {
 
@@ -533,7 +533,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_colsum_add(const float* __restric
 
 __global__ __launch_bounds__(MKE_BLOCK) void k_dense_update(const DenseJob j) { dense_update_range(j, blockIdx.x, gridDim.x); }
 
-
+int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
+                    int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain);
+int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
+                         int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
+                         const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,
+                         int acc1, hipStream_t st);
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
@@ -751,12 +756,10 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
   // backward
   if (phases & MKE_ATTR_BWD) {
-  // dz = dL/dzpre = inv (g_out - z coef)(1 - z^2) — the backward through the batch-wide normalisation and tanh — is applied
-  // to g_out as it is loaded by the two gradient products (GemmOperandXform) instead of by a kernel of its own:
+  if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre
   // [dW; dbias] = [flat, 1]^T dz (split-K, atomic)  and  dflat = dz W^T, one launch
-  const GemmOperandXform xf{(int64_t)(z - gout), ssq, dot, MKE_LOSS_PARTIALS};
   if ((rc = launch_gemm_f32_pair(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1,
-                                 gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st, &xf))) return rc;
+                                 gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st))) return rc;
   {
     if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
     ConvParams p{};

@@ -30,14 +30,6 @@ struct GemmParams {
   int gx, gy, gz;  // this problem's grid (k_gemm_f32_batch decodes its linear block index with it)
   int ext;         // != 0: the GemmEpilogue below replaces the partials / epi_plain epilogue
   GemmEpilogue e;
-  // operand transform at load (the attribute step's tail backward folded into its gradient products): an operand element g
-  // with companion z = (&g)[xf_delta] is read as  inv * (g - z * coef) * (1 - z^2),  inv = rsqrt(max(S, eps)),
-  // coef = S > eps ? T * inv^2 : 0,  S / T = the sums of the xf_np partials at xf_ssq / xf_dot (every block adds them up).
-  int xf_a, xf_b;  // which operand is transformed
-  int64_t xf_delta;
-  const double* xf_ssq;
-  const double* xf_dot;
-  int xf_np;
 };
 
 // Extended epilogue (mke_gemm.h) for one wavefront's 32 x 32 accumulator whose top-left element is (row0, col0) of C.
@@ -119,39 +111,13 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, 
   const int64_t a_slab = GK * p.a_cs, b_slab = GK * p.b_rs;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float ra[GE], rb[GE];
-  float xf_inv = 0.f, xf_coef = 0.f;
-  if (p.xf_a | p.xf_b) {  // block-uniform: the two batch-wide scalars from their partials
-    __shared__ double s_xf[2];
-    double v1 = 0.0, v2 = 0.0;
-    for (int i = tid; i < p.xf_np; i += MKE_BLOCK) { v1 += p.xf_ssq[i]; v2 += p.xf_dot[i]; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); }
-    __shared__ double s_p[2][MKE_BLOCK / 64];
-    if (lane == 0) { s_p[0][wv] = v1; s_p[1][wv] = v2; }
-    __syncthreads();
-    if (tid == 0) {
-      double a = 0.0, b = 0.0;
-      for (int w = 0; w < MKE_BLOCK / 64; ++w) { a += s_p[0][w]; b += s_p[1][w]; }
-      s_xf[0] = a; s_xf[1] = b;
-    }
-    __syncthreads();
-    const float Sf = (float)s_xf[0];
-    xf_inv = rsqrtf(fmaxf(Sf, MKE_L2_EPS));
-    xf_coef = Sf > MKE_L2_EPS ? (float)s_xf[1] * xf_inv * xf_inv : 0.f;
-  }
-  auto xf = [&](const float* q) {
-    const float g = *q, z = q[p.xf_delta];
-    return xf_inv * (g - z * xf_coef) * (1.0f - z * z);
-  };
   auto fetch = [&](int k0) {  // one slab into registers, zero beyond the matrix / split edges; all loads independent
     const float* qa = pa;
     const float* qb = pb;
 #pragma unroll
     for (int e = 0; e < GE; ++e) {
-      const bool oka = m0 + a_m + e * a_dm < p.M && k0 + a_k + e * a_dk < k_hi;
-      const bool okb = k0 + b_k + e * b_dk < k_hi && n0 + b_n + e * b_dn < p.N;
-      ra[e] = oka ? (p.xf_a ? xf(qa) : *qa) : 0.f;
-      rb[e] = okb ? (p.xf_b ? xf(qb) : *qb) : 0.f;
+      ra[e] = (m0 + a_m + e * a_dm < p.M && k0 + a_k + e * a_dk < k_hi) ? *qa : 0.f;
+      rb[e] = (k0 + b_k + e * b_dk < k_hi && n0 + b_n + e * b_dn < p.N) ? *qb : 0.f;
       qa += a_step;
       qb += b_step;
     }
@@ -324,7 +290,6 @@ static bool gemm_setup(GemmParams& p, const float* A, int64_t a_rs, int64_t a_cs
   p.epi_plain = epi_plain;
   p.ext = 0;
   p.e = GemmEpilogue{};
-  p.xf_a = p.xf_b = 0; p.xf_delta = 0; p.xf_ssq = p.xf_dot = nullptr; p.xf_np = 0;
   p.gx = (N + GT - 1) / GT; p.gy = (M + GT - 1) / GT; p.gz = nz;
   return true;
 }
@@ -350,7 +315,7 @@ int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, 
 int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
                          int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
                          const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,
-                         int acc1, hipStream_t st, const GemmOperandXform* xf) {
+                         int acc1, hipStream_t st) {
   GemmBatch b;
   b.n = 0;
   b.first[0] = 0;
@@ -363,13 +328,6 @@ int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const fl
     ++b.n;
   }
   if (b.n == 0) return MKE_OK;
-  if (xf) {  // problem 0: B operand transformed; problem 1: A operand (the attribute step's [dW; dbias] and dflat products)
-    for (int i = 0; i < b.n; ++i) {
-      b.g[i].xf_delta = xf->delta; b.g[i].xf_ssq = xf->ssq; b.g[i].xf_dot = xf->dot; b.g[i].xf_np = xf->n_partials;
-    }
-    if (b.n == 2) { b.g[0].xf_b = 1; b.g[1].xf_a = 1; }
-    else { set_error("operand transform needs both products"); return MKE_E_SHAPE; }
-  }
   hipLaunchKernelGGL(k_gemm_f32_batch, dim3(b.first[b.n]), dim3(MKE_BLOCK), 0, st, b);
   return check_launch("k_gemm_f32_batch");
 }
