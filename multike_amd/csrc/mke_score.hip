@@ -64,10 +64,10 @@ struct ScoreParams {
 __device__ __forceinline__ int64_t stage_slot(int64_t g, int npp, int n, int c) { return ((g * (npp + 1) + n) * 3 + c); }
 
 // one gradient-row contribution: atomic add + touched flag, or (deterministic mode) a plain store into its slot
-template <int FPL>
+template <int FPL, bool DET = false>
 __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, float* __restrict__ table_grad, int32_t* __restrict__ touched,
                                          int row, int64_t slot, int j, const float (&v)[FPL], float sgn) {
-  if (p.stage_keys) {
+  if (DET) {
     float* o = p.stage_rows + slot * p.stride + j;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) o[k * 16] = sgn * v[k];
@@ -79,7 +79,7 @@ __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, floa
 }
 
 // One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
-template <int FPL>
+template <int FPL, bool DET = false>
 __device__ __forceinline__ float independent_triple(const ScoreParams& p, float* __restrict__ grel, int j, int h, int r,
                                                     int t, float w, float sign, int64_t slot0) {
   float H[FPL], R[FPL], T[FPL];
@@ -102,9 +102,9 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
     const float c = 2.0f * sign * w * p.scale * sigmoid_f(z);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) H[k] *= c;
-    emit_row<FPL>(p, false, p.gent, p.tent, h, slot0, j, H, 1.0f);
-    emit_row<FPL>(p, true, grel, p.trel, r, slot0 + 1, j, H, 1.0f);
-    emit_row<FPL>(p, false, p.gent, p.tent, t, slot0 + 2, j, H, -1.0f);
+    emit_row<FPL, DET>(p, false, p.gent, p.tent, h, slot0, j, H, 1.0f);
+    emit_row<FPL, DET>(p, true, grel, p.trel, r, slot0 + 1, j, H, 1.0f);
+    emit_row<FPL, DET>(p, false, p.gent, p.tent, t, slot0 + 2, j, H, -1.0f);
   }
   return l;
 }
@@ -118,7 +118,9 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // QPG (quarter-waves per group): 4 = the wavefront owns one group; 2 = each HALF of the wavefront owns a group of its own
 // (short groups: with the reference's default 10 negatives a whole wavefront leaves a third of its quarter-wave slots
 // idle in the last round and pays the positive's three row loads per 11 triples instead of per 22).
-template <int FPL, int U, bool X, int QPG>  // X: exclusive-row fast path compiled in
+// DET: deterministic staging compiled in (a separate instantiation: its slot arithmetic costs the training kernel ten
+// registers, 129 instead of 119 = three instead of four wavefronts per SIMD)
+template <int FPL, int U, bool X, int QPG, bool DET = false>  // X: exclusive-row fast path compiled in
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                 }
                 if (j == 0) p.refcount[e[u]] = 0;
               } else {
-                emit_row<FPL>(p, false, p.gent, p.tent, e[u], stage_slot(g, npp, n0 + QPG * u, sideH[u] ? 0 : 2), j, d,
+                emit_row<FPL, DET>(p, false, p.gent, p.tent, e[u], stage_slot(g, npp, n0 + QPG * u, sideH[u] ? 0 : 2), j, d,
                               sideH[u] ? 1.0f : -1.0f);
               }
             }
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
           const int64_t idx = nbase + n;
           const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
           if (!((nr == pr) && ((nh != ph) != (nt != pt))))
-            loss += independent_triple<FPL>(p, grel, j, nh, nr, nt, p.nw ? p.nw[idx] : 1.0f, -1.0f, stage_slot(g, npp, n, 0));
+            loss += independent_triple<FPL, DET>(p, grel, j, nh, nr, nt, p.nw ? p.nw[idx] : 1.0f, -1.0f, stage_slot(g, npp, n, 0));
         }
       }
 
@@ -336,15 +338,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
             for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : (q == 1 ? gR[k] : -gT[k]);
             float* __restrict__ base = q == 1 ? grel : p.gent;
             const int row = q == 0 ? ph : (q == 1 ? pr : pt);
-            if (q < 3) emit_row<FPL>(p, q == 1, base, q == 1 ? p.trel : p.tent, row, stage_slot(g, npp, npp, q), j, v, 1.0f);
+            if (q < 3) emit_row<FPL, DET>(p, q == 1, base, q == 1 ? p.trel : p.tent, row, stage_slot(g, npp, npp, q), j, v, 1.0f);
           } else {
             // two quarter-waves per group: quarter 0 -> h, quarter 1 -> t, then quarter 0 -> r
             float v[FPL];
 #pragma unroll
             for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : -gT[k];
             const int row = q == 0 ? ph : pt;
-            emit_row<FPL>(p, false, p.gent, p.tent, row, stage_slot(g, npp, npp, q == 0 ? 0 : 2), j, v, 1.0f);
-            if (q == 0) emit_row<FPL>(p, true, grel, p.trel, pr, stage_slot(g, npp, npp, 1), j, gR, 1.0f);
+            emit_row<FPL, DET>(p, false, p.gent, p.tent, row, stage_slot(g, npp, npp, q == 0 ? 0 : 2), j, v, 1.0f);
+            if (q == 0) emit_row<FPL, DET>(p, true, grel, p.trel, pr, stage_slot(g, npp, npp, 1), j, gR, 1.0f);
           }
         }
       }
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
     for (int64_t i = sub0; i < p.n_pos + p.n_neg; i += nsub) {
       float* __restrict__ grel = bwd ? p.grel + (i % p.grel_copies) * p.grel_copy_elems : nullptr;
       if (i < p.n_pos) {
-        loss += independent_triple<FPL>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f, i * 3);
+        loss += independent_triple<FPL, DET>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f, i * 3);
       } else {
         const int64_t n = i - p.n_pos;
-        loss += independent_triple<FPL>(p, grel, j, p.nh[n], p.nr[n], p.nt[n], p.nw ? p.nw[n] : 1.0f, -1.0f, i * 3);
+        loss += independent_triple<FPL, DET>(p, grel, j, p.nh[n], p.nr[n], p.nt[n], p.nw ? p.nw[n] : 1.0f, -1.0f, i * 3);
       }
     }
   }
@@ -455,7 +457,16 @@ static int score_impl(
     constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);
     // short groups: two groups per wavefront (mke_set_option("score_half_groups", 0) switches it off)
     const bool half = neg_per_pos > 0 && neg_per_pos <= g_score_half_max && splits == 1;
-    if (half) {
+    if (stage_keys) {
+      // deterministic mode: staging stores instead of atomics
+      if (half) {
+        if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+        else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 2, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      } else {
+        if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+        else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      }
+    } else if (half) {
       if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
     } else {
