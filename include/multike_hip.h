@@ -582,7 +582,8 @@ int mke_dense_update_opt(float* param, float* slot1, float* slot2, float* grad, 
  *   l2n = tf.nn.l2_normalize with no axis (the whole [n, dim] batch), M = [n_views][dim][dim] packed, row-major.
  *   One call = forward, backward, the row update of the shared table and the dense update of the matrices (update != 0).
  *   gM must be all-zero on entry (the dense update restores it; with update == 0 the caller reads and clears it).
- *   scratch: mke_mapping_scratch_floats(n, dim) floats.  partials: double[2 * MKE_LOSS_PARTIALS] scratch.
+ *   scratch: mke_mapping_scratch_floats(n, dim) floats.  partials: double[2 * MKE_MAPPING_MAX_VIEWS * MKE_LOSS_PARTIALS]
+ *   scratch (per view k: block 2k = partial sums of P_k^2, block 2k+1 = partial sums of G_k . out_k).
  *   loss_partials: double[(MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS], overwritten: one block per view (map loss) and one
  *   for the orthogonality + norm terms; the loss is the sum of all of it.  dim <= 88.
  * ------------------------------------------------------------------------------------------------ */
@@ -600,6 +601,17 @@ typedef struct mke_mapping_step_args {
 } mke_mapping_step_args;
 int64_t mke_mapping_scratch_floats(int64_t n, int dim);
 int mke_mapping_step(const mke_mapping_step_args* args, double* loss_partials, void* stream);
+/* The same step cut where the batch-wide sums live, for the row-sharded trainer (every rank maps the entities of the step it
+ * owns; multike_amd/distributed_views.py): FWD (gathers, P_k = V_k M_k, partials block 2k) | all-reduce of sum P_k^2 — the
+ * caller replaces block 2k by the total | TAIL (losses, G_k, partials block 2k+1) | all-reduce of sum G_k . out_k, block 2k+1
+ * replaced | BWD (gM += V_k^T dP_k) | all-reduce of gM | UPD (orthogonality / norm terms added to gM, row scatter, updates).
+ * A part with n == 0 contributes zeros.  MKE_MAP_ALL in one call is mke_mapping_step. */
+#define MKE_MAP_FWD 1
+#define MKE_MAP_TAIL 2
+#define MKE_MAP_BWD 4
+#define MKE_MAP_UPD 8
+#define MKE_MAP_ALL 15
+int mke_mapping_step_phases(const mke_mapping_step_args* args, double* loss_partials, int phases, void* stream);
 /* n_steps consecutive steps: step s uses idx[step_off[s] .. step_off[s+1]) (step_off: HOST array), tag args->tag + s, and writes
  * its loss partials to loss_ring[s % ring][(MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS]; args->n is ignored. */
 int mke_mapping_steps(const mke_mapping_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,

@@ -31,7 +31,7 @@ SYMBOLS = (
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
-    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_steps",
+    "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
@@ -464,6 +464,15 @@ def topk_rows(vals: torch.Tensor, k: int, idx=None, seg_count=None, id_map=None,
 
 def mapping_scratch_floats(n: int, dim: int) -> int:
     return int(lib().mke_mapping_scratch_floats(C.c_int64(n), C.c_int(dim)))
+
+
+MAP_FWD, MAP_TAIL, MAP_BWD, MAP_UPD, MAP_ALL = 1, 2, 4, 8, 15
+MAPPING_MAX_VIEWS = 3
+
+
+def mapping_step_phases(args: MappingStepArgs, loss_partials: torch.Tensor, phases: int):
+    rc = lib().mke_mapping_step_phases(C.byref(args), _dev(loss_partials, torch.float64, "loss_partials"), C.c_int(phases), _stream())
+    _check(rc, "mke_mapping_step_phases")
 
 
 def mapping_step(args: MappingStepArgs, loss_partials: torch.Tensor):

@@ -130,7 +130,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_scatter_dense_rows(const int32_t*
   }
 }
 
-static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void* stream) {
+// phases (MKE_MAP_*): the single-GPU step is FWD | TAIL | BWD | UPD back to back; the row-sharded trainer
+// (multike_amd/distributed_views.py) cuts it where the batch-wide sums live — between FWD and TAIL every rank's sum P_k^2,
+// between TAIL and BWD every rank's sum G_k . out_k (it overwrites the partials with the all-reduced totals) — and all-reduces
+// the data part of gM between BWD and UPD; the orthogonality / norm terms depend on the replicated matrices only and are added
+// in UPD, after that reduction, identically on every rank.
+static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void* stream, int phases) {
   if (!a) { set_error("mke_mapping_step: NULL args"); return MKE_E_NULL; }
   const int d = a->dim;
   const int64_t n = a->n;
@@ -138,57 +143,77 @@ static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void
   if (a->n_views < 1 || a->n_views > MKE_MAPPING_MAX_VIEWS) { set_error("mke_mapping_step: n_views must be in [1,%d]", MKE_MAPPING_MAX_VIEWS); return MKE_E_SHAPE; }
   if (!a->ent_table || !a->M || !a->gM || !a->scratch || !a->partials || !loss4 || (n > 0 && !a->idx)) { set_error("mke_mapping_step: NULL pointer"); return MKE_E_NULL; }
   if (a->ent_grad && !a->ent_touched) { set_error("mke_mapping_step: NULL touched array"); return MKE_E_NULL; }
+  if (!(phases & MKE_MAP_ALL)) { set_error("mke_mapping_step: empty phase mask"); return MKE_E_SHAPE; }
   for (int k = 0; k < a->n_views; ++k)
     if (!a->views[k].table) { set_error("mke_mapping_step: view %d has no table", k); return MKE_E_NULL; }
   hipStream_t st = (hipStream_t)stream;
   const int V = a->n_views;
-  if (n == 0) {
-    hipError_t e = hipMemsetAsync(loss4, 0, sizeof(double) * (MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS, st);
-    if (e != hipSuccess) { set_error("mke_mapping_step: memset failed"); return (int)e; }
-    return MKE_OK;
-  }
-  float* F = a->scratch;
-  float* Vr = F + n * d;
-  float* P = Vr + n * d;
-  float* G = P + n * d;
-  float* GF = G + n * d;
-  double* ssq = a->partials;
-  double* dot = a->partials + MKE_LOSS_PARTIALS;
   const int64_t total = n * d;
+  float* F = a->scratch;          // F | GF | per view: V_k, P_k, G_k
+  float* GF = F + total;
+  auto Vr = [&](int k) { return GF + total + (int64_t)k * 3 * total; };
+  auto Pm = [&](int k) { return Vr(k) + total; };
+  auto Gm = [&](int k) { return Vr(k) + 2 * total; };
+  auto ssq = [&](int k) { return a->partials + (int64_t)(2 * k) * MKE_LOSS_PARTIALS; };
+  auto dot = [&](int k) { return a->partials + (int64_t)(2 * k + 1) * MKE_LOSS_PARTIALS; };
   int64_t eb = (total + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
   eb = std::max<int64_t>(1, std::min<int64_t>(eb, MKE_LOSS_PARTIALS));
   int rc;
-  if ((rc = mke_gather_rows(a->ent_table, a->ent_normalize, a->stride, d, a->idx, n, F, stream))) return rc;
-  for (int k = 0; k < V; ++k) {
-    float* M = a->M + (int64_t)k * d * d;
-    float* gM = a->gM + (int64_t)k * d * d;
-    double* lossp = loss4 + (int64_t)k * MKE_LOSS_PARTIALS;
-    if ((rc = mke_gather_rows(a->views[k].table, a->views[k].normalize, a->stride, d, a->idx, n, Vr, stream))) return rc;
-    if ((rc = launch_gemm_f32(Vr, d, 1, M, d, 1, P, d, (int)n, d, d, 1, 0, st, ssq, 1))) return rc;      // P = V M, sum P^2
-    // the tails run on exactly MKE_LOSS_PARTIALS blocks so that every partial slot is rewritten
-    hipLaunchKernelGGL(k_map_tail1, dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, P, F, ssq, total, G, GF, k == 0 ? 1 : 0, lossp, dot);
-    if ((rc = check_launch("k_map_tail1"))) return rc;
-    hipLaunchKernelGGL(k_map_tail2, dim3((unsigned)eb), dim3(MKE_BLOCK), 0, st, P, G, ssq, dot, total);
-    if ((rc = check_launch("k_map_tail2"))) return rc;
-    if ((rc = launch_gemm_f32(Vr, 1, d, G, d, 1, gM, d, d, d, (int)n, 16, 1, st, nullptr, 0))) return rc;  // gM += V^T dP
-  }
-  for (int k = V; k < MKE_MAPPING_MAX_VIEWS; ++k) {
-    hipError_t e = hipMemsetAsync(loss4 + (int64_t)k * MKE_LOSS_PARTIALS, 0, sizeof(double) * MKE_LOSS_PARTIALS, st);
+  auto zero = [&](double* p, int64_t blocks) -> int {
+    hipError_t e = hipMemsetAsync(p, 0, sizeof(double) * blocks * MKE_LOSS_PARTIALS, st);
     if (e != hipSuccess) { set_error("mke_mapping_step: memset failed"); return (int)e; }
+    return MKE_OK;
+  };
+
+  if (phases & MKE_MAP_FWD) {
+    if (n == 0) {
+      for (int k = 0; k < V; ++k) if ((rc = zero(ssq(k), 1))) return rc;   // this part adds nothing to the batch-wide sums
+    } else {
+      if ((rc = mke_gather_rows(a->ent_table, a->ent_normalize, a->stride, d, a->idx, n, F, stream))) return rc;
+      for (int k = 0; k < V; ++k) {
+        if ((rc = mke_gather_rows(a->views[k].table, a->views[k].normalize, a->stride, d, a->idx, n, Vr(k), stream))) return rc;
+        if ((rc = launch_gemm_f32(Vr(k), d, 1, a->M + (int64_t)k * d * d, d, 1, Pm(k), d, (int)n, d, d, 1, 0, st, ssq(k), 1))) return rc;  // P = V M, sum P^2
+      }
+    }
   }
-  hipLaunchKernelGGL(k_map_ortho, dim3(V), dim3(MKE_BLOCK), 2 * d * (d + 1) * sizeof(float), st, a->M, a->gM, d, a->orthogonal_weight, a->norm_w,
-                     loss4 + (int64_t)MKE_MAPPING_MAX_VIEWS * MKE_LOSS_PARTIALS);
-  if ((rc = check_launch("k_map_ortho"))) return rc;
-  if (a->ent_grad) {
-    hipLaunchKernelGGL(k_scatter_dense_rows, dim3((unsigned)eb), dim3(MKE_BLOCK), 0, st, a->idx, GF, n, d, a->stride, a->ent_grad, a->ent_touched, a->tag);
-    if ((rc = check_launch("k_scatter_dense_rows"))) return rc;
+  if (phases & MKE_MAP_TAIL) {
+    if (n == 0) {
+      for (int k = 0; k < V; ++k) {
+        if ((rc = zero(dot(k), 1))) return rc;
+        if ((rc = zero(loss4 + (int64_t)k * MKE_LOSS_PARTIALS, 1))) return rc;
+      }
+    } else {
+      for (int k = 0; k < V; ++k) {
+        // the tails run on exactly MKE_LOSS_PARTIALS blocks so that every partial slot is rewritten
+        hipLaunchKernelGGL(k_map_tail1, dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, Pm(k), F, ssq(k), total, Gm(k), GF, k == 0 ? 1 : 0,
+                           loss4 + (int64_t)k * MKE_LOSS_PARTIALS, dot(k));
+        if ((rc = check_launch("k_map_tail1"))) return rc;
+      }
+    }
+    for (int k = V; k < MKE_MAPPING_MAX_VIEWS; ++k) if ((rc = zero(loss4 + (int64_t)k * MKE_LOSS_PARTIALS, 1))) return rc;
   }
-  if (a->update) {
-    if (a->optimizer != MKE_OPT_ADAGRAD && a->optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", a->optimizer); return MKE_E_UNSUPPORTED; }
-    if (a->optimizer == MKE_OPT_ADAGRAD && (!a->accM || (a->ent_grad && !a->ent_acc))) { set_error("mke_mapping_step: Adagrad needs accumulators"); return MKE_E_NULL; }
-    mke_update_table tab{a->ent_table, a->ent_acc, a->ent_grad, a->ent_touched, a->n_ent, a->ent_normalize, 1, nullptr};
-    DenseJob dj{a->M, a->accM, a->gM, (int64_t)V * d * d, a->optimizer, a->lr, nullptr, 0, 0, 0};
-    if ((rc = launch_rows_update_multi(&tab, a->ent_grad ? 1 : 0, a->tag, a->stride, d, a->optimizer, a->lr, st, nullptr, &dj))) return rc;
+  if ((phases & MKE_MAP_BWD) && n > 0) {
+    for (int k = 0; k < V; ++k) {
+      hipLaunchKernelGGL(k_map_tail2, dim3((unsigned)eb), dim3(MKE_BLOCK), 0, st, Pm(k), Gm(k), ssq(k), dot(k), total);
+      if ((rc = check_launch("k_map_tail2"))) return rc;
+      if ((rc = launch_gemm_f32(Vr(k), 1, d, Gm(k), d, 1, a->gM + (int64_t)k * d * d, d, d, d, (int)n, 16, 1, st, nullptr, 0))) return rc;  // gM += V^T dP
+    }
+  }
+  if (phases & MKE_MAP_UPD) {
+    hipLaunchKernelGGL(k_map_ortho, dim3(V), dim3(MKE_BLOCK), 2 * d * (d + 1) * sizeof(float), st, a->M, a->gM, d, a->orthogonal_weight, a->norm_w,
+                       loss4 + (int64_t)MKE_MAPPING_MAX_VIEWS * MKE_LOSS_PARTIALS);
+    if ((rc = check_launch("k_map_ortho"))) return rc;
+    if (a->ent_grad && n > 0) {
+      hipLaunchKernelGGL(k_scatter_dense_rows, dim3((unsigned)eb), dim3(MKE_BLOCK), 0, st, a->idx, GF, n, d, a->stride, a->ent_grad, a->ent_touched, a->tag);
+      if ((rc = check_launch("k_scatter_dense_rows"))) return rc;
+    }
+    if (a->update) {
+      if (a->optimizer != MKE_OPT_ADAGRAD && a->optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", a->optimizer); return MKE_E_UNSUPPORTED; }
+      if (a->optimizer == MKE_OPT_ADAGRAD && (!a->accM || (a->ent_grad && !a->ent_acc))) { set_error("mke_mapping_step: Adagrad needs accumulators"); return MKE_E_NULL; }
+      mke_update_table tab{a->ent_table, a->ent_acc, a->ent_grad, a->ent_touched, a->n_ent, a->ent_normalize, 1, nullptr};
+      DenseJob dj{a->M, a->accM, a->gM, (int64_t)V * d * d, a->optimizer, a->lr, nullptr, 0, 0, 0};
+      if ((rc = launch_rows_update_multi(&tab, a->ent_grad ? 1 : 0, a->tag, a->stride, d, a->optimizer, a->lr, st, nullptr, &dj))) return rc;
+    }
   }
   return MKE_OK;
 }
@@ -197,11 +222,15 @@ static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void
 
 extern "C" int64_t mke_mapping_scratch_floats(int64_t n, int dim) {
   if (n < 0 || dim <= 0) return 0;
-  return n * (int64_t)dim * 5;  // F | V | P | G | GF
+  return n * (int64_t)dim * (2 + 3 * MKE_MAPPING_MAX_VIEWS);  // F | GF | per view: V, P, G
 }
 
 extern "C" int mke_mapping_step(const mke_mapping_step_args* args, double* loss_partials, void* stream) {
-  return mke::mapping_step_impl(args, loss_partials, stream);
+  return mke::mapping_step_impl(args, loss_partials, stream, MKE_MAP_ALL);
+}
+
+extern "C" int mke_mapping_step_phases(const mke_mapping_step_args* args, double* loss_partials, int phases, void* stream) {
+  return mke::mapping_step_impl(args, loss_partials, stream, phases);
 }
 
 extern "C" int mke_mapping_steps(const mke_mapping_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
@@ -217,7 +246,7 @@ extern "C" int mke_mapping_steps(const mke_mapping_step_args* args, const int64_
     a.idx = args->idx ? args->idx + lo : nullptr;
     a.n = hi - lo;
     a.tag = args->tag + s;
-    const int rc = mapping_step_impl(&a, loss_ring + (int64_t)(s % ring) * (MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS, stream);
+    const int rc = mapping_step_impl(&a, loss_ring + (int64_t)(s % ring) * (MKE_MAPPING_MAX_VIEWS + 1) * MKE_LOSS_PARTIALS, stream, MKE_MAP_ALL);
     if (rc) return rc;
   }
   return MKE_OK;

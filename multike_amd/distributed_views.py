@@ -14,6 +14,14 @@ replicated.  Two consequences:
   and the gradients of the replicated parameters (CNN pack ~91 KB, attribute table) — one all-reduce each before the
   identical update on every rank (`ShardedAttributeView`; native phases: `mke_attr_step_phases`).
 
+* **Space mapping** (SSL driver; code/losses.py:53-63, code/MultiKE_model.py:241-261, 439-454): the sampled entities' rows of
+  the shared table and of the three view tables are local to the entity's owner; the three d x d mapping matrices are
+  replicated.  Per view the mapped batch is normalised as a WHOLE (`tf.nn.l2_normalize` without an axis, losses.py:55):
+  sum P_k^2 in the forward and sum G_k . out_k in its backward — one all-reduce of three scalars each — and the data part of
+  the matrix gradients — one all-reduce of 3 d^2 floats; the orthogonality / norm terms depend on the replicated matrices only
+  and are added after that reduction, identically on every rank (`ShardedSpaceMapping`; native phases:
+  `mke_mapping_step_phases`).
+
 Compute goes through a backend object (HIP kernels in production; tests inject a NumPy backend built on the oracle to run
 this logic under gloo with world_size 2).
 """
@@ -232,3 +240,131 @@ class ShardedCommonSpace:
                 full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].numpy()
             out[k] = full
         return out
+
+
+# ======================================================================================================================
+# Space mapping (SSL driver)
+# ======================================================================================================================
+class HipSpaceMappingBackend:
+    device_type = "cuda"
+
+    def __init__(self, view: "ShardedSpaceMapping", ent0, views0, matrices):
+        from .runner import SpaceMappingState
+        d = view.dim
+        mk = lambda name, vals, trainable: EmbeddingTable(max(1, len(vals)), d, name, normalize=True, trainable=trainable,
+                                                          values=vals if len(vals) else np.zeros((1, d)))
+        self.ent = mk("ent_embeds", ent0, True)
+        self.views = [mk(f"view{k}", v, False) for k, v in enumerate(views0)]
+        self.state = SpaceMappingState([torch.as_tensor(np.asarray(m)) for m in matrices], "cuda")
+        self.eng = StepEngine()
+        LP = _lib.LOSS_PARTIALS
+        self.lossp = torch.zeros((_lib.MAPPING_MAX_VIEWS + 1) * LP, dtype=torch.float64, device="cuda")
+        self.loss = torch.zeros(2, dtype=torch.float64, device="cuda")      # [sum of the ranks' map losses, orthogonality + norm terms]
+        self.args = None
+
+    def _args(self, view, rows):
+        f32, i32 = torch.float32, torch.int32
+        n = len(rows)
+        self._idx = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int32), device="cuda")
+        a = _lib.MappingStepArgs()
+        e = self.ent
+        a.ent_table, a.n_ent, a.ent_normalize = _lib.ptr(e.data, f32, "ent"), e.n_rows, 1
+        a.ent_acc = _lib.ptr(e.slot("mapping"), f32, "acc")
+        a.ent_grad, a.ent_touched = _lib.ptr(e.grad, f32, "grad"), _lib.ptr(e.touched, i32, "touched")
+        a.n_views = len(self.views)
+        for k, t in enumerate(self.views):
+            a.views[k].table, a.views[k].normalize = _lib.ptr(t.data, f32, "view"), 1
+        a.stride, a.dim = e.stride, e.dim
+        a.idx, a.n = (_lib.ptr(self._idx, i32, "idx") if n else None), n
+        st = self.state
+        a.M, a.gM, a.accM = _lib.ptr(st.M, f32, "M"), _lib.ptr(st.gM, f32, "gM"), _lib.ptr(st.accM, f32, "accM")
+        a.orthogonal_weight, a.norm_w = view.orthogonal_weight, view.norm_w
+        a.scratch = _lib.ptr(st.scratch(max(n, 1)), f32, "scratch")
+        a.partials = _lib.ptr(st.partials, torch.float64, "partials")
+        tag, _ = self.eng._next()
+        a.optimizer, a.lr, a.tag, a.update = _lib.OPT_ADAGRAD, view.lr, tag, 1
+        return a
+
+    def _scalars(self, which):
+        LP, V = _lib.LOSS_PARTIALS, len(self.views)
+        return self.state.partials.view(_lib.MAPPING_MAX_VIEWS, 2, LP)[:V, which].sum(dim=1)
+
+    def _set_scalars(self, which, v):
+        LP, V = _lib.LOSS_PARTIALS, len(self.views)
+        blk = self.state.partials.view(_lib.MAPPING_MAX_VIEWS, 2, LP)[:V, which]
+        blk.zero_()
+        blk[:, 0] = v
+
+    def forward(self, view, rows):
+        self.args = self._args(view, rows)
+        _lib.mapping_step_phases(self.args, self.lossp, _lib.MAP_FWD)
+        return self._scalars(0)
+
+    def tail(self, view, S):
+        self._set_scalars(0, S)
+        _lib.mapping_step_phases(self.args, self.lossp, _lib.MAP_TAIL)
+        return self._scalars(1)
+
+    def backward(self, view, T):
+        self._set_scalars(1, T)
+        _lib.mapping_step_phases(self.args, self.lossp, _lib.MAP_BWD)
+        return self.state.gM
+
+    def update(self, view):
+        _lib.mapping_step_phases(self.args, self.lossp, _lib.MAP_UPD)
+        LP, MV = _lib.LOSS_PARTIALS, _lib.MAPPING_MAX_VIEWS
+        self.loss[0] += self.lossp[:MV * LP].sum()
+        self.loss[1] += self.lossp[MV * LP:].sum()
+
+    def take_loss(self):
+        v = self.loss.clone()
+        self.loss.zero_()
+        return v
+
+    def tables(self):
+        return self.ent.raw().cpu().numpy(), self.state.M.double().cpu().numpy()
+
+
+class ShardedSpaceMapping:
+    def __init__(self, ent0, views0, matrices, rank: int, world: int, lr: float = 0.01, orthogonal_weight: float = 2.0,
+                 norm_w: float = 0.0001, backend_cls=None, comm=None):
+        """ent0: the shared table [n_ent, dim]; views0: the (constant) view tables mapped onto it; matrices: [dim, dim] each."""
+        self.rank, self.world, self.lr = rank, world, float(lr)
+        self.orthogonal_weight, self.norm_w = float(orthogonal_weight), float(norm_w)
+        self.dim, self.n_ent = ent0.shape[1], ent0.shape[0]
+        self.comm = comm or ViewComm()
+        self.backend = (backend_cls or HipSpaceMappingBackend)(self, ent0[rank::world], [v[rank::world] for v in views0], matrices)
+
+    def step(self, entities):
+        """One `session.run([shared_comb_loss, shared_comb_optimizer])` on the GLOBAL sample of entity ids (distinct;
+        identical on every rank): this rank maps the entities it owns."""
+        be, cm = self.backend, self.comm
+        _, rows = _owned(entities, self.rank, self.world)
+        S = be.forward(self, rows)
+        cm.all_reduce(S)                                   # per view: sum P^2 over the whole batch (code/losses.py:55)
+        T = be.tail(self, S)
+        cm.all_reduce(T)                                   # per view: sum G . out over the whole batch (its backward)
+        cm.all_reduce(be.backward(self, T))                # data part of the three matrix gradients
+        be.update(self)
+
+    def epoch_loss(self) -> float:
+        t = self.backend.take_loss()
+        data = t[0:1].clone()
+        self.comm.all_reduce(data)
+        return float(data) + float(t[1])                   # the orthogonality / norm terms are the same on every rank
+
+    def gather(self):
+        """(full shared table [n_ent, dim], matrices [n_views, dim, dim]) — tests / checkpoint."""
+        ent, M = self.backend.tables()
+        pad = -(-self.n_ent // self.world)
+        n_local = len(range(self.rank, self.n_ent, self.world))
+        mine = torch.zeros(pad, self.dim, dtype=torch.float64)
+        mine[:n_local] = torch.as_tensor(ent[:n_local], dtype=torch.float64)
+        if self.world == 1 or not dist.is_initialized():
+            return mine[:n_local].numpy(), M
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        full = np.zeros((self.n_ent, self.dim))
+        for r in range(self.world):
+            full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].numpy()
+        return full, M

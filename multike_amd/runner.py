@@ -271,7 +271,7 @@ class SpaceMappingState:
         self.M = torch.stack([m.detach().to(device=device, dtype=torch.float32) for m in matrices]).contiguous()
         self.gM = torch.zeros_like(self.M)
         self.accM = torch.full_like(self.M, 0.1)                 # tf.train.AdagradOptimizer initial accumulator
-        self.partials = torch.zeros(2 * _lib.LOSS_PARTIALS, dtype=torch.float64, device=device)
+        self.partials = torch.zeros(2 * _lib.MAPPING_MAX_VIEWS * _lib.LOSS_PARTIALS, dtype=torch.float64, device=device)
         self._scratch = None
 
     def scratch(self, n):

@@ -369,3 +369,75 @@ class OracleCommonSpaceBackend:
 
     def tables(self):
         return {k: self.t[k] for k in ("ent", "rv", "av")}
+
+
+class OracleSpaceMappingBackend:
+    """NumPy (float64) part-wise evaluation of the space-mapping step (oracle.space_mapping_grads cut at the two batch-wide
+    sums), for multike_amd.distributed_views.ShardedSpaceMapping under gloo."""
+    device_type = "cpu"
+
+    def __init__(self, view, ent0, views0, matrices):
+        self.ent = np.array(ent0, dtype=np.float64)
+        self.acc_ent = np.full_like(self.ent, 0.1)
+        self.views = [np.array(v, dtype=np.float64) for v in views0]
+        self.M = [np.array(m, dtype=np.float64) for m in matrices]
+        self.accM = [np.full_like(m, 0.1) for m in self.M]
+        self.loss = np.zeros(2)
+
+    def forward(self, view, rows):
+        import torch
+        self.rows = np.asarray(rows, dtype=np.int64)
+        E = mo.l2_normalize_rows(self.ent) if len(self.ent) else self.ent
+        self.F = E[self.rows]
+        self.V = [(mo.l2_normalize_rows(t) if len(t) else t)[self.rows] for t in self.views]
+        self.P = [v @ m for v, m in zip(self.V, self.M)]
+        return torch.tensor([float(np.sum(p * p)) for p in self.P], dtype=torch.float64)
+
+    def tail(self, view, S):
+        import torch
+        S = S.numpy()
+        self.inv = [1.0 / np.sqrt(max(s, mo.L2_EPS)) for s in S]
+        self.S = S
+        self.out = [p * i for p, i in zip(self.P, self.inv)]
+        self.gF = np.zeros_like(self.F)
+        self.G = []
+        T = []
+        for out in self.out:
+            diff = self.F - out
+            self.loss[0] += float(np.sum(diff * diff))
+            self.gF += 2.0 * diff
+            self.G.append(-2.0 * diff)
+            T.append(float(np.sum(self.G[-1] * out)))
+        return torch.tensor(T, dtype=torch.float64)
+
+    def backward(self, view, T):
+        import torch
+        T = T.numpy()
+        g = []
+        for k in range(len(self.M)):
+            dP = self.inv[k] * (self.G[k] - self.out[k] * T[k]) if self.S[k] > mo.L2_EPS else self.inv[k] * self.G[k]
+            g.append(self.V[k].T @ dP)
+        self.gM = torch.as_tensor(np.stack(g))
+        return self.gM
+
+    def update(self, view):
+        gM = self.gM.numpy()
+        d = self.M[0].shape[0]
+        for k, M in enumerate(self.M):
+            Q = M @ M.T - np.eye(d)
+            self.loss[1] += view.orthogonal_weight * float(np.sum(Q * Q)) + view.norm_w * float(np.sum(M * M))
+            g = gM[k] + view.orthogonal_weight * 4.0 * (Q @ M) + view.norm_w * 2.0 * M
+            mo.adagrad_dense(M, self.accM[k], g, view.lr)
+        if len(self.rows):
+            ge = np.zeros_like(self.ent)
+            np.add.at(ge, self.rows, self.gF)
+            mo.adagrad_dense(self.ent, self.acc_ent, mo.l2_normalize_rows_backward(self.ent, ge), view.lr)
+
+    def take_loss(self):
+        import torch
+        v = torch.as_tensor(self.loss.copy())
+        self.loss[:] = 0.0
+        return v
+
+    def tables(self):
+        return self.ent, np.stack(self.M)

@@ -139,3 +139,56 @@ def test_sharded_common_space_equals_single_process_oracle():
     np.testing.assert_allclose(loss, tot, rtol=1e-12)
     for k, ref in (("ent", ent), ("rv", rv), ("av", av)):
         np.testing.assert_allclose(out[k], ref, rtol=1e-10, atol=1e-13, err_msg=k)
+
+
+def _sm_data():
+    rng = np.random.default_rng(SEED + 2)
+    mk = lambda: mo.xavier_truncated_normal((N_ENT, DIM), rng).astype(np.float64)
+    ent, views = mk(), [mk(), mk(), mk()]
+    mats = [np.eye(DIM) + 0.1 * rng.standard_normal((DIM, DIM)) for _ in range(3)]
+    batches = [rng.choice(N_ENT, 19, replace=False) for _ in range(STEPS)]
+    batches[1] = 3 * rng.choice(N_ENT // 3, 6, replace=False)   # multiples of 3: ranks 1, 2 of 3 own nothing in this step
+    return ent, views, mats, batches
+
+
+def _sm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import ShardedSpaceMapping
+        from oracle_backend import OracleSpaceMappingBackend
+        ent, views, mats, batches = _sm_data()
+        v = ShardedSpaceMapping(ent, views, mats, rank, world, lr=0.05, orthogonal_weight=2.0, backend_cls=OracleSpaceMappingBackend)
+        for ids in batches:
+            v.step(ids)
+        loss = v.epoch_loss()
+        full, M = v.gather()
+        if rank == 0:
+            ret.put((full, M, loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_space_mapping_equals_single_process_oracle(world):
+    """SSL space-mapping step (code/losses.py:53-63): per view the two batch-wide sums of the axis-less l2_normalize and the
+    matrix gradients are all-reduced; the orthogonality terms are added once, after the reduction."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sm_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, M, loss = ret.get(timeout=240)
+    for q in procs:
+        q.join(60)
+        assert q.exitcode == 0
+    ent, views, mats, batches = _sm_data()
+    acc_e = np.full_like(ent, 0.1)
+    acc_m = [np.full_like(m, 0.1) for m in mats]
+    tot = sum(mo.space_mapping_step_dense(ent, acc_e, [(v, True) for v in views], mats, acc_m, ids, 0.05, 2.0) for ids in batches)
+    np.testing.assert_allclose(loss, tot, rtol=1e-11)
+    np.testing.assert_allclose(full, ent, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(M, np.stack(mats), rtol=1e-9, atol=1e-12)
