@@ -130,3 +130,72 @@ def test_two_ranks_common_space_equals_dense_oracle():
     np.testing.assert_allclose(loss, tot, rtol=2e-6)
     for k, ref in (("ent", ent), ("rv", rv), ("av", av)):
         np.testing.assert_allclose(out[k], ref, rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def _sm_data():
+    rng = np.random.default_rng(SEED + 2)
+    mk = lambda: mo.xavier_truncated_normal((N_ENT, DIM), rng)
+    ent, views = mk(), [mk(), mk(), mk()]
+    mats = [(np.eye(DIM) + 0.05 * rng.standard_normal((DIM, DIM))).astype(np.float32) for _ in range(3)]
+    batches = [rng.choice(N_ENT, 500, replace=False) for _ in range(STEPS)]
+    batches[1] = 2 * rng.choice(N_ENT // 2, 60, replace=False)   # rank 1 of 2 owns none of this step's entities
+    return ent, views, mats, batches
+
+
+def _sm_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import HostStagedViewComm, ShardedSpaceMapping
+        torch.cuda.set_device(0)
+        ent, views, mats, batches = _sm_data()
+        v = ShardedSpaceMapping(ent, views, mats, rank, world, lr=0.01, orthogonal_weight=2.0, comm=HostStagedViewComm())
+        for ids in batches:
+            v.step(ids)
+        loss = v.epoch_loss()
+        full, M = v.gather()
+        ok = float(v.backend.state.gM.abs().max()) == 0.0 and float(v.backend.ent.grad.abs().max()) == 0.0
+        if rank == 0:
+            ret.put((full, M, loss, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def _sm_reference():
+    ent, views, mats, batches = _sm_data()
+    e64 = ent.astype(np.float64)
+    v64 = [(v.astype(np.float64), True) for v in views]
+    m64 = [m.astype(np.float64) for m in mats]
+    acc_e, acc_m = np.full_like(e64, 0.1), [np.full_like(m, 0.1) for m in m64]
+    tot = sum(mo.space_mapping_step_dense(e64, acc_e, v64, m64, acc_m, ids, 0.01, 2.0) for ids in batches)
+    return e64, np.stack(m64), tot
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_space_mapping_equals_dense_oracle():
+    """mke_mapping_step_phases on two ranks sharing the GPU: per view the batch-wide sums and the matrix gradients travel
+    through the (host-staged) all-reduces; a step in which rank 1 owns nothing."""
+    full, M, loss, ok = _run(_sm_worker)
+    e64, m64, tot = _sm_reference()
+    assert ok
+    np.testing.assert_allclose(loss, tot, rtol=2e-5)
+    np.testing.assert_allclose(full, e64, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(M, m64, rtol=2e-4, atol=2e-6)
+
+
+def test_one_rank_space_mapping_phases_equal_the_single_call():
+    """The phased step at world 1 (no process group) against the float64 oracle — and therefore against mke_mapping_step,
+    which tests/test_mapping_gpu.py pins to the same oracle."""
+    from multike_amd.distributed_views import ShardedSpaceMapping
+    ent, views, mats, batches = _sm_data()
+    v = ShardedSpaceMapping(ent, views, mats, 0, 1, lr=0.01, orthogonal_weight=2.0)
+    for ids in batches:
+        v.step(ids)
+    loss = v.epoch_loss()
+    full, M = v.gather()
+    e64, m64, tot = _sm_reference()
+    np.testing.assert_allclose(loss, tot, rtol=2e-5)
+    np.testing.assert_allclose(full, e64, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(M, m64, rtol=2e-4, atol=2e-6)
