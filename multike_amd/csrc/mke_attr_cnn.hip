@@ -502,6 +502,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p
   if (threadIdx.x == 0) {
     p.lossp[blockIdx.x] = lt * (double)p.scale;
     p.dotp[blockIdx.x] = dt;
+    // one pass over the rows takes n / 16 blocks; the partial slots no block owns are cleared here (every block of this and
+    // of the next kernel re-adds all MKE_LOSS_PARTIALS slots: 2048 blocks doing that was 32 MB of L2 reads)
+    for (int k = blockIdx.x + gridDim.x; k < MKE_LOSS_PARTIALS; k += gridDim.x) { p.lossp[k] = 0.0; p.dotp[k] = 0.0; }
   }
 }
 
@@ -638,8 +641,10 @@ extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, 
   p.ws = weights; p.scale = scale; p.n = n; p.dim = dim; p.gout = gout; p.dotp = dot_partials; p.gent = grad_ent;
   p.tent = touched_ent; p.tag = tag; p.lossp = loss_partials;
   const int fpl = ent_stride / 16;
+  int64_t blocks = (n + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK;
+  blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, MKE_LOSS_PARTIALS));
   MKE_DISPATCH_FPL(fpl, {
-    hipLaunchKernelGGL((k_attr_tail_loss<FPL>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((k_attr_tail_loss<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   });
   return check_launch("k_attr_tail_loss");
 }

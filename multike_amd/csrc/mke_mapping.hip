@@ -59,6 +59,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_map_tail1(const float* __restrict
   if (threadIdx.x == 0) {
     lossp[blockIdx.x] = lt;
     dotp[blockIdx.x] = dt;
+    for (int k = blockIdx.x + gridDim.x; k < MKE_LOSS_PARTIALS; k += gridDim.x) { lossp[k] = 0.0; dotp[k] = 0.0; }   // slots no block owns
   }
 }
 
@@ -184,8 +185,8 @@ static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void
       }
     } else {
       for (int k = 0; k < V; ++k) {
-        // the tails run on exactly MKE_LOSS_PARTIALS blocks so that every partial slot is rewritten
-        hipLaunchKernelGGL(k_map_tail1, dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, Pm(k), F, ssq(k), total, Gm(k), GF, k == 0 ? 1 : 0,
+        // every partial slot is rewritten: a block clears the slots beyond the grid (each block re-adds all of them)
+        hipLaunchKernelGGL(k_map_tail1, dim3((unsigned)eb), dim3(MKE_BLOCK), 0, st, Pm(k), F, ssq(k), total, Gm(k), GF, k == 0 ? 1 : 0,
                            loss4 + (int64_t)k * MKE_LOSS_PARTIALS, dot(k));
         if ((rc = check_launch("k_map_tail1"))) return rc;
       }

@@ -161,15 +161,13 @@ struct MultiUpdateParams {
 
 template <int FPL, bool SHARD>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
-  const int64_t upd_blocks = mp.n_tables > 0 ? mp.block_end[mp.n_tables - 1] : 0;
-  if ((int64_t)blockIdx.x >= upd_blocks + mp.count_blocks) {  // rider blocks: dense parameter update
-    dense_update_range(mp.dj, (int64_t)blockIdx.x - upd_blocks - mp.count_blocks, mp.dense_blocks);
-    return;
-  }
-  if ((int64_t)blockIdx.x >= upd_blocks) {  // rider blocks: count the next step's entity references
+  // rider blocks come FIRST in the grid: they are dispatched with the first update blocks and finish under them (at the end
+  // of the grid they were a tail of their own: 13.6 -> 16.7 us at the C2 shape)
+  const int64_t riders = (int64_t)mp.count_blocks + mp.dense_blocks;
+  if ((int64_t)blockIdx.x < mp.count_blocks) {  // count the next step's entity references
     const mke_count_job& c = mp.cj;
     const int64_t total = c.n_pos + c.n_neg;
-    for (int64_t i = ((int64_t)blockIdx.x - upd_blocks) * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)mp.count_blocks * MKE_BLOCK) {
+    for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)mp.count_blocks * MKE_BLOCK) {
       if (i < c.n_pos) {
         atomicAdd(&c.ref_count[c.pos_h[i]], 1);
         atomicAdd(&c.ref_count[c.pos_t[i]], 1);
@@ -183,15 +181,20 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
     }
     return;
   }
+  if ((int64_t)blockIdx.x < riders) {  // dense parameter update
+    dense_update_range(mp.dj, (int64_t)blockIdx.x - mp.count_blocks, mp.dense_blocks);
+    return;
+  }
+  const int64_t ub = (int64_t)blockIdx.x - riders;   // index among the update blocks
   int ti = 0;
   int64_t first = 0;
 #pragma unroll
   for (int k = 0; k < MKE_MAX_UPDATE_TABLES - 1; ++k) {
-    if (ti == k && k + 1 < mp.n_tables && (int64_t)blockIdx.x >= mp.block_end[k]) { first = mp.block_end[k]; ti = k + 1; }
+    if (ti == k && k + 1 < mp.n_tables && ub >= mp.block_end[k]) { first = mp.block_end[k]; ti = k + 1; }
   }
   const UpdateParams& p = mp.t[ti];
   const int j = threadIdx.x & 15;
-  const int64_t wave = (((int64_t)blockIdx.x - first) * MKE_BLOCK + threadIdx.x) >> 6;
+  const int64_t wave = ((ub - first) * MKE_BLOCK + threadIdx.x) >> 6;
   walk_chunk<FPL, SHARD>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
