@@ -156,7 +156,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
           for (int kh = 0; kh + h < 2; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 4; ++kw) acc = fmaf(k1[(kh * 4 + kw) * 2 + f], xs[h + kh][w + kw], acc);
-          c1[h][f][i] = w < d ? tanhf(acc) : 0.f;
+          c1[h][f][i] = w < d ? tanh_f(acc) : 0.f;
           c1s[h][f][w + 1] = c1[h][f][i];
         }
     }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
             for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
               for (int c = 0; c < 2; ++c) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], c1s[h + kh][c][w + kw], acc);
-          c2[h][f][i] = w < d ? tanhf(acc) : 0.f;
+          c2[h][f][i] = w < d ? tanh_f(acc) : 0.f;
           ssq[h][f] = fmaf(c2[h][f][i], c2[h][f][i], ssq[h][f]);
         }
     }
