@@ -352,7 +352,13 @@ def main():
             trainer.bat.shuffle()
         else:
             from multike_amd.distributed_oc import OcHostStagedComm, OwnerComputesTrainer
-            chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 else "1"))
+            # split-batch pipelining pays when a collective's wire time is well above what an asynchronous collective
+            # costs on its own (tools/rccl_latency.py at world 1: ~30 us of device time per async call + wait against
+            # ~15 us in line; 27 us against 13 us on the host): two parts when a rank's all-gather moves >= 32 MB
+            # (the c5 shape at 8 ranks: 75 MB), one otherwise (c2: 23.5 MB)
+            stride_f = (d + 15) // 16 * 16
+            wire = (world - 1) * 2 * 1.05 * B * stride_f * 4
+            chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 and wire >= 32e6 else "1"))
             # MKE_SHARD_PEER=1: peer-mapped blocks read / written directly by the score kernel instead of the all-gather /
             # reduce-scatter (opt-in: exercised with two ranks on one GPU only)
             trainer = OwnerComputesTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, chunks=chunks,
