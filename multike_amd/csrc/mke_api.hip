@@ -30,6 +30,7 @@ int check_launch(const char* what) {
 namespace mke {
 int g_score_splits = 0;
 int g_score_half_max = 12;   // groups of <= 12 negatives: two groups per wavefront (mke_score.hip)
+int g_score_o32 = 1;         // 32-bit row offsets in the training kernel when the tables allow (mke_score.hip, row_at)
 int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on large tables: 0 = by table size, 16, 64
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
 }
@@ -44,6 +45,11 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "score_half_groups")) {
     if (old_value) *old_value = mke::g_score_half_max;
     mke::g_score_half_max = value < 0 ? 0 : (value > 32 ? 32 : value);
+    return MKE_OK;
+  }
+  if (!strcmp(name, "score_offsets32")) {
+    if (old_value) *old_value = mke::g_score_o32;
+    mke::g_score_o32 = value != 0;
     return MKE_OK;
   }
   if (!strcmp(name, "update_chunk")) {

@@ -18,6 +18,7 @@ namespace mke {
 #define MKE_SCORE_U 2
 #endif
 extern int g_score_splits;    // mke_set_option("score_splits")
+extern int g_score_o32;       // mke_set_option("score_offsets32"), default 1
 extern int g_score_half_max;  // mke_set_option("score_half_groups"): largest neg_per_pos scored two groups per wavefront (0 = off)
 
 struct ScoreParams {
@@ -63,8 +64,29 @@ struct ScoreParams {
 // slot of contribution c (0 head row, 1 relation row, 2 tail row) of triple n of group g (n == npp: the group's flush)
 __device__ __forceinline__ int64_t stage_slot(int64_t g, int npp, int n, int c) { return ((g * (npp + 1) + n) * 3 + c); }
 
+// Address of column j of a row.  O32 (tables below 4 GB): byte offset in 32 bits with the compile-time stride, so that the
+// access is `global_* v_off, s[base]` — the generic form costs a 64-bit multiply-add per row and pointer (v_mad_u64_u32 /
+// v_lshl_add_u64: 34 such instructions per loop iteration of the training kernel, each worth four ordinary VALU slots)
+template <int FPL, bool O32>
+__device__ __forceinline__ float* row_at(const float* base, int row, int stride, int j) {
+  if (O32) return (float*)((char*)const_cast<float*>(base) + (((uint32_t)row * (uint32_t)(FPL * 16) + (uint32_t)j) << 2));
+  return const_cast<float*>(base) + (int64_t)row * stride + j;
+}
+template <int FPL>
+__device__ __forceinline__ void load_at(const float* __restrict__ q, float (&v)[FPL]) {
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) v[k] = q[k * 16];
+}
+template <int FPL>
+__device__ __forceinline__ void atomic_add_at(float* __restrict__ q, int dim, int j, const float (&v)[FPL], float sgn) {
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    if (k * 16 + 16 <= dim || k * 16 + j < dim) atomic_add_f32(q + k * 16, sgn * v[k]);
+  }
+}
+
 // one gradient-row contribution: atomic add + touched flag, or (deterministic mode) a plain store into its slot
-template <int FPL, bool DET = false>
+template <int FPL, bool DET = false, bool O32 = false>
 __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, float* __restrict__ table_grad, int32_t* __restrict__ touched,
                                          int row, int64_t slot, int j, const float (&v)[FPL], float sgn) {
   if (DET) {
@@ -73,7 +95,7 @@ __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, floa
     for (int k = 0; k < FPL; ++k) o[k * 16] = sgn * v[k];
     if (j == 0) p.stage_keys[slot] = (is_rel ? MKE_STAGE_REL : 0ll) | (int64_t)row;
   } else {
-    atomic_add_row<FPL>(table_grad, row, p.stride, p.dim, j, v, sgn);
+    atomic_add_at<FPL>(row_at<FPL, O32>(table_grad, row, p.stride, j), p.dim, j, v, sgn);
     if (j == 0) touched[row] = p.tag;
   }
 }
@@ -120,7 +142,7 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // idle in the last round and pays the positive's three row loads per 11 triples instead of per 22).
 // DET: deterministic staging compiled in (a separate instantiation: its slot arithmetic costs the training kernel ten
 // registers, 129 instead of 119 = three instead of four wavefronts per SIMD)
-template <int FPL, int U, bool X, int QPG, bool DET = false>  // X: exclusive-row fast path compiled in
+template <int FPL, int U, bool X, int QPG, bool DET = false, bool O32 = false>  // X: exclusive-row fast path compiled in; O32: see row_at
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
@@ -147,9 +169,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
       const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
       float H[FPL], R[FPL], T[FPL];
-      load_row<FPL>(p.ent, ph, p.stride, j, H);
-      load_row<FPL>(p.rel, pr, p.stride, j, R);
-      load_row<FPL>(p.ent, pt, p.stride, j, T);
+      load_at<FPL>(row_at<FPL, O32>(p.ent, ph, p.stride, j), H);
+      load_at<FPL>(row_at<FPL, O32>(p.rel, pr, p.stride, j), R);
+      load_at<FPL>(row_at<FPL, O32>(p.ent, pt, p.stride, j), T);
       l2_normalize_row<FPL>(H, p.ent_norm);
       l2_normalize_row<FPL>(R, p.rel_norm);
       l2_normalize_row<FPL>(T, p.ent_norm);
@@ -213,10 +235,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         for (int u = 0; u < U; ++u) {
           cnt[u] = 0;
           if (fast[u]) {
-            load_row<FPL>(p.ent, e[u], p.stride, j, C[u]);
+            load_at<FPL>(row_at<FPL, O32>(p.ent, e[u], p.stride, j), C[u]);
             if constexpr (X) {
               cnt[u] = p.refcount[e[u]];
-              if (p.ent_acc) load_row<FPL>(p.ent_acc, e[u], p.stride, j, A[u]);
+              if (p.ent_acc) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
             }
           } else {
 #pragma unroll
@@ -278,9 +300,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 #pragma unroll
                   for (int k = 0; k < FPL; ++k) g[k] = sg * d[k];
                 }
-                float* wp = p.ent_w + (int64_t)e[u] * p.stride + j;
+                float* wp = row_at<FPL, O32>(p.ent_w, e[u], p.stride, j);
                 if (p.optimizer == MKE_OPT_ADAGRAD) {
-                  float* ap = p.ent_acc + (int64_t)e[u] * p.stride + j;
+                  float* ap = row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j);
 #pragma unroll
                   for (int k = 0; k < FPL; ++k) {
                     const float a = fmaf(g[k], g[k], A[u][k]);
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
                 }
                 if (j == 0) p.refcount[e[u]] = 0;
               } else {
-                emit_row<FPL, DET>(p, false, p.gent, p.tent, e[u], stage_slot(g, npp, n0 + QPG * u, sideH[u] ? 0 : 2), j, d,
+                emit_row<FPL, DET, O32>(p, false, p.gent, p.tent, e[u], stage_slot(g, npp, n0 + QPG * u, sideH[u] ? 0 : 2), j, d,
                               sideH[u] ? 1.0f : -1.0f);
               }
             }
@@ -450,6 +472,8 @@ static int score_impl(
   p.refcount = excl ? ref_count : nullptr; p.ent_w = ent_w; p.ent_acc = ent_acc; p.optimizer = optimizer; p.lr = lr;
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;
+  // every row address of the launch fits 32 bits of byte offset (entity table = accumulator = gradient scratch in size)
+  const bool o32 = g_score_o32 && n_ent * (int64_t)stride < (1ll << 30) && n_rel * (int64_t)stride < (1ll << 30);
   MKE_DISPATCH_FPL(fpl, {
     // corrupt rows in flight per quarter-wave.  2, not 4, at FPL <= 5: with the accumulator rows of the exclusive-row path
     // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
@@ -466,6 +490,9 @@ static int score_impl(
         if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
         else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       }
+    } else if (excl && o32) {   // the training step on tables below 4 GB: 32-bit row offsets (row_at)
+      if (half) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
     } else if (half) {
       if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
