@@ -535,9 +535,18 @@ def main():
             out["variants"] = variants
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio: into a pipe that is flushed at exit, i.e. AFTER everything Python
+    # printed.  Flush it now, so that the JSON line is the last line of the stream whatever the parser takes.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

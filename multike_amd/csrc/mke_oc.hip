@@ -96,6 +96,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) {
 // in flight per quarter.
 template <int FPL, int U>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
+  constexpr int STRIDE = FPL * 16;   // == s.stride (the dispatch picks FPL from it): row offsets by shift-add, not a 64-bit multiply
   const mke_oc_step& s = p.s;
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
     const int home = (int)(i / s.per);
     // the vectors' home: this rank's all-gathered copy, or (peer-direct) the owner's own send block over xGMI
-    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * s.stride;
-    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * s.stride;
+    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * STRIDE;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
-    load_row<FPL>(vh, 0, s.stride, j, HR);
-    load_row<FPL>(vt, 0, s.stride, j, RT);
+    load_row<FPL>(vh, 0, STRIDE, j, HR);
+    load_row<FPL>(vt, 0, STRIDE, j, RT);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
     int code = 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
 
     if (home == s.rank && q == 0) {  // the positive itself: d = h^ + r^ - t^ = HR + RT - r^
       float R[FPL];
-      load_row<FPL>(s.rel, pr, s.stride, j, R);
+      load_row<FPL>(s.rel, pr, STRIDE, j, R);
       l2_normalize_row<FPL>(R, true);
       float d[FPL];
       float x = 0.f;
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         gHR[k] += d[k];   // -> head row +g, relation row +g
         gRT[k] += d[k];   // -> relation row +g, tail row -g;  the relation row's surplus g is taken back here:
       }
-      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
-      atomic_add_row<FPL>(grel, pr, s.stride, s.dim, j, d, -1.0f);
+      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)STRIDE);
+      atomic_add_row<FPL>(grel, pr, STRIDE, s.dim, j, d, -1.0f);
       if (j == 0) s.rel_touched[pr] = s.tag;
     }
 
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
       for (int u = 0; u < U; ++u) {
         cnt[u] = 0;
         if (live[u]) {
-          load_row<FPL>(s.ent, e[u], s.stride, j, Cr[u]);
+          load_row<FPL>(s.ent, e[u], STRIDE, j, Cr[u]);
           cnt[u] = s.ref_count ? s.ref_count[e[u]] : 0;
-          if (s.ref_count && s.ent_acc) load_row<FPL>(s.ent_acc, e[u], s.stride, j, A[u]);
+          if (s.ref_count && s.ent_acc) load_row<FPL>(s.ent_acc, e[u], STRIDE, j, A[u]);
         } else {
 #pragma unroll
           for (int k = 0; k < FPL; ++k) Cr[u][k] = 0.f;
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
           float g[FPL];
 #pragma unroll
           for (int k = 0; k < FPL; ++k) g[k] = fmaf(a2, Cr[u][k], a1 * d[k]);
-          float* wp = s.ent + (int64_t)e[u] * s.stride + j;
+          float* wp = s.ent + (int64_t)e[u] * STRIDE + j;
           if (s.optimizer == MKE_OPT_ADAGRAD) {
-            float* ap = s.ent_acc + (int64_t)e[u] * s.stride + j;
+            float* ap = s.ent_acc + (int64_t)e[u] * STRIDE + j;
 #pragma unroll
             for (int k = 0; k < FPL; ++k) {
               const float a = fmaf(g[k], g[k], A[u][k]);
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
           }
           if (j == 0) s.ref_count[e[u]] = 0;
         } else {
-          atomic_add_row<FPL>(s.ent_grad, e[u], s.stride, s.dim, j, d, sg);
+          atomic_add_row<FPL>(s.ent_grad, e[u], STRIDE, s.dim, j, d, sg);
           if (j == 0) s.ent_touched[e[u]] = s.tag;
         }
       }
@@ -241,10 +242,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
       gRT[k] += __shfl_xor(gRT[k], 16, 64); gRT[k] += __shfl_xor(gRT[k], 32, 64);
     }
     if (q < 2) {
-      const int64_t gb = 2 * C * (int64_t)s.stride;
+      const int64_t gb = 2 * C * (int64_t)STRIDE;
       const int own = q == 0 ? ph % G : pt % G;
       float* o = (s.n_peers ? s.peer_g[own] : p.g_all + (int64_t)own * gb) +
-                 (q == 0 ? (int64_t)s.slot_h[i] : C + s.slot_t[i]) * s.stride + j;
+                 (q == 0 ? (int64_t)s.slot_h[i] : C + s.slot_t[i]) * STRIDE + j;
 #pragma unroll
       for (int k = 0; k < FPL; ++k) o[k * 16] = q == 0 ? gHR[k] : gRT[k];
     }

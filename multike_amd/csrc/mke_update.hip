@@ -38,8 +38,9 @@ struct UpdateParams {
 // single-GPU step does not carry its registers and branches
 template <int FPL, bool SHARD>
 __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t row, int j) {
-  float* gp = p.grad + row * (int64_t)p.stride + j;
-  float* wp = p.table + row * (int64_t)p.stride + j;
+  constexpr int64_t STRIDE = FPL * 16;   // == p.stride (the dispatch picks FPL from it): a shift-add, not a 64-bit multiply
+  float* gp = p.grad + row * STRIDE + j;
+  float* wp = p.table + row * STRIDE + j;
   float g[FPL], w[FPL], a[FPL];
   if (SHARD && p.slot_of) {  // rank-ordered sum of the rows sent back for this row (deterministic, no atomics)
     int32_t* so = p.slot_of + row * (int64_t)p.n_ranks;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 #pragma unroll
   for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
   const bool adagrad = p.optimizer == MKE_OPT_ADAGRAD;
-  float* ap = adagrad ? p.acc + row * (int64_t)p.stride + j : nullptr;
+  float* ap = adagrad ? p.acc + row * STRIDE + j : nullptr;
   if (adagrad) {
 #pragma unroll
     for (int k = 0; k < FPL; ++k) a[k] = ap[k * 16];
