@@ -166,6 +166,9 @@ static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void
     return MKE_OK;
   };
 
+  if (n == 0 && phases == MKE_MAP_ALL) {   // an empty step of the single-GPU loop: no loss, nothing moves
+    return zero(loss4, MKE_MAPPING_MAX_VIEWS + 1);
+  }
   if (phases & MKE_MAP_FWD) {
     if (n == 0) {
       for (int k = 0; k < V; ++k) if ((rc = zero(ssq(k), 1))) return rc;   // this part adds nothing to the batch-wide sums
