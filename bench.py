@@ -340,9 +340,9 @@ def main():
     if world > 1 or args.force_sharded:
         if dist is None:  # exercise the sharded path on one GPU (1-rank RCCL group)
             import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            import tempfile
+            dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))   # a rendezvous file: no TCP port to collide on
         # MKE_SHARD_MODE=oc (default): owner-computes step (multike_amd/distributed_oc.py: the negatives go to the rows, 2
         # vectors per positive cross the links); =rowfetch: round 1's row-exchange step (multike_amd/distributed.py)
         shard_mode = os.environ.get("MKE_SHARD_MODE", "oc")

@@ -151,6 +151,22 @@ int mke_triple_score_fwd_bwd_x(
     int32_t* ref_count, float* ent_acc /*nullable for SGD*/, int optimizer, float lr,
     double* loss_partials, void* stream);
 
+/* The same, and the first blocks of the launch also count the entity references of the NEXT step into next_count->ref_count
+ * (mke_count_entity_refs semantics; a different buffer than `ref_count`; NULL = plain mke_triple_score_fwd_bwd_x): the counting
+ * finishes under the scoring blocks instead of paying a launch or a tail of its own.  mke_count_job: section (2). */
+struct mke_count_job;
+int mke_triple_score_fwd_bwd_xc(
+    float* ent_table, int64_t n_ent, int ent_normalize,
+    const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim,
+    const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w /*nullable*/, int64_t n_pos,
+    const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w /*nullable*/, int64_t n_neg,
+    int neg_per_pos, float scale,
+    float* grad_ent, float* grad_rel, int grad_rel_copies,
+    int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+    int32_t* ref_count, float* ent_acc /*nullable for SGD*/, int optimizer, float lr,
+    const struct mke_count_job* next_count /*nullable*/, double* loss_partials, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (2) Per-row optimizer step on the rows touched in this step: Jacobian of normalise-on-read, then
  *     the optimizer update; consumes (re-zeroes) the gradient rows.

@@ -25,7 +25,7 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
     "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_triple_score_fwd_bwd_x",
-    "mke_count_entity_refs", "mke_triple_score_fwd_bwd_det", "mke_stage_reduce", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
+    "mke_count_entity_refs", "mke_triple_score_fwd_bwd_xc", "mke_triple_score_fwd_bwd_det", "mke_stage_reduce", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",

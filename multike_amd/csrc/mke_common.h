@@ -92,6 +92,24 @@ __device__ __forceinline__ float tanh_f(float x) {
 // g / sqrt(a) of the Adagrad rule on v_rsq_f32 (an IEEE sqrt + division is ~20 instructions per element)
 __device__ __forceinline__ float adagrad_scale(float a) { return __builtin_amdgcn_rsqf(a); }
 
+// Reference counting of a step's entity references (mke_count_entity_refs semantics) by `n_blocks` rider blocks of some
+// other kernel's grid; `block` = index among them.
+__device__ __forceinline__ void count_refs_range(const mke_count_job& c, int64_t block, int64_t n_blocks) {
+  const int64_t total = c.n_pos + c.n_neg;
+  for (int64_t i = block * MKE_BLOCK + threadIdx.x; i < total; i += n_blocks * MKE_BLOCK) {
+    if (i < c.n_pos) {
+      atomicAdd(&c.ref_count[c.pos_h[i]], 1);
+      atomicAdd(&c.ref_count[c.pos_t[i]], 1);
+    } else {
+      const int64_t n = i - c.n_pos;
+      const int64_t g = n / c.neg_per_pos;
+      const int a = c.neg_h[n], b = c.neg_t[n];
+      if (a != c.pos_h[g]) atomicAdd(&c.ref_count[a], 1);
+      if (b != c.pos_t[g]) atomicAdd(&c.ref_count[b], 1);
+    }
+  }
+}
+
 // Block-wide sum of one float per thread, accumulated in double; thread 0 gets the result.
 __device__ __forceinline__ double block_sum_double(float v) {
   __shared__ double s_part[MKE_BLOCK / 64];

@@ -5,6 +5,7 @@
 #include "mke_common.h"
 
 namespace mke {
+extern int g_count_in_score;   // mke_set_option("count_in_score"), default 1
 #define RUN_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("mke_relation_steps: %s: %s", #x, hipGetErrorString(e_)); rc = (int)e_; goto done; } } while (0)
 #define RUN_MKE(x) do { rc = (x); if (rc) goto done; } while (0)
 
@@ -155,17 +156,11 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
       if (rc) return rc;
     }
     counted_ahead = false;
-    rc = mke_triple_score_fwd_bwd_x(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
-                                    pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
-                                    N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
-                                    nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies,
-                                    pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,
-                                    pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, stream);
-    if (rc) return rc;
-    ut[1].ref_count = refc;
+    // the next step's negatives exist already (same sample chunk): its reference counts are taken by rider blocks of THIS
+    // step's score launch (into the other half of ent_ref_count)
     mke_count_job cj{};
     const mke_count_job* cjp = nullptr;
-    if (refc && s + 1 < step_end && s + 1 < chunk_end) {  // next step's negatives exist already: count them in this launch
+    if (refc && s + 1 < step_end && s + 1 < chunk_end) {
       const int64_t lo1 = pl->step_off[s + 1], hi1 = pl->step_off[s + 2], no1 = (lo1 - chunk_lo) * N;
       cj.pos_h = pl->pos_h + lo1; cj.pos_t = pl->pos_t + lo1; cj.n_pos = hi1 - lo1;
       cj.neg_h = pl->neg_h + no1; cj.neg_t = pl->neg_t + no1; cj.n_neg = (hi1 - lo1) * N; cj.neg_per_pos = N;
@@ -173,6 +168,17 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
       cjp = &cj;
       counted_ahead = true;
     }
+    const bool in_score = g_count_in_score != 0;
+    rc = mke_triple_score_fwd_bwd_xc(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
+                                     pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
+                                     N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
+                                     nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies,
+                                     pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,
+                                     in_score ? cjp : nullptr,
+                                     pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, stream);
+    if (rc) return rc;
+    ut[1].ref_count = refc;
+    if (in_score) cjp = nullptr;
     rc = mke_rows_update_multi_count(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, cjp, stream);
     if (rc) return rc;
   }

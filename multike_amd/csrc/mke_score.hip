@@ -58,6 +58,10 @@ struct ScoreParams {
   // atomically; mke_stage_reduce sums a row's slots in slot order afterwards
   float* __restrict__ stage_rows;   // [slots][stride]
   int64_t* __restrict__ stage_keys; // [slots]: (is_relation << 40) | row; untouched slots keep the caller's fill value
+  // rider: the first count_blocks blocks of the grid count the NEXT step's entity references (they finish under the scoring
+  // blocks; as riders of the update launch they were a 4 us tail of it)
+  mke_count_job cj;
+  int count_blocks;
 };
 
 #define MKE_STAGE_REL (1ll << 40)
@@ -144,14 +148,20 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // registers, 129 instead of 119 = three instead of four wavefronts per SIMD)
 template <int FPL, int U, bool X, int QPG, bool DET = false, bool O32 = false>  // X: exclusive-row fast path compiled in; O32: see row_at
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
+  if ((int)blockIdx.x < p.count_blocks) {
+    count_refs_range(p.cj, blockIdx.x, p.count_blocks);
+    if (threadIdx.x == 0) p.lossp[blockIdx.x] = 0.0;
+    return;
+  }
+  const int bid = blockIdx.x - p.count_blocks, nblk = gridDim.x - p.count_blocks;   // among the scoring blocks
   const int lane = threadIdx.x & 63;
   const int j = lane & 15;
   const int q4 = lane >> 4;
   constexpr int GPW = 4 / QPG;             // groups per wavefront
   const int sub = QPG == 4 ? 0 : (q4 >> 1);  // which group of the wavefront this lane works for
   const int q = QPG == 4 ? q4 : (q4 & 1);    // quarter-wave index inside the group
-  const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
+  const int64_t wave0 = ((int64_t)bid * MKE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)nblk * MKE_BLOCK) >> 6;
   const bool bwd = p.gent != nullptr;
   float loss = 0.f;  // identical on the 16 lanes of a quarter-wave; lane j==0 contributes
 
@@ -240,9 +250,6 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
               cnt[u] = p.refcount[e[u]];
               if (p.ent_acc) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
             }
-          } else {
-#pragma unroll
-            for (int k = 0; k < FPL; ++k) C[u][k] = 0.f;
           }
         }
         // phase 3: score, loss, gradient
@@ -375,8 +382,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
     }
   } else {
     // no grouping: every positive / negative is an independent triple, one quarter-wave each
-    const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
-    const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+    const int64_t sub0 = ((int64_t)bid * MKE_BLOCK + threadIdx.x) >> 4;
+    const int64_t nsub = ((int64_t)nblk * MKE_BLOCK) >> 4;
     for (int64_t i = sub0; i < p.n_pos + p.n_neg; i += nsub) {
       float* __restrict__ grel = bwd ? p.grel + (i % p.grel_copies) * p.grel_copy_elems : nullptr;
       if (i < p.n_pos) {
@@ -420,7 +427,7 @@ static int score_impl(
     const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
     int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream,
     int32_t* ref_count, float* ent_w, float* ent_acc, int optimizer, float lr, float* stage_rows = nullptr,
-    int64_t* stage_keys = nullptr, int64_t stage_slots = 0) {
+    int64_t* stage_keys = nullptr, int64_t stage_slots = 0, const mke_count_job* next_count = nullptr) {
   using namespace mke;
   if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
   if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
@@ -462,6 +469,15 @@ static int score_impl(
     if (!stage_rows || !grad_ent || need > stage_slots) { set_error("deterministic mode: %lld staging slots needed, %lld given", (long long)need, (long long)stage_slots); return MKE_E_SHAPE; }
   }
   p.stage_rows = stage_rows; p.stage_keys = stage_keys;
+  p.cj = mke_count_job{};
+  p.count_blocks = 0;
+  if (next_count && next_count->n_pos + next_count->n_neg > 0) {
+    if (!next_count->ref_count || !next_count->pos_h || !next_count->pos_t || (next_count->n_neg > 0 && (!next_count->neg_h || !next_count->neg_t))) { set_error("count job: NULL pointer"); return MKE_E_NULL; }
+    int64_t cb = (next_count->n_pos + next_count->n_neg + 4 * MKE_BLOCK - 1) / (4 * MKE_BLOCK);
+    p.cj = *next_count;
+    if (p.cj.neg_per_pos < 1) p.cj.neg_per_pos = 1;
+    p.count_blocks = (int)std::min<int64_t>(cb, MKE_LOSS_PARTIALS / 4);
+  }
   p.splits = splits;
   p.scale = scale;
   p.gent = grad_ent; p.grel = grad_rel; p.grel_copies = grad_rel_copies < 1 ? 1 : grad_rel_copies;
@@ -513,6 +529,23 @@ extern "C" int mke_triple_score_fwd_bwd(
   return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
                     n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
                     touched_ent, touched_rel, tag, loss_partials, stream, nullptr, nullptr, nullptr, 0, 0.f);
+}
+
+extern "C" int mke_triple_score_fwd_bwd_xc(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int grad_rel_copies, int32_t* touched_ent,
+    int32_t* touched_rel, int32_t tag, int32_t* ref_count, float* ent_acc, int optimizer, float lr,
+    const mke_count_job* next_count, double* loss_partials, void* stream) {
+  using namespace mke;
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (ref_count && optimizer == MKE_OPT_ADAGRAD && !ent_acc) { set_error("exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  if (ref_count && !grad_ent) { set_error("exclusive-row path needs the gradient scratch (it is a training step)"); return MKE_E_NULL; }
+  return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
+                    n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
+                    touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
+                    optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr, nullptr, nullptr, 0, next_count);
 }
 
 extern "C" int mke_triple_score_fwd_bwd_x(

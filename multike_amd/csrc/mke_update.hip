@@ -166,20 +166,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   // of the grid they were a tail of their own: 13.6 -> 16.7 us at the C2 shape)
   const int64_t riders = (int64_t)mp.count_blocks + mp.dense_blocks;
   if ((int64_t)blockIdx.x < mp.count_blocks) {  // count the next step's entity references
-    const mke_count_job& c = mp.cj;
-    const int64_t total = c.n_pos + c.n_neg;
-    for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)mp.count_blocks * MKE_BLOCK) {
-      if (i < c.n_pos) {
-        atomicAdd(&c.ref_count[c.pos_h[i]], 1);
-        atomicAdd(&c.ref_count[c.pos_t[i]], 1);
-      } else {
-        const int64_t n = i - c.n_pos;
-        const int64_t g = n / c.neg_per_pos;
-        const int a = c.neg_h[n], b = c.neg_t[n];
-        if (a != c.pos_h[g]) atomicAdd(&c.ref_count[a], 1);
-        if (b != c.pos_t[g]) atomicAdd(&c.ref_count[b], 1);
-      }
-    }
+    count_refs_range(mp.cj, blockIdx.x, mp.count_blocks);
     return;
   }
   if ((int64_t)blockIdx.x < riders) {  // dense parameter update

@@ -15,11 +15,10 @@ from oracle import multike_oracle as mo
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A fresh rendezvous file for init_method="file://..." (a TCP port picked by bind-and-close can be taken again before the
+    workers listen on it: one EADDRINUSE in ~200 runs on the GPU boxes)."""
+    import tempfile
+    return tempfile.mktemp(prefix="mke_rdv_")
 
 
 N_REL, DIM, B, NEG, STEPS, SEED = 12, 20, 64, 5, 4, 7
@@ -27,8 +26,7 @@ N_REL, DIM, B, NEG, STEPS, SEED = 12, 20, 64, 5, 4, 7
 
 def _worker(rank, world, port, ret, N_ENT):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed import ShardedRelationTrainer
         from multike_amd.synthetic import SyntheticKGs

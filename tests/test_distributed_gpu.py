@@ -20,8 +20,9 @@ def test_one_rank_sharded_equals_single_table_path(lookahead):
     from multike_amd.synthetic import SyntheticKGs
     from multike_amd.tables import EmbeddingTable, StepEngine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ.setdefault("MASTER_PORT", "29641")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import tempfile
+    dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     try:
         n_ent, n_rel, d, B, N = 6000, 40, 75, 700, 10
         kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, seed=2)
@@ -62,8 +63,7 @@ N_ENT2, N_REL2, DIM2, B2, NEG2, STEPS2, SEED2 = 3000, 20, 75, 300, 8, 7, 11
 def _two_rank_worker(rank, world, port, ret, lookahead=0):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
         from multike_amd.synthetic import SyntheticKGs
@@ -100,7 +100,8 @@ def test_two_ranks_on_one_gpu_equal_single_process_oracle(lookahead):
     from oracle import c_oracle as co
     from multike_amd.sampling import KGSide, RelationBatcher
     from multike_amd.synthetic import SyntheticKGs
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import tempfile
+    port = tempfile.mktemp(prefix="mke_rdv_")   # rendezvous file (init_method="file://..."): no TCP port to collide on
     world = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()

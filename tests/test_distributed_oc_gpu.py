@@ -119,8 +119,7 @@ def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
 def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
@@ -142,7 +141,8 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer):
     """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
     negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
     import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import tempfile
+    port = tempfile.mktemp(prefix="mke_rdv_")   # rendezvous file (init_method="file://..."): no TCP port to collide on
     world, steps = 2, 7
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -168,8 +168,9 @@ def test_one_rank_rccl_collectives_run():
     import torch.distributed as dist
     from multike_amd.distributed_oc import OcComm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ.setdefault("MASTER_PORT", "29655")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import tempfile
+    dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     try:
         cm = OcComm()
         a = torch.arange(8, dtype=torch.float32, device="cuda")

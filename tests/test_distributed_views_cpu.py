@@ -18,11 +18,10 @@ N_ENT, N_ATTR, N_LIT, DIM, B, STEPS, SEED = 61, 9, 40, 12, 50, 4, 3
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A fresh rendezvous file for init_method="file://..." (a TCP port picked by bind-and-close can be taken again before the
+    workers listen on it: one EADDRINUSE in ~200 runs on the GPU boxes)."""
+    import tempfile
+    return tempfile.mktemp(prefix="mke_rdv_")
 
 
 def _attr_data():
@@ -45,8 +44,7 @@ def _attr_data():
 
 def _attr_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import ShardedAttributeView
         from oracle_backend import OracleAttrBackend
@@ -102,8 +100,7 @@ def _cs_data():
 
 def _cs_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import ShardedCommonSpace
         from oracle_backend import OracleCommonSpaceBackend
@@ -153,8 +150,7 @@ def _sm_data():
 
 def _sm_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import ShardedSpaceMapping
         from oracle_backend import OracleSpaceMappingBackend

@@ -37,8 +37,7 @@ def _attr_data():
 def _attr_worker(rank, world, port, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import HostStagedViewComm, ShardedAttributeView
         torch.cuda.set_device(0)
@@ -58,7 +57,8 @@ def _attr_worker(rank, world, port, ret):
 
 def _run(worker, world=2):
     import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import tempfile
+    port = tempfile.mktemp(prefix="mke_rdv_")   # rendezvous file (init_method="file://..."): no TCP port to collide on
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=worker, args=(r, world, port, ret)) for r in range(world)]
@@ -104,8 +104,7 @@ def _cs_data():
 def _cs_worker(rank, world, port, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import HostStagedViewComm, ShardedCommonSpace
         torch.cuda.set_device(0)
@@ -145,8 +144,7 @@ def _sm_data():
 def _sm_worker(rank, world, port, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import HostStagedViewComm, ShardedSpaceMapping
         torch.cuda.set_device(0)

@@ -97,6 +97,30 @@ def test_runner_partial_ranges_and_second_epoch():
     assert not torch.equal(bat1.pos_h, _setup(seed=5)[3]()[2].pos_h)  # the shuffle really permuted the epoch
 
 
+def test_next_step_counting_in_the_score_or_in_the_update_launch():
+    """`count_in_score` (default 1): the next step's reference counts are taken by rider blocks of the score launch; 0: of the
+    update launch.  Same steps either way, and the same as counting in a launch of its own (sample_chunk = 1 never counts
+    ahead)."""
+    from multike_amd import _lib
+    from multike_amd.runner import RelationViewRunner
+    kgs, ent, rel, fresh = _setup(seed=9)
+    outs = []
+    for opt, chunk in ((1, None), (0, None), (1, 1)):
+        old = _lib.set_option("count_in_score", opt)
+        try:
+            E, R, bat = fresh()
+            r = RelationViewRunner(E, R, bat, lr=0.01, sample_chunk=chunk)
+            r.run()
+            outs.append((r.step_losses().cpu().numpy(), E.raw().cpu().numpy(), R.raw().cpu().numpy()))
+            assert int(r.refcount.abs().sum()) == 0
+        finally:
+            _lib.set_option("count_in_score", old)
+    for l, e, rr in outs[1:]:
+        np.testing.assert_allclose(l, outs[0][0], rtol=2e-6)
+        np.testing.assert_allclose(e, outs[0][1], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(rr, outs[0][2], rtol=1e-4, atol=1e-6)
+
+
 def test_run_epochs_prefetch_equals_plain_epochs():
     """run_epochs (next epoch permuted + sampled on a side stream) == the plain loop run(); shuffle(); run(); ..."""
     from multike_amd.runner import RelationViewRunner

@@ -4,8 +4,8 @@ import os, time
 import torch
 import torch.distributed as dist
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-dist.init_process_group("nccl", rank=0, world_size=1)
+import tempfile
+dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1)
 torch.cuda.set_device(0)
 for nbytes in (4, 176_000, 3_400_000, 23_500_000):
     n = max(1, nbytes // 4)
