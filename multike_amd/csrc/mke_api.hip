@@ -32,6 +32,7 @@ int g_score_splits = 0;
 int g_score_half_max = 12;   // groups of <= 12 negatives: two groups per wavefront (mke_score.hip)
 int g_score_o32 = 1;         // 32-bit row offsets in the training kernel when the tables allow (mke_score.hip, row_at)
 int g_count_in_score = 1;    // runner: the next step's reference counting rides in the score launch (0: in the update launch)
+int g_score_lane_ids = 1;    // training kernel: a group's ids and reference counts fetched once, one negative per lane (mke_score.hip)
 int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on large tables: 0 = by table size, 16, 64
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
 }
@@ -56,6 +57,11 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "count_in_score")) {
     if (old_value) *old_value = mke::g_count_in_score;
     mke::g_count_in_score = value != 0;
+    return MKE_OK;
+  }
+  if (!strcmp(name, "score_lane_ids")) {
+    if (old_value) *old_value = mke::g_score_lane_ids;
+    mke::g_score_lane_ids = value != 0;
     return MKE_OK;
   }
   if (!strcmp(name, "update_chunk")) {

@@ -18,6 +18,7 @@ namespace mke {
 #define MKE_SCORE_U 2
 #endif
 extern int g_score_splits;    // mke_set_option("score_splits")
+extern int g_score_lane_ids;  // mke_set_option("score_lane_ids")
 extern int g_score_o32;       // mke_set_option("score_offsets32"), default 1
 extern int g_score_half_max;  // mke_set_option("score_half_groups"): largest neg_per_pos scored two groups per wavefront (0 = off)
 
@@ -146,8 +147,10 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
 // idle in the last round and pays the positive's three row loads per 11 triples instead of per 22).
 // DET: deterministic staging compiled in (a separate instantiation: its slot arithmetic costs the training kernel ten
 // registers, 129 instead of 119 = three instead of four wavefronts per SIMD)
-template <int FPL, int U, bool X, int QPG, bool DET = false, bool O32 = false>  // X: exclusive-row fast path compiled in; O32: see row_at
+template <int FPL, int U, bool X, int QPG, bool DET = false, bool O32 = false, bool LID = false>  // X: exclusive-row fast path compiled in; O32: see row_at; LID: see LIDS
 __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p) {
+  constexpr bool LIDS = LID && X && !DET;   // ids and reference counts of a group fetched once, one negative per lane
+  constexpr int LPG = 64 / (4 / QPG);            // lanes per group: the whole wavefront, or one half of it per group
   if ((int)blockIdx.x < p.count_blocks) {
     count_refs_range(p.cj, blockIdx.x, p.count_blocks);
     if (threadIdx.x == 0) p.lossp[blockIdx.x] = 0.0;
@@ -220,7 +223,31 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       const int n_hi = active ? min(npp, n_lo + per) : n_lo;
       const int64_t nbase = g * (int64_t)npp;
       bool any_slow = false;
-      for (int n0 = n_lo + q; n0 < n_hi; n0 += QPG * U) {
+      // LIDS (the training instantiation): lane n of the wavefront fetches the ids AND the reference count of negative n of the
+      // group once (two round trips for up to 64 negatives); the rounds below take them out of the lanes.  A round is then
+      // one round trip instead of two (ids, then rows), and — the count being known before the gathers are issued — the
+      // accumulator row is only fetched for rows that are finished in place (65 % of them; the first round, whose counts
+      // arrive with its rows, fetches all): 10 % less traffic for a kernel that runs at the copy rate beyond its fixed cost.
+      const int n_end = min(npp, n_lo + per);
+      for (int b0 = n_lo; b0 < (LIDS ? n_end : n_lo + 1); b0 += LPG) {
+      int el = 0, fl = 0, rcl = 0, nblk = 0;
+      float wl = 1.0f;
+      const int lbase = lane & ~(LPG - 1);   // first lane of this lane's group
+      if constexpr (LIDS) {
+        nblk = min(LPG, n_end - b0);
+        const bool has = active && lane - lbase < nblk;
+        const int64_t idx = nbase + b0 + (has ? lane - lbase : 0);
+        const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+        wl = p.nw ? p.nw[idx] : 1.0f;
+        const bool dh = nh != ph, dt = nt != pt;
+        const bool fastl = has && (nr == pr) && (dh != dt);
+        el = dh ? nh : nt;
+        fl = (fastl ? 1 : 0) | (dh ? 2 : 0);
+        any_slow |= __any(has && !fastl) != 0;
+        rcl = fastl ? p.refcount[el] : 0;
+      }
+      const int it_lo = LIDS ? 0 : n_lo + q, it_hi = LIDS ? nblk : n_hi, it_step = QPG * U;
+      for (int n0 = it_lo; n0 < it_hi; n0 += it_step) {
         int e[U], cnt[U];
         bool fast[U], sideH[U];
         float w[U];
@@ -229,26 +256,38 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
         // phase 1: ids
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int n = n0 + QPG * u;
-          const bool live = n < n_hi;
-          const int64_t idx = nbase + (live ? n : n_lo);
-          const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
-          w[u] = p.nw ? p.nw[idx] : 1.0f;
-          const bool dh = nh != ph, dt = nt != pt;
-          fast[u] = live && (nr == pr) && (dh != dt);
-          sideH[u] = dh;
-          e[u] = dh ? nh : nt;
-          any_slow |= live && !fast[u];
+          if constexpr (LIDS) {
+            const int slot = n0 + q + QPG * u;
+            const bool live = slot < nblk;
+            const int src = lbase + (live ? slot : 0);
+            e[u] = __shfl(el, src, 64);
+            const int f = __shfl(fl, src, 64);
+            cnt[u] = __shfl(rcl, src, 64);
+            w[u] = __shfl(wl, src, 64);
+            fast[u] = live && (f & 1);
+            sideH[u] = (f & 2) != 0;
+          } else {
+            const int n = n0 + QPG * u;
+            const bool live = n < n_hi;
+            const int64_t idx = nbase + (live ? n : n_lo);
+            const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+            w[u] = p.nw ? p.nw[idx] : 1.0f;
+            const bool dh = nh != ph, dt = nt != pt;
+            fast[u] = live && (nr == pr) && (dh != dt);
+            sideH[u] = dh;
+            e[u] = dh ? nh : nt;
+            any_slow |= live && !fast[u];
+          }
         }
         // phase 2: all corrupt-row gathers of the chunk in flight together
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          cnt[u] = 0;
+          if constexpr (!LIDS) cnt[u] = 0;
           if (fast[u]) {
             load_at<FPL>(row_at<FPL, O32>(p.ent, e[u], p.stride, j), C[u]);
             if constexpr (X) {
-              cnt[u] = p.refcount[e[u]];
-              if (p.ent_acc) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
+              if constexpr (!LIDS) cnt[u] = p.refcount[e[u]];
+              if (p.ent_acc && (!LIDS || n0 == 0 || cnt[u] == 1)) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
             }
           }
         }
@@ -329,6 +368,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
           }
         }
       }
+      }   // id blocks
 
       if (any_slow) {
         // rare: negatives that are not "the positive with exactly one entity replaced" (both sides or the
@@ -507,7 +547,14 @@ static int score_impl(
         else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       }
     } else if (excl && o32) {   // the training step on tables below 4 GB: 32-bit row offsets (row_at)
-      if (half) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      // short groups leave the chip half empty (10 negatives, 5000 positives: 2,500 wavefronts): what counts there is the
+      // length of one wavefront's chain of dependent round trips, not registers — a group's whole share of negatives (5 per
+      // quarter-wave) in flight at once
+      constexpr int UH = FPL <= 5 ? 5 : U;
+      if (half && g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else if (half && n_pos <= 6144) hipLaunchKernelGGL((k_triple_score<FPL, UH, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else if (half) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else if (g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
     } else if (half) {
       if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
