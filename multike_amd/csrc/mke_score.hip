@@ -181,6 +181,29 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       const int s = (int)(wk / p.n_pos);
       float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
       const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
+      // LIDS: the group's first block of negative ids is requested with the positive's ids, its reference counts with the
+      // positive's rows (see below): two round trips fewer at the head of a wavefront's chain
+      const int npp_ = p.npp;
+      const int per_ = (npp_ + p.splits - 1) / p.splits;
+      const int nlo_ = s * per_, nend_ = min(npp_, nlo_ + per_);
+      const int lbase = lane & ~(LPG - 1);   // first lane of this lane's group
+      int el = 0, fl = 0, rcl = 0, nblk = 0;
+      float wl = 1.0f;
+      bool slow_l = false;
+      auto fetch_block = [&](int b0) {
+        nblk = min(LPG, nend_ - b0);
+        const bool has = active && lane - lbase < nblk;
+        const int64_t idx = g * (int64_t)npp_ + b0 + (has ? lane - lbase : 0);
+        const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
+        wl = p.nw ? p.nw[idx] : 1.0f;
+        const bool dh = nh != ph, dt = nt != pt;
+        const bool fastl = has && (nr == pr) && (dh != dt);
+        el = dh ? nh : nt;
+        fl = (fastl ? 1 : 0) | (dh ? 2 : 0);
+        slow_l = has && !fastl;
+        rcl = fastl ? p.refcount[el] : 0;
+      };
+      if constexpr (LIDS) fetch_block(nlo_);
       float H[FPL], R[FPL], T[FPL];
       load_at<FPL>(row_at<FPL, O32>(p.ent, ph, p.stride, j), H);
       load_at<FPL>(row_at<FPL, O32>(p.rel, pr, p.stride, j), R);
@@ -226,25 +249,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       // LIDS (the training instantiation): lane n of the wavefront fetches the ids AND the reference count of negative n of the
       // group once (two round trips for up to 64 negatives); the rounds below take them out of the lanes.  A round is then
       // one round trip instead of two (ids, then rows), and — the count being known before the gathers are issued — the
-      // accumulator row is only fetched for rows that are finished in place (65 % of them; the first round, whose counts
-      // arrive with its rows, fetches all): 10 % less traffic for a kernel that runs at the copy rate beyond its fixed cost.
+      // accumulator row is only fetched for rows that are finished in place (65 % of them): 10 % less traffic for a kernel
+      // that runs at the copy rate beyond its fixed cost.
       const int n_end = min(npp, n_lo + per);
       for (int b0 = n_lo; b0 < (LIDS ? n_end : n_lo + 1); b0 += LPG) {
-      int el = 0, fl = 0, rcl = 0, nblk = 0;
-      float wl = 1.0f;
-      const int lbase = lane & ~(LPG - 1);   // first lane of this lane's group
       if constexpr (LIDS) {
-        nblk = min(LPG, n_end - b0);
-        const bool has = active && lane - lbase < nblk;
-        const int64_t idx = nbase + b0 + (has ? lane - lbase : 0);
-        const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
-        wl = p.nw ? p.nw[idx] : 1.0f;
-        const bool dh = nh != ph, dt = nt != pt;
-        const bool fastl = has && (nr == pr) && (dh != dt);
-        el = dh ? nh : nt;
-        fl = (fastl ? 1 : 0) | (dh ? 2 : 0);
-        any_slow |= __any(has && !fastl) != 0;
-        rcl = fastl ? p.refcount[el] : 0;
+        if (b0 != n_lo) fetch_block(b0);
+        any_slow |= __any(slow_l) != 0;
       }
       const int it_lo = LIDS ? 0 : n_lo + q, it_hi = LIDS ? nblk : n_hi, it_step = QPG * U;
       for (int n0 = it_lo; n0 < it_hi; n0 += it_step) {
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
             load_at<FPL>(row_at<FPL, O32>(p.ent, e[u], p.stride, j), C[u]);
             if constexpr (X) {
               if constexpr (!LIDS) cnt[u] = p.refcount[e[u]];
-              if (p.ent_acc && (!LIDS || n0 == 0 || cnt[u] == 1)) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
+              if (p.ent_acc && (!LIDS || cnt[u] == 1)) load_at<FPL>(row_at<FPL, O32>(p.ent_acc, e[u], p.stride, j), A[u]);
             }
           }
         }
@@ -547,12 +558,7 @@ static int score_impl(
         else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       }
     } else if (excl && o32) {   // the training step on tables below 4 GB: 32-bit row offsets (row_at)
-      // short groups leave the chip half empty (10 negatives, 5000 positives: 2,500 wavefronts): what counts there is the
-      // length of one wavefront's chain of dependent round trips, not registers — a group's whole share of negatives (5 per
-      // quarter-wave) in flight at once
-      constexpr int UH = FPL <= 5 ? 5 : U;
       if (half && g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
-      else if (half && n_pos <= 6144) hipLaunchKernelGGL((k_triple_score<FPL, UH, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else if (half) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else if (g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
