@@ -110,14 +110,17 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     // the vectors' home: this rank's all-gathered copy, or (peer-direct) the owner's own send block over xGMI
     const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * STRIDE;
     const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * STRIDE;
+    // codes first (one negative per lane), then the owned rows' reference counts together with the positive's two vectors: a
+    // round below is one round trip, and the accumulator row is gathered only for rows that are finished in place
+    int code = 0;
+    if (lane < N) code = oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane];
+    const bool mine = lane < N && ((code >> 1) % G) == s.rank;
+    const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
     load_row<FPL>(vh, 0, STRIDE, j, HR);
     load_row<FPL>(vt, 0, STRIDE, j, RT);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
-    int code = 0;
-    if (lane < N) code = oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane];
-    const bool mine = lane < N && ((code >> 1) % G) == s.rank;
     const uint64_t mask = __ballot(mine);
     const int total = __popcll(mask);
 
@@ -159,17 +162,16 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         live[u] = rest != 0;
         const int src = live[u] ? __builtin_ctzll(rest) : 0;
         const int cd = __shfl(code, src, 64);
+        cnt[u] = __shfl(rcl, src, 64);
         sideH[u] = cd & 1;
         e[u] = (cd >> 1) / G;
         rest &= rest - 1; rest &= rest - 1; rest &= rest - 1; rest &= rest - 1;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        cnt[u] = 0;
         if (live[u]) {
           load_row<FPL>(s.ent, e[u], STRIDE, j, Cr[u]);
-          cnt[u] = s.ref_count ? s.ref_count[e[u]] : 0;
-          if (s.ref_count && s.ent_acc) load_row<FPL>(s.ent_acc, e[u], STRIDE, j, A[u]);
+          if (s.ref_count && s.ent_acc && cnt[u] == 1) load_row<FPL>(s.ent_acc, e[u], STRIDE, j, A[u]);
         } else {
 #pragma unroll
           for (int k = 0; k < FPL; ++k) Cr[u][k] = 0.f;
