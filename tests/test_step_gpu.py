@@ -447,3 +447,51 @@ def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
         eng2.relation_step(E2, R2, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg), neg_per_pos=N,
                            lr=0.01, exclusive_rows=False)
     np.testing.assert_allclose(E.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("d,P,N", [(75, 100, 70), (75, 3000, 64), (32, 40, 100), (75, 9, 25), (256, 60, 64), (75, 700, 12)])
+def test_lane_ids_path_blocks_and_slices(d, P, N):
+    """The training instantiation that fetches a group's ids and reference counts once, one negative per lane (`score_lane_ids`):
+    more than 64 negatives per positive (two id blocks), small batches (a group sliced over several wavefronts), two groups
+    per wavefront (N <= 12), weights, an irregular negative — two steps against the float64 dense oracle, and against the
+    per-round id fetch (`score_lane_ids = 0`)."""
+    from gpu_util import dev_i32, make_tables
+    from multike_amd import _lib
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(d + P * 7 + N)
+    n_ent, n_rel = 4000, 11
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    ph, pt, prl = rng.integers(0, n_ent, P), rng.integers(0, n_ent, P), rng.integers(0, n_rel, P)
+    nh, nt, nr = np.repeat(ph, N), np.repeat(pt, N), np.repeat(prl, N)
+    side = rng.integers(0, 2, P * N).astype(bool)
+    c = rng.integers(0, n_ent, P * N)
+    nh, nt = np.where(side, c, nh), np.where(side, nt, c)
+    nh[N + 1], nt[N + 1] = rng.integers(0, n_ent, 2)                # an irregular negative in the second group
+    nh[2 * N - 1] = ph[1]; nt[2 * N - 1] = pt[1]                    # a negative equal to its positive
+    pos = tuple(a.astype(np.int32) for a in (ph, prl, pt))
+    neg = tuple(a.astype(np.int32) for a in (nh, nr, nt))
+    pw, nw = rng.uniform(0.5, 1.5, P).astype(np.float32), rng.uniform(0.5, 1.5, P * N).astype(np.float32)
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    losses64 = [mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01, pos_w=pw.astype(np.float64),
+                                            neg_w=nw.astype(np.float64))[0] for _ in range(2)]
+    outs = []
+    for lane_ids in (1, 0):
+        old = _lib.set_option("score_lane_ids", lane_ids)
+        try:
+            E, R = make_tables(ent, rel)
+            eng = StepEngine()
+            ls = [float(eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg),
+                                          neg_per_pos=N, lr=0.01, pos_w=torch.as_tensor(pw, device="cuda"),
+                                          neg_w=torch.as_tensor(nw, device="cuda")).sum()) for _ in range(2)]
+            assert float(E.grad.abs().max()) == 0.0 and int(E.refcount.abs().sum()) == 0
+            outs.append((ls, E.raw().cpu().numpy(), R.raw().cpu().numpy(), E.slot("relation")[:, :d].cpu().numpy()))
+        finally:
+            _lib.set_option("score_lane_ids", old)
+    for ls, e, r, acc in outs:
+        np.testing.assert_allclose(ls, losses64, rtol=LOSS_RTOL)
+        np.testing.assert_allclose(e, e64, rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(r, r64, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(acc, a64, rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-6)
