@@ -63,6 +63,12 @@ const char* mke_last_error(void);
  *                     kernels themselves are selected by which entry point is called)
  *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per
  *                     half; default 12, 0 = never) — the reference's default of 10 negatives fills a whole wavefront badly
+ *   "score_offsets32"   : 1 (default) = the training kernel addresses rows with 32-bit byte offsets when the tables are
+ *                     below 4 GB; 0 = 64-bit addresses always
+ *   "score_lane_ids"    : 1 (default) = the training kernel fetches a group's negative ids and reference counts once, one
+ *                     negative per lane, and gathers accumulator rows only for rows it finishes in place; 0 = per round
+ *   "count_in_score"    : 1 (default) = mke_relation_steps lets the NEXT step's reference counting ride in the score
+ *                     launch (mke_triple_score_fwd_bwd_xc); 0 = in the update launch (mke_rows_update_multi_count)
  * Returns the previous value through *old_value when it is not NULL. */
 int mke_set_option(const char* name, int value, int* old_value);
 
