@@ -112,6 +112,87 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
   for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
 }
 
+// Wide rows on sparse tables (stride a multiple of 64 floats, one flag per lane): a WHOLE wavefront per row, lane l holding
+// columns [l V, (l + 1) V).  With the quarter-wave shape a wavefront that finds one touched row among its 64 flags (the C5
+// shape: 1.1 on average) issues 96 quarter-populated dword loads / stores for it — the row update was bound by vector-memory
+// instruction issue (3.3 M wave-instructions per launch), not by the 204 MB it moves; here a row is 3 loads + 3 stores of
+// 16 bytes per lane.  Same arithmetic per element; the two row sums are reduced over 64 lanes instead of 16.
+template <int V>
+__device__ __forceinline__ void update_one_row_wave(const UpdateParams& p, int64_t row, int lane) {
+  const int64_t off = row * (int64_t)(V * 64) + lane * V;
+  float* gp = p.grad + off;
+  float* wp = p.table + off;
+  const bool adagrad = p.optimizer == MKE_OPT_ADAGRAD;
+  float* ap = adagrad ? p.acc + off : nullptr;
+  float g[V], w[V], a[V];
+  auto ld = [&](const float* q, float (&v)[V]) {
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(q); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = q[k];
+    }
+  };
+  auto st = [&](float* q, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) q[k] = v[k];
+    }
+  };
+  ld(gp, g);
+  ld(wp, w);
+  if (adagrad) ld(ap, a);
+  if (p.copies > 1) {  // privatised gradient: sum (and consume) the other copies
+    const int64_t ce = p.n_rows * (int64_t)(V * 64);
+    for (int c = 1; c < p.copies; ++c) {
+      float t[V];
+      ld(gp + c * ce, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { g[k] += t[k]; t[k] = 0.f; }
+      st(gp + c * ce, t);
+    }
+  }
+  {
+    float z[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) z[k] = 0.f;
+    st(gp, z);  // consume: restore the all-zero invariant
+  }
+  if (p.refcount && lane == 0) p.refcount[row] = 0;
+  auto wave_sum = [](float v) {
+    v = sub16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  };
+  if (p.normalize) {
+    float s = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      s = fmaf(w[k], w[k], s);
+      dot = fmaf(w[k], g[k], dot);
+    }
+    s = wave_sum(s);
+    dot = wave_sum(dot);
+    const float inv = rsqrtf(fmaxf(s, MKE_L2_EPS));
+    const float coef = (s > MKE_L2_EPS) ? dot * inv * inv : 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = (g[k] - w[k] * coef) * inv;
+  }
+  if (adagrad) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      a[k] = fmaf(g[k], g[k], a[k]);
+      w[k] -= p.lr * g[k] * adagrad_scale(a[k]);
+    }
+    st(ap, a);
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) w[k] -= p.lr * g[k];
+  }
+  st(wp, w);
+}
+
 // One wavefront, one 16-row chunk: ballot the flags, deal the set bits round-robin to the four quarter-waves.  Every
 // quarter looks up ITS row of the round (the (4*round + q)-th set bit) so that the four row visits of a round execute
 // together in one instruction stream — a branch per set bit would serialise them.
@@ -132,6 +213,15 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
     mine = p.touched == nullptr || p.touched[r] == p.tag;
   }
   uint64_t m = __ballot(mine);
+  if constexpr (!SHARD && FPL % 4 == 0) {
+    if (p.chunk == 64) {   // one flag per lane, wide rows: the whole wavefront visits the set rows one after the other
+      while (m) {
+        update_one_row_wave<FPL / 4>(p, base + __builtin_ctzll(m), lane);
+        m &= m - 1;
+      }
+      return;
+    }
+  }
   if (p.chunk < 64) m &= (1ull << p.chunk) - 1ull;
   // quarter q takes the q-th, (q+4)-th, ... set bit: a running copy of the mask with the bits already dealt removed
   for (int k = 0; k < q; ++k) m &= m - 1;

@@ -495,3 +495,36 @@ def test_lane_ids_path_blocks_and_slices(d, P, N):
         np.testing.assert_allclose(r, r64, rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(acc, a64, rtol=2e-3, atol=1e-6)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [256, 128, 64, 180, 75])
+def test_row_update_one_flag_per_lane(d):
+    """`update_chunk = 64` (what tables of more than 500K rows get): one touched flag per lane; on strides that are a multiple of 64
+    floats (d = 256, 128, 64, 180 -> 192) the whole wavefront then visits a row, 16 bytes per lane; d = 75 (stride 80) keeps the
+    quarter-wave shape.  Two training steps against the float64 dense oracle, exclusive rows on and off."""
+    from gpu_util import dev_i32, grouped_batch, make_tables
+    from multike_amd import _lib
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(d)
+    n_ent, n_rel, P, N = 20000, 23, 400, 10
+    ent = mo.xavier_truncated_normal((n_ent, d), rng)
+    rel = mo.xavier_truncated_normal((n_rel, d), rng)
+    pos, neg = grouped_batch(rng, n_ent, n_rel, P, N)
+    old = _lib.set_option("update_chunk", 64)
+    try:
+        for excl in (True, False):
+            e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+            a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+            E, R = make_tables(ent, rel)
+            eng = StepEngine()
+            for step in range(2):
+                L = mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01)[0]
+                lp = eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg),
+                                       neg_per_pos=N, lr=0.01, exclusive_rows=excl)
+                np.testing.assert_allclose(float(lp.sum()), L, rtol=LOSS_RTOL)
+            np.testing.assert_allclose(E.raw().cpu().numpy(), e64, rtol=ROW_RTOL, atol=ROW_ATOL)
+            np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=ROW_RTOL, atol=ROW_ATOL)
+            np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=1e-4, atol=1e-7)
+            assert float(E.grad.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+    finally:
+        _lib.set_option("update_chunk", old)
