@@ -58,14 +58,27 @@ struct ConvParams {
 };
 
 // K1[kh][kw][0][f] at k1[(kh*4+kw)*2+f]; K2[kh][kw][c][f] at k2[((kh*4+kw)*2+c)*2+f]  (TF HWIO order)
-template <int WPL, bool BWD>
+// LPT lanes per triple (64: a wavefront per triple; 32: one per HALF — dim 75 fills 75 of 128 lane slots in two passes of 64
+// lanes but 75 of 96 in three passes of 32, and a wavefront then carries two triples: a quarter fewer instructions per
+// triple), WPL width positions per lane: position w = tl + LPT * i of lane tl of the group.
+template <int WPL, int LPT, bool BWD>
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
-  constexpr int DP = 64 * WPL + 4;
-  __shared__ float s_x[MKE_BLOCK / 64][2][DP];
-  __shared__ float s_c1[MKE_BLOCK / 64][2][2][DP];
-  __shared__ float s_d2[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
-  __shared__ float s_d1[BWD ? MKE_BLOCK / 64 : 1][2][2][BWD ? DP : 1];
+  constexpr int TPW = 64 / LPT;                    // triples per wavefront
+  constexpr int NSLOT = (MKE_BLOCK / 64) * TPW;    // triples in flight per block, each with its own LDS strips
+  constexpr int DP = LPT * WPL + 4;
+  __shared__ float s_x[NSLOT][2][DP];
+  __shared__ float s_c1[NSLOT][2][2][DP];
+  __shared__ float s_d2[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
+  __shared__ float s_d1[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tl = lane & (LPT - 1);               // lane inside the triple's group
+  const int slot = wv * TPW + lane / LPT;         // which of the block's triples
+  auto group_sum = [](float v) {                  // over the LPT lanes of a triple
+    v = sub16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    if (LPT == 64) v += __shfl_xor(v, 32, 64);
+    return v;
+  };
   const int d = p.dim;
   const float bn_s = rsqrtf(1.0f + CNN_BN_EPS);
   const float* __restrict__ gamma = p.params;
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   float gam[WPL], bet[WPL];
 #pragma unroll
   for (int i = 0; i < WPL; ++i) {
-    const int w = lane + 64 * i;
+    const int w = tl + LPT * i;
     gam[i] = w < d ? gamma[w] : 0.f;
     bet[i] = w < d ? beta[w] : 0.f;
   }
@@ -105,11 +118,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < WPL; ++i) a_gam[i] = a_bet[i] = 0.f;
   }
-  float(*xs)[DP] = s_x[wv];
-  float(*c1s)[2][DP] = s_c1[wv];
+  float(*xs)[DP] = s_x[slot];
+  float(*c1s)[2][DP] = s_c1[slot];
 
-  const int64_t wave0 = (int64_t)blockIdx.x * (MKE_BLOCK / 64) + wv;
-  const int64_t nwaves = (int64_t)gridDim.x * (MKE_BLOCK / 64);
+  const int64_t wave0 = (int64_t)blockIdx.x * NSLOT + slot;
+  const int64_t nwaves = (int64_t)gridDim.x * NSLOT;
   const int64_t iters = (p.n + nwaves - 1) / nwaves;  // block-uniform trip count (barriers inside)
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t t = wave0 + it * nwaves;
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     float raw[2][WPL];
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      const int w = lane + 64 * i;
+      const int w = tl + LPT * i;
       raw[0][i] = (live && w < d) ? p.attr[(int64_t)ra * p.attr_stride + w] : 0.f;
       raw[1][i] = (live && w < d) ? p.lit[(int64_t)rv * p.lit_stride + w] : 0.f;
     }
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < WPL; ++i) s = fmaf(raw[0][i], raw[0][i], s);
-      s = wave_sum(s);
+      s = group_sum(s);
       const float inv = rsqrtf(fmaxf(s, MKE_L2_EPS));
 #pragma unroll
       for (int i = 0; i < WPL; ++i) raw[0][i] *= inv;
@@ -136,17 +149,17 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        const int w = lane + 64 * i;
+        const int w = tl + LPT * i;
         xs[h][w + 1] = w < d ? fmaf(gam[i] * bn_s, raw[h][i], bet[i]) : 0.f;
       }
-      if (lane < 4) xs[h][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
+      if (tl < 4) xs[h][tl == 0 ? 0 : LPT * WPL + tl] = 0.f;
     }
     wave_lds_sync();
     // ---- conv1 ---------------------------------------------------------------------------------------------
     float c1[2][2][WPL];
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      const int w = lane + 64 * i;
+      const int w = tl + LPT * i;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -160,11 +173,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
           c1s[h][f][w + 1] = c1[h][f][i];
         }
     }
-    if (lane < 4) {
+    if (tl < 4) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) c1s[h][f][lane == 0 ? 0 : 64 * WPL + lane] = 0.f;
+        for (int f = 0; f < 2; ++f) c1s[h][f][tl == 0 ? 0 : LPT * WPL + tl] = 0.f;
     }
     wave_lds_sync();
     // ---- conv2 + width normalisation -----------------------------------------------------------------------
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       for (int f = 0; f < 2; ++f) ssq[h][f] = 0.f;
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      const int w = lane + 64 * i;
+      const int w = tl + LPT * i;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -195,16 +208,16 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        ssq[h][f] = wave_sum(ssq[h][f]);
+        ssq[h][f] = group_sum(ssq[h][f]);
         nrm[h][f] = rsqrtf(fmaxf(ssq[h][f], MKE_L2_EPS));
       }
     if constexpr (!BWD) {
       if (live) {
         float* o = p.flat + t * (int64_t)p.flat_stride;
-        if (lane == 0 && p.flat_stride > 4 * d) o[4 * d] = 1.0f;  // bias column: [flat, 1] @ [W; bias]
+        if (tl == 0 && p.flat_stride > 4 * d) o[4 * d] = 1.0f;  // bias column: [flat, 1] @ [W; bias]
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
-          const int w = lane + 64 * i;
+          const int w = tl + LPT * i;
           if (w < d) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       continue;
     }
     if constexpr (BWD) {
-      float(*d2s)[2][DP] = s_d2[wv];
-      float(*d1s)[2][DP] = s_d1[wv];
+      float(*d2s)[2][DP] = s_d2[slot];
+      float(*d1s)[2][DP] = s_d1[slot];
       // ---- width-normalisation backward, tanh', parameter gradients of conv2 -------------------------------
       float dy[2][2][WPL], dot[2][2];
       const float* gi = p.dflat + t * (int64_t)(4 * d);
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         for (int f = 0; f < 2; ++f) dot[h][f] = 0.f;
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        const int w = lane + 64 * i;
+        const int w = tl + LPT * i;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float2 v = make_float2(0.f, 0.f);
@@ -242,11 +255,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) dot[h][f] = wave_sum(dot[h][f]);
+        for (int f = 0; f < 2; ++f) dot[h][f] = group_sum(dot[h][f]);
       float dp2[2][2][WPL];
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        const int w = lane + 64 * i;
+        const int w = tl + LPT * i;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -275,22 +288,22 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
               for (int h = 0; h + kh < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < WPL; ++i) a = fmaf(dp2[h][f][i], c1s[h + kh][c][lane + 64 * i + kw], a);
+                for (int i = 0; i < WPL; ++i) a = fmaf(dp2[h][f][i], c1s[h + kh][c][tl + LPT * i + kw], a);
               park(18 + ((kh * 4 + kw) * 2 + c) * 2 + f, a);
             }
       }
-      if (lane < 4) {
+      if (tl < 4) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) d2s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
+          for (int f = 0; f < 2; ++f) d2s[h][f][tl < 2 ? tl : LPT * WPL + tl] = 0.f;
       }
       wave_lds_sync();
       // ---- conv2 transposed -> dc1, tanh', parameter gradients of conv1 -----------------------------------
       float dp1[2][2][WPL];
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        const int w = lane + 64 * i;
+        const int w = tl + LPT * i;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -321,21 +334,21 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
             for (int hh = 0; hh + kh < 2; ++hh)
 #pragma unroll
-              for (int i = 0; i < WPL; ++i) a = fmaf(dp1[hh][c][i], xs[hh + kh][lane + 64 * i + kw], a);
+              for (int i = 0; i < WPL; ++i) a = fmaf(dp1[hh][c][i], xs[hh + kh][tl + LPT * i + kw], a);
             park((kh * 4 + kw) * 2 + c, a);
           }
       }
-      if (lane < 4) {
+      if (tl < 4) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) d1s[h][f][lane < 2 ? lane : 64 * WPL + lane] = 0.f;
+          for (int f = 0; f < 2; ++f) d1s[h][f][tl < 2 ? tl : LPT * WPL + tl] = 0.f;
       }
       wave_lds_sync();
       // ---- conv1 transposed -> dx, batch-norm affine backward, attribute-row gradient ---------------------
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
-        const int w = lane + 64 * i;
+        const int w = tl + LPT * i;
         float dx[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         a_bet[i] += dx[0] + dx[1];
         if (live && w < d && p.gattr) atomic_add_f32(p.gattr + (int64_t)ra * p.attr_stride + w, dx[0] * gam[i] * bn_s);
       }
-      if (live && lane == 0 && p.gattr) p.tattr[ra] = p.tag;
+      if (live && tl == 0 && p.gattr) p.tattr[ra] = p.tag;
       wave_lds_sync();
     }
   }
@@ -368,8 +381,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < WPL; ++i) {
-      gsum[wv * 64 * WPL + lane + 64 * i] = a_gam[i];
-      bsum[wv * 64 * WPL + lane + 64 * i] = a_bet[i];
+      gsum[slot * LPT * WPL + tl + LPT * i] = a_gam[i];
+      bsum[slot * LPT * WPL + tl + LPT * i] = a_bet[i];
     }
     __syncthreads();
     // Every block adding its 2d + 52 sums straight into grad_params is a chain of gridDim.x same-address atomics per
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     for (int w = threadIdx.x; w < d; w += MKE_BLOCK) {
       float g = 0.f, b = 0.f;
 #pragma unroll
-      for (int k = 0; k < MKE_BLOCK / 64; ++k) { g += gsum[k * 64 * WPL + w]; b += bsum[k * 64 * WPL + w]; }
+      for (int k = 0; k < NSLOT; ++k) { g += gsum[k * LPT * WPL + w]; b += bsum[k * LPT * WPL + w]; }
       atomic_add_f32(dst + w, g);
       atomic_add_f32(dst + d + w, b);
     }
@@ -546,20 +559,28 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
                              float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
-  const int wpl = (p.dim + 63) / 64;
-  int64_t blocks = (p.n + 3) / 4;
-  if (blocks > 4096) blocks = 4096;  // one triple per wave up to 16K triples: no half-idle second pass
+  // dim <= 96: two triples per wavefront, 32 lanes each (dim 75: three passes of 32 lanes instead of two of 64)
+  // (the backward only: it is bound by instruction issue; the forward is a latency chain and prefers twice the wavefronts)
+  const bool half = bwd && p.dim <= 96;
+  const int wpl = half ? (p.dim + 31) / 32 : (p.dim + 63) / 64;
+  const int per_block = (MKE_BLOCK / 64) * (half ? 2 : 1);
+  int64_t blocks = (p.n + per_block - 1) / per_block;
+  if (blocks > 4096) blocks = 4096;  // one triple per group up to 16K (32K) triples: no half-idle second pass
   if (blocks < 1) blocks = 1;
-#define MKE_CONV_CASE(W)                                                                                        \
-  case W:                                                                                                       \
-    if (bwd) hipLaunchKernelGGL((k_attr_conv<W, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);      \
-    else hipLaunchKernelGGL((k_attr_conv<W, false>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);        \
+#define MKE_CONV_CASE(W, L)                                                                                        \
+    if (bwd) hipLaunchKernelGGL((k_attr_conv<W, L, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);      \
+    else hipLaunchKernelGGL((k_attr_conv<W, L, false>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);        \
     break;
-  switch (wpl) {
-    MKE_CONV_CASE(1) MKE_CONV_CASE(2) MKE_CONV_CASE(3) MKE_CONV_CASE(4) MKE_CONV_CASE(5)
-    default:
-      set_error("attribute CNN: dim %d not supported (<= 320)", p.dim);
-      return MKE_E_UNSUPPORTED;
+  if (half) {
+    switch (wpl) {
+      case 1: MKE_CONV_CASE(1, 32) case 2: MKE_CONV_CASE(2, 32) case 3: MKE_CONV_CASE(3, 32)
+      default: set_error("attribute CNN: dim %d not supported", p.dim); return MKE_E_UNSUPPORTED;
+    }
+  } else {
+    switch (wpl) {
+      case 2: MKE_CONV_CASE(2, 64) case 3: MKE_CONV_CASE(3, 64) case 4: MKE_CONV_CASE(4, 64) case 5: MKE_CONV_CASE(5, 64)
+      default: set_error("attribute CNN: dim %d not supported (<= 320)", p.dim); return MKE_E_UNSUPPORTED;
+    }
   }
 #undef MKE_CONV_CASE
   return check_launch("k_attr_conv");
