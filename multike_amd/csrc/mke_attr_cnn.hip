@@ -578,7 +578,7 @@ static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
     }
   } else {
     switch (wpl) {
-      case 2: MKE_CONV_CASE(2, 64) case 3: MKE_CONV_CASE(3, 64) case 4: MKE_CONV_CASE(4, 64) case 5: MKE_CONV_CASE(5, 64)
+      case 1: MKE_CONV_CASE(1, 64) case 2: MKE_CONV_CASE(2, 64) case 3: MKE_CONV_CASE(3, 64) case 4: MKE_CONV_CASE(4, 64) case 5: MKE_CONV_CASE(5, 64)
       default: set_error("attribute CNN: dim %d not supported (<= 320)", p.dim); return MKE_E_UNSUPPORTED;
     }
   }
