@@ -423,12 +423,15 @@ class MultiKE:
         return self._done(_EpochLoss('att. view', epoch, value, total, start))
 
     # --- training for cross-kg identity inference ----------------------------------------------------------
-    def _next_sample_stream(self):
-        """(seed, stream id) of the next `mke_sample_distinct` launch: one stream id per call, in call order."""
-        self._sample_calls = getattr(self, "_sample_calls", 0) + 1
-        return (int(getattr(self.args, "seed", 0)) & 0xFFFFFFFF, 0x4D4B45), self._sample_calls
+    def _next_sample_stream(self, lane=0):
+        """(seed, stream id) of the next `mke_sample_distinct` launch: one stream id per call.  Three independent
+        sequences (lane 0: relation group, 1: attribute group, 2: everything else), so that the draws of a phase do not
+        depend on the order in which the drivers enqueue the two groups of an epoch."""
+        calls = self.__dict__.setdefault("_sample_calls", [0, 0, 0])
+        calls[lane] += 1
+        return (int(getattr(self.args, "seed", 0)) & 0xFFFFFFFF, 0x4D4B45), calls[lane] * 4 + lane
 
-    def _positives_epoch(self, epoch, sup_triples, batch_size, run_fn, label):
+    def _positives_epoch(self, epoch, sup_triples, batch_size, run_fn, label, lane):
         """Shared loop shape of code/MultiKE_model.py:349-437: steps = ceil(len / B); each step is
         random.sample(sup_triples, B) (B = len if one step).  All steps of the epoch are sampled by one launch and run
         inside one native call; `run_fn(cols, w, step_off)` returns the loss partials [steps, LOSS_PARTIALS]."""
@@ -438,7 +441,7 @@ class MultiKE:
         lst = self._list(sup_triples)
         steps = int(math.ceil(lst.n / batch_size))
         bs = batch_size if steps > 1 else lst.n
-        seed, stream = self._next_sample_stream()
+        seed, stream = self._next_sample_stream(lane)
         cols, w, idx = lst.sample_epoch(bs, steps, seed, stream)
         self._last_sample = (seed, stream, lst.n, bs, steps)   # tests replay it with oracle.sampler_oracle.distinct_sample
         ring = run_fn(cols, w, np.arange(steps + 1, dtype=np.int64) * bs)
@@ -477,27 +480,27 @@ class MultiKE:
         """code/MultiKE_model.py:349-369."""
         return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
                                      lambda cols, w, off: self._relation_positive_steps(self._ckge_rel, cols, None, off),
-                                     'cross-kg entity inference in rel. view')
+                                     'cross-kg entity inference in rel. view', 0)
 
     def train_cross_kg_entity_inference_attribute_view_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:371-391: 2 * sum log(1+exp(-conv))."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
             lambda cols, w, off: self._run_attr_steps(self._ckge_attr_cnn, cols, None, off, 2.0, "ckge_attr"),
-            'cross-kg entity inference in attr. view')
+            'cross-kg entity inference in attr. view', 1)
 
     def train_cross_kg_relation_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:393-414: weighted 4-tuples, x2."""
         return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
                                      lambda cols, w, off: self._relation_positive_steps(self._ckgp_rel, cols, w, off),
-                                     'cross-kg relation inference in rel. view')
+                                     'cross-kg relation inference in rel. view', 0)
 
     def train_cross_kg_attribute_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:416-437: weighted, not doubled."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
             lambda cols, w, off: self._run_attr_steps(self._ckga_attr_cnn, cols, w, off, 1.0, "ckga_attr"),
-            'cross-kg attribute inference in attr. view')
+            'cross-kg attribute inference in attr. view', 1)
 
     # --- shared / common space ------------------------------------------------------------------------------
     def _entity_tensor(self, entities):
@@ -507,7 +510,7 @@ class MultiKE:
         t = self._entity_tensor(entities)
         steps = int(math.ceil(len(entities) / batch_size))
         bs = batch_size if steps > 1 else len(entities)
-        seed, stream = self._next_sample_stream()
+        seed, stream = self._next_sample_stream(2)
         self._last_sample = (seed, stream, len(entities), bs, steps)
         picked = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).long()]   # [steps, bs]
         for s in range(steps):
@@ -532,7 +535,7 @@ class MultiKE:
             B = self.args.entity_batch_size
             steps = int(math.ceil(len(entities) / B))
             bs = B if steps > 1 else len(entities)
-            seed, stream = self._next_sample_stream()
+            seed, stream = self._next_sample_stream(2)
             self._last_sample = (seed, stream, len(entities), bs, steps)
             idx = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).reshape(-1).long()]
             tag_base = self.engine.tag + 1
@@ -576,7 +579,7 @@ class MultiKE:
             B = self.args.entity_batch_size
             steps = int(math.ceil(len(entities) / B))
             bs = B if steps > 1 else len(entities)
-            seed, stream = self._next_sample_stream()
+            seed, stream = self._next_sample_stream(2)
             self._last_sample = (seed, stream, len(entities), bs, steps)
             idx = t[_lib.sample_distinct(len(entities), bs, steps, seed, stream, device=self.device).reshape(-1).long()]
             tag_base = self.engine.tag + 1
