@@ -55,17 +55,43 @@ struct ConvParams {
   int32_t* __restrict__ tattr;
   int32_t tag;
   float* __restrict__ ws;            // bwd: MKE_CNN_WORKSPACE_FLOATS(dim) zero-invariant floats (nullable)
+  // fwd with the dense layer in the same launch (k_attr_conv<WPL, 16, false, true>): z = tanh([flat, 1] W), W [4 dim + 1][dim]
+  const float* __restrict__ W;
+  float* __restrict__ z;
+  double* __restrict__ ssq;          // per-block sums of z^2 (MKE_LOSS_PARTIALS slots; the ones no block owns are cleared)
 };
 
 // K1[kh][kw][0][f] at k1[(kh*4+kw)*2+f]; K2[kh][kw][c][f] at k2[((kh*4+kw)*2+c)*2+f]  (TF HWIO order)
 // LPT lanes per triple (64: a wavefront per triple; 32: one per HALF — dim 75 fills 75 of 128 lane slots in two passes of 64
 // lanes but 75 of 96 in three passes of 32, and a wavefront then carries two triples: a quarter fewer instructions per
 // triple), WPL width positions per lane: position w = tl + LPT * i of lane tl of the group.
-template <int WPL, int LPT, bool BWD>
+// DENSE (forward, LPT = 16: a quarter-wave per triple, 16 triples per block = the rows of one 16 x 16 MFMA tile): the dense
+// layer follows in the same block — flat rows stay in LDS as the A operand of z = tanh([flat, 1] W) (dim <= 80: five column
+// tiles, K = 4 dim + 1 <= 321 split over the four wavefronts as in k_gemm_tall), W fragments requested before the
+// convolution starts; flat still goes to memory once (the weight-gradient product reads it).
+template <int WPL, int LPT, bool BWD, bool DENSE = false>
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
+  static_assert(!DENSE || (!BWD && LPT == 16), "dense layer: forward, a quarter-wave per triple");
   constexpr int TPW = 64 / LPT;                    // triples per wavefront
   constexpr int NSLOT = (MKE_BLOCK / 64) * TPW;    // triples in flight per block, each with its own LDS strips
   constexpr int DP = LPT * WPL + 4;
+  constexpr int FS = 4 * LPT * WPL + 5;            // DENSE: row stride of the flat tile (odd: conflict-free column reads)
+  constexpr int KS = 21;                           // DENSE: k-steps of 4 per wavefront (K <= 336)
+  constexpr int NCT = 5;                           // DENSE: column tiles of 16
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float s_flat[DENSE ? NSLOT : 1][DENSE ? FS : 1];
+  __shared__ float s_acc[DENSE ? MKE_BLOCK / 64 : 1][DENSE ? NCT : 1][4][DENSE ? 64 : 1];
+  float wfrag[DENSE ? KS : 1][DENSE ? NCT : 1];
+  if constexpr (DENSE) {
+    const int r16 = threadIdx.x & 15, kq = (threadIdx.x & 63) >> 4, wvv = threadIdx.x >> 6;
+    const int K = 4 * p.dim + 1;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const float* __restrict__ bp = p.W + (int64_t)min(4 * KS * wvv + kq + 4 * i, K - 1) * p.dim;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) wfrag[i][c] = bp[min(16 * c + r16, p.dim - 1)];
+    }
+  }
   __shared__ float s_x[NSLOT][2][DP];
   __shared__ float s_c1[NSLOT][2][2][DP];
   __shared__ float s_d2[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
@@ -75,7 +101,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   const int slot = wv * TPW + lane / LPT;         // which of the block's triples
   auto group_sum = [](float v) {                  // over the LPT lanes of a triple
     v = sub16_sum(v);
-    v += __shfl_xor(v, 16, 64);
+    if (LPT >= 32) v += __shfl_xor(v, 16, 64);
     if (LPT == 64) v += __shfl_xor(v, 32, 64);
     return v;
   };
@@ -212,6 +238,20 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         nrm[h][f] = rsqrtf(fmaxf(ssq[h][f], MKE_L2_EPS));
       }
     if constexpr (!BWD) {
+      if constexpr (DENSE) {
+        if (tl == 0) s_flat[slot][4 * d] = live ? 1.0f : 0.f;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+          const int w = tl + LPT * i;
+          if (w < d) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              s_flat[slot][h * 2 * d + w * 2] = live ? c2[h][0][i] * nrm[h][0] : 0.f;
+              s_flat[slot][h * 2 * d + w * 2 + 1] = live ? c2[h][1][i] * nrm[h][1] : 0.f;
+            }
+          }
+        }
+      }
       if (live) {
         float* o = p.flat + t * (int64_t)p.flat_stride;
         if (tl == 0 && p.flat_stride > 4 * d) o[4 * d] = 1.0f;  // bias column: [flat, 1] @ [W; bias]
@@ -371,6 +411,47 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   }
 
   __syncthreads();  // the strips are reused by the block-level reduction below
+  if constexpr (DENSE) {
+    // ---- z tile = tanh([flat, 1] W): the block's 16 flat rows (LDS) x W [K][d], K split over the four wavefronts ----
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int K = 4 * d + 1, k0 = 4 * KS * wv + kq;
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int k = k0 + 4 * i;
+      const float ai = k < K ? s_flat[r16][min(k, K - 1)] : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, wfrag[i][c], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_acc[wv][c][r][lane] = acc[c][r];
+    __syncthreads();
+    // wave w finishes column tiles w, w + 4: C/D map of the 16x16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg
+    float ssq = 0.f;
+    const int64_t m0 = (int64_t)blockIdx.x * NSLOT;
+    for (int c = wv; c < NCT; c += MKE_BLOCK / 64) {
+      const int col = 16 * c + r16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s_acc[0][c][r][lane] + s_acc[1][c][r][lane] + s_acc[2][c][r][lane] + s_acc[3][c][r][lane];
+        const int64_t orow = m0 + 4 * kq + r;
+        if (col < d && orow < p.n) {
+          v = tanhf(v);
+          p.z[orow * d + col] = v;
+          ssq = fmaf(v, v, ssq);
+        }
+      }
+    }
+    const double tot = block_sum_double(ssq);
+    if (threadIdx.x == 0) {
+      p.ssq[blockIdx.x] = tot;
+      for (int k = blockIdx.x + gridDim.x; k < MKE_LOSS_PARTIALS; k += gridDim.x) p.ssq[k] = 0.0;
+    }
+  }
   if constexpr (BWD) {
     // ---- block-reduce the parameter gradients, one atomic per block per scalar --------------------------------
     // the 16 quarter-wave slots of every scalar were filled during the loop (`park`); 52 threads add them up.  (First
@@ -561,6 +642,17 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   // dim <= 96: two triples per wavefront, 32 lanes each (dim 75: three passes of 32 lanes instead of two of 64)
   // (the backward only: it is bound by instruction issue; the forward is a latency chain and prefers twice the wavefronts)
+  if (!bwd && p.W) {   // conv stack + dense layer, 16 triples per block (the caller checked dim <= 80, n <= 16 MKE_LOSS_PARTIALS)
+    const unsigned nb = (unsigned)((p.n + 15) / 16);
+    switch ((p.dim + 15) / 16) {
+      case 1: hipLaunchKernelGGL((k_attr_conv<1, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_attr_conv<2, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((k_attr_conv<3, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 4: hipLaunchKernelGGL((k_attr_conv<4, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_attr_conv<5, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+    }
+    return check_launch("k_attr_conv");
+  }
   const bool half = bwd && p.dim <= 96;
   const int wpl = half ? (p.dim + 31) / 32 : (p.dim + 63) / 64;
   const int per_block = (MKE_BLOCK / 64) * (half ? 2 : 1);
@@ -771,10 +863,19 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   int rc;
   // forward: conv stack -> dense -> tanh -> batch-global normalisation -> loss
   if (phases & MKE_ATTR_FWD) {
-    if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
-                                a->params, flat, fs, stream))) return rc;
-    // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
-    if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq, 0))) return rc;
+    if (d <= 80 && (n + 15) / 16 <= MKE_LOSS_PARTIALS) {
+      // one launch: conv stack, then z = tanh([flat, 1] [W; bias]) on the block's 16 flat rows, per-block sums of z^2
+      ConvParams p{};
+      p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
+      p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.flat = flat;
+      p.flat_stride = fs; p.W = W; p.z = z; p.ssq = ssq;
+      if ((rc = conv_dispatch(p, false, st))) return rc;
+    } else {
+      if ((rc = mke_attr_conv_fwd(a->attr_table, a->attr_stride, a->attr_normalize, a->lit_table, a->lit_stride, d, a->ia, a->iv, n,
+                                  a->params, flat, fs, stream))) return rc;
+      // z = tanh([flat, 1] [W; bias]) with the per-block sums of z^2 written by the GEMM's epilogue
+      if ((rc = launch_gemm_f32(flat, fs, 1, W, d, 1, z, d, (int)n, d, 4 * d + 1, 1, 0, st, ssq, 0))) return rc;
+    }
   }
   const bool upd = a->update != 0 && (phases & MKE_ATTR_UPD);
   if ((phases & MKE_ATTR_TAIL) &&
