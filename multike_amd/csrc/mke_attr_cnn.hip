@@ -37,6 +37,26 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// two arrays of partials at once (one pass over both, one pair of barriers)
+__device__ __forceinline__ void totals_of_partials2(const double* __restrict__ pa, const double* __restrict__ pb, double& ta, double& tb) {
+  __shared__ double s_t2[2];
+  __shared__ double s_w2[2][MKE_BLOCK / 64];
+  double va = 0.0, vb = 0.0;
+  for (int i = threadIdx.x; i < MKE_LOSS_PARTIALS; i += MKE_BLOCK) { va += pa[i]; vb += pb[i]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { va += __shfl_down(va, off, 64); vb += __shfl_down(vb, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_w2[0][threadIdx.x >> 6] = va; s_w2[1][threadIdx.x >> 6] = vb; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < MKE_BLOCK / 64; ++w) t += s_w2[threadIdx.x][w];
+    s_t2[threadIdx.x] = t;
+  }
+  __syncthreads();
+  ta = s_t2[0];
+  tb = s_t2[1];
+}
+
 struct ConvParams {
   const float* __restrict__ attr;
   int attr_stride, attr_norm;
@@ -553,27 +573,41 @@ struct TailParams {
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p) {
-  const double S = total_of_partials(p.sumsq);
-  const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  // a row's id, z values and weight are requested one row ahead — the first row's before the partial sums are added up, so
+  // that its memory round trip and theirs are the same one
+  int row_n = 0;
+  float Zn[FPL], w_n = 1.0f;
+  auto request = [&](int64_t i) {
+    const bool ok = i < p.n;
+    row_n = ok ? p.ih[i] : 0;
+    w_n = (ok && p.ws) ? p.ws[i] : 1.0f;
+    const float* zp = p.z + (ok ? i : 0) * (int64_t)p.dim + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) Zn[k] = (ok && k * 16 + j < p.dim) ? zp[k * 16] : 0.f;
+  };
+  request(sub0);
+  const double S = total_of_partials(p.sumsq);
+  const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
   float loss = 0.f, dotacc = 0.f;
   for (int64_t i = sub0; i < p.n; i += nsub) {
-    const int row = p.ih[i];
+    const int row = row_n;
+    const float w = w_n;
     float H[FPL], Z[FPL];
     load_row<FPL>(p.ent, row, p.ent_stride, j, H);
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) Z[k] = Zn[k];
+    request(i + nsub);
     l2_normalize_row<FPL>(H, p.ent_norm);
-    const float* zp = p.z + i * (int64_t)p.dim + j;
     float x = 0.f;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) {
-      Z[k] = (k * 16 + j < p.dim) ? zp[k * 16] : 0.f;
       H[k] = H[k] - Z[k] * inv;  // diff = h - out
       x = fmaf(H[k], H[k], x);
     }
     x = sub16_sum(x);
-    const float w = p.ws ? p.ws[i] : 1.0f;
     loss += w * softplus_f(x);
     const float c = 2.0f * p.scale * w * sigmoid_f(x);
     float dz = 0.f;
@@ -606,15 +640,29 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_bwd(const float* __restrict__ z, float* __restrict__ g,
                                                              const double* __restrict__ sumsq, const double* __restrict__ dotp,
                                                              int64_t n, int dim) {
-  const double S = total_of_partials(sumsq);
-  __syncthreads();
-  const double T = total_of_partials(dotp);
+  // the first four elements of every thread (all of them when the grid is sized by the launcher) are requested before the
+  // partial sums: one memory round trip in front of the arithmetic instead of three
+  const int64_t total = n * dim;
+  const int64_t i0 = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x, step = (int64_t)gridDim.x * MKE_BLOCK;
+  float zv[4], gv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = i0 + j * step;
+    zv[j] = i < total ? z[i] : 0.f;
+    gv[j] = i < total ? g[i] : 0.f;
+  }
+  double S, T;
+  totals_of_partials2(sumsq, dotp, S, T);
   const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
   const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;  // out * (g.out) = z * inv^2 * T
-  const int64_t total = n * dim;
-  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    const float zv = z[i];
-    g[i] = inv * (g[i] - zv * coef) * (1.0f - zv * zv);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = i0 + j * step;
+    if (i < total) g[i] = inv * (gv[j] - zv[j] * coef) * (1.0f - zv[j] * zv[j]);
+  }
+  for (int64_t i = i0 + 4 * step; i < total; i += step) {
+    const float zz = z[i];
+    g[i] = inv * (g[i] - zz * coef) * (1.0f - zz * zz);
   }
 }
 
