@@ -36,6 +36,7 @@ struct OcParams {
   float* g_all;         // [G][2 C stride]
   const float* gv;      // [2 C stride]
   double* lossp;
+  int count_blocks;     // k_oc_bases: the first count_blocks blocks of the launch count the step's references instead
 };
 
 // codes of the negatives of home rank g's positives of this part: [n_mine_g][neg_per_pos]
@@ -52,12 +53,37 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_pack_codes(const int32_t* __re
   }
 }
 
+// reference counts of the rows this rank owns over the whole global step: the negatives' codes of every home rank + the
+// owned positives' heads / tails.  Block `block` of `n_blocks` (its own launch, or rider blocks of k_oc_bases: the counts need
+// only the epoch's codes, nothing of this step's)
+__device__ __forceinline__ void oc_count_range(const OcParams& p, int block, int n_blocks) {
+  const mke_oc_step& s = p.s;
+  const int64_t n_codes = s.n_pos * s.neg_per_pos;
+  const int64_t total = n_codes + s.n_own_h + s.n_own_t;
+  for (int64_t e = (int64_t)block * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)n_blocks * MKE_BLOCK) {
+    if (e < n_codes) {
+      const int64_t i = e / s.neg_per_pos;
+      const int g = (int)(i / s.per);
+      const int c = oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)] >> 1;
+      if (c % s.n_ranks == s.rank) atomicAdd(&s.ref_count[c / s.n_ranks], 1);
+    } else {
+      const int64_t k = e - n_codes;
+      const int ent = k < s.n_own_h ? s.pos_h[s.own_h[k]] : s.pos_t[s.own_t[k - s.n_own_h]];
+      atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
+    }
+  }
+}
+
 // quarter-wave per owned slot (HR slots, then RT slots)
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_bases(const OcParams p) {
+  if ((int)blockIdx.x < p.count_blocks) {  // block-uniform
+    oc_count_range(p, blockIdx.x, p.count_blocks);
+    return;
+  }
   const mke_oc_step& s = p.s;
   const int j = threadIdx.x & 15;
-  const int64_t sub = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t sub = (((int64_t)blockIdx.x - p.count_blocks) * MKE_BLOCK + threadIdx.x) >> 4;
   if (sub >= s.n_own_h + s.n_own_t) return;
   const bool is_h = sub < s.n_own_h;
   const int64_t k = is_h ? sub : sub - s.n_own_h;
@@ -73,23 +99,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_bases(const OcParams p) {
   for (int q = 0; q < FPL; ++q) o[q * 16] = is_h ? E[q] + R[q] : R[q] - E[q];
 }
 
-__global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) {
-  const mke_oc_step& s = p.s;
-  const int64_t n_codes = s.n_pos * s.neg_per_pos;
-  const int64_t total = n_codes + s.n_own_h + s.n_own_t;
-  for (int64_t e = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * MKE_BLOCK) {
-    if (e < n_codes) {
-      const int64_t i = e / s.neg_per_pos;
-      const int g = (int)(i / s.per);
-      const int c = oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)] >> 1;
-      if (c % s.n_ranks == s.rank) atomicAdd(&s.ref_count[c / s.n_ranks], 1);
-    } else {
-      const int64_t k = e - n_codes;
-      const int ent = k < s.n_own_h ? s.pos_h[s.own_h[k]] : s.pos_t[s.own_t[k - s.n_own_h]];
-      atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
-    }
-  }
-}
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) { oc_count_range(p, blockIdx.x, gridDim.x); }
 
 // One wavefront per positive of the global step.  Lane l holds the code of negative l (neg_per_pos <= 64); the negatives
 // this rank owns are dealt round-robin to the four quarter-waves (the (4 round + q)-th set bit of the ballot), U of them
@@ -332,18 +342,27 @@ extern "C" int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, con
   return check_launch("k_oc_pack_codes");
 }
 
-extern "C" int mke_oc_bases(const mke_oc_step* s, float* send_block, void* stream) {
-  using namespace mke;
+namespace mke {
+// bases, with the step's reference counting on rider blocks of the same launch when with_count
+static int oc_bases_impl(const mke_oc_step* s, float* send_block, bool with_count, void* stream) {
   int rc = oc_check(s, "mke_oc_bases");
   if (rc) return rc;
   if (!send_block) { set_error("mke_oc_bases: NULL send block"); return MKE_E_NULL; }
   OcParams p{};
   p.s = *s; p.send = send_block;
   const int64_t subs = s->n_own_h + s->n_own_t;
-  if (subs == 0) return MKE_OK;
+  const int64_t n_count = (with_count && s->ref_count) ? s->n_pos * s->neg_per_pos + subs : 0;
+  if (subs == 0) return n_count ? mke_oc_count(s, stream) : MKE_OK;
+  p.count_blocks = n_count ? (int)oc_blocks(n_count, MKE_BLOCK, 1024) : 0;
   const int fpl = s->stride / 16;
-  MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_bases<FPL>), dim3((unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); });
+  const unsigned blocks = (unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK) + p.count_blocks;
+  MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_bases<FPL>), dim3(blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); });
   return check_launch("k_oc_bases");
+}
+}  // namespace mke
+
+extern "C" int mke_oc_bases(const mke_oc_step* s, float* send_block, void* stream) {
+  return mke::oc_bases_impl(s, send_block, false, stream);
 }
 
 extern "C" int mke_oc_count(const mke_oc_step* s, void* stream) {
@@ -404,8 +423,9 @@ extern "C" int mke_oc_run(const mke_oc_step* s, int phases, float* send_block, c
                           const float* gv, double* loss_partials, void* stream) {
   using namespace mke;
   int rc = MKE_OK;
-  if ((phases & MKE_OC_BASES) && (rc = mke_oc_bases(s, send_block, stream))) return rc;
-  if ((phases & MKE_OC_COUNT) && (rc = mke_oc_count(s, stream))) return rc;
+  const bool both = (phases & MKE_OC_BASES) && (phases & MKE_OC_COUNT);   // one launch: the counting rides with the bases
+  if ((phases & MKE_OC_BASES) && (rc = oc_bases_impl(s, send_block, both, stream))) return rc;
+  if ((phases & MKE_OC_COUNT) && !both && (rc = mke_oc_count(s, stream))) return rc;
   if ((phases & MKE_OC_SCORE) && (rc = mke_oc_score(s, v_all, block_floats, g_all, loss_partials, stream))) return rc;
   if ((phases & MKE_OC_APPLY) && (rc = mke_oc_apply(s, gv, stream))) return rc;
   if (phases & MKE_OC_UPDATE) {

@@ -581,14 +581,12 @@ class OwnerComputesTrainer:
         pipelined = len(ks) > 1 and self.device.type == "cuda"
         works = {}
         # ---- HR / RT vectors of every part, all-gathered (asynchronously when pipelining) -------------------------
+        # The reference counts over the WHOLE global step (all parts) are complete before any part is scored; they need
+        # only the epoch's codes and ride on blocks of the bases launch (one kernel boundary less per part, and nothing
+        # of theirs left behind the all-gather)
         for c, k in enumerate(ks):
-            be.run(self, k, tag, BASES, c, slot0 + c)
+            be.run(self, k, tag, BASES | (COUNT if self.ref_count is not None else 0), c, slot0 + c)
             works[("ag", c)] = cm.all_gather(self._v_all[c], self._send[c], async_op=pipelined)
-        # ---- reference counts over the WHOLE global step (all parts) before any part is scored: they need only the
-        #      epoch's codes, so this runs while the all-gathers are on the wire ----------------------------------
-        if self.ref_count is not None:
-            for c, k in enumerate(ks):
-                be.run(self, k, tag, COUNT, c, slot0 + c)
         # ---- score part c while part c+1's all-gather / part c-1's reduce-scatter are on the wire ------------------
         for c, k in enumerate(ks):
             if works.get(("ag", c)) is not None:
