@@ -46,7 +46,12 @@ def test_golden_loss_and_every_gradient(ci):
 
 
 @pytest.mark.parametrize("d,B,n_ent,n_attr,n_lit", [(75, 5000, 20000, 300, 8000), (75, 37, 100, 9, 50), (32, 513, 900, 20, 400),
-                                                    (130, 64, 200, 11, 90)])
+                                                    (130, 64, 200, 11, 90),
+                                                    # every width of the fused forward (conv stack + dense layer in one
+                                                    # launch: dim <= 80, a quarter-wave per triple, 1..5 positions per lane),
+                                                    # its upper edge, and the first width past it
+                                                    (8, 100, 60, 7, 30), (40, 300, 500, 13, 200), (64, 215, 300, 10, 100),
+                                                    (80, 129, 400, 12, 150), (96, 70, 150, 9, 60)])
 def test_three_steps_vs_oracle(d, B, n_ent, n_attr, n_lit):
     """Full step (scatter with duplicate rows, Jacobian + Adagrad on the entity table, plain Adagrad on the raw attribute
     table and on the packed CNN parameters) against the float64 dense oracle."""
