@@ -762,7 +762,8 @@ int mke_oc_count(const mke_oc_step* step, void* stream);
 int mke_oc_score(const mke_oc_step* step, const float* v_all, int64_t block_floats, float* g_all,
                  double* loss_partials /* [MKE_LOSS_PARTIALS] */, void* stream);
 int mke_oc_apply(const mke_oc_step* step, const float* gv, void* stream);
-/* the phases selected by the bit mask, in the order above, in one call (what lies between two collectives): */
+/* the phases selected by the bit mask, in the order above, in one call (what lies between two collectives);
+ * MKE_OC_BASES | MKE_OC_COUNT is ONE launch (the counting needs only the codes: it runs on rider blocks beside the bases): */
 #define MKE_OC_BASES 1
 #define MKE_OC_COUNT 2
 #define MKE_OC_SCORE 4
