@@ -50,6 +50,9 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 
 int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
                     int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain);
+bool launch_gemm_tallsplit_plus(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, float* C0, int64_t ldc0,
+                                int M0, int N0, int K0, const float* A1, int64_t a1_rs, int64_t a1_cs, const float* B1, int64_t b1_rs,
+                                int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, hipStream_t st, int* rc);
 int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, int64_t b0_cs, float* C0,
                          int64_t ldc0, int M0, int N0, int K0, int splits0, int acc0, const float* A1, int64_t a1_rs, int64_t a1_cs,
                          const float* B1, int64_t b1_rs, int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, int splits1,

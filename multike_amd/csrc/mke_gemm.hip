@@ -196,15 +196,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // arrays stay in registers and the MFMA sequence is straight-line code.  Loads are unconditional from clamped addresses
 // (a guarded load makes the compiler wait for each one before its select): a k-step past K gets a = 0, so whatever b
 // holds there multiplies to nothing; columns past N and rows past M are computed from valid memory and never stored.
-template <int NCT, int KS>
-__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
-  __shared__ float s_part[MKE_BLOCK / 64][NCT][4][64];
+// EPI: tanh (unless epi_plain) + per-block sums of squares — the forward products, K <= 16 KS.  !EPI: a K SPLIT of a product
+// with a short M (the attribute step's weight gradient [flat, 1]^T dz: 301 x 75 over K = 5000): block (bx, by) owns rows
+// [16 bx, 16 bx + 16) and k in [by k_per_split, (by + 1) k_per_split), k_per_split <= 16 KS, and adds its 16 x N partial
+// product to C atomically — 304 blocks of ONE round of loads each and 0.39 M atomics, where 64 x 64 tiles through LDS were
+// 320 blocks of five dependent K slabs and 1.3 M atomics (a 64-wide column tile holds 11 of N = 75 columns).
+// A(i, k) = A[i a_rs + k a_cs] (offsets fit 32 bits: the launcher checks), B n-contiguous.
+template <int NCT, int KS, bool EPI>
+__device__ __forceinline__ void gemm_tall_block(const GemmParams& p, int bx, int by, float (*s_part)[NCT][4][64]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * 16;
-  const int k0 = 4 * KS * wv + kq;  // this lane's first k
+  const int m0 = bx * 16;
+  const int k_lo = EPI ? 0 : by * p.k_per_split;
+  const int k_hi = EPI ? p.K : min(p.K, k_lo + p.k_per_split);
+  const int k0 = k_lo + 4 * KS * wv + kq;  // this lane's first k
   const int row = min(m0 + r16, p.M - 1);
   const float* ap = p.A + (int64_t)row * p.a_rs;
+  const int a_cs = (int)p.a_cs;
   int bcol[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c) bcol[c] = min(16 * c + r16, p.N - 1);
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     const int kc = min(k0 + 4 * i, p.K - 1);
-    a[i] = ap[kc];
+    a[i] = EPI ? ap[kc] : ap[kc * a_cs];
     const float* bp = p.B + (int64_t)kc * p.b_rs;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) b[i][c] = bp[bcol[c]];
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
   for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const float ai = (k0 + 4 * i < p.K) ? a[i] : 0.f;
+    const float ai = (k0 + 4 * i < k_hi) ? a[i] : 0.f;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b[i][c], acc[c], 0, 0, 0);
   }
@@ -240,18 +248,30 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
       float v = s_part[0][c][r][lane] + s_part[1][c][r][lane] + s_part[2][c][r][lane] + s_part[3][c][r][lane];
       const int orow = m0 + 4 * kq + r;
       if (col < p.N && orow < p.M) {
-        if (!p.epi_plain) v = tanhf(v);
-        p.C[(int64_t)orow * p.ldc + col] = v;
-        ssq = fmaf(v, v, ssq);
+        if constexpr (EPI) {
+          if (!p.epi_plain) v = tanhf(v);
+          p.C[(int64_t)orow * p.ldc + col] = v;
+          ssq = fmaf(v, v, ssq);
+        } else {
+          atomic_add_f32(p.C + (int64_t)orow * p.ldc + col, v);
+        }
       }
     }
   }
-  const double tot = block_sum_double(ssq);
-  if (tid == 0) {
-    const int nb = gridDim.x, bi = blockIdx.x;
-    p.partials[bi] = tot;
-    for (int k = bi + nb; k < MKE_LOSS_PARTIALS; k += nb) p.partials[k] = 0.0;
+  if constexpr (EPI) {
+    const double tot = block_sum_double(ssq);
+    if (tid == 0) {
+      const int nb = gridDim.x, bi = blockIdx.x;
+      p.partials[bi] = tot;
+      for (int k = bi + nb; k < MKE_LOSS_PARTIALS; k += nb) p.partials[k] = 0.0;
+    }
   }
+}
+
+template <int NCT, int KS>
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tall(const GemmParams p) {
+  __shared__ float s_part[MKE_BLOCK / 64][NCT][4][64];
+  gemm_tall_block<NCT, KS, true>(p, blockIdx.x, 0, s_part);
 }
 
 __global__ __launch_bounds__(MKE_BLOCK) void k_gemm_f32(const GemmParams p) { gemm_block(p, blockIdx.x, blockIdx.y, blockIdx.z); }
@@ -309,6 +329,45 @@ int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, 
   if (tanh_sumsq_partials && p.gx * p.gy > MKE_LOSS_PARTIALS) { set_error("gemm epilogue: more than %d blocks", MKE_LOSS_PARTIALS); return MKE_E_SHAPE; }
   hipLaunchKernelGGL(k_gemm_f32, dim3(p.gx, p.gy, p.gz), dim3(MKE_BLOCK), 0, st, p);
   return check_launch("k_gemm_f32");
+}
+
+// the attribute step's two gradient products in one launch: blocks [0, t.gx t.gz) the K-split tall product t (dW), the
+// rest the 64 x 64-tile product g (dflat)
+struct GemmTallPlus {
+  GemmParams t, g;
+  int tall_blocks;
+};
+__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tallsplit_plus(const GemmTallPlus b) {
+  if ((int)blockIdx.x < b.tall_blocks) {   // block-uniform
+    __shared__ float s_part[MKE_BLOCK / 64][5][4][64];
+    gemm_tall_block<5, 20, false>(b.t, blockIdx.x % b.t.gx, blockIdx.x / b.t.gx, s_part);
+    return;
+  }
+  int r = blockIdx.x - b.tall_blocks;
+  const int bx = r % b.g.gx;
+  r /= b.g.gx;
+  gemm_block(b.g, bx, r % b.g.gy, r / b.g.gy);
+}
+
+// C0 += A0^T-style tall product, split over K (M0 x N0, N0 <= 80, atomically into a zeroed / running C0) and C1 = A1 B1 in one
+// launch.  Returns false when the first product's shape does not fit (the caller uses launch_gemm_f32_pair).
+bool launch_gemm_tallsplit_plus(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, float* C0, int64_t ldc0,
+                                int M0, int N0, int K0, const float* A1, int64_t a1_rs, int64_t a1_cs, const float* B1, int64_t b1_rs,
+                                int64_t b1_cs, float* C1, int64_t ldc1, int M1, int N1, int K1, hipStream_t st, int* rc) {
+  if (N0 > 80 || N0 < 1 || M0 < 1 || K0 < 1 || (int64_t)K0 * a0_cs >= (1LL << 31) || a0_cs < 1) return false;
+  GemmTallPlus b;
+  GemmParams& t = b.t;
+  t = GemmParams{};
+  t.A = A0; t.B = B0; t.C = C0; t.M = M0; t.N = N0; t.K = K0; t.a_rs = a0_rs; t.a_cs = a0_cs; t.b_rs = b0_rs; t.b_cs = 1; t.ldc = ldc0;
+  t.k_per_split = 320;   // 16 x KS(20) k per block: 4 wavefronts x 20 k-steps of 4
+  t.gx = (M0 + 15) / 16; t.gy = 1; t.gz = (K0 + t.k_per_split - 1) / t.k_per_split; t.atomic = 1;
+  b.tall_blocks = t.gx * t.gz;
+  int g_blocks = 0;
+  if (gemm_setup(b.g, A1, a1_rs, a1_cs, B1, b1_rs, b1_cs, C1, ldc1, M1, N1, K1, 1, 0, nullptr)) g_blocks = b.g.gx * b.g.gy * b.g.gz;
+  else b.g = GemmParams{};
+  hipLaunchKernelGGL(k_gemm_tallsplit_plus, dim3(b.tall_blocks + g_blocks), dim3(MKE_BLOCK), 0, st, b);
+  *rc = check_launch("k_gemm_tallsplit_plus");
+  return true;
 }
 
 // two independent products in one launch (the attribute step's dW and dflat)
