@@ -112,7 +112,10 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       for (int c = 0; c < NCT; ++c) wfrag[i][c] = bp[min(16 * c + r16, p.dim - 1)];
     }
   }
-  __shared__ float s_x[NSLOT][2][DP];
+  // LPT = 16: a half-wave reads two triples' strips at once — their distance must be 16 banks (mod 32) for the two 16-lane
+  // runs not to overlap: 4 DP already is (the c1 strips); the x strips get their own row length (2 DPX = 16 mod 32)
+  constexpr int DPX = LPT == 16 ? DP + ((8 - DP % 16) + 16) % 16 : DP;
+  __shared__ float s_x[NSLOT][2][DPX];
   __shared__ float s_c1[NSLOT][2][2][DP];
   __shared__ float s_d2[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
   __shared__ float s_d1[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < WPL; ++i) a_gam[i] = a_bet[i] = 0.f;
   }
-  float(*xs)[DP] = s_x[slot];
+  float(*xs)[DPX] = s_x[slot];
   float(*c1s)[2][DP] = s_c1[slot];
 
   const int64_t wave0 = (int64_t)blockIdx.x * NSLOT + slot;
