@@ -21,6 +21,8 @@ namespace mke {
 #define CNN_WS_COPIES 32
 #define CNN_WS_STRIDE(d) (2 * (d) + 64)  // MKE_CNN_WORKSPACE_FLOATS(dim) = copies * stride
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = sub16_sum(v);
   v += __shfl_xor(v, 16, 64);
@@ -211,16 +213,21 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       const int w = tl + LPT * i;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
+      {
+        // the two filters of a tap are adjacent in the packed weights: one v_pk_fma_f32 per tap for both (the input broadcast)
+        v2f acc = {b1[0], b1[1]};
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          float acc = b1[f];
+        for (int kh = 0; kh + h < 2; ++kh)
 #pragma unroll
-          for (int kh = 0; kh + h < 2; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) acc = fmaf(k1[(kh * 4 + kw) * 2 + f], xs[h + kh][w + kw], acc);
-          c1[h][f][i] = w < d ? tanh_f(acc) : 0.f;
-          c1s[h][f][w + 1] = c1[h][f][i];
-        }
+          for (int kw = 0; kw < 4; ++kw) {
+            const float x = xs[h + kh][w + kw];
+            acc = __builtin_elementwise_fma(v2f{k1[(kh * 4 + kw) * 2], k1[(kh * 4 + kw) * 2 + 1]}, v2f{x, x}, acc);
+          }
+        c1[h][0][i] = w < d ? tanh_f(acc.x) : 0.f;
+        c1[h][1][i] = w < d ? tanh_f(acc.y) : 0.f;
+        c1s[h][0][w + 1] = c1[h][0][i];
+        c1s[h][1][w + 1] = c1[h][1][i];
+      }
     }
     if (tl < 4) {
 #pragma unroll
@@ -240,18 +247,23 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       const int w = tl + LPT * i;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
+      {
+        v2f acc = {b2[0], b2[1]};
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          float acc = b2[f];
+        for (int kh = 0; kh + h < 2; ++kh)
 #pragma unroll
-          for (int kh = 0; kh + h < 2; ++kh)
+          for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-              for (int c = 0; c < 2; ++c) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], c1s[h + kh][c][w + kw], acc);
-          c2[h][f][i] = w < d ? tanh_f(acc) : 0.f;
-          ssq[h][f] = fmaf(c2[h][f][i], c2[h][f][i], ssq[h][f]);
-        }
+            for (int c = 0; c < 2; ++c) {
+              const float x = c1s[h + kh][c][w + kw];
+              const int ki = ((kh * 4 + kw) * 2 + c) * 2;
+              acc = __builtin_elementwise_fma(v2f{k2[ki], k2[ki + 1]}, v2f{x, x}, acc);
+            }
+        c2[h][0][i] = w < d ? tanh_f(acc.x) : 0.f;
+        c2[h][1][i] = w < d ? tanh_f(acc.y) : 0.f;
+        ssq[h][0] = fmaf(c2[h][0][i], c2[h][0][i], ssq[h][0]);
+        ssq[h][1] = fmaf(c2[h][1][i], c2[h][1][i], ssq[h][1]);
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -335,24 +347,29 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
       }
       // parameter gradients of conv2, one scalar at a time: db2[f] = sum dp2[.][f][.],
       // dK2[kh][kw][c][f] = sum_{h, w} dp2[h][f][w] * c1[h + kh][c][w + kw - 1]
+      {
+        // both filters of a tap at once (v_pk_fma_f32: the pair (dp2[.][0], dp2[.][1]) times the broadcast c1 value)
+        v2f v = {0.f, 0.f};
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < WPL; ++i) v += dp2[0][f][i] + dp2[1][f][i];
-        park(50 + f, v);
+        for (int i = 0; i < WPL; ++i) v += v2f{dp2[0][0][i], dp2[0][1][i]} + v2f{dp2[1][0][i], dp2[1][1][i]};
+        park(50, v.x);
+        park(51, v.y);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-              float a = 0.f;
+              v2f a = {0.f, 0.f};
 #pragma unroll
               for (int h = 0; h + kh < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < WPL; ++i) a = fmaf(dp2[h][f][i], c1s[h + kh][c][tl + LPT * i + kw], a);
-              park(18 + ((kh * 4 + kw) * 2 + c) * 2 + f, a);
+                for (int i = 0; i < WPL; ++i) {
+                  const float x = c1s[h + kh][c][tl + LPT * i + kw];
+                  a = __builtin_elementwise_fma(v2f{dp2[h][0][i], dp2[h][1][i]}, v2f{x, x}, a);
+                }
+              park(18 + ((kh * 4 + kw) * 2 + c) * 2, a.x);
+              park(18 + ((kh * 4 + kw) * 2 + c) * 2 + 1, a.y);
             }
       }
       if (tl < 4) {
@@ -371,34 +388,41 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            float acc = 0.f;
+            v2f acc2 = {0.f, 0.f};   // the two filters' terms side by side, added at the end
 #pragma unroll
             for (int kh = 0; kh <= hh; ++kh)
 #pragma unroll
-              for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) acc = fmaf(k2[((kh * 4 + kw) * 2 + c) * 2 + f], d2s[hh - kh][f][w + 3 - kw], acc);
+              for (int kw = 0; kw < 4; ++kw) {
+                const int ki = ((kh * 4 + kw) * 2 + c) * 2;
+                acc2 = __builtin_elementwise_fma(v2f{k2[ki], k2[ki + 1]},
+                                                 v2f{d2s[hh - kh][0][w + 3 - kw], d2s[hh - kh][1][w + 3 - kw]}, acc2);
+              }
+            const float acc = acc2.x + acc2.y;
             dp1[hh][c][i] = (w < d) ? acc * (1.0f - c1[hh][c][i] * c1[hh][c][i]) : 0.f;
             d1s[hh][c][w + 2] = dp1[hh][c][i];
           }
       }
       // parameter gradients of conv1: db1[c], dK1[kh][kw][0][c] = sum_{h, w} dp1[h][c][w] * x[h + kh][w + kw - 1]
+      {
+        v2f v = {0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < WPL; ++i) v += dp1[0][c][i] + dp1[1][c][i];
-        park(16 + c, v);
+        for (int i = 0; i < WPL; ++i) v += v2f{dp1[0][0][i], dp1[0][1][i]} + v2f{dp1[1][0][i], dp1[1][1][i]};
+        park(16, v.x);
+        park(17, v.y);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 4; ++kw) {
-            float a = 0.f;
+            v2f a = {0.f, 0.f};
 #pragma unroll
             for (int hh = 0; hh + kh < 2; ++hh)
 #pragma unroll
-              for (int i = 0; i < WPL; ++i) a = fmaf(dp1[hh][c][i], xs[hh + kh][tl + LPT * i + kw], a);
-            park((kh * 4 + kw) * 2 + c, a);
+              for (int i = 0; i < WPL; ++i) {
+                const float x = xs[hh + kh][tl + LPT * i + kw];
+                a = __builtin_elementwise_fma(v2f{dp1[hh][0][i], dp1[hh][1][i]}, v2f{x, x}, a);
+              }
+            park((kh * 4 + kw) * 2, a.x);
+            park((kh * 4 + kw) * 2 + 1, a.y);
           }
       }
       if (tl < 4) {
@@ -415,14 +439,14 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
         float dx[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          float acc = 0.f;
+          v2f acc2 = {0.f, 0.f};
 #pragma unroll
           for (int kh = 0; kh <= hh; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-              for (int f = 0; f < 2; ++f) acc = fmaf(k1[(kh * 4 + kw) * 2 + f], d1s[hh - kh][f][w + 3 - kw], acc);
-          dx[hh] = (live && w < d) ? acc : 0.f;
+              acc2 = __builtin_elementwise_fma(v2f{k1[(kh * 4 + kw) * 2], k1[(kh * 4 + kw) * 2 + 1]},
+                                               v2f{d1s[hh - kh][0][w + 3 - kw], d1s[hh - kh][1][w + 3 - kw]}, acc2);
+          dx[hh] = (live && w < d) ? acc2.x + acc2.y : 0.f;
         }
         a_gam[i] += (dx[0] * raw[0][i] + dx[1] * raw[1][i]) * bn_s;
         a_bet[i] += dx[0] + dx[1];
