@@ -1,4 +1,4 @@
-"""Attribute-view step only (B = 5000, dim 75), for rocprofv3 --kernel-trace: `python tools/attr_prof.py [steps]`."""
+"""Attribute-view step only (B = 5000, dim 75), for rocprofv3 --kernel-trace: `python tools/attr_prof.py [steps] [B]`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -6,7 +6,7 @@ from multike_amd.attr_cnn import AttrCNN
 from multike_amd.tables import EmbeddingTable, StepEngine
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-d, B = 75, 5000
+d, B = 75, (int(sys.argv[2]) if len(sys.argv) > 2 else 5000)
 E = EmbeddingTable(200_000, d, "av", seed=1); A = EmbeddingTable(600, d, "attr", normalize=False, seed=2)
 lit = np.random.default_rng(0).standard_normal((100_000, d)).astype(np.float32); lit /= np.linalg.norm(lit, axis=1, keepdims=True)
 L = EmbeddingTable(100_000, d, "lit", normalize=False, trainable=False, values=lit)
