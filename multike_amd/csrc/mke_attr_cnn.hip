@@ -91,11 +91,16 @@ struct ConvParams {
 // layer follows in the same block — flat rows stay in LDS as the A operand of z = tanh([flat, 1] W) (dim <= 80: five column
 // tiles, K = 4 dim + 1 <= 321 split over the four wavefronts as in k_gemm_tall), W fragments requested before the
 // convolution starts; flat still goes to memory once (the weight-gradient product reads it).
-template <int WPL, int LPT, bool BWD, bool DENSE = false>
-__global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
+// NW wavefronts per block (4; the two-triples-per-wavefront backward: 2 — each convolution kernel costs the latency chain of
+// one block plus ~2 us per further 4-wavefront block on the same CU (batch-size scan in profiles/r02_attr_step.md); 5000
+// triples are 625 such blocks = three on 113 of the 256 CUs, but 1250 half blocks = at most five halves per CU)
+template <int WPL, int LPT, bool BWD, bool DENSE = false, int NW = MKE_BLOCK / 64>
+__global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
+  static_assert(NW == MKE_BLOCK / 64 || (BWD && !DENSE), "short blocks: backward only");
+  constexpr int NT = NW * 64;                      // threads per block
   static_assert(!DENSE || (!BWD && LPT == 16), "dense layer: forward, a quarter-wave per triple");
   constexpr int TPW = 64 / LPT;                    // triples per wavefront
-  constexpr int NSLOT = (MKE_BLOCK / 64) * TPW;    // triples in flight per block, each with its own LDS strips
+  constexpr int NSLOT = NW * TPW;                  // triples in flight per block, each with its own LDS strips
   constexpr int DP = LPT * WPL + 4;
   constexpr int FS = 4 * LPT * WPL + 5;            // DENSE: row stride of the flat tile (odd: conflict-free column reads)
   constexpr int KS = 21;                           // DENSE: k-steps of 4 per wavefront (K <= 336)
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   // The 52 conv-parameter gradients are NOT kept in registers: each is reduced over its quarter-wave as soon as it is
   // formed and added to the quarter's own LDS slot (s_part).  48 + 4 long-lived accumulators pushed the backward kernel to
   // 208 unified registers = 2 waves per SIMD = three rounds of waves for 5000 triples.
-  __shared__ float s_part[BWD ? CNN_NCONV : 1][17];
+  __shared__ float s_part[BWD ? CNN_NCONV : 1][4 * NW + 1];
   const int pq = (lane >> 4) + 4 * wv;
   const bool plead = (lane & 15) == 0;
   auto park = [&](int idx, float v) {
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
   };
   float a_gam[WPL], a_bet[WPL];
   if constexpr (BWD) {
-    for (int i = threadIdx.x; i < CNN_NCONV * 17; i += MKE_BLOCK) (&s_part[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < CNN_NCONV * (4 * NW + 1); i += NT) (&s_part[0][0])[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < WPL; ++i) a_gam[i] = a_bet[i] = 0.f;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     // update, or k_cnn_ws_fold) adds the copies up and zeroes them.  (A last-block-done ticket was tried first: the
     // ticket is itself a gridDim.x-long same-address chain and cost more than it saved, 95 us.)
     float* dst = p.ws ? p.ws + (size_t)(blockIdx.x % CNN_WS_COPIES) * CNN_WS_STRIDE(d) : p.gparams;
-    for (int w = threadIdx.x; w < d; w += MKE_BLOCK) {
+    for (int w = threadIdx.x; w < d; w += NT) {
       float g = 0.f, b = 0.f;
 #pragma unroll
       for (int k = 0; k < NSLOT; ++k) { g += gsum[k * LPT * WPL + w]; b += bsum[k * LPT * WPL + w]; }
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_conv(const ConvParams p) {
     if (threadIdx.x < CNN_NCONV) {
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v += s_part[threadIdx.x][k];
+      for (int k = 0; k < 4 * NW; ++k) v += s_part[threadIdx.x][k];
       atomic_add_f32(dst + 2 * d + threadIdx.x, v);
     }
   }
@@ -733,7 +738,8 @@ static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   }
   const bool half = bwd && p.dim <= 96;
   const int wpl = half ? (p.dim + 31) / 32 : (p.dim + 63) / 64;
-  const int per_block = (MKE_BLOCK / 64) * (half ? 2 : 1);
+  const int nw = half ? 2 : MKE_BLOCK / 64;   // the two-triples-per-wavefront backward runs in blocks of two wavefronts
+  const int per_block = nw * (half ? 2 : 1);
   int64_t blocks = (p.n + per_block - 1) / per_block;
   if (blocks > 4096) blocks = 4096;  // one triple per group up to 16K (32K) triples: no half-idle second pass
   if (blocks < 1) blocks = 1;
@@ -743,7 +749,9 @@ static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
     break;
   if (half) {
     switch (wpl) {
-      case 1: MKE_CONV_CASE(1, 32) case 2: MKE_CONV_CASE(2, 32) case 3: MKE_CONV_CASE(3, 32)
+      case 1: hipLaunchKernelGGL((k_attr_conv<1, 32, true, false, 2>), dim3((unsigned)blocks), dim3(128), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_attr_conv<2, 32, true, false, 2>), dim3((unsigned)blocks), dim3(128), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((k_attr_conv<3, 32, true, false, 2>), dim3((unsigned)blocks), dim3(128), 0, st, p); break;
       default: set_error("attribute CNN: dim %d not supported", p.dim); return MKE_E_UNSUPPORTED;
     }
   } else {
