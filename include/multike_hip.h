@@ -705,6 +705,22 @@ typedef struct mke_ae_plan {
 int64_t mke_ae_scratch_floats(const mke_ae_plan* plan, int64_t rows);
 int mke_ae_train_steps(const mke_ae_plan* plan, const float* x, int64_t n_rows, int64_t ldx, int64_t batch_rows,
                        double* loss_out /* device [ceil(n_rows / batch_rows)] */, void* stream);
+/* ONE batch cut at its batch-wide sums, for data-parallel training of the auto-encoder (the code matrix is
+ * normalised as a whole, code/literal_encoder.py:65-66): every rank holds the replicated parameters and `rows` of the
+ * `global_rows` rows of the batch (rows may be 0).  Between the phases the caller all-reduces
+ *   plan->partials[0 ..)                      (sum code^2)      after MKE_AE_ENC,
+ *   plan->partials[MKE_LOSS_PARTIALS ..)      (sum dcn . code)  after MKE_AE_DEC,
+ * (replace each array by [global sum, 0, 0, ...]: the consuming phase adds the entries up itself and re-zeroes them), and
+ * plan->grads after MKE_AE_BWD (then identical updates on every rank).  loss_out[0] = this rank's share of the batch's
+ * loss, sum over its rows / (global_rows * dims[0]): the shares add up to mean((decoded - x)^2).  MKE_AE_ALL with
+ * rows == global_rows is one step of mke_ae_train_steps. */
+#define MKE_AE_ENC 1
+#define MKE_AE_DEC 2
+#define MKE_AE_BWD 4
+#define MKE_AE_UPD 8
+#define MKE_AE_ALL 15
+int mke_ae_step_phases(const mke_ae_plan* plan, const float* x, int64_t rows, int64_t ldx, int64_t global_rows, int phases,
+                       double* loss_out, void* stream);
 /* out [n_rows][ld_out] = encoder(x): code/literal_encoder.py:114-144 (no normalisation of input or output) */
 int mke_ae_encode(const mke_ae_plan* plan, const float* x, int64_t n_rows, int64_t ldx, float* out, int64_t ld_out, void* stream);
 /* one dense layer, out [M][ld_out] = act(x [M][ldx] @ w [K][ldw] + b [N]) (b nullable): the `encoder` / `decoder` methods of

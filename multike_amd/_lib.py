@@ -32,7 +32,7 @@ SYMBOLS = (
     "mke_attr_conv_fwd", "mke_attr_conv_bwd", "mke_attr_tail_z", "mke_attr_tail_loss", "mke_attr_tail_bwd",
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
-    "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_encode", "mke_dense_layer_fwd",
+    "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
@@ -718,6 +718,16 @@ def ae_train_steps(plan: AEPlanStruct, x: torch.Tensor, batch_rows: int, loss_ou
     rc = lib().mke_ae_train_steps(C.byref(plan), _dev(x, torch.float32, "x"), C.c_int64(x.shape[0]), C.c_int64(x.stride(0)),
                                   C.c_int64(batch_rows), _dev(loss_out, torch.float64, "loss_out"), _stream())
     _check(rc, "mke_ae_train_steps")
+
+
+AE_ENC, AE_DEC, AE_BWD, AE_UPD, AE_ALL = 1, 2, 4, 8, 15
+
+
+def ae_step_phases(plan: AEPlanStruct, x, rows: int, ldx: int, global_rows: int, phases: int, loss_out: torch.Tensor):
+    """mke_ae_step_phases: one batch of the auto-encoder cut at its batch-wide sums (x: float32 [rows, ldx] CUDA or None)."""
+    rc = lib().mke_ae_step_phases(C.byref(plan), (_dev(x, torch.float32, "x") if rows else None), C.c_int64(rows), C.c_int64(ldx),
+                                  C.c_int64(global_rows), C.c_int(phases), _dev(loss_out, torch.float64, "loss_out"), _stream())
+    _check(rc, "mke_ae_step_phases")
 
 
 def ae_encode(plan: AEPlanStruct, x: torch.Tensor, out: torch.Tensor):

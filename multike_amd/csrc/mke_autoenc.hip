@@ -81,35 +81,22 @@ extern "C" int64_t mke_ae_scratch_floats(const mke_ae_plan* pl, int64_t rows) {
   return rows * per_row * 4 + 64;
 }
 
-extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t n_rows, int64_t ldx, int64_t batch_rows,
-                                  double* loss_out, void* stream) {
-  using namespace mke;
-  if (!pl) { set_error("mke_ae_train_steps: NULL plan"); return MKE_E_NULL; }
+namespace mke {
+// One batch, the phases selected by the bit mask (MKE_AE_ALL = the whole step).  m_global: rows of the GLOBAL batch (the loss is
+// a mean over it; the ranks of a data-parallel run each hold M of them).
+static int ae_batch(const mke_ae_plan* pl, const float* X, int M, int64_t ldx, int64_t m_global, int phases, double* loss_out,
+                    hipStream_t st) {
   const int n = pl->n_layers;
-  if (n < 1 || n > MKE_AE_MAX_LAYERS) { set_error("mke_ae_train_steps: n_layers must be in [1,%d]", MKE_AE_MAX_LAYERS); return MKE_E_SHAPE; }
-  for (int i = 0; i <= n; ++i)
-    if (pl->dims[i] < 1) { set_error("mke_ae_train_steps: bad layer width"); return MKE_E_SHAPE; }
-  if (n_rows < 0 || batch_rows < 1 || ldx < pl->dims[0]) { set_error("mke_ae_train_steps: bad row counts / ldx"); return MKE_E_SHAPE; }
-  if (pl->act != MKE_ACT_NONE && pl->act != MKE_ACT_TANH && pl->act != MKE_ACT_SIGMOID) { set_error("unknown activation %d", pl->act); return MKE_E_UNSUPPORTED; }
-  if (pl->optimizer != MKE_OPT_ADAGRAD && pl->optimizer != MKE_OPT_SGD) { set_error("mke_ae_train_steps: Adagrad or SGD (update = 0 leaves the gradients to the caller)"); return MKE_E_UNSUPPORTED; }
-  if (n_rows == 0) return MKE_OK;
-  if (!x || !pl->params || !pl->grads || !pl->scratch || !pl->partials || !pl->scalars || !loss_out) { set_error("mke_ae_train_steps: NULL pointer"); return MKE_E_NULL; }
-  if (pl->update && pl->optimizer == MKE_OPT_ADAGRAD && !pl->acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
-  if (pl->scratch_floats < mke_ae_scratch_floats(pl, batch_rows < n_rows ? batch_rows : n_rows)) { set_error("mke_ae_train_steps: scratch too small"); return MKE_E_SHAPE; }
-  hipStream_t st = (hipStream_t)stream;
   const int* d = pl->dims;
   const int act = pl->act;
   double* P_ssq = pl->partials;
   double* P_dot = pl->partials + MKE_LOSS_PARTIALS;
   double* P_loss = pl->partials + 2 * MKE_LOSS_PARTIALS;
   float* scal = pl->scalars;
+  void* stream = (void*)st;
   int rc = MKE_OK;
 #define AE_RUN(x) do { rc = (x); if (rc) return rc; } while (0)
-
-  int64_t batch_i = 0;
-  for (int64_t r0 = 0; r0 < n_rows; r0 += batch_rows, ++batch_i) {
-    const int M = (int)((n_rows - r0) < batch_rows ? (n_rows - r0) : batch_rows);
-    const float* X = x + r0 * ldx;
+  {
     // ---- scratch carve-up (leading dimensions padded to 4 floats = 16 bytes) ----
     float* sp = pl->scratch;
     auto take = [&](int width) { float* q = sp; sp += (int64_t)M * pad4(width); return q; };
@@ -128,6 +115,7 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
     auto ldD = [&](int j) { return pad4(d[n - j]); };
 
     // ---- forward: encoder ----
+    if (phases & MKE_AE_ENC)
     for (int i = 0; i < n; ++i) {
       GemmEpilogue e;
       e.bias = pl->params + pl->b_off[i];
@@ -135,6 +123,7 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
       if (i == n - 1 && pl->normalize) e.sumsq = P_ssq;
       AE_RUN(launch_gemm_f32_ex(H[i], ldH(i), 1, pl->params + pl->w_off[i], pad4(d[i + 1]), 1, H[i + 1], ldH(i + 1), M, d[i + 1], d[i], 1, 0, st, &e));
     }
+    if (phases & MKE_AE_DEC) {
     if (pl->normalize) hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_ssq, scal, 0, 1.0, (double*)nullptr);   // scal[0] = 1 / ||code||
     // ---- forward: decoder (layer j maps width d[n-j] -> d[n-j-1]) ----
     for (int j = 0; j < n; ++j) {
@@ -143,14 +132,14 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
       e.act = act;
       if (j == 0 && pl->normalize) e.alpha = scal;
       if (j == n - 1) {  // loss tail: D[n] = d loss / d pre-activation of the output layer; its column sums = the output bias gradient
-        e.target = X; e.ld_target = ldx; e.target_scale = 2.0f / ((float)M * (float)d[0]);
+        e.target = X; e.ld_target = ldx; e.target_scale = 2.0f / ((float)m_global * (float)d[0]);
         e.sumsq = P_loss;
         e.colsum = pl->grads + pl->b_off[n + j];
       }
       AE_RUN(launch_gemm_f32_ex(D[j], j == 0 ? ldH(n) : ldD(j), 1, pl->params + pl->w_off[n + j], pad4(d[n - j - 1]), 1, D[j + 1], ldD(j + 1), M,
                                 d[n - j - 1], d[n - j], 1, 0, st, &e));
     }
-    hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_loss, scal, 2, (double)M * (double)d[0], loss_out + batch_i);
+    hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_loss, scal, 2, (double)m_global * (double)d[0], loss_out);
 
     // ---- backward: decoder.  dZ of layer j is `dz` (width d[n-j-1]); its input is D[j] (times inv for j = 0) ----
     const float* dz = D[n];
@@ -178,11 +167,16 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
         AE_RUN(launch_gemm_f32_ex(dz, ld_dz, 1, Win, 1, pad4(dout), dcn, pad4(din), M, din, dout, 1, 0, st, &e));
       }
     }
+    }   // MKE_AE_DEC
+    if (phases & MKE_AE_BWD) {
     if (pl->normalize) hipLaunchKernelGGL(k_ae_scalar, dim3(1), dim3(MKE_BLOCK), 0, st, P_dot, scal, 1, 1.0, (double*)nullptr);
-    hipLaunchKernelGGL(k_ae_norm_bwd, dim3((M + 15) / 16), dim3(MKE_BLOCK), 0, st, dcn, H[n], dzc, pad4(d[n]), M, d[n], act, pl->normalize,
-                       scal, pl->grads + pl->b_off[n - 1]);
+    if (M > 0)
+      hipLaunchKernelGGL(k_ae_norm_bwd, dim3((M + 15) / 16), dim3(MKE_BLOCK), 0, st, dcn, H[n], dzc, pad4(d[n]), M, d[n], act, pl->normalize,
+                         scal, pl->grads + pl->b_off[n - 1]);
     // ---- backward: encoder ----
-    dz = dzc; ld_dz = pad4(d[n]);
+    const float* dz = dzc;
+    int64_t ld_dz = pad4(d[n]);
+    int gsel = 0;
     for (int i = n - 1; i >= 0; --i) {
       const int din = d[i], dout = d[i + 1];
       AE_RUN(launch_gemm_f32_ex(H[i], 1, ldH(i), dz, ld_dz, 1, pl->grads + pl->w_off[i], pad4(dout), din, dout, M, 0, 1, st, nullptr));
@@ -196,15 +190,60 @@ extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t
         dz = out; ld_dz = pad4(din);
       }
     }
+    }   // MKE_AE_BWD
     if ((rc = check_launch("mke_ae_train_steps"))) return rc;
-    if (pl->update) AE_RUN(mke_dense_update(pl->params, pl->optimizer == MKE_OPT_ADAGRAD ? pl->acc : nullptr, pl->grads, pl->n_params,
+    if ((phases & MKE_AE_UPD) && pl->update) AE_RUN(mke_dense_update(pl->params, pl->optimizer == MKE_OPT_ADAGRAD ? pl->acc : nullptr, pl->grads, pl->n_params,
                                             pl->optimizer, pl->lr, stream));
   }
 #undef AE_RUN
   return MKE_OK;
 }
 
-// Forward of the encoder only (code/literal_encoder.py:114-144: the final encoding; no normalisation of input or output).
+static int ae_check(const mke_ae_plan* pl, const char* who) {
+  if (!pl) { set_error("%s: NULL plan", who); return MKE_E_NULL; }
+  const int n = pl->n_layers;
+  if (n < 1 || n > MKE_AE_MAX_LAYERS) { set_error("%s: n_layers must be in [1,%d]", who, MKE_AE_MAX_LAYERS); return MKE_E_SHAPE; }
+  for (int i = 0; i <= n; ++i)
+    if (pl->dims[i] < 1) { set_error("%s: bad layer width", who); return MKE_E_SHAPE; }
+  if (pl->act != MKE_ACT_NONE && pl->act != MKE_ACT_TANH && pl->act != MKE_ACT_SIGMOID) { set_error("unknown activation %d", pl->act); return MKE_E_UNSUPPORTED; }
+  if (pl->optimizer != MKE_OPT_ADAGRAD && pl->optimizer != MKE_OPT_SGD) { set_error("%s: Adagrad or SGD (update = 0 leaves the gradients to the caller)", who); return MKE_E_UNSUPPORTED; }
+  if (!pl->params || !pl->grads || !pl->scratch || !pl->partials || !pl->scalars) { set_error("%s: NULL pointer", who); return MKE_E_NULL; }
+  if (pl->update && pl->optimizer == MKE_OPT_ADAGRAD && !pl->acc) { set_error("Adagrad needs an accumulator"); return MKE_E_NULL; }
+  return MKE_OK;
+}
+}  // namespace mke
+
+extern "C" int mke_ae_train_steps(const mke_ae_plan* pl, const float* x, int64_t n_rows, int64_t ldx, int64_t batch_rows,
+                                  double* loss_out, void* stream) {
+  using namespace mke;
+  int rc = ae_check(pl, "mke_ae_train_steps");
+  if (rc) return rc;
+  if (n_rows < 0 || batch_rows < 1 || ldx < pl->dims[0]) { set_error("mke_ae_train_steps: bad row counts / ldx"); return MKE_E_SHAPE; }
+  if (n_rows == 0) return MKE_OK;
+  if (!x || !loss_out) { set_error("mke_ae_train_steps: NULL pointer"); return MKE_E_NULL; }
+  if (pl->scratch_floats < mke_ae_scratch_floats(pl, batch_rows < n_rows ? batch_rows : n_rows)) { set_error("mke_ae_train_steps: scratch too small"); return MKE_E_SHAPE; }
+  int64_t batch_i = 0;
+  for (int64_t r0 = 0; r0 < n_rows; r0 += batch_rows, ++batch_i) {
+    const int M = (int)((n_rows - r0) < batch_rows ? (n_rows - r0) : batch_rows);
+    if ((rc = ae_batch(pl, x + r0 * ldx, M, ldx, M, MKE_AE_ALL, loss_out + batch_i, (hipStream_t)stream))) return rc;
+  }
+  return MKE_OK;
+}
+
+// One batch cut at its batch-wide sums, for data-parallel training (every rank holds the replicated parameters and `rows` of the
+// `global_rows` of the batch): see include/multike_hip.h.
+extern "C" int mke_ae_step_phases(const mke_ae_plan* pl, const float* x, int64_t rows, int64_t ldx, int64_t global_rows, int phases,
+                                  double* loss_out, void* stream) {
+  using namespace mke;
+  int rc = ae_check(pl, "mke_ae_step_phases");
+  if (rc) return rc;
+  if (phases <= 0 || phases > MKE_AE_ALL) { set_error("mke_ae_step_phases: bad phase mask"); return MKE_E_SHAPE; }
+  if (rows < 0 || global_rows < rows || global_rows < 1 || rows > 0x7FFFFFFF || ldx < pl->dims[0]) { set_error("mke_ae_step_phases: bad row counts / ldx"); return MKE_E_SHAPE; }
+  if ((rows > 0 && !x) || !loss_out) { set_error("mke_ae_step_phases: NULL pointer"); return MKE_E_NULL; }
+  if (pl->scratch_floats < mke_ae_scratch_floats(pl, rows)) { set_error("mke_ae_step_phases: scratch too small"); return MKE_E_SHAPE; }
+  return ae_batch(pl, x, (int)rows, ldx, global_rows, phases, loss_out, (hipStream_t)stream);
+}
+
 extern "C" int mke_ae_encode(const mke_ae_plan* pl, const float* x, int64_t n_rows, int64_t ldx, float* out, int64_t ld_out,
                              void* stream) {
   using namespace mke;

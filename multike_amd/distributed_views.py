@@ -22,6 +22,12 @@ replicated.  Two consequences:
   and are added after that reduction, identically on every rank (`ShardedSpaceMapping`; native phases:
   `mke_mapping_step_phases`).
 
+* **Literal auto-encoder** (code/literal_encoder.py:41-112): plain data parallelism over the rows of a batch (rank r takes
+  rows r, r + world, ...), parameters replicated.  The code matrix of a batch is normalised as a WHOLE (:65-66): sum code^2
+  in the forward and sum dcn . code in its backward — one scalar all-reduce each — then the all-reduce of the packed
+  gradient buffer (4.3 M floats at 1500-1024-512-75) and the identical update on every rank (`ShardedAutoEncoder`; native
+  phases: `mke_ae_step_phases`).
+
 Compute goes through a backend object (HIP kernels in production; tests inject a NumPy backend built on the oracle to run
 this logic under gloo with world_size 2).
 """
@@ -368,3 +374,98 @@ class ShardedSpaceMapping:
         for r in range(self.world):
             full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].numpy()
         return full, M
+
+
+# ======================================================================================================================
+# Literal auto-encoder
+# ======================================================================================================================
+class HipAutoEncoderBackend:
+    device_type = "cuda"
+
+    def __init__(self, view: "ShardedAutoEncoder", params: dict):
+        from types import SimpleNamespace
+        from .literal_encoder import AutoEncoderModel
+        args = SimpleNamespace(dim=view.dims[-1], encoder_normalize=view.normalize, encoder_active=view.active,
+                               optimizer="Adagrad", learning_rate=view.lr)
+        self.model = AutoEncoderModel(np.zeros((0, view.dims[0]), dtype=np.float32), args, input_dimension=view.dims[0],
+                                      hidden_dimensions=list(view.dims[1:]), seed=0)
+        self.model.set_params(params)
+        self.loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self._one = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self._x, self._mg = None, 0
+
+    def _block(self, k):
+        LP = _lib.LOSS_PARTIALS
+        return self.model._partials[k * LP:(k + 1) * LP]
+
+    def _run(self, phases):
+        m, p = self.model, self.model._plan
+        p.optimizer, p.update, p.lr = _lib.OPT_ADAGRAD, 1, float(m.args.learning_rate)
+        rows = 0 if self._x is None else self._x.shape[0]
+        _lib.ae_step_phases(p, self._x if rows else None, rows, (self._x.stride(0) if rows else m.input_dimension), self._mg,
+                            phases, self._one)
+
+    def encode(self, view, x_rows, m_global):
+        self._x = torch.as_tensor(np.ascontiguousarray(x_rows, dtype=np.float32), device="cuda") if len(x_rows) else None
+        self._mg = int(m_global)
+        self.model._ensure_scratch(max(1, len(x_rows)))
+        self._run(_lib.AE_ENC)
+        return self._block(0).sum().reshape(1)
+
+    def decode(self, view, S):
+        b = self._block(0)
+        b.zero_()
+        b[0] = S[0]
+        self._run(_lib.AE_DEC)
+        self.loss += self._one
+        return self._block(1).sum().reshape(1)
+
+    def backward(self, view, T):
+        b = self._block(1)
+        b.zero_()
+        b[0] = T[0]
+        self._run(_lib.AE_BWD)
+        return self.model.grads
+
+    def update(self, view):
+        self._run(_lib.AE_UPD)
+
+    def take_loss(self):
+        v = self.loss.clone()
+        self.loss.zero_()
+        return v
+
+    def params(self) -> dict:
+        return {k: v.astype(np.float64) for k, v in self.model.numpy_params().items()}
+
+
+class ShardedAutoEncoder:
+    def __init__(self, params: dict, dims, rank: int, world: int, lr: float = 0.01, active: str = "thah", normalize: bool = True,
+                 backend_cls=None, comm=None):
+        """params: {encoder_h0, encoder_b0, ..., decoder_h0, ...} (replicated; code/literal_encoder.py:41-61); dims: input width,
+        hidden widths, code width."""
+        self.rank, self.world, self.lr = rank, world, float(lr)
+        self.dims, self.active, self.normalize = [int(v) for v in dims], active, bool(normalize)
+        self.comm = comm or ViewComm()
+        self.backend = (backend_cls or HipAutoEncoderBackend)(self, params)
+
+    def step(self, x):
+        """One `session.run([loss, optimizer])` (code/literal_encoder.py:63-69, 98-107) on the GLOBAL batch x [M, dims[0]]
+        (identical on every rank): this rank trains rows rank, rank + world, ..."""
+        be, cm = self.backend, self.comm
+        x = np.asarray(x)
+        S = be.encode(self, x[self.rank::self.world], x.shape[0])
+        cm.all_reduce(S)                                   # sum code^2 over the whole batch (:65-66)
+        T = be.decode(self, S)
+        cm.all_reduce(T)                                   # sum dcn . code over the whole batch (its backward)
+        cm.all_reduce(be.backward(self, T))                # the packed gradient of the replicated parameters
+        be.update(self)
+
+    def epoch_loss(self) -> float:
+        """Sum over the steps of mean((decoded - x)^2)."""
+        t = self.backend.take_loss()
+        self.comm.all_reduce(t)
+        return float(t)
+
+    def params(self) -> dict:
+        return self.backend.params()

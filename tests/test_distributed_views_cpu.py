@@ -188,3 +188,64 @@ def test_sharded_space_mapping_equals_single_process_oracle(world):
     np.testing.assert_allclose(loss, tot, rtol=1e-11)
     np.testing.assert_allclose(full, ent, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(M, np.stack(mats), rtol=1e-9, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# literal auto-encoder
+# ----------------------------------------------------------------------------------------------------------------------
+AE_DIMS, AE_STEPS = [24, 16, 8, 5], 3
+
+
+def _ae_data(active):
+    from oracle import literal_oracle as lo
+    rng = np.random.default_rng(17)
+    p = lo.init_params(AE_DIMS, rng)
+    p = {k: 0.3 * v for k, v in p.items()}
+    # batches: ragged, and one smaller than the world (a rank without rows still takes part in the reductions)
+    batches = [rng.standard_normal((m, AE_DIMS[0])) for m in (37, 2, 20)][:AE_STEPS]
+    return p, batches
+
+
+def _ae_worker(rank, world, port, active, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import ShardedAutoEncoder
+        from oracle_backend import OracleAutoEncoderBackend
+        p, batches = _ae_data(active)
+        v = ShardedAutoEncoder(p, AE_DIMS, rank, world, lr=0.05, active=active, normalize=True, backend_cls=OracleAutoEncoderBackend)
+        for x in batches:
+            v.step(x)
+        loss = v.epoch_loss()
+        if rank == 0:
+            ret.put((v.params(), loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,active", [(2, "thah"), (3, "tanh")])
+def test_sharded_auto_encoder_equals_single_process_oracle(world, active):
+    """Literal auto-encoder, data parallel over the rows of a batch (code/literal_encoder.py:63-69): the two batch-wide sums of
+    the whole-matrix l2_normalize of the code (:65-66) and the packed parameter gradient are all-reduced."""
+    from oracle import literal_oracle as lo
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ae_worker, args=(r, world, port, active, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, loss = ret.get(timeout=240)
+    for q in procs:
+        q.join(60)
+        assert q.exitcode == 0
+    p, batches = _ae_data(active)
+    acc = {k: np.full_like(v, 0.1) for k, v in p.items()}
+    tot = 0.0
+    for x in batches:
+        L, g = lo.loss_and_grads(p, x, len(AE_DIMS) - 1, active, True)
+        lo.adagrad_step(p, acc, g, 0.05)
+        tot += L
+    np.testing.assert_allclose(loss, tot, rtol=1e-11)
+    for k in p:
+        np.testing.assert_allclose(got[k], p[k], rtol=1e-9, atol=1e-12, err_msg=k)

@@ -197,3 +197,87 @@ def test_one_rank_space_mapping_phases_equal_the_single_call():
     np.testing.assert_allclose(loss, tot, rtol=2e-5)
     np.testing.assert_allclose(full, e64, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(M, m64, rtol=2e-4, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# literal auto-encoder (mke_ae_step_phases)
+# ----------------------------------------------------------------------------------------------------------------------
+AE_DIMS, AE_LR = [150, 96, 40, 20], 0.01
+
+
+def _ae_data():
+    from oracle import literal_oracle as lo
+    rng = np.random.default_rng(23)
+    p = {k: 0.2 * v for k, v in lo.init_params(AE_DIMS, rng).items()}
+    batches = [rng.standard_normal((m, AE_DIMS[0])).astype(np.float32) for m in (300, 1, 129)]   # the 1-row batch: rank 1 has none
+    return p, batches
+
+
+def _ae_reference(active):
+    from oracle import literal_oracle as lo
+    p, batches = _ae_data()
+    acc = {k: np.full_like(v, 0.1) for k, v in p.items()}
+    tot = 0.0
+    for x in batches:
+        L, g = lo.loss_and_grads(p, x.astype(np.float64), len(AE_DIMS) - 1, active, True)
+        lo.adagrad_step(p, acc, g, AE_LR)
+        tot += L
+    return p, tot
+
+
+def _ae_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import HostStagedViewComm, ShardedAutoEncoder
+        torch.cuda.set_device(0)
+        p, batches = _ae_data()
+        v = ShardedAutoEncoder(p, AE_DIMS, rank, world, lr=AE_LR, active="tanh", normalize=True, comm=HostStagedViewComm())
+        for x in batches:
+            v.step(x)
+        loss = v.epoch_loss()
+        m = v.backend.model
+        ok = float(m.grads.abs().max()) == 0.0 and float(m._partials.abs().max()) == 0.0
+        if rank == 0:
+            ret.put((v.params(), loss, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_auto_encoder_equals_dense_oracle():
+    """mke_ae_step_phases on two ranks sharing the GPU (rows r, r + 2, ... of every batch each): the two batch-wide sums of the
+    whole-matrix normalisation of the code and the packed gradient travel through the (host-staged) all-reduces; a batch in
+    which rank 1 has no row."""
+    got, loss, ok = _run(_ae_worker)
+    p64, tot = _ae_reference("tanh")
+    assert ok
+    np.testing.assert_allclose(loss, tot, rtol=2e-5)
+    for k in p64:
+        np.testing.assert_allclose(got[k], p64[k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("active", ["thah", "tanh"])
+def test_one_rank_auto_encoder_phases_equal_the_single_call(active):
+    """The phased step at world 1 against mke_ae_train_steps on the same batches and against the float64 oracle."""
+    from types import SimpleNamespace
+    from multike_amd.distributed_views import ShardedAutoEncoder
+    from multike_amd.literal_encoder import AutoEncoderModel
+    p, batches = _ae_data()
+    v = ShardedAutoEncoder(p, AE_DIMS, 0, 1, lr=AE_LR, active=active, normalize=True)
+    for x in batches:
+        v.step(x)
+    loss = v.epoch_loss()
+    args = SimpleNamespace(dim=AE_DIMS[-1], encoder_normalize=True, encoder_active=active, optimizer="Adagrad", learning_rate=AE_LR)
+    m = AutoEncoderModel(np.zeros((0, AE_DIMS[0]), dtype=np.float32), args, input_dimension=AE_DIMS[0], hidden_dimensions=AE_DIMS[1:], seed=0)
+    m.set_params(p)
+    tot1 = sum(float(m.train_step(torch.as_tensor(x, device="cuda"))) for x in batches)
+    got, ref1 = v.params(), m.numpy_params()
+    for k in got:   # same kernels in the same order; the split-K products and the bias column sums add atomically
+        np.testing.assert_allclose(got[k], ref1[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(loss, tot1, rtol=1e-6)
+    p64, tot = _ae_reference(active)
+    np.testing.assert_allclose(loss, tot, rtol=2e-5)
+    for k in p64:
+        np.testing.assert_allclose(got[k], p64[k], rtol=2e-4, atol=2e-6, err_msg=k)
