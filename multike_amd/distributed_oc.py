@@ -276,8 +276,8 @@ class OwnerComputesTrainer:
         self.dim = ent0.shape[1]
         self.stride = _lib.stride_for(self.dim)
         self.N = int(neg_per_pos)
-        if not 0 < self.N <= 64:
-            raise _lib.MultiKEHipError("the sharded relation view needs 1..64 negatives per positive")
+        if not 0 <= self.N <= 64:   # 0: positives only (the shape of the cross-KG inference loops, code/MultiKE_model.py:349-369)
+            raise _lib.MultiKEHipError("the sharded relation view takes 0..64 negatives per positive")
         self.n_ent = ent0.shape[0]
         self.batch_size = int(batch_size)
         self.chunks = max(1, int(chunks))
@@ -372,7 +372,7 @@ class OwnerComputesTrainer:
         n_all, parts, part_id = self._n_all, self._parts, self._part_id
         plan = {"bs": bs}
         codes = self._persist(("codes", bs), torch.zeros(0, **i32), max(1, n_all * N))
-        if n_all:
+        if n_all and N:
             neg = tuple(torch.empty(n_all * N, **i32) for _ in range(3))
             self.backend.sample_at((ph[:n_all], pr[:n_all], pt[:n_all]), self._all_idx, b.pos_kg[:n_all], b.side1, b.side2, N,
                                    b.rng_seed, rng_stream, neg)

@@ -60,7 +60,8 @@ def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg
 
 
 @pytest.mark.parametrize("chunks,excl,dim,neg", [(1, True, 75, 8), (2, True, 75, 25), (1, False, 75, 8), (1, True, 256, 64),
-                                                  (3, True, 20, 1)])
+                                                  (3, True, 20, 1),
+                                                  (1, True, 75, 0)])   # positives only: the shape of the cross-KG loops
 def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg):
     """G = 1: every vector / code / gradient slot is local; the kernels alone against the float64 dense oracle over the
     first epoch's steps (the oracle's CPU batcher and the device batcher draw different permutations at the epoch
@@ -116,14 +117,14 @@ def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), R.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False):
+def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
-        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer)
+        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer, neg=neg)
         for i in range(steps):
             tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
@@ -136,8 +137,8 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks,peer", [(1, False), (2, False), (1, True)])
-def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer):
+@pytest.mark.parametrize("chunks,peer,neg", [(1, False, NEG), (2, False, NEG), (1, True, NEG), (1, False, 0)])   # neg 0: positives only
+def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg):
     """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
     negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
     import torch.multiprocessing as mp
@@ -148,14 +149,14 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer):
     ret = ctx.Queue()
     # peer = True: no all-gather / reduce-scatter — each process maps the other's send block and gradient inbox (IPC) and the
     # score kernel reads / writes them directly
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer, neg)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, ok = ret.get(timeout=480)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    e, r, losses, spe = _reference(world, steps)
+    e, r, losses, spe = _reference(world, steps, neg=neg)
     assert steps <= spe and ok
     np.testing.assert_allclose(loss, sum(losses), rtol=2e-6)
     np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
