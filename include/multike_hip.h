@@ -768,6 +768,7 @@ typedef struct mke_oc_step {
    * the n_ranks slices of its own inbox in rank order.  The caller places a cross-GPU barrier after mke_oc_bases and after
    * mke_oc_score. */
   int n_peers; const float* peer_v[MKE_OC_MAX_RANKS]; float* peer_g[MKE_OC_MAX_RANKS];
+  const float* pos_w;   /* nullable: [n_pos] weights of the positives (the weighted cross-KG loops, code/losses.py:44-50) */
 } mke_oc_step;
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output */

@@ -98,7 +98,7 @@ class OcStepStruct(C.Structure):
                 ("own_t", C.c_void_p), ("n_own_t", C.c_int64), ("neg_per_pos", C.c_int), ("capacity", C.c_int64),
                 ("codes", C.c_void_p), ("code_off", C.c_int64 * 16),
                 ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32),
-                ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16)]
+                ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16), ("pos_w", C.c_void_p)]
 
 
 class AEPlanStruct(C.Structure):

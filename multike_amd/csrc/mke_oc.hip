@@ -146,8 +146,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         x = fmaf(d[k], d[k], x);
       }
       x = sub16_sum(x);
-      loss += softplus_f(x);
-      const float c = 2.0f * s.scale * sigmoid_f(x);
+      const float pw = s.pos_w ? s.pos_w[i] : 1.0f;   // weighted positives: code/losses.py:44-50
+      loss += pw * softplus_f(x);
+      const float c = 2.0f * s.scale * pw * sigmoid_f(x);
 #pragma unroll
       for (int k = 0; k < FPL; ++k) {
         d[k] *= c;

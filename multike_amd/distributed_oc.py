@@ -62,6 +62,7 @@ class OcStep:
     codes: torch.Tensor = None      # the epoch's negative codes of every rank, [world][codes_per_rank]
     code_off: tuple = ()            # per home rank: offset of its codes of this part inside `codes`
     native: object = None           # backend-private cache (the ctypes mke_oc_step of the HIP backend)
+    pos_w: torch.Tensor = None      # per-positive weights of the part (weighted cross-KG loops), or None
 
 
 class OcHipBackend:
@@ -101,7 +102,8 @@ class OcHipBackend:
         s.codes = _lib.ptr(st.codes, i32, "codes")
         for g, o in enumerate(st.code_off):
             s.code_off[g] = int(o)
-        s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, 1.0, st.tag
+        s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, tr.scale, st.tag
+        s.pos_w = _lib.ptr(st.pos_w, f32, "pos_w") if st.pos_w is not None else None
         s.n_peers = 0
         if tr.peer_direct and tr.world > 1:   # peer-mapped blocks (chunk 0: peer-direct runs unchunked)
             gb = 2 * tr.C * tr.stride * 4
@@ -138,12 +140,15 @@ class OcHipBackend:
             base = self._struct(tr, tr._build_part_step(0, 0))
             ph, pr, pt = (_lib.ptr(x, i32, "pos") for x in (b.pos_h, b.pos_r, b.pos_t))
             sh, stt = _lib.ptr(tr._slot[0], i32, "slot"), _lib.ptr(tr._slot[1], i32, "slot")
+            pw = getattr(b, "pos_w", None)
+            pw = _lib.ptr(pw, torch.float32, "pos_w") if pw is not None else None
             out = []
             for k, (_, lo, hi) in enumerate(tr._parts):
                 s = _lib.OcStepStruct()
                 C.memmove(C.byref(s), C.byref(base), C.sizeof(s))
                 s.pos_h, s.pos_r, s.pos_t = ph + 4 * lo, pr + 4 * lo, pt + 4 * lo
                 s.slot_h, s.slot_t = sh + 4 * lo, stt + 4 * lo
+                s.pos_w = (pw + 4 * lo) if pw is not None else None
                 s.n_pos = hi - lo
                 s.per = max(1, -(-(hi - lo) // tr.world))
                 for g in range(tr.world):
@@ -263,10 +268,86 @@ class OcHostStagedComm(OcGlooComm):
         dist.barrier(group=self.group)
 
 
+class TripleListBatcher:
+    """Epoch source of the owner-computes trainer for the cross-KG inference loops (code/MultiKE_model.py:349-369, 393-414):
+    `steps = ceil(len / B)` steps per epoch, each `random.sample(triples, B)` (B = len when there is one step) — distinct
+    inside a step, steps independent.  Positives only (no negative sampler: `neg_per_pos` must be 0).  The draws are a
+    function of (seed, epoch) alone, so every rank lays out the same epoch without exchanging a byte: on the GPU through
+    `mke_sample_distinct` (the sampler of the single-GPU loops, multike_amd/MultiKE_model.py `_positives_epoch`), on the CPU
+    (gloo tests) through NumPy's generator."""
+
+    def __init__(self, triples, batch_size: int, device="cuda", seed: int = 0):
+        arr = np.ascontiguousarray(np.asarray([t[:3] for t in triples], dtype=np.int32).reshape(-1, 3))
+        self.device, self.seed, self.n = torch.device(device), int(seed), int(arr.shape[0])
+        self.cols = tuple(torch.as_tensor(np.ascontiguousarray(arr[:, k]), device=self.device) for k in range(3))
+        # 4-tuples (h, r, t, w): the weighted loops (code/MultiKE_model.py:393-414); drawn with their triples
+        self.w_all = (torch.as_tensor(np.asarray([t[3] for t in triples], dtype=np.float32), device=self.device)
+                      if self.n and len(triples[0]) > 3 else None)
+        self.steps = int(math.ceil(self.n / batch_size)) if self.n else 0
+        self.bs = int(batch_size) if self.steps > 1 else self.n
+        self.off = np.arange(self.steps + 1, dtype=np.int64) * self.bs
+        self.epoch, self._alt = 0, None
+        self.pos_kg = self.side1 = self.side2 = None           # no negatives: nothing the sampler would need
+        (self.pos_h, self.pos_r, self.pos_t), self.pos_w = self._draw(0)
+
+    def _draw(self, epoch: int):
+        """((h, r, t), w or None) of every step of `epoch`, in step order."""
+        total = self.steps * self.bs
+        if total == 0:
+            z = torch.zeros(1, dtype=torch.int32, device=self.device)
+            return (z, z.clone(), z.clone()), None
+        if self.device.type == "cuda":
+            idx = _lib.sample_distinct(self.n, self.bs, self.steps, (self.seed & 0xFFFFFFFF, 0x434B47), epoch + 1,
+                                       device=self.device).reshape(-1).long()
+        else:
+            rng = np.random.default_rng([self.seed, epoch])
+            idx = torch.as_tensor(np.concatenate([rng.choice(self.n, self.bs, replace=False) for _ in range(self.steps)]))
+        return tuple(c[idx].contiguous() for c in self.cols), (self.w_all[idx].contiguous() if self.w_all is not None else None)
+
+    def shuffle(self):
+        """The next epoch's draws, into the SAME buffers (native step descriptors point into them)."""
+        self.epoch += 1
+        cols, w = self._draw(self.epoch)
+        for dst, src in zip((self.pos_h, self.pos_r, self.pos_t), cols):
+            dst.copy_(src)
+        if w is not None:
+            self.pos_w.copy_(w)
+
+    def stage_next_epoch(self):
+        new, self._w_next = self._draw(self.epoch + 1)
+        if self._alt is None:
+            self._alt = new
+        else:
+            for dst, src in zip(self._alt, new):
+                dst.copy_(src)
+        return self._alt
+
+    def commit_staged(self):
+        cur = (self.pos_h, self.pos_r, self.pos_t)
+        self.pos_h, self.pos_r, self.pos_t = self._alt
+        self._alt = cur
+        if self.pos_w is not None:
+            self.pos_w.copy_(self._w_next)   # one weight buffer: the staged epoch's weights arrive with the swap
+        self.epoch += 1
+
+    @property
+    def rng_seed(self):
+        return (self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+
+    @property
+    def rng_stream(self):
+        return (self.epoch * 2) & 0xFFFFFFFF
+
+
 class OwnerComputesTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
-                 exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True):
+                 exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
+                 batcher=None, scale: float = 1.0):
+        """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
+        loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
+        with); scale: the loss factor (2 for code/MultiKE_model.py:349-369)."""
+        self.scale = float(scale)
         self.backend = backend or OcHipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         if comm is None:
@@ -306,13 +387,18 @@ class OwnerComputesTrainer:
         self.rel_grad = torch.zeros_like(self.rel)
         self.rel_touched = torch.zeros(rel0.shape[0], **i32)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
-        sides = []
-        for k in (0, 1):
-            t = torch.as_tensor(np.asarray(kgs.triples[k], dtype=np.int32), device=dev)
-            known = self.backend.make_known(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
-            sides.append(KGSide(kgs.entities(k), known, device=dev))
-        self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
-                                   device=dev, seed=seed)
+        if batcher is not None:
+            if self.N != 0:
+                raise _lib.MultiKEHipError("an explicit epoch source carries positives only: neg_per_pos must be 0")
+            self.bat = batcher
+        else:
+            sides = []
+            for k in (0, 1):
+                t = torch.as_tensor(np.asarray(kgs.triples[k], dtype=np.int32), device=dev)
+                known = self.backend.make_known(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
+                sides.append(KGSide(kgs.entities(k), known, device=dev))
+            self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
+                                       device=dev, seed=seed)
         self.steps = self.bat.steps
         self.tag = 0
         self.loss_ring = torch.zeros(max(1, self.steps) * self.chunks, _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
@@ -531,8 +617,10 @@ class OwnerComputesTrainer:
         per, _, _ = self.my_slice(lo, hi)
         oh, ot = self._own_off[0], self._own_off[1]
         code_off = tuple((lo + g * per) * self.N for g in range(self.world))   # codes are laid out by epoch position
+        pw = getattr(b, "pos_w", None)
         return OcStep(b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi], per, self._slot[0][lo:hi], self._slot[1][lo:hi],
-                      self._own[0][oh[k]:oh[k + 1]], self._own[1][ot[k]:ot[k + 1]], tag, self._codes, code_off)
+                      self._own[0][oh[k]:oh[k + 1]], self._own[1][ot[k]:ot[k + 1]], tag, self._codes, code_off,
+                      pos_w=(pw[lo:hi] if pw is not None else None))
 
     def step(self, i: int):
         """Global step i (steps must be issued in order)."""

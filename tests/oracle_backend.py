@@ -207,14 +207,16 @@ class OcOracleBackend(OracleBackend):
         sh, stt = st.slot_h.numpy(), st.slot_t.numpy()
         codes = self._codes_of(tr, st)
         loss = 0.0
+        sc = float(getattr(tr, "scale", 1.0))
         for i in range(len(ph)):
             HR, RT = V[ph[i] % G, sh[i], :d], V[pt[i] % G, C + stt[i], :d]
             gHR, gRT = np.zeros(d), np.zeros(d)
             if i // st.per == rank:
                 dv = HR + RT - self._nrm(rel[pr[i], :d])
                 x = float(dv @ dv)
-                loss += np.log1p(np.exp(x))
-                g = 2.0 / (1.0 + np.exp(-x)) * dv
+                pw = float(st.pos_w[i]) if st.pos_w is not None else 1.0
+                loss += pw * np.log1p(np.exp(x))
+                g = pw * sc * 2.0 / (1.0 + np.exp(-x)) * dv
                 gHR += g
                 gRT += g
                 rg[pr[i], :d] -= g
@@ -228,7 +230,7 @@ class OcOracleBackend(OracleBackend):
                 dv = ch + RT if head else HR - ch
                 y = float(dv @ dv)
                 loss += np.log1p(np.exp(-y))
-                g = -2.0 / (1.0 + np.exp(y)) * dv
+                g = sc * -2.0 / (1.0 + np.exp(y)) * dv
                 if head:
                     gRT += g
                 else:
@@ -246,7 +248,7 @@ class OcOracleBackend(OracleBackend):
             Gout[pt[i] % G, C + stt[i], :d] = gRT
         lp = loss_partials.numpy()
         lp[:] = 0
-        lp[0] = loss
+        lp[0] = loss * sc
 
     def apply(self, tr, st, gv):
         G, C, S, d = tr.world, tr.C, tr.stride, tr.dim

@@ -133,3 +133,85 @@ def test_parts_and_slices_partition_every_global_step():
                     assert c2 == hi
                     cur = hi
                 assert cur == t.bat.off[s + 1]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cross-KG inference loops: positives only, `random.sample` batches of a triple list, loss x 2
+# ----------------------------------------------------------------------------------------------------------------------
+CK_N_ENT, CK_TRIPLES, CK_B = 400, 333, 100      # 4 steps per epoch (the last draws like the others: B of 333)
+
+
+def _ck_setup():
+    rng = np.random.default_rng(SEED + 1)
+    triples = np.stack([rng.integers(0, CK_N_ENT, CK_TRIPLES), rng.integers(0, N_REL, CK_TRIPLES),
+                        rng.integers(0, CK_N_ENT, CK_TRIPLES)], 1).astype(np.int32)
+    ent0 = mo.xavier_truncated_normal((CK_N_ENT, DIM), rng).astype(np.float64)
+    rel0 = mo.xavier_truncated_normal((N_REL, DIM), rng).astype(np.float64)
+    return triples, ent0, rel0
+
+
+def _ck_list(triples, weighted):
+    """The model's list form: (h, r, t) or weighted 4-tuples (h, r, t, w) (code/MultiKE_model.py:393-414)."""
+    if not weighted:
+        return triples
+    w = np.random.default_rng(SEED + 2).uniform(0.2, 1.0, len(triples))
+    return [(int(h), int(r), int(t), float(x)) for (h, r, t), x in zip(triples, w)]
+
+
+def _ck_worker(rank, world, port, ret, steps, chunks, weighted=False):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OwnerComputesTrainer, TripleListBatcher
+        from oracle_backend import OcOracleBackend
+        triples, ent0, rel0 = _ck_setup()
+        bat = TripleListBatcher(_ck_list(triples, weighted), CK_B, device="cpu", seed=SEED)
+        tr = OwnerComputesTrainer(None, ent0, rel0, CK_B, 0, rank, world, seed=SEED, lr=0.05, backend=OcOracleBackend(), device="cpu",
+                                  dtype=torch.float64, chunks=chunks, batcher=bat, scale=2.0)
+        for i in range(steps):
+            tr.step(i)
+        full = tr.gather_entity_table().numpy()
+        assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+        loss = tr.epoch_loss()
+        if rank == 0:
+            ret.put((full, tr.rel[:, :DIM].numpy().copy(), loss, tr.steps))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,chunks,weighted", [(2, 1, False), (3, 2, False), (2, 1, True)])
+def test_cross_kg_positive_steps_equal_single_process_oracle(world, chunks, weighted):
+    """The owner-computes exchange on the cross-KG entity-inference loop (code/MultiKE_model.py:349-369): positives only,
+    every step a `random.sample` of the triple list (drawn identically on every rank), 2 x the loss; past the epoch boundary."""
+    from multike_amd.distributed_oc import TripleListBatcher
+    steps = 6
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ck_worker, args=(r, world, port, ret, steps, chunks, weighted)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss, spe = ret.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    triples, e, r = _ck_setup()
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = TripleListBatcher(_ck_list(triples, weighted), CK_B, device="cpu", seed=SEED)
+    assert spe == bat.steps == 4
+    losses = []
+    for i in range(steps):
+        s = i % bat.steps
+        if s == 0 and i > 0:
+            bat.shuffle()
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        pos = tuple(x.numpy()[lo:hi] for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        assert len(set(map(tuple, np.stack(pos, 1)))) <= hi - lo
+        pw = bat.pos_w.numpy()[lo:hi].astype(np.float64) if weighted else None
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, pos, None, 0.05, pos_w=pw, scale=2.0)
+        losses.append(L)
+    np.testing.assert_allclose(full, e, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rel, r, rtol=1e-9, atol=1e-12)
+    # the loss ring holds one slot per step of an epoch: steps 0 and 1 were overwritten by the second epoch's first two
+    np.testing.assert_allclose(loss, sum(losses[2:]), rtol=1e-11)

@@ -188,3 +188,107 @@ def test_one_rank_rccl_collectives_run():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cross-KG inference loops on the sharded tables: positives only, `random.sample` batches of a triple list, loss x 2
+# ----------------------------------------------------------------------------------------------------------------------
+CK_TRIPLES, CK_B = 1700, 600
+
+
+def _ck_setup():
+    rng = np.random.default_rng(SEED + 3)
+    triples = np.stack([rng.integers(0, N_ENT, CK_TRIPLES), rng.integers(0, N_REL, CK_TRIPLES), rng.integers(0, N_ENT, CK_TRIPLES)],
+                       1).astype(np.int32)
+    return triples, mo.xavier_truncated_normal((N_ENT, DIM), rng), mo.xavier_truncated_normal((N_REL, DIM), rng)
+
+
+def _ck_list(triples, weighted):
+    if not weighted:
+        return triples
+    w = np.random.default_rng(SEED + 4).uniform(0.2, 1.0, len(triples))
+    return [(int(h), int(r), int(t), float(x)) for (h, r, t), x in zip(triples, w)]
+
+
+def _ck_trainer(rank, world, comm=None, weighted=False):
+    from multike_amd.distributed_oc import OwnerComputesTrainer, TripleListBatcher
+    triples, ent0, rel0 = _ck_setup()
+    bat = TripleListBatcher(_ck_list(triples, weighted), CK_B, device="cuda", seed=SEED)
+    return OwnerComputesTrainer(None, ent0, rel0, CK_B, 0, rank, world, seed=SEED, lr=0.02, comm=comm, batcher=bat, scale=2.0)
+
+
+def _ck_reference(steps, weighted=False):
+    """Dense float64 oracle on the same draws (the batcher's draws are a function of (seed, epoch): built again here)."""
+    from multike_amd.distributed_oc import TripleListBatcher
+    triples, e, r = _ck_setup()
+    e, r = e.astype(np.float64), r.astype(np.float64)
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = TripleListBatcher(_ck_list(triples, weighted), CK_B, device="cuda", seed=SEED)
+    losses = []
+    for i in range(steps):
+        s = i % bat.steps
+        if s == 0 and i > 0:
+            bat.shuffle()
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        pos = tuple(x[lo:hi].cpu().numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        assert len({tuple(t) for t in np.stack(pos, 1)}) >= 1
+        pw = bat.pos_w[lo:hi].cpu().numpy().astype(np.float64) if weighted else None
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, pos, None, 0.02, pos_w=pw, scale=2.0)
+        losses.append(L)
+    return e, r, losses, bat.steps
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_one_rank_cross_kg_positive_steps_equal_dense_oracle(weighted):
+    steps = 5                                  # 3 steps per epoch: crosses the epoch boundary
+    tr = _ck_trainer(0, 1, weighted=weighted)
+    for i in range(steps):
+        tr.step(i)
+    e, r, losses, spe = _ck_reference(steps, weighted)
+    assert spe == 3
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses[2:]), rtol=2e-6)   # the ring keeps the last 3 steps
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :DIM].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+
+
+def _ck_two_rank_worker(rank, world, port, ret, steps, weighted):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OcHostStagedComm
+        torch.cuda.set_device(0)
+        tr = _ck_trainer(rank, world, comm=OcHostStagedComm(), weighted=weighted)
+        for i in range(steps):
+            tr.step(i)
+        full = tr.gather_entity_table().cpu().numpy()
+        loss = tr.epoch_loss()
+        if rank == 0:
+            ret.put((full, tr.rel[:, :DIM].cpu().numpy().copy(), loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("weighted", [False, True])
+def test_two_ranks_cross_kg_positive_steps_equal_dense_oracle(weighted):
+    """Two ranks sharing the GPU: heads / tails of the sampled cross-KG triples live on either rank; 2 vectors per positive
+    each way, nothing else."""
+    import torch.multiprocessing as mp
+    import tempfile
+    port = tempfile.mktemp(prefix="mke_rdv_")
+    world, steps = 2, 5
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_ck_two_rank_worker, args=(r, world, port, ret, steps, weighted)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss = ret.get(timeout=480)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    e, r, losses, _ = _ck_reference(steps, weighted)
+    np.testing.assert_allclose(loss, sum(losses[2:]), rtol=2e-6)
+    np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
