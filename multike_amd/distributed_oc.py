@@ -343,11 +343,17 @@ class OwnerComputesTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
-                 batcher=None, scale: float = 1.0):
+                 batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None):
         """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
         loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
-        with); scale: the loss factor (2 for code/MultiKE_model.py:349-369)."""
+        with); scale: the loss factor (2 for code/MultiKE_model.py:349-369); tables_of: another trainer of the same
+        (rank, world, device, dtype) whose entity shard and relation table this one trains too — the graphs of one view
+        share their variables and have one optimizer each (code/MultiKE_model.py:17-31): shared tables and (zero-invariant)
+        gradient / flag scratch, own Adagrad accumulators, own tag range; `ent0` / `rel0` are then unused."""
         self.scale = float(scale)
+        if tables_of is not None:
+            ent0 = np.empty((tables_of.n_ent, tables_of.dim), dtype=np.float32)    # shapes only
+            rel0 = np.empty((tables_of.rel.shape[0], tables_of.dim), dtype=np.float32)
         self.backend = backend or OcHipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
         if comm is None:
@@ -374,18 +380,28 @@ class OwnerComputesTrainer:
         # --- row-sharded entity state ---------------------------------------------------------------
         mine = np.arange(rank, self.n_ent, world)
         self.n_local = len(mine)
-        self.ent = torch.zeros(max(1, self.n_local), st, dtype=dtype, device=dev)
-        self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
-        self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)
-        self.ent_grad = torch.zeros_like(self.ent)
-        self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
-        self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
-        # --- replicated relation state --------------------------------------------------------------
-        self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
-        self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
+        if tables_of is not None:
+            o = tables_of
+            if (o.rank, o.world, o.device, o.ent.dtype) != (rank, world, dev, dtype):
+                raise _lib.MultiKEHipError("tables_of: the two trainers must agree on rank / world / device / dtype")
+            self.ent, self.ent_grad, self.ent_touched = o.ent, o.ent_grad, o.ent_touched
+            self.rel, self.rel_grad, self.rel_touched = o.rel, o.rel_grad, o.rel_touched
+            if exclusive_rows and o.ref_count is None:
+                o.ref_count = torch.zeros(max(1, self.n_local), **i32)
+            self.ref_count = o.ref_count if exclusive_rows else None
+        else:
+            self.ent = torch.zeros(max(1, self.n_local), st, dtype=dtype, device=dev)
+            self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
+            self.ent_grad = torch.zeros_like(self.ent)
+            self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
+            self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
+            # --- replicated relation state ----------------------------------------------------------
+            self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
+            self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
+            self.rel_grad = torch.zeros_like(self.rel)
+            self.rel_touched = torch.zeros(rel0.shape[0], **i32)
+        self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)     # per-optimizer slots (code/MultiKE_model.py:17)
         self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
-        self.rel_grad = torch.zeros_like(self.rel)
-        self.rel_touched = torch.zeros(rel0.shape[0], **i32)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
         if batcher is not None:
             if self.N != 0:
@@ -400,7 +416,11 @@ class OwnerComputesTrainer:
             self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
                                        device=dev, seed=seed)
         self.steps = self.bat.steps
-        self.tag = 0
+        # trainers sharing the touched-flag arrays keep apart in tag space (a flag is `touched[row] == tag`)
+        self._n_sharing = 0
+        if tables_of is not None:
+            tables_of._n_sharing += 1
+        self.tag = 0 if tables_of is None else (tables_of._n_sharing << 26)
         self.loss_ring = torch.zeros(max(1, self.steps) * self.chunks, _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
         self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
         self.C = 0

@@ -215,3 +215,100 @@ def test_cross_kg_positive_steps_equal_single_process_oracle(world, chunks, weig
     np.testing.assert_allclose(rel, r, rtol=1e-9, atol=1e-12)
     # the loss ring holds one slot per step of an epoch: steps 0 and 1 were overwritten by the second epoch's first two
     np.testing.assert_allclose(loss, sum(losses[2:]), rtol=1e-11)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the relation group of an epoch on shared sharded tables: relation view, then a cross-KG loop, one optimizer each
+# ----------------------------------------------------------------------------------------------------------------------
+def _group_setup():
+    from multike_amd.synthetic import SyntheticKGs
+    kgs = SyntheticKGs(n_ent=CK_N_ENT, n_rel=N_REL, seed=SEED)
+    rng = np.random.default_rng(SEED + 5)
+    triples, _, _ = _ck_setup()
+    ent0 = mo.xavier_truncated_normal((CK_N_ENT, DIM), rng).astype(np.float64)
+    rel0 = mo.xavier_truncated_normal((N_REL, DIM), rng).astype(np.float64)
+    return kgs, _ck_list(triples, True), ent0, rel0
+
+
+def _group_worker(rank, world, port, ret, epochs):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OwnerComputesTrainer, TripleListBatcher
+        from oracle_backend import OcOracleBackend
+        kgs, lst, ent0, rel0 = _group_setup()
+        a = OwnerComputesTrainer(kgs, ent0, rel0, B, NEG, rank, world, seed=SEED, lr=0.05, backend=OcOracleBackend(), device="cpu",
+                                 dtype=torch.float64)
+        b = OwnerComputesTrainer(None, None, None, CK_B, 0, rank, world, seed=SEED, lr=0.05, backend=OcOracleBackend(), device="cpu",
+                                 dtype=torch.float64, batcher=TripleListBatcher(lst, CK_B, device="cpu", seed=SEED), scale=2.0,
+                                 tables_of=a)
+        assert b.ent is a.ent and b.rel is a.rel and b.ent_acc is not a.ent_acc
+        losses = []
+        for ep in range(epochs):
+            for s in range(a.steps):
+                a.step(ep * a.steps + s)
+            la = a.epoch_loss()
+            for s in range(b.steps):
+                b.step(ep * b.steps + s)
+            losses.append((la, b.epoch_loss()))
+        full = a.gather_entity_table().numpy()
+        if rank == 0:
+            ret.put((full, a.rel[:, :DIM].numpy().copy(), losses, a.steps, b.steps))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_relation_group_on_shared_sharded_tables_equals_single_process_oracle():
+    """Two trainers on ONE pair of sharded tables — the relation view (negatives, Adagrad slot 1) and the weighted cross-KG
+    relation-inference loop (positives only, x 2, Adagrad slot 2), alternating for two epochs: what the relation group of an
+    ITC epoch does (code/MultiKE_model.py:291-317, 393-414), against the dense oracle with one accumulator pair per optimizer."""
+    from multike_amd.distributed_oc import TripleListBatcher
+    from multike_amd.sampling import KGSide, RelationBatcher
+    world, epochs = 2, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, ret, epochs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, losses, sa, sb = ret.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    kgs, lst, e, r = _group_setup()
+    acc_a = (np.full_like(e, 0.1), np.full_like(r, 0.1))
+    acc_b = (np.full_like(e, 0.1), np.full_like(r, 0.1))
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None, device="cpu"),
+                          KGSide(kgs.entities(1), None, device="cpu"), B * world, NEG, device="cpu", seed=SEED)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    lb = TripleListBatcher(lst, CK_B, device="cpu", seed=SEED)
+    assert (sa, sb) == (bat.steps, lb.steps)
+    for ep in range(epochs):
+        if ep > 0:
+            bat.shuffle()
+            lb.shuffle()
+        la = 0.0
+        ph, pr, pt = (x.numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        for s in range(bat.steps):
+            lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+            mid = lo + int(bat.cnt1[s])
+            parts = []
+            for k, (a, c) in enumerate(((lo, mid), (mid, hi))):
+                elo, ehi = kgs.ent_range[k]
+                parts.append(co.neg_sample(ph[a:c], pr[a:c], pt[a:c], NEG, ehi - elo, ent_lo=elo, known=sets[k], seed=bat.rng_seed,
+                                           stream_id=bat.rng_stream + k, pos_offset=a))
+            neg = [np.concatenate([parts[0][j], parts[1][j]]) for j in range(3)]
+            L, _, _ = mo.relation_view_step_dense(e, r, acc_a[0], acc_a[1], (ph[lo:hi], pr[lo:hi], pt[lo:hi]), neg, 0.05)
+            la += L
+        lbs = 0.0
+        for s in range(lb.steps):
+            lo, hi = int(lb.off[s]), int(lb.off[s + 1])
+            pos = tuple(x.numpy()[lo:hi] for x in (lb.pos_h, lb.pos_r, lb.pos_t))
+            L, _, _ = mo.relation_view_step_dense(e, r, acc_b[0], acc_b[1], pos, None, 0.05, pos_w=lb.pos_w.numpy()[lo:hi].astype(np.float64),
+                                                  scale=2.0)
+            lbs += L
+        np.testing.assert_allclose(losses[ep][0], la, rtol=1e-11)
+        np.testing.assert_allclose(losses[ep][1], lbs, rtol=1e-11)
+    np.testing.assert_allclose(full, e, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rel, r, rtol=1e-9, atol=1e-12)

@@ -292,3 +292,37 @@ def test_two_ranks_cross_kg_positive_steps_equal_dense_oracle(weighted):
     np.testing.assert_allclose(loss, sum(losses[2:]), rtol=2e-6)
     np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
+
+
+def test_relation_group_on_shared_tables_one_rank():
+    """The relation view and the weighted cross-KG relation-inference loop as two trainers on ONE pair of tables (own Adagrad
+    slots, own tag ranges): a few steps of the first, then an epoch of the second, against the dense oracle."""
+    from multike_amd.distributed_oc import OwnerComputesTrainer, TripleListBatcher
+    steps_a = 4
+    a = _make(0, 1)
+    triples, _, _ = _ck_setup()
+    lst = _ck_list(triples, True)
+    b = OwnerComputesTrainer(None, None, None, CK_B, 0, 0, 1, seed=SEED, lr=0.02, batcher=TripleListBatcher(lst, CK_B, device="cuda", seed=SEED),
+                             scale=2.0, tables_of=a)
+    assert b.ent is a.ent and b.rel is a.rel and b.ent_acc is not a.ent_acc
+    for i in range(steps_a):
+        a.step(i)
+    la = a.epoch_loss()
+    for i in range(b.steps):
+        b.step(i)
+    lb = b.epoch_loss()
+    # reference: the relation view's steps (same dense oracle as above), then the list's steps with their own accumulators
+    e, r, losses, _ = _reference(1, steps_a)
+    np.testing.assert_allclose(la, sum(losses), rtol=2e-6)
+    ae, ar = np.full_like(e, 0.1), np.full_like(r, 0.1)
+    bat = TripleListBatcher(lst, CK_B, device="cuda", seed=SEED)
+    tot = 0.0
+    for s in range(bat.steps):
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        pos = tuple(x[lo:hi].cpu().numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+        L, _, _ = mo.relation_view_step_dense(e, r, ae, ar, pos, None, 0.02, pos_w=bat.pos_w[lo:hi].cpu().numpy().astype(np.float64), scale=2.0)
+        tot += L
+    np.testing.assert_allclose(lb, tot, rtol=2e-6)
+    np.testing.assert_allclose(a.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(a.rel[:, :DIM].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert float(a.ent_grad.abs().max()) == 0.0 and float(a.rel_grad.abs().max()) == 0.0 and int(a.ref_count.abs().sum()) == 0
