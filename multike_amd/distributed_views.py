@@ -69,12 +69,15 @@ def _owned(ids: np.ndarray, rank: int, world: int):
 class HipAttrBackend:
     device_type = "cuda"
 
-    def __init__(self, view: "ShardedAttributeView", ent0, attr0, lit, cnn_params):
+    def __init__(self, view: "ShardedAttributeView", ent0, attr0, lit, cnn_params, tables_of=None):
         from .attr_cnn import AttrCNN
         d = view.dim
-        self.ent = EmbeddingTable(max(1, len(ent0)), d, "av_ent_embeds", normalize=True, values=ent0 if len(ent0) else np.zeros((1, d)))
-        self.attr = EmbeddingTable(attr0.shape[0], d, "attr_embeds", normalize=False, values=attr0)
-        self.lit = EmbeddingTable(lit.shape[0], d, "literal_embeds", normalize=False, trainable=False, values=lit)
+        if tables_of is not None:   # another graph of the same view: the same tables (their Adagrad slots are per optimizer name)
+            self.ent, self.attr, self.lit = tables_of.ent, tables_of.attr, tables_of.lit
+        else:
+            self.ent = EmbeddingTable(max(1, len(ent0)), d, "av_ent_embeds", normalize=True, values=ent0 if len(ent0) else np.zeros((1, d)))
+            self.attr = EmbeddingTable(attr0.shape[0], d, "attr_embeds", normalize=False, values=attr0)
+            self.lit = EmbeddingTable(lit.shape[0], d, "literal_embeds", normalize=False, trainable=False, values=lit)
         self.cnn = AttrCNN(d, params=cnn_params)
         self.eng = StepEngine()
         self.loss = torch.zeros((), dtype=torch.float64, device="cuda")
@@ -130,8 +133,18 @@ class HipAttrBackend:
 
 class ShardedAttributeView:
     def __init__(self, ent0: np.ndarray, attr0: np.ndarray, lit: np.ndarray, cnn_params: dict, rank: int, world: int,
-                 lr: float = 0.001, opt_name: str = "attribute", backend_cls=None, comm=None):
+                 lr: float = 0.001, opt_name: str = "attribute", backend_cls=None, comm=None, tables_of: "ShardedAttributeView" = None):
+        """tables_of: another attribute graph of the same run (code/MultiKE_model.py:134-151, 153-190: the attribute view and
+        the two cross-KG attribute-inference graphs share `av_ent_embeds` / `attr_embeds` and have a CNN parameter set and an
+        optimizer each): this one trains ITS tables — pass a different `opt_name`; `ent0` / `attr0` / `lit` are then unused."""
         self.rank, self.world, self.lr, self.opt_name = rank, world, float(lr), opt_name
+        if tables_of is not None:
+            if (tables_of.rank, tables_of.world) != (rank, world) or tables_of.opt_name == opt_name:
+                raise ValueError("tables_of: same rank / world and a different optimizer name")
+            self.dim, self.n_ent = tables_of.dim, tables_of.n_ent
+            self.comm = comm or tables_of.comm
+            self.backend = (backend_cls or type(tables_of.backend))(self, None, None, None, cnn_params, tables_of=tables_of.backend)
+            return
         self.dim = ent0.shape[1]
         self.n_ent = ent0.shape[0]
         self.comm = comm or ViewComm()

@@ -295,11 +295,14 @@ class OcOracleBackend(OracleBackend):
 class OracleAttrBackend:
     device_type = "cpu"
 
-    def __init__(self, view, ent_shard, attr0, lit, cnn_params):
+    def __init__(self, view, ent_shard, attr0, lit, cnn_params, tables_of=None):
         from oracle import attr_cnn_oracle as ao
         self.ao = ao
-        self.ent = np.array(ent_shard, dtype=np.float64)
-        self.attr, self.lit = np.array(attr0, dtype=np.float64), np.array(lit, dtype=np.float64)
+        if tables_of is not None:   # another graph on the same tables: own CNN set, own accumulators
+            self.ent, self.attr, self.lit = tables_of.ent, tables_of.attr, tables_of.lit
+        else:
+            self.ent = np.array(ent_shard, dtype=np.float64)
+            self.attr, self.lit = np.array(attr0, dtype=np.float64), np.array(lit, dtype=np.float64)
         self.p = {k: np.array(v, dtype=np.float64) for k, v in cnn_params.items()}
         self.acc_p = {k: np.full_like(v, 0.1) for k, v in self.p.items()}
         self.acc_ent, self.acc_attr = np.full_like(self.ent, 0.1), np.full_like(self.attr, 0.1)

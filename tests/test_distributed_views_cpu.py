@@ -249,3 +249,62 @@ def test_sharded_auto_encoder_equals_single_process_oracle(world, active):
     np.testing.assert_allclose(loss, tot, rtol=1e-11)
     for k in p:
         np.testing.assert_allclose(got[k], p[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the attribute group: two attribute graphs (own CNN set, own optimizer) on shared sharded tables
+# ----------------------------------------------------------------------------------------------------------------------
+def _attr_group_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_views import ShardedAttributeView
+        from oracle_backend import OracleAttrBackend
+        ent, attr, lit, P, batches = _attr_data()
+        P2 = {k: 0.5 * v for k, v in P.items()}
+        v1 = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.05, backend_cls=OracleAttrBackend)
+        v2 = ShardedAttributeView(None, None, None, P2, rank, world, lr=0.05, opt_name="ckge_attr", tables_of=v1)
+        for (ih, ia, iv, w) in batches:
+            v1.step(ih, ia, iv, w, scale=1.0)
+            v2.step(ih[::-1], ia, iv, None, scale=2.0)
+        l1, l2 = v1.epoch_loss(), v2.epoch_loss()
+        full, a, p1 = v1.gather()
+        _, _, p2 = v2.gather()
+        if rank == 0:
+            ret.put((full, a, p1, p2, l1, l2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_attribute_graphs_on_shared_sharded_tables():
+    """The attribute view and the cross-KG entity-inference graph of the attribute view (code/MultiKE_model.py:134-151,
+    371-391): same `av_ent_embeds` / `attr_embeds`, a CNN parameter set and an optimizer each; alternating steps."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_attr_group_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, a, p1, p2, l1, l2 = ret.get(timeout=240)
+    for q in procs:
+        q.join(60)
+        assert q.exitcode == 0
+    ent, attr, lit, P, batches = _attr_data()
+    P2 = {k: 0.5 * v for k, v in P.items()}
+    acc1 = {k: np.full_like(x, 0.1) for k, x in P.items()}
+    acc2 = {k: np.full_like(x, 0.1) for k, x in P2.items()}
+    ae1, aa1 = np.full_like(ent, 0.1), np.full_like(attr, 0.1)
+    ae2, aa2 = np.full_like(ent, 0.1), np.full_like(attr, 0.1)
+    t1 = t2 = 0.0
+    for (ih, ia, iv, w) in batches:
+        t1 += ao.attribute_step_dense(P, acc1, ent, attr, lit, ae1, aa1, ih, ia, iv, w, 1.0, 0.05)[0]
+        t2 += ao.attribute_step_dense(P2, acc2, ent, attr, lit, ae2, aa2, ih[::-1], ia, iv, None, 2.0, 0.05)[0]
+    np.testing.assert_allclose(l1, t1, rtol=1e-11)
+    np.testing.assert_allclose(l2, t2, rtol=1e-11)
+    np.testing.assert_allclose(full, ent, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a, attr, rtol=1e-9, atol=1e-12)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(p1[k], P[k], rtol=1e-8, atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(p2[k], P2[k], rtol=1e-8, atol=1e-12, err_msg=k)

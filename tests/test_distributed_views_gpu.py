@@ -281,3 +281,37 @@ def test_one_rank_auto_encoder_phases_equal_the_single_call(active):
     np.testing.assert_allclose(loss, tot, rtol=2e-5)
     for k in p64:
         np.testing.assert_allclose(got[k], p64[k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_two_attribute_graphs_on_shared_tables_one_rank():
+    """The attribute view and a cross-KG attribute-inference graph on the SAME tables (HIP kernels, one rank): a CNN parameter
+    set and an Adagrad slot each (EmbeddingTable slots are per optimizer name), alternating steps, against the dense oracle."""
+    from multike_amd.distributed_views import ShardedAttributeView
+    ent, attr, lit, P, batches = _attr_data()
+    P2 = {k: (0.5 * np.asarray(v)).astype(np.asarray(v).dtype) for k, v in P.items()}
+    v1 = ShardedAttributeView(ent, attr, lit, P, 0, 1, lr=0.01)
+    v2 = ShardedAttributeView(None, None, None, P2, 0, 1, lr=0.01, opt_name="ckge_attr", tables_of=v1)
+    assert v2.backend.ent is v1.backend.ent and v2.backend.cnn is not v1.backend.cnn
+    for (ih, ia, iv, w) in batches:
+        v1.step(ih, ia, iv, w, scale=1.0)
+        v2.step(ih[::-1], ia, iv, None, scale=2.0)
+    l1, l2 = v1.epoch_loss(), v2.epoch_loss()
+    full, a, p1 = v1.gather()
+    _, _, p2 = v2.gather()
+    f64 = lambda d: {k: np.asarray(v).astype(np.float64) for k, v in d.items()}
+    q1, q2 = f64(P), f64(P2)
+    acc1 = {k: np.full_like(v, 0.1) for k, v in q1.items()}
+    acc2 = {k: np.full_like(v, 0.1) for k, v in q2.items()}
+    e64, a64, l64 = ent.astype(np.float64), attr.astype(np.float64), lit.astype(np.float64)
+    ae1, aa1, ae2, aa2 = (np.full_like(x, 0.1) for x in (e64, a64, e64, a64))
+    t1 = t2 = 0.0
+    for (ih, ia, iv, w) in batches:
+        t1 += ao.attribute_step_dense(q1, acc1, e64, a64, l64, ae1, aa1, ih, ia, iv, w.astype(np.float32).astype(np.float64), 1.0, 0.01)[0]
+        t2 += ao.attribute_step_dense(q2, acc2, e64, a64, l64, ae2, aa2, ih[::-1], ia, iv, None, 2.0, 0.01)[0]
+    np.testing.assert_allclose(l1, t1, rtol=1e-5)
+    np.testing.assert_allclose(l2, t2, rtol=1e-5)
+    np.testing.assert_allclose(full, e64, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(a, a64, rtol=2e-3, atol=2e-5)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(p1[k], q1[k], rtol=2e-3, atol=1e-4, err_msg=k)
+        np.testing.assert_allclose(p2[k], q2[k], rtol=2e-3, atol=1e-4, err_msg=k)
