@@ -1,0 +1,150 @@
+"""The training phases of an ITC epoch (code/MultiKE_CSL.py:57-79) on row-sharded tables, one process per GPU.
+
+New design (the reference is single-device): every entity table is sharded id % world, the small tables and the CNN sets are
+replicated, and each phase of the epoch runs in its sharded form on the SAME tables —
+
+    relation view            OwnerComputesTrainer (negatives, optimizer "relation")
+    ckge relation            OwnerComputesTrainer on a TripleListBatcher (positives only, x 2)
+    ckgp relation            the same, weighted 4-tuples
+    attribute view           ShardedAttributeView (CNN set 0)
+    ckge attribute           ShardedAttributeView (CNN set 1, x 2)
+    ckga attribute           ShardedAttributeView (CNN set 2, weighted)
+    common-space learning    ShardedCommonSpace
+
+(multike_amd/distributed_oc.py, multike_amd/distributed_views.py; byte / latency model in DESIGN.md §5).  The host-side
+batch draws (attribute batches, cross-KG samples, entity samples) come from a NumPy generator seeded by (seed, epoch, phase):
+identical on every rank, no exchange.  Not here: the soft predicate alignment refresh, truncated-sampling k-NN refresh,
+validation (host-side or evaluator work that the single-GPU drivers do between epochs).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .distributed_oc import OwnerComputesTrainer, TripleListBatcher
+from .distributed_views import ShardedAttributeView, ShardedCommonSpace
+from .tables import EmbeddingTable
+
+
+class ShardedITC:
+    def __init__(self, kgs, tables: dict, cnn_sets, lists: dict, rank: int, world: int, batch_size: int = 5000,
+                 attribute_batch_size: int = 5000, entity_batch_size: int = 5000, neg_triple_num: int = 10,
+                 learning_rate: float = 0.001, itc_learning_rate: float = 0.004, cv_name_weight: float = 1.0, cv_weight: float = 1.0,
+                 seed: int = 0, comm_oc=None, comm_views=None):
+        """kgs: the two KGs' relation triples (multike_amd.synthetic.SyntheticKGs / base.kgs.KGs interface: `triples`,
+        `entities(k)`, `ent_range`); tables: full float32 arrays {"rv_ent", "av_ent", "ent", "name", "rel", "attr", "lit"}
+        (every rank passes the same; each keeps its shard); cnn_sets: three CNN parameter dicts (attribute view, ckge, ckga);
+        lists: {"attr": [(h, a, v, w)], "ckge_rel": [(h, r, t)], "ckgp_rel": [(h, r, t, w)], "ckge_attr": [(h, a, v)],
+        "ckga_attr": [(h, a, v, w)], "entities": [ids]}; batch sizes are GLOBAL (a step trains that many across the ranks)."""
+        self.rank, self.world, self.seed = rank, world, int(seed)
+        d = tables["ent"].shape[1]
+        self.n_ent = n_ent = tables["ent"].shape[0]
+        shard = lambda k, norm=True, train=True: EmbeddingTable(max(1, len(range(rank, n_ent, world))), d, k, normalize=norm,
+                                                                trainable=train, values=_pad1(tables[k][rank::world], d))
+        full = lambda k, norm, train=True: EmbeddingTable(tables[k].shape[0], d, k, normalize=norm, trainable=train, values=tables[k])
+        self.rv_ent, self.av_ent, self.ent = shard("rv_ent"), shard("av_ent"), shard("ent")
+        self.name = shard("name", norm=False, train=False)
+        self.rel, self.attr = full("rel", True), full("attr", False)
+        self.lit = full("lit", False, train=False)
+        self.sizes = (int(batch_size), int(attribute_batch_size), int(entity_batch_size))
+        # one tag range per component (they share the tables' touched-flag arrays: a flag is `touched[row] == tag`)
+        base = iter(k << 26 for k in range(1, 16))
+        oc = dict(rank=rank, world=world, seed=seed, lr=learning_rate, comm=comm_oc, ent_table=self.rv_ent, rel_table=self.rel, n_ent=n_ent)
+        self.relation = OwnerComputesTrainer(kgs, None, None, max(1, batch_size // world), neg_triple_num, opt_name="relation",
+                                             tag_base=next(base), **oc)
+        mk_list = lambda key, opt: (OwnerComputesTrainer(None, None, None, batch_size, 0, opt_name=opt, scale=2.0, tag_base=next(base),
+                                                         batcher=TripleListBatcher(lists[key], batch_size, device="cuda", seed=seed), **oc)
+                                    if len(lists.get(key, ())) else None)
+        self.ckge_rel, self.ckgp_rel = mk_list("ckge_rel", "ckge_rel"), mk_list("ckgp_rel", "ckgp_rel")
+        av = dict(rank=rank, world=world, lr=learning_rate, comm=comm_views, tables=(self.av_ent, self.attr, self.lit), n_ent=n_ent)
+        self.attr_views = [ShardedAttributeView(None, None, None, cnn_sets[k], opt_name=name, **av)
+                           for k, name in enumerate(("attribute", "ckge_attr", "ckga_attr"))]
+        for v in self.attr_views:
+            v.backend.eng.tag = next(base)
+        self.common = ShardedCommonSpace(None, None, None, None, rank, world, lr=itc_learning_rate, cv_name_weight=cv_name_weight,
+                                         cv_weight=cv_weight, comm=comm_views, n_ent=n_ent,
+                                         tables={"ent": self.ent, "name": self.name, "rv": self.rv_ent, "av": self.av_ent})
+        self.common.backend.eng.tag = next(base)
+        self.lists = {k: lists.get(k, []) for k in ("attr", "ckge_attr", "ckga_attr", "entities")}
+        self._cols = {k: _columns(v) for k, v in self.lists.items() if k != "entities"}
+        self._entities = np.asarray(self.lists["entities"], dtype=np.int64)
+        self._oc_steps = {id(t): 0 for t in (self.relation, self.ckge_rel, self.ckgp_rel) if t is not None}
+
+    # ------------------------------------------------------------------------------------------------
+    def _rng(self, epoch: int, phase: int):
+        return np.random.default_rng([self.seed, int(epoch), int(phase)])
+
+    def _oc_epoch(self, tr):
+        if tr is None:
+            return 0.0
+        i0 = self._oc_steps[id(tr)]
+        for i in range(i0, i0 + tr.steps):
+            tr.step(i)
+        self._oc_steps[id(tr)] = i0 + tr.steps
+        return tr.epoch_loss()
+
+    def _attr_epoch(self, view, key, epoch, phase, scale, sampled):
+        cols = self._cols[key]
+        n = len(cols[0])
+        if n == 0:
+            return 0.0
+        B = self.sizes[1]
+        rng = self._rng(epoch, phase)
+        steps = int(math.ceil(n / B))
+        if sampled:     # `steps` x random.sample(list, B) (code/MultiKE_model.py:378)
+            bs = B if steps > 1 else n
+            batches = [rng.choice(n, bs, replace=False) for _ in range(steps)]
+        else:           # random.shuffle, then consecutive slices (code/MultiKE_model.py:336-343)
+            perm = rng.permutation(n)
+            batches = [perm[s * B:(s + 1) * B] for s in range(steps)]
+        for idx in batches:
+            w = cols[3][idx] if cols[3] is not None else None
+            view.step(cols[0][idx], cols[1][idx], cols[2][idx], w, scale=scale)
+        return view.epoch_loss()
+
+    def _common_epoch(self, epoch, phase):
+        n = len(self._entities)
+        if n == 0:
+            return 0.0
+        B = self.sizes[2]
+        rng = self._rng(epoch, phase)
+        steps = int(math.ceil(n / B))
+        bs = B if steps > 1 else n
+        for _ in range(steps):      # random.sample(entity_list, B) (code/MultiKE_model.py:446)
+            self.common.step(self._entities[rng.choice(n, bs, replace=False)])
+        return self.common.epoch_loss()
+
+    def epoch(self, i: int) -> dict:
+        """The seven training phases of epoch i in the reference's order (code/MultiKE_CSL.py:62-79); returns their summed losses."""
+        out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel),
+               "ckgp_rel": self._oc_epoch(self.ckgp_rel)}
+        out["attribute"] = self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False)
+        out["ckge_attr"] = self._attr_epoch(self.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)
+        out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
+        out["common"] = self._common_epoch(i, 3)
+        return out
+
+    def gather(self) -> dict:
+        """Full tables (tests / checkpoint): the three entity tables gathered from their shards, the replicated ones as they are."""
+        out = self.common.gather()              # ent, rv, av
+        out["rel"] = self.rel.raw().cpu().numpy()
+        out["attr"] = self.attr.raw().cpu().numpy()
+        out["cnn"] = [v.backend.cnn.numpy_params() for v in self.attr_views]
+        return out
+
+
+def _pad1(a, d):
+    return a if len(a) else np.zeros((1, d), dtype=np.float32)
+
+
+def _columns(lst):
+    """[(h, a, v[, w])] -> (h, a, v, w or None) int64 / float arrays."""
+    if len(lst) == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return z, z, z, None
+    arr = np.asarray([t[:3] for t in lst], dtype=np.int64)
+    w = np.asarray([t[3] for t in lst], dtype=np.float64) if len(lst[0]) > 3 else None
+    return arr[:, 0], arr[:, 1], arr[:, 2], w

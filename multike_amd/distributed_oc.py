@@ -343,7 +343,8 @@ class OwnerComputesTrainer:
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
-                 batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None):
+                 batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None, ent_table=None, rel_table=None,
+                 opt_name: str = "relation", n_ent: int = None, tag_base: int = None):
         """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
         loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
         with); scale: the loss factor (2 for code/MultiKE_model.py:349-369); tables_of: another trainer of the same
@@ -351,6 +352,14 @@ class OwnerComputesTrainer:
         share their variables and have one optimizer each (code/MultiKE_model.py:17-31): shared tables and (zero-invariant)
         gradient / flag scratch, own Adagrad accumulators, own tag range; `ent0` / `rel0` are then unused."""
         self.scale = float(scale)
+        # ent_table / rel_table (multike_amd.tables.EmbeddingTable: this rank's shard of `n_ent` global rows, and the
+        # replicated relation table): train THOSE — the trainer then shares them with whatever else holds them (other
+        # trainers, the common-space step of multike_amd.distributed_views) and takes its Adagrad slot by `opt_name`.
+        if ent_table is not None:
+            if rel_table is None or n_ent is None:
+                raise _lib.MultiKEHipError("ent_table needs rel_table and n_ent (the global row count)")
+            ent0 = np.empty((int(n_ent), ent_table.dim), dtype=np.float32)          # shapes only
+            rel0 = np.empty((rel_table.n_rows, rel_table.dim), dtype=np.float32)
         if tables_of is not None:
             ent0 = np.empty((tables_of.n_ent, tables_of.dim), dtype=np.float32)    # shapes only
             rel0 = np.empty((tables_of.rel.shape[0], tables_of.dim), dtype=np.float32)
@@ -380,7 +389,13 @@ class OwnerComputesTrainer:
         # --- row-sharded entity state ---------------------------------------------------------------
         mine = np.arange(rank, self.n_ent, world)
         self.n_local = len(mine)
-        if tables_of is not None:
+        if ent_table is not None:
+            if ent_table.n_rows != max(1, self.n_local) or ent_table.stride != st or rel_table.stride != st:
+                raise _lib.MultiKEHipError("ent_table: the shard must hold ceil-share rows of n_ent with the trainer's stride")
+            self.ent, self.ent_grad, self.ent_touched = ent_table.data, ent_table.grad, ent_table.touched
+            self.rel, self.rel_grad, self.rel_touched = rel_table.data, rel_table.grad, rel_table.touched
+            self.ref_count = ent_table.refcount if exclusive_rows else None
+        elif tables_of is not None:
             o = tables_of
             if (o.rank, o.world, o.device, o.ent.dtype) != (rank, world, dev, dtype):
                 raise _lib.MultiKEHipError("tables_of: the two trainers must agree on rank / world / device / dtype")
@@ -400,8 +415,11 @@ class OwnerComputesTrainer:
             self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
             self.rel_grad = torch.zeros_like(self.rel)
             self.rel_touched = torch.zeros(rel0.shape[0], **i32)
-        self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)     # per-optimizer slots (code/MultiKE_model.py:17)
-        self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
+        if ent_table is not None:
+            self.ent_acc, self.rel_acc = ent_table.slot(opt_name), rel_table.slot(opt_name)
+        else:
+            self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)     # per-optimizer slots (code/MultiKE_model.py:17)
+            self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
         if batcher is not None:
             if self.N != 0:
@@ -421,6 +439,8 @@ class OwnerComputesTrainer:
         if tables_of is not None:
             tables_of._n_sharing += 1
         self.tag = 0 if tables_of is None else (tables_of._n_sharing << 26)
+        if tag_base is not None:
+            self.tag = int(tag_base)
         self.loss_ring = torch.zeros(max(1, self.steps) * self.chunks, _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
         self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
         self.C = 0

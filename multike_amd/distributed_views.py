@@ -69,10 +69,12 @@ def _owned(ids: np.ndarray, rank: int, world: int):
 class HipAttrBackend:
     device_type = "cuda"
 
-    def __init__(self, view: "ShardedAttributeView", ent0, attr0, lit, cnn_params, tables_of=None):
+    def __init__(self, view: "ShardedAttributeView", ent0, attr0, lit, cnn_params, tables_of=None, tables=None):
         from .attr_cnn import AttrCNN
         d = view.dim
-        if tables_of is not None:   # another graph of the same view: the same tables (their Adagrad slots are per optimizer name)
+        if tables is not None:      # (av_ent shard, attr, literal) EmbeddingTables held by the caller (multike_amd.distributed_model)
+            self.ent, self.attr, self.lit = tables
+        elif tables_of is not None:   # another graph of the same view: the same tables (their Adagrad slots are per optimizer name)
             self.ent, self.attr, self.lit = tables_of.ent, tables_of.attr, tables_of.lit
         else:
             self.ent = EmbeddingTable(max(1, len(ent0)), d, "av_ent_embeds", normalize=True, values=ent0 if len(ent0) else np.zeros((1, d)))
@@ -133,11 +135,17 @@ class HipAttrBackend:
 
 class ShardedAttributeView:
     def __init__(self, ent0: np.ndarray, attr0: np.ndarray, lit: np.ndarray, cnn_params: dict, rank: int, world: int,
-                 lr: float = 0.001, opt_name: str = "attribute", backend_cls=None, comm=None, tables_of: "ShardedAttributeView" = None):
+                 lr: float = 0.001, opt_name: str = "attribute", backend_cls=None, comm=None, tables_of: "ShardedAttributeView" = None,
+                 tables=None, n_ent: int = None):
         """tables_of: another attribute graph of the same run (code/MultiKE_model.py:134-151, 153-190: the attribute view and
         the two cross-KG attribute-inference graphs share `av_ent_embeds` / `attr_embeds` and have a CNN parameter set and an
         optimizer each): this one trains ITS tables — pass a different `opt_name`; `ent0` / `attr0` / `lit` are then unused."""
         self.rank, self.world, self.lr, self.opt_name = rank, world, float(lr), opt_name
+        if tables is not None:      # EmbeddingTables of the caller: (this rank's av_ent shard of n_ent rows, attr, literal)
+            self.dim, self.n_ent = tables[0].dim, int(n_ent)
+            self.comm = comm or ViewComm()
+            self.backend = (backend_cls or HipAttrBackend)(self, None, None, None, cnn_params, tables=tables)
+            return
         if tables_of is not None:
             if (tables_of.rank, tables_of.world) != (rank, world) or tables_of.opt_name == opt_name:
                 raise ValueError("tables_of: same rank / world and a different optimizer name")
@@ -194,15 +202,18 @@ class ShardedAttributeView:
 class HipCommonSpaceBackend:
     device_type = "cuda"
 
-    def __init__(self, view, shards: dict):
+    def __init__(self, view, shards: dict, tables: dict = None):
         d = view.dim
+        self.eng = StepEngine()
+        self.loss = torch.zeros((), dtype=torch.float64, device="cuda")
+        if tables is not None:      # {"ent", "name", "rv", "av"}: EmbeddingTables held by the caller
+            self.ent, self.name, self.rv, self.av = (tables[k] for k in ("ent", "name", "rv", "av"))
+            return
         mk = lambda name, trainable, norm: EmbeddingTable(max(1, len(shards[name])), d, name, normalize=norm, trainable=trainable,
                                                           values=shards[name] if len(shards[name]) else np.zeros((1, d)))
         # name_embeds is a constant read as-is (code/MultiKE_model.py:88); the other three are normalise-on-read variables
         self.ent, self.name = mk("ent", True, True), mk("name", False, False)
         self.rv, self.av = mk("rv", True, True), mk("av", True, True)
-        self.eng = StepEngine()
-        self.loss = torch.zeros((), dtype=torch.float64, device="cuda")
 
     def step(self, view, rows):
         if len(rows) == 0:
@@ -224,11 +235,15 @@ class HipCommonSpaceBackend:
 
 class ShardedCommonSpace:
     def __init__(self, ent0, name0, rv0, av0, rank: int, world: int, lr: float = 0.004, cv_name_weight: float = 1.0,
-                 cv_weight: float = 1.0, backend_cls=None, comm=None):
+                 cv_weight: float = 1.0, backend_cls=None, comm=None, tables: dict = None, n_ent: int = None):
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.cv_name_weight, self.cv_weight = float(cv_name_weight), float(cv_weight)
-        self.dim, self.n_ent = ent0.shape[1], ent0.shape[0]
         self.comm = comm or ViewComm()
+        if tables is not None:      # the caller's EmbeddingTable shards {"ent", "name", "rv", "av"} of n_ent global rows
+            self.dim, self.n_ent = tables["ent"].dim, int(n_ent)
+            self.backend = (backend_cls or HipCommonSpaceBackend)(self, None, tables=tables)
+            return
+        self.dim, self.n_ent = ent0.shape[1], ent0.shape[0]
         shards = {k: v[rank::world] for k, v in (("ent", ent0), ("name", name0), ("rv", rv0), ("av", av0))}
         self.backend = (backend_cls or HipCommonSpaceBackend)(self, shards)
 
