@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .distributed_oc import OwnerComputesTrainer, TripleListBatcher
-from .distributed_views import ShardedAttributeView, ShardedCommonSpace
+from .distributed_views import ShardedAttributeView, ShardedCommonSpace, ShardedSpaceMapping
 from .tables import EmbeddingTable
 
 
@@ -33,7 +33,8 @@ class ShardedITC:
     def __init__(self, kgs, tables: dict, cnn_sets, lists: dict, rank: int, world: int, batch_size: int = 5000,
                  attribute_batch_size: int = 5000, entity_batch_size: int = 5000, neg_triple_num: int = 10,
                  learning_rate: float = 0.001, itc_learning_rate: float = 0.004, cv_name_weight: float = 1.0, cv_weight: float = 1.0,
-                 seed: int = 0, comm_oc=None, comm_views=None):
+                 seed: int = 0, comm_oc=None, comm_views=None, mapping_matrices=None, mapping_learning_rate: float = 0.01,
+                 orthogonal_weight: float = 2.0):
         """kgs: the two KGs' relation triples (multike_amd.synthetic.SyntheticKGs / base.kgs.KGs interface: `triples`,
         `entities(k)`, `ent_range`); tables: full float32 arrays {"rv_ent", "av_ent", "ent", "name", "rel", "attr", "lit"}
         (every rank passes the same; each keeps its shard); cnn_sets: three CNN parameter dicts (attribute view, ckge, ckga);
@@ -68,6 +69,14 @@ class ShardedITC:
                                          cv_weight=cv_weight, comm=comm_views, n_ent=n_ent,
                                          tables={"ent": self.ent, "name": self.name, "rv": self.rv_ent, "av": self.av_ent})
         self.common.backend.eng.tag = next(base)
+        # SSL schedule (code/MultiKE_Late.py:201-280): the shared table is learned by mapping the three views onto it
+        # (code/MultiKE_model.py:439-454) instead of the common-space step
+        self.mapping = None
+        if mapping_matrices is not None:
+            self.mapping = ShardedSpaceMapping(None, None, mapping_matrices, rank, world, lr=mapping_learning_rate,
+                                               orthogonal_weight=orthogonal_weight, comm=comm_views, n_ent=n_ent,
+                                               tables=(self.ent, [self.name, self.rv_ent, self.av_ent]))
+            self.mapping.backend.eng.tag = next(base)
         self.lists = {k: lists.get(k, []) for k in ("attr", "ckge_attr", "ckga_attr", "entities")}
         self._cols = {k: _columns(v) for k, v in self.lists.items() if k != "entities"}
         self._entities = np.asarray(self.lists["entities"], dtype=np.int64)
@@ -117,6 +126,28 @@ class ShardedITC:
             self.common.step(self._entities[rng.choice(n, bs, replace=False)])
         return self.common.epoch_loss()
 
+    def _mapping_epoch(self, epoch, phase):
+        n = len(self._entities)
+        if n == 0 or self.mapping is None:
+            return 0.0
+        B = self.sizes[2]
+        rng = self._rng(epoch, phase)
+        steps = int(math.ceil(n / B))
+        bs = B if steps > 1 else n
+        for _ in range(steps):
+            self.mapping.step(self._entities[rng.choice(n, bs, replace=False)])
+        return self.mapping.epoch_loss()
+
+    def epoch_ssl(self, i: int) -> dict:
+        """The SSL schedule's training phases (code/MultiKE_Late.py:216-243): the six view phases, then the space mapping."""
+        out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel),
+               "ckgp_rel": self._oc_epoch(self.ckgp_rel)}
+        out["attribute"] = self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False)
+        out["ckge_attr"] = self._attr_epoch(self.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)
+        out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
+        out["mapping"] = self._mapping_epoch(i, 4)
+        return out
+
     def epoch(self, i: int) -> dict:
         """The seven training phases of epoch i in the reference's order (code/MultiKE_CSL.py:62-79); returns their summed losses."""
         out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel),
@@ -133,6 +164,8 @@ class ShardedITC:
         out["rel"] = self.rel.raw().cpu().numpy()
         out["attr"] = self.attr.raw().cpu().numpy()
         out["cnn"] = [v.backend.cnn.numpy_params() for v in self.attr_views]
+        if self.mapping is not None:
+            out["matrices"] = self.mapping.backend.state.M.double().cpu().numpy()
         return out
 
 

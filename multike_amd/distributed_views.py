@@ -282,13 +282,16 @@ class ShardedCommonSpace:
 class HipSpaceMappingBackend:
     device_type = "cuda"
 
-    def __init__(self, view: "ShardedSpaceMapping", ent0, views0, matrices):
+    def __init__(self, view: "ShardedSpaceMapping", ent0, views0, matrices, tables=None):
         from .runner import SpaceMappingState
         d = view.dim
         mk = lambda name, vals, trainable: EmbeddingTable(max(1, len(vals)), d, name, normalize=True, trainable=trainable,
                                                           values=vals if len(vals) else np.zeros((1, d)))
-        self.ent = mk("ent_embeds", ent0, True)
-        self.views = [mk(f"view{k}", v, False) for k, v in enumerate(views0)]
+        if tables is not None:      # (shared-table shard, [view shards]): EmbeddingTables held by the caller
+            self.ent, self.views = tables[0], list(tables[1])
+        else:
+            self.ent = mk("ent_embeds", ent0, True)
+            self.views = [mk(f"view{k}", v, False) for k, v in enumerate(views0)]
         self.state = SpaceMappingState([torch.as_tensor(np.asarray(m)) for m in matrices], "cuda")
         self.eng = StepEngine()
         LP = _lib.LOSS_PARTIALS
@@ -361,12 +364,17 @@ class HipSpaceMappingBackend:
 
 class ShardedSpaceMapping:
     def __init__(self, ent0, views0, matrices, rank: int, world: int, lr: float = 0.01, orthogonal_weight: float = 2.0,
-                 norm_w: float = 0.0001, backend_cls=None, comm=None):
-        """ent0: the shared table [n_ent, dim]; views0: the (constant) view tables mapped onto it; matrices: [dim, dim] each."""
+                 norm_w: float = 0.0001, backend_cls=None, comm=None, tables=None, n_ent: int = None):
+        """ent0: the shared table [n_ent, dim]; views0: the (constant) view tables mapped onto it; matrices: [dim, dim] each.
+        tables: (shared-table shard, [view shards]) EmbeddingTables of the caller instead of ent0 / views0 (n_ent global rows)."""
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.orthogonal_weight, self.norm_w = float(orthogonal_weight), float(norm_w)
-        self.dim, self.n_ent = ent0.shape[1], ent0.shape[0]
         self.comm = comm or ViewComm()
+        if tables is not None:
+            self.dim, self.n_ent = tables[0].dim, int(n_ent)
+            self.backend = (backend_cls or HipSpaceMappingBackend)(self, None, None, matrices, tables=tables)
+            return
+        self.dim, self.n_ent = ent0.shape[1], ent0.shape[0]
         self.backend = (backend_cls or HipSpaceMappingBackend)(self, ent0[rank::world], [v[rank::world] for v in views0], matrices)
 
     def step(self, entities):

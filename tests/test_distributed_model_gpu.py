@@ -42,17 +42,23 @@ def _setup():
     return kgs, tables, cnn, lists
 
 
-def _train(rank, world, comm_oc=None, comm_views=None):
+def _matrices():
+    rng = np.random.default_rng(SEED + 1)
+    return [np.linalg.qr(rng.standard_normal((DIM, DIM)))[0].astype(np.float32) + 0.01 * rng.standard_normal((DIM, DIM)).astype(np.float32)
+            for _ in range(3)]
+
+
+def _train(rank, world, comm_oc=None, comm_views=None, ssl=False):
     from multike_amd.distributed_model import ShardedITC
     kgs, tables, cnn, lists = _setup()
     m = ShardedITC(kgs, tables, cnn, lists, rank, world, batch_size=B, attribute_batch_size=AB, entity_batch_size=EB,
                    neg_triple_num=NEG, learning_rate=0.01, itc_learning_rate=0.02, cv_name_weight=0.7, cv_weight=1.3, seed=SEED,
-                   comm_oc=comm_oc, comm_views=comm_views)
-    losses = [m.epoch(i) for i in range(1, EPOCHS + 1)]
+                   comm_oc=comm_oc, comm_views=comm_views, mapping_matrices=_matrices() if ssl else None)
+    losses = [(m.epoch_ssl(i) if ssl else m.epoch(i)) for i in range(1, EPOCHS + 1)]
     return m, losses
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, ssl=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
@@ -60,7 +66,7 @@ def _worker(rank, world, port, ret):
         from multike_amd.distributed_oc import OcHostStagedComm
         from multike_amd.distributed_views import HostStagedViewComm
         torch.cuda.set_device(0)
-        m, losses = _train(rank, world, OcHostStagedComm(), HostStagedViewComm())
+        m, losses = _train(rank, world, OcHostStagedComm(), HostStagedViewComm(), ssl)
         out = m.gather()
         if rank == 0:
             ret.put((out, losses))
@@ -69,15 +75,17 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_equal_one_rank_over_two_epochs():
+@pytest.mark.parametrize("ssl", [False, True])
+def test_two_ranks_equal_one_rank_over_two_epochs(ssl):
+    """ssl: the SSL schedule's phases — space mapping of the three views onto the shared table instead of the common-space step."""
     import tempfile
     import torch.multiprocessing as mp
-    m1, l1 = _train(0, 1)
+    m1, l1 = _train(0, 1, ssl=ssl)
     ref = m1.gather()
     port = tempfile.mktemp(prefix="mke_rdv_")
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, ssl)) for r in range(2)]
     for p in procs:
         p.start()
     got, l2 = ret.get(timeout=800)
@@ -90,6 +98,9 @@ def test_two_ranks_equal_one_rank_over_two_epochs():
             np.testing.assert_allclose(l2[ep][k], l1[ep][k], rtol=2e-5, err_msg=f"epoch {ep} {k}")
     for k in ("ent", "rv", "av", "rel", "attr"):
         np.testing.assert_allclose(got[k], ref[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    if ssl:
+        np.testing.assert_allclose(got["matrices"], ref["matrices"], rtol=2e-4, atol=2e-6)
+        assert np.abs(ref["matrices"] - np.stack(_matrices())).max() > 1e-4
     for a, b in zip(got["cnn"], ref["cnn"]):
         for k in a:
             np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-4, err_msg=k)
