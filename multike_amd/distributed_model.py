@@ -21,9 +21,7 @@ from __future__ import annotations
 import math
 
 import numpy as np
-import torch
 
-from . import _lib
 from .distributed_oc import OwnerComputesTrainer, TripleListBatcher
 from .distributed_views import ShardedAttributeView, ShardedCommonSpace, ShardedSpaceMapping
 from .tables import EmbeddingTable
