@@ -90,7 +90,8 @@ class HipAttrBackend:
     def forward(self, view, lh, ia, iv, w, scale):
         """Conv stack + dense layer on this rank's triples; returns the device scalar sum z^2 of its part."""
         wt = None if w is None else torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32), device="cuda")
-        self._keep = (self._i32(lh), self._i32(ia), self._i32(iv), wt)
+        ids = self._i32(np.stack([np.asarray(lh), np.asarray(ia), np.asarray(iv)]).reshape(3, -1))   # one host-to-device copy
+        self._keep = (ids[0], ids[1], ids[2], wt)
         self.args, self.part = self.cnn._args(self.eng, self.ent, self.attr, self.lit, *self._keep, len(lh), scale, view.opt_name,
                                               view.lr, "Adagrad", True, 1)
         _lib.attr_step_phases(self.args, _lib.ATTR_FWD)
