@@ -107,9 +107,9 @@ class ShardedITC:
         else:           # random.shuffle, then consecutive slices (code/MultiKE_model.py:336-343)
             perm = rng.permutation(n)
             batches = [perm[s * B:(s + 1) * B] for s in range(steps)]
-        for idx in batches:
-            w = cols[3][idx] if cols[3] is not None else None
-            view.step(cols[0][idx], cols[1][idx], cols[2][idx], w, scale=scale)
+        order = np.concatenate(batches)                      # the epoch in step order: staged on the device once
+        off = np.concatenate([[0], np.cumsum([len(b) for b in batches])])
+        view.steps(cols[0][order], cols[1][order], cols[2][order], cols[3][order] if cols[3] is not None else None, off, scale=scale)
         return view.epoch_loss()
 
     def _common_epoch(self, epoch, phase):

@@ -87,15 +87,28 @@ class HipAttrBackend:
     def _i32(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device="cuda")
 
-    def forward(self, view, lh, ia, iv, w, scale):
-        """Conv stack + dense layer on this rank's triples; returns the device scalar sum z^2 of its part."""
+    def stage(self, lh, ia, iv, w):
+        """Host arrays of this rank's triples (one step or a whole epoch) -> device (one copy for the three id columns)."""
         wt = None if w is None else torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32), device="cuda")
-        ids = self._i32(np.stack([np.asarray(lh), np.asarray(ia), np.asarray(iv)]).reshape(3, -1))   # one host-to-device copy
-        self._keep = (ids[0], ids[1], ids[2], wt)
-        self.args, self.part = self.cnn._args(self.eng, self.ent, self.attr, self.lit, *self._keep, len(lh), scale, view.opt_name,
-                                              view.lr, "Adagrad", True, 1)
+        ids = self._i32(np.stack([np.asarray(lh), np.asarray(ia), np.asarray(iv)]).reshape(3, -1))
+        return ids[0], ids[1], ids[2], wt
+
+    def forward(self, view, lh, ia, iv, w, scale, staged=None):
+        """Conv stack + dense layer on this rank's triples; returns the device scalar sum z^2 of its part.  staged: the
+        triples as device tensors (slices of an epoch staged once) instead of the host arrays."""
+        self._keep = staged if staged is not None else self.stage(lh, ia, iv, w)
+        self.args, self.part = self.cnn._args(self.eng, self.ent, self.attr, self.lit, *self._keep, int(self._keep[0].numel()), scale,
+                                              view.opt_name, view.lr, "Adagrad", True, 1)
         _lib.attr_step_phases(self.args, _lib.ATTR_FWD)
         return self._scalar(1)
+
+    def step_alone(self, view, lh, ia, iv, w, scale, staged=None):
+        """world == 1: nothing separates the phases — the whole step as ONE native call (`mke_attr_step`)."""
+        h, a, v, wt = staged if staged is not None else self.stage(lh, ia, iv, w)
+        if h.numel() == 0:
+            return
+        self.loss += self.cnn.step(self.eng, self.ent, self.attr, self.lit, h, a, v, wt, scale=scale, opt_name=view.opt_name,
+                                   lr=view.lr).sum()
 
     def _scalar(self, k):
         LP = _lib.LOSS_PARTIALS
@@ -166,6 +179,9 @@ class ShardedAttributeView:
         pos, lh = _owned(ih, self.rank, self.world)
         ia, iv = np.asarray(ia)[pos], np.asarray(iv)[pos]
         w = None if w is None else np.asarray(w)[pos]
+        if self.world == 1 and hasattr(be, "step_alone"):
+            be.step_alone(self, lh, ia, iv, w, scale)
+            return
         S = be.forward(self, lh, ia, iv, w, scale)
         cm.all_reduce(S)                                   # sum z^2 over the whole batch (code/MultiKE_model.py:60)
         T = be.tail(self, S)
@@ -173,6 +189,33 @@ class ShardedAttributeView:
         for g in be.backward(self, T):
             cm.all_reduce(g)                               # replicated parameters: CNN pack, attribute table
         be.update(self)
+
+    def steps(self, ih, ia, iv, w, step_off, scale: float = 1.0):
+        """Consecutive steps over epoch-ordered host arrays (step s = positions [step_off[s], step_off[s + 1])): what `step`
+        does per step, with this rank's triples of ALL steps filtered and copied to the device once."""
+        be = self.backend
+        if not hasattr(be, "stage"):
+            for s in range(len(step_off) - 1):
+                lo, hi = int(step_off[s]), int(step_off[s + 1])
+                self.step(ih[lo:hi], ia[lo:hi], iv[lo:hi], None if w is None else w[lo:hi], scale)
+            return
+        ih = np.asarray(ih, dtype=np.int64)
+        mine = np.nonzero(ih % self.world == self.rank)[0]
+        off = np.searchsorted(mine, np.asarray(step_off, dtype=np.int64))      # this rank's slice of every step
+        staged = be.stage(ih[mine] // self.world, np.asarray(ia)[mine], np.asarray(iv)[mine], None if w is None else np.asarray(w)[mine])
+        cm = self.comm
+        for s in range(len(step_off) - 1):
+            part = tuple(None if t is None else t[off[s]:off[s + 1]] for t in staged)
+            if self.world == 1 and hasattr(be, "step_alone"):
+                be.step_alone(self, None, None, None, None, scale, staged=part)
+                continue
+            S = be.forward(self, None, None, None, None, scale, staged=part)
+            cm.all_reduce(S)
+            T = be.tail(self, S)
+            cm.all_reduce(T)
+            for g in be.backward(self, T):
+                cm.all_reduce(g)
+            be.update(self)
 
     def epoch_loss(self) -> float:
         t = self.backend.take_loss()

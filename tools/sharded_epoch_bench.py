@@ -27,3 +27,15 @@ for i in range(1, 4):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"sharded epoch {i} at G = 1: {dt * 1e3:.1f} ms  (relation steps {m.relation.steps}, attribute steps {-(-n_at // 5000)}, "
           f"ckge-rel {m.ckge_rel.steps}, ckge-attr {-(-n_ck // 5000)}, common {-(-n_ent // 5000)})")
+
+# per phase (synchronised around each)
+import time as _t
+def timed(label, fn):
+    torch.cuda.synchronize(); t0 = _t.perf_counter(); fn(); torch.cuda.synchronize()
+    return f"{label} {(_t.perf_counter() - t0) * 1e3:.1f}"
+i = 4
+parts = [timed("relation", lambda: m._oc_epoch(m.relation)), timed("ckge-rel", lambda: m._oc_epoch(m.ckge_rel)),
+         timed("attribute", lambda: m._attr_epoch(m.attr_views[0], "attr", i, 0, 1.0, sampled=False)),
+         timed("ckge-attr", lambda: m._attr_epoch(m.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)),
+         timed("common", lambda: m._common_epoch(i, 3))]
+print("phases (ms): " + " | ".join(parts))
