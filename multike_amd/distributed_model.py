@@ -12,8 +12,9 @@ replicated, and each phase of the epoch runs in its sharded form on the SAME tab
     common-space learning    ShardedCommonSpace
 
 (multike_amd/distributed_oc.py, multike_amd/distributed_views.py; byte / latency model in DESIGN.md §5).  The host-side
-batch draws (attribute batches, cross-KG samples, entity samples) come from a NumPy generator seeded by (seed, epoch, phase):
-identical on every rank, no exchange.  Not here: the soft predicate alignment refresh, truncated-sampling k-NN refresh,
+batch draws (attribute batches, cross-KG samples, entity samples) are made ON THE DEVICE from (seed, epoch, phase) — a seeded
+`torch.randperm` for the shuffled attribute view, `mke_sample_distinct` for the `random.sample` loops: identical on every rank,
+no exchange, no per-step host-to-device copy.  Not here: the soft predicate alignment refresh, truncated-sampling k-NN refresh,
 validation (host-side or evaluator work that the single-GPU drivers do between epochs).
 """
 from __future__ import annotations
@@ -21,7 +22,9 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import torch
 
+from . import _lib
 from .distributed_oc import OwnerComputesTrainer, TripleListBatcher
 from .distributed_views import ShardedAttributeView, ShardedCommonSpace, ShardedSpaceMapping
 from .tables import EmbeddingTable
@@ -76,14 +79,14 @@ class ShardedITC:
                                                tables=(self.ent, [self.name, self.rv_ent, self.av_ent]))
             self.mapping.backend.eng.tag = next(base)
         self.lists = {k: lists.get(k, []) for k in ("attr", "ckge_attr", "ckga_attr", "entities")}
-        self._cols = {k: _columns(v) for k, v in self.lists.items() if k != "entities"}
-        self._entities = np.asarray(self.lists["entities"], dtype=np.int64)
+        dev = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+        self._cols = {k: tuple(dev(c, torch.float32 if j == 3 else torch.int64) for j, c in enumerate(_columns(v)))
+                      for k, v in self.lists.items() if k != "entities"}
+        self._entities = dev(np.asarray(self.lists["entities"], dtype=np.int64), torch.int64)
+        self._gen = torch.Generator(device="cuda")
         self._oc_steps = {id(t): 0 for t in (self.relation, self.ckge_rel, self.ckgp_rel) if t is not None}
 
     # ------------------------------------------------------------------------------------------------
-    def _rng(self, epoch: int, phase: int):
-        return np.random.default_rng([self.seed, int(epoch), int(phase)])
-
     def _oc_epoch(self, tr):
         if tr is None:
             return 0.0
@@ -93,47 +96,43 @@ class ShardedITC:
         self._oc_steps[id(tr)] = i0 + tr.steps
         return tr.epoch_loss()
 
+    def _draw(self, n: int, B: int, epoch: int, phase: int, sampled: bool):
+        """(positions of an epoch in step order [device int64], step_off): `steps` x random.sample(range(n), B) when sampled
+        (code/MultiKE_model.py:358, 378, 446), else random.shuffle + consecutive slices (:336-343)."""
+        steps = int(math.ceil(n / B))
+        if sampled:
+            bs = B if steps > 1 else n
+            idx = _lib.sample_distinct(n, bs, steps, (self.seed & 0xFFFFFFFF, 0x495443 + phase), epoch, device="cuda").reshape(-1).long()
+            return idx, np.arange(steps + 1, dtype=np.int64) * bs
+        self._gen.manual_seed((self.seed * 1000003 + epoch * 101 + phase) & 0x7FFFFFFFFFFFFFFF)
+        idx = torch.randperm(n, generator=self._gen, device="cuda")
+        return idx, np.minimum(np.arange(steps + 1, dtype=np.int64) * B, n)
+
     def _attr_epoch(self, view, key, epoch, phase, scale, sampled):
         cols = self._cols[key]
-        n = len(cols[0])
+        n = int(cols[0].numel())
         if n == 0:
             return 0.0
-        B = self.sizes[1]
-        rng = self._rng(epoch, phase)
-        steps = int(math.ceil(n / B))
-        if sampled:     # `steps` x random.sample(list, B) (code/MultiKE_model.py:378)
-            bs = B if steps > 1 else n
-            batches = [rng.choice(n, bs, replace=False) for _ in range(steps)]
-        else:           # random.shuffle, then consecutive slices (code/MultiKE_model.py:336-343)
-            perm = rng.permutation(n)
-            batches = [perm[s * B:(s + 1) * B] for s in range(steps)]
-        order = np.concatenate(batches)                      # the epoch in step order: staged on the device once
-        off = np.concatenate([[0], np.cumsum([len(b) for b in batches])])
+        order, off = self._draw(n, self.sizes[1], epoch, phase, sampled)
         view.steps(cols[0][order], cols[1][order], cols[2][order], cols[3][order] if cols[3] is not None else None, off, scale=scale)
         return view.epoch_loss()
 
     def _common_epoch(self, epoch, phase):
-        n = len(self._entities)
+        n = int(self._entities.numel())
         if n == 0:
             return 0.0
-        B = self.sizes[2]
-        rng = self._rng(epoch, phase)
-        steps = int(math.ceil(n / B))
-        bs = B if steps > 1 else n
-        for _ in range(steps):      # random.sample(entity_list, B) (code/MultiKE_model.py:446)
-            self.common.step(self._entities[rng.choice(n, bs, replace=False)])
+        order, off = self._draw(n, self.sizes[2], epoch, phase, True)      # random.sample(entity_list, B) (code/MultiKE_model.py:446)
+        self.common.steps(self._entities[order], off)
         return self.common.epoch_loss()
 
     def _mapping_epoch(self, epoch, phase):
-        n = len(self._entities)
+        n = int(self._entities.numel())
         if n == 0 or self.mapping is None:
             return 0.0
-        B = self.sizes[2]
-        rng = self._rng(epoch, phase)
-        steps = int(math.ceil(n / B))
-        bs = B if steps > 1 else n
-        for _ in range(steps):
-            self.mapping.step(self._entities[rng.choice(n, bs, replace=False)])
+        order, off = self._draw(n, self.sizes[2], epoch, phase, True)
+        ids = self._entities[order].cpu().numpy()
+        for s in range(len(off) - 1):
+            self.mapping.step(ids[off[s]:off[s + 1]])
         return self.mapping.epoch_loss()
 
     def epoch_ssl(self, i: int) -> dict:

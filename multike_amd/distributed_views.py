@@ -199,10 +199,16 @@ class ShardedAttributeView:
                 lo, hi = int(step_off[s]), int(step_off[s + 1])
                 self.step(ih[lo:hi], ia[lo:hi], iv[lo:hi], None if w is None else w[lo:hi], scale)
             return
-        ih = np.asarray(ih, dtype=np.int64)
-        mine = np.nonzero(ih % self.world == self.rank)[0]
-        off = np.searchsorted(mine, np.asarray(step_off, dtype=np.int64))      # this rank's slice of every step
-        staged = be.stage(ih[mine] // self.world, np.asarray(ia)[mine], np.asarray(iv)[mine], None if w is None else np.asarray(w)[mine])
+        if isinstance(ih, torch.Tensor):     # the epoch already on the device (shuffled there): filter by ownership there too
+            mine = torch.nonzero(ih % self.world == self.rank).reshape(-1)
+            off = torch.searchsorted(mine, torch.as_tensor(np.asarray(step_off, dtype=np.int64), device=ih.device)).cpu().numpy()
+            i32 = lambda t: t.to(torch.int32).contiguous()
+            staged = (i32(ih[mine] // self.world), i32(ia[mine]), i32(iv[mine]), None if w is None else w[mine].to(torch.float32).contiguous())
+        else:
+            ih = np.asarray(ih, dtype=np.int64)
+            mine = np.nonzero(ih % self.world == self.rank)[0]
+            off = np.searchsorted(mine, np.asarray(step_off, dtype=np.int64))      # this rank's slice of every step
+            staged = be.stage(ih[mine] // self.world, np.asarray(ia)[mine], np.asarray(iv)[mine], None if w is None else np.asarray(w)[mine])
         cm = self.comm
         for s in range(len(step_off) - 1):
             part = tuple(None if t is None else t[off[s]:off[s + 1]] for t in staged)
@@ -262,7 +268,7 @@ class HipCommonSpaceBackend:
     def step(self, view, rows):
         if len(rows) == 0:
             return
-        idx = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int32), device="cuda")
+        idx = rows if isinstance(rows, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int32), device="cuda")
         cvw = view.cv_weight
         terms = [(self.ent, idx, self.name, idx, cvw * view.cv_name_weight), (self.ent, idx, self.rv, idx, cvw),
                  (self.ent, idx, self.av, idx, cvw)]
@@ -295,6 +301,15 @@ class ShardedCommonSpace:
         """One common-space step on the GLOBAL sample of entity ids (distinct; identical on every rank)."""
         _, rows = _owned(entities, self.rank, self.world)
         self.backend.step(self, rows)
+
+    def steps(self, entities: torch.Tensor, step_off):
+        """Consecutive steps over a device tensor of GLOBAL entity ids in step order (step s = [step_off[s], step_off[s + 1])):
+        ownership filtered on the device, one host read of the slice boundaries per call."""
+        mine = torch.nonzero(entities % self.world == self.rank).reshape(-1)
+        off = torch.searchsorted(mine, torch.as_tensor(np.asarray(step_off, dtype=np.int64), device=entities.device)).cpu().numpy()
+        rows = (entities[mine] // self.world).to(torch.int32).contiguous()
+        for s in range(len(step_off) - 1):
+            self.backend.step(self, rows[off[s]:off[s + 1]])
 
     def epoch_loss(self) -> float:
         t = self.backend.take_loss()
