@@ -1,5 +1,5 @@
 """ShardedITC at G = 1 (no collectives) at C2-synth scale: what the sharded epoch driver costs on one GPU, next to the
-single-GPU driver's epoch (tools/epoch_bench.py).  python tools/sharded_epoch_bench.py [n_ent]"""
+single-GPU driver's epoch (tools/epoch_bench.py; same default: 10 negatives per positive).  python tools/sharded_epoch_bench.py [n_ent] [neg]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +8,7 @@ from multike_amd.synthetic import SyntheticKGs
 from oracle import attr_cnn_oracle as ao
 
 n_ent = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+neg = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d, n_rel, n_attr, n_lit = 75, 550, 600, 100_000
 kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, seed=5)
 rng = np.random.default_rng(5)
@@ -20,7 +21,7 @@ lists = {"attr": list(zip(ri(n_ent, n_at).tolist(), ri(n_attr, n_at).tolist(), r
          "ckge_rel": list(zip(ri(n_ent, n_ck).tolist(), ri(n_rel, n_ck).tolist(), ri(n_ent, n_ck).tolist())),
          "ckgp_rel": [], "ckge_attr": list(zip(ri(n_ent, n_ck).tolist(), ri(n_attr, n_ck).tolist(), ri(n_lit, n_ck).tolist())),
          "ckga_attr": [], "entities": list(range(n_ent))}
-m = ShardedITC(kgs, tables, cnn, lists, 0, 1, batch_size=5000, attribute_batch_size=5000, entity_batch_size=5000, neg_triple_num=25, seed=5)
+m = ShardedITC(kgs, tables, cnn, lists, 0, 1, batch_size=5000, attribute_batch_size=5000, entity_batch_size=5000, neg_triple_num=neg, seed=5)
 for i in range(1, 4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = m.epoch(i)
