@@ -56,6 +56,11 @@ class HostStagedViewComm(ViewComm):
         t.copy_(c)
 
 
+def _gather_device():
+    """Where the shards meet in gather(): the GPU under RCCL ("nccl" moves device tensors only), the host under gloo."""
+    return torch.device("cuda") if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+
+
 def _owned(ids: np.ndarray, rank: int, world: int):
     """(positions of the batch this rank trains, their local rows)."""
     ids = np.asarray(ids, dtype=np.int64)
@@ -232,17 +237,17 @@ class ShardedAttributeView:
         """(full av_ent table [n_ent, dim], attr table, CNN parameter dict) — tests / checkpoint."""
         ent, attr, params = self.backend.tables()
         pad = -(-self.n_ent // self.world)
-        mine = torch.zeros(pad, self.dim, dtype=torch.float64)
+        mine = torch.zeros(pad, self.dim, dtype=torch.float64, device=_gather_device())
         n_local = len(range(self.rank, self.n_ent, self.world))
         mine[:n_local] = torch.as_tensor(ent[:n_local], dtype=torch.float64)
         if self.world == 1 or not dist.is_initialized():
-            return mine[:n_local].numpy(), attr, params
+            return mine[:n_local].cpu().numpy(), attr, params
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         full = np.zeros((self.n_ent, self.dim))
         for r in range(self.world):
             n = len(range(r, self.n_ent, self.world))
-            full[r::self.world] = parts[r][:n].numpy()
+            full[r::self.world] = parts[r][:n].cpu().numpy()
         return full, attr, params
 
 
@@ -321,16 +326,16 @@ class ShardedCommonSpace:
         for k, v in self.backend.tables().items():
             pad = -(-self.n_ent // self.world)
             n_local = len(range(self.rank, self.n_ent, self.world))
-            mine = torch.zeros(pad, self.dim, dtype=torch.float64)
+            mine = torch.zeros(pad, self.dim, dtype=torch.float64, device=_gather_device())
             mine[:n_local] = torch.as_tensor(v[:n_local], dtype=torch.float64)
             if self.world == 1 or not dist.is_initialized():
-                out[k] = mine[:n_local].numpy()
+                out[k] = mine[:n_local].cpu().numpy()
                 continue
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(parts, mine)
             full = np.zeros((self.n_ent, self.dim))
             for r in range(self.world):
-                full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].numpy()
+                full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].cpu().numpy()
             out[k] = full
         return out
 
@@ -459,15 +464,15 @@ class ShardedSpaceMapping:
         ent, M = self.backend.tables()
         pad = -(-self.n_ent // self.world)
         n_local = len(range(self.rank, self.n_ent, self.world))
-        mine = torch.zeros(pad, self.dim, dtype=torch.float64)
+        mine = torch.zeros(pad, self.dim, dtype=torch.float64, device=_gather_device())
         mine[:n_local] = torch.as_tensor(ent[:n_local], dtype=torch.float64)
         if self.world == 1 or not dist.is_initialized():
-            return mine[:n_local].numpy(), M
+            return mine[:n_local].cpu().numpy(), M
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         full = np.zeros((self.n_ent, self.dim))
         for r in range(self.world):
-            full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].numpy()
+            full[r::self.world] = parts[r][:len(range(r, self.n_ent, self.world))].cpu().numpy()
         return full, M
 
 
