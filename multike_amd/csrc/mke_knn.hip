@@ -38,10 +38,11 @@ struct SimSelectParams {
   int32_t* __restrict__ seg_count;   // [rows][n_seg]
 };
 
+// KS <= 5 (dim <= 80): three blocks per CU (the 43 KB of LDS allow it): the compiler's own choice was 180 + 32 registers = two —
+// 18.3 -> 16.3 ms for 100K x 100K (98 TFLOP/s); the extra wavefront per SIMD covers the epilogue's compare / append between
+// MFMA bursts.  Wider rows would only fit by spilling (10 .. 330 registers at KS 6 .. 16): left to the compiler.
 template <int KS>  // kpad / 16
-// three blocks per CU (the 43 KB of LDS allow it): the compiler's own choice was 180 + 32 registers = two — 18.3 -> 16.3 ms
-// for 100K x 100K (98 TFLOP/s); the extra wavefront per SIMD covers the epilogue's compare / append between MFMA bursts
-__global__ __launch_bounds__(MKE_BLOCK, 3) void k_sim_select(const SimSelectParams p) {
+__global__ __launch_bounds__(MKE_BLOCK, KS <= 5 ? 3 : 1) void k_sim_select(const SimSelectParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int strip0 = p.row_lo + blockIdx.x * SIMT_BM + wv * 32;
