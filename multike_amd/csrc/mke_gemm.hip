@@ -337,7 +337,9 @@ struct GemmTallPlus {
   GemmParams t, g;
   int tall_blocks;
 };
-__global__ __launch_bounds__(MKE_BLOCK) void k_gemm_tallsplit_plus(const GemmTallPlus b) {
+// three blocks per CU: at the compiler's own 158 + 20 registers (two) 512 of the launch's 699 blocks were resident — the two
+// products (~11 us each alone) took 16.2 us together, 14.9 us now
+__global__ __launch_bounds__(MKE_BLOCK, 3) void k_gemm_tallsplit_plus(const GemmTallPlus b) {
   if ((int)blockIdx.x < b.tall_blocks) {   // block-uniform
     __shared__ float s_part[MKE_BLOCK / 64][5][4][64];
     gemm_tall_block<5, 20, false>(b.t, blockIdx.x % b.t.gx, blockIdx.x / b.t.gx, s_part);
