@@ -62,7 +62,8 @@ const char* mke_last_error(void);
  *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
  *                     kernels themselves are selected by which entry point is called)
  *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per
- *                     half; default 12, 0 = never) — the reference's default of 10 negatives fills a whole wavefront badly
+ *                     half: half as many wavefronts, all resident at once); -1 (default) = by row width — rows up to 128
+ *                     floats: always, wider rows: up to 31 negatives; 0 = never
  *   "score_offsets32"   : 1 (default) = the training kernel addresses rows with 32-bit byte offsets when the tables are
  *                     below 4 GB; 0 = 64-bit addresses always
  *   "score_lane_ids"    : 1 (default) = the training kernel fetches a group's negative ids and reference counts once, one

@@ -29,7 +29,7 @@ int check_launch(const char* what) {
 
 namespace mke {
 int g_score_splits = 0;
-int g_score_half_max = 12;   // groups of <= 12 negatives: two groups per wavefront (mke_score.hip)
+int g_score_half_max = -1;   // largest neg_per_pos scored two groups per wavefront; -1 = by row width (mke_score.hip), 0 = never
 int g_score_o32 = 1;         // 32-bit row offsets in the training kernel when the tables allow (mke_score.hip, row_at)
 int g_count_in_score = 1;    // runner: the next step's reference counting rides in the score launch (0: in the update launch)
 int g_score_lane_ids = 1;    // training kernel: a group's ids and reference counts fetched once, one negative per lane (mke_score.hip)
@@ -46,7 +46,7 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   }
   if (!strcmp(name, "score_half_groups")) {
     if (old_value) *old_value = mke::g_score_half_max;
-    mke::g_score_half_max = value < 0 ? 0 : (value > 32 ? 32 : value);
+    mke::g_score_half_max = value < 0 ? -1 : (value > 64 ? 64 : value);
     return MKE_OK;
   }
   if (!strcmp(name, "score_offsets32")) {

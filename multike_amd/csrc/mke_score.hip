@@ -546,8 +546,14 @@ static int score_impl(
     // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
     // latency than the two extra gathers in flight did (41.9 -> 40.2 us at the C2 shape)
     constexpr int U = FPL <= 5 ? MKE_SCORE_U : (FPL <= 8 ? 2 : 1);
-    // short groups: two groups per wavefront (mke_set_option("score_half_groups", 0) switches it off)
-    const bool half = neg_per_pos > 0 && neg_per_pos <= g_score_half_max && splits == 1;
+    // two groups per wavefront (a half-wave each): 5000 groups then need 2.4 wavefronts per SIMD instead of 4.9 and are all
+    // resident at once (the kernel's 112+ registers allow four per SIMD).  Whole epochs, us per step, one / two groups per
+    // wavefront (tools/half_groups_scan.py): dim 75: N 10 35.2 / 32.7, N 25 56.4 / 53.2, N 64 136 / 133; dim 128: N 25 89.7 / 83.6,
+    // N 64 209 / 201; dim 200: N 25 143 / 140, N 40 208 / 210, N 64 312 / 326; dim 256, N 64 (C5): 238 / 277 us per launch.
+    // Default: rows up to 128 floats always, wider rows up to 31 negatives (mke_set_option("score_half_groups", n): up to
+    // n negatives at every width; 0: never).
+    const int half_max = g_score_half_max >= 0 ? g_score_half_max : (FPL <= 8 ? 64 : 31);
+    const bool half = neg_per_pos > 0 && neg_per_pos <= half_max && splits == 1;
     if (stage_keys) {
       // deterministic mode: staging stores instead of atomics
       if (half) {

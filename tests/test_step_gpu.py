@@ -140,7 +140,9 @@ def test_variants(variant):
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=ROW_RTOL, atol=ROW_ATOL)
 
 
-@pytest.mark.parametrize("P,N,half", [(333, 10, 12), (333, 10, 0), (1, 3, 12), (64, 12, 12), (77, 1, 12)])
+@pytest.mark.parametrize("P,N,half", [(333, 10, 12), (333, 10, 0), (1, 3, 12), (64, 12, 12), (77, 1, 12),
+                                      # long groups (more entries than a half-wave has lanes: several id blocks per group)
+                                      (333, 25, 64), (101, 40, 64), (51, 64, 64), (333, 25, -1)])
 def test_two_groups_per_wavefront_equals_one(P, N, half):
     """Short groups are scored two per wavefront (each half owns a group; `score_half_groups`): same losses and tables as
     the one-group-per-wavefront form and as the oracle, odd group counts (the last wavefront's second half idle) included."""
