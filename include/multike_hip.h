@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 100 /* 0.1.0 */
+#define MKE_VERSION 101 /* 0.1.1: mke_align_rank gained the `ties` output (argument order changed) */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0

@@ -5,8 +5,10 @@ The reference calls `conv()` (code/MultiKE_model.py:34-63) from three graphs; on
 graph.  Parameters live in one packed float32 buffer (layout in include/multike_hip.h §8); each optimizer keeps its
 own Adagrad accumulator for it, like every other variable.
 
-The step is HIP kernels for the conv stack and the loss tail, and three library GEMMs (rocBLAS through torch.matmul)
-for the dense layer — the only contractions on the path (flat[n,4d] @ W[4d,d] and its two gradients).
+The training step is ONE native call (`mke_attr_step` / `mke_attr_steps`, multike_amd/csrc/mke_attr_cnn.hip): hand-written
+HIP kernels for the conv stack, the loss tail and the updates; the dense layer's three products — the only contractions on
+the path, flat[n,4d] @ W[4d,d] and its two gradients — on the library's own f32 MFMA tiles (mke_gemm.hip).  No library GEMM,
+no autograd.
 """
 from __future__ import annotations
 

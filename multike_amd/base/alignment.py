@@ -20,12 +20,9 @@ def _prep(x, device, normalize):
     return t
 
 
-def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
-    """(rank [n1] float64, best [n1] int64): rank_i = #{j: sim_ij > sim_ii} + (#{j: sim_ij == sim_ii} - 1) / 2; best_i =
-    argmax_j sim_ij.  Ties: the reference's argsort / argpartition leaves the gold at an arbitrary position among the columns
-    that tie with it (code/base/alignment.py:152-160); the MID-rank is reported here, so degenerate inputs — a zero name
-    vector has similarity 0 to every column, duplicated embeddings — do not count as Hits@1 (counting only strictly
-    greater columns would resolve every tie in the gold's favour).  Without ties this is the reference's rank exactly."""
+def alignment_counts(embed1, embed2, normalize=True, device="cuda"):
+    """(greater [n1] int64, ties [n1] int64, best [n1] int64): greater_i = #{j: sim_ij > sim_ii}, ties_i = #{j: sim_ij ==
+    sim_ii} (the gold column included, so >= 1), best_i = argmax_j sim_ij."""
     a, b = _prep(embed1, device, normalize), _prep(embed2, device, normalize)
     n1, d = a.shape
     n2 = b.shape[0]
@@ -41,7 +38,29 @@ def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
     best = torch.zeros(n1, dtype=torch.int64, device=device)
     _lib.align_rank(ap, bp, kpad, n1, n2, rank, best, ties)
     col = 0xFFFFFFFF - (best & 0xFFFFFFFF)
-    return rank.double() + (ties.double() - 1.0).clamp_min(0.0) * 0.5, col
+    return rank.long(), ties.long().clamp_min(1), col
+
+
+def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):
+    """(rank [n1] float64, best [n1] int64): rank_i = greater_i + (ties_i - 1) / 2 — the gold's EXPECTED 0-based position when
+    the columns that tie with it are ordered at random.  The reference's argsort / argpartition leaves the gold at an arbitrary
+    position among them (code/base/alignment.py:152-160).  Without ties this is the reference's rank exactly."""
+    greater, ties, col = alignment_counts(embed1, embed2, normalize, device)
+    return greater.double() + (ties.double() - 1.0) * 0.5, col
+
+
+def tie_aware_metrics(greater, ties, top_k):
+    """Expected Hits@k counts / MR / MRR over a uniformly random order of the columns tied with the gold: the gold's position
+    is uniform on [greater, greater + ties - 1], so P(position < k) = clamp((k - greater) / ties, 0, 1) — a gold tied with one
+    other column is HALF a Hits@1, not a whole one (a threshold on the mid-rank 0.5 < 1 would count it fully) — E[position + 1]
+    = greater + (ties + 1) / 2, E[1 / (position + 1)] = (H(greater + ties) - H(greater)) / ties.  Degenerate inputs (a zero
+    name vector ties with every column; duplicated embeddings) therefore score their chance level.  Without ties
+    (ties == 1) these are exactly the reference's integer counts (code/base/alignment.py:141-163)."""
+    g, t = greater.double(), ties.double()
+    hits = [float(((k - g) / t).clamp(0.0, 1.0).sum()) for k in top_k]
+    mr = float((g + (t + 1.0) * 0.5).mean())
+    mrr = float(((torch.special.digamma(g + t + 1.0) - torch.special.digamma(g + 1.0)) / t).mean())
+    return hits, mr, mrr
 
 
 def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
@@ -54,12 +73,10 @@ def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csl
         raise _lib.MultiKEHipError(f"greedy_alignment: metric {metric!r} is not built (the reference uses 'inner')")
     assert 1 in top_k
     t = time.time()
-    rank, best = alignment_ranks(embed1, embed2, normalize)
-    num = rank.numel()
-    hits = np.array([float((rank < k).sum()) for k in top_k]) / num * 100
-    hits = np.round(hits, 3)
-    mr = float((rank + 1).mean())
-    mrr = float((1.0 / (rank + 1)).mean())
+    greater, ties, best = alignment_counts(embed1, embed2, normalize)
+    num = greater.numel()
+    hits, mr, mrr = tie_aware_metrics(greater, ties, top_k)
+    hits = np.round(np.array(hits) / num * 100, 3)
     alignment_rest = set(zip(range(num), best.cpu().tolist()))
     cost = time.time() - t
     if accurate:

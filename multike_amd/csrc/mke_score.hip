@@ -193,7 +193,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       auto fetch_block = [&](int b0) {
         nblk = min(LPG, nend_ - b0);
         const bool has = active && lane - lbase < nblk;
-        const int64_t idx = g * (int64_t)npp_ + b0 + (has ? lane - lbase : 0);
+        const int64_t idx = g * (int64_t)npp_ + (has ? b0 + (lane - lbase) : 0);   // an empty slice (b0 >= npp under a forced `score_splits`) reads the group's first id, never past the arrays
         const int nh = p.nh[idx], nr = p.nr[idx], nt = p.nt[idx];
         wl = p.nw ? p.nw[idx] : 1.0f;
         const bool dh = nh != ph, dt = nt != pt;

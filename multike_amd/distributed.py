@@ -394,18 +394,21 @@ class ShardedRelationTrainer:
         return full
 
     def check(self) -> dict:
-        """Synchronising: raise if ANY rank's row set overflowed the exchange capacity since the last check (the steps
+        """Synchronising: raise if ANY rank's row set overflowed the exchange capacity at any time (the steps
         concerned dropped the overflowing rows' contributions: their results are invalid); returns the capacity and the
         largest per-owner request count any rank has seen.  Call it before results are used (bench.py: after the timed
         region; training: `epoch_loss` calls it every epoch)."""
+        if self._cuda:   # look-ahead plans already in flight on the plan stream write both words: read them behind it
+            torch.cuda.current_stream().wait_stream(self._plan_stream)
         t = torch.stack([self._overflow[0].to(torch.int64), self._max_rows[0].to(torch.int64)])
         if dist.is_initialized() and self.world > 1:
             self.comm.all_reduce(t, op=dist.ReduceOp.MAX)
         over, worst = int(t[0]), int(t[1])
-        self._overflow.zero_()
+        # the flag is STICKY (never cleared): an overflow invalidates the trainer's state for good, and clearing it here could
+        # erase one raised by a plan that was enqueued between this read and the clear
         if over:
             raise _lib.MultiKEHipError(f"row-set capacity {self.C} per owner exceeded (largest request seen: > {self.C}): the "
-                                       f"steps since the last check dropped rows; rebuild the trainer with a larger capacity")
+                                       f"steps concerned dropped rows; rebuild the trainer with a larger capacity")
         return {"capacity_rows_per_owner": self.C, "max_rows_per_owner_seen": worst}
 
     def epoch_loss(self) -> float:

@@ -35,13 +35,17 @@ class ShardedITC:
                  attribute_batch_size: int = 5000, entity_batch_size: int = 5000, neg_triple_num: int = 10,
                  learning_rate: float = 0.001, itc_learning_rate: float = 0.004, cv_name_weight: float = 1.0, cv_weight: float = 1.0,
                  seed: int = 0, comm_oc=None, comm_views=None, mapping_matrices=None, mapping_learning_rate: float = 0.01,
-                 orthogonal_weight: float = 2.0):
+                 orthogonal_weight: float = 2.0, start_predicate_soft_alignment: int = 0):
         """kgs: the two KGs' relation triples (multike_amd.synthetic.SyntheticKGs / base.kgs.KGs interface: `triples`,
         `entities(k)`, `ent_range`); tables: full float32 arrays {"rv_ent", "av_ent", "ent", "name", "rel", "attr", "lit"}
         (every rank passes the same; each keeps its shard); cnn_sets: three CNN parameter dicts (attribute view, ckge, ckga);
         lists: {"attr": [(h, a, v, w)], "ckge_rel": [(h, r, t)], "ckgp_rel": [(h, r, t, w)], "ckge_attr": [(h, a, v)],
-        "ckga_attr": [(h, a, v, w)], "entities": [ids]}; batch sizes are GLOBAL (a step trains that many across the ranks)."""
+        "ckga_attr": [(h, a, v, w)], "entities": [ids]}; batch sizes are GLOBAL (a step trains that many across the ranks).
+        start_predicate_soft_alignment: the two predicate-alignment phases (ckgp_rel, ckga_attr) run in epoch i only when
+        i > this (code/MultiKE_CSL.py:62-70, code/args.json "start_predicate_soft_alignment": 10); their lists are replaced
+        between epochs with `set_lists` (the reference rebuilds them every 10 epochs, code/MultiKE_CSL.py:80-87)."""
         self.rank, self.world, self.seed = rank, world, int(seed)
+        self.start_soft = int(start_predicate_soft_alignment)
         d = tables["ent"].shape[1]
         self.n_ent = n_ent = tables["ent"].shape[0]
         shard = lambda k, norm=True, train=True: EmbeddingTable(max(1, len(range(rank, n_ent, world))), d, k, normalize=norm,
@@ -57,9 +61,11 @@ class ShardedITC:
         oc = dict(rank=rank, world=world, seed=seed, lr=learning_rate, comm=comm_oc, ent_table=self.rv_ent, rel_table=self.rel, n_ent=n_ent)
         self.relation = OwnerComputesTrainer(kgs, None, None, max(1, batch_size // world), neg_triple_num, opt_name="relation",
                                              tag_base=next(base), **oc)
-        mk_list = lambda key, opt: (OwnerComputesTrainer(None, None, None, batch_size, 0, opt_name=opt, scale=2.0, tag_base=next(base),
-                                                         batcher=TripleListBatcher(lists[key], batch_size, device="cuda", seed=seed), **oc)
-                                    if len(lists.get(key, ())) else None)
+        self._oc_args, self._list_tags, self._list_gen = oc, {}, {}
+
+        def mk_list(key, opt):
+            self._list_tags.setdefault(key, next(base))
+            return self._make_list_trainer(key, lists.get(key, ()))
         self.ckge_rel, self.ckgp_rel = mk_list("ckge_rel", "ckge_rel"), mk_list("ckgp_rel", "ckgp_rel")
         av = dict(rank=rank, world=world, lr=learning_rate, comm=comm_views, tables=(self.av_ent, self.attr, self.lit), n_ent=n_ent)
         self.attr_views = [ShardedAttributeView(None, None, None, cnn_sets[k], opt_name=name, **av)
@@ -87,6 +93,44 @@ class ShardedITC:
         self._oc_steps = {id(t): 0 for t in (self.relation, self.ckge_rel, self.ckgp_rel) if t is not None}
 
     # ------------------------------------------------------------------------------------------------
+    def _make_list_trainer(self, key, triples):
+        """Owner-computes trainer of a cross-KG relation loop over `triples` (positives only, x 2).  A replacement trainer
+        (set_lists) keeps the loop's optimizer — the Adagrad slots live in the tables under the loop's name — and continues
+        its tag range; its draws are seeded by (seed, generation) so that a new list does not replay the old one's."""
+        if not len(triples):
+            return None
+        gen = self._list_gen.get(key, 0)
+        self._list_gen[key] = gen + 1
+        bs = self.sizes[0]
+        tr = OwnerComputesTrainer(None, None, None, bs, 0, opt_name=key, scale=2.0, tag_base=self._list_tags[key],
+                                  batcher=TripleListBatcher(triples, bs, device="cuda", seed=self.seed + 7919 * gen),
+                                  **self._oc_args)
+        return tr
+
+    def set_lists(self, **lists):
+        """Replace supervision lists between epochs: `ckgp_rel=[(h, r, t, w)]`, `ckga_attr=[(h, a, v, w)]` after a soft
+        predicate-alignment update (code/MultiKE_CSL.py:80-87), or any of the other keys.  Every rank must pass the same
+        lists.  Optimizer state is untouched (the slots belong to the tables / CNN sets)."""
+        dev = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+        for key, lst in lists.items():
+            if key in ("ckge_rel", "ckgp_rel"):
+                old = getattr(self, key)
+                if old is not None:
+                    self._list_tags[key] = old.tag            # continue the tag range: flags of earlier steps stay stale
+                    self._oc_steps.pop(id(old), None)
+                new = self._make_list_trainer(key, lst)
+                setattr(self, key, new)
+                if new is not None:
+                    self._oc_steps[id(new)] = 0
+            elif key in ("attr", "ckge_attr", "ckga_attr"):
+                self.lists[key] = lst
+                self._cols[key] = tuple(dev(c, torch.float32 if j == 3 else torch.int64) for j, c in enumerate(_columns(lst)))
+            elif key == "entities":
+                self.lists[key] = lst
+                self._entities = dev(np.asarray(lst, dtype=np.int64), torch.int64)
+            else:
+                raise _lib.MultiKEHipError(f"set_lists: unknown list {key!r}")
+
     def _oc_epoch(self, tr):
         if tr is None:
             return 0.0
@@ -135,23 +179,29 @@ class ShardedITC:
             self.mapping.step(ids[off[s]:off[s + 1]])
         return self.mapping.epoch_loss()
 
-    def epoch_ssl(self, i: int) -> dict:
-        """The SSL schedule's training phases (code/MultiKE_Late.py:216-243): the six view phases, then the space mapping."""
-        out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel),
-               "ckgp_rel": self._oc_epoch(self.ckgp_rel)}
+    def _view_phases(self, i: int) -> dict:
+        """The six view / cross-KG phases of epoch i in the reference's order; the two predicate-alignment phases only when
+        i > start_predicate_soft_alignment (code/MultiKE_CSL.py:62-70, code/MultiKE_Late.py:218-228) — a skipped phase is
+        absent from the result."""
+        soft = i > self.start_soft
+        out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel)}
+        if soft:
+            out["ckgp_rel"] = self._oc_epoch(self.ckgp_rel)
         out["attribute"] = self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False)
         out["ckge_attr"] = self._attr_epoch(self.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)
-        out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
+        if soft:
+            out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
+        return out
+
+    def epoch_ssl(self, i: int) -> dict:
+        """The SSL schedule's training phases (code/MultiKE_Late.py:216-243): the six view phases, then the space mapping."""
+        out = self._view_phases(i)
         out["mapping"] = self._mapping_epoch(i, 4)
         return out
 
     def epoch(self, i: int) -> dict:
         """The seven training phases of epoch i in the reference's order (code/MultiKE_CSL.py:62-79); returns their summed losses."""
-        out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel),
-               "ckgp_rel": self._oc_epoch(self.ckgp_rel)}
-        out["attribute"] = self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False)
-        out["ckge_attr"] = self._attr_epoch(self.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)
-        out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
+        out = self._view_phases(i)
         out["common"] = self._common_epoch(i, 3)
         return out
 

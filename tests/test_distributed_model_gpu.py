@@ -110,3 +110,36 @@ def test_two_ranks_equal_one_rank_over_two_epochs(ssl):
     assert np.abs(ref["av"] - tables["av_ent"]).max() > 1e-4 and np.abs(ref["attr"] - tables["attr"]).max() > 1e-5
     for t in (m1.rv_ent, m1.av_ent, m1.ent, m1.rel, m1.attr):
         assert float(t.grad.abs().max()) == 0.0
+
+
+def test_soft_alignment_gate_and_list_refresh_one_rank():
+    """code/MultiKE_CSL.py:62-70, 80-87: the two predicate-alignment phases run only when i > start_predicate_soft_alignment,
+    and their lists are rebuilt between epochs (`set_lists`) without resetting the loops' optimizers."""
+    from multike_amd.distributed_model import ShardedITC
+    kgs, tables, cnn, lists = _setup()
+    m = ShardedITC(kgs, tables, cnn, lists, 0, 1, batch_size=B, attribute_batch_size=AB, entity_batch_size=EB, neg_triple_num=NEG,
+                   learning_rate=0.01, itc_learning_rate=0.02, seed=SEED, start_predicate_soft_alignment=1)
+    first = m.epoch(1)
+    assert "ckgp_rel" not in first and "ckga_attr" not in first and first["relation"] > 0 and first["ckge_rel"] > 0
+    # nothing has trained under the gated loops' optimizers yet: their Adagrad slots are still at the initial 0.1
+    assert "ckgp_rel" not in m.rv_ent.slots or float((m.rv_ent.slot("ckgp_rel")[:, :DIM] - 0.1).abs().max()) == 0.0
+    second = m.epoch(2)
+    assert second["ckgp_rel"] > 0 and second["ckga_attr"] > 0
+    acc_before = m.rel.slot("ckgp_rel").clone()
+    assert float((acc_before[:, :DIM] - 0.1).abs().max()) > 0.0
+    steps_before = m.ckgp_rel.steps
+    rng = np.random.default_rng(3)
+    new_rel = [(int(h), int(r), int(t_), 0.5) for h, r, t_ in zip(rng.integers(0, N_ENT, 900), rng.integers(0, N_REL, 900),
+                                                                   rng.integers(0, N_ENT, 900))]
+    new_attr = [(int(h), int(a), int(v), 0.9) for h, a, v in zip(rng.integers(0, N_ENT, 50), rng.integers(0, N_ATTR, 50),
+                                                                 rng.integers(0, N_LIT, 50))]
+    m.set_lists(ckgp_rel=new_rel, ckga_attr=new_attr)
+    assert m.ckgp_rel.steps == 3 and steps_before == 1           # ceil(900 / 400) against ceil(300 / 400)
+    third = m.epoch(3)
+    assert third["ckgp_rel"] > 0 and third["ckga_attr"] > 0
+    acc_after = m.rel.slot("ckgp_rel")
+    assert bool((acc_after >= acc_before).all()) and float((acc_after - acc_before).abs().max()) > 0.0   # same slot, grown
+    m.set_lists(ckgp_rel=[])                                      # an empty list switches the phase off
+    assert m.epoch(4)["ckgp_rel"] == 0.0
+    for t in (m.rv_ent, m.rel, m.av_ent, m.attr):
+        assert float(t.grad.abs().max()) == 0.0

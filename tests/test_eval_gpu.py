@@ -54,6 +54,7 @@ def test_ties_are_ranked_at_mid_rank():
     e1 = e2.copy()
     e1[7] = 0.0                                   # no name vector: sim = 0 against all n columns
     e2[11] = e2[10]                               # column 11 duplicates column 10: row 10's gold ties with column 11
+    e1[11] = e2[10]                               # ... and row 11's gold with column 10
     rank, _ = alignment_ranks(e1, e2)
     r = rank.cpu().numpy()
     assert r[7] == (n - 1) / 2.0                  # n columns tie (the gold among them): mid-rank
@@ -62,7 +63,15 @@ def test_ties_are_ranked_at_mid_rank():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         _, hits1, mr, mrr = greedy_alignment(e1, e2, [1, 10], 1, "inner", True, 0, True)
-    assert hits1 < 100.0
+    # expected values over a random order of the tied columns: rows 10 and 11 are half a Hits@1 each (their golds tie with one
+    # other column), row 7 is 1/n of one; every other row is a whole one
+    exp_hits1 = (n - 3 + 0.5 + 0.5 + 1.0 / n) / n * 100
+    assert hits1 == round(exp_hits1, 3)
+    H = lambda m: sum(1.0 / i for i in range(1, m + 1))
+    exp_mrr = (n - 3 + 2 * (1 + 0.5) / 2 + H(n) / n) / n
+    assert abs(mrr - exp_mrr) < 1e-12
+    exp_mr = (n - 3 + 2 * 1.5 + (n + 1) / 2) / n
+    assert abs(mr - exp_mr) < 1e-12
 
 
 def test_neighbour_table_matches_reference_definition():
