@@ -414,6 +414,46 @@ def data_fixture(ref_kgs, ref_utils, ref_pa, out_json):
     out_json.update(res)
 
 
+def schedule_fixture(out_json):
+    """The reference's epoch schedules, EXECUTED: `MultiKE_CV.run` (code/MultiKE_CSL.py:36-107) and `MultiKE_Late.run`
+    (code/MultiKE_Late.py:201-280) are imported unmodified and run on a recording stand-in model (tests/schedule_mock.py:
+    instances are created without __init__, every train / valid / test / save call appends to a trace).  TensorFlow is only
+    touched at import time (default arguments such as `dtype=tf.float32`), so the forwarder module answers unknown
+    attributes with a placeholder."""
+    import contextlib
+    import io
+    from unittest import mock
+    sys.path.insert(0, os.path.dirname(HERE))
+    import schedule_mock as sm
+    tf = sys.modules["tensorflow"]
+    tf.__getattr__ = lambda name: mock.MagicMock(name="tf." + name)
+    tf.nn.__getattr__ = lambda name: mock.MagicMock(name="tf.nn." + name)
+    ref_csl = importlib.import_module("MultiKE_CSL")
+    ref_late = importlib.import_module("MultiKE_Late")
+    ref_bat = importlib.import_module("base.batch")
+
+    class _Manager:                       # mp.Manager().Queue(): the queues are only passed through to the (mocked) loops
+        def Queue(self):
+            return None
+
+    out_json["schedules"] = {}
+    for method, mod, cls in (("ITC", ref_csl, ref_csl.MultiKE_CV), ("SSL", ref_late, ref_late.MultiKE_Late)):
+        for name in sm.SCENARIOS:
+            trace = []
+            model = object.__new__(cls)
+            fns = sm.instrument(model, name, trace)
+            patches = [mock.patch.object(mod, "valid", fns["valid"]), mock.patch.object(mod, "test", fns["test"]),
+                       mock.patch.object(ref_bat, "generate_neighbours", fns["neighbours"]),
+                       mock.patch.object(mod.mp, "Manager", _Manager)]
+            if mod is ref_late:
+                patches += [mock.patch.object(mod, "valid_WVA", fns["valid_WVA"]), mock.patch.object(mod, "test_WVA", fns["test_WVA"])]
+            with contextlib.ExitStack() as st, contextlib.redirect_stdout(io.StringIO()):
+                for p_ in patches:
+                    st.enter_context(p_)
+                model.run()
+            out_json["schedules"][f"{method}/{name}"] = trace
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -447,6 +487,10 @@ def main():
     data_fixture(importlib.import_module("base.kgs"), ref_utils, importlib.import_module("predicate_alignment"), dj)
     with open(os.path.join(HERE, "data_golden.json"), "w") as f:
         json.dump(dj, f, separators=(",", ":"), sort_keys=True)
+    sj = {}
+    schedule_fixture(sj)
+    with open(os.path.join(HERE, "schedule_golden.json"), "w") as f:
+        json.dump(sj, f, separators=(",", ":"))
     print("wrote", sorted(os.listdir(HERE)))
 
 
