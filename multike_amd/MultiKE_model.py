@@ -183,6 +183,10 @@ class MultiKE:
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._lists: dict = {}
         self._defer_losses = False      # drivers set it while they enqueue independent phases on two streams
+        # test / debugging hook: `recorder(phase, **index_streams)` is called by every native train_*_1epo with the exact
+        # device index streams the epoch consumed (positives, sampled negatives, weights, step offsets) — what a float64
+        # oracle needs to replay the schedule on identical batches (tests/test_schedule_trace_gpu.py)
+        self._recorder = None
         self._pending: list = []
         if self.args.optimizer not in _HIP_OPTS + _DENSE_OPTS:
             raise _lib.MultiKEHipError(f"optimizer {self.args.optimizer!r}: Adagrad, SGD, Adam or Adadelta")
@@ -353,6 +357,12 @@ class MultiKE:
         if run is not None:
             run.run(0, steps)
             total = run.loss[:steps].sum()
+            if self._recorder is not None:
+                if run.sample_chunk < run.steps or run.overlap:
+                    raise _lib.MultiKEHipError("recorder: the relation runner must sample whole epochs (the default)")
+                N = b.neg_per_pos
+                self._recorder("relation", pos=(b.pos_h[:trained], b.pos_r[:trained], b.pos_t[:trained]),
+                               neg=tuple(x[:trained * N] for x in run.neg), off=b.off[:steps + 1].copy(), neg_per_pos=N)
         else:   # Adam / Adadelta: step-wise (sampler launch -> fused score/gradient -> whole-table updates)
             from .sampling import sample_negatives
             N, total = b.neg_per_pos, None
@@ -418,6 +428,8 @@ class MultiKE:
                 for k, src in enumerate(lst.cols + (lst.w,)):
                     cols[k][dest] = src[:m] if perm is None else src[perm[:m]]
             value = self._run_attr_steps(self._attr_cnn, cols[:3], cols[3], off, 1.0, "attribute").sum()
+            if self._recorder is not None:
+                self._recorder("attribute", cols=tuple(cols[:3]), w=cols[3], off=np.asarray(off).copy())
         # random.shuffle of both weighted lists (:342-343): a device permutation applied when the epoch is laid out
         self._attr_perm = [torch.randperm(l.n, generator=self._gen, device=self.device) if l.n else None for l in (l1, l2)]
         return self._done(_EpochLoss('att. view', epoch, value, total, start))
@@ -431,7 +443,7 @@ class MultiKE:
         calls[lane] += 1
         return (int(getattr(self.args, "seed", 0)) & 0xFFFFFFFF, 0x4D4B45), calls[lane] * 4 + lane
 
-    def _positives_epoch(self, epoch, sup_triples, batch_size, run_fn, label, lane):
+    def _positives_epoch(self, epoch, sup_triples, batch_size, run_fn, label, lane, key=None):
         """Shared loop shape of code/MultiKE_model.py:349-437: steps = ceil(len / B); each step is
         random.sample(sup_triples, B) (B = len if one step).  All steps of the epoch are sampled by one launch and run
         inside one native call; `run_fn(cols, w, step_off)` returns the loss partials [steps, LOSS_PARTIALS]."""
@@ -445,6 +457,8 @@ class MultiKE:
         cols, w, idx = lst.sample_epoch(bs, steps, seed, stream)
         self._last_sample = (seed, stream, lst.n, bs, steps)   # tests replay it with oracle.sampler_oracle.distinct_sample
         ring = run_fn(cols, w, np.arange(steps + 1, dtype=np.int64) * bs)
+        if self._recorder is not None:
+            self._recorder(key, cols=cols, w=w, off=np.arange(steps + 1, dtype=np.int64) * bs)
         return self._done(_EpochLoss(label, epoch, ring.sum(), steps * bs, start))
 
     def _run_attr_steps(self, cnn, cols, w, off, scale, opt_name):
@@ -480,27 +494,27 @@ class MultiKE:
         """code/MultiKE_model.py:349-369."""
         return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
                                      lambda cols, w, off: self._relation_positive_steps(self._ckge_rel, cols, None, off),
-                                     'cross-kg entity inference in rel. view', 0)
+                                     'cross-kg entity inference in rel. view', 0, 'ckge_rel')
 
     def train_cross_kg_entity_inference_attribute_view_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:371-391: 2 * sum log(1+exp(-conv))."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
             lambda cols, w, off: self._run_attr_steps(self._ckge_attr_cnn, cols, None, off, 2.0, "ckge_attr"),
-            'cross-kg entity inference in attr. view', 1)
+            'cross-kg entity inference in attr. view', 1, 'ckge_attr')
 
     def train_cross_kg_relation_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:393-414: weighted 4-tuples, x2."""
         return self._positives_epoch(epoch, sup_triples, self.args.batch_size,
                                      lambda cols, w, off: self._relation_positive_steps(self._ckgp_rel, cols, w, off),
-                                     'cross-kg relation inference in rel. view', 0)
+                                     'cross-kg relation inference in rel. view', 0, 'ckgp_rel')
 
     def train_cross_kg_attribute_inference_1epo(self, epoch, sup_triples):
         """code/MultiKE_model.py:416-437: weighted, not doubled."""
         return self._positives_epoch(
             epoch, sup_triples, self.args.attribute_batch_size,
             lambda cols, w, off: self._run_attr_steps(self._ckga_attr_cnn, cols, w, off, 1.0, "ckga_attr"),
-            'cross-kg attribute inference in attr. view', 1)
+            'cross-kg attribute inference in attr. view', 1, 'ckga_attr')
 
     # --- shared / common space ------------------------------------------------------------------------------
     def _entity_tensor(self, entities):
@@ -543,6 +557,8 @@ class MultiKE:
             ring = run_space_mapping_steps(self._map_state, self.ent_embeds, [self.name_embeds, self.rv_ent_embeds, self.av_ent_embeds],
                                            idx, np.arange(steps + 1, dtype=np.int64) * bs, "shared_comb", tag_base,
                                            self.args.learning_rate, self.args.orthogonal_weight, optimizer=self.args.optimizer)
+            if self._recorder is not None:
+                self._recorder("mapping", idx=idx, off=np.arange(steps + 1, dtype=np.int64) * bs)
             epoch_loss = float(ring.sum()) / (steps * bs)
             print('epoch {} of shared space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
                                                                                                time.time() - start))
@@ -588,6 +604,8 @@ class MultiKE:
                                        [(0, 1, cvw * float(self.args.cv_name_weight)), (0, 2, cvw), (0, 3, cvw)], idx, idx,
                                        np.arange(steps + 1, dtype=np.int64) * bs, g["opt"], tag_base, g["lr"],
                                        optimizer=self.args.optimizer)
+            if self._recorder is not None:
+                self._recorder("common", idx=idx, off=np.arange(steps + 1, dtype=np.int64) * bs)
             epoch_loss = float(ring.sum()) / cvw / (steps * bs) if cvw != 0 else 0.0
             print('epoch {} of common space learning, avg. loss: {:.4f}, time: {:.4f}s'.format(epoch, epoch_loss,
                                                                                                time.time() - start))

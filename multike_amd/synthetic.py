@@ -62,9 +62,23 @@ class SyntheticData:
     train links (code/base/read.py:130-146 semantics: e1's triples re-written onto e2 and vice versa)."""
 
     def __init__(self, n_ent=2000, n_rel=30, n_attr=24, n_values=500, dim=32, triples_per_entity=4.6, attr_per_entity=3.0,
-                 link_share=0.3, seed=7):
+                 link_share=0.3, seed=7, shared_structure=0.0):
+        """shared_structure = p > 0: KG2 is a noisy copy of KG1 — each relation / attribute triple of KG1 is carried over with
+        probability p (entity i <-> entity n/2 + i, predicates mapped into KG2's id range), the rest of KG2 stays random — so
+        that the relation and attribute views have something to align on (p = 0: independent graphs)."""
         rng = np.random.default_rng(seed)
         base = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, triples_per_entity=triples_per_entity, seed=seed)
+        if shared_structure > 0:
+            e1 = n_ent // 2
+            (rlo1, rhi1), (rlo2, rhi2) = base.rel_range
+            t1, t2 = base.triples
+            keep = t1[rng.random(len(t1)) < shared_structure]
+            keep = keep[(keep[:, 0] + e1 < n_ent) & (keep[:, 2] + e1 < n_ent)]
+            copy = np.stack([keep[:, 0] + e1, rlo2 + (keep[:, 1] - rlo1) % max(1, rhi2 - rlo2), keep[:, 2] + e1], 1).astype(np.int32)
+            allt = np.concatenate([copy, t2[:max(0, len(t2) - len(copy))]], 0)
+            key = (allt[:, 0].astype(np.int64) << 38) | (allt[:, 2].astype(np.int64) << 12) | allt[:, 1].astype(np.int64)
+            _, first = np.unique(key, return_index=True)
+            base.triples[1] = allt[np.sort(first)]
         self.base = base
         kgs = _KG()
         kgs.entities_num, kgs.relations_num, kgs.attributes_num = n_ent, n_rel, n_attr
@@ -91,6 +105,11 @@ class SyntheticData:
             n_at = int(kg.entities_num * attr_per_entity)
             at = {(int(rng.integers(lo, hi)), int(rng.integers(alo, max(ahi, alo + 1))), int(rng.integers(0, n_values)))
                   for _ in range(n_at)}
+            if k == 1 and shared_structure > 0:      # KG1's attribute triples carried over onto the counterpart entities
+                a_hi1 = a1
+                at = {t for t in at if rng.random() >= shared_structure}
+                at |= {(h + n1, alo + a % max(1, ahi - alo), v) for (h, a, v) in kg_list[0].local_attribute_triples_list
+                       if rng.random() < shared_structure and h + n1 < n_ent}
             kg.local_attribute_triples_list = sorted(at)
             kg.local_attribute_triples_num = len(at)
             kg.entities_id_dict = kg.relations_id_dict = kg.attributes_id_dict = None

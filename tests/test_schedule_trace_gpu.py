@@ -1,0 +1,156 @@
+"""Whole-schedule parity (SURVEY.md §8 f1 "epoch-loss traces from the CPU oracle"; north_star "per-batch loss within 1e-4,
+reproduces Hits@1/10"): the product's ITC and SSL drivers run their FULL schedules — every training phase of every epoch, the
+soft-alignment gate, validation, the truncated-sampling refresh, and for SSL the shared-space mapping epochs — while a recorder
+captures the exact index streams each phase consumed (positives, the device sampler's negatives, weights, random.sample draws).
+A float64 oracle of the whole model (oracle/model_oracle.py: dense-table semantics, one Adagrad accumulator per optimizer and
+variable as in the reference) then replays the same schedule on the same batches.  Asserted:
+
+  * every phase's printed epoch loss, epoch by epoch, to 1e-4 relative (the north_star tolerance);
+  * every trainable table, the three CNN parameter sets and the mapping matrices after the last epoch, to fp32 tolerance;
+  * Hits@1 / Hits@10 / MRR of the product's evaluator (k_align_rank) on the HIP tables == the float64 evaluator oracle on the
+    oracle's tables, for every view the drivers test.
+
+DBP-WD itself is absent (/root/reference/.MISSING_LARGE_BLOBS); this is the stand-in SURVEY §7 names for its acceptance row."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle as eo
+from oracle.model_oracle import OracleMultiKE
+
+pytestmark = pytest.mark.gpu
+
+PHASE_OF = {
+    "train_relation_view_1epo": "relation", "train_cross_kg_entity_inference_relation_view_1epo": "ckge_rel",
+    "train_cross_kg_relation_inference_1epo": "ckgp_rel", "train_attribute_view_1epo": "attribute",
+    "train_cross_kg_entity_inference_attribute_view_1epo": "ckge_attr", "train_cross_kg_attribute_inference_1epo": "ckga_attr",
+    "train_common_space_learning_1epo": "common", "train_shared_space_mapping_1epo": "mapping",
+}
+DIM = 24
+
+
+def _data():
+    """Two KGs that share 80 % of their relation / attribute structure and whose counterpart entities have noisy copies of one
+    name vector: every view has something to learn, none becomes perfect in a few epochs — the Hits figures sit in the
+    sensitive middle of their range."""
+    from multike_amd.synthetic import SyntheticData
+    data = SyntheticData(n_ent=1800, n_rel=24, n_attr=20, n_values=400, dim=DIM, seed=21, shared_structure=0.8)
+    n1 = data.kgs.entities_num // 2
+    rng = np.random.default_rng(4)
+    base = rng.standard_normal((n1, DIM)).astype(np.float32)
+    nm = np.concatenate([base, base + 0.9 * rng.standard_normal((n1, DIM)).astype(np.float32)])
+    data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
+    return data
+
+
+def _np(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy().copy()
+    if isinstance(v, (tuple, list)):
+        return tuple(_np(x) for x in v)
+    return v
+
+
+def _run(method):
+    from multike_amd.MultiKE_CSL import MultiKE_CV
+    from multike_amd.MultiKE_Late import MultiKE_Late
+    from multike_amd.synthetic import synthetic_args
+    data = _data()
+    args = synthetic_args(dim=DIM, batch_size=900, attribute_batch_size=700, entity_batch_size=500, neg_triple_num=6,
+                          learning_rate=0.03, ITC_learning_rate=0.05, cv_name_weight=0.8, cv_weight=1.5, orthogonal_weight=2,
+                          max_epoch=10, shared_learning_max_epoch=8, start_valid=2, eval_freq=2, start_predicate_soft_alignment=2,
+                          truncated_freq=3, truncated_epsilon=0.9, neg_sampling="truncated", seed=5)
+    model = (MultiKE_CV if method == "ITC" else MultiKE_Late)(data, args, data.predicate_align_model)
+    model.overlap_views = False               # one stream: the phases then run (and are recorded) in the reference's order
+    raw = lambda t: t.raw().cpu().numpy()
+    tables = {"rv_ent": raw(model.rv_ent_embeds), "av_ent": raw(model.av_ent_embeds), "ent": raw(model.ent_embeds),
+              "rel": raw(model.rel_embeds), "attr": raw(model.attr_embeds), "name": data.local_name_vectors, "lit": data.value_vectors}
+    cnn = [c.numpy_params() for c in (model._attr_cnn, model._ckge_attr_cnn, model._ckga_attr_cnn)]
+    maps = [m.detach().cpu().numpy() for m in (model.nv_mapping, model.rv_mapping, model.av_mapping)] if method == "SSL" else None
+    oracle = OracleMultiKE(tables, cnn, maps, learning_rate=args.learning_rate, itc_learning_rate=args.ITC_learning_rate,
+                           cv_name_weight=args.cv_name_weight, cv_weight=args.cv_weight, orthogonal_weight=args.orthogonal_weight)
+    oracle.M0 = None if maps is None else [np.array(m, dtype=np.float64) for m in maps]
+    recs, losses = [], []
+    model._recorder = lambda phase, **kw: recs.append((phase, {k: _np(v) for k, v in kw.items()}))
+    for name, phase in PHASE_OF.items():
+        orig = getattr(model, name)
+        setattr(model, name, (lambda f, ph: lambda *a, **k: losses.append((ph, a[0], f(*a, **k))) or losses[-1][2])(orig, phase))
+    with contextlib.redirect_stdout(io.StringIO()):
+        results = model.run()
+    torch.cuda.synchronize()
+    return model, oracle, recs, losses, results, data, args
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("method", ["ITC", "SSL"])
+def test_whole_schedule_tracks_the_float64_oracle(method):
+    model, oracle, recs, losses, results, data, args = _run(method)
+    # the schedule that ran: every phase of every epoch, gated phases from epoch 3 (i > 2), SSL's mapping epochs at the end
+    n_ep = args.max_epoch
+    expected = []
+    for i in range(1, n_ep + 1):
+        expected += [("relation", i), ("ckge_rel", i)] + ([("ckgp_rel", i)] if i > 2 else [])
+        expected += [("attribute", i), ("ckge_attr", i)] + ([("ckga_attr", i)] if i > 2 else [])
+        expected += [("common", i)] if method == "ITC" else []
+    expected += [("mapping", i) for i in range(1, args.shared_learning_max_epoch + 1)] if method == "SSL" else []
+    assert [(p, i) for p, i, _ in losses] == expected
+    assert [p for p, _ in recs] == [p for p, _ in expected]
+    # the truncated-sampling refresh happened (after epoch 3) and later epochs drew their negatives from the k-NN lists
+    assert model._neighbors[0] is not None
+    # ---- replay on the float64 oracle, phase by phase -------------------------------------------------------------
+    worst = 0.0
+    for (phase, rec), (p2, epoch, got) in zip(recs, losses):
+        exp = oracle.replay(phase, rec)
+        assert np.isfinite(got) and got > 0.0, (phase, epoch, got)
+        err = abs(got - exp) / abs(exp)
+        worst = max(worst, err)
+        assert err <= 1e-4, f"{method}: epoch {epoch} phase {phase}: product {got!r} vs oracle {exp!r} (rel {err:.2e})"
+    # ---- final state -------------------------------------------------------------------------------------------------
+    pairs = {"rv_ent": model.rv_ent_embeds, "av_ent": model.av_ent_embeds, "ent": model.ent_embeds, "rel": model.rel_embeds,
+             "attr": model.attr_embeds}
+    for k, tab in pairs.items():
+        got = tab.raw().cpu().numpy().astype(np.float64)
+        ref = oracle.t[k]
+        bad = ~np.isclose(got, ref, rtol=1e-3, atol=2e-5)
+        assert bad.mean() < 1e-4, (k, float(bad.mean()), float(np.abs(got - ref).max()))
+        assert float(np.abs(got - ref).max()) < 5e-3, (k, float(np.abs(got - ref).max()))
+    for c, P in zip((model._attr_cnn, model._ckge_attr_cnn, model._ckga_attr_cnn), oracle.cnn):
+        for name, got in c.numpy_params().items():
+            np.testing.assert_allclose(got, P[name], rtol=5e-3, atol=5e-4, err_msg=name)
+    if method == "SSL":
+        for got, ref in zip((model.nv_mapping, model.rv_mapping, model.av_mapping), oracle.M):
+            np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=1e-3, atol=2e-5)
+        assert float(np.abs(oracle.M[1] - oracle.M0[1]).max()) > 1e-3                         # the matrices did move
+    # ---- Hits / MRR: product evaluator on HIP tables == float64 evaluator on oracle tables ---------------------------
+    from multike_amd.base.alignment import alignment_counts, tie_aware_metrics
+    kgs = data.kgs
+    e1, e2 = kgs.test_entities1, kgs.test_entities2
+    views = {"nv": ("name", model.name_embeds), "rv": ("rv_ent", model.rv_ent_embeds), "av": ("av_ent", model.av_ent_embeds),
+             "final": ("ent", model.ent_embeds)}
+    top_k = [1, 5, 10, 50]
+    summary = {}
+    for choice, (oname, tab) in views.items():
+        hv = tab.eval()
+        greater, ties, _ = alignment_counts(hv[e1], hv[e2])
+        hits, mr, mrr = tie_aware_metrics(greater, ties, top_k)
+        hits = np.round(np.array(hits) / len(e1) * 100, 3)
+        ov = oracle.view(oname)
+        orank, _ = eo.ranks(ov[e1], ov[e2])
+        ohits, omr, omrr = eo.metrics(orank, top_k)
+        summary[choice] = (hits, ohits)
+        # ranks are integers: a handful of near-ties may flip between fp32 tables / fp32 similarities and float64
+        n_diff = int(np.sum(greater.cpu().numpy() != orank))
+        assert n_diff <= max(2, len(e1) // 50), (choice, n_diff)
+        assert np.all(np.abs(hits - ohits) <= 0.5), (choice, hits, ohits)       # north_star: Hits within +-0.5
+        assert abs(mrr - omrr) <= 2e-3, (choice, mrr, omrr)
+    # the views are neither trivially perfect nor at chance: the comparison is sensitive
+    assert 20.0 < summary["nv"][1][0] < 99.0
+    if method == "ITC":       # the shared table of the SSL schedule only starts to move in its few mapping epochs
+        assert summary["final"][1][2] > 5.0
+    # the drivers' own closing tests report the same figures (results[...] is the MRR `test` returns)
+    assert abs(results["final"] - eo.metrics(eo.ranks(oracle.view("ent")[e1], oracle.view("ent")[e2])[0], top_k)[2]) <= 2e-3
+    print(f"{method}: worst phase-loss error {worst:.2e}; Hits@[1,5,10,50] product / oracle: "
+          + "; ".join(f"{k} {v[0].tolist()} / {v[1].tolist()}" for k, v in summary.items()))
