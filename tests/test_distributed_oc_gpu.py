@@ -326,3 +326,114 @@ def test_relation_group_on_shared_tables_one_rank():
     np.testing.assert_allclose(a.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(a.rel[:, :DIM].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
     assert float(a.ent_grad.abs().max()) == 0.0 and float(a.rel_grad.abs().max()) == 0.0 and int(a.ref_count.abs().sum()) == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at its per-GPU shape, FULL size, in the sharded (owner-computes) form
+# ----------------------------------------------------------------------------------------------------------------------
+C5 = dict(n_ent=2_000_000, n_rel=2000, dim=256, neg=64, batch=5000)
+
+
+def _c5_ent0(n_ent, dim, seed):
+    """The initial entity table, identical on every rank: truncated normal at the xavier scale, drawn in float32 blocks."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    sigma = float(np.sqrt(2.6 / (n_ent + dim)))
+    return (torch.randn(n_ent, dim, generator=g).clamp_(-2, 2) * sigma).numpy()
+
+
+def _c5_full_size(rank, world, comm, steps=2):
+    """`steps` global steps of the owner-computes trainer at |E| = 2M, |R| = 2000, dim 256, 64 negatives, 5000 positives PER
+    RANK, checked on this rank against the float64 C oracle run on the COMPACTED problem (the rows the steps touch, renumbered:
+    untouched rows take no part and must stay bit-identical — asserted on the shard).  Every rank recomputes the oracle for the
+    whole global step (the tables start from the same seed) and checks the rows IT owns; nothing but the loss crosses ranks."""
+    from multike_amd.distributed_oc import OwnerComputesTrainer
+    from multike_amd.synthetic import SyntheticKGs
+    n_ent, n_rel, d, N, P = C5["n_ent"], C5["n_rel"], C5["dim"], C5["neg"], C5["batch"]
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, triples_per_entity=1.0, seed=5)
+    ent0 = _c5_ent0(n_ent, d, 5)
+    rel0 = mo.xavier_truncated_normal((n_rel, d), np.random.default_rng(6))
+    tr = OwnerComputesTrainer(kgs, ent0, rel0, P, N, rank, world, seed=2, lr=0.001, comm=comm, chunks=1)
+    shard0 = tr.ent.clone()
+    batches = []
+    for s in range(steps):                       # the global batches (the Philox stream is indexed by the epoch position)
+        pos, neg = tr.bat.batch(s)
+        batches.append((tuple(x.cpu().numpy() for x in pos), tuple(x.cpu().numpy() for x in neg)))
+    assert len(batches[0][0][0]) == P * world and len(batches[0][1][0]) == P * world * N
+    for s in range(steps):
+        tr.step(s)
+    loss = tr.epoch_loss()
+    used = np.unique(np.concatenate([a for pos, neg in batches for a in (pos[0], pos[2], neg[0], neg[2])]))
+    remap = np.full(n_ent, -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    e64 = ent0[used].astype(np.float64)
+    r64 = rel0.astype(np.float64)
+    a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+    orc = co.RelationStepOracle(len(e64), n_rel, d, np.float64)
+    exp = 0.0
+    for pos, neg in batches:
+        exp += orc.step(e64, r64, a64, b64, (remap[pos[0]], pos[1], remap[pos[2]]), (remap[neg[0]], neg[1], remap[neg[2]]), 0.001)
+    np.testing.assert_allclose(loss, exp, rtol=2e-6)
+    mine = used[used % world == rank]
+    loc = torch.as_tensor(mine // world, device="cuda")
+    np.testing.assert_allclose(tr.ent[loc][:, :d].cpu().numpy(), e64[remap[mine]], rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(tr.ent_acc[loc][:, :d].cpu().numpy(), a64[remap[mine]], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), r64, rtol=1e-4, atol=5e-7)
+    mask = torch.ones(tr.ent.shape[0], dtype=torch.bool, device="cuda")
+    mask[loc] = False
+    assert torch.equal(tr.ent[mask], shard0[mask])                       # the shard's untouched rows: bit-identical
+    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+    moved = float((tr.ent[loc] - shard0[loc]).abs().max())
+    assert moved > 0.0
+    return dict(rank=rank, used=int(len(used)), owned=int(len(mine)), loss=loss, oracle_loss=exp)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_c5_owner_computes_one_rank_over_rccl():
+    """configs[4] per-GPU shape at full size on the SHARDED path, G = 1, the communicator a real 1-rank RCCL group."""
+    import tempfile
+    import torch.distributed as dist
+    from multike_amd.distributed_oc import OcComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        out = _c5_full_size(0, 1, OcComm())
+        assert out["used"] > 500_000 and out["owned"] == out["used"]     # 2 steps x ~300K distinct rows of 2M
+    finally:
+        dist.destroy_process_group()
+        torch.cuda.empty_cache()
+
+
+def _c5_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OcHostStagedComm
+        torch.cuda.set_device(0)
+        ret.put(_c5_full_size(rank, world, OcHostStagedComm()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_c5_owner_computes_two_ranks_on_one_gpu():
+    """The same at world 2 (two ranks sharing the GPU, 1M-row shards, 10,000 positives / 650K scored triples per global step,
+    collectives staged through gloo): each rank scores, for all positives, the negatives whose corrupt entity it owns; 2 x
+    10.5K x 256 floats cross the ranks each way per step."""
+    import tempfile
+    import torch.multiprocessing as mp
+    port = tempfile.mktemp(prefix="mke_rdv_")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [ret.get(timeout=1400) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(o["rank"] for o in outs) == [0, 1]
+    assert outs[0]["used"] == outs[1]["used"] and outs[0]["owned"] + outs[1]["owned"] == outs[0]["used"]
+    assert abs(outs[0]["loss"] - outs[1]["loss"]) <= 1e-9 * abs(outs[0]["loss"])
