@@ -43,7 +43,7 @@ KERNEL_SOURCES = ("mke_score.hip", "mke_update.hip", "mke_common.h")
 
 def kernel_source_hash():
     """sha256 over the sources of the two kernels of the step: a committed PMC figure is only quoted for the build it
-    was collected on (profiles/r02_pmc_<config>.json carries the hash)."""
+    was collected on (profiles/r0N_pmc_<config>.json carries the hash)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "multike_amd", "csrc", f), "rb") as fh:
@@ -306,7 +306,7 @@ def host_threads():
 
 def pmc_traffic(args):
     """HBM-side bytes per launch of k_triple_score from the committed rocprofv3 PMC passes (tools/pmc_passes.sh ->
-    profiles/r02_pmc_<config>.json), quoted only when the file was collected on THIS build of the kernels (source hash)
+    profiles/r0N_pmc_<config>.json), quoted only when the file was collected on THIS build of the kernels (source hash)
     and on this workload; None otherwise."""
     if getattr(args, "custom", False):
         return None

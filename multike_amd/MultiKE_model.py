@@ -95,26 +95,24 @@ def generate_optimizer(loss, learning_rate, var_list=None, opt="SGD"):
     return st
 
 
-def conv(attr_hs, attr_as, attr_vs, dim, cnn: AttrCNN | None = None, feature_map_size=2, kernel_size=(2, 4),
-         activation="tanh", layer_num=2):
-    """code/MultiKE_model.py:34-63 on gathered rows: returns the score vector [B] (forward only — the training
-    graphs use `AttrCNN.step`, which fuses forward, backward and update).  `cnn` holds the parameters."""
-    if feature_map_size != 2 or tuple(kernel_size) != (2, 4) or layer_num != 2 or activation != "tanh":
+def conv(attr_hs, attr_as, attr_vs, dim, feature_map_size=2, kernel_size=(2, 4), activation="tanh", layer_num=2, *,
+         cnn: AttrCNN | None = None):
+    """code/MultiKE_model.py:34-63 on gathered DEVICE rows [B, dim]: returns the score vector [B], differentiable w.r.t.
+    `attr_hs`, `attr_as` and the CNN's parameters (`cnn.params`, one packed leaf tensor — set `requires_grad_()` on it to
+    receive its gradient) through a hand-written backward (multike_amd/attr_cnn.py `_ConvScore`: HIP conv-stack kernels, the
+    dense layer on the library's own MFMA GEMM; no host copy, no library GEMM).  Same positional signature as the reference.
+    `cnn` owns the parameters; None = a fresh parameter set with tf.layers' default initialisers, as every un-scoped
+    `tf.layers` call creates in TF1 — it is returned on the result as `score.cnn`.  The training graphs do not go through
+    this op: they use `AttrCNN.step(s)`, which fuses forward, backward and update."""
+    if feature_map_size != 2 or tuple(kernel_size) != (2, 4) or layer_num != 2 or (activation != "tanh" and activation is not torch.tanh):
         raise _lib.MultiKEHipError("conv: only the reference's configuration (2 filters, 2x4, 2 layers, tanh) is built")
+    from .attr_cnn import conv_score
     if cnn is None:
-        raise _lib.MultiKEHipError("conv: pass the AttrCNN that owns the parameters")
-    B = attr_hs.shape[0]
-    dev = attr_hs.device
-    a = EmbeddingTable(B, dim, normalize=False, trainable=False, values=attr_as.detach().cpu().numpy(), device=dev)
-    v = EmbeddingTable(B, dim, normalize=False, trainable=False, values=attr_vs.detach().cpu().numpy(), device=dev)
-    idx = torch.arange(B, dtype=torch.int32, device=dev)
-    flat = torch.empty(B, 4 * dim, dtype=torch.float32, device=dev)
-    _lib.attr_conv_fwd(a.data, False, v.data, dim, idx, idx, cnn.params, flat)
-    z = torch.matmul(flat, cnn.views["W"])
-    ssq = torch.empty(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
-    _lib.attr_tail_z(z, cnn.views["bias"], ssq)
-    out = z * torch.rsqrt(torch.clamp_min(ssq.sum().float(), 1e-12))
-    return -torch.sum(torch.square(attr_hs - out), 1)
+        cnn = AttrCNN(int(dim), attr_hs.device)
+        cnn.params.requires_grad_(True)
+    score = conv_score(attr_hs, attr_as, attr_vs, dim, cnn)
+    score.cnn = cnn
+    return score
 
 
 def _dev_i32(x, device):

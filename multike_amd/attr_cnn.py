@@ -152,3 +152,76 @@ class AttrCNN:
         a, part = self._args(eng, ent, attr, lit, ih, ia, iv, weights, int(ih.numel()), scale, opt_name, lr, optimizer, update, 1)
         _lib.attr_step(a)
         return part[:_lib.LOSS_PARTIALS]
+
+
+class _ConvScore(torch.autograd.Function):
+    """score_i = -|| h_i - out_i ||^2 with out = l2_normalize(tanh([flat, 1] @ [W; bias])) over the WHOLE batch and flat = the
+    conv stack of (a_i, v_i) — `conv()` of code/MultiKE_model.py:34-63 as a differentiable op on gathered DEVICE rows.
+
+    Forward: `mke_attr_conv_fwd` (BN affine, 2 x conv + tanh, width l2-norm) -> the dense layer on the library's own f32 MFMA
+    GEMM (`mke_dense_layer_fwd`) -> `mke_attr_tail_z` (bias, tanh, sum z^2).  Backward (hand-derived, the derivation of
+    oracle/attr_cnn_oracle.py): `mke_attr_tail_bwd` (through the batch-wide normalisation and tanh), the dense layer's two
+    gradient products on `mke_gemm_f32` (dW split over K), `mke_attr_conv_bwd` (recomputes the stack, back-propagates it into
+    the attribute rows and the 52 + 2 dim conv / BN parameters).  No host copy, no library GEMM, no autograd inside.
+    Gradients flow to attr_hs, attr_as and the packed parameter buffer; attr_vs (the literal vectors, a constant in the
+    reference: code/MultiKE_model.py:88) gets none."""
+
+    @staticmethod
+    def forward(ctx, attr_hs, attr_as, attr_vs, params, dim):
+        dev = attr_hs.device
+        hs, as_, vs = (t.detach().contiguous().float() for t in (attr_hs, attr_as, attr_vs))
+        B = hs.shape[0]
+        if not (hs.shape == as_.shape == vs.shape == (B, dim)):
+            raise _lib.MultiKEHipError(f"conv: row shapes {tuple(hs.shape)} {tuple(as_.shape)} {tuple(vs.shape)} != [B, {dim}]")
+        if attr_vs.requires_grad:
+            raise _lib.MultiKEHipError("conv: attr_vs is a constant (literal vectors); its gradient is not built")
+        p = params.detach()
+        nconv = _lib.cnn_conv_params(dim)
+        W, bias = p[nconv:nconv + 4 * dim * dim].view(4 * dim, dim), p[nconv + 4 * dim * dim:]
+        idx = torch.arange(B, dtype=torch.int32, device=dev)
+        flat = torch.empty(B, 4 * dim, dtype=torch.float32, device=dev)
+        z = torch.empty(B, dim, dtype=torch.float32, device=dev)
+        ssq = torch.zeros(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
+        if B:
+            _lib.attr_conv_fwd(as_, False, vs, dim, idx, idx, p, flat)
+            _lib.dense_layer_fwd(flat, W, None, _lib.ACT_NONE, z)
+            _lib.attr_tail_z(z, bias, ssq)
+        inv = torch.rsqrt(torch.clamp_min(ssq.sum(), 1e-12)).float()
+        diff = hs - z * inv
+        ctx.dim = dim
+        ctx.save_for_backward(hs, as_, vs, p, flat, z, ssq, idx)
+        return -(diff * diff).sum(1)
+
+    @staticmethod
+    def backward(ctx, gs):
+        hs, as_, vs, p, flat, z, ssq, idx = ctx.saved_tensors
+        dim, dev, B = ctx.dim, hs.device, hs.shape[0]
+        nconv = _lib.cnn_conv_params(dim)
+        W = p[nconv:nconv + 4 * dim * dim].view(4 * dim, dim)
+        inv = torch.rsqrt(torch.clamp_min(ssq.sum(), 1e-12)).float()
+        diff = hs - z * inv
+        g2 = (2.0 * gs.float()).unsqueeze(1) * diff        # dL/dout = +2 gs (h - out);  dL/dh = -that
+        g_h = -g2 if ctx.needs_input_grad[0] else None
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]) or B == 0:
+            return g_h, None, None, None, None
+        gout = g2.contiguous()
+        dot = torch.zeros(_lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
+        dot[0] = (gout.double() * z.double()).sum()
+        gp = torch.zeros_like(p)
+        _lib.attr_tail_bwd(z, gout, ssq, dot, grad_bias=gp[nconv + 4 * dim * dim:])      # gout <- dL/dzpre, dbias += column sums
+        gW = gp[nconv:nconv + 4 * dim * dim].view(4 * dim, dim)
+        _lib.gemm_f32(flat, gout, gW, transpose_a=True, splits=max(1, min(32, B // 160)), accumulate=True)   # gW is zero: split-K adds into it
+        dflat = torch.empty_like(flat)
+        _lib.gemm_f32(gout, W, dflat, transpose_b=True)
+        g_as = torch.zeros_like(as_)              # the kernel scatters with the attribute rows' own stride
+        touched = torch.zeros(B, dtype=torch.int32, device=dev)
+        _lib.attr_conv_bwd(as_, False, vs, dim, idx, idx, p, dflat, gp, g_as, touched, 1)
+        return g_h, (g_as if ctx.needs_input_grad[1] else None), None, (gp if ctx.needs_input_grad[3] else None), None
+
+
+def conv_score(attr_hs, attr_as, attr_vs, dim, cnn: AttrCNN):
+    """Differentiable score vector [B] of `cnn` on gathered device rows (see `_ConvScore`)."""
+    for t, nm in ((attr_hs, "attr_hs"), (attr_as, "attr_as"), (attr_vs, "attr_vs")):
+        if not t.is_cuda:
+            raise _lib.MultiKEHipError(f"conv: {nm} must be a CUDA/HIP tensor (multike_amd has no CPU path)")
+    return _ConvScore.apply(attr_hs, attr_as, attr_vs, cnn.params, int(dim))

@@ -88,3 +88,74 @@ def test_three_steps_vs_oracle(d, B, n_ent, n_attr, n_lit):
     for k in ao.PARAM_NAMES:
         np.testing.assert_allclose(got[k], p64[k], rtol=2e-3, atol=1e-4, err_msg=k)
     assert float(cnn.grads.abs().max()) == 0.0 and float(E.grad.abs().max()) == 0.0 and float(A.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_conv_op_is_differentiable_and_matches_the_golden_gradients(ci):
+    """`MultiKE_model.conv` (code/MultiKE_model.py:34-63) as an autograd op on DEVICE rows: the score vector and, through a
+    loss built on it with ordinary torch ops, the gradients w.r.t. attr_hs, attr_as and every CNN parameter — against
+    cnn_golden.npz (float64 autograd over an independent torch restatement of the TF graph)."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.MultiKE_model import conv
+    g = np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+    pre = f"n{ci}_"
+    d = int(g[pre + "meta"][0])
+    cnn = AttrCNN(d, params={k: g[pre + "p_" + k] for k in ao.PARAM_NAMES})
+    cnn.params.requires_grad_(True)
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    hs, as_ = dev(g[pre + "hs"]).requires_grad_(True), dev(g[pre + "as"]).requires_grad_(True)
+    vs = dev(g[pre + "vs"])
+    score = conv(hs, as_, vs, d, cnn=cnn)
+    assert score.shape == (hs.shape[0],) and score.requires_grad and score.cnn is cnn
+    np.testing.assert_allclose(score.detach().cpu().numpy(), g[pre + "score"], rtol=2e-5, atol=1e-6)
+    per = torch.log(1 + torch.exp(-score))
+    if (pre + "ws") in g.files:
+        per = per * dev(g[pre + "ws"])
+    loss = float(g[pre + "scale"]) * per.sum()
+    np.testing.assert_allclose(float(loss.detach()), g[pre + "loss"], rtol=5e-6)
+    loss.backward()
+    np.testing.assert_allclose(hs.grad.cpu().numpy(), g[pre + "g_hs"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(as_.grad.cpu().numpy(), g[pre + "g_as"], rtol=2e-3, atol=2e-6)
+    o = 0
+    for name in ao.PARAM_NAMES:
+        ref = g[pre + "g_" + name]
+        got = cnn.params.grad[o:o + ref.size].view(ref.shape).cpu().numpy()
+        o += ref.size
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+    assert o == cnn.params.numel()
+    # positional signature of the reference, a fresh parameter set when none is given, loud failure on host tensors
+    s2 = conv(hs.detach(), as_.detach(), vs, d, 2, [2, 4], "tanh", 2)
+    assert s2.shape == score.shape and s2.cnn is not cnn and s2.cnn.params.requires_grad
+    from multike_amd._lib import MultiKEHipError
+    with pytest.raises(MultiKEHipError):
+        conv(hs.detach().cpu(), as_.detach().cpu(), vs.cpu(), d, cnn=cnn)
+    with pytest.raises(MultiKEHipError):
+        conv(hs, as_, vs, d, 3, cnn=cnn)
+
+
+def test_conv_op_gradcheck_against_the_training_step():
+    """The op's gradients == what the fused training step (`AttrCNN.step(update=False)`) leaves in the gradient scratch, on a
+    batch with an arbitrary upstream gradient shape (the attribute-view loss), dim 75, 1000 rows."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.MultiKE_model import conv
+    from multike_amd.tables import StepEngine
+    rng = np.random.default_rng(9)
+    d, B = 75, 1000
+    hs = rng.standard_normal((B, d)); hs /= np.linalg.norm(hs, axis=1, keepdims=True)
+    as_, vs = 0.3 * rng.standard_normal((B, d)), rng.standard_normal((B, d))
+    vs /= np.linalg.norm(vs, axis=1, keepdims=True)
+    w = rng.uniform(0.2, 1.0, B).astype(np.float32)
+    cnn = AttrCNN(d, seed=4)
+    cnn.views["bias"].copy_(torch.tensor(0.05 * rng.standard_normal(d), dtype=torch.float32))
+    ent, attr, lit, idx = _tables(hs.astype(np.float32), as_.astype(np.float32), vs.astype(np.float32))
+    lp = cnn.step(StepEngine(), ent, attr, lit, idx, idx, idx, torch.tensor(w, device="cuda"), scale=1.0, update=False)
+    step_g = cnn.grads.clone()
+    cnn.params.requires_grad_(True)
+    th, ta = ent.lookup(idx).requires_grad_(True), attr.raw().clone().requires_grad_(True)
+    score = conv(th, ta, lit.raw(), d, cnn=cnn)
+    loss = (torch.tensor(w, device="cuda") * torch.log(1 + torch.exp(-score))).sum()
+    np.testing.assert_allclose(float(loss.detach()), float(lp.sum()), rtol=5e-6)
+    loss.backward()
+    np.testing.assert_allclose(cnn.params.grad.cpu().numpy(), step_g.cpu().numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(th.grad.cpu().numpy(), ent.grad[:, :d].cpu().numpy(), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), attr.grad[:, :d].cpu().numpy(), rtol=2e-3, atol=2e-6)

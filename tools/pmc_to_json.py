@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of a bench.py run -> r02_pmc_<config>.json / .md.
+"""rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of a bench.py run -> r03_pmc_<config>.json / .md.
 
 Reading rules (MI355X_MICROARCH.md §HBM): unit KB (x 1024 = bytes); on gfx950 FETCH_SIZE under-reports reads (exactly 1/2
 for 16 B/lane streams, "other widths uncalibrated: calibrate on a known byte count in your own access pattern"), WRITE_SIZE
@@ -56,9 +56,9 @@ def main():
            "update_kernel": {"fetch_size_kb": uf[3], "write_size_kb": uw[3],
                              "known_write_bytes": rows * 3 * stride * 4}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"r02_pmc_{cfg}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"r03_pmc_{cfg}.json"), "w") as f:
         json.dump(out, f, indent=1)
-    md = [f"# Round 2 — PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --config {cfg} --steps 40 --warmup 5`", "",
+    md = [f"# Round 3 — PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --config {cfg} --steps 40 --warmup 5`", "",
           f"workload: {c['workload']}; kernel sources sha {out['kernel_source_sha']}", "",
           "Two separate passes, each `rocprofv3 --kernel-trace --pmc <COUNTER>`; per dispatch, unit KB.", "",
           "| kernel | counter | dispatches | avg | min | max |", "|---|---|---|---|---|---|"]
@@ -70,7 +70,7 @@ def main():
            f"* `k_triple_score`: {sf[3] * 1024 * corr / 1e6:.1f} MB read + {sw[3] * 1024 / 1e6:.1f} MB written = "
            f"**{traffic / 1e6:.1f} MB per launch** against {alg / 1e6:.1f} MB algorithmic "
            f"({traffic / alg:.2f}x); bench.py divides it by the UNPROFILED launch duration (`roofline.achieved_counter`)"]
-    with open(os.path.join(ROOT, "gpurun_out", f"r02_pmc_{cfg}.md"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"r03_pmc_{cfg}.md"), "w") as f:
         f.write("\n".join(md) + "\n")
     print("\n".join(md))
 

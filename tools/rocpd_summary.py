@@ -25,5 +25,24 @@ def summarise(db, top=12, by_grid=False):
     return "\n".join(out)
 
 
+def dump_dispatches(db, substr, csv_path):
+    """Per-dispatch rows (start ns, end ns, duration ns, grid) of every kernel whose name contains `substr`: small enough to
+    commit under profiles/, so that a summary's average can be recomputed by a reader."""
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(c.execute(f"select s.kernel_name, d.start, d.end, d.end - d.start, d.grid_size_x from {kd} d join {ks} s "
+                          f"on d.kernel_id = s.id where s.kernel_name like ? order by d.start", (f"%{substr}%",)))
+    with open(csv_path, "w") as f:
+        f.write("kernel,start_ns,end_ns,duration_ns,grid_x\n")
+        for r in rows:
+            f.write(f"\"{r[0][:70]}\",{r[1]},{r[2]},{r[3]},{r[4]}\n")
+    return len(rows)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--dump":          # rocpd_summary.py <db> --dump <kernel substring> <csv>
+        print(dump_dispatches(sys.argv[1], sys.argv[3], sys.argv[4]), "dispatches written to", sys.argv[4])
+        sys.exit(0)
     print(summarise(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12, by_grid=len(sys.argv) > 3))
