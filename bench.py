@@ -571,7 +571,25 @@ def main():
         ms = np.array([a.elapsed_time(b) for a, b, _ in trainer.score_events])
         tr = np.array([n for _, _, n in trainer.score_events])
         trainer.score_events = None
-        shard_info = trainer.check()   # raises when any step's row set overflowed the exchange capacity (results invalid)
+        shard_info = trainer.check() if hasattr(trainer, "check") else {}   # raises when a row set overflowed (results invalid)
+        # the replicated relation table must be bit-identical on every rank (its gradient is all-reduced, the update identical);
+        # a transport that delivered different sums to different ranks shows up here, and the epoch's loss must be finite
+        rel_t = getattr(trainer, "rel", None)
+        if rel_t is not None and world > 1:
+            ref_t = rel_t.clone()
+            if staged:
+                c = ref_t.cpu(); dist.broadcast(c, 0); ref_t.copy_(c)
+            else:
+                dist.broadcast(ref_t, 0)
+            same = torch.tensor([1 if torch.equal(ref_t, rel_t) else 0], dtype=torch.int32, device="cpu" if staged else "cuda")
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if int(same) != 1:
+                raise SystemExit("bench.py: the replicated relation table differs between ranks: collectives are not trustworthy "
+                                 "(run tools/multi_gpu_selftest.py)")
+            shard_info = dict(shard_info or {}, replicas_bit_identical=True)
+        ep_loss = trainer.epoch_loss()
+        if not np.isfinite(ep_loss):
+            raise SystemExit(f"bench.py: non-finite loss {ep_loss} on the sharded path")
         achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
         roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": float(ms.mean()) * 1e3,

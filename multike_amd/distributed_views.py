@@ -47,6 +47,18 @@ class ViewComm:
             dist.all_reduce(t)
 
 
+class NoComm(ViewComm):
+    """world == 1: a view's collectives are no-ops whatever process group the process is part of (a one-rank view may live
+    inside a multi-rank job: the self-test's reference run, a replicated small model)."""
+
+    def all_reduce(self, t):
+        pass
+
+
+def _comm_for(world, comm, default=None):
+    return NoComm() if world == 1 else (comm or default or ViewComm())
+
+
 class HostStagedViewComm(ViewComm):
     """Test vehicle: two ranks sharing one GPU, collectives staged through gloo over the host."""
 
@@ -162,19 +174,19 @@ class ShardedAttributeView:
         self.rank, self.world, self.lr, self.opt_name = rank, world, float(lr), opt_name
         if tables is not None:      # EmbeddingTables of the caller: (this rank's av_ent shard of n_ent rows, attr, literal)
             self.dim, self.n_ent = tables[0].dim, int(n_ent)
-            self.comm = comm or ViewComm()
+            self.comm = _comm_for(world, comm)
             self.backend = (backend_cls or HipAttrBackend)(self, None, None, None, cnn_params, tables=tables)
             return
         if tables_of is not None:
             if (tables_of.rank, tables_of.world) != (rank, world) or tables_of.opt_name == opt_name:
                 raise ValueError("tables_of: same rank / world and a different optimizer name")
             self.dim, self.n_ent = tables_of.dim, tables_of.n_ent
-            self.comm = comm or tables_of.comm
+            self.comm = _comm_for(world, comm, tables_of.comm)
             self.backend = (backend_cls or type(tables_of.backend))(self, None, None, None, cnn_params, tables_of=tables_of.backend)
             return
         self.dim = ent0.shape[1]
         self.n_ent = ent0.shape[0]
-        self.comm = comm or ViewComm()
+        self.comm = _comm_for(world, comm)
         self.backend = (backend_cls or HipAttrBackend)(self, ent0[rank::world], attr0, lit, cnn_params)
 
     def step(self, ih, ia, iv, w=None, scale: float = 1.0):
@@ -293,7 +305,7 @@ class ShardedCommonSpace:
                  cv_weight: float = 1.0, backend_cls=None, comm=None, tables: dict = None, n_ent: int = None):
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.cv_name_weight, self.cv_weight = float(cv_name_weight), float(cv_weight)
-        self.comm = comm or ViewComm()
+        self.comm = _comm_for(world, comm)
         if tables is not None:      # the caller's EmbeddingTable shards {"ent", "name", "rv", "av"} of n_ent global rows
             self.dim, self.n_ent = tables["ent"].dim, int(n_ent)
             self.backend = (backend_cls or HipCommonSpaceBackend)(self, None, tables=tables)
@@ -433,7 +445,7 @@ class ShardedSpaceMapping:
         tables: (shared-table shard, [view shards]) EmbeddingTables of the caller instead of ent0 / views0 (n_ent global rows)."""
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.orthogonal_weight, self.norm_w = float(orthogonal_weight), float(norm_w)
-        self.comm = comm or ViewComm()
+        self.comm = _comm_for(world, comm)
         if tables is not None:
             self.dim, self.n_ent = tables[0].dim, int(n_ent)
             self.backend = (backend_cls or HipSpaceMappingBackend)(self, None, None, matrices, tables=tables)
@@ -546,7 +558,7 @@ class ShardedAutoEncoder:
         hidden widths, code width."""
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.dims, self.active, self.normalize = [int(v) for v in dims], active, bool(normalize)
-        self.comm = comm or ViewComm()
+        self.comm = _comm_for(world, comm)
         self.backend = (backend_cls or HipAutoEncoderBackend)(self, params)
 
     def step(self, x):

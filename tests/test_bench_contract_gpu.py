@@ -77,3 +77,23 @@ def test_two_rank_launch_dry_run():
     assert d["config"]["scored_per_step"] == 2 * d["config"]["batch"] * (1 + d["config"]["neg"])
     assert abs(d["value"] - d["config"]["scored_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_multi_gpu_selftest_tool(nproc):
+    """tools/multi_gpu_selftest.py — what a multi-GPU node runs before bench.py: every collective of the sharded trainers on
+    known data, then every sharded loop against the same global steps on one rank.  nproc 1: a real 1-rank RCCL group;
+    nproc 2: two ranks sharing the GPU, collectives staged through gloo (dry run of the N > 1 control flow)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    if nproc > 1:
+        env["MKE_BENCH_COMM"] = "staged"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "multi_gpu_selftest.py")],
+                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    d = json.loads(lines[-1])
+    assert d["selftest"] == "ok" and d["world"] == nproc and d["relation_chunks2_max_abs_diff"] < 2e-5
