@@ -2,7 +2,7 @@
 combination: every epoch ends with common-space learning).  run_ITC.py's model."""
 from __future__ import annotations
 
-from .MultiKE_Late import _ScheduledMultiKE, test, valid
+from .MultiKE_Late import _ScheduledMultiKE, test, valid  # noqa: F401  (re-exported: run_ITC.py imports them from here)
 
 
 class MultiKE_CV(_ScheduledMultiKE):
@@ -23,19 +23,19 @@ class MultiKE_CV(_ScheduledMultiKE):
         """code/MultiKE_CSL.py:36-107."""
         a = self.args
         self._prepare()
-        test(self, embed_choice='nv')
+        self._test('nv')
         for i in range(1, a.max_epoch + 1):
             print('epoch {}:'.format(i))
             self._train_views(i)
             self.train_common_space_learning_1epo(i, self._entity_list)
             if i >= a.start_valid and i % a.eval_freq == 0:
-                valid(self, embed_choice='rv')
-                valid(self, embed_choice='av')
-                valid(self, embed_choice='final')
+                self._valid('rv')
+                self._valid('av')
+                self._valid('final')
                 if self.early_stop or i == a.max_epoch:
                     break
             if i >= a.start_predicate_soft_alignment and i % 10 == 0:
                 self._update_predicate_alignment()
             self._refresh_neighbours(i)
         self.save()
-        return {k: test(self, embed_choice=k) for k in ('nv', 'rv', 'av', 'final')}
+        return {k: self._test(k) for k in ('nv', 'rv', 'av', 'final')}

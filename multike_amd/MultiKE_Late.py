@@ -95,6 +95,20 @@ class _ScheduledMultiKE(MultiKE):
     """What `MultiKE_CV.run` and `MultiKE_Late.run` share (code/MultiKE_CSL.py:36-56, code/MultiKE_Late.py:201-223):
     step counts, supervision lists, the per-epoch view training block and the periodic refreshes."""
 
+    # The evaluation calls of the schedules go through these hooks (module-level functions by default, looked up when called);
+    # the multi-GPU drivers (multike_amd/distributed_run.py) override them with rank-sharded evaluation.
+    def _valid(self, embed_choice):
+        return valid(self, embed_choice=embed_choice)
+
+    def _test(self, embed_choice):
+        return test(self, embed_choice=embed_choice)
+
+    def _valid_WVA(self):
+        return valid_WVA(self)
+
+    def _test_WVA(self):
+        return test_WVA(self)
+
     def _prepare(self):
         kgs, pam, a = self.kgs, self.predicate_align_model, self.args
         rel_n = kgs.kg1.local_relation_triples_num + kgs.kg2.local_relation_triples_num
@@ -222,16 +236,16 @@ class MultiKE_Late(_ScheduledMultiKE):
     def run(self):
         a = self.args
         self._prepare()
-        valid(self, embed_choice='nv')
-        valid(self, embed_choice='avg')
+        self._valid('nv')
+        self._valid('avg')
         for i in range(1, a.max_epoch + 1):
             print('epoch {}:'.format(i))
             self._train_views(i)
             if i >= a.start_valid and i % a.eval_freq == 0:
-                valid(self, embed_choice='rv')
-                valid(self, embed_choice='av')
-                valid(self, embed_choice='avg')
-                valid_WVA(self)
+                self._valid('rv')
+                self._valid('av')
+                self._valid('avg')
+                self._valid_WVA()
                 if i >= a.start_predicate_soft_alignment:
                     self._update_predicate_alignment()
             if self.early_stop or i == a.max_epoch:
@@ -240,9 +254,9 @@ class MultiKE_Late(_ScheduledMultiKE):
         for i in range(1, a.shared_learning_max_epoch + 1):
             self.train_shared_space_mapping_1epo(i, self._entity_list)
             if i >= a.start_valid and i % a.eval_freq == 0:
-                valid(self, embed_choice='final')
+                self._valid('final')
         self.save()
-        results = {k: test(self, embed_choice=k) for k in ('nv', 'rv', 'av', 'avg')}
-        results['wva'] = test_WVA(self)
-        results['final'] = test(self, embed_choice='final')
+        results = {k: self._test(k) for k in ('nv', 'rv', 'av', 'avg')}
+        results['wva'] = self._test_WVA()
+        results['final'] = self._test('final')
         return results

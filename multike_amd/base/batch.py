@@ -104,7 +104,7 @@ def generate_relation_triple_batch_queue(triple_list1, triple_list2, triple_set1
 
 
 def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, device="cuda", block_rows=4096,
-                    rows_per_launch=None):
+                    rows_per_launch=None, part=None):
     """Truncated-sampling k-NN refresh on the device (code/base/batch.py:119-150): inner product of the (already
     row-normalised) relation-view rows of one KG's useful entities, top `neighbors_num` per row INCLUDING the entity
     itself, unordered.  Returns (cand_table [n_ent_total, k] int32, cand_valid [n_ent_total] uint8) for
@@ -115,7 +115,11 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     `mke_sim_select` computes the similarities tile by tile on the matrix cores and keeps only the ~1.4 k columns above
     the threshold, `mke_topk_rows` takes the exact top k of that short list.  The few rows whose estimate came out too
     tight (fewer than k hits) or too loose (a segment overflowed) are redone at full width (library GEMM + torch.topk,
-    which is also the path of short rows).  The result is the exact top-k set."""
+    which is also the path of short rows).  The result is the exact top-k set.
+
+    part = (r, G): compute only the r-th of G contiguous slices of the rows (in the function's own working order) — the
+    multi-GPU refresh: every rank holds all rows, ranks the slice it is given against all columns and the slices are
+    all-gathered.  Returns (table, valid, ids_of_the_slice) with only those rows filled."""
     from .. import _lib
     e = (entity_embeds.to(device).float() if isinstance(entity_embeds, torch.Tensor)
          else torch.as_tensor(np.asarray(entity_embeds), dtype=torch.float32, device=device))
@@ -130,11 +134,13 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     def full_width(rows):
         return torch.topk(e[rows] @ e.t(), k, dim=1, sorted=False).indices
 
+    p_lo, p_hi = (0, n) if part is None else (n * part[0] // part[1], n * (part[0] + 1) // part[1])
     if not short:
-        for lo in range(0, n, block_rows):
-            table[ids[lo:lo + block_rows]] = ids[full_width(slice(lo, lo + block_rows))].to(torch.int32)
-        valid[ids] = 1
-        return table, valid
+        for lo in range(p_lo, p_hi, block_rows):
+            hi = min(p_hi, lo + block_rows)
+            table[ids[lo:hi]] = ids[full_width(slice(lo, hi))].to(torch.int32)
+        valid[ids[p_lo:p_hi]] = 1
+        return (table, valid) if part is None else (table, valid, ids[p_lo:p_hi])
 
     g = torch.Generator(device="cpu")
     g.manual_seed(12345)
@@ -153,8 +159,8 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     chunk = (1 << 29) // cap - 128                        # rows per launch: 2^29 candidate slots (8 bytes each) at most
     if rows_per_launch:
         chunk = min(chunk, int(rows_per_launch))
-    for lo in range(0, n, chunk):
-        hi = min(n, lo + chunk)
+    for lo in range(p_lo, p_hi, chunk):
+        hi = min(p_hi, lo + chunk)
         # enough (row block, column segment) work items to fill the chip several times over, segments of >= 4096 columns
         n_seg = 1
         while n_seg < 8 and ((hi - lo + 127) // 128) * n_seg < 6144 and n // (2 * n_seg) >= 4096:
@@ -173,8 +179,8 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
             for a in range(0, rows.numel(), block_rows):
                 r = rows[a:a + block_rows]
                 table[ids[r]] = ids[full_width(r)].to(torch.int32)
-    valid[ids] = 1
-    return table, valid
+    valid[ids[p_lo:p_hi]] = 1
+    return (table, valid) if part is None else (table, valid, ids[p_lo:p_hi])
 
 
 def _pow2_at_least(x: int) -> int:

@@ -35,7 +35,7 @@ class ShardedITC:
                  attribute_batch_size: int = 5000, entity_batch_size: int = 5000, neg_triple_num: int = 10,
                  learning_rate: float = 0.001, itc_learning_rate: float = 0.004, cv_name_weight: float = 1.0, cv_weight: float = 1.0,
                  seed: int = 0, comm_oc=None, comm_views=None, mapping_matrices=None, mapping_learning_rate: float = 0.01,
-                 orthogonal_weight: float = 2.0, start_predicate_soft_alignment: int = 0):
+                 orthogonal_weight: float = 2.0, start_predicate_soft_alignment: int = 0, attr_steps: int = None):
         """kgs: the two KGs' relation triples (multike_amd.synthetic.SyntheticKGs / base.kgs.KGs interface: `triples`,
         `entities(k)`, `ent_range`); tables: full float32 arrays {"rv_ent", "av_ent", "ent", "name", "rel", "attr", "lit"}
         (every rank passes the same; each keeps its shard); cnn_sets: three CNN parameter dicts (attribute view, ckge, ckga);
@@ -86,6 +86,14 @@ class ShardedITC:
             self.mapping.backend.eng.tag = next(base)
         self.lists = {k: lists.get(k, []) for k in ("attr", "ckge_attr", "ckga_attr", "entities")}
         dev = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+        # lists["attr"] = (KG1's weighted attribute triples, KG2's): the attribute view then batches as the reference does —
+        # both lists shuffled after every epoch, step s = [KG1 slice s | KG2 slice s] in the proportion of the list sizes
+        # (code/attr_batch.py:28-41, code/MultiKE_model.py:319-345); a single list: one shuffled list cut into steps
+        self._attr_pair, self.attr_steps = None, attr_steps
+        if isinstance(self.lists["attr"], tuple):
+            self._attr_pair = tuple(tuple(dev(c, torch.float32 if j == 3 else torch.int64) for j, c in enumerate(_columns(l)))
+                                    for l in self.lists["attr"])
+            self.lists["attr"] = []
         self._cols = {k: tuple(dev(c, torch.float32 if j == 3 else torch.int64) for j, c in enumerate(_columns(v)))
                       for k, v in self.lists.items() if k != "entities"}
         self._entities = dev(np.asarray(self.lists["entities"], dtype=np.int64), torch.int64)
@@ -161,6 +169,47 @@ class ShardedITC:
         view.steps(cols[0][order], cols[1][order], cols[2][order], cols[3][order] if cols[3] is not None else None, off, scale=scale)
         return view.epoch_loss()
 
+    def _attr_pair_epoch(self, view, epoch, phase):
+        """The attribute view on two per-KG lists: the reference's proportional split (code/attr_batch.py:28-41 through
+        code/base/batch.py:36-37 arithmetic) and per-epoch shuffles, laid out on the device from (seed, epoch)."""
+        c1, c2 = self._attr_pair
+        n1, n2 = int(c1[0].numel()), int(c2[0].numel())
+        if n1 + n2 == 0:
+            return 0.0
+        B = self.sizes[1]
+        b1 = int(n1 / (n1 + n2) * B)
+        b2 = B - b1
+        steps = self.attr_steps if self.attr_steps is not None else int(math.ceil((n1 + n2) / B))
+        key = (n1, n2, b1, b2, steps)
+        if getattr(self, "_attr_layout_key", None) != key:
+            k1 = np.clip(n1 - np.arange(steps) * b1, 0, b1) if b1 > 0 else np.zeros(steps, np.int64)
+            k2 = np.clip(n2 - np.arange(steps) * b2, 0, b2) if b2 > 0 else np.zeros(steps, np.int64)
+            off = np.zeros(steps + 1, dtype=np.int64)
+            off[1:] = np.cumsum(k1 + k2)
+            p1, p2 = np.arange(int(k1.sum())), np.arange(int(k2.sum()))
+            d1 = off[p1 // max(b1, 1)] + p1 % max(b1, 1) if len(p1) else p1
+            d2 = off[p2 // max(b2, 1)] + k1[p2 // max(b2, 1)] + p2 % max(b2, 1) if len(p2) else p2
+            tod = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64), device="cuda")
+            self._attr_layout, self._attr_layout_key = (off, tod(d1), tod(d2)), key
+        off, d1, d2 = self._attr_layout
+        total = int(off[-1])
+        if total == 0:
+            return 0.0
+        cols = [torch.empty(total, dtype=torch.int64, device="cuda") for _ in range(3)] + [torch.empty(total, dtype=torch.float32, device="cuda")]
+        for kg, (c, dest, n) in enumerate(((c1, d1, n1), (c2, d2, n2))):
+            m = int(dest.numel())
+            if m == 0:
+                continue
+            if epoch <= 1:
+                src = torch.arange(m, device="cuda")                       # the first epoch runs in list order
+            else:
+                self._gen.manual_seed((self.seed * 1000003 + epoch * 101 + phase * 7 + kg) & 0x7FFFFFFFFFFFFFFF)
+                src = torch.randperm(n, generator=self._gen, device="cuda")[:m]
+            for k in range(4):
+                cols[k][dest] = c[k][src] if c[k] is not None else torch.ones(m, device="cuda")
+        view.steps(cols[0], cols[1], cols[2], cols[3], off, scale=1.0)
+        return view.epoch_loss()
+
     def _common_epoch(self, epoch, phase):
         n = int(self._entities.numel())
         if n == 0:
@@ -187,11 +236,46 @@ class ShardedITC:
         out = {"relation": self._oc_epoch(self.relation), "ckge_rel": self._oc_epoch(self.ckge_rel)}
         if soft:
             out["ckgp_rel"] = self._oc_epoch(self.ckgp_rel)
-        out["attribute"] = self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False)
+        out["attribute"] = (self._attr_pair_epoch(self.attr_views[0], i, 0) if self._attr_pair is not None else
+                            self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False))
         out["ckge_attr"] = self._attr_epoch(self.attr_views[1], "ckge_attr", i, 1, 2.0, sampled=True)
         if soft:
             out["ckga_attr"] = self._attr_epoch(self.attr_views[2], "ckga_attr", i, 2, 1.0, sampled=True)
         return out
+
+    # the drivers' building blocks (multike_amd/distributed_run.py): one training phase of epoch i -> (summed loss, positives)
+    def run_phase(self, name: str, i: int):
+        if name in ("relation", "ckge_rel", "ckgp_rel"):
+            tr = getattr(self, name)
+            return (self._oc_epoch(tr), int(tr.bat.off[-1])) if tr is not None else (0.0, 0)
+        if name == "attribute":
+            if self._attr_pair is not None:
+                loss = self._attr_pair_epoch(self.attr_views[0], i, 0)
+                return loss, int(self._attr_layout[0][-1]) if getattr(self, "_attr_layout", None) else 0
+            return self._attr_epoch(self.attr_views[0], "attr", i, 0, 1.0, sampled=False), int(self._cols["attr"][0].numel())
+        if name in ("ckge_attr", "ckga_attr"):
+            k = 1 if name == "ckge_attr" else 2
+            n = int(self._cols[name][0].numel())
+            B = self.sizes[1]
+            steps = int(math.ceil(n / B)) if n else 0
+            return self._attr_epoch(self.attr_views[k], name, i, k, 2.0 if k == 1 else 1.0, sampled=True), steps * (B if steps > 1 else n)
+        n = int(self._entities.numel())
+        B = self.sizes[2]
+        steps = int(math.ceil(n / B)) if n else 0
+        if name == "common":
+            return self._common_epoch(i, 3), steps * (B if steps > 1 else n)
+        if name == "mapping":
+            return self._mapping_epoch(i, 4), steps * (B if steps > 1 else n)
+        raise _lib.MultiKEHipError(f"run_phase: unknown phase {name!r}")
+
+    def views_epoch(self, i: int) -> dict:
+        return self._view_phases(i)
+
+    def common_epoch(self, i: int) -> float:
+        return self._common_epoch(i, 3)
+
+    def mapping_epoch(self, i: int) -> float:
+        return self._mapping_epoch(i, 4)
 
     def epoch_ssl(self, i: int) -> dict:
         """The SSL schedule's training phases (code/MultiKE_Late.py:216-243): the six view phases, then the space mapping."""

@@ -428,7 +428,10 @@ class OwnerComputesTrainer:
         else:
             sides = []
             for k in (0, 1):
-                t = torch.as_tensor(np.asarray(kgs.triples[k], dtype=np.int32), device=dev)
+                # the sampler's membership filter: `kgs.known[k]` when the caller has one (the reference filters against
+                # local_relation_triples_set, which also holds the swapped training-link triples: SURVEY 3.1), else the KG's own
+                kt = getattr(kgs, "known", None)
+                t = torch.as_tensor(np.asarray(kt[k] if kt is not None else kgs.triples[k], dtype=np.int32).reshape(-1, 3), device=dev)
                 known = self.backend.make_known(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
                 sides.append(KGSide(kgs.entities(k), known, device=dev))
             self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
@@ -613,6 +616,17 @@ class OwnerComputesTrainer:
         else:
             self.bat.shuffle()
             self._plan_epoch()
+
+    def set_neighbours(self, tables):
+        """Truncated negative sampling (code/MultiKE_CSL.py:89-102): install ((cand_table, cand_valid), (...)) for the two KGs
+        (None = back to uniform) — identical on every rank.  Takes effect with the NEXT epoch, as in the reference (the refresh
+        sits at the end of an epoch): a plan of that epoch prefetched with the old candidates is dropped."""
+        for side, nb in ((self.bat.side1, tables[0]), (self.bat.side2, tables[1])):
+            side.set_neighbours(*(nb if nb is not None else (None, None)))
+        if getattr(self, "_next_plan", None) is not None:
+            if getattr(self, "_side", None) is not None:
+                torch.cuda.current_stream().wait_stream(self._side)    # the dropped plan may still be writing its buffer set
+            self._next_plan = None
 
     def _map_peers(self, gb):
         """Exchange IPC handles of this rank's send block and gradient inbox ([world][2 C][stride]: one slice per writer) and

@@ -14,11 +14,25 @@ import json
 def main(argv=None):
     ap = argparse.ArgumentParser(description="MultiKE on MI355X: ITC (MultiKE_CV) or SSL (MultiKE_Late)")
     ap.add_argument("--method", choices=["ITC", "SSL"], default="ITC")
-    ap.add_argument("--training_data", type=str, required=True, help="dataset folder (trailing slash optional)")
+    ap.add_argument("--training_data", type=str, default="synthetic/", help="dataset folder (trailing slash optional)")
     ap.add_argument("--args", type=str, default=None, help="JSON file with args.json-style overrides")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override one args.json entry (VALUE parsed as JSON, falling back to a string)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node to train on: > 1 runs the row-sharded drivers (multike_amd/distributed_run.py), one "
+                         "process per GPU over RCCL; started without torch.distributed.run, this command launches it itself")
+    ap.add_argument("--synthetic", type=str, default=None, metavar="JSON",
+                    help="train on multike_amd.synthetic.SyntheticData(**JSON) instead of a dataset folder (smoke runs, tests)")
     a = ap.parse_args(argv)
+    import os
+    import sys
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "-m", "multike_amd.run"] + list(sys.argv[1:] if argv is None else argv)
+        raise SystemExit(subprocess.call(cmd))
 
     from .data_model import DataModel
     from .MultiKE_CSL import MultiKE_CV
@@ -38,8 +52,39 @@ def main(argv=None):
         except json.JSONDecodeError:
             pass
         setattr(args, k, v)
-    data = DataModel(args)
-    predicate_align_model = PredicateAlignModel(data.kgs, args)
+    if a.synthetic is not None:
+        from .synthetic import SyntheticData
+        data = SyntheticData(**dict({"dim": args.dim}, **json.loads(a.synthetic)))
+        predicate_align_model = data.predicate_align_model
+    else:
+        data = DataModel(args)
+        predicate_align_model = PredicateAlignModel(data.kgs, args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import contextlib
+        import io
+        import torch
+        import torch.distributed as dist
+        from .distributed_run import ShardedMultiKE_CV, ShardedMultiKE_Late, init_process_group_from_env
+        comm_oc = comm_v = None
+        if os.environ.get("MKE_BENCH_COMM", "") == "staged":     # dry run: ranks share GPUs, collectives staged through gloo
+            from .distributed_oc import OcHostStagedComm
+            from .distributed_views import HostStagedViewComm
+            rank = int(os.environ["RANK"])
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            comm_oc, comm_v = OcHostStagedComm(), HostStagedViewComm()
+        else:
+            rank, world = init_process_group_from_env()
+        cls = ShardedMultiKE_CV if a.method == "ITC" else ShardedMultiKE_Late
+        with (contextlib.redirect_stdout(io.StringIO()) if rank else contextlib.nullcontext()):    # the readers print per rank
+            model = cls(data, args, predicate_align_model, rank, world, comm_oc, comm_v)
+        res = model.run()
+        if rank == 0:
+            print("results:", json.dumps({k: float(v) for k, v in res.items()}))
+        dist.destroy_process_group()
+        return res
     model = (MultiKE_CV if a.method == "ITC" else MultiKE_Late)(data, args, predicate_align_model)
     return model.run()
 

@@ -1,0 +1,132 @@
+"""The multi-GPU drivers (multike_amd/distributed_run.py: `python -m multike_amd.run --gpus N`): the single-GPU schedule code
+(MultiKE_CV.run / MultiKE_Late.run, pinned to the reference's loops by tests/test_schedule_golden.py) on row-sharded tables,
+with rank-sharded validation / test, the rank-sharded k-NN refresh of truncated sampling and the soft-alignment list refresh.
+One rank in-process, and two ranks SHARING the test box's GPU (collectives staged through gloo) against it."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIM = 24
+
+
+def _setup():
+    from multike_amd.synthetic import SyntheticData, synthetic_args
+    data = SyntheticData(n_ent=1600, n_rel=20, n_attr=16, n_values=300, dim=DIM, seed=13, shared_structure=0.8)
+    n1 = data.kgs.entities_num // 2
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((n1, DIM)).astype(np.float32)
+    nm = np.concatenate([base, base + 0.8 * rng.standard_normal((n1, DIM)).astype(np.float32)])
+    data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
+    args = synthetic_args(dim=DIM, batch_size=800, attribute_batch_size=600, entity_batch_size=500, neg_triple_num=6,
+                          learning_rate=0.03, ITC_learning_rate=0.05, max_epoch=6, shared_learning_max_epoch=3, start_valid=2,
+                          eval_freq=2, start_predicate_soft_alignment=2, truncated_freq=2, truncated_epsilon=0.9,
+                          neg_sampling="truncated", seed=3, output="/tmp/multike_out_sharded/")
+    return data, args
+
+
+def _run(method, rank, world, comm_oc=None, comm_v=None):
+    from multike_amd.distributed_run import ShardedMultiKE_CV, ShardedMultiKE_Late
+    data, args = _setup()
+    cls = ShardedMultiKE_CV if method == "ITC" else ShardedMultiKE_Late
+    model = cls(data, args, data.predicate_align_model, rank, world, comm_oc, comm_v)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        res = model.run()
+    torch.cuda.synchronize()
+    return model, res, out.getvalue()
+
+
+@pytest.mark.parametrize("method", ["ITC", "SSL"])
+def test_one_rank_runs_the_whole_schedule(method):
+    model, res, log = _run(method, 0, 1)
+    assert all(np.isfinite(v) for v in res.values()) and set(res) >= {"nv", "rv", "av", "final"}
+    assert res["nv"] > 0.5 and res["final"] > 0.05            # MRR: the name view aligns; the learned shared space well above chance
+    # the schedule's between-epoch work happened on the sharded state
+    assert model._neighbors[0] is not None and model.m.relation.bat.side1.cand_table is not None      # truncated sampling active
+    assert "generating neighbors" in log and "rv valid results:" in log and "final test results:" in log
+    assert log.count("cross-kg relation inference in rel. view") == 4                                   # epochs 3..6: i > 2
+    assert os.path.exists(os.path.join(model.out_folder, "ent_embeds.npy"))
+    # relation-view loss went down
+    rel = [float(l.split("avg. loss: ")[1].split(",")[0]) for l in log.splitlines() if " of rel. view" in l]
+    assert len(rel) == 6 and rel[-1] < rel[0]
+    # sharded evaluation == the single-GPU evaluator on the gathered tables
+    from multike_amd.base.alignment import greedy_alignment
+    full = model.rv_ent_embeds.eval()
+    k = model.kgs
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, h1, mr, mrr = greedy_alignment(full[k.test_entities1], full[k.test_entities2], model.args.top_k, 1, "inner", True, 0, True)
+    np.testing.assert_allclose(res["rv"], mrr, rtol=1e-6)
+
+
+def _worker(rank, world, port, ret, method):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from multike_amd.distributed_oc import OcHostStagedComm
+        from multike_amd.distributed_views import HostStagedViewComm
+        torch.cuda.set_device(0)
+        model, res, log = _run(method, rank, world, OcHostStagedComm(), HostStagedViewComm())
+        tables = model.m.gather()
+        if rank == 0:
+            ret.put((res, {k: np.asarray(tables[k]) for k in ("ent", "rv", "av", "rel", "attr")}, log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("method", ["ITC", "SSL"])
+def test_two_ranks_equal_one_rank(method):
+    """Sharding changes nothing but the order of fp32 sums: same batches (every draw is a function of (seed, epoch)), same
+    candidate tables from the sharded k-NN refresh, same metrics from the sharded evaluator."""
+    import tempfile
+    import torch.multiprocessing as mp
+    m1, r1, _ = _run(method, 0, 1)
+    ref = m1.m.gather()
+    port = tempfile.mktemp(prefix="mke_rdv_")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, method)) for r in range(2)]
+    for p in procs:
+        p.start()
+    r2, got, log = ret.get(timeout=800)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k in r1:
+        assert abs(r2[k] - r1[k]) <= 5e-3, (k, r2[k], r1[k])
+    for k in ("ent", "rv", "av", "rel", "attr"):
+        err = np.abs(got[k] - np.asarray(ref[k]))
+        assert float(np.mean(err)) < 2e-4 and float(err.max()) < 2e-2, (k, float(np.mean(err)), float(err.max()))
+    assert "generating neighbors" in log
+
+
+@pytest.mark.timeout(600)
+def test_command_line_launches_itself_with_gpus_2():
+    """`python -m multike_amd.run --gpus 2 ...` started plainly launches torch.distributed.run itself, one process per rank
+    (here: both on the test box's one GPU, collectives staged through gloo) and rank 0 prints the closing results."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MKE_BENCH_COMM="staged", PYTHONPATH=ROOT)
+    sets = ["max_epoch=2", "shared_learning_max_epoch=1", "start_valid=1", "eval_freq=1", "batch_size=700", "attribute_batch_size=500",
+            "entity_batch_size=400", "neg_triple_num=4", "dim=16", "truncated_freq=1", "truncated_epsilon=0.9",
+            "start_predicate_soft_alignment=0", "output=\"/tmp/multike_out_cli/\""]
+    cmd = [sys.executable, "-m", "multike_amd.run", "--method", "SSL", "--gpus", "2", "--synthetic",
+           json.dumps({"n_ent": 1000, "n_rel": 12, "n_attr": 10, "n_values": 200})]
+    for s_ in sets:
+        cmd += ["--set", s_]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("results:")]
+    assert len(line) == 1, out.stdout[-2000:]
+    res = json.loads(line[0][len("results:"):])
+    assert set(res) == {"nv", "rv", "av", "avg", "wva", "final"} and all(np.isfinite(v) for v in res.values())
+    assert out.stdout.count("wvag test results:") == 1           # printed by rank 0 only
