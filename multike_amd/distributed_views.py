@@ -47,11 +47,22 @@ class ViewComm:
             dist.all_reduce(t)
 
 
+def _bcast(self, t, src=0):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src)
+
+
+ViewComm.broadcast = _bcast
+
+
 class NoComm(ViewComm):
     """world == 1: a view's collectives are no-ops whatever process group the process is part of (a one-rank view may live
     inside a multi-rank job: the self-test's reference run, a replicated small model)."""
 
     def all_reduce(self, t):
+        pass
+
+    def broadcast(self, t, src=0):
         pass
 
 
@@ -65,6 +76,11 @@ class HostStagedViewComm(ViewComm):
     def all_reduce(self, t):
         c = t.cpu()
         dist.all_reduce(c)
+        t.copy_(c)
+
+    def broadcast(self, t, src=0):
+        c = t.cpu()
+        dist.broadcast(c, src)
         t.copy_(c)
 
 
@@ -155,6 +171,57 @@ class HipAttrBackend:
     def scalar_like(self):
         return torch.zeros(1, dtype=torch.float64, device="cuda")
 
+    # --- replicated-compute step (ShardedAttributeView mode="replicated") -------------------------------------------------
+    def gather_heads(self, view, pos, lh, n):
+        """[n, dim] float32: the RAW rows of the batch's head entities at the positions this rank owns, zero elsewhere (the
+        all-reduce that follows assembles the whole batch's heads on every rank: adding zeros is exact)."""
+        out = torch.zeros(n, view.dim, dtype=torch.float32, device="cuda")
+        if len(pos):
+            out[torch.as_tensor(pos, device="cuda")] = self.ent.raw()[torch.as_tensor(np.asarray(lh, dtype=np.int64), device="cuda")]
+        return out
+
+    def replicated_step(self, view, H, ia, iv, w, scale):
+        """The WHOLE batch's forward + backward on this rank, on a compact table of the gathered head rows (read through
+        l2_normalize like the shard).  Leaves the heads' gradient rows in the compact table's scratch and returns the packed
+        [CNN parameter gradients | attribute-table gradient] buffer (a view into it is what `apply_replicated` consumes)."""
+        n, d = H.shape
+        if getattr(self, "_cent", None) is None or self._cent.n_rows < n:
+            self._cent = EmbeddingTable(max(n, 1), d, "batch_heads", normalize=True)
+        ct = self._cent
+        ct.data[:n, :d] = H
+        idx = torch.arange(n, dtype=torch.int32, device="cuda")
+        ia_, iv_ = self._i32(ia), self._i32(iv)
+        wt = None if w is None else torch.as_tensor(np.ascontiguousarray(w, dtype=np.float32), device="cuda")
+        self._keep = (idx, ia_, iv_, wt)
+        self.args, self.part = self.cnn._args(self.eng, ct, self.attr, self.lit, idx, ia_, iv_, wt, n, scale, view.opt_name, view.lr,
+                                              "Adagrad", True, 1)
+        self.args.update = 0
+        _lib.attr_step_phases(self.args, _lib.ATTR_FWD | _lib.ATTR_TAIL | _lib.ATTR_BWD)
+        if view.rank == 0:                       # every rank computed the whole batch's loss: count it once
+            self.loss += self.part[:_lib.LOSS_PARTIALS].sum()
+        self._n_rep = n
+        return torch.cat([self.cnn.grads, self.attr.grad.reshape(-1)])
+
+    def apply_replicated(self, view, pos, lh, canon):
+        """canon: rank 0's [parameter | attribute] gradients (identical updates of the replicated state on every rank); the
+        heads this rank owns take their gradient rows from its own (bit-wise equally good) copy of the batch's."""
+        ct, n = self._cent, self._n_rep
+        npar = self.cnn.grads.numel()
+        self.cnn.grads.copy_(canon[:npar])
+        self.attr.grad.copy_(canon[npar:].view_as(self.attr.grad))
+        a = self.args
+        if len(pos):
+            rows = ct.grad[torch.as_tensor(pos, device="cuda")].contiguous()
+            _lib.rows_scatter_add(self._i32(lh), rows, view.dim, self.ent.grad, self.ent.touched, a.tag)
+        ct.grad[:n].zero_()
+        f32, i32 = torch.float32, torch.int32
+        a.ent_table, a.n_ent = _lib.ptr(self.ent.data, f32, "ent"), self.ent.n_rows
+        a.ent_acc = _lib.ptr(self.ent.slot(view.opt_name), f32, "acc")
+        a.ent_grad, a.ent_touched = _lib.ptr(self.ent.grad, f32, "grad"), _lib.ptr(self.ent.touched, i32, "touched")
+        a.attr_touched = None
+        a.update = 1
+        _lib.attr_step_phases(a, _lib.ATTR_UPD)
+
     def tables(self):
         return (self.ent.raw().cpu().numpy(), self.attr.raw().cpu().numpy(), self.cnn.numpy_params())
 
@@ -167,11 +234,21 @@ class HipAttrBackend:
 class ShardedAttributeView:
     def __init__(self, ent0: np.ndarray, attr0: np.ndarray, lit: np.ndarray, cnn_params: dict, rank: int, world: int,
                  lr: float = 0.001, opt_name: str = "attribute", backend_cls=None, comm=None, tables_of: "ShardedAttributeView" = None,
-                 tables=None, n_ent: int = None):
+                 tables=None, n_ent: int = None, mode: str = None):
         """tables_of: another attribute graph of the same run (code/MultiKE_model.py:134-151, 153-190: the attribute view and
         the two cross-KG attribute-inference graphs share `av_ent_embeds` / `attr_embeds` and have a CNN parameter set and an
         optimizer each): this one trains ITS tables — pass a different `opt_name`; `ent0` / `attr0` / `lit` are then unused."""
         self.rank, self.world, self.lr, self.opt_name = rank, world, float(lr), opt_name
+        # mode "parallel" (default): each rank trains the triples whose head it owns — 2 scalar all-reduces + 2 gradient
+        #   all-reduces per step.  mode "replicated": the batch's head rows are assembled on every rank (1 all-reduce of
+        #   [B, dim]), EVERY rank computes the whole step (at 5000 triples the step is a latency chain: a rank's 1 / world share
+        #   costs what the whole batch costs, DESIGN.md 5.3), rank 0's parameter / attribute-table gradients are broadcast
+        #   (replicas stay bit-identical: each rank's own sums differ in the order of their fp32 atomics) and every rank
+        #   updates the head rows it owns: 2 collectives per step instead of 4.  MKE_ATTR_MODE overrides.
+        import os
+        self.mode = mode or os.environ.get("MKE_ATTR_MODE", "parallel")
+        if self.mode not in ("parallel", "replicated"):
+            raise ValueError(f"ShardedAttributeView: mode {self.mode!r}")
         if tables is not None:      # EmbeddingTables of the caller: (this rank's av_ent shard of n_ent rows, attr, literal)
             self.dim, self.n_ent = tables[0].dim, int(n_ent)
             self.comm = _comm_for(world, comm)
@@ -194,10 +271,14 @@ class ShardedAttributeView:
         identical on every rank): this rank trains the triples whose head it owns."""
         be, cm = self.backend, self.comm
         pos, lh = _owned(ih, self.rank, self.world)
+        ia_all, iv_all, w_all = ia, iv, w
         ia, iv = np.asarray(ia)[pos], np.asarray(iv)[pos]
         w = None if w is None else np.asarray(w)[pos]
         if self.world == 1 and hasattr(be, "step_alone"):
             be.step_alone(self, lh, ia, iv, w, scale)
+            return
+        if self.mode == "replicated" and self.world > 1:
+            self._replicated_step(np.asarray(ih), pos, lh, np.asarray(ia_all), np.asarray(iv_all), w_all, scale)
             return
         S = be.forward(self, lh, ia, iv, w, scale)
         cm.all_reduce(S)                                   # sum z^2 over the whole batch (code/MultiKE_model.py:60)
@@ -207,11 +288,22 @@ class ShardedAttributeView:
             cm.all_reduce(g)                               # replicated parameters: CNN pack, attribute table
         be.update(self)
 
+    def _replicated_step(self, ih, pos, lh, ia, iv, w, scale):
+        be, cm = self.backend, self.comm
+        H = be.gather_heads(self, pos, lh, len(ih))
+        cm.all_reduce(H)                                   # every rank: the raw rows of all the batch's heads
+        canon = be.replicated_step(self, H, ia, iv, w, scale)
+        cm.broadcast(canon, 0)                             # rank 0's sums are everybody's: replicas stay bit-identical
+        be.apply_replicated(self, pos, lh, canon)
+
     def steps(self, ih, ia, iv, w, step_off, scale: float = 1.0):
         """Consecutive steps over epoch-ordered host arrays (step s = positions [step_off[s], step_off[s + 1])): what `step`
         does per step, with this rank's triples of ALL steps filtered and copied to the device once."""
         be = self.backend
-        if not hasattr(be, "stage"):
+        if not hasattr(be, "stage") or (self.mode == "replicated" and self.world > 1):
+            if isinstance(ih, torch.Tensor):
+                ih, ia, iv = (t.cpu().numpy() for t in (ih, ia, iv))
+                w = None if w is None else w.cpu().numpy()
             for s in range(len(step_off) - 1):
                 lo, hi = int(step_off[s]), int(step_off[s + 1])
                 self.step(ih[lo:hi], ia[lo:hi], iv[lo:hi], None if w is None else w[lo:hi], scale)

@@ -341,6 +341,34 @@ class OracleAttrBackend:
             mo.adagrad_dense(self.p[k], self.acc_p[k], self.flat[o:o + n].reshape(self.p[k].shape), view.lr)
             o += n
 
+    # replicated-compute step (ShardedAttributeView mode="replicated"): the same three hooks as the HIP backend
+    def gather_heads(self, view, pos, lh, n):
+        import torch
+        out = np.zeros((n, view.dim))
+        out[pos] = self.ent[lh]
+        return torch.from_numpy(out)
+
+    def replicated_step(self, view, H, ia, iv, w, scale):
+        import torch
+        hs = mo.l2_normalize_rows(H.numpy())
+        self.ia = np.asarray(ia, dtype=np.int64)
+        _, c = self.ao.forward(self.p, hs, self.attr[self.ia], self.lit[np.asarray(iv, dtype=np.int64)])
+        loss, self.g_h_all, g_out, T, t = self.ao.dp_tail(c, hs, w, scale, c["S"])
+        if view.rank == 0:
+            self.loss += loss
+        g = self.ao.dp_backward(self.p, c, t, g_out, c["S"], T)
+        ga = np.zeros_like(self.attr)
+        np.add.at(ga, self.ia, g["as"])
+        return torch.from_numpy(np.concatenate([np.concatenate([g[k].reshape(-1) for k in self.ao.PARAM_NAMES]), ga.reshape(-1)]))
+
+    def apply_replicated(self, view, pos, lh, canon):
+        canon = canon.numpy()
+        npar = sum(self.p[k].size for k in self.ao.PARAM_NAMES)
+        self.flat, self.ga = canon[:npar], canon[npar:].reshape(self.attr.shape)
+        self.ge = np.zeros_like(self.ent)
+        np.add.at(self.ge, lh, self.g_h_all[pos])
+        self.update(view)
+
     def take_loss(self):
         import torch
         v = torch.tensor([self.loss], dtype=torch.float64)

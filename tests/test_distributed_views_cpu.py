@@ -42,14 +42,14 @@ def _attr_data():
     return ent, attr, lit, P, batches
 
 
-def _attr_worker(rank, world, port, ret):
+def _attr_worker(rank, world, port, ret, mode="parallel"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_views import ShardedAttributeView
         from oracle_backend import OracleAttrBackend
         ent, attr, lit, P, batches = _attr_data()
-        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.05, backend_cls=OracleAttrBackend)
+        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.05, backend_cls=OracleAttrBackend, mode=mode)
         for (ih, ia, iv, w) in batches:
             v.step(ih, ia, iv, w, scale=2.0)
         loss = v.epoch_loss()
@@ -61,12 +61,14 @@ def _attr_worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_attribute_view_equals_single_process_oracle(world):
+@pytest.mark.parametrize("world,mode", [(2, "parallel"), (3, "parallel"), (2, "replicated"), (3, "replicated")])
+def test_sharded_attribute_view_equals_single_process_oracle(world, mode):
+    """mode "replicated": the batch's head rows assembled on every rank, the whole step computed by every rank, rank 0's
+    replicated-state gradients broadcast, every rank updating the heads it owns (2 collectives per step instead of 4)."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_attr_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_attr_worker, args=(r, world, port, ret, mode)) for r in range(world)]
     for p in procs:
         p.start()
     full, a, p, loss = ret.get(timeout=240)

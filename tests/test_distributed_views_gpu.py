@@ -34,7 +34,7 @@ def _attr_data():
     return ent, attr, lit, P, batches
 
 
-def _attr_worker(rank, world, port, ret):
+def _attr_worker(rank, world, port, ret, mode="parallel"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
@@ -42,11 +42,20 @@ def _attr_worker(rank, world, port, ret):
         from multike_amd.distributed_views import HostStagedViewComm, ShardedAttributeView
         torch.cuda.set_device(0)
         ent, attr, lit, P, batches = _attr_data()
-        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.01, comm=HostStagedViewComm())
+        v = ShardedAttributeView(ent, attr, lit, P, rank, world, lr=0.01, comm=HostStagedViewComm(), mode=mode)
         for (ih, ia, iv, w) in batches:
             v.step(ih, ia, iv, w, scale=2.0)
         loss = v.epoch_loss()
         full, a, p = v.gather()
+        # replicated state must be BIT-identical on the two ranks (rank 0's gradients are everybody's in "replicated" mode;
+        # all-reduced sums in "parallel" mode)
+        import torch.distributed as dist2
+        mine = torch.cat([v.backend.cnn.params.detach().reshape(-1), v.backend.attr.data.reshape(-1)]).cpu()
+        other = mine.clone()
+        dist2.broadcast(other, 0)
+        same = torch.tensor([1 if torch.equal(mine, other) else 0])
+        dist2.all_reduce(same, op=dist2.ReduceOp.MIN)
+        assert int(same) == 1, "replicated parameters differ between the ranks"
         ok = float(v.backend.cnn.grads.abs().max()) == 0.0 and float(v.backend.attr.grad.abs().max()) == 0.0 and \
             float(v.backend.ent.grad.abs().max()) == 0.0
         if rank == 0:
@@ -55,13 +64,13 @@ def _attr_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def _run(worker, world=2):
+def _run(worker, world=2, extra=()):
     import torch.multiprocessing as mp
     import tempfile
     port = tempfile.mktemp(prefix="mke_rdv_")   # rendezvous file (init_method="file://..."): no TCP port to collide on
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, ret) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
     out = ret.get(timeout=480)
@@ -72,8 +81,12 @@ def _run(worker, world=2):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_attribute_view_equals_dense_oracle():
-    full, a, p, loss, ok = _run(_attr_worker)
+@pytest.mark.parametrize("mode", ["parallel", "replicated"])
+def test_two_ranks_attribute_view_equals_dense_oracle(mode):
+    """mode "replicated": every rank computes the whole step on the gathered head rows (1 all-reduce + 1 broadcast per step
+    instead of 4 all-reduces), applies the heads it owns; a rank that owns none of a step's heads still updates the replicated
+    state identically."""
+    full, a, p, loss, ok = _run(_attr_worker, extra=(mode,))
     ent, attr, lit, P, batches = _attr_data()
     p64 = {k: v.astype(np.float64) for k, v in P.items()}
     acc = {k: np.full_like(v, 0.1) for k, v in p64.items()}
