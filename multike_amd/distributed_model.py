@@ -59,8 +59,8 @@ class ShardedITC:
         # one tag range per component (they share the tables' touched-flag arrays: a flag is `touched[row] == tag`)
         base = iter(k << 26 for k in range(1, 16))
         oc = dict(rank=rank, world=world, seed=seed, lr=learning_rate, comm=comm_oc, ent_table=self.rv_ent, rel_table=self.rel, n_ent=n_ent)
-        self.relation = OwnerComputesTrainer(kgs, None, None, max(1, batch_size // world), neg_triple_num, opt_name="relation",
-                                             tag_base=next(base), **oc)
+        self.relation = OwnerComputesTrainer(kgs, None, None, max(1, -(-batch_size // world)), neg_triple_num, opt_name="relation",
+                                             tag_base=next(base), global_batch=batch_size, **oc)
         self._oc_args, self._list_tags, self._list_gen = oc, {}, {}
 
         def mk_list(key, opt):

@@ -344,7 +344,7 @@ class OwnerComputesTrainer:
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
                  batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None, ent_table=None, rel_table=None,
-                 opt_name: str = "relation", n_ent: int = None, tag_base: int = None):
+                 opt_name: str = "relation", n_ent: int = None, tag_base: int = None, global_batch: int = None):
         """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
         loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
         with); scale: the loss factor (2 for code/MultiKE_model.py:349-369); tables_of: another trainer of the same
@@ -434,7 +434,10 @@ class OwnerComputesTrainer:
                 t = torch.as_tensor(np.asarray(kt[k] if kt is not None else kgs.triples[k], dtype=np.int32).reshape(-1, 3), device=dev)
                 known = self.backend.make_known(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())
                 sides.append(KGSide(kgs.entities(k), known, device=dev))
-            self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], batch_size * world, neg_per_pos,
+            # a global step = `global_batch` positives when given (the reference's batch_size whatever the world size: every
+            # rank is home of ceil(global / world) of them, the last of fewer), else batch_size per rank (weak scaling)
+            self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1],
+                                       int(global_batch) if global_batch else batch_size * world, neg_per_pos,
                                        device=dev, seed=seed)
         self.steps = self.bat.steps
         # trainers sharing the touched-flag arrays keep apart in tag space (a flag is `touched[row] == tag`)

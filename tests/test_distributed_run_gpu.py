@@ -23,7 +23,7 @@ def _setup():
     base = rng.standard_normal((n1, DIM)).astype(np.float32)
     nm = np.concatenate([base, base + 0.8 * rng.standard_normal((n1, DIM)).astype(np.float32)])
     data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
-    args = synthetic_args(dim=DIM, batch_size=800, attribute_batch_size=600, entity_batch_size=500, neg_triple_num=6,
+    args = synthetic_args(dim=DIM, batch_size=801, attribute_batch_size=601, entity_batch_size=499, neg_triple_num=6,
                           learning_rate=0.03, ITC_learning_rate=0.05, max_epoch=6, shared_learning_max_epoch=3, start_valid=2,
                           eval_freq=2, start_predicate_soft_alignment=2, truncated_freq=2, truncated_epsilon=0.9,
                           neg_sampling="truncated", seed=3, output="/tmp/multike_out_sharded/")
