@@ -3,6 +3,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import GOLDEN
 from oracle import eval_oracle as eo
@@ -230,3 +231,66 @@ def test_sim_sample_matches_product_and_select(n, d, lo, hi, ns):
         assert int(cnt.min()) == n and int(cnt.max()) == n
         sims = cand[:, 0, :n, 1].contiguous().view(torch.float32)           # column order = column index
         assert torch.equal(sims[:, cols], out)
+
+
+@pytest.mark.timeout(600)
+def test_evaluator_at_full_size_properties_and_spot_checks():
+    """SURVEY f2's size: 60K x 60K x 75 (the matrix the reference materialises as 14 GB).  Size-independent properties —
+    perfect alignment ranks every row first; a rotation of the columns changes no rank (what the rank-sharded evaluator of
+    multike_amd/distributed_run.py relies on) — plus 64 rows checked against the float64 oracle on all 60K columns."""
+    from multike_amd.base.alignment import alignment_counts
+    rng = np.random.default_rng(60)
+    n, d = 60_000, 75
+    e2 = rng.standard_normal((n, d)).astype(np.float32)
+    greater, ties, best = alignment_counts(e2, e2)
+    assert int(greater.max()) == 0 and int(ties.max()) == 1 and np.array_equal(best.cpu().numpy(), np.arange(n))
+    e1 = (0.35 * e2 + rng.standard_normal((n, d))).astype(np.float32)
+    g1, t1, b1 = alignment_counts(e1, e2)
+    lo, hi = 17_000, 24_500                                   # a block of rows against the rotated columns
+    rot = np.concatenate([e2[lo:hi], e2[:lo], e2[hi:]])
+    g2, t2, _ = alignment_counts(e1[lo:hi], rot)
+    assert torch.equal(g2, g1[lo:hi]) and torch.equal(t2, t1[lo:hi])
+    rows = rng.choice(n, 64, replace=False)
+    a = eo.normalize_rows(e1[rows].astype(np.float64))
+    b = eo.normalize_rows(e2.astype(np.float64))
+    sim = a @ b.T
+    exp = np.sum(sim > sim[np.arange(64), rows][:, None], axis=1)
+    got = g1.cpu().numpy()[rows]
+    assert np.mean(got == exp) >= 0.95 and np.max(np.abs(got - exp)) <= 2          # integer ranks; fp32 near-ties may flip one
+    assert 0.05 < float((g1 == 0).double().mean()) < 0.95                                # neither trivial nor hopeless
+
+
+@pytest.mark.timeout(900)
+def test_knn_refresh_at_full_size_and_its_sharded_form():
+    """SURVEY f3's size: 100K entities, k = int(0.02 * 100K) = 2000 neighbours.  Every row contains itself; 24 rows checked
+    against the float64 definition (top-k inner products, unordered); the four slices of `neighbour_table(part=(r, 4))` — what
+    each of four ranks computes in the multi-GPU refresh — reassemble the single-GPU table exactly."""
+    from multike_amd.base.batch import neighbour_table
+    rng = np.random.default_rng(100)
+    n, d, k = 100_000, 75, 2000
+    centres = rng.standard_normal((400, d))
+    e = (centres[rng.integers(0, 400, n)] + 0.8 * rng.standard_normal((n, d))).astype(np.float32)     # clustered: real neighbourhoods
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    ids = np.arange(n) + 7
+    table, valid = neighbour_table(e, ids, k, n + 7)
+    t = table.cpu().numpy()
+    assert int(valid.sum()) == n and int(valid[:7].sum()) == 0
+    assert bool((table[7:] == torch.arange(7, n + 7, device=table.device, dtype=torch.int32)[:, None]).any(dim=1).all())
+    e64 = e.astype(np.float64)
+    for i in rng.choice(n, 24, replace=False):
+        sim = e64 @ e64[i]
+        chosen = t[i + 7].astype(np.int64) - 7
+        assert len(set(chosen.tolist())) == k
+        out = np.ones(n, dtype=bool)
+        out[chosen] = False
+        assert sim[chosen].min() >= sim[out].max() - 2e-6, i                                          # a true top-k set up to fp32 ties
+    full = torch.zeros_like(table)
+    seen = torch.zeros(n + 7, dtype=torch.int32, device=table.device)
+    for r in range(4):
+        tp, vp, ip = neighbour_table(e, ids, k, n + 7, part=(r, 4))
+        full[ip] = tp[ip]
+        seen[ip] += 1
+        assert int(vp.sum()) == ip.numel()
+    assert int(seen[7:].min()) == 1 and int(seen[7:].max()) == 1 and int(seen[:7].sum()) == 0
+    # the same top-k SETS (the order inside a row is unspecified, and identical here because the kernels are deterministic)
+    assert torch.equal(torch.sort(full[7:], dim=1).values, torch.sort(table[7:], dim=1).values)
