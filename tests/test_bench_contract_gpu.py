@@ -80,11 +80,12 @@ def test_two_rank_launch_dry_run():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("nproc", [1, 2])
+@pytest.mark.parametrize("nproc", [1, 2, 8])
 def test_multi_gpu_selftest_tool(nproc):
     """tools/multi_gpu_selftest.py — what a multi-GPU node runs before bench.py: every collective of the sharded trainers on
     known data, then every sharded loop against the same global steps on one rank.  nproc 1: a real 1-rank RCCL group;
-    nproc 2: two ranks sharing the GPU, collectives staged through gloo (dry run of the N > 1 control flow)."""
+    nproc 2 / 8: that many ranks sharing the GPU, collectives staged through gloo (dry run of the N > 1 control flow at the
+    world sizes the driver launches)."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
