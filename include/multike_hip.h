@@ -73,14 +73,6 @@ const char* mke_last_error(void);
  * Returns the previous value through *old_value when it is not NULL. */
 int mke_set_option(const char* name, int value, int* old_value);
 
-/* Optional allocator hooks for a host side that wants its LARGE tables physically contiguous (not used by any entry point
- * above or below: those never allocate).  Signatures are torch.cuda.memory.CUDAPluggableAllocator's.  Why: GBs of randomly
- * gathered 1-KB rows run 239-304 us per step-kernel launch at the configs[4] shape depending on where the driver placed the
- * pages of THAT allocation, 258 us on every hipDeviceMallocContiguous one — reproducible, not faster on average
- * (tools/c5_variance.py, tools/c5_contig_ab.sh); the Python host side uses them when MKE_CONTIGUOUS_TABLES=1.
- * mke_alloc_contiguous falls back to hipMalloc when no contiguous range is left; NULL = out of memory. */
-void* mke_alloc_contiguous(long size, int device, void* stream);
-void mke_free_contiguous(void* ptr, long size, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (1) Fused relation-view triple step: gather + normalise-on-read + translation score + logistic loss

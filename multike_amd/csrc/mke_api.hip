@@ -81,27 +81,3 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
 extern "C" int mke_version(void) { return MKE_VERSION; }
 extern "C" const char* mke_last_error(void) { return mke::g_err; }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Optional allocator hooks for the HOST side (not used by any entry point of the step API, which never allocates): tables of
-// GBs of randomly gathered 1-KB rows run 20 % faster or slower depending on where the driver places their pages
-// (tools/c5_variance.py: 242-305 us for the same kernel on the same batches, stable per allocation); physically contiguous
-// memory (hipDeviceMallocContiguous) takes the same 258 us every time (opt-in on the host side).  Signatures are
-// torch.cuda.memory.CUDAPluggableAllocator's: (size, device, stream) -> pointer, (pointer, size, device, stream).
-extern "C" void* mke_alloc_contiguous(long size, int device, void* stream) {
-  (void)stream;
-  void* p = nullptr;
-  int cur = 0;
-  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
-  if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
-  hipError_t e = hipExtMallocWithFlags(&p, (size_t)size, hipDeviceMallocContiguous);
-  if (e != hipSuccess) {   // not enough contiguous memory: an ordinary allocation is still correct
-    (void)hipGetLastError();
-    e = hipMalloc(&p, (size_t)size);
-  }
-  if (cur != device) (void)hipSetDevice(cur);
-  return e == hipSuccess ? p : nullptr;
-}
-extern "C" void mke_free_contiguous(void* ptr, long size, int device, void* stream) {
-  (void)size; (void)device; (void)stream;
-  if (ptr) (void)hipFree(ptr);
-}

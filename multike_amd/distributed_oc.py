@@ -405,11 +405,9 @@ class OwnerComputesTrainer:
                 o.ref_count = torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = o.ref_count if exclusive_rows else None
         else:
-            from .tables import alloc_like_table
-            big = lambda fill=0.0: alloc_like_table((max(1, self.n_local), st), fill, dtype=dtype, device=dev)   # contiguous when large
-            self.ent = big()
+            self.ent = torch.zeros(max(1, self.n_local), st, dtype=dtype, device=dev)
             self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
-            self.ent_grad = big()
+            self.ent_grad = torch.zeros_like(self.ent)
             self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
             # --- replicated relation state ----------------------------------------------------------
@@ -420,8 +418,7 @@ class OwnerComputesTrainer:
         if ent_table is not None:
             self.ent_acc, self.rel_acc = ent_table.slot(opt_name), rel_table.slot(opt_name)
         else:
-            from .tables import alloc_like_table
-            self.ent_acc = alloc_like_table(tuple(self.ent.shape), ADAGRAD_INIT_ACC, dtype=self.ent.dtype, device=self.ent.device)  # per-optimizer slot (code/MultiKE_model.py:17)
+            self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)     # per-optimizer slots (code/MultiKE_model.py:17)
             self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
         if batcher is not None:

@@ -20,39 +20,6 @@ from . import _lib
 ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_value (TF1)
 
 
-# Where the driver places the pages of a multi-GB table decides how fast randomly gathered rows come back: with the default
-# allocator the SAME kernel on the SAME batches takes 239-304 us at the c5 shape (and the row update 46-57 us) depending on
-# the allocation — stable for the life of an allocation, different for the next one, whatever its virtual address and whatever
-# the offsets between table, gradient scratch and accumulator inside one arena (tools/c5_variance.py, tools/c5_skew.py).
-# PHYSICALLY CONTIGUOUS allocations (hipExtMallocWithFlags(hipDeviceMallocContiguous) through a torch MemPool over
-# mke_alloc_contiguous) take 258 / 57 us every time: reproducible, and no faster on average (three fresh processes each,
-# tools/c5_contig_ab.sh: 328-329 us per step contiguous, 310 / 325 / 343 default).  Hence opt-in: MKE_CONTIGUOUS_TABLES=1
-# allocates tables, scratch and slots of >= 256 MB this way (measurement runs that must repeat); default off.
-CONTIGUOUS_MIN_BYTES = 256 << 20
-_pool = None
-
-
-def _contiguous_pool():
-    global _pool
-    if _pool is None:
-        alloc = torch.cuda.memory.CUDAPluggableAllocator(_lib.SO_PATH, "mke_alloc_contiguous", "mke_free_contiguous")
-        _pool = (torch.cuda.MemPool(alloc.allocator()), alloc)        # both live as long as the process
-    return _pool[0]
-
-
-def alloc_like_table(shape, fill: float = 0.0, dtype=torch.float32, device="cuda") -> torch.Tensor:
-    """A [rows, stride] (or [copies, rows, stride]) float array for a table, its gradient scratch or an optimizer slot."""
-    import os
-    device = torch.device(device)
-    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-    contig = device.type == "cuda" and os.environ.get("MKE_CONTIGUOUS_TABLES", "0") == "1" and nbytes >= CONTIGUOUS_MIN_BYTES
-    if not contig:
-        return torch.full(shape, fill, dtype=dtype, device=device) if fill else torch.zeros(shape, dtype=dtype, device=device)
-    with torch.cuda.use_mem_pool(_contiguous_pool()):
-        t = torch.empty(shape, dtype=dtype, device=device)
-    return t.fill_(fill) if fill else t.zero_()
-
-
 class EmbeddingTable:
     def __init__(self, n_rows: int, dim: int, name: str = "", normalize: bool = True, trainable: bool = True,
                  device="cuda", values=None, seed=None, grad_copies: int = 1):
@@ -60,7 +27,7 @@ class EmbeddingTable:
         self.normalize, self.trainable = bool(normalize), bool(trainable)
         self.stride = _lib.stride_for(self.dim)
         self.device = torch.device(device)
-        self.data = alloc_like_table((self.n_rows, self.stride), device=self.device)
+        self.data = torch.zeros(self.n_rows, self.stride, dtype=torch.float32, device=self.device)
         if values is not None:
             v = torch.as_tensor(np.asarray(values), dtype=torch.float32)
             assert v.shape == (self.n_rows, self.dim), (v.shape, (self.n_rows, self.dim))
@@ -86,8 +53,8 @@ class EmbeddingTable:
     @property
     def grad(self) -> torch.Tensor:
         if self._grad is None:
-            self._grad = alloc_like_table(tuple(self.data.shape) if self.grad_copies == 1 else
-                                          (self.grad_copies,) + tuple(self.data.shape), device=self.device)
+            self._grad = torch.zeros_like(self.data) if self.grad_copies == 1 else \
+                torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
         return self._grad
 
     @property
@@ -100,7 +67,7 @@ class EmbeddingTable:
         """Adagrad accumulator of one optimizer (created on first use, filled with 0.1)."""
         s = self.slots.get(optimizer_name)
         if s is None:
-            s = alloc_like_table(tuple(self.data.shape), ADAGRAD_INIT_ACC, device=self.device)
+            s = torch.full_like(self.data, ADAGRAD_INIT_ACC)
             self.slots[optimizer_name] = s
         return s
 

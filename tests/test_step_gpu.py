@@ -531,34 +531,3 @@ def test_row_update_one_flag_per_lane(d):
     finally:
         _lib.set_option("update_chunk", old)
 
-
-def test_contiguous_table_allocation_is_the_same_function(monkeypatch):
-    """MKE_CONTIGUOUS_TABLES=1: tables, gradient scratch and optimizer slots from a torch MemPool over
-    hipExtMallocWithFlags(hipDeviceMallocContiguous) (reproducible timings on multi-GB tables, multike_amd/tables.py): the
-    step on them equals the step on ordinary allocations."""
-    from gpu_util import grouped_batch, dev_i32
-    from multike_amd import tables
-    from multike_amd.tables import EmbeddingTable, StepEngine
-    rng = np.random.default_rng(3)
-    n_ent, n_rel, d, P, N = 4000, 30, 75, 600, 10
-    ent = mo.xavier_truncated_normal((n_ent, d), rng)
-    rel = mo.xavier_truncated_normal((n_rel, d), rng)
-    pos, neg = grouped_batch(rng, n_ent, n_rel, P, N, irregular=False)
-    pos_d, neg_d = tuple(dev_i32(a) for a in pos), tuple(dev_i32(a) for a in neg)
-
-    def run():
-        E = EmbeddingTable(n_ent, d, "ent", values=ent)
-        R = EmbeddingTable(n_rel, d, "rel", values=rel)
-        eng = StepEngine()
-        loss = [float(eng.relation_step(E, R, "relation", pos_d, neg_d, neg_per_pos=N, lr=0.01).sum()) for _ in range(3)]
-        return E, R, loss
-
-    E0, R0, l0 = run()
-    monkeypatch.setenv("MKE_CONTIGUOUS_TABLES", "1")
-    monkeypatch.setattr(tables, "CONTIGUOUS_MIN_BYTES", 1 << 12)
-    E1, R1, l1 = run()
-    assert tables._pool is not None                                   # the pool was really used
-    np.testing.assert_allclose(l1, l0, rtol=1e-6)
-    np.testing.assert_allclose(E1.raw().cpu().numpy(), E0.raw().cpu().numpy(), rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(E1.slot("relation").cpu().numpy(), E0.slot("relation").cpu().numpy(), rtol=1e-4, atol=1e-7)
-    assert float(E1.grad.abs().max()) == 0.0 and float(E1.data[:, d:].abs().max()) == 0.0
