@@ -110,6 +110,14 @@ class _ShardedMixin:
             setattr(self, name, _View(self, {"name_embeds": "nv", "rv_ent_embeds": "rv", "av_ent_embeds": "av", "ent_embeds": "final"}[name]))
         self.rel_embeds, self.attr_embeds = self.m.rel, self.m.attr        # replicated: plain tables
 
+    def _prepare(self):
+        """The schedule's own preparation (step counts, supervision lists), then: the lists it will hand to the phases ARE the
+        ones the sharded trainers were built on (same concatenations) — recorded by identity so that only a soft-alignment
+        refresh (new list objects) rebuilds a trainer."""
+        super()._prepare()
+        self._installed = {"ckge_rel": self._ckge_rel_triples, "ckge_attr": self._ckge_attr_triples,
+                           "ckgp_rel": self._ckgp_rel_triples, "ckga_attr": self._ckga_attr_triples}
+
     # --- rows of a view, assembled on every rank ----------------------------------------------------------------------
     def rows(self, choice, ids, w=(1, 1, 1)) -> torch.Tensor:
         """[len(ids), dim] float32 on the device: the rows `choice` denotes (code/MultiKE_Late.py:15-28) of the GLOBAL entity
