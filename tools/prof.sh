@@ -17,7 +17,8 @@ python tools/rocpd_summary.py $db $top g
 python tools/rocpd_summary.py $db --dump "k_triple_score" gpurun_out/${name}_dispatches.csv > /dev/null
 python tools/rocpd_summary.py $db --dump "k_rows_update_multi" gpurun_out/${name}_dispatches_update.csv > /dev/null
 echo
-echo "result line of the same invocation (profiler attached):"
+echo "result line of the same invocation (profiler attached: its HIP-event figures — roofline.avg_launch_us, the step breakdown —"
+echo "carry the profiler's per-dispatch overhead; the kernel times to read are the table's averages):"
 echo
 grep '^{' gpurun_out/$name.log | tail -1 | python -c '
 import json, sys
