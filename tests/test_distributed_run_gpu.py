@@ -131,3 +131,38 @@ def test_command_line_launches_itself_with_gpus_2():
     res = json.loads(line[0][len("results:"):])
     assert set(res) == {"nv", "rv", "av", "avg", "wva", "final"} and all(np.isfinite(v) for v in res.values())
     assert out.stdout.count("wvag test results:") == 1           # printed by rank 0 only
+
+
+@pytest.mark.timeout(900)
+def test_sharded_driver_from_a_dataset_folder_learns_like_the_single_gpu_driver(tmp_path):
+    """Dataset folder -> DataModel -> the REAL PredicateAlignModel (its `update_predicate_alignment` rebuilds the two predicate
+    lists after epoch 10: `set_lists` on the sharded trainers) -> `ShardedMultiKE_CV.run()` on two KGs that share 80 % of their
+    structure: the relation and attribute views learn the held-out links, to the level the single-GPU driver reaches from the
+    same initial state (different batch draws: statistically, not bit for bit)."""
+    from multike_amd.data_model import DataModel
+    from multike_amd.distributed_run import ShardedMultiKE_CV
+    from multike_amd.MultiKE_CSL import MultiKE_CV
+    from multike_amd.predicate_alignment import PredicateAlignModel
+    from multike_amd.synthetic import synthetic_args, write_dataset_folder
+    folder = str(tmp_path) + "/"
+    wf = write_dataset_folder(folder, n_pairs=1500, n_extra=150, n_rel=40, n_attr=30, triples_per_entity=5.0, shared_structure=0.8)
+    args = synthetic_args(training_data=folder, output=folder + "out/", word2vec_path=wf, dataset_division="631/", encoder_epoch=5,
+                          encoder_active="tanh", encoder_normalize=True, retrain_literal_embeds=False, literal_normalize=True, dim=64,
+                          batch_size=2000, attribute_batch_size=2000, entity_batch_size=2000, neg_triple_num=10, learning_rate=0.01,
+                          ITC_learning_rate=0.01, max_epoch=24, start_valid=12, eval_freq=12, start_predicate_soft_alignment=10,
+                          truncated_freq=10, truncated_epsilon=0.98, is_save=True, seed=1)
+    res = {}
+    for name, make in (("sharded", lambda d, p: ShardedMultiKE_CV(d, args, p, 0, 1)), ("single", lambda d, p: MultiKE_CV(d, args, p))):
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            data = DataModel(args)
+            pam = PredicateAlignModel(data.kgs, args)
+            model = make(data, pam)
+            res[name] = model.run()
+        log = out.getvalue()
+        assert "generating neighbors" in log and log.count("valid results:") >= 6, name        # k-NN refresh, two validation rounds
+        if name == "sharded":
+            assert model.m._list_gen["ckgp_rel"] >= 2            # the relation-alignment list was rebuilt after epoch 10 and re-installed
+    for name in res:
+        assert res[name]["rv"] > 0.75 and res[name]["av"] > 0.4 and res[name]["final"] > 0.6, (name, res[name])
+    for k in ("nv", "rv", "av", "final"):
+        assert abs(res["sharded"][k] - res["single"][k]) < (1e-6 if k == "nv" else 0.12), (k, res)
