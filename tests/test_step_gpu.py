@@ -440,7 +440,11 @@ def test_heavy_collisions_exclusive_row_path(n_ent, P, N):
     np.testing.assert_allclose(R.raw().cpu().numpy(), r64, rtol=1e-4, atol=2e-5)
     # accumulator = sum of g^2 where a hub row's g is itself a cancelling sum of hundreds of fp32 terms in atomic order:
     # single elements land a few 1e-3 off in about one run out of 25
-    np.testing.assert_allclose(E.slot("relation")[:, :d].cpu().numpy(), a64, rtol=1e-2, atol=1e-6)
+    acc = E.slot("relation")[:, :d].cpu().numpy()
+    np.testing.assert_allclose(acc, a64, rtol=1e-2, atol=1e-6)
+    # ... and that is the tail: all but a handful of elements agree to 2e-4 (the deterministic mode, `test_deterministic_*`,
+    # holds 1e-3 on every element)
+    assert np.mean(np.isclose(acc, a64, rtol=2e-4, atol=1e-6)) > 0.9995, float(np.mean(np.isclose(acc, a64, rtol=2e-4, atol=1e-6)))
     assert int(E.refcount.abs().sum()) == 0 and float(E.grad.abs().max()) == 0.0
     # and the two paths agree with each other
     E2, R2 = make_tables(ent, rel)
