@@ -44,6 +44,21 @@ def test_ranks_vs_oracle(n1, n2, d):
     assert int(rank0.max()) == 0 and np.array_equal(best0.cpu().numpy(), np.arange(n1))
 
 
+def test_rows_wider_than_the_widest_instantiation():
+    """dim 257..320 (the tables' widest stride is 320, k_align_rank's is 256): library-GEMM row blocks, same counts."""
+    from multike_amd.base.alignment import alignment_counts
+    rng = np.random.default_rng(3)
+    for d in (257, 300, 320):
+        e2 = rng.standard_normal((900, d)).astype(np.float32)
+        e1 = (0.3 * e2[:700] + rng.standard_normal((700, d))).astype(np.float32)
+        e2[5] = e2[4]                                                          # golds 4 and 5 tie with each other
+        greater, ties, best = alignment_counts(e1, e2)
+        r64, b64 = eo.ranks(e1.astype(np.float64), e2.astype(np.float64))
+        assert np.mean(greater.cpu().numpy() == r64) > 0.99 and np.max(np.abs(greater.cpu().numpy() - r64)) <= 2
+        assert int(ties[4]) == 2 and int(ties[5]) == 2 and int((ties != 1).sum()) == 2
+        assert np.mean(best.cpu().numpy() == b64) > 0.99
+
+
 def test_ties_are_ranked_at_mid_rank():
     """The reference's argsort leaves the gold at an arbitrary place among the columns that tie with it; the evaluator
     reports the mid-rank: a zero row (similarity 0 to every column) lands in the middle, not at Hits@1; a duplicated gold
