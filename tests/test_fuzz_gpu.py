@@ -30,3 +30,14 @@ def test_random_shapes_of_the_surfaces_around_the_step():
     for line in ("sampler: 60 / 60", "evaluator: 30 / 30", "k-NN refresh: 15 / 15", "common-space step: 30 / 30",
                  "space-mapping step: 15 / 15"):
         assert line in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_random_datasets_and_hyper_parameters_track_the_whole_model_oracle():
+    """tools/fuzz_model.py: ITC / SSL drivers on random synthetic datasets and hyper-parameters (batch sizes smaller and larger
+    than the data, 1..25 negatives, gates, uniform / truncated sampling); every phase's epoch loss within 1e-4 of the float64
+    whole-model oracle replaying the recorded batches."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_model.py"), "8", "17"], capture_output=True, text=True,
+                       timeout=850)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "whole schedule: 8 / 8" in r.stdout

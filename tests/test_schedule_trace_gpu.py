@@ -32,16 +32,16 @@ PHASE_OF = {
 DIM = 24
 
 
-def _data():
+def _data(n_ent=1800, n_rel=24, n_attr=20, n_values=400, dim=DIM, seed=21):
     """Two KGs that share 80 % of their relation / attribute structure and whose counterpart entities have noisy copies of one
     name vector: every view has something to learn, none becomes perfect in a few epochs — the Hits figures sit in the
     sensitive middle of their range."""
     from multike_amd.synthetic import SyntheticData
-    data = SyntheticData(n_ent=1800, n_rel=24, n_attr=20, n_values=400, dim=DIM, seed=21, shared_structure=0.8)
+    data = SyntheticData(n_ent=n_ent, n_rel=n_rel, n_attr=n_attr, n_values=n_values, dim=dim, seed=seed, shared_structure=0.8)
     n1 = data.kgs.entities_num // 2
     rng = np.random.default_rng(4)
-    base = rng.standard_normal((n1, DIM)).astype(np.float32)
-    nm = np.concatenate([base, base + 0.9 * rng.standard_normal((n1, DIM)).astype(np.float32)])
+    base = rng.standard_normal((n1, dim)).astype(np.float32)
+    nm = np.concatenate([base, base + 0.9 * rng.standard_normal((n1, dim)).astype(np.float32)])
     data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
     return data
 
@@ -54,12 +54,13 @@ def _np(v):
     return v
 
 
-def _run(method):
+def _run(method, data_kw=None, args_kw=None):
     from multike_amd.MultiKE_CSL import MultiKE_CV
     from multike_amd.MultiKE_Late import MultiKE_Late
     from multike_amd.synthetic import synthetic_args
-    data = _data()
-    args = synthetic_args(dim=DIM, batch_size=900, attribute_batch_size=700, entity_batch_size=500, neg_triple_num=6,
+    data = _data(**(data_kw or {}))
+    args = synthetic_args(**(args_kw or {})) if args_kw else \
+        synthetic_args(dim=DIM, batch_size=900, attribute_batch_size=700, entity_batch_size=500, neg_triple_num=6,
                           learning_rate=0.03, ITC_learning_rate=0.05, cv_name_weight=0.8, cv_weight=1.5, orthogonal_weight=2,
                           max_epoch=10, shared_learning_max_epoch=8, start_valid=2, eval_freq=2, start_predicate_soft_alignment=2,
                           truncated_freq=3, truncated_epsilon=0.9, neg_sampling="truncated", seed=5)
