@@ -8,6 +8,8 @@
 // operand with two ds_read_b128 per eight v_mfma_f32_32x32x2_f32.  MFMA j of slab s multiplies k = 16 s + 8 (lane >> 5) + j
 // for both operands, i.e. every similarity is the SAME k-ordered fma chain wherever it is computed — two evaluations of
 // one (row, column) pair are bit-identical, which the evaluator's `sim > gold` comparison relies on.
+// -DSIMT_ABLATE=1|2|3 (tools/sweep_ablate.sh, timing only, results wrong): 1 drops the epilogue, 2 also the staging of the next
+// tile, 3 also the tile barrier — what is left is the bare ds_read + MFMA loop.
 #pragma once
 #include "mke_common.h"
 
@@ -77,7 +79,9 @@ __device__ __forceinline__ void simt_sweep(const float (&a)[KS * 8], const float
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) % NBUF;
+#if !defined(SIMT_ABLATE) || SIMT_ABLATE < 2
     if (t + 1 < t1) fetch(t + 1);  // in flight during the MFMAs below
+#endif
     f32x16 acc[BN / 32];
 #pragma unroll
     for (int cg = 0; cg < BN / 32; ++cg) {
@@ -97,17 +101,29 @@ __device__ __forceinline__ void simt_sweep(const float (&a)[KS * 8], const float
         acc[cg] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s * 8 + 7], y.w, acc[cg], 0, 0, 0);
       }
     }
+#if !defined(SIMT_ABLATE) || SIMT_ABLATE < 2
     if (NBUF == 2 && t + 1 < t1) stage((t + 1 - t0) % NBUF);
+#endif
+#if !defined(SIMT_ABLATE) || SIMT_ABLATE < 1
 #pragma unroll
     for (int cg = 0; cg < BN / 32; ++cg) {
       const int col = t * BN + cg * 32 + l31;
       epi(acc[cg], col, col < n_cols);
     }
+#else
+    {
+      f32x16 z = acc[0];
+      for (int cg = 1; cg < BN / 32; ++cg) z += acc[cg];
+      if (z[0] == 12345.678f) epi(z, t * BN + l31, true);      // keeps the MFMAs alive; never taken
+    }
+#endif
     if (NBUF == 1) {
       __syncthreads();  // every wave is done reading the only buffer
       if (t + 1 < t1) stage(0);
     }
+#if !defined(SIMT_ABLATE) || SIMT_ABLATE < 3
     __syncthreads();
+#endif
   }
 }
 
