@@ -88,4 +88,35 @@ for c in range(cases):
         bad += 1
         print(f"PIN case {c}: E={E} R={R} d={d} P={P} N={N}: {msg}", flush=True)
 print(f"oracle vs the reference's losses.py (executed) + torch autograd + torch Adagrad: {cases - bad} / {cases} random cases agree")
-sys.exit(1 if bad else 0)
+
+# ---- evaluator oracle vs the reference's own greedy_alignment (code/base/alignment.py:8-79,141-163), executed -----------------------
+import contextlib, io
+ref_al = importlib.import_module("base.alignment")
+from oracle import eval_oracle as eo
+bad2 = 0
+ne = max(cases // 5, 10)
+for c in range(ne):
+    d = int(rng.integers(2, 120)); n1 = int(rng.integers(2, 400)); n2 = n1 + int(rng.integers(0, 300))
+    e2 = rng.standard_normal((n2, d)).astype(np.float32)
+    e1 = (float(rng.uniform(0.0, 1.0)) * e2[:n1] + rng.standard_normal((n1, d))).astype(np.float32)
+    top_k = sorted({1} | set(int(x) for x in rng.integers(1, min(n2, 60) + 1, 3)))   # the reference asserts 1 in top_k
+    msg = ""
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            rest, h1, mr, mrr = ref_al.greedy_alignment(e1, e2, top_k, 1, "inner", True, 0, True)
+            _, _, hits_x, _ = ref_al.calculate_rank(list(range(n1)), ref_al.sim(e1, e2, normalize=True), top_k, True, n1)
+        rank, best = eo.ranks(e1, e2)
+        hits, omr, omrr = eo.metrics(rank, top_k)
+        assert np.array_equal(np.round(np.array(hits_x) / n1 * 100, 3), hits), f"hits {hits_x} vs {hits}"
+        assert abs(mr - omr) <= 1e-9 * omr and abs(mrr - omrr) <= 1e-9, f"mr {mr} vs {omr}, mrr {mrr} vs {omrr}"
+        assert sorted(rest) == sorted((i, int(b)) for i, b in enumerate(best)), "hits1_rest pairs"
+    except AssertionError as ex:
+        msg = f"DIFFERS: {str(ex)[:300]}"
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        msg = f"{type(ex).__name__}: {str(ex)[:200]} @ {traceback.format_exc().strip().splitlines()[-3][:200]}"
+    if msg:
+        bad2 += 1
+        print(f"EVAL-PIN case {c}: n1={n1} n2={n2} d={d} top_k={top_k}: {msg}", flush=True)
+print(f"evaluator oracle vs the reference's greedy_alignment (executed): {ne - bad2} / {ne} random cases agree")
+sys.exit(1 if bad + bad2 else 0)
