@@ -30,3 +30,37 @@ with contextlib.redirect_stdout(io.StringIO()):
 dt = (time.perf_counter() - t0) / (n_ep * (L // 5000))
 print(f"activation {act!r}: {dt * 1e3:.3f} ms per 5000-row training step = {flop / dt / 1e12:.1f} TFLOP/s "
       f"({100 * flop / dt / 157.3e12:.0f} % of the 157.3 TFLOP/s f32 matrix peak); {flop / 1e9:.1f} GFLOP per step")
+
+# ---- the same step through the library: torch.nn.functional.linear (hipBLASLt) + autograd + torch.optim.Adagrad ----------------
+# (what a straight PyTorch port of code/literal_encoder.py:63-107 costs on this part: library GEMMs, separate elementwise /
+# reduction kernels, autograd bookkeeping; same shapes, same activation, row-normalised code, mean-squared reconstruction loss)
+if os.environ.get("AE_LIBRARY", "1") == "1":
+    dev = torch.device("cuda")
+    dims = [1500, 1024, 512, 75, 512, 1024, 1500]
+    Ws = [torch.nn.Parameter(0.02 * torch.randn(dims[i], dims[i + 1], device=dev)) for i in range(6)]
+    bs = [torch.nn.Parameter(torch.zeros(dims[i + 1], device=dev)) for i in range(6)]
+    opt = torch.optim.Adagrad(Ws + bs, lr=0.001, initial_accumulator_value=0.1, eps=0.0)
+    xb = torch.randn(5000, 1500, device=dev)
+    xb = xb / xb.norm(dim=1, keepdim=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        h = xb
+        for i in range(6):
+            h = torch.tanh(torch.addmm(bs[i], h, Ws[i]))
+            if i == 2:
+                h = torch.nn.functional.normalize(h, dim=1)
+        loss = ((h - xb) ** 2).sum()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 40
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dl = (time.perf_counter() - t0) / n
+    print(f"the same step on torch autograd + the library's GEMMs + torch.optim.Adagrad: {dl * 1e3:.3f} ms per step "
+          f"({flop / dl / 1e12:.1f} TFLOP/s); native / library = {dt / dl:.2f}")
