@@ -1,4 +1,5 @@
 #!/bin/bash
+export ATTR_LIBRARY=0   # tools/attr_prof.py: the native step only
 # SQ counters of the attribute step's kernels (separate --pmc passes with --kernel-trace only): tools/attr_prof.py 100
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp

@@ -7,6 +7,7 @@ shutil.copy(os.path.join(ROOT, "multike_amd", "libmultike_hip.so"), "/tmp/keep.s
 shutil.copy(os.path.join(ROOT, "tools", "ab", "libstamp.so"), os.path.join(ROOT, "multike_amd", "libmultike_hip.so"))
 try:
     import numpy as np, torch
+    os.environ["ATTR_LIBRARY"] = "0"
     sys.argv = [sys.argv[0], "50"] + sys.argv[1:]
     exec(open(os.path.join(ROOT, "tools", "attr_prof.py")).read())
     from multike_amd import _lib

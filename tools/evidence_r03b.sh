@@ -7,7 +7,7 @@ cd $root; mkdir -p gpurun_out
 timeout 600 python tools/c5_variance.py > gpurun_out/r03_c5_variance.log 2>&1
 timeout 600 python tools/c5_skew.py > gpurun_out/r03_c5_skew.log 2>&1
 timeout 1200 tools/c5_contig_ab.sh > gpurun_out/r03_c5_contig_ab.log 2>&1
-timeout 300 tools/prof.sh r03_attr 9 tools/attr_prof.py 400 > gpurun_out/r03_attr_trace.md 2>&1
+ATTR_LIBRARY=0 timeout 300 tools/prof.sh r03_attr 9 tools/attr_prof.py 400 > gpurun_out/r03_attr_trace.md 2>&1
 timeout 200 python tools/attr_prof.py 400 > gpurun_out/r03_attr.log 2>&1
 timeout 300 python tools/epoch_bench.py > gpurun_out/r03_epoch.log 2>&1
 timeout 300 python tools/oc_bench.py > gpurun_out/r03_oc.log 2>&1
