@@ -235,7 +235,47 @@ def reference_default_variants(args, kgs, ent0, rel0, sides):
         out.append(row)
         del runner, bat, E, R, vs
     out.append(attribute_step_variant(args))
+    out.append(pytorch_port_variant(args, kgs, ent0, rel0, sides))
     return out
+
+
+def pytorch_port_variant(args, kgs, ent0, rel0, sides):
+    """Side line: the headline step as a straight PyTorch program on the SAME GPU — what a port of code/MultiKE_model.py:114-132
+    costs when every op is an ATen kernel: tf.nn.l2_normalize of both tables, six embedding_lookups, the logistic loss,
+    autograd, and Adagrad over the whole variables (the reference's dense semantics).  Negatives come from this package's
+    device sampler and are NOT inside the timed region (the reference's sampler runs in CPU worker processes)."""
+    from multike_amd.sampling import KGSide, RelationBatcher
+    d, B, N = args.dim, args.batch, args.neg
+    E = torch.nn.Parameter(torch.as_tensor(ent0, dtype=torch.float32, device="cuda").clone())
+    R = torch.nn.Parameter(torch.as_tensor(rel0, dtype=torch.float32, device="cuda").clone())
+    opt = torch.optim.Adagrad([E, R], lr=0.001, initial_accumulator_value=0.1, eps=0.0)
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), sides[0].known), KGSide(kgs.entities(1), sides[1].known),
+                          B, N, seed=1234)
+    n_steps = min(24, bat.steps)
+    batches = []
+    for s_ in range(n_steps):
+        pos, neg = bat.batch(s_)
+        batches.append(tuple(x.long() for x in pos) + tuple(x.long() for x in neg))
+
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        En, Rn = torch.nn.functional.normalize(E, dim=1), torch.nn.functional.normalize(R, dim=1)
+        ph, pr, pt, nh, nr, nt = b
+        x = ((En[ph] + Rn[pr] - En[pt]) ** 2).sum(1)
+        y = ((En[nh] + Rn[nr] - En[nt]) ** 2).sum(1)
+        loss = torch.nn.functional.softplus(x).sum() + torch.nn.functional.softplus(-y).sum()
+        loss.backward()
+        opt.step()
+    for b in batches[:4]:
+        step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[4:]:
+        step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / max(1, n_steps - 4)
+    return {"name": "the same step as a straight PyTorch program on this GPU (ATen kernels, autograd, dense Adagrad; sampler excluded)",
+            "value": B * (1 + N) / dt, "unit": "triples/s", "steps": n_steps - 4, "ms_per_step": dt * 1e3, "scored_per_step": B * (1 + N)}
 
 
 def attribute_step_variant(args):

@@ -49,6 +49,7 @@ def test_n1_line():
     k = v[1]["knn_refresh_ms_untimed"]
     assert 0 < k["warm_second_call"] <= k["cold_first_call"] * 1.5
     assert "attribute" in v[2]["name"] and v[2]["value"] > 1e6 and v[2]["roofline"]["frac_hbm"] < 1
+    assert "PyTorch" in v[3]["name"] and 0 < v[3]["value"] < d["value"]      # the straight port on the same GPU is the slower one
     assert r["kernel_source_sha"] and (r["traffic"] is None or r["achieved_counter"] > 0)
     assert d["value"] > 50e6          # north_star floor: >= 50 M scored triples/s on one MI355X
 
