@@ -128,9 +128,9 @@ class _TripleList:
         if self.n == 0:
             self.cols, self.w = None, None
             return
-        if hasattr(triples, "cols"):          # base.kgs.TripleArray: already columns
-            arr = triples.cols.astype(np.int32)
-            self.cols = tuple(torch.as_tensor(np.ascontiguousarray(arr[:, k]), device=device) for k in range(3))
+        if hasattr(triples, "cols"):          # base.kgs.TripleArray: one [n, 3] upload, the columns split on the device
+            t = torch.as_tensor(triples.cols.astype(np.int32), device=device)
+            self.cols = tuple(t[:, k].contiguous() for k in range(3))
             self.w = None if triples.w is None else torch.as_tensor(triples.w.astype(np.float32), device=device)
             return
         arr = np.asarray([t[:3] for t in triples], dtype=np.int32)

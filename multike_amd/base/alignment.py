@@ -76,16 +76,19 @@ def tie_aware_metrics(greater, ties, top_k):
     name vector ties with every column; duplicated embeddings) therefore score their chance level.  Without ties
     (ties == 1) these are exactly the reference's integer counts (code/base/alignment.py:141-163)."""
     g, t = greater.double(), ties.double()
-    hits = [float(((k - g) / t).clamp(0.0, 1.0).sum()) for k in top_k]
-    mr = float((g + (t + 1.0) * 0.5).mean())
-    mrr = float(((torch.special.digamma(g + t + 1.0) - torch.special.digamma(g + 1.0)) / t).mean())
-    return hits, mr, mrr
+    ks = torch.as_tensor([float(k) for k in top_k], dtype=torch.float64, device=g.device)
+    hits = ((ks[:, None] - g[None, :]) / t[None, :]).clamp(0.0, 1.0).sum(1)
+    mr = (g + (t + 1.0) * 0.5).mean()
+    mrr = ((torch.special.digamma(g + t + 1.0) - torch.special.digamma(g + 1.0)) / t).mean()
+    out = torch.cat([hits, mr[None], mrr[None]]).cpu().tolist()          # one read-back for all of them
+    return out[:-2], out[-2], out[-1]
 
 
-def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
+def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate, want_pairs=True):
     """code/base/alignment.py:8-79.  Returns (alignment_rest, hits1, mr, mrr).  `nums_threads` is accepted and ignored
     (one kernel launch).  Only the path the reference uses is built: inner product (or cosine == inner product of
-    normalised rows), csls_k == 0."""
+    normalised rows), csls_k == 0.  want_pairs = False (base.evaluation.valid, which drops them): alignment_rest is None —
+    the set of (row, best column) tuples is a Python object per row."""
     if csls_k and csls_k > 0:
         raise _lib.MultiKEHipError("greedy_alignment: CSLS re-scoring is not built (the reference never enables it)")
     if not (metric == "inner" or (metric == "cosine" and normalize)):
@@ -96,7 +99,7 @@ def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csl
     num = greater.numel()
     hits, mr, mrr = tie_aware_metrics(greater, ties, top_k)
     hits = np.round(np.array(hits) / num * 100, 3)
-    alignment_rest = set(zip(range(num), best.cpu().tolist()))
+    alignment_rest = set(zip(range(num), best.cpu().tolist())) if want_pairs else None
     cost = time.time() - t
     if accurate:
         print("accurate results: hits@{} = {}%, mr = {:.3f}, mrr = {:.6f}, time = {:.3f} s ".format(top_k, hits, mr, mrr, cost))

@@ -142,18 +142,18 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         valid[ids[p_lo:p_hi]] = 1
         return (table, valid) if part is None else (table, valid, ids[p_lo:p_hi])
 
-    g = torch.Generator(device="cpu")
+    g = torch.Generator(device=device)     # on the device: a CPU permutation of 100K ids is 9 ms the GPU waits for
     g.manual_seed(12345)
     # Work in a fixed random order of the entities: a row's hits are then spread evenly over the column segments whatever
     # the order of the ids (in id order similar entities sit together — URIs of one namespace, one generator block — and
     # most rows overflowed one of their segments on the DBP-WD-like folder: 54-75 % of the rows went to the full-width path).
-    perm = torch.randperm(n, generator=g).to(device)
+    perm = torch.randperm(n, generator=g, device=device)
     e, ids = e[perm], ids[perm]
     kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
     ep = torch.zeros(n, kpad, dtype=torch.float32, device=device)
     ep[:, :d] = e
     ids32 = ids.to(torch.int32)
-    samp = torch.randperm(n, generator=g)[:n_samp].to(device)
+    samp = torch.randperm(n, generator=g, device=device)[:n_samp]
     es = ep[samp].contiguous()
     m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
     chunk = (1 << 29) // cap - 128                        # rows per launch: 2^29 candidate slots (8 bytes each) at most

@@ -20,9 +20,18 @@ args = synthetic_args(training_data=folder, output=folder + "out/", word2vec_pat
                       encoder_active="tanh", encoder_normalize=True, retrain_literal_embeds=False, literal_normalize=True, is_save=True,
                       max_epoch=epochs, shared_learning_max_epoch=epochs, start_valid=100, eval_freq=10)
 quiet = contextlib.redirect_stdout(io.StringIO())
+prof = None
+if os.environ.get("FULL_RUN_PROFILE") == "1":       # cProfile of the host side: where DataModel and run() spend their wall time
+    import cProfile, pstats
+    prof = cProfile.Profile()
 t = time.time()
 with quiet:
+    if prof: prof.enable()
     data = DataModel(args)
+    if prof: prof.disable()
+if prof:
+    pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
+    prof = cProfile.Profile()
 torch.cuda.synchronize(); t_data = time.time() - t
 t = time.time()
 with quiet:
@@ -35,8 +44,12 @@ t = time.time()
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     model = (MultiKE_CV if method == "ITC" else MultiKE_Late)(data, args, pam)
+    if prof: prof.enable()
     res = model.run()
+    if prof: prof.disable()
 torch.cuda.synchronize()
+if prof:
+    pstats.Stats(prof).sort_stats("tottime").print_stats(40)
 print(f"{type(model).__name__}.run(): {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
 print("test Hits@1:", {k_: round(float(v), 3) for k_, v in res.items()})
 log = buf.getvalue().splitlines()
@@ -54,4 +67,4 @@ for l in log:
         agg["valid/test ranking"] = agg.get("valid/test ranking", 0.0) + float(m.group(1))
 print("time by phase (s):", {k_: round(v, 2) for k_, v in agg.items()}, "| sum", round(sum(agg.values()), 2))
 print("epochs executed:", sum(1 for l in log if l.startswith("epoch ") and l.rstrip().endswith(":")), "| k-NN refreshes:", sum(1 for l in log if "neighbors of" in l))
-print("\n".join([l for l in log if "neighbors of" in l][:2]))
+print(" | ".join([l.split("costs ")[1] for l in log if "neighbors of" in l]))
