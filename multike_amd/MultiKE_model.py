@@ -13,6 +13,7 @@ with the same attributes; only the attributes this file reads are required (see 
 """
 from __future__ import annotations
 
+import itertools
 import math
 import time
 
@@ -133,10 +134,17 @@ class _TripleList:
             self.cols = tuple(t[:, k].contiguous() for k in range(3))
             self.w = None if triples.w is None else torch.as_tensor(triples.w.astype(np.float32), device=device)
             return
+        width = len(triples[0])
+        if width == 3 and all(isinstance(x, (int, np.integer)) for x in triples[0]):
+            flat = np.fromiter(itertools.chain.from_iterable(triples), dtype=np.int64, count=3 * self.n)   # 3x faster than asarray(list)
+            t = torch.as_tensor(flat.reshape(self.n, 3).astype(np.int32), device=device)
+            self.cols = tuple(t[:, k].contiguous() for k in range(3))
+            self.w = None
+            return
         arr = np.asarray([t[:3] for t in triples], dtype=np.int32)
         self.cols = tuple(torch.as_tensor(np.ascontiguousarray(arr[:, k]), device=device) for k in range(3))
         self.w = (torch.as_tensor(np.asarray([t[3] for t in triples], dtype=np.float32), device=device)
-                  if len(triples[0]) > 3 else None)
+                  if width > 3 else None)
 
     def sample_epoch(self, batch_size, steps, seed, stream_id):
         """`steps` x random.sample(list, batch_size) (code/MultiKE_model.py:358: distinct inside a step, steps
@@ -298,13 +306,12 @@ class MultiKE:
         cannot be recycled for a different list while the entry lives (the predicate lists are re-created every ten
         epochs); the cache is bounded, oldest entry out."""
         key = id(key_obj)
-        hit = self._lists.get(key)
+        hit = self._lists.pop(key, None)
         if hit is None or hit[0] is not key_obj or hit[1] != len(key_obj):
             hit = (key_obj, len(key_obj), build(key_obj))
-            self._lists.pop(key, None)
-            self._lists[key] = hit
-            while len(self._lists) > self._CACHE_MAX:
-                self._lists.pop(next(iter(self._lists)))
+        self._lists[key] = hit              # (re-)inserted last: the entry evicted below is the least recently USED one — the
+        while len(self._lists) > self._CACHE_MAX:      # supervision lists of every epoch must outlive the predicate lists that
+            self._lists.pop(next(iter(self._lists)))   # are re-created every ten epochs (rebuilding one costs 50-90 ms of host time)
         return hit[2]
 
     def _list(self, triples) -> _TripleList:

@@ -166,23 +166,28 @@ def clear_attribute_triples(attribute_triples):
     @en suffixes; delete . ( ) , " and turn _ - / into spaces; drop values that still contain 'http'.
     Returns (triples, numeric literals, string literals) -- the literal lists classify the value after the suffix
     cut and before the character clean-up, dropped triples included, as the reference does."""
-    triples = set(attribute_triples)
+    triples = dict.fromkeys(attribute_triples)      # the reference's set(): duplicates dropped; here in the input's own order
     freq = {}
     for _, a, _ in triples:
         freq[a] = freq.get(a, 0) + 1
     kept, numbers, strings = [], [], []
-    for e, a, v in sorted(triples, key=repr):
+    memo = {}                                       # a literal value is cleaned once, however many triples carry it
+    for e, a, v in triples:
         if freq[a] < 10:
             continue
-        cut = v.find('"^^')
-        if cut >= 0:
-            v = v[:cut]
-        if v.endswith('"@en'):
-            v = v[:v.index('"@en')]
-        (numbers if is_number(v) else strings).append(v)
-        v = v.translate(_DROP).translate(_SPACE)
-        if "http" not in v:
-            kept.append((e, a, v))
+        m = memo.get(v)
+        if m is None:
+            w = v
+            cut = w.find('"^^')
+            if cut >= 0:
+                w = w[:cut]
+            if w.endswith('"@en'):
+                w = w[:w.index('"@en')]
+            c = w.translate(_DROP).translate(_SPACE)
+            m = memo[v] = (w, is_number(w), None if "http" in c else c)
+        (numbers if m[1] else strings).append(m[0])
+        if m[2] is not None:
+            kept.append((e, a, m[2]))
     return kept, numbers, strings
 
 
