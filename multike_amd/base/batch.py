@@ -131,11 +131,32 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     n_samp, cap = 4096, _pow2_at_least(int(1.4 * k) + 64)
     short = n >= 8 * n_samp and cap * 4 <= n and cap <= 4096 and d <= 256
 
+    own = d <= _lib.SIM_SELECT_KPADS[-1]          # rows up to 256 floats: the package's own MFMA sweep, no library GEMM
+    if own:
+        kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
+
     def full_width(rows):
-        return torch.topk(e[rows] @ e.t(), k, dim=1, sorted=False).indices
+        """top k of whole similarity rows (short KGs; rows whose threshold estimate was off).  The similarities come from the
+        same sweep as the main pass (`mke_sim_sample` against ALL columns: identical fma chains) — a library GEMM here was
+        the refresh's only library call and cost its 170 ms initialisation at the first refresh of a run."""
+        if own:
+            cols = ep if ep is not None else _padded(e)
+            src = cols[rows].contiguous()
+            sim = _lib.sim_sample(src, kpad, 0, int(src.shape[0]), cols)
+        else:
+            sim = e[rows] @ e.t()
+        return torch.topk(sim, k, dim=1, sorted=False).indices
+
+    def _padded(x):
+        out = torch.zeros(x.shape[0], kpad, dtype=torch.float32, device=device)
+        out[:, :d] = x
+        return out
+    ep = None
 
     p_lo, p_hi = (0, n) if part is None else (n * part[0] // part[1], n * (part[0] + 1) // part[1])
     if not short:
+        if own:
+            ep = _padded(e)
         for lo in range(p_lo, p_hi, block_rows):
             hi = min(p_hi, lo + block_rows)
             table[ids[lo:hi]] = ids[full_width(slice(lo, hi))].to(torch.int32)
@@ -149,9 +170,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     # most rows overflowed one of their segments on the DBP-WD-like folder: 54-75 % of the rows went to the full-width path).
     perm = torch.randperm(n, generator=g, device=device)
     e, ids = e[perm], ids[perm]
-    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
-    ep = torch.zeros(n, kpad, dtype=torch.float32, device=device)
-    ep[:, :d] = e
+    ep = _padded(e)
     ids32 = ids.to(torch.int32)
     samp = torch.randperm(n, generator=g, device=device)[:n_samp]
     es = ep[samp].contiguous()
