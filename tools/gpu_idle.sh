@@ -36,5 +36,12 @@ hist = collections.Counter()
 for g, _, _ in gaps:
     hist["<10us" if g < 1e4 else "<100us" if g < 1e5 else "<1ms" if g < 1e6 else "<10ms" if g < 1e7 else ">=10ms"] += g
 print({k: round(v/1e9, 3) for k, v in hist.items()})
+tot = collections.Counter(); cnt = collections.Counter()
+for s_, e_, n_ in rows:
+    key = n_.split("(")[0][:48]
+    tot[key] += e_ - s_; cnt[key] += 1
+print("kernel time by name (sum over both streams; the union above counts overlap once):")
+for k_, v_ in tot.most_common(14):
+    print(f"  {v_/1e9:6.3f} s  {cnt[k_]:7d} x {v_/cnt[k_]/1e3:7.1f} us  {k_}")
 P
 rm -rf gpurun_out/fr
