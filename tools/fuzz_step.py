@@ -56,7 +56,7 @@ for c in range(cases):
         nz = np.linalg.norm(ent, axis=1) > 0
         if not np.allclose(got[nz], e64[nz], rtol=5e-4, atol=5e-6 + 3e-5 * np.abs(e64[nz]).max()):   # fp32 noise scales with the largest entry
             ok, msg = False, msg + f" ent max diff {np.abs(got[nz] - e64[nz]).max():.2e}"
-        if not np.allclose(R.raw().cpu().numpy(), r64, rtol=5e-4, atol=2e-5):
+        if not np.allclose(R.raw().cpu().numpy(), r64, rtol=5e-4, atol=2e-5 + 1e-4 * np.abs(r64).max()):   # a hub row sums tens of thousands of fp32 terms
             ok, msg = False, msg + f" rel max diff {np.abs(R.raw().cpu().numpy() - r64).max():.2e}"
         if float(E.grad.abs().max()) != 0.0 or float(R.grad.abs().max()) != 0.0 or (E._refcount is not None and int(E.refcount.abs().sum()) != 0):
             ok, msg = False, msg + " scratch not consumed"
