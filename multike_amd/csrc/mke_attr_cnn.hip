@@ -470,10 +470,15 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
     f32x4 acc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // all of the wavefront's A operands out of LDS first, unconditionally from clamped columns (a guarded read compiles to an
+    // exec-masked branch + a full LDS wait in front of EVERY k-step's five MFMAs: 21 exposed LDS round trips, ~2,300 of the
+    // phase's 5,800 cycles; s_memtime stamps, tools/attr_stamps.py), then the 105 MFMAs back to back
+    float av[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) av[i] = s_flat[r16][min(k0 + 4 * i, K - 1)];
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      const int k = k0 + 4 * i;
-      const float ai = k < K ? s_flat[r16][min(k, K - 1)] : 0.f;
+      const float ai = (k0 + 4 * i < K) ? av[i] : 0.f;
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, wfrag[i][c], acc[c], 0, 0, 0);
     }
@@ -492,14 +497,22 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
         float v = s_acc[0][c][r][lane] + s_acc[1][c][r][lane] + s_acc[2][c][r][lane] + s_acc[3][c][r][lane];
         const int64_t orow = m0 + 4 * kq + r;
         if (col < d && orow < p.n) {
-          v = tanhf(v);
+          v = tanh_f(v);
           p.z[orow * d + col] = v;
           ssq = fmaf(v, v, ssq);
         }
       }
     }
-    const double tot = block_sum_double(ssq);
+    // <= 8 squares per lane: 16-lane rows in f32 on DPP, the block's 16 row sums in double (block_sum_double's six 64-bit
+    // shuffle steps were 1,900 cycles at the very end of the launch's critical path)
+    __shared__ double s_rows[MKE_BLOCK / 16];
+    ssq = sub16_sum(ssq);
+    if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4] = (double)ssq;
+    __syncthreads();
     if (threadIdx.x == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < MKE_BLOCK / 16; ++k) tot += s_rows[k];
       p.ssq[blockIdx.x] = tot;
       for (int k = blockIdx.x + gridDim.x; k < MKE_LOSS_PARTIALS; k += gridDim.x) p.ssq[k] = 0.0;
     }

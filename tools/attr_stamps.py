@@ -19,10 +19,18 @@ try:
     nw = min(1024, ((B + 15) // 16) * 4)
     st = st[:nw]
     t0 = st[:, 0].min()
+    bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd" or os.environ.get("STAMPS") == "bwd"
     names = ["enter", "W fragment loads issued", "conv params / gamma / beta loaded", "ids arrived", "rows arrived (+ attr norm)", "x strips staged",
              "conv1 done", "conv2 + width norms done", "flat stored (LDS + global issue)", "block barrier passed", "MFMA done", "s_acc exchanged (barrier)",
              "tanh + z stored", "block sum done"]
-    print(f"rc {rc}; {nw} wavefronts; kernel span first enter -> last block-sum: {(st[:, 13].max() - t0)} cycles")
+    if bwd:
+        names = ["enter", "conv params / gamma / beta loaded, s_part zeroed", "ids arrived", "rows arrived (+ attr norm)", "x strips staged", "conv1 (recomputed)",
+                 "conv2 + width norms (recomputed)", "width-norm backward, conv2 parameter gradients", "conv2 transposed, conv1 parameter gradients",
+                 "conv1 transposed, dx, attribute-row scatter", "block barrier passed", "gamma / beta through LDS (2 barriers)", "parameter atomics issued"]
+        nw = min(1024, ((B + 3) // 4) * 2)
+        st = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.int64)[:nw]
+        t0 = st[:, 0].min()
+    print(f"rc {rc}; {nw} wavefronts")
     print("stage | median cycles since the wavefront entered | median delta | first wavefront to reach it (since first enter) | last")
     prev = None
     for i, n in enumerate(names):
