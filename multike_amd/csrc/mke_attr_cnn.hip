@@ -1011,6 +1011,7 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
     if (a->attr_grad) tabs[nt++] = mke_update_table{a->attr_table, a->attr_acc, a->attr_grad, a->attr_touched, a->n_attr, a->attr_normalize, 1, nullptr};
     DenseJob dj{a->params, a->param_acc, a->param_grads, (int64_t)MKE_CNN_PARAMS(d), a->optimizer, a->lr, a->workspace,
                 MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), CNN_WS_COPIES};
+    UpdateTouchedHint hint(a->n);   // at most one head row per triple
     if ((rc = launch_rows_update_multi(tabs, nt, a->tag, a->ent_grad ? a->ent_stride : a->attr_stride, d, a->optimizer, a->lr, st,
                                        nullptr, &dj))) return rc;
   }

@@ -110,6 +110,15 @@ __device__ __forceinline__ void count_refs_range(const mke_count_job& c, int64_t
   }
 }
 
+// Upper bound of the rows the NEXT k_rows_update_multi launch of this host thread will find touched (0 = unknown).  A step that
+// touches at most a 16th of a large table (an attribute step's 5,000 heads of 200K rows, a positives-only step) is walked in
+// 64-row chunks — a quarter of the wavefronts, each still finding about one row — instead of 16-row chunks (mke_update.hip).
+extern thread_local int64_t g_update_touched_hint;
+struct UpdateTouchedHint {
+  explicit UpdateTouchedHint(int64_t rows) { g_update_touched_hint = rows; }
+  ~UpdateTouchedHint() { g_update_touched_hint = 0; }
+};
+
 // Block-wide sum of one float per thread, accumulated in double; thread 0 gets the result.
 __device__ __forceinline__ double block_sum_double(float v) {
   __shared__ double s_part[MKE_BLOCK / 64];

@@ -216,6 +216,7 @@ static int mapping_step_impl(const mke_mapping_step_args* a, double* loss4, void
       if (a->optimizer == MKE_OPT_ADAGRAD && (!a->accM || (a->ent_grad && !a->ent_acc))) { set_error("mke_mapping_step: Adagrad needs accumulators"); return MKE_E_NULL; }
       mke_update_table tab{a->ent_table, a->ent_acc, a->ent_grad, a->ent_touched, a->n_ent, a->ent_normalize, 1, nullptr};
       DenseJob dj{a->M, a->accM, a->gM, (int64_t)V * d * d, a->optimizer, a->lr, nullptr, 0, 0, 0};
+      UpdateTouchedHint hint(a->n);
       if ((rc = launch_rows_update_multi(&tab, a->ent_grad ? 1 : 0, a->tag, a->stride, d, a->optimizer, a->lr, st, nullptr, &dj))) return rc;
     }
   }

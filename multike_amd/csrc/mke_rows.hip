@@ -288,6 +288,7 @@ extern "C" int mke_align_steps(const mke_align_plan* pl, void* stream) {
       if (rc) return rc;
     }
     if (nu) {
+      UpdateTouchedHint hint(pl->step_off[s + 1] - pl->step_off[s]);   // a term touches one row per batch entry and table
       const int rc = mke_rows_update_multi(ut, nu, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, stream);
       if (rc) return rc;
     }

@@ -179,6 +179,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
     if (rc) return rc;
     ut[1].ref_count = refc;
     if (in_score) cjp = nullptr;
+    UpdateTouchedHint hint(N == 0 ? 2 * (hi - lo) : 0);   // positives only (the cross-KG loops): head + tail per triple
     rc = mke_rows_update_multi_count(ut, 2, tag, pl->stride, pl->dim, pl->optimizer, pl->lr, cjp, stream);
     if (rc) return rc;
   }

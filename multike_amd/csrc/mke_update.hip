@@ -280,7 +280,13 @@ extern int g_update_chunk;  // mke_set_option("update_chunk"): rows per wavefron
 // 4 rows for small dense tables (every quarter-wave gets a row at once); 16 for tables where a step touches a good share of the
 // rows (C2: 17 % of 200K: 2.8 flags set per 16); 64 (one flag per lane) for large tables touched sparsely (C5: 1.7 % of 2M rows —
 // a quarter as many wavefronts, each still finding about one row: 77 -> 59 us).  "update_chunk" = 16 / 64 forces one.
-static inline int chunk_for(int64_t n_rows) { return n_rows <= 16384 ? 4 : (g_update_chunk ? g_update_chunk : (n_rows > 500000 ? 64 : 16)); }
+thread_local int64_t g_update_touched_hint = 0;
+static inline int chunk_for(int64_t n_rows) {
+  if (n_rows <= 16384) return 4;
+  if (g_update_chunk) return g_update_chunk;
+  if (n_rows > 500000) return 64;
+  return (g_update_touched_hint > 0 && g_update_touched_hint * 16 <= n_rows) ? 64 : 16;   // sparse step on a mid-sized table
+}
 
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count = nullptr, const DenseJob* dense = nullptr) {
