@@ -344,15 +344,15 @@ def host_threads():
     return n
 
 
-def pmc_traffic(args):
+def pmc_traffic(config, custom=False):
     """HBM-side bytes per launch of k_triple_score from the committed rocprofv3 PMC passes (tools/pmc_passes.sh ->
     profiles/r0N_pmc_<config>.json), quoted only when the file was collected on THIS build of the kernels (source hash)
     and on this workload; None otherwise."""
-    if getattr(args, "custom", False):
+    if custom:
         return None
-    for rnd in ("r03", "r02"):          # newest round first; a file is quoted only for the build it was collected on
+    for rnd in ("r04", "r03", "r02"):          # newest round first; a file is quoted only for the build it was collected on
         try:
-            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{args.config}.json")) as f:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")) as f:
                 pmc = json.load(f)
             if pmc.get("kernel_source_sha") == kernel_source_hash():
                 return int(pmc["traffic_bytes_per_launch"])
@@ -361,15 +361,238 @@ def pmc_traffic(args):
     return None
 
 
+def hbm_resident_variant(args):
+    """Side line at BASELINE.json configs[4]'s per-GPU shape (C5-synth: |E| 2M, |R| 2K, dim 256, neg 64, batch 5000): the 2 GB
+    table + slot + gradient scratch do not fit the 256 MB Infinity Cache, so this — not the C2 headline, whose 192 MB working
+    set is cache-resident — is the HBM measurement of the same kernels.  Same code path as the headline: native
+    step loop timed over `steps` steps after `warmup`, then the instrumented pass for the kernel's own duration."""
+    cfg = {k: CONFIGS["c5"][k] for k in ("n_ent", "n_rel", "dim", "neg", "batch")}
+    t_setup = time.perf_counter()
+    w = FusedWorkload(cfg, device_init=True)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    warm, steps = 200, max(200, min(args.steps, 600))
+    w.run_steps(0, warm)
+    dt = w.timed(warm, steps)
+    scored = sum(w.triples_of(i) for i in range(warm, warm + steps))
+    roof = w.instrumented(warm + steps, 100, pmc_traffic("c5"), dt / steps * 1e6)
+    return {"name": "C5-synth: the HBM-resident shape (BASELINE configs[4] per GPU: |E|=2M |R|=2K dim=256 neg=64 batch=5000)",
+            "value": scored / dt, "unit": "triples/s", "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
+            "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "setup_s_untimed": t_setup, "roofline": roof}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the driver's
+    documented line does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`),
+    on a free port of the loopback interface; the ranks re-enter main() with WORLD_SIZE set."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def device_report(dist, staged, world, rank, local_rank):
+    """What the process group really is — read back from torch.distributed, not from the command line: backend, world size
+    and the device of every rank (index, name, PCI bus id), gathered over the group itself."""
+    p = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "device": local_rank, "name": p.name,
+            "pci_bus_id": getattr(p, "pci_bus_id", None), "hbm_GB": round(p.total_memory / 2 ** 30, 1)}
+    if dist is None or not dist.is_initialized():
+        return {"world": 1, "backend": None, "devices": [mine], "note": "single process: no process group at N=1"}
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, mine)
+    return {"world": dist.get_world_size(), "backend": dist.get_backend() + (" (host-staged dry run: ranks share GPUs)" if staged else
+                                                                             " (= RCCL on ROCm)" if dist.get_backend() == "nccl" else ""),
+            "devices": every, "distinct_devices": len({(d["device"], d["pci_bus_id"]) for d in every})}
+
+
+def roofline_object(kernel, ms, triples, dim, traffic):
+    """One self-consistent object: `achieved` and `frac` are on the ALGORITHMIC basis (12 + 24 dim bytes per scored
+    triple x the triples of a launch / the launch's duration by HIP events; frac = achieved / peak).  The kernel loads a
+    positive's rows once for its N negatives, so it moves FEWER bytes than that model counts: the bytes the memory side really
+    moved (`traffic`, rocprofv3 PMC passes on file for this build of the kernels, per launch) give the counter-based pair
+    `achieved_counter` / `frac_counter` beside it."""
+    ms, triples = np.asarray(ms), np.asarray(triples)
+    avg_ms = float(ms.mean())
+    achieved = float((triples * b_alg(dim)).sum() / (ms.sum() * 1e-3) / 1e9)
+    ach_counter = None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "frac_basis": "algorithmic bytes / launch duration / peak (fixed basis)",
+            "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "achieved_counter": ach_counter,
+            "frac_counter": None if ach_counter is None else ach_counter / HBM_PEAK_GBS,
+            "avg_launch_us": avg_ms * 1e3, "median_launch_us": float(np.median(ms)) * 1e3, "launches_timed": int(len(ms)),
+            "alg_bytes_per_triple": b_alg(dim), "triples_per_launch": float(triples.mean()),
+            "streaming_copy_GBps": HBM_ACHIEVABLE_GBS,      # what a float4 copy reaches on this part (same guide)
+            "kernel_source_sha": kernel_source_hash()}
+
+
+class FusedWorkload:
+    """The single-GPU form of the step on one synthetic shape: tables, batcher, native runner, and the two measurements —
+    the timed region (native step loop, no Python between steps) and the instrumented pass (HIP events per launch)."""
+
+    def __init__(self, cfg, sample_chunk=None, rel_grad_copies=1, device_init=False):
+        from multike_amd.runner import RelationViewRunner
+        from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
+        from multike_amd.synthetic import SyntheticKGs
+        from multike_amd.tables import EmbeddingTable, StepEngine
+        from multike_amd.tables import xavier_truncated_normal  # the product's initialiser (TF1 xavier, SURVEY §9.4)
+        self.cfg = cfg
+        d, N, B = cfg["dim"], cfg["neg"], cfg["batch"]
+        self.d, self.N, self.B = d, N, B
+        self.kgs = kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234)
+        if device_init:      # side lines of big shapes: the same distribution drawn on the device (9 s on the host at 2M x 256)
+            g = torch.Generator(device="cuda"); g.manual_seed(1234)
+            def init(n):
+                x = torch.empty(n, d, dtype=torch.float32, device="cuda")
+                torch.nn.init.trunc_normal_(x, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+                return x * float(np.sqrt(2.6 / (n + d)))
+            self.ent0 = self.rel0 = None
+            self.E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", trainable=False)
+            self.E.trainable = True
+            self.E.data[:, :d] = init(kgs.entities_num)
+            self.R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", trainable=False, grad_copies=rel_grad_copies)
+            self.R.trainable = True
+            self.R.data[:, :d] = init(kgs.relations_num)
+        else:
+            self.ent0 = xavier_truncated_normal(kgs.entities_num, d, "cpu", seed=1234).numpy()
+            self.rel0 = xavier_truncated_normal(kgs.relations_num, d, "cpu", seed=1235).numpy()
+            self.E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", values=self.ent0)
+            self.R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=self.rel0, grad_copies=rel_grad_copies)
+        self.sides = []
+        for k in (0, 1):
+            t = torch.as_tensor(kgs.triples[k], device="cuda")
+            self.sides.append(KGSide(kgs.entities(k),
+                                     KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
+        self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], self.sides[0], self.sides[1], B, N, seed=1234)
+        self.bat.shuffle()  # epoch-boundary code path (randperm + regather) exercised once before the timed region
+        self.runner = RelationViewRunner(self.E, self.R, self.bat, "relation", lr=0.001, sample_chunk=sample_chunk or None)
+        self.eng = StepEngine()
+        self.n_steps_epoch = self.bat.steps
+        self.ev = []
+
+    def run_steps(self, i0, i1):
+        """global step indices [i0, i1): whole epochs go through runner.run_epochs; a partial epoch is ONE call into the
+        native runner."""
+        bat, runner, n = self.bat, self.runner, self.n_steps_epoch
+        i = i0
+        while i < i1:
+            s = i % n
+            if s == 0 and i1 - i >= n:
+                n_ep = (i1 - i) // n
+                if i > 0:
+                    bat.shuffle()
+                runner.run_epochs(n_ep)
+                i += n_ep * n
+                continue
+            e = min(n, s + (i1 - i))
+            if s == 0 and i > 0:
+                bat.shuffle()
+            runner.run(s, e)
+            i += e - s
+
+    def triples_of(self, i):
+        s = i % self.n_steps_epoch
+        return int(self.bat.off[s + 1] - self.bat.off[s]) * (1 + self.N)
+
+    def timed(self, first, steps, barrier=lambda: None):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.run_steps(first, first + steps)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def _step_timed(self, i):
+        """Python-driven step with HIP events at every launch boundary (same stream): count | score | update."""
+        from multike_amd import _lib
+        E, R, d, N = self.E, self.R, self.d, self.N
+        s = i % self.n_steps_epoch
+        pos, neg = self.bat.batch(s)
+        tag, lp = self.eng._next()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], N, E.refcount)
+        e[1].record()
+        _lib.triple_score_fwd_bwd_x(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
+                                    E.touched, R.touched, tag, E.refcount, E.slot("relation"), _lib.OPT_ADAGRAD, 0.001, lp)
+        e[2].record()
+        _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
+                                (E.data, E.slot("relation"), E.grad, E.touched, True, E.refcount)], tag, E.stride, d,
+                               _lib.OPT_ADAGRAD, 0.001)
+        e[3].record()
+        self.ev.append((e, pos[0].numel() * (1 + N), tag))
+
+    def instrumented(self, base, n_inst, traffic, step_wall_us):
+        """HIP events bracket every launch of the step.  This pass is driven from Python (one ctypes call per launch), i.e. the
+        host is slower than the GPU; to keep host latency out of the event pairs the stream is first blocked by a spin kernel
+        long enough for every instrumented step to be queued behind it, so that the GPU then runs them back to back."""
+        from multike_amd.sampling import sample_negatives
+        E, R, bat, runner, N = self.E, self.R, self.bat, self.runner, self.N
+        t_h = time.perf_counter()
+        for i in range(base, base + 5):
+            self._step_timed(i)
+        torch.cuda.synchronize()
+        host_per_step = (time.perf_counter() - t_h) / 5
+        self.ev.clear()
+        torch.cuda._sleep(int(2.4e9 * (host_per_step * n_inst * 1.5 + 0.02)))
+        for i in range(base + 5, base + 5 + n_inst):
+            self._step_timed(i)
+        torch.cuda.synchronize()
+        cnt = np.array([e[0].elapsed_time(e[1]) for e, _, _ in self.ev])
+        ms = np.array([e[1].elapsed_time(e[2]) for e, _, _ in self.ev])
+        ums = np.array([e[2].elapsed_time(e[3]) for e, _, _ in self.ev])
+        whole = np.array([e[0].elapsed_time(e[3]) for e, _, _ in self.ev])
+        tr = np.array([n for _, n, _ in self.ev])
+        roofline = roofline_object("k_triple_score", ms, tr, self.d, traffic)
+        # second kernel of the step, reported beside it: rows left to it (referenced more than once in the step) x 6 row
+        # streams (grad, w, acc read; 0, w, acc written); rows referenced once were updated inside k_triple_score
+        last_tag = self.ev[-1][2]
+        touched_rows = int((E.touched == last_tag).sum()) + int((R.touched == last_tag).sum())
+        upd_bytes = touched_rows * 6 * E.stride * 4
+        roofline["update_kernel"] = {"kernel": "k_rows_update_multi", "avg_launch_us": float(ums.mean()) * 1e3,
+                                     "touched_rows_last_step": touched_rows, "bytes_per_launch": upd_bytes,
+                                     "achieved": upd_bytes / (float(ums.mean()) * 1e-3) / 1e9, "unit": "GB/s"}
+        # the epoch sampler (one launch per epoch in the native loop), timed here with events and amortised over its steps
+        total_neg = int(bat.off[-1]) * N
+        samp_us = None
+        if N and runner.neg[0].numel() >= total_neg:
+            se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            se0.record()
+            sample_negatives((bat.pos_h, bat.pos_r, bat.pos_t), bat.side1, N, seed=bat.rng_seed, stream_id=bat.rng_stream,
+                             pos_offset=0, out=tuple(x[:total_neg] for x in runner.neg), side1=bat.side2, pos_kg=bat.pos_kg)
+            se1.record()
+            torch.cuda.synchronize()
+            samp_us = se0.elapsed_time(se1) * 1e3 / self.n_steps_epoch
+        # Two different loops, kept apart: the NATIVE loop (what `value` times: no events, the next step's reference counts
+        # ride inside the score launch) and the INSTRUMENTED loop (three launches per step, an event record at every boundary:
+        # each bracket carries its boundary and ~1-2 us of event overhead).  Parts of the second do not add up to the first,
+        # so no difference of the two is printed; what the native step spends outside its two kernels is bounded from the
+        # rocprofv3 kernel times (profiles/r04_gap_table_c2.md), not from these events.
+        roofline["step_breakdown_us"] = {
+            "native_loop": {"step_wall": step_wall_us, "sampler_amortised": samp_us},
+            "instrumented_loop": {"count_kernel_incl_boundary": float(cnt.mean()) * 1e3,
+                                  "score_kernel": roofline["avg_launch_us"],
+                                  "update_kernel_incl_its_boundary": float(ums.mean()) * 1e3,
+                                  "step_first_to_last_event": float(whole.mean()) * 1e3},
+            "step_wall": step_wall_us, "score_kernel": roofline["avg_launch_us"],
+            "update_kernel_incl_its_boundary": float(ums.mean()) * 1e3, "sampler_amortised": samp_us}
+        return roofline
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (multike_amd has no CPU path)"
     # MKE_BENCH_COMM=staged: dry run of the multi-rank flow on fewer GPUs than ranks (ranks share devices, collectives go
@@ -392,17 +615,18 @@ def main():
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
 
-    from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
-    from multike_amd.synthetic import SyntheticKGs
-    from multike_amd.tables import EmbeddingTable, StepEngine
-    from multike_amd.tables import xavier_truncated_normal  # the product's initialiser (TF1 xavier)
-
     d, N, B = args.dim, args.neg, args.batch
-    kgs = SyntheticKGs(n_ent=args.n_ent, n_rel=args.n_rel, seed=1234)
-    ent0 = xavier_truncated_normal(kgs.entities_num, d, "cpu", seed=1234).numpy()
-    rel0 = xavier_truncated_normal(kgs.relations_num, d, "cpu", seed=1235).numpy()
+    cfg = dict(n_ent=args.n_ent, n_rel=args.n_rel, dim=d, neg=N, batch=B)
+    sharded = world > 1 or args.force_sharded
+    rccl = None
+    fused = None
 
-    if world > 1 or args.force_sharded:
+    if sharded:
+        from multike_amd.synthetic import SyntheticKGs
+        from multike_amd.tables import xavier_truncated_normal  # the product's initialiser (TF1 xavier)
+        kgs = SyntheticKGs(n_ent=args.n_ent, n_rel=args.n_rel, seed=1234)
+        ent0 = xavier_truncated_normal(kgs.entities_num, d, "cpu", seed=1234).numpy()
+        rel0 = xavier_truncated_normal(kgs.relations_num, d, "cpu", seed=1235).numpy()
         if dist is None:  # exercise the sharded path on one GPU (1-rank RCCL group)
             import torch.distributed as dist
             import tempfile
@@ -432,75 +656,21 @@ def main():
         run_step = trainer.step
         n_steps_epoch = trainer.steps
         triples_of = trainer.global_scored
-        score_ms = None
-    else:
-        E = EmbeddingTable(kgs.entities_num, d, "rv_ent_embeds", values=ent0)
-        R = EmbeddingTable(kgs.relations_num, d, "rel_embeds", values=rel0, grad_copies=args.rel_grad_copies)
-        sides = []
-        for k in (0, 1):
-            t = torch.as_tensor(kgs.triples[k], device="cuda")
-            sides.append(KGSide(kgs.entities(k),
-                                KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
-        bat = RelationBatcher(kgs.triples[0], kgs.triples[1], sides[0], sides[1], B, N, seed=1234)
-        bat.shuffle()  # epoch-boundary code path (randperm + regather) exercised once before the timed region
-        from multike_amd.runner import RelationViewRunner
-        runner = RelationViewRunner(E, R, bat, "relation", lr=0.001, sample_chunk=args.sample_chunk or None)
-        eng = StepEngine()
-        n_steps_epoch = bat.steps
-        ev, ev_upd = [], []
 
         def run_steps(i0, i1):
-            """global step indices [i0, i1): whole epochs go through runner.run_epochs (next epoch's permutation and
-            negatives prepared on a side stream meanwhile); a partial epoch is ONE call into the native runner."""
-            i = i0
-            while i < i1:
-                s = i % n_steps_epoch
-                if s == 0 and i1 - i >= n_steps_epoch:
-                    n_ep = (i1 - i) // n_steps_epoch
-                    if i > 0:
-                        bat.shuffle()
-                    runner.run_epochs(n_ep)
-                    i += n_ep * n_steps_epoch
-                    continue
-                e = min(n_steps_epoch, s + (i1 - i))
-                if s == 0 and i > 0:
-                    bat.shuffle()
-                runner.run(s, e)
-                i += e - s
-
-        def run_step_timed(i):
-            """Python-driven step with HIP events around the dominant kernel only (same stream)."""
-            from multike_amd import _lib
-            s = i % n_steps_epoch
-            pos, neg = bat.batch(s)
-            tag, lp = eng._next()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], N, E.refcount)
-            e0.record()
-            _lib.triple_score_fwd_bwd_x(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
-                                        E.touched, R.touched, tag, E.refcount, E.slot("relation"), _lib.OPT_ADAGRAD, 0.001, lp)
-            e1.record()
-            ev.append((e0, e1, pos[0].numel() * (1 + N)))
-            _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
-                                    (E.data, E.slot("relation"), E.grad, E.touched, True, E.refcount)], tag, E.stride, d,
-                                   _lib.OPT_ADAGRAD, 0.001)
-            e2 = torch.cuda.Event(enable_timing=True)
-            e2.record()
-            ev_upd.append((e1, e2, tag))
-
-        def triples_of(i):
-            s = i % n_steps_epoch
-            return int(bat.off[s + 1] - bat.off[s]) * (1 + N)
+            for i in range(i0, i1):
+                run_step(i)
+    else:
+        fused = FusedWorkload(cfg, sample_chunk=args.sample_chunk, rel_grad_copies=args.rel_grad_copies)
+        kgs, ent0, rel0 = fused.kgs, fused.ent0, fused.rel0
+        n_steps_epoch = fused.n_steps_epoch
+        run_steps, triples_of = fused.run_steps, fused.triples_of
+    rccl = device_report(dist, staged, world, rank, local_rank)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    sharded = world > 1 or args.force_sharded
-    if sharded:
-        def run_steps(i0, i1):
-            for i in range(i0, i1):
-                run_step(i)
     # pre-warm: the driver's invocation is the first command on a fresh box (cold clocks, cold caches, first launch of every
     # kernel).  Whole untimed epochs of the same work first, then the --warmup steps, then the timed region.
     pre = max(0, args.prewarm_epochs) * n_steps_epoch
@@ -527,80 +697,17 @@ def main():
 
     roofline = None
     if not sharded:
-        # instrumented pass: HIP events bracket every launch of the dominant kernel.  This pass is driven from Python
-        # (one ctypes call per launch), i.e. the host is slower than the GPU; to keep host latency out of the event pairs
-        # the stream is first blocked by a spin kernel long enough for every instrumented step to be queued behind it, so
-        # that the GPU then runs them back to back.
         base = args_w0 + args.warmup + args.steps
         n_inst = max(min(args.steps, 300), 100)      # >= 100 launches whatever --steps is (the driver passes 20)
-        t_h = time.perf_counter()
-        for i in range(base, base + 5):
-            run_step_timed(i)
-        torch.cuda.synchronize()
-        host_per_step = (time.perf_counter() - t_h) / 5
-        ev.clear(); ev_upd.clear()
-        torch.cuda._sleep(int(2.4e9 * (host_per_step * n_inst * 1.5 + 0.02)))
-        for i in range(base + 5, base + 5 + n_inst):
-            run_step_timed(i)
-        torch.cuda.synchronize()
-        ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
-        tr = np.array([n for _, _, n in ev])
-        avg_ms = float(ms.mean())
-        med_ms = float(np.median(ms))
-        achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
-        traffic = pmc_traffic(args)  # PMC bytes per launch of this kernel (separate rocprofv3 --pmc passes), or None
-        # `achieved` = ALGORITHMIC bytes / launch duration (independent-triple model, 12 + 24 dim bytes per scored
-        # triple).  The kernel loads a positive's rows once for its N negatives, so it moves FEWER bytes than that model
-        # counts and the algorithmic figure can exceed what the memory system delivers (it does at the c5 shape).  When the
-        # PMC byte count of THIS build is on file, `frac` is therefore the counter-based fraction — bytes the memory side
-        # really moved / launch duration / peak — and the algorithmic one is kept beside it as `frac_algorithmic`.
-        ach_counter = None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS if ach_counter is None else ach_counter / HBM_PEAK_GBS,
-                    "frac_basis": "algorithmic bytes (no PMC file for this build)" if ach_counter is None else
-                                  "counter: PMC bytes per launch / launch duration / peak",
-                    "frac_algorithmic": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "avg_launch_us": avg_ms * 1e3, "median_launch_us": med_ms * 1e3, "launches_timed": int(len(ms)),
-                    "alg_bytes_per_triple": b_alg(d),
-                    "triples_per_launch": float(tr.mean()),
-                    "achieved_counter": ach_counter,
-                    "streaming_copy_GBps": HBM_ACHIEVABLE_GBS,      # what a float4 copy reaches on this part (same guide)
-                    "kernel_source_sha": kernel_source_hash()}
-        # second kernel of the step, reported beside it: rows left to it (referenced more than once in the step) x 6 row
-        # streams (grad, w, acc read; 0, w, acc written); rows referenced once were updated inside k_triple_score
-        touched_rows = int((E.touched == ev_upd[-1][2]).sum()) + int((R.touched == ev_upd[-1][2]).sum())
-        ums = np.array([a.elapsed_time(b) for a, b, _ in ev_upd])
-        upd_bytes = touched_rows * 6 * E.stride * 4
-        roofline["update_kernel"] = {"kernel": "k_rows_update_multi", "avg_launch_us": float(ums.mean()) * 1e3,
-                                     "touched_rows_last_step": touched_rows, "bytes_per_launch": upd_bytes,
-                                     "achieved": upd_bytes / (float(ums.mean()) * 1e-3) / 1e9, "unit": "GB/s"}
-
-    if not sharded:
-        # where a step's time goes: the two kernels (events above), the epoch sampler amortised over its steps (one launch per
-        # epoch, timed here with events), and what is left — kernel boundaries and launch gaps of the native step loop
-        from multike_amd.sampling import sample_negatives
-        total_neg = int(bat.off[-1]) * N
-        samp_us = None
-        if N and runner.neg[0].numel() >= total_neg:
-            se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            se0.record()
-            sample_negatives((bat.pos_h, bat.pos_r, bat.pos_t), bat.side1, N, seed=bat.rng_seed, stream_id=bat.rng_stream,
-                             pos_offset=0, out=tuple(x[:total_neg] for x in runner.neg), side1=bat.side2, pos_kg=bat.pos_kg)
-            se1.record()
-            torch.cuda.synchronize()
-            samp_us = se0.elapsed_time(se1) * 1e3 / n_steps_epoch
-        step_us = dt / args.steps * 1e6
-        upd_us = roofline["update_kernel"]["avg_launch_us"]
-        roofline["step_breakdown_us"] = {
-            "step_wall": step_us, "score_kernel": roofline["avg_launch_us"], "update_kernel_incl_its_boundary": upd_us,
-            "sampler_amortised": samp_us,
-            "boundaries_and_gaps": step_us - roofline["avg_launch_us"] - upd_us - (samp_us or 0.0)}
+        # PMC bytes per launch of this kernel (separate rocprofv3 --pmc passes), or None
+        roofline = fused.instrumented(base, n_inst, pmc_traffic(args.config, getattr(args, "custom", False)), dt / args.steps * 1e6)
 
     variants = None
     if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False):
-        variants = reference_default_variants(args, kgs, ent0, rel0, sides)
+        variants = reference_default_variants(args, kgs, ent0, rel0, fused.sides)
+        del fused
+        torch.cuda.empty_cache()
+        variants.insert(0, hbm_resident_variant(args))
 
     if sharded:
         # same instrumentation on the sharded path: events around this rank's score-kernel launches (extra steps)
@@ -630,11 +737,8 @@ def main():
         ep_loss = trainer.epoch_loss()
         if not np.isfinite(ep_loss):
             raise SystemExit(f"bench.py: non-finite loss {ep_loss} on the sharded path")
-        achieved = float((tr * b_alg(d)).sum() / (ms.sum() * 1e-3) / 1e9)
-        roofline = {"bound": "hbm", "kernel": "k_triple_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": float(ms.mean()) * 1e3,
-                    "alg_bytes_per_triple": b_alg(d), "triples_per_launch": float(tr.mean()), "scope": "per GPU (rank 0)",
-                    "exchange": shard_info}
+        roofline = roofline_object("k_oc_score" if shard_mode != "rowfetch" else "k_triple_score", ms, tr, d, None)
+        roofline.update({"scope": "per GPU (rank 0): the triples whose corrupt entity this rank owns", "exchange": shard_info})
 
     if rank == 0:
         out = {
@@ -648,8 +752,9 @@ def main():
                        "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,
                        "scored_per_step": B * (1 + N) * world, "steps_per_epoch": n_steps_epoch},
             "roofline": roofline,
+            "rccl": rccl,
         }
-        if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False):
+        if variants is not None:
             out["variants"] = variants
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)

@@ -776,6 +776,13 @@ int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output */
 int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, const int32_t* neg_t, int64_t n_pos, int neg_per_pos,
                       int32_t* codes, void* stream);
+/* Per-epoch plan (table-independent; new design, no reference counterpart): part k of the epoch = epoch positions
+ * [part_lo[k], part_lo[k+1]) (device array of n_parts + 1 offsets).  slot_h[i] / slot_t[i] = rank of positive i among the
+ * positives of its part whose head / tail has the same owner (id % n_ranks), in epoch order; own_h / own_t[part_lo[k] + s] =
+ * position inside part k of the positive holding slot s of THIS rank's block (s < counts[...][rank]);
+ * counts[(x * n_parts + k) * n_ranks + g] = positives of part k whose head (x = 0) / tail (x = 1) rank g owns. */
+int mke_oc_plan(const int32_t* pos_h, const int32_t* pos_t, const int64_t* part_lo, int n_parts, int n_ranks, int rank,
+                int32_t* slot_h, int32_t* slot_t, int32_t* own_h, int32_t* own_t, int32_t* counts, void* stream);
 int mke_oc_bases(const mke_oc_step* step, float* send_block, void* stream);
 int mke_oc_count(const mke_oc_step* step, void* stream);
 int mke_oc_score(const mke_oc_step* step, const float* v_all, int64_t block_floats, float* g_all,

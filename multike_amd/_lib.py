@@ -33,7 +33,7 @@ SYMBOLS = (
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
-    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
+    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -402,7 +402,7 @@ def neg_sample_at(pos, pos_index, pos_kg, sides, neg_per_pos, max_try, seed, str
     _check(rc, "mke_neg_sample_at")
 
 
-SIM_SELECT_KPADS = (16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 208, 256)   # instantiations of k_sim_select
+SIM_SELECT_KPADS = (16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 208, 256, 320)   # instantiations of k_sim_select / k_sim_sample / k_align_rank: up to MAX_STRIDE
 
 
 def sim_select(emb: torch.Tensor, kpad: int, row_lo: int, row_hi: int, tau: torch.Tensor, n_seg: int, seg_cap: int):
@@ -673,6 +673,15 @@ def oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos: int, codes):
                                  _dev(neg_t, torch.int32, "neg_t"), C.c_int64(pos_h.numel()), C.c_int(neg_per_pos),
                                  _dev(codes, torch.int32, "codes"), _stream())
     _check(rc, "mke_oc_pack_codes")
+
+
+def oc_plan(pos_h, pos_t, part_lo, n_parts: int, n_ranks: int, rank: int, slot_h, slot_t, own_h, own_t, counts):
+    """The epoch's slots / owned lists / per-(part, owner) counts in one launch (mke_oc_plan)."""
+    i32 = torch.int32
+    rc = lib().mke_oc_plan(_dev(pos_h, i32, "pos_h"), _dev(pos_t, i32, "pos_t"), _dev(part_lo, torch.int64, "part_lo"),
+                           C.c_int(n_parts), C.c_int(n_ranks), C.c_int(rank), _dev(slot_h, i32, "slot_h"), _dev(slot_t, i32, "slot_t"),
+                           _dev(own_h, i32, "own_h"), _dev(own_t, i32, "own_t"), _dev(counts, i32, "counts"), _stream())
+    _check(rc, "mke_oc_plan")
 
 
 def oc_bases(step: OcStepStruct, send_block):

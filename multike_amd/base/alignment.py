@@ -28,8 +28,9 @@ def alignment_counts(embed1, embed2, normalize=True, device="cuda"):
     n2 = b.shape[0]
     if n2 < n1:
         raise _lib.MultiKEHipError("greedy_alignment: gold column = row index needs len(embed2) >= len(embed1)")
-    if d > _lib.SIM_SELECT_KPADS[-1]:
-        return _counts_wide(a, b)
+    if d > _lib.SIM_SELECT_KPADS[-1]:      # wider than the widest table the package supports (MKE_MAX_STRIDE): no second backend
+        raise _lib.MultiKEHipError(f"greedy_alignment: rows of {d} floats exceed the widest k_align_rank instantiation "
+                                   f"({_lib.SIM_SELECT_KPADS[-1]} = MKE_MAX_STRIDE)")
     kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
     ap = torch.zeros(n1, kpad, dtype=torch.float32, device=device)
     ap[:, :d] = a
@@ -41,23 +42,6 @@ def alignment_counts(embed1, embed2, normalize=True, device="cuda"):
     _lib.align_rank(ap, bp, kpad, n1, n2, rank, best, ties)
     col = 0xFFFFFFFF - (best & 0xFFFFFFFF)
     return rank.long(), ties.long().clamp_min(1), col
-
-
-def _counts_wide(a, b, block_rows=4096):
-    """Rows wider than the widest `k_align_rank` instantiation (256 floats; the tables go to 320): the same three counts from
-    row blocks of the library GEMM on the device, the gold similarity read out of the same product."""
-    n1 = a.shape[0]
-    greater = torch.empty(n1, dtype=torch.int64, device=a.device)
-    ties, best = torch.empty_like(greater), torch.empty_like(greater)
-    bt = b.t().contiguous()
-    for lo in range(0, n1, block_rows):
-        hi = min(n1, lo + block_rows)
-        sim = a[lo:hi] @ bt
-        gold = sim.gather(1, torch.arange(lo, hi, device=a.device)[:, None])
-        greater[lo:hi] = (sim > gold).sum(1)
-        ties[lo:hi] = (sim == gold).sum(1)
-        best[lo:hi] = sim.argmax(1)
-    return greater, ties.clamp_min(1), best
 
 
 def alignment_ranks(embed1, embed2, normalize=True, device="cuda"):

@@ -129,22 +129,19 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     table = torch.zeros(n_ent_total, k, dtype=torch.int32, device=device)
     valid = torch.zeros(n_ent_total, dtype=torch.uint8, device=device)
     n_samp, cap = 4096, _pow2_at_least(int(1.4 * k) + 64)
-    short = n >= 8 * n_samp and cap * 4 <= n and cap <= 4096 and d <= 256
-
-    own = d <= _lib.SIM_SELECT_KPADS[-1]          # rows up to 256 floats: the package's own MFMA sweep, no library GEMM
-    if own:
-        kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
+    short = n >= 8 * n_samp and cap * 4 <= n and cap <= 4096
+    if d > _lib.SIM_SELECT_KPADS[-1]:     # wider than the widest table the package supports (MKE_MAX_STRIDE): no second backend
+        raise _lib.MultiKEHipError(f"neighbour_table: rows of {d} floats exceed the widest k_sim_select instantiation "
+                                   f"({_lib.SIM_SELECT_KPADS[-1]} = MKE_MAX_STRIDE)")
+    kpad = min(x for x in _lib.SIM_SELECT_KPADS if x >= d)
 
     def full_width(rows):
         """top k of whole similarity rows (short KGs; rows whose threshold estimate was off).  The similarities come from the
         same sweep as the main pass (`mke_sim_sample` against ALL columns: identical fma chains) — a library GEMM here was
         the refresh's only library call and cost its 170 ms initialisation at the first refresh of a run."""
-        if own:
-            cols = ep if ep is not None else _padded(e)
-            src = cols[rows].contiguous()
-            sim = _lib.sim_sample(src, kpad, 0, int(src.shape[0]), cols)
-        else:
-            sim = e[rows] @ e.t()
+        cols = ep if ep is not None else _padded(e)
+        src = cols[rows].contiguous()
+        sim = _lib.sim_sample(src, kpad, 0, int(src.shape[0]), cols)
         return torch.topk(sim, k, dim=1, sorted=False).indices
 
     def _padded(x):
@@ -155,8 +152,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
 
     p_lo, p_hi = (0, n) if part is None else (n * part[0] // part[1], n * (part[0] + 1) // part[1])
     if not short:
-        if own:
-            ep = _padded(e)
+        ep = _padded(e)
         for lo in range(p_lo, p_hi, block_rows):
             hi = min(p_hi, lo + block_rows)
             table[ids[lo:hi]] = ids[full_width(slice(lo, hi))].to(torch.int32)

@@ -133,7 +133,7 @@ extern "C" int mke_align_rank(const float* emb1, int ld1, const float* emb2, int
     break;
   switch (kpad) {
     EV_CASE(16) EV_CASE(32) EV_CASE(48) EV_CASE(64) EV_CASE(80) EV_CASE(96) EV_CASE(112) EV_CASE(128) EV_CASE(160)
-    EV_CASE(192) EV_CASE(208) EV_CASE(256)
+    EV_CASE(192) EV_CASE(208) EV_CASE(256) EV_CASE(320)
     default:
       set_error("unsupported kpad %d", kpad);
       return MKE_E_UNSUPPORTED;

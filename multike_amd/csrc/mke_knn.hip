@@ -329,7 +329,7 @@ extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols
     break;
   switch (kpad) {
     KNN_CASE(16) KNN_CASE(32) KNN_CASE(48) KNN_CASE(64) KNN_CASE(80) KNN_CASE(96) KNN_CASE(112) KNN_CASE(128) KNN_CASE(160)
-    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256)
+    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256) KNN_CASE(320)
     default:
       set_error("mke_sim_select: unsupported kpad %d", kpad);
       return MKE_E_UNSUPPORTED;
@@ -362,7 +362,7 @@ extern "C" int mke_sim_sample(const float* emb, int ld, int kpad, int64_t n_rows
     break;
   switch (kpad) {
     KNN_CASE(16) KNN_CASE(32) KNN_CASE(48) KNN_CASE(64) KNN_CASE(80) KNN_CASE(96) KNN_CASE(112) KNN_CASE(128) KNN_CASE(160)
-    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256)
+    KNN_CASE(192) KNN_CASE(208) KNN_CASE(256) KNN_CASE(320)
     default:
       set_error("mke_sim_sample: unsupported kpad %d", kpad);
       return MKE_E_UNSUPPORTED;

@@ -82,6 +82,10 @@ class OcHipBackend:
     def pack_codes(self, pos_h, neg_h, neg_t, neg_per_pos, codes):
         _lib.oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos, codes)
 
+    def plan(self, pos_h, pos_t, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts):
+        """slots, owned lists and per-(part, owner) counts of the whole epoch in ONE launch (mke_oc_plan)."""
+        _lib.oc_plan(pos_h, pos_t, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts)
+
     def _struct(self, tr: "OwnerComputesTrainer", st: OcStep):
         f32, i32 = torch.float32, torch.int32
         s = _lib.OcStepStruct()
@@ -159,10 +163,10 @@ class OcHipBackend:
             self._steps = cache[key] = out
             self._ring = tr.loss_ring.data_ptr()
             self._ring_stride = tr.loss_ring.shape[1] * 8
-        offh, offt = (x.tolist() for x in tr._own_off)
-        for k, s in enumerate(self._steps):
-            s.own_h, s.n_own_h = oh + 4 * offh[k], offh[k + 1] - offh[k]
-            s.own_t, s.n_own_t = ot + 4 * offt[k], offt[k + 1] - offt[k]
+        cnth, cntt = (x.tolist() for x in tr._own_cnt)
+        for k, (s, (_, lo, _hi)) in enumerate(zip(self._steps, tr._parts)):     # a part's owned list starts at the part's own offset
+            s.own_h, s.n_own_h = oh + 4 * lo, cnth[k]
+            s.own_t, s.n_own_t = ot + 4 * lo, cntt[k]
 
     def bases(self, tr, st, send):
         _lib.oc_bases(self._cached(tr, st), send)
@@ -487,6 +491,7 @@ class OwnerComputesTrainer:
         self._part_id = torch.repeat_interleave(torch.arange(len(parts), device=dev), torch.as_tensor(hi - lo, device=dev)) \
             if len(parts) else torch.zeros(0, dtype=torch.int64, device=dev)
         self._lo_of = torch.as_tensor(lo, device=dev)
+        self._part_lo = torch.as_tensor(np.concatenate([lo, [self._n_all]]).astype(np.int64), device=dev)   # [parts + 1]
         self._parts_of = {}
         for k, (ps, _, _) in enumerate(parts):
             self._parts_of.setdefault(ps, []).append(k)
@@ -510,29 +515,35 @@ class OwnerComputesTrainer:
                                    b.rng_seed, rng_stream, neg)
             self.backend.pack_codes(ph[:n_all], neg[0], neg[2], N, codes[:n_all * N])
         plan["codes"] = codes
-        plan["slot"], plan["own"], plan["cnt_dev"] = [], [], []
-        for x, ids in enumerate((ph, pt)):
-            if n_all == 0:
-                plan["slot"].append(torch.zeros(1, **i32)); plan["own"].append(torch.zeros(1, **i32))
-                continue
-            key = part_id * G + (ids[:n_all].long() % G)
-            order = torch.argsort(key, stable=True)
-            ks = key[order]
-            counts = torch.bincount(ks, minlength=len(parts) * G)
-            start = torch.cumsum(counts, 0) - counts
-            slot = torch.empty(n_all, dtype=torch.int64, device=dev)
-            slot[order] = torch.arange(n_all, device=dev) - start[ks]
-            plan["slot"].append(self._persist(("slot", x, bs), slot.to(torch.int32), n_all))
-            # owned positives (as positions inside their part), in slot order, for every part: the sorted order restricted
-            # to this rank's keys is exactly that
-            own_pos = order[ks % G == self.rank]
-            plan["own"].append(self._persist(("own", x, bs), (own_pos - self._lo_of[part_id[own_pos]]).to(torch.int32), n_all))
-            plan["cnt_dev"].append(counts)
+        # slot of every positive's HR / RT vector in its owner's block (rank among the positives of its part with the same
+        # owner, epoch order), this rank's owned positives per part in slot order (part k's list starts at own[lo_k]), and
+        # the per-(part, owner) counts.  HIP backend: one launch (mke_oc_plan); other backends (the CPU tests): torch.
+        slot = [self._persist(("slot", x, bs), torch.zeros(0, **i32), max(1, n_all)) for x in range(2)]
+        own = [self._persist(("own", x, bs), torch.zeros(0, **i32), max(1, n_all)) for x in range(2)]
+        plan["slot"], plan["own"] = slot, own
         if n_all:
-            c = torch.stack(plan["cnt_dev"]).to(torch.int64)
+            cnt = self._persist(("cnt", bs), torch.zeros(0, **i32), 2 * len(parts) * G)
+            if hasattr(self.backend, "plan"):
+                self.backend.plan(ph, pt, self._part_lo, len(parts), G, self.rank, slot[0], slot[1], own[0], own[1], cnt)
+            else:
+                for x, ids in enumerate((ph, pt)):
+                    owner = ids[:n_all].long() % G
+                    key = part_id * G + owner
+                    order = torch.argsort(key, stable=True)
+                    ks = key[order]
+                    counts = torch.bincount(ks, minlength=len(parts) * G)
+                    start = torch.cumsum(counts, 0) - counts
+                    sl = torch.empty(n_all, dtype=torch.int64, device=dev)
+                    sl[order] = torch.arange(n_all, device=dev) - start[ks]
+                    slot[x][:n_all].copy_(sl.to(torch.int32))
+                    mine = torch.nonzero(owner == self.rank).reshape(-1)
+                    lo_m = self._lo_of[part_id[mine]]
+                    own[x][(lo_m + sl[mine])] = (mine - lo_m).to(torch.int32)
+                    cnt[x * len(parts) * G:(x + 1) * len(parts) * G].copy_(counts.to(torch.int32))
+            c = cnt[:2 * len(parts) * G].view(2, len(parts), G)
             host = self._persistent.get(("cnt_host", bs))
             if host is None or host.shape != c.shape:
-                host = torch.empty(c.shape, dtype=torch.int64, pin_memory=dev.type == "cuda")
+                host = torch.empty(c.shape, dtype=torch.int32, pin_memory=dev.type == "cuda")
                 self._persistent[("cnt_host", bs)] = host
             host.copy_(c, non_blocking=True)
             plan["cnt_host"] = host
@@ -549,15 +560,15 @@ class OwnerComputesTrainer:
             plan["event"].synchronize()
         parts = self._parts
         self._codes, self._slot, self._own = plan["codes"], plan["slot"], plan["own"]
-        self._own_off = []
+        self._own_cnt = []                      # per part: how many HR / RT vectors of it this rank owns
         worst = 0
         for x in range(2):
-            off = np.zeros(len(parts) + 1, dtype=np.int64)
+            mine = np.zeros(len(parts), dtype=np.int64)
             if self._n_all:
                 cnt = plan["cnt_host"][x].numpy().reshape(len(parts), G)
                 worst = max(worst, int(cnt.max()))
-                off[1:] = np.cumsum(cnt[:, self.rank])
-            self._own_off.append(off)
+                mine = cnt[:, self.rank].astype(np.int64)
+            self._own_cnt.append(mine)
         # -- capacity: exact for this epoch, buffers only ever grow ----------------------------------------
         need = max(worst, 1)
         if need > self.C:
@@ -672,11 +683,11 @@ class OwnerComputesTrainer:
         _, lo, hi = self._parts[k]
         b = self.bat
         per, _, _ = self.my_slice(lo, hi)
-        oh, ot = self._own_off[0], self._own_off[1]
+        nh, nt = int(self._own_cnt[0][k]), int(self._own_cnt[1][k])
         code_off = tuple((lo + g * per) * self.N for g in range(self.world))   # codes are laid out by epoch position
         pw = getattr(b, "pos_w", None)
         return OcStep(b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi], per, self._slot[0][lo:hi], self._slot[1][lo:hi],
-                      self._own[0][oh[k]:oh[k + 1]], self._own[1][ot[k]:ot[k + 1]], tag, self._codes, code_off,
+                      self._own[0][lo:lo + nh], self._own[1][lo:lo + nt], tag, self._codes, code_off,
                       pos_w=(pw[lo:hi] if pw is not None else None))
 
     def step(self, i: int):

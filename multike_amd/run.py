@@ -52,21 +52,16 @@ def main(argv=None):
         except json.JSONDecodeError:
             pass
         setattr(args, k, v)
-    if a.synthetic is not None:
-        from .synthetic import SyntheticData
-        data = SyntheticData(**dict({"dim": args.dim}, **json.loads(a.synthetic)))
-        predicate_align_model = data.predicate_align_model
-    else:
-        data = DataModel(args)
-        predicate_align_model = PredicateAlignModel(data.kgs, args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, comm_oc, comm_v = 0, None, None
+    if a.synthetic is None and a.training_data == "synthetic/" and not os.path.isdir(args.training_data):
+        raise SystemExit("multike_amd.run: give --training_data <dataset folder> (or --synthetic '{...}' for a generated dataset)")
     if world > 1:
-        import contextlib
-        import io
+        # the process group and this rank's device come FIRST: DataModel trains the literal auto-encoder on the device, and
+        # before set_device every rank would do that on GPU 0
         import torch
         import torch.distributed as dist
         from .distributed_run import ShardedMultiKE_CV, ShardedMultiKE_Late, init_process_group_from_env
-        comm_oc = comm_v = None
         if os.environ.get("MKE_BENCH_COMM", "") == "staged":     # dry run: ranks share GPUs, collectives staged through gloo
             from .distributed_oc import OcHostStagedComm
             from .distributed_views import HostStagedViewComm
@@ -77,14 +72,38 @@ def main(argv=None):
             comm_oc, comm_v = OcHostStagedComm(), HostStagedViewComm()
         else:
             rank, world = init_process_group_from_env()
-        cls = ShardedMultiKE_CV if a.method == "ITC" else ShardedMultiKE_Late
-        with (contextlib.redirect_stdout(io.StringIO()) if rank else contextlib.nullcontext()):    # the readers print per rank
+
+    def load_data():
+        if a.synthetic is not None:
+            from .synthetic import SyntheticData
+            data = SyntheticData(**dict({"dim": args.dim}, **json.loads(a.synthetic)))
+            return data, data.predicate_align_model
+        data = DataModel(args)
+        return data, PredicateAlignModel(data.kgs, args)
+
+    if world > 1:
+        import contextlib
+        import io
+        # rank 0 prepares the dataset first (it trains the literal auto-encoder ONCE and writes the literal cache into the
+        # folder); the others wait and then read that cache, so the replicated constants (literal / name vectors) are the
+        # same bytes on every rank instead of N independently trained copies
+        quiet = contextlib.redirect_stdout(io.StringIO()) if rank else contextlib.nullcontext()    # the readers print per rank
+        with quiet:
+            if rank == 0:
+                data, predicate_align_model = load_data()
+            dist.barrier()
+            if rank != 0:
+                retrain, args.retrain_literal_embeds = getattr(args, "retrain_literal_embeds", False), False
+                data, predicate_align_model = load_data()
+                args.retrain_literal_embeds = retrain
+            cls = ShardedMultiKE_CV if a.method == "ITC" else ShardedMultiKE_Late
             model = cls(data, args, predicate_align_model, rank, world, comm_oc, comm_v)
-        res = model.run()
+            res = model.run()               # the schedule prints once (rank 0), not once per rank
         if rank == 0:
             print("results:", json.dumps({k: float(v) for k, v in res.items()}))
         dist.destroy_process_group()
         return res
+    data, predicate_align_model = load_data()
     model = (MultiKE_CV if a.method == "ITC" else MultiKE_Late)(data, args, predicate_align_model)
     return model.run()
 

@@ -99,8 +99,13 @@ class RelationViewRunner:
             if getattr(self, "_det_engine", None) is None:
                 self._det_engine = StepEngine(self.ent.device, loss_ring=max(2, self.steps))
                 self._det_engine.tag = 1 << 29
+            N = self.bat.neg_per_pos
             for s in range(step_begin, step_end):
                 pos, neg = self.bat.batch(s)
+                if N and self.sample_chunk >= self.steps:       # the epoch's negatives where the native loop leaves them
+                    lo = int(self.bat.off[s])
+                    for dst, src in zip(self.neg, neg):
+                        dst[lo * N:lo * N + src.numel()].copy_(src)
                 lp = self._det_engine.relation_step(self.ent, self.rel, self.opt_name, pos, neg if self.bat.neg_per_pos else None,
                                                     neg_per_pos=self.bat.neg_per_pos, lr=self.lr, scale=self.scale,
                                                     optimizer=self.optimizer, exclusive_rows=self.exclusive_rows)

@@ -38,10 +38,13 @@ SLOTS = {
 
 class OracleMultiKE:
     def __init__(self, tables: dict, cnn_sets, mappings=None, learning_rate=0.001, itc_learning_rate=0.004,
-                 cv_name_weight=1.0, cv_weight=1.0, orthogonal_weight=2.0):
+                 cv_name_weight=1.0, cv_weight=1.0, orthogonal_weight=2.0, dtype=np.float64):
         """tables: raw values {"rv_ent", "av_ent", "ent", "rel", "attr"} (trainable) + {"name", "lit"} (constants);
-        cnn_sets: three parameter dicts (attribute view, ckge_attr, ckga_attr); mappings: [nv, rv, av] d x d or None."""
-        f = lambda a: np.array(a, dtype=np.float64)
+        cnn_sets: three parameter dicts (attribute view, ckge_attr, ckga_attr); mappings: [nv, rv, av] d x d or None.
+        dtype: float64 = the truth; float32 = the same schedule in the reference's WORKING precision with NumPy's summation
+        order — what any other correct fp32 implementation of the same arithmetic looks like next to the truth (the yardstick
+        tests/test_schedule_trace_gpu.py holds the HIP tables against)."""
+        f = lambda a: np.array(a, dtype=dtype)
         self.t = {k: f(v) for k, v in tables.items()}
         self.acc = {(opt, var): np.full_like(self.t[var], ACC0) for opt, vs in SLOTS.items() for var in vs}
         self.cnn = [{k: f(v) for k, v in p.items()} for p in cnn_sets]
@@ -73,7 +76,7 @@ class OracleMultiKE:
             lo, hi = int(off[s]), int(off[s + 1])
             L, _, _ = mo.relation_view_step_dense(t["rv_ent"], t["rel"], self.acc[(opt, "rv_ent")], self.acc[(opt, "rel")],
                                                   tuple(c[lo:hi] for c in cols), None, self.lr,
-                                                  pos_w=None if w is None else np.asarray(w[lo:hi], dtype=np.float64), scale=scale)
+                                                  pos_w=None if w is None else np.asarray(w[lo:hi], dtype=t["rel"].dtype), scale=scale)
             total += L
         return total / max(int(off[-1]), 1)
 
@@ -90,7 +93,7 @@ class OracleMultiKE:
                                            self.acc[(opt, "av_ent")], self.acc[(opt, "attr")],
                                            np.asarray(cols[0][lo:hi], dtype=np.int64), np.asarray(cols[1][lo:hi], dtype=np.int64),
                                            np.asarray(cols[2][lo:hi], dtype=np.int64),
-                                           None if w is None else np.asarray(w[lo:hi], dtype=np.float64), scale, self.lr)
+                                           None if w is None else np.asarray(w[lo:hi], dtype=t["attr"].dtype), scale, self.lr)
             total += L
         return total / max(int(off[-1]), 1)
 

@@ -22,6 +22,20 @@ def _run(extra):
     return json.loads(lines[0])
 
 
+def _check_roofline(r):
+    """One basis per pair: (achieved, frac) algorithmic — the contract's definition — and (achieved_counter, frac_counter)
+    from the PMC bytes on file for this build, or both None."""
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["frac_algorithmic"] == r["frac"] and r["achieved_algorithmic"] == r["achieved"]
+    assert abs(r["achieved"] - r["alg_bytes_per_triple"] * r["triples_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * r["achieved"]
+    if r["traffic"] is None:
+        assert r["achieved_counter"] is None and r["frac_counter"] is None
+    else:
+        assert abs(r["frac_counter"] - r["achieved_counter"] / r["peak"]) < 1e-12 and 0 < r["frac_counter"] < 1.0
+        assert abs(r["achieved_counter"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved_counter"]
+
+
 def test_n1_line():
     d = _run([])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -31,32 +45,52 @@ def test_n1_line():
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - d["config"]["scored_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac_algorithmic"] - r["achieved"] / r["peak"]) < 1e-9
-    # `frac` is counter-based when the PMC byte count of this build is on file, algorithmic otherwise; never above 1 by design
-    if r["traffic"] is None:
-        assert r["frac"] == r["frac_algorithmic"] and r["achieved_counter"] is None
-    else:
-        assert abs(r["frac"] - r["achieved_counter"] / r["peak"]) < 1e-9 and r["frac"] < 1.0
-    assert "frac_of_achievable" not in r
+    _check_roofline(r)
     b = r["step_breakdown_us"]
     assert abs(b["step_wall"] - d["ms_per_step"] * 1e3) < 1e-6 and b["score_kernel"] > 0 and b["sampler_amortised"] > 0
+    # no difference of figures from two different loops is printed (it went negative in round 3)
+    assert "boundaries_and_gaps" not in b and all(v > 0 for v in b["instrumented_loop"].values())
+    assert d["rccl"]["world"] == 1 and len(d["rccl"]["devices"]) == 1
     assert r["peak"] == 8000.0 and r["alg_bytes_per_triple"] == 12 + 24 * d["config"]["dim"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["one_thread_value"] > 0 and c["whole_table_passes_value"] > 0
-    v = d["variants"]                 # the reference's default shape (code/args.json:25-28) as side lines
+    v = d["variants"]
+    c5 = v.pop(0)                     # the HBM-resident shape (configs[4] per GPU) with its own roofline object
+    assert "C5-synth" in c5["name"] and c5["scored_per_step"] == 5000 * 65 and c5["value"] > 50e6
+    assert abs(c5["value"] - c5["scored_per_step"] / (c5["ms_per_step"] * 1e-3)) / c5["value"] < 0.02
+    _check_roofline(c5["roofline"])
+    assert c5["roofline"]["alg_bytes_per_triple"] == 12 + 24 * 256
+    # then the reference's default shape (code/args.json:25-28) as side lines
     assert [x["scored_per_step"] for x in v[:2]] == [d["config"]["batch"] * 11] * 2 and all(x["value"] > 50e6 for x in v[:2])
     k = v[1]["knn_refresh_ms_untimed"]
     assert 0 < k["warm_second_call"] <= k["cold_first_call"] * 1.5
     assert "attribute" in v[2]["name"] and v[2]["value"] > 1e6 and v[2]["roofline"]["frac_hbm"] < 1
     assert "PyTorch" in v[3]["name"] and 0 < v[3]["value"] < d["value"]      # the straight port on the same GPU is the slower one
-    assert r["kernel_source_sha"] and (r["traffic"] is None or r["achieved_counter"] > 0)
+    assert r["kernel_source_sha"]
     assert d["value"] > 50e6          # north_star floor: >= 50 M scored triples/s on one MI355X
 
 
 def test_sharded_line_one_rank():
     d = _run(["--force-sharded"])
     assert d["n_gpus"] == 1 and d["roofline"]["achieved"] > 0 and "cpu_baseline" not in d
+    assert d["rccl"]["world"] == 1 and d["rccl"]["backend"].startswith("nccl")      # a real one-rank RCCL group
+
+
+@pytest.mark.timeout(900)
+def test_bare_multi_gpu_command_launches_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 line): bench.py starts the two
+    ranks itself and rank 0 prints the one JSON line, with the process group's own view of the job in `rccl`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MKE_BENCH_COMM"] = "staged"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and [x["rank"] for x in d["rccl"]["devices"]] == [0, 1]
+    assert "DRY RUN" in d["data"] and "gloo" in d["rccl"]["backend"]
 
 
 @pytest.mark.timeout(900)

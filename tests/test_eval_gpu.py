@@ -45,7 +45,9 @@ def test_ranks_vs_oracle(n1, n2, d):
 
 
 def test_rows_wider_than_the_widest_instantiation():
-    """dim 257..320 (the tables' widest stride is 320, k_align_rank's is 256): library-GEMM row blocks, same counts."""
+    """dim 257..320 (the tables' widest stride, MKE_MAX_STRIDE): the 320-float instantiation of the same MFMA sweep — no
+    library GEMM anywhere in the evaluator; wider rows cannot come from a table of this package and are an error."""
+    from multike_amd import _lib
     from multike_amd.base.alignment import alignment_counts
     rng = np.random.default_rng(3)
     for d in (257, 300, 320):
@@ -57,6 +59,24 @@ def test_rows_wider_than_the_widest_instantiation():
         assert np.mean(greater.cpu().numpy() == r64) > 0.99 and np.max(np.abs(greater.cpu().numpy() - r64)) <= 2
         assert int(ties[4]) == 2 and int(ties[5]) == 2 and int((ties != 1).sum()) == 2
         assert np.mean(best.cpu().numpy() == b64) > 0.99
+        rank0, _, best0 = alignment_counts(e2[:700], e2)                       # gold from the same fma chain: never counts itself
+        assert int(rank0.max()) == 0
+    with pytest.raises(_lib.MultiKEHipError):
+        alignment_counts(np.zeros((4, 321), np.float32), np.zeros((4, 321), np.float32))
+
+
+def test_neighbour_table_of_320_float_rows():
+    """k-NN refresh at the widest supported row (k_sim_sample / k_sim_select at kpad 320): exact top-k sets vs float64."""
+    from multike_amd.base.batch import neighbour_table
+    rng = np.random.default_rng(9)
+    n, d, k = 600, 300, 12
+    e = rng.standard_normal((n, d)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    table, valid = neighbour_table(e, list(range(n)), k, n)
+    sim = e.astype(np.float64) @ e.astype(np.float64).T
+    got = np.sort(table.cpu().numpy(), axis=1)
+    exp = np.sort(np.argpartition(-sim, k - 1, axis=1)[:, :k], axis=1)
+    assert np.mean(got == exp) > 0.995 and int(valid.sum()) == n
 
 
 def test_ties_are_ranked_at_mid_rank():

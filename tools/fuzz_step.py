@@ -1,6 +1,8 @@
 """Randomised sweep of the relation step and the attribute step against the float64 oracles: shapes the parametrised tests do
 not list (every supported row width, 0..64 negatives, tiny and ragged batches, heavy duplicates, weights, SGD / Adagrad,
-un-normalised tables).  python tools/fuzz_step.py [cases] [seed]"""
+un-normalised tables).  python tools/fuzz_step.py [cases] [seed]
+MKE_FUZZ_ONLY=<case>: draw every case (same random sequence) but run only that relation case, verbosely, in the atomic AND the
+deterministic mode (fixed-order double accumulation): a difference that the deterministic mode removes is summation noise."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -16,6 +18,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 DIMS = [d for f in _lib._SUPPORTED_FPL for d in (16 * f, 16 * f - int(rng.integers(1, 15)))]
 bad = 0
+ONLY = os.environ.get("MKE_FUZZ_ONLY")
+ONLY = None if ONLY is None else int(ONLY)
 for c in range(cases):
     d = int(rng.choice(DIMS))
     n_ent, n_rel = int(rng.integers(8, 3000)), int(rng.integers(1, 40))
@@ -31,6 +35,36 @@ for c in range(cases):
     pw = rng.uniform(0.2, 1.0, P).astype(np.float32) if rng.random() < 0.3 else None
     scale = float(rng.choice([1.0, 2.0]))
     excl = bool(rng.random() < 0.7)
+    if ONLY is not None:
+        if c != ONLY:
+            continue
+        for det in (0, 1):
+            _lib.set_option("deterministic", det)
+            E, R = make_tables(ent, rel, ent_norm, rel_norm)
+            eng = StepEngine()
+            e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+            a64, b64 = np.full_like(e64, 0.1), np.full_like(r64, 0.1)
+            for step in range(2):
+                eng.relation_step(E, R, "relation", tuple(dev_i32(a) for a in pos), None if neg is None else tuple(dev_i32(a) for a in neg),
+                                  neg_per_pos=N, lr=0.01, scale=scale, optimizer=opt, exclusive_rows=excl, pos_w=None if pw is None else dev_f32(pw))
+                if opt == "Adagrad":
+                    mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01, pos_w=None if pw is None else pw.astype(np.float64),
+                                                scale=scale, ent_norm=ent_norm, rel_norm=rel_norm)
+                else:
+                    _, ge, gr = mo.relation_view_step_dense(e64, r64, a64, b64, pos, neg, 0.01, pos_w=None if pw is None else pw.astype(np.float64),
+                                                            scale=scale, ent_norm=ent_norm, rel_norm=rel_norm, update=False)
+                    if step == 0:
+                        terms = P * (1 + N)
+                        print(f"case {c}: d={d} n_ent={n_ent} n_rel={n_rel} P={P} N={N} opt={opt} norm=({ent_norm},{rel_norm}): relation row 0 sums "
+                              f"{terms} terms; |gradient row| max {np.abs(gr[0]).max():.3e}, sum of |terms| bound ~ {terms} x O(1)")
+                    mo.rows_update_sparse(e64, None, ge, 0.01, normalize=ent_norm, optimizer="SGD")
+                    mo.rows_update_sparse(r64, None, gr, 0.01, normalize=rel_norm, optimizer="SGD")
+            dr = np.abs(R.raw().cpu().numpy() - r64)
+            de = np.abs(E.raw().cpu().numpy() - e64)
+            print(f"  deterministic={det}: rel max diff {dr.max():.3e} (|rel| max {np.abs(r64).max():.3e}, ||rel row|| {np.linalg.norm(r64[0]):.3e}); "
+                  f"ent max diff {de.max():.3e}")
+        _lib.set_option("deterministic", 0)
+        sys.exit(0)
     E, R = make_tables(ent, rel, ent_norm, rel_norm)
     eng = StepEngine()
     e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
@@ -56,7 +90,12 @@ for c in range(cases):
         nz = np.linalg.norm(ent, axis=1) > 0
         if not np.allclose(got[nz], e64[nz], rtol=5e-4, atol=5e-6 + 3e-5 * np.abs(e64[nz]).max()):   # fp32 noise scales with the largest entry
             ok, msg = False, msg + f" ent max diff {np.abs(got[nz] - e64[nz]).max():.2e}"
-        if not np.allclose(R.raw().cpu().numpy(), r64, rtol=5e-4, atol=2e-5 + 1e-4 * np.abs(r64).max()):   # a hub row sums tens of thousands of fp32 terms
+        # a hub row sums tens of thousands of fp32 terms in atomic order: with T = P (1 + N) / n_rel terms per row the rounding
+        # of the running sum grows like sqrt(T) * 2^-24 of the sum of |terms|, and SGD on a normalised row divides by ||w||
+        # (profiles/r04_fuzz_case17.log: case 17 of the round-3 sweep, one relation, 26K terms, is 5.7e-4 in atomic order and
+        # ~1e-6 with the deterministic mode's fixed-order double accumulation)
+        hub = P * (1 + N) / n_rel
+        if not np.allclose(R.raw().cpu().numpy(), r64, rtol=5e-4, atol=2e-5 + (1e-4 + 2e-6 * np.sqrt(hub)) * np.abs(r64).max()):
             ok, msg = False, msg + f" rel max diff {np.abs(R.raw().cpu().numpy() - r64).max():.2e}"
         if float(E.grad.abs().max()) != 0.0 or float(R.grad.abs().max()) != 0.0 or (E._refcount is not None and int(E.refcount.abs().sum()) != 0):
             ok, msg = False, msg + " scratch not consumed"

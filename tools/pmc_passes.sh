@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tools/pmc_passes.sh <config: c2|c5> [bench args...]
 # Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel trace only, no other trace domain) over a short
-# bench.py run, then tools/pmc_to_json.py -> gpurun_out/r03_pmc_<config>.{json,md} (copy into profiles/ to commit).
+# bench.py run, then tools/pmc_to_json.py -> gpurun_out/r04_pmc_<config>.{json,md} (copy into profiles/ to commit).
 cfg=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp

@@ -12,6 +12,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = os.environ.get("MKE_ROUND", "r04")
 sys.path.insert(0, ROOT)
 
 
@@ -56,9 +57,9 @@ def main():
            "update_kernel": {"fetch_size_kb": uf[3], "write_size_kb": uw[3],
                              "known_write_bytes": rows * 3 * stride * 4}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"r03_pmc_{cfg}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"{RND}_pmc_{cfg}.json"), "w") as f:
         json.dump(out, f, indent=1)
-    md = [f"# Round 3 — PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --config {cfg} --steps 40 --warmup 5`", "",
+    md = [f"# {RND} — PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --config {cfg} --steps 40 --warmup 5`", "",
           f"workload: {c['workload']}; kernel sources sha {out['kernel_source_sha']}", "",
           "Two separate passes, each `rocprofv3 --kernel-trace --pmc <COUNTER>`; per dispatch, unit KB.", "",
           "| kernel | counter | dispatches | avg | min | max |", "|---|---|---|---|---|---|"]
@@ -70,7 +71,7 @@ def main():
            f"* `k_triple_score`: {sf[3] * 1024 * corr / 1e6:.1f} MB read + {sw[3] * 1024 / 1e6:.1f} MB written = "
            f"**{traffic / 1e6:.1f} MB per launch** against {alg / 1e6:.1f} MB algorithmic "
            f"({traffic / alg:.2f}x); bench.py divides it by the UNPROFILED launch duration (`roofline.achieved_counter`)"]
-    with open(os.path.join(ROOT, "gpurun_out", f"r03_pmc_{cfg}.md"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"{RND}_pmc_{cfg}.md"), "w") as f:
         f.write("\n".join(md) + "\n")
     print("\n".join(md))
 

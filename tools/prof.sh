@@ -29,7 +29,7 @@ except Exception:
 r = d.get("roofline") or {}
 keep = {k: d[k] for k in ("value", "ms_per_step", "steps", "warmup") if k in d}
 keep["workload"] = d.get("config", {}).get("workload")
-keep["roofline"] = {k: r.get(k) for k in ("avg_launch_us", "achieved", "frac", "frac_basis", "frac_algorithmic", "traffic", "step_breakdown_us") if k in r}
+keep["roofline"] = {k: r.get(k) for k in ("avg_launch_us", "achieved", "frac", "frac_basis", "achieved_counter", "frac_counter", "traffic", "step_breakdown_us") if k in r}
 if "update_kernel" in r:
     keep["update_kernel_avg_launch_us"] = r["update_kernel"]["avg_launch_us"]
 print("```json"); print(json.dumps(keep, indent=1)); print("```")
