@@ -459,6 +459,12 @@ int mke_sim_sample(const float* emb, int ld, int kpad, int64_t n_rows, int64_t r
 int mke_topk_candidates(const mke_candidate* cand, const int32_t* seg_count, int64_t rows, int n_seg, int seg_cap, int k,
                         const int32_t* id_map /*nullable*/, int32_t* out_idx /*nullable*/, float* out_kth /*nullable*/,
                         int32_t* status /*nullable*/, void* stream);
+/* exact top k of LONG rows (vals [rows][ld], n <= ld values each, any n): the k columns with the largest values, the first
+ * ties of the k-th value in column order, written in column order as out_idx[row][0..k) (through id_map when given).
+ * replaces: np.argpartition over a whole similarity row at code/base/batch.py:143-150 (short KGs, and the rows of the
+ * thresholded pass that have to be redone at full width) */
+int mke_topk_long(const float* vals, int64_t rows, int64_t n, int64_t ld, int k, const int32_t* id_map /*nullable*/,
+                  int32_t* out_idx /* [rows][k] */, void* stream);
 int mke_topk_rows(const float* vals, const int32_t* idx /*nullable*/, const int32_t* seg_count /*nullable*/, int64_t rows,
                   int n_seg, int seg_cap, int k, const int32_t* id_map /*nullable*/, int32_t* out_idx /*nullable*/,
                   float* out_kth /*nullable*/, int32_t* status /*nullable*/, void* stream);

@@ -33,7 +33,7 @@ SYMBOLS = (
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
-    "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
+    "mke_topk_long", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -460,6 +460,19 @@ def topk_rows(vals: torch.Tensor, k: int, idx=None, seg_count=None, id_map=None,
                              _dev(kth, torch.float32, "out_kth"), _dev(status, torch.int32, "status"), _stream())
     _check(rc, "mke_topk_rows")
     return out, kth, status
+
+
+def topk_long(vals: torch.Tensor, k: int, id_map=None) -> torch.Tensor:
+    """mke_topk_long over whole rows vals [rows, n] (any n) -> int32 [rows, k], column order."""
+    if vals.dim() != 2 or vals.stride(1) != 1:
+        raise MultiKEHipError("topk_long: vals must be [rows, n] with unit column stride")
+    rows, n = vals.shape
+    out = torch.empty(rows, k, dtype=torch.int32, device=vals.device)
+    rc = lib().mke_topk_long(C.c_void_p(vals.data_ptr()) if vals.is_cuda and vals.dtype == torch.float32 else _dev(vals, torch.float32, "vals"),
+                             C.c_int64(rows), C.c_int64(n), C.c_int64(vals.stride(0) if rows > 1 else n), C.c_int(k),
+                             _dev(id_map, torch.int32, "id_map"), _dev(out, torch.int32, "out_idx"), _stream())
+    _check(rc, "mke_topk_long")
+    return out
 
 
 def mapping_scratch_floats(n: int, dim: int) -> int:

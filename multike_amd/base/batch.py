@@ -114,7 +114,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
     the k-th largest value is estimated from a fixed column sample (`mke_sim_sample` + `mke_topk_rows`),
     `mke_sim_select` computes the similarities tile by tile on the matrix cores and keeps only the ~1.4 k columns above
     the threshold, `mke_topk_rows` takes the exact top k of that short list.  The few rows whose estimate came out too
-    tight (fewer than k hits) or too loose (a segment overflowed) are redone at full width (library GEMM + torch.topk,
+    tight (fewer than k hits) or too loose (a segment overflowed) are redone at full width (`mke_sim_sample` + `mke_topk_long`,
     which is also the path of short rows).  The result is the exact top-k set.
 
     part = (r, G): compute only the r-th of G contiguous slices of the rows (in the function's own working order) — the
@@ -142,7 +142,7 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         cols = ep if ep is not None else _padded(e)
         src = cols[rows].contiguous()
         sim = _lib.sim_sample(src, kpad, 0, int(src.shape[0]), cols)
-        return torch.topk(sim, k, dim=1, sorted=False).indices
+        return _lib.topk_long(sim, k).long()          # exact top k of whole rows: radix select in the package's own kernel
 
     def _padded(x):
         out = torch.zeros(x.shape[0], kpad, dtype=torch.float32, device=device)

@@ -303,6 +303,86 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_topk_rows(const TopkParams p) {
   }
 }
 
+
+// Exact top k of LONG rows (whole similarity rows: a short KG, or a row of the main pass whose threshold estimate was off —
+// up to n = 100K+ values, far beyond the 4096 keys k_topk_rows holds in LDS).  One block per row; the row stays in global
+// memory (L2) and is streamed five times: four byte-wise radix-select passes (private histogram per wavefront, the 256
+// threads scan the bins from the top) fix the k-th largest key and how many of its ties belong to the top k, a fifth pass
+// compacts the columns above it plus the first ties in COLUMN order (block scan per 256-column chunk) — the output is a
+// deterministic function of the row.  Replaces torch.topk (a library call: its first use in a run cost a 170 ms
+// compilation / initialisation on a fresh box).
+struct TopkLongParams {
+  const float* __restrict__ vals;   // [rows][ld]
+  int64_t ld;
+  int n, k;
+  const int32_t* __restrict__ id_map;  // nullable
+  int32_t* __restrict__ out_idx;       // [rows][k], column order
+};
+
+__global__ __launch_bounds__(MKE_BLOCK) void k_topk_long(const TopkLongParams p) {
+  static_assert(MKE_BLOCK == 256, "one histogram bin per thread");
+  __shared__ int s_hist[MKE_BLOCK / 64][256];
+  __shared__ int s_wave[MKE_BLOCK / 64];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* __restrict__ v = p.vals + (int64_t)blockIdx.x * p.ld;
+  if (tid == 0) { s_prefix = 0u; s_need = p.k; }
+  __syncthreads();
+  for (int hi = 32; hi > 0; hi -= 8) {
+    const int shift = hi - 8;
+#pragma unroll
+    for (int q = 0; q < MKE_BLOCK / 64; ++q) s_hist[q][tid] = 0;
+    __syncthreads();
+    const unsigned pre = s_prefix;
+    const int need = s_need;
+    for (int i = tid; i < p.n; i += MKE_BLOCK) {
+      const unsigned kx = float_key(v[i]);
+      if (hi >= 32 || (kx >> hi) == (pre >> hi)) atomicAdd(&s_hist[wv][(kx >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    const int dgt = 255 - tid;                       // thread t owns digit 255 - t: inclusive scan from the largest digit down
+    const int h = s_hist[0][dgt] + s_hist[1][dgt] + s_hist[2][dgt] + s_hist[3][dgt];
+    int incl = h;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    for (int q = 0; q < wv; ++q) incl += s_wave[q];
+    if (incl >= need && incl - h < need) {           // exactly one thread: the digit where the count from the top reaches `need`
+      s_prefix = pre | ((unsigned)dgt << shift);
+      s_need = need - (incl - h);
+    }
+    __syncthreads();
+  }
+  const unsigned kth = s_prefix;
+  const int ties = s_need;                           // how many of the keys equal to kth belong to the top k
+  int32_t* __restrict__ o = p.out_idx + (int64_t)blockIdx.x * p.k;
+  int gt_run = 0, eq_run = 0;                        // block-uniform running counts of the chunks before this one
+  for (int base = 0; base < p.n; base += MKE_BLOCK) {
+    const int i = base + tid;
+    const unsigned kx = i < p.n ? float_key(v[i]) : 0u;
+    const bool is_gt = i < p.n && kx > kth, is_eq = i < p.n && kx == kth;
+    const uint64_t mg = __ballot(is_gt), me = __ballot(is_eq);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if (lane == 0) s_wave[wv] = __popcll(mg) | (__popcll(me) << 16);
+    __syncthreads();
+    int gt = gt_run + __popcll(mg & lt), eq = eq_run + __popcll(me & lt), tot = 0;
+    for (int q = 0; q < MKE_BLOCK / 64; ++q) {
+      const int c = s_wave[q];
+      if (q < wv) { gt += c & 0xFFFF; eq += c >> 16; }
+      tot += c;                                      // packed sums: <= 256 per half, no carry between the halves
+    }
+    if (is_gt || (is_eq && eq < ties)) o[gt + min(eq, ties)] = p.id_map ? p.id_map[i] : i;
+    gt_run += tot & 0xFFFF;
+    eq_run += tot >> 16;
+    __syncthreads();
+  }
+}
+
 }  // namespace mke
 
 extern "C" int mke_sim_select(const float* emb, int ld, int kpad, int64_t n_cols, int64_t row_lo, int64_t row_hi, const float* tau,
@@ -399,4 +479,16 @@ extern "C" int mke_topk_candidates(const mke_candidate* cand, const int32_t* seg
                                    const int32_t* id_map, int32_t* out_idx, float* out_kth, int32_t* status, void* stream) {
   return topk_launch(cand, nullptr, nullptr, seg_count, rows, n_seg, seg_cap, k, id_map, out_idx, out_kth, status, stream,
                      "mke_topk_candidates");
+}
+
+extern "C" int mke_topk_long(const float* vals, int64_t rows, int64_t n, int64_t ld, int k, const int32_t* id_map, int32_t* out_idx,
+                             void* stream) {
+  using namespace mke;
+  if (rows < 0 || rows > 0x7FFFFFFFLL || n < 1 || n > 0x7FFFFF00LL || ld < n || k < 1 || k > n) { set_error("mke_topk_long: need rows >= 0, 1 <= k <= n <= ld"); return MKE_E_SHAPE; }
+  if (rows == 0) return MKE_OK;
+  if (!vals || !out_idx) { set_error("mke_topk_long: NULL pointer"); return MKE_E_NULL; }
+  TopkLongParams p;
+  p.vals = vals; p.ld = ld; p.n = (int)n; p.k = k; p.id_map = id_map; p.out_idx = out_idx;
+  hipLaunchKernelGGL(k_topk_long, dim3((unsigned)rows), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+  return check_launch("k_topk_long");
 }

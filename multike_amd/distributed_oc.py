@@ -510,7 +510,9 @@ class OwnerComputesTrainer:
         plan = {"bs": bs}
         codes = self._persist(("codes", bs), torch.zeros(0, **i32), max(1, n_all * N))
         if n_all and N:
-            neg = tuple(torch.empty(n_all * N, **i32) for _ in range(3))
+            # scratch of the sampler's (h, r, t) output: kept across epochs (2.4 GB per column at the C5 shape — a fresh
+            # allocation per epoch was tens of ms of hipMalloc inside the plan)
+            neg = tuple(self._persist(("neg", k_), torch.zeros(0, **i32), n_all * N)[:n_all * N] for k_ in range(3))
             self.backend.sample_at((ph[:n_all], pr[:n_all], pt[:n_all]), self._all_idx, b.pos_kg[:n_all], b.side1, b.side2, N,
                                    b.rng_seed, rng_stream, neg)
             self.backend.pack_codes(ph[:n_all], neg[0], neg[2], N, codes[:n_all * N])

@@ -79,6 +79,27 @@ def test_neighbour_table_of_320_float_rows():
     assert np.mean(got == exp) > 0.995 and int(valid.sum()) == n
 
 
+@pytest.mark.parametrize("rows,n,k", [(3, 70_000, 2000), (40, 5000, 1), (7, 4097, 4097), (5, 300, 17), (2, 100_003, 64)])
+def test_topk_long_is_the_exact_top_k_in_column_order(rows, n, k):
+    """mke_topk_long (whole similarity rows, any length): the k largest columns, the k-th value's ties taken in column order,
+    written in column order — against a stable float64 sort; rows with heavy ties and with negative / zero values."""
+    from multike_amd import _lib
+    rng = np.random.default_rng(rows * 1000 + k)
+    v = rng.standard_normal((rows, n)).astype(np.float32)
+    v[0] = np.round(v[0], 1)                       # many exact ties around the threshold
+    if rows > 1:
+        v[1] = 0.0                                 # every column ties: the first k columns win
+    out = _lib.topk_long(torch.as_tensor(v, device="cuda"), k).cpu().numpy()
+    for r in range(rows):
+        order = np.argsort(-v[r].astype(np.float64), kind="stable")[:k]      # largest first, ties by column
+        assert np.array_equal(out[r], np.sort(order)), r
+    # a strided view (rows of a wider matrix) and the id map
+    wide = torch.as_tensor(np.concatenate([v, v], 1), device="cuda")
+    ids = torch.arange(n, dtype=torch.int32, device="cuda") * 3 + 1
+    out2 = _lib.topk_long(wide[:, :n], k, id_map=ids).cpu().numpy()
+    assert np.array_equal(out2, out * 3 + 1)
+
+
 def test_ties_are_ranked_at_mid_rank():
     """The reference's argsort leaves the gold at an arbitrary place among the columns that tie with it; the evaluator
     reports the mid-rank: a zero row (similarity 0 to every column) lands in the middle, not at Hits@1; a duplicated gold

@@ -54,7 +54,7 @@ def _np(v):
     return v
 
 
-def _run(method, data_kw=None, args_kw=None):
+def _run(method, data_kw=None, args_kw=None, snapshots=None):
     from multike_amd.MultiKE_CSL import MultiKE_CV
     from multike_amd.MultiKE_Late import MultiKE_Late
     from multike_amd.synthetic import synthetic_args
@@ -75,7 +75,17 @@ def _run(method, data_kw=None, args_kw=None):
                            cv_name_weight=args.cv_name_weight, cv_weight=args.cv_weight, orthogonal_weight=args.orthogonal_weight)
     oracle.M0 = None if maps is None else [np.array(m, dtype=np.float64) for m in maps]
     recs, losses = [], []
-    model._recorder = lambda phase, **kw: recs.append((phase, {k: _np(v) for k, v in kw.items()}))
+    def record(phase, **kw):
+        recs.append((phase, {k: _np(v) for k, v in kw.items()}))
+        if snapshots is not None:          # the trainable tables right after the phase (tools/parity_noise.py)
+            torch.cuda.synchronize()
+            snap = {k: raw(t) for k, t in (("rv_ent", model.rv_ent_embeds), ("av_ent", model.av_ent_embeds),
+                                           ("ent", model.ent_embeds), ("rel", model.rel_embeds), ("attr", model.attr_embeds))}
+            for k, t in (("rv_ent", model.rv_ent_embeds), ("av_ent", model.av_ent_embeds), ("ent", model.ent_embeds)):
+                if "cross_name" in t.slots:
+                    snap["acc_cross_name_" + k] = t.slots["cross_name"][:, :t.dim].cpu().numpy()
+            snapshots.append(snap)
+    model._recorder = record
     for name, phase in PHASE_OF.items():
         orig = getattr(model, name)
         setattr(model, name, (lambda f, ph: lambda *a, **k: losses.append((ph, a[0], f(*a, **k))) or losses[-1][2])(orig, phase))

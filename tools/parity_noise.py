@@ -17,15 +17,70 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def replay(oracle, recs, track):
-    """phase by phase; after every phase the smallest row norm seen so far of every trainable table"""
+def replay(oracle, recs, track, snapshots=None, label=""):
+    """phase by phase; after every phase the smallest row norm seen so far of every trainable table, and (snapshots = the HIP
+    tables after each phase) where the two implementations part: the worst element error after each phase"""
     mins = {k: np.full(oracle.t[k].shape[0], np.inf) for k in track}
     losses = []
-    for phase, rec in recs:
+    epoch_of = {}
+    prev_worst = 0.0
+    for n, (phase, rec) in enumerate(recs):
+        before = None
+        if snapshots is not None and phase == "common":
+            import copy
+            before = (copy.deepcopy(oracle.t), copy.deepcopy(oracle.acc))
         losses.append(oracle.replay(phase, rec))
         for k in track:
             mins[k] = np.minimum(mins[k], np.linalg.norm(oracle.t[k].astype(np.float64), axis=1))
+        if snapshots is not None:
+            epoch_of[phase] = epoch_of.get(phase, 0) + 1
+            errs = {k: np.abs(snapshots[n][k].astype(np.float64) - oracle.t[k]) for k in track}
+            worst = max(track, key=lambda k: errs[k].max())
+            r = int(errs[worst].max(1).argmax())
+            print(f"    {label} after {phase:10s} #{epoch_of[phase]:2d}: " + "  ".join(f"{k} {errs[k].max():.1e}" for k in track)
+                  + f"   worst: {worst} row {r}")
+            now = max(e.max() for e in errs.values())
+            if before is not None and now > 10 * max(prev_worst, 1e-7):
+                explain_common(oracle, before, rec, r)
+                for k in ("ent", "rv_ent", "av_ent"):      # the error vector of that row: along the row (immaterial to the
+                    w64 = oracle.t[k][r]                   # normalised view every lookup reads) or across it?
+                    e = snapshots[n][k][r].astype(np.float64) - w64
+                    what = w64 / np.linalg.norm(w64)
+                    rad = float(e @ what)
+                    tan = float(np.linalg.norm(e - rad * what))
+                    line = f"        {k} row {r}: |err| {np.linalg.norm(e):.2e} = radial {rad:+.2e} / tangential {tan:.2e}"
+                    ak = "acc_cross_name_" + k
+                    if ak in snapshots[n]:
+                        a64 = oracle.acc[("cross_name", k)][r]
+                        ea = snapshots[n][ak][r].astype(np.float64) - a64
+                        line += f";  Adagrad slot: max |err| {np.abs(ea).max():.2e} (slot values {a64.min():.3f} .. {a64.max():.3f})"
+                    print(line)
+                    print("          err:", np.array2string(e, precision=1, max_line_width=200))
+                    print("          w  :", np.array2string(w64, precision=3, max_line_width=200))
+            prev_worst = now
     return losses, mins
+
+
+def explain_common(oracle, before, rec, row):
+    """The common-space phase after which the error jumped: replay it step by step from the state before it and print, for the
+    row that came out worst, what the step saw — the raw rows' norms (the Jacobian of the normalised view divides by them)."""
+    import copy
+    from oracle import multike_oracle as mo
+    t, acc = copy.deepcopy(before[0]), copy.deepcopy(before[1])
+    idx, off = rec["idx"], rec["off"]
+    for s_ in range(len(off) - 1):
+        ids = np.asarray(idx[int(off[s_]):int(off[s_ + 1])], dtype=np.int64)
+        hit = int(np.sum(ids == row))
+        nb = {k: float(np.linalg.norm(t[k][row])) for k in ("ent", "rv_ent", "av_ent")}
+        old = {k: t[k][row].copy() for k in ("ent", "rv_ent", "av_ent")}
+        mo.common_space_step_dense(t["ent"], t["name"], t["rv_ent"], t["av_ent"], acc[("cross_name", "ent")], acc[("cross_name", "rv_ent")],
+                                   acc[("cross_name", "av_ent")], ids, oracle.itc_lr, oracle.cv_name_weight, oracle.cv_weight)
+        if hit:
+            print(f"        step {s_}: row {row} sampled {hit}x; ||w|| before the step: " + "  ".join(f"{k} {v:.3e}" for k, v in nb.items())
+                  + ";  after: " + "  ".join(f"{k} {np.linalg.norm(t[k][row]):.3e}" for k in nb)
+                  + ";  |step|: " + "  ".join(f"{k} {np.linalg.norm(t[k][row] - old[k]):.3e}" for k in nb))
+    small = {k: int(np.sum(np.linalg.norm(before[0][k], axis=1) < 1e-2)) for k in ("ent", "rv_ent", "av_ent")}
+    print(f"        rows with ||w|| < 1e-2 before this phase: {small}")
 
 
 def main():
@@ -38,7 +93,8 @@ def main():
     for mode in ("atomic", "deterministic"):
         _lib.set_option("deterministic", 1 if mode == "deterministic" else 0)
         try:
-            model, oracle, recs, losses, results, data, args = T._run(method)
+            snaps = []
+            model, oracle, recs, losses, results, data, args = T._run(method, snapshots=snaps)
         finally:
             _lib.set_option("deterministic", 0)
         o32 = OracleMultiKE({k: v for k, v in oracle.t.items()}, oracle.cnn, oracle.M0, learning_rate=args.learning_rate,
@@ -51,7 +107,7 @@ def main():
         for a in (last["pos"][0], last["pos"][2], last["neg"][0], last["neg"][2]):
             deg += np.bincount(np.asarray(a), minlength=len(deg))
         deg /= max(1, len(last["off"]) - 1)
-        l64, mins = replay(oracle, recs, track)
+        l64, mins = replay(oracle, recs, track, snaps if os.environ.get("MKE_NOISE_TRACE") else None, "HIP vs f64")
         l32, _ = replay(o32, recs, track)
         worst = max(abs(g - e) / abs(e) for (_, _, g), e in zip(losses, l64))
         worst32 = max(abs(float(g) - e) / abs(e) for g, e in zip(l32, l64))

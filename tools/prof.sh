@@ -26,6 +26,8 @@ try:
     d = json.loads(sys.stdin.read())
 except Exception:
     sys.exit(0)
+if not isinstance(d, dict) or "value" not in d:
+    print("```json"); print(json.dumps(d, indent=1)); print("```"); sys.exit(0)
 r = d.get("roofline") or {}
 keep = {k: d[k] for k in ("value", "ms_per_step", "steps", "warmup") if k in d}
 keep["workload"] = d.get("config", {}).get("workload")
