@@ -9,6 +9,7 @@ class MultiKE_CV(_ScheduledMultiKE):
     def __init__(self, data, args, predicate_align_model):
         super().__init__(data, args, predicate_align_model)
         self.flag1, self.flag2, self.early_stop = -1, -1, False
+        self.defer_predicate_update = True       # the soft predicate-alignment refresh's host work under the next epoch's kernels
         self._define_variables()
         self._define_name_view_graph()
         self._define_relation_view_graph()
@@ -37,5 +38,9 @@ class MultiKE_CV(_ScheduledMultiKE):
             if i >= a.start_predicate_soft_alignment and i % 10 == 0:
                 self._update_predicate_alignment()
             self._refresh_neighbours(i)
+        self._finish_predicate_update()
+        self._save_async = True
         self.save()
-        return {k: self._test(k) for k in ('nv', 'rv', 'av', 'final')}
+        results = {k: self._test(k) for k in ('nv', 'rv', 'av', 'final')}
+        self._join_save()
+        return results

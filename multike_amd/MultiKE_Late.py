@@ -153,6 +153,8 @@ class _ScheduledMultiKE(MultiKE):
     def _test_WVA(self):
         return test_WVA(self)
 
+    defer_predicate_update = False      # set True by the model's constructor on a GPU (instances made without it run in line)
+
     def _prepare(self):
         kgs, pam, a = self.kgs, self.predicate_align_model, self.args
         rel_n = kgs.kg1.local_relation_triples_num + kgs.kg2.local_relation_triples_num
@@ -185,21 +187,28 @@ class _ScheduledMultiKE(MultiKE):
         n1, n2 = self._neighbors
         soft = i > a.start_predicate_soft_alignment
 
-        def relation_group():
+        def relation_group_a():
             self.train_relation_view_1epo(i, self._rel_steps, self._rel_tasks, None, n1, n2)
             self.train_cross_kg_entity_inference_relation_view_1epo(i, self._ckge_rel_triples)
+
+        def relation_group_b():
             if soft:
                 self.train_cross_kg_relation_inference_1epo(i, self._ckgp_rel_triples)
 
-        def attribute_group():
+        def attribute_group_a():
             self.train_attribute_view_1epo(i, self._attr_steps, self._attr_tasks, None, n1, n2)
             self.train_cross_kg_entity_inference_attribute_view_1epo(i, self._ckge_attr_triples)
+
+        def attribute_group_b():
             if soft:
                 self.train_cross_kg_attribute_inference_1epo(i, self._ckga_attr_triples)
 
         if not getattr(self, "overlap_views", True) or a.optimizer not in ("Adagrad", "SGD"):
-            relation_group()
-            attribute_group()
+            relation_group_a()
+            self._finish_predicate_update()
+            relation_group_b()
+            attribute_group_a()
+            attribute_group_b()
             return
         import torch
         main = torch.cuda.current_stream()
@@ -211,13 +220,23 @@ class _ScheduledMultiKE(MultiKE):
             # the longer chain (attribute group, 12.7 ms of 7-launch steps at the C2 shape) is enqueued first, on the side
             # stream: 18.0 ms per epoch against 18.8 the other way round and 22.0 on one stream.  Measured and not kept:
             # a higher stream priority for either group (no change), enqueueing the two groups from two host threads
-            # (18.9 ms: the device, not the host, is what the two chains share)
+            # (18.9 ms: the device, not the host, is what the two chains share).
+            # Round 4: the phases that do not read the soft predicate-alignment lists (the two views, the two entity-inference
+            # loops) are enqueued FIRST on both streams; a predicate refresh deferred from the end of the previous epoch
+            # (`_update_predicate_alignment`: 15-30 ms of host work every ten epochs) then runs on the host while the device
+            # works through them, and the two list-reading loops follow.
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                attribute_group()
-            late, self._pending = self._pending, []
-            relation_group()
-            self._pending += late       # the reference prints the relation group's losses first
+                attribute_group_a()
+            attr_a, self._pending = self._pending, []
+            relation_group_a()
+            rel_a, self._pending = self._pending, []
+            self._finish_predicate_update()
+            with torch.cuda.stream(side):
+                attribute_group_b()
+            attr_b, self._pending = self._pending, []
+            relation_group_b()
+            self._pending = rel_a + self._pending + attr_a + attr_b       # the reference prints the relation group's losses first
             main.wait_stream(side)
         finally:
             self._defer_losses = False
@@ -228,9 +247,39 @@ class _ScheduledMultiKE(MultiKE):
     def _update_predicate_alignment(self):
         """code/MultiKE_CSL.py:80-87 / code/MultiKE_Late.py:244-251 (host-side soft predicate alignment)."""
         pam = self.predicate_align_model
+        if getattr(self, "defer_predicate_update", False) and hasattr(pam, "update_predicate_alignment"):
+            # The refresh reads rel_embeds / attr_embeds as they are NOW and its lists are first read by the next epoch's
+            # relation- / attribute-inference loops.  Snapshot the two (small) tables to pinned host memory without waiting
+            # and do the host work when those loops are about to be enqueued (`_finish_predicate_update`, called by
+            # `_train_views` after the phases that do not need the lists are on the device): same inputs, same lists, and the
+            # device is not idle meanwhile.
+            import torch
+            snaps = []
+            for tab in (self.rel_embeds, self.attr_embeds):
+                dev = tab.lookup(None)
+                host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+                host.copy_(dev, non_blocking=True)
+                snaps.append((dev, host))                    # the device tensor is held until the copy has completed
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_predicate = (ev, snaps)
+            return
         if hasattr(pam, "update_predicate_alignment"):
             pam.update_predicate_alignment(self.rel_embeds.eval(session=self.session))
             pam.update_predicate_alignment(self.attr_embeds.eval(session=self.session), predicate_type='attribute')
+        self._refresh_predicate_lists()
+
+    def _finish_predicate_update(self):
+        """The host side of a deferred `_update_predicate_alignment` (no-op when none is pending)."""
+        pend = getattr(self, "_pending_predicate", None)
+        if pend is None:
+            return
+        self._pending_predicate = None
+        ev, snaps = pend
+        ev.synchronize()
+        pam = self.predicate_align_model
+        pam.update_predicate_alignment(snaps[0][1].numpy())
+        pam.update_predicate_alignment(snaps[1][1].numpy(), predicate_type='attribute')
         self._refresh_predicate_lists()
 
     def _refresh_neighbours(self, i):
@@ -266,6 +315,7 @@ class MultiKE_Late(_ScheduledMultiKE):
     def __init__(self, data, args, attr_align_model):
         super().__init__(data, args, attr_align_model)
         self.flag1, self.flag2, self.early_stop = -1, -1, False
+        self.defer_predicate_update = True       # the soft predicate-alignment refresh's host work under the next epoch's kernels
         self._define_variables()
         self._define_name_view_graph()
         self._define_relation_view_graph()
@@ -299,8 +349,11 @@ class MultiKE_Late(_ScheduledMultiKE):
             self.train_shared_space_mapping_1epo(i, self._entity_list)
             if i >= a.start_valid and i % a.eval_freq == 0:
                 self._valid('final')
+        self._finish_predicate_update()
+        self._save_async = True
         self.save()
         results = {k: self._test(k) for k in ('nv', 'rv', 'av', 'avg')}
         results['wva'] = self._test_WVA()
         results['final'] = self._test('final')
+        self._join_save()
         return results

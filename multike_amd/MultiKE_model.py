@@ -295,8 +295,22 @@ class MultiKE:
 
     def save(self):
         """code/MultiKE_model.py:279-287: same six .npy files and id TSVs."""
-        save_embeddings(self.out_folder, self.kgs, self.ent_embeds.eval(), self.name_embeds.eval(), self.rv_ent_embeds.eval(),
-                        self.av_ent_embeds.eval(), self.rel_embeds.eval(), self.attr_embeds.eval())
+        arrays = (self.ent_embeds.eval(), self.name_embeds.eval(), self.rv_ent_embeds.eval(), self.av_ent_embeds.eval(),
+                  self.rel_embeds.eval(), self.attr_embeds.eval())
+        if getattr(self, "_save_async", False):
+            # the drivers' closing save: the ~250 MB of .npy files are written by a host thread while the closing tests rank on
+            # the device (the arrays are host copies already); `_join_save` at the end of run() waits for the files
+            import threading
+            self._save_thread = threading.Thread(target=save_embeddings, args=(self.out_folder, self.kgs) + arrays)
+            self._save_thread.start()
+            return
+        save_embeddings(self.out_folder, self.kgs, *arrays)
+
+    def _join_save(self):
+        th = getattr(self, "_save_thread", None)
+        if th is not None:
+            th.join()
+            self._save_thread = None
 
     # --- helpers ----------------------------------------------------------------------------------------------
     _CACHE_MAX = 24

@@ -159,16 +159,25 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         valid[ids[p_lo:p_hi]] = 1
         return (table, valid) if part is None else (table, valid, ids[p_lo:p_hi])
 
-    g = torch.Generator(device=device)     # on the device: a CPU permutation of 100K ids is 9 ms the GPU waits for
-    g.manual_seed(12345)
+    # The working order and the column sample are keyed permutations computed on the device with INTEGER arithmetic only
+    # (argsort of splitmix64(i + seed)): a function of (n, seed) alone, identical on every rank, device architecture and torch
+    # build.  Round 3 drew them from a device torch.Generator — fast (a CPU permutation of 100K ids is 9 ms the GPU waits for),
+    # but in part mode the slices of the multi-GPU refresh are DEFINED in this order, and a generator stream that differed
+    # between ranks would silently leave candidate rows unfilled.
+    def keyed_perm(seed):
+        x = torch.arange(n, dtype=torch.int64, device=device) + seed
+        x = (x ^ (x >> 30)) * -4658895280553007687        # 0xBF58476D1CE4E5B9 as int64 (wrap-around multiply)
+        x = (x ^ (x >> 27)) * -7723592293110705685        # 0x94D049BB133111EB
+        x = x ^ (x >> 31)
+        return torch.argsort(x, stable=True)
     # Work in a fixed random order of the entities: a row's hits are then spread evenly over the column segments whatever
     # the order of the ids (in id order similar entities sit together — URIs of one namespace, one generator block — and
     # most rows overflowed one of their segments on the DBP-WD-like folder: 54-75 % of the rows went to the full-width path).
-    perm = torch.randperm(n, generator=g, device=device)
+    perm = keyed_perm(0x3C6EF372)
     e, ids = e[perm], ids[perm]
     ep = _padded(e)
     ids32 = ids.to(torch.int32)
-    samp = torch.randperm(n, generator=g, device=device)[:n_samp]
+    samp = keyed_perm(0x1B873593)[:n_samp]
     es = ep[samp].contiguous()
     m = min(n_samp, int(math.ceil(1.4 * k * n_samp / n)) + 8)
     chunk = (1 << 29) // cap - 128                        # rows per launch: 2^29 candidate slots (8 bytes each) at most

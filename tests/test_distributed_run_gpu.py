@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DIM = 24
 
 
-def _setup():
+def _setup(itc_lr=0.05):
     from multike_amd.synthetic import SyntheticData, synthetic_args
     data = SyntheticData(n_ent=1600, n_rel=20, n_attr=16, n_values=300, dim=DIM, seed=13, shared_structure=0.8)
     n1 = data.kgs.entities_num // 2
@@ -24,15 +24,15 @@ def _setup():
     nm = np.concatenate([base, base + 0.8 * rng.standard_normal((n1, DIM)).astype(np.float32)])
     data.local_name_vectors = nm / np.linalg.norm(nm, axis=1, keepdims=True)
     args = synthetic_args(dim=DIM, batch_size=801, attribute_batch_size=601, entity_batch_size=499, neg_triple_num=6,
-                          learning_rate=0.03, ITC_learning_rate=0.05, max_epoch=6, shared_learning_max_epoch=3, start_valid=2,
+                          learning_rate=0.03, ITC_learning_rate=itc_lr, max_epoch=6, shared_learning_max_epoch=3, start_valid=2,
                           eval_freq=2, start_predicate_soft_alignment=2, truncated_freq=2, truncated_epsilon=0.9,
                           neg_sampling="truncated", seed=3, output="/tmp/multike_out_sharded/")
     return data, args
 
 
-def _run(method, rank, world, comm_oc=None, comm_v=None):
+def _run(method, rank, world, comm_oc=None, comm_v=None, itc_lr=0.05):
     from multike_amd.distributed_run import ShardedMultiKE_CV, ShardedMultiKE_Late
-    data, args = _setup()
+    data, args = _setup(itc_lr)
     cls = ShardedMultiKE_CV if method == "ITC" else ShardedMultiKE_Late
     model = cls(data, args, data.predicate_align_model, rank, world, comm_oc, comm_v)
     out = io.StringIO()
@@ -64,7 +64,7 @@ def test_one_rank_runs_the_whole_schedule(method):
     np.testing.assert_allclose(res["rv"], mrr, rtol=1e-6)
 
 
-def _worker(rank, world, port, ret, method):
+def _worker(rank, world, port, ret, method, itc_lr):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
@@ -72,7 +72,7 @@ def _worker(rank, world, port, ret, method):
         from multike_amd.distributed_oc import OcHostStagedComm
         from multike_amd.distributed_views import HostStagedViewComm
         torch.cuda.set_device(0)
-        model, res, log = _run(method, rank, world, OcHostStagedComm(), HostStagedViewComm())
+        model, res, log = _run(method, rank, world, OcHostStagedComm(), HostStagedViewComm(), itc_lr)
         tables = model.m.gather()
         if rank == 0:
             ret.put((res, {k: np.asarray(tables[k]) for k in ("ent", "rv", "av", "rel", "attr")}, log))
@@ -81,18 +81,25 @@ def _worker(rank, world, port, ret, method):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("method", ["ITC", "SSL"])
-def test_two_ranks_equal_one_rank(method):
+@pytest.mark.parametrize("method,itc_lr,elementwise", [("SSL", 0.05, True), ("ITC", 0.004, True), ("ITC", 0.05, False)])
+def test_two_ranks_equal_one_rank(method, itc_lr, elementwise):
     """Sharding changes nothing but the order of fp32 sums: same batches (every draw is a function of (seed, epoch)), same
-    candidate tables from the sharded k-NN refresh, same metrics from the sharded evaluator."""
+    candidate tables from the sharded k-NN refresh, same metrics from the sharded evaluator.
+
+    Elementwise (tighter than rounds 2-3: max 2e-3 against 2e-2, mean 5e-5 against 2e-4) wherever the schedule does not itself amplify rounding noise:
+    the SSL schedule, and the ITC schedule at the reference's own ITC_learning_rate (code/args.json: 0.004).  At this file's
+    aggressive 0.05 the early common-space Adagrad steps expand a perturbation by up to x1000 per phase on a handful of
+    (row, element) pairs (tests/test_schedule_trace_gpu.py has the derivation and the float64 finite-difference evidence is in
+    profiles/r04_parity_noise.log) — two fp32 runs that differ in summation order then differ there by construction, so that
+    variant asserts the statistics (mean error, metrics), not a maximum."""
     import tempfile
     import torch.multiprocessing as mp
-    m1, r1, _ = _run(method, 0, 1)
+    m1, r1, _ = _run(method, 0, 1, itc_lr=itc_lr)
     ref = m1.m.gather()
     port = tempfile.mktemp(prefix="mke_rdv_")
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, method)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, method, itc_lr)) for r in range(2)]
     for p in procs:
         p.start()
     r2, got, log = ret.get(timeout=800)
@@ -100,11 +107,15 @@ def test_two_ranks_equal_one_rank(method):
         p.join(120)
         assert p.exitcode == 0
     for k in r1:
-        assert abs(r2[k] - r1[k]) <= 1e-2, (k, r2[k], r1[k])      # MRR over ~500 test pairs: a few fp32-order rank flips are 1e-3 each
+        assert abs(r2[k] - r1[k]) <= (2e-3 if elementwise else 1e-2), (k, r2[k], r1[k])   # MRR over ~500 test pairs
     for k in ("ent", "rv", "av", "rel", "attr"):
         err = np.abs(got[k] - np.asarray(ref[k]))
-        # fp32 atomic-order noise through the epochs; a near-zero-norm row amplifies it through the Jacobian (one element in 40K)
-        assert float(np.mean(err)) < 2e-4 and float(err.max()) < 1e-1, (k, float(np.mean(err)), float(err.max()))
+        if elementwise:
+            # measured (profiles/r04_pytest_gpu.log run): rel (20 hub rows, thousands of fp32 terms each per step) mean 2.7e-5 / max
+            # 5.3e-4; the entity tables a decade below
+            assert float(np.mean(err)) < 5e-5 and float(err.max()) < 2e-3, (k, float(np.mean(err)), float(err.max()))
+        else:
+            assert float(np.mean(err)) < 2e-4 and float(np.quantile(err, 0.999)) < 2e-3, (k, float(np.mean(err)), float(err.max()))
     assert "generating neighbors" in log
 
 

@@ -112,9 +112,15 @@ def test_whole_schedule_tracks_the_float64_oracle(method):
     # the truncated-sampling refresh happened (after epoch 3) and later epochs drew their negatives from the k-NN lists
     assert model._neighbors[0] is not None
     # ---- replay on the float64 oracle, phase by phase -------------------------------------------------------------
+    # ... and on the SAME oracle in float32 (NumPy's summation order): what another correct fp32 implementation of this
+    # schedule looks like next to the float64 truth — the yardstick of the final-state check below
+    o32 = OracleMultiKE(dict(oracle.t), oracle.cnn, oracle.M0, learning_rate=args.learning_rate, itc_learning_rate=args.ITC_learning_rate,
+                        cv_name_weight=args.cv_name_weight, cv_weight=args.cv_weight, orthogonal_weight=args.orthogonal_weight,
+                        dtype=np.float32)
     worst = 0.0
     for (phase, rec), (p2, epoch, got) in zip(recs, losses):
         exp = oracle.replay(phase, rec)
+        o32.replay(phase, rec)
         assert np.isfinite(got) and got > 0.0, (phase, epoch, got)
         err = abs(got - exp) / abs(exp)
         worst = max(worst, err)
@@ -122,14 +128,33 @@ def test_whole_schedule_tracks_the_float64_oracle(method):
     # ---- final state -------------------------------------------------------------------------------------------------
     pairs = {"rv_ent": model.rv_ent_embeds, "av_ent": model.av_ent_embeds, "ent": model.ent_embeds, "rel": model.rel_embeds,
              "attr": model.attr_embeds}
+    # Round 3 widened this check (rtol 2e-3, 5e-4 of the elements outside) and blamed near-zero-norm rows.  Round 4 looked
+    # (tools/parity_noise.py, profiles/r04_parity_noise.log): the offending rows have ordinary norms (0.25 .. 0.45).  What
+    # happens is that early Adagrad steps of the common-space phase EXPAND perturbations: for a row read through l2_normalize
+    # d w_new / d w_old = 1 - lr W / ||w||^2 * acc / (acc + g^2)^1.5 per element, and with this schedule's ITC_learning_rate
+    # 0.05, summed loss weight W = 8.4, ||w||^2 = 0.07 and a young accumulator (0.1) that is up to -18 where an element's
+    # gradient is near zero.  float64 finite differences (a 1e-9 nudge of one element, the phase replayed) put the
+    # amplification of ONE common-space phase at x139 on the worst (row, element) and at x1.00 in the median (90th percentile
+    # x1.7).  ANY fp32 implementation inherits it: the float32 run of the oracle itself is off by 3e-5 on exactly those rows
+    # (2e-7 elsewhere), and the HIP tables' error there is a constant ~16x the float32 oracle's on every such row — the ratio
+    # of the two implementations' rounding noise (hardware exp / rcp / rsqrt, atomic order) carried through the same
+    # linearised dynamics.  So: (1) every element is inside the ORIGINAL band (rtol 1e-3, atol 2e-5) widened per row by 40 x
+    # what NumPy's float32 makes of that row; (2) rows with an element outside the plain original band are < 1 % of the rows
+    # and every one of them is a row where float32 itself leaves its noise floor (> 2e-6); (3) the absolute cap is 2e-3
+    # (5e-3 before).
     for k, tab in pairs.items():
         got = tab.raw().cpu().numpy().astype(np.float64)
         ref = oracle.t[k]
-        # fp32 atomic-order noise of every step, carried through ten epochs of Adagrad at lr 0.03 (a handful of near-zero-norm
-        # rows amplify it through the Jacobian): the bulk agrees to 2e-3 relative, no element is off by more than 5e-3 absolute
-        bad = ~np.isclose(got, ref, rtol=2e-3, atol=5e-5)
-        assert bad.mean() < 5e-4, (k, float(bad.mean()), float(np.abs(got - ref).max()))
-        assert float(np.abs(got - ref).max()) < 5e-3, (k, float(np.abs(got - ref).max()))
+        err = np.abs(got - ref)
+        row_noise = np.abs(o32.t[k].astype(np.float64) - ref).max(axis=1, keepdims=True)
+        plain = 2e-5 + 1e-3 * np.abs(ref)
+        bad = err > plain + 40.0 * row_noise
+        assert not bad.any(), (k, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist(),
+                               float((err / np.maximum(row_noise, 1e-12))[bad].max()))
+        out_rows = (err > plain).any(axis=1)
+        assert out_rows.mean() < 0.01, (k, int(out_rows.sum()))
+        assert (row_noise[out_rows, 0] > 2e-6).all(), (k, np.flatnonzero(out_rows)[:8].tolist(), row_noise[out_rows, 0][:8].tolist())
+        assert float(err.max()) < 2e-3, (k, float(err.max()))
     for c, P in zip((model._attr_cnn, model._ckge_attr_cnn, model._ckga_attr_cnn), oracle.cnn):
         for name, got in c.numpy_params().items():
             np.testing.assert_allclose(got, P[name], rtol=5e-3, atol=5e-4, err_msg=name)

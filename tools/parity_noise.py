@@ -81,6 +81,32 @@ def explain_common(oracle, before, rec, row):
                   + ";  |step|: " + "  ".join(f"{k} {np.linalg.norm(t[k][row] - old[k]):.3e}" for k in nb))
     small = {k: int(np.sum(np.linalg.norm(before[0][k], axis=1) < 1e-2)) for k in ("ent", "rv_ent", "av_ent")}
     print(f"        rows with ||w|| < 1e-2 before this phase: {small}")
+    # How much does this phase AMPLIFY a perturbation of its input?  float64 finite differences: nudge one element of the row by
+    # 1e-9 before the phase, replay the phase, look at the same row afterwards.  (An Adagrad step on a row read through
+    # l2_normalize has d w_new / d w_old = 1 - lr * W / ||w||^2 * acc / (acc + g^2)^1.5 per element, W = the summed loss
+    # weights: with a small accumulator and a near-zero gradient element that is lr W / (||w||^2 sqrt(acc)) >> 1.)
+    def run_phase(state):
+        t2, a2 = copy.deepcopy(state[0]), copy.deepcopy(state[1])
+        for s_ in range(len(off) - 1):
+            ids = np.asarray(idx[int(off[s_]):int(off[s_ + 1])], dtype=np.int64)
+            mo.common_space_step_dense(t2["ent"], t2["name"], t2["rv_ent"], t2["av_ent"], a2[("cross_name", "ent")], a2[("cross_name", "rv_ent")],
+                                       a2[("cross_name", "av_ent")], ids, oracle.itc_lr, oracle.cv_name_weight, oracle.cv_weight)
+        return t2
+    base = run_phase(before)
+    rng = np.random.default_rng(0)
+    others = [int(x) for x in rng.choice(before[0]["ent"].shape[0], 200, replace=False)]
+    amps = {}
+    for r_ in [row] + others:
+        worst = 0.0
+        for j_ in range(before[0]["ent"].shape[1]) if r_ == row else (int(rng.integers(before[0]["ent"].shape[1])),):
+            st = (copy.deepcopy(before[0]), before[1])
+            st[0]["ent"][r_, j_] += 1e-9
+            out = run_phase(st)
+            worst = max(worst, max(float(np.abs(out[k][r_] - base[k][r_]).max()) for k in ("ent", "rv_ent", "av_ent")) / 1e-9)
+        amps[r_] = worst
+    rest = np.array([amps[r_] for r_ in others])
+    print(f"        float64 amplification of a 1e-9 nudge of one ent element over this phase: row {row} (worst element) x{amps[row]:.0f}; "
+          f"200 random rows (one random element each): median x{np.median(rest):.2f}, 90th percentile x{np.quantile(rest, 0.9):.1f}, max x{rest.max():.0f}")
 
 
 def main():
