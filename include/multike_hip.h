@@ -59,6 +59,11 @@ const char* mke_last_error(void);
 /* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
  *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
  *   "update_chunk"  : rows per wavefront of the row-update kernels on large tables: 0 = by table size (default), 16, 64
+ *   "attr_fused_bwd" : attribute step, 64 < dim <= 80: 1 (default) = the dflat product inside the convolution-backward launch and
+ *                     the weight-gradient product on rider blocks of it (5 launches per step); 0 = the two products as their own
+ *                     launch (6 launches)
+ *   "oc_score_quarter" : mke_oc_score with a quarter-wave per positive (four positives per wavefront) instead of a wavefront:
+ *                     -1 = by shape (default: n_ranks >= 4, neg_per_pos <= 8 n_ranks, stride <= 128), 0 = never, 1 = always
  *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
  *                     kernels themselves are selected by which entry point is called)
  *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per

@@ -35,6 +35,8 @@ int g_count_in_score = 1;    // runner: the next step's reference counting rides
 int g_score_lane_ids = 1;    // training kernel: a group's ids and reference counts fetched once, one negative per lane (mke_score.hip)
 int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on large tables: 0 = by table size, 16, 64
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
+extern int g_attr_fused_bwd;     // mke_attr_cnn.hip: dflat product inside the convolution-backward launch, dW on rider blocks
+extern int g_oc_score_quarter;   // mke_oc.hip: quarter-wave per positive in the owner-computes score kernel: -1 = by shape, 0 / 1
 }
 
 extern "C" int mke_set_option(const char* name, int value, int* old_value) {
@@ -67,6 +69,26 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "update_chunk")) {
     if (old_value) *old_value = mke::g_update_chunk;
     mke::g_update_chunk = value == 16 ? 16 : (value == 64 ? 64 : 0);
+    return MKE_OK;
+  }
+  if (!strcmp(name, "oc_score_quarter")) {
+    if (old_value) *old_value = mke::g_oc_score_quarter;
+    mke::g_oc_score_quarter = value < 0 ? -1 : (value != 0);
+    return MKE_OK;
+  }
+  if (!strcmp(name, "attr_fused_bwd")) {
+    if (old_value) *old_value = mke::g_attr_fused_bwd;
+    mke::g_attr_fused_bwd = value != 0;
+    return MKE_OK;
+  }
+  if (!strcmp(name, "oc_score_quarter")) {
+    if (old_value) *old_value = mke::g_oc_score_quarter;
+    mke::g_oc_score_quarter = value < 0 ? -1 : (value != 0);
+    return MKE_OK;
+  }
+  if (!strcmp(name, "attr_fused_bwd")) {
+    if (old_value) *old_value = mke::g_attr_fused_bwd;
+    mke::g_attr_fused_bwd = value != 0;
     return MKE_OK;
   }
   if (!strcmp(name, "deterministic")) {

@@ -12,7 +12,7 @@
 // the batch-norm affine, scatters the attribute-row gradient with atomics and block-reduces the parameter gradients.
 // The batch-global normalisation needs two batch-wide sums (sum z^2, sum g.z): kernels write per-block partials
 // and the next kernel's blocks add them up themselves — no extra reduction launches, no host round trip.
-#include "mke_common.h"
+#include "mke_gemm.h"
 
 namespace mke {
 
@@ -81,6 +81,11 @@ struct ConvParams {
   const float* __restrict__ W;
   float* __restrict__ z;
   double* __restrict__ ssq;          // per-block sums of z^2 (MKE_LOSS_PARTIALS slots; the ones no block owns are cleared)
+  // bwd with the dflat product in the block (k_attr_conv<WPL, 16, true, false, 4, true>): dflat tile = 16 rows of dz x W^T; the blocks
+  // behind the first conv_blocks of the grid are riders that compute the weight-gradient product `tall` ([flat, 1]^T dz over K splits)
+  const float* __restrict__ dz;      // [n][dim] dL/dzpre
+  int conv_blocks;
+  GemmParams tall;
 };
 
 // K1[kh][kw][0][f] at k1[(kh*4+kw)*2+f]; K2[kh][kw][c][f] at k2[((kh*4+kw)*2+c)*2+f]  (TF HWIO order)
@@ -94,9 +99,16 @@ struct ConvParams {
 // NW wavefronts per block (4; the two-triples-per-wavefront backward: 2 — each convolution kernel costs the latency chain of
 // one block plus ~2 us per further 4-wavefront block on the same CU (batch-size scan in profiles/r02_attr_step.md); 5000
 // triples are 625 such blocks = three on 113 of the 256 CUs, but 1250 half blocks = at most five halves per CU)
-template <int WPL, int LPT, bool BWD, bool DENSE = false, int NW = MKE_BLOCK / 64>
-__global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
+// DFL (backward, LPT = 16, four wavefronts: the forward's shape): round 4 — the block first computes ITS 16 rows of dflat = dz W^T on
+// the matrix cores (K = dim <= 80: 20 k-steps; 4 dim <= 320 columns: five 16-column tiles per wavefront, no exchange between the
+// wavefronts) straight into the d1 strips of its 16 triples (a triple's 4 dim values fit its own strip, which the backward only
+// writes after it has taken them out), so dflat never goes to memory and the product needs no blocks of its own; the
+// weight-gradient product rides on extra blocks at the END of the grid (dispatched after the convolution blocks, which are the
+// long ones), its LDS exchange area aliased onto the c1 strips.
+template <int WPL, int LPT, bool BWD, bool DENSE = false, int NW = MKE_BLOCK / 64, bool DFL = false>
+__global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvParams p) {
   static_assert(NW == MKE_BLOCK / 64 || (BWD && !DENSE), "short blocks: backward only");
+  static_assert(!DFL || (BWD && !DENSE && LPT == 16 && NW == MKE_BLOCK / 64), "in-block dflat: backward, a quarter-wave per triple");
   constexpr int NT = NW * 64;                      // threads per block
   static_assert(!DENSE || (!BWD && LPT == 16), "dense layer: forward, a quarter-wave per triple");
   constexpr int TPW = 64 / LPT;                    // triples per wavefront
@@ -126,6 +138,19 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
   __shared__ float s_c1[NSLOT][2][2][DP];
   __shared__ float s_d2[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
   __shared__ float s_d1[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
+  if constexpr (DFL) {
+    // the rider's exchange area (20 KB): aliased onto the c1 strips where they are large enough (dim > 64: the block is at 79 KB
+    // of LDS, two per CU), its own array otherwise
+    constexpr bool ALIAS = sizeof(s_c1) >= sizeof(float) * (MKE_BLOCK / 64) * 5 * 4 * 64;
+    __shared__ float s_rider[ALIAS ? 1 : (MKE_BLOCK / 64) * 5 * 4 * 64];
+    static_assert(2 * 2 * DP >= 4 * LPT * WPL, "a triple's dflat row must fit its own d1 strip");
+    if ((int)blockIdx.x >= p.conv_blocks) {      // block-uniform: a rider of the weight-gradient product
+      const int r = (int)blockIdx.x - p.conv_blocks;
+      gemm_tall_block<5, 20, false>(p.tall, r % p.tall.gx, r / p.tall.gx,
+                                    reinterpret_cast<float (*)[5][4][64]>(ALIAS ? &s_c1[0][0][0][0] : &s_rider[0]));
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tl = lane & (LPT - 1);               // lane inside the triple's group
   const int slot = wv * TPW + lane / LPT;         // which of the block's triples
@@ -135,6 +160,57 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
     if (LPT == 64) v += __shfl_xor(v, 32, 64);
     return v;
   };
+  if constexpr (DFL) {
+    // ---- dflat rows of the block's 16 triples: [16 x dim] (dz) x [dim x 4 dim] (W^T), f32 MFMA 16x16x4.  BEFORE the convolution's
+    // constants are loaded: the 100 B fragments and the 50 filter weights are never live together (together: 256 registers and
+    // 232 spilled).  The host launches one block per 16 triples (a single pass of the loop below).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int KSB = 20, NTB = 5;             // k-steps of 4 (dim <= 80), column tiles per wavefront (4 dim <= 320 = 20 tiles)
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * NSLOT;
+    const int d = p.dim;
+    const int ncol = 4 * d;
+    // B = W^T [dim][4 dim] (p.W: the transposed copy k_attr_tail_bwd left): lane (r16, kq) of k-step i reads wt[4 i + kq][16 ct + r16]
+    // — a quarter-wave reads 16 consecutive floats (from W itself the same operand is 16 rows 300 bytes apart: 16 cache lines per
+    // load instead of 1, and the phase took 14 us instead of 3).  A = the block's 16 rows of dz: 1200 consecutive floats, copied
+    // into the (still unused) x strips with coalesced loads and read back per lane.
+    float bw[KSB][NTB];
+#pragma unroll
+    for (int i = 0; i < KSB; ++i) {
+      const int kc = min(4 * i + kq, d - 1);       // unconditional loads from clamped addresses; k >= dim contributes a = 0
+#pragma unroll
+      for (int c = 0; c < NTB; ++c) bw[i][c] = p.W[kc * ncol + min(16 * (wv + 4 * c) + r16, ncol - 1)];
+    }
+    float* s_dz = &s_x[0][0][0];
+    static_assert(sizeof(s_x) >= sizeof(float) * NSLOT * LPT * WPL, "the dz tile (16 rows of dim <= 16 WPL floats) must fit the x strips");
+    {
+      const int64_t e0 = m0 * d, e_end = min(p.n, m0 + NSLOT) * d;
+      for (int e = threadIdx.x; e < NSLOT * d; e += NT) s_dz[e] = e0 + e < e_end ? p.dz[e0 + e] : 0.f;
+    }
+    __syncthreads();
+    float av[KSB];
+#pragma unroll
+    for (int i = 0; i < KSB; ++i) av[i] = s_dz[r16 * d + min(4 * i + kq, d - 1)];
+    f32x4 acc[NTB];
+#pragma unroll
+    for (int c = 0; c < NTB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KSB; ++i) {
+      const float ai = (4 * i + kq < d) ? av[i] : 0.f;   // rows past n are zero in the tile
+#pragma unroll
+      for (int c = 0; c < NTB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bw[i][c], acc[c], 0, 0, 0);
+    }
+    // C/D map of the 16x16 forms: col = lane & 15, row = 4 * (lane >> 4) + reg  ->  triple slot = row, dflat column = col
+#pragma unroll
+    for (int c = 0; c < NTB; ++c) {
+      const int col = 16 * (wv + 4 * c) + r16;
+      if (col < ncol) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (&s_d1[4 * kq + r][0][0][0])[col] = acc[c][r];
+      }
+    }
+    __syncthreads();
+  }
   const int d = p.dim;
   const float bn_s = rsqrtf(1.0f + CNN_BN_EPS);
   const float* __restrict__ gamma = p.params;
@@ -178,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
   float(*c1s)[2][DP] = s_c1[slot];
 
   const int64_t wave0 = (int64_t)blockIdx.x * NSLOT + slot;
-  const int64_t nwaves = (int64_t)gridDim.x * NSLOT;
+  const int64_t nwaves = (int64_t)(DFL ? p.conv_blocks : (int)gridDim.x) * NSLOT;
   const int64_t iters = (p.n + nwaves - 1) / nwaves;  // block-uniform trip count (barriers inside)
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t t = wave0 + it * nwaves;
@@ -315,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void k_attr_conv(const ConvParams p) {
       float(*d1s)[2][DP] = s_d1[slot];
       // ---- width-normalisation backward, tanh', parameter gradients of conv2 -------------------------------
       float dy[2][2][WPL], dot[2][2];
-      const float* gi = p.dflat + t * (int64_t)(4 * d);
+      const float* gi = DFL ? &s_d1[slot][0][0][0] : p.dflat + t * (int64_t)(4 * d);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -682,9 +758,18 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p
 }
 
 // dzpre = inv * (g_out - out * (g_out . out)) * (1 - z^2), in place over gout
+// w / wt (nullable): side job of the launch — wt[k][f] = w[f][k] for f < 4 dim, k < dim (the dense layer's weights transposed: the
+// B operand of the dflat product inside the convolution-backward launch then reads 16 consecutive floats per quarter-wave)
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_bwd(const float* __restrict__ z, float* __restrict__ g,
                                                              const double* __restrict__ sumsq, const double* __restrict__ dotp,
-                                                             int64_t n, int dim) {
+                                                             int64_t n, int dim, const float* __restrict__ w, float* __restrict__ wt) {
+  if (wt) {
+    const int total_w = 4 * dim * dim;
+    for (int e = blockIdx.x * MKE_BLOCK + threadIdx.x; e < total_w; e += gridDim.x * MKE_BLOCK) {
+      const int k = e / (4 * dim), f = e - k * (4 * dim);      // consecutive threads write consecutive wt elements
+      wt[e] = w[f * dim + k];
+    }
+  }
   // the first four elements of every thread (all of them when the grid is sized by the launcher) are requested before the
   // partial sums: one memory round trip in front of the arithmetic instead of three
   const int64_t total = n * dim;
@@ -735,6 +820,8 @@ int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const fl
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
+int g_attr_fused_bwd = 1;     // mke_set_option("attr_fused_bwd"): dflat inside the convolution-backward launch, dW on rider blocks (dim <= 80)
+
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   // dim <= 96: two triples per wavefront, 32 lanes each (dim 75: three passes of 32 lanes instead of two of 64)
   // (the backward only: it is bound by instruction issue; the forward is a latency chain and prefers twice the wavefronts)
@@ -746,6 +833,17 @@ static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
       case 3: hipLaunchKernelGGL((k_attr_conv<3, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
       case 4: hipLaunchKernelGGL((k_attr_conv<4, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
       default: hipLaunchKernelGGL((k_attr_conv<5, 16, false, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+    }
+    return check_launch("k_attr_conv");
+  }
+  if (bwd && p.dz) {   // the backward with its dflat rows computed in the block and the weight-gradient product on rider blocks
+    const unsigned nb = (unsigned)p.conv_blocks + (unsigned)(p.tall.gx * p.tall.gz);
+    switch ((p.dim + 15) / 16) {
+      case 1: hipLaunchKernelGGL((k_attr_conv<1, 16, true, false, 4, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_attr_conv<2, 16, true, false, 4, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((k_attr_conv<3, 16, true, false, 4, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      case 4: hipLaunchKernelGGL((k_attr_conv<4, 16, true, false, 4, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_attr_conv<5, 16, true, false, 4, true>), dim3(nb), dim3(MKE_BLOCK), 0, st, p); break;
     }
     return check_launch("k_attr_conv");
   }
@@ -861,6 +959,16 @@ extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, 
   return check_launch("k_attr_tail_loss");
 }
 
+namespace mke {
+static int tail_bwd_impl(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials, int64_t n, int dim,
+                         const float* w, float* wt, hipStream_t st) {
+  int64_t blocks = (n * dim + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
+  blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 1024));
+  hipLaunchKernelGGL(k_attr_tail_bwd, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, z, gout, sumsq_partials, dot_partials, n, dim, w, wt);
+  return check_launch("k_attr_tail_bwd");
+}
+}  // namespace mke
+
 extern "C" int mke_attr_tail_bwd(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials,
                                  int64_t n, int dim, float* grad_bias, void* stream) {
   using namespace mke;
@@ -870,7 +978,7 @@ extern "C" int mke_attr_tail_bwd(const float* z, float* gout, const double* sums
   int64_t blocks = (n * dim + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
   blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 1024));
   hipLaunchKernelGGL(k_attr_tail_bwd, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, gout, sumsq_partials,
-                     dot_partials, n, dim);
+                     dot_partials, n, dim, (const float*)nullptr, (float*)nullptr);
   int rc = check_launch("k_attr_tail_bwd");
   if (rc || !grad_bias) return rc;
   hipLaunchKernelGGL(k_colsum_add, dim3(64), dim3(MKE_BLOCK), 0, (hipStream_t)stream, gout, n, dim, grad_bias);
@@ -982,19 +1090,32 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
                                a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
   // backward
   if (phases & MKE_ATTR_BWD) {
-  if ((rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre
-  // [dW; dbias] = [flat, 1]^T dz (split-K, atomic)  and  dflat = dz W^T, one launch
-  if (!launch_gemm_tallsplit_plus(flat, 1, fs, gout, d, gW, d, 4 * d + 1, d, (int)n,
-                                  gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, st, &rc))
-    rc = launch_gemm_f32_pair(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1,
-                              gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st);
-  if (rc) return rc;
-  {
-    if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
-    ConvParams p{};
-    p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
-    p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
-    p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
+  // the fused backward (below) wants W transposed: written by the tail-backward launch into the (then unused) dflat region
+  const bool fused = g_attr_fused_bwd && d > 64 && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;   // narrower rows: the strips are too small to host the rider's exchange area (one block per CU)
+  if ((rc = tail_bwd_impl(z, gout, ssq, dot, n, d, fused ? W : nullptr, fused ? dflat : nullptr, st))) return rc;   // gout = dL/dzpre
+  if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
+  ConvParams p{};
+  p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
+  p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
+  p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
+  if (fused) {
+    // round 4: ONE launch for the rest of the backward — every convolution-backward block computes its 16 rows of dflat = dz W^T
+    // itself (matrix cores, straight into its LDS strips: dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split
+    // over K, atomic) rides on extra blocks of the same grid
+    p.dz = gout; p.W = dflat /* W^T [dim][4 dim] */; p.conv_blocks = (int)((n + 15) / 16);
+    GemmParams& t = p.tall;
+    t = GemmParams{};
+    t.A = flat; t.B = gout; t.C = gW; t.M = 4 * d + 1; t.N = d; t.K = (int)n; t.a_rs = 1; t.a_cs = fs; t.b_rs = d; t.b_cs = 1; t.ldc = d;
+    t.k_per_split = 320;   // 16 x KS(20) k per block: 4 wavefronts x 20 k-steps of 4
+    t.gx = (t.M + 15) / 16; t.gy = 1; t.gz = (t.K + t.k_per_split - 1) / t.k_per_split; t.atomic = 1;
+    if ((rc = conv_dispatch(p, true, st))) return rc;
+  } else {
+    // [dW; dbias] = [flat, 1]^T dz (split-K, atomic)  and  dflat = dz W^T, one launch; then the convolution backward
+    if (!launch_gemm_tallsplit_plus(flat, 1, fs, gout, d, gW, d, 4 * d + 1, d, (int)n,
+                                    gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, st, &rc))
+      rc = launch_gemm_f32_pair(flat, 1, fs, gout, d, 1, gW, d, 4 * d + 1, d, (int)n, 32, 1,
+                                gout, d, 1, W, 1, d, dflat, 4 * d, (int)n, 4 * d, d, 1, 0, st);
+    if (rc) return rc;
     if ((rc = conv_dispatch(p, true, st))) return rc;
   }
   if (!upd && a->workspace && (rc = ws_fold(a->workspace, a->param_grads, d, st))) return rc;   // gradients complete in param_grads

@@ -28,6 +28,8 @@
 
 namespace mke {
 
+int g_oc_score_quarter = -1;   // mke_set_option("oc_score_quarter")
+
 struct OcParams {
   mke_oc_step s;
   float* send;          // k_oc_bases: this rank's block
@@ -267,6 +269,152 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)s.scale;
 }
 
+// The same step with a QUARTER-wave per positive (four positives per wavefront), for the multi-rank shapes: at G ranks a rank owns
+// ~N / G of a positive's negatives (3 of 25 at G = 8), so k_oc_score's wavefront-per-positive spends its instructions on the per-
+// positive overhead (ids, codes, two vector loads, two butterfly reductions, two slot writes) with most quarter-wave slots of its
+// single round idle — measured at the C2 shape as rank 0 of 8: 56.7 us for 40,000 positives against 39.0 us for 5,000 positives
+// with all 25 negatives each (profiles/r04_oc_rank_compute.md).  Here a quarter owns its positive outright: its 16 lanes fetch the
+// codes 16 at a time, the owned ones are visited one after the other (the four quarters of a wavefront iterate together until the
+// busiest is done), the partial gradient vectors need no cross-quarter reduction.  Same arithmetic, same slots, same in-place /
+// scatter rule per corrupt row as k_oc_score.
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
+  constexpr int STRIDE = FPL * 16;
+  const mke_oc_step& s = p.s;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;   // quarter-wave index
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  const int G = s.n_ranks, N = s.neg_per_pos;
+  const int64_t C = s.capacity;
+  float loss = 0.f;
+  const int64_t iters = (s.n_pos + nsub - 1) / nsub;          // wave-uniform trip count (ballots inside)
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t i_raw = sub0 + it * nsub;
+    const bool act = i_raw < s.n_pos;
+    const int64_t i = act ? i_raw : 0;
+    const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
+    const int home = (int)(i / s.per);
+    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * STRIDE;
+    float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
+    load_row<FPL>(vh, 0, STRIDE, j, HR);
+    load_row<FPL>(vt, 0, STRIDE, j, RT);
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
+    if (act && home == s.rank) {  // the positive itself: d = h^ + r^ - t^ = HR + RT - r^
+      float R[FPL];
+      load_row<FPL>(s.rel, pr, STRIDE, j, R);
+      l2_normalize_row<FPL>(R, true);
+      float d[FPL];
+      float x = 0.f;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        d[k] = (HR[k] + RT[k]) - R[k];
+        x = fmaf(d[k], d[k], x);
+      }
+      x = sub16_sum(x);
+      const float pw = s.pos_w ? s.pos_w[i] : 1.0f;
+      loss += pw * softplus_f(x);
+      const float c = 2.0f * s.scale * pw * sigmoid_f(x);
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) {
+        d[k] *= c;
+        gHR[k] += d[k];
+        gRT[k] += d[k];
+      }
+      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)STRIDE);
+      atomic_add_row<FPL>(grel, pr, STRIDE, s.dim, j, d, -1.0f);
+      if (j == 0) s.rel_touched[pr] = s.tag;
+    }
+    const int32_t* cp = oc_codes(p, home) + (i - (int64_t)home * s.per) * N;
+    for (int c0 = 0; c0 < N; c0 += 16) {                      // the group's codes, 16 per quarter at a time
+      int code = 0;
+      const bool has = act && c0 + j < N;
+      if (has) code = cp[c0 + j];
+      const bool mine = has && ((code >> 1) % G) == s.rank;
+      const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
+      const uint64_t mall = __ballot(mine);
+      unsigned rest = (unsigned)(mall >> (16 * q)) & 0xFFFFu;  // this quarter's owned negatives of the chunk
+      while (__ballot(rest != 0)) {                            // the four quarters visit their next owned negative together
+        const bool live = rest != 0;
+        const int src = 16 * q + (live ? __builtin_ctz(rest) : 0);
+        const int cd = __shfl(code, src, 64);
+        const int cnt = __shfl(rcl, src, 64);
+        rest &= rest - 1;
+        if (!live) continue;
+        const bool sideH = cd & 1;
+        const int e = (cd >> 1) / G;
+        float Cr[FPL], A[FPL];
+        load_row<FPL>(s.ent, e, STRIDE, j, Cr);
+        const bool in_place = s.ref_count && cnt == 1;
+        if (in_place && s.ent_acc) load_row<FPL>(s.ent_acc, e, STRIDE, j, A);
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) ss = fmaf(Cr[k], Cr[k], ss);
+        const float cinv = rsqrtf(fmaxf(sub16_sum(ss), MKE_L2_EPS));
+        float d[FPL];
+        float y = 0.f;
+        const float sc = sideH ? cinv : -cinv;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) {
+          d[k] = fmaf(sc, Cr[k], sideH ? RT[k] : HR[k]);
+          y = fmaf(d[k], d[k], y);
+        }
+        y = sub16_sum(y);
+        const float t_ = __expf(-y);
+        const float s1 = 1.0f + t_;
+        loss += __logf(s1);
+        const float c = -2.0f * s.scale * t_ * __builtin_amdgcn_rcpf(s1);
+        const float cHR = sideH ? 0.f : c, cRT = sideH ? c : 0.f;
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) {
+          gHR[k] = fmaf(cHR, d[k], gHR[k]);
+          gRT[k] = fmaf(cRT, d[k], gRT[k]);
+          d[k] *= c;
+        }
+        const float sg = sideH ? 1.0f : -1.0f;
+        if (in_place) {  // the only reference to this row in the whole global step: finish it here
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) dot = fmaf(Cr[k], d[k], dot);
+          dot = sub16_sum(dot) * (sg * cinv);
+          const float a1 = sg * cinv;
+          const float a2 = cinv < 0.99e6f ? -dot * cinv * cinv : 0.f;
+          float g[FPL];
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) g[k] = fmaf(a2, Cr[k], a1 * d[k]);
+          float* wp = s.ent + (int64_t)e * STRIDE + j;
+          if (s.optimizer == MKE_OPT_ADAGRAD) {
+            float* ap = s.ent_acc + (int64_t)e * STRIDE + j;
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+              const float a = fmaf(g[k], g[k], A[k]);
+              ap[k * 16] = a;
+              wp[k * 16] = Cr[k] - s.lr * g[k] * adagrad_scale(a);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) wp[k * 16] = Cr[k] - s.lr * g[k];
+          }
+          if (j == 0) s.ref_count[e] = 0;
+        } else {
+          atomic_add_row<FPL>(s.ent_grad, e, STRIDE, s.dim, j, d, sg);
+          if (j == 0) s.ent_touched[e] = s.tag;
+        }
+      }
+    }
+    if (act) {   // this positive's partial gradient vectors: every slot of g_all is written by exactly one quarter-wave per step
+      const int64_t gb = 2 * C * (int64_t)STRIDE;
+      float* oh = (s.n_peers ? s.peer_g[ph % G] : p.g_all + (int64_t)(ph % G) * gb) + (int64_t)s.slot_h[i] * STRIDE + j;
+      float* ot = (s.n_peers ? s.peer_g[pt % G] : p.g_all + (int64_t)(pt % G) * gb) + (C + s.slot_t[i]) * STRIDE + j;
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) { oh[k * 16] = gHR[k]; ot[k * 16] = gRT[k]; }
+    }
+  }
+  const double tot = block_sum_double(j == 0 ? loss : 0.f);
+  if (threadIdx.x == 0) p.lossp[blockIdx.x] = tot * (double)s.scale;
+}
+
 // quarter-wave per owned slot: the summed gradient vector goes to the head (+) / tail (-) row's gradient and to the
 // relation row's
 template <int FPL>
@@ -462,6 +610,14 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   OcParams p{};
   p.s = *s; p.v_all = v_all; p.block_floats = block_floats; p.g_all = g_all; p.lossp = loss_partials;
   const int fpl = s->stride / 16;
+  // a quarter-wave per positive when a rank owns only a few of a positive's negatives (N / G <= 8 at G >= 4, rows up to 128 floats:
+  // wider rows leave two wavefronts per SIMD at 194 registers) — k_oc_score_q;
+  // option "oc_score_quarter": -1 = by shape (default), 0 = never, 1 = always
+  const bool quarter = g_oc_score_quarter < 0 ? (s->n_ranks >= 4 && s->neg_per_pos <= 8 * s->n_ranks && s->stride <= 128) : g_oc_score_quarter != 0;
+  if (quarter) {
+    MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); });
+    return check_launch("k_oc_score_q");
+  }
   MKE_DISPATCH_FPL(fpl, {
     constexpr int U = FPL <= 5 ? 2 : 1;
     hipLaunchKernelGGL((k_oc_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);

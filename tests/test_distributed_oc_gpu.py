@@ -81,6 +81,31 @@ def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg):
     assert tr.stride == dim or float(tr.ent[:, dim:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("excl,dim,neg", [(True, 75, 8), (True, 75, 25), (False, 75, 33), (True, 256, 64), (True, 20, 1), (True, 75, 0)])
+def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg):
+    """k_oc_score_q (a quarter-wave per positive, four positives per wavefront: the multi-rank shapes' kernel) forced on at one rank
+    — every negative owned, so the per-quarter chains are as long as they get; codes in chunks of 16 (neg 25, 33, 64 span several),
+    ragged last wavefronts — against the same float64 dense oracle as the wavefront-per-positive kernel."""
+    from multike_amd import _lib
+    n_ent = 3000 if dim < 256 else 1200
+    _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
+    steps = min(spe, 7)
+    old = _lib.set_option("oc_score_quarter", 1)
+    try:
+        tr = _make(0, 1, excl=excl, n_ent=n_ent, dim=dim, neg=neg)
+        for i in range(steps):
+            tr.step(i)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("oc_score_quarter", old)
+    e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+    assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("chunks", [1, 2])
 def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     """Same global steps as the single-table StepEngine path (same device batcher, same seed => same shuffle): losses and

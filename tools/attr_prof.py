@@ -5,6 +5,9 @@ import numpy as np, torch
 from multike_amd.attr_cnn import AttrCNN
 from multike_amd.tables import EmbeddingTable, StepEngine
 
+from multike_amd import _lib
+for kv in filter(None, os.environ.get("MKE_SET", "").split(",")):      # MKE_SET=option=value,...: A/B of a kernel choice
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 d, B = 75, (int(sys.argv[2]) if len(sys.argv) > 2 else 5000)
 E = EmbeddingTable(200_000, d, "av", seed=1); A = EmbeddingTable(600, d, "attr", normalize=False, seed=2)

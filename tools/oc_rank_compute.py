@@ -49,7 +49,11 @@ def main():
     ap.add_argument("--config", choices=["c2", "c5"], default="c2")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--chunks", type=int, default=1)
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
     a = ap.parse_args()
+    for kv in a.set:
+        k, _, v = kv.partition("=")
+        _lib.set_option(k, int(v))
     cfg = dict(n_ent=200_000, n_rel=550, dim=75, neg=25) if a.config == "c2" else dict(n_ent=2_000_000, n_rel=2000, dim=256, neg=64)
     G, B = a.world, 5000
     kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234)
@@ -96,7 +100,7 @@ def main():
     phases = {}
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
-    out = {"tool": "oc_rank_compute", "config": a.config, "world": G, "rank": 0, "chunks": a.chunks, "global_batch": B * G,
+    out = {"tool": "oc_rank_compute", "config": a.config, "options": a.set, "world": G, "rank": 0, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
            "capacity_vectors": tr.C,
            "phase_us": {k: float(np.mean(v)) for k, v in phases.items()},
