@@ -140,7 +140,7 @@ def test_whole_schedule_tracks_the_float64_oracle(method):
     # of the two implementations' rounding noise (hardware exp / rcp / rsqrt, atomic order) carried through the same
     # linearised dynamics.  So: (1) every element is inside the ORIGINAL band (rtol 1e-3, atol 2e-5) widened per row by 40 x
     # what NumPy's float32 makes of that row; (2) rows with an element outside the plain original band are < 1 % of the rows
-    # and every one of them is a row where float32 itself leaves its noise floor (> 2e-6); (3) the absolute cap is 2e-3
+    # and every one of them is a row where float32 itself leaves its noise floor (> 5 x the table's median row); (3) the absolute cap is 2e-3
     # (5e-3 before).
     for k, tab in pairs.items():
         got = tab.raw().cpu().numpy().astype(np.float64)
@@ -153,7 +153,8 @@ def test_whole_schedule_tracks_the_float64_oracle(method):
                                float((err / np.maximum(row_noise, 1e-12))[bad].max()))
         out_rows = (err > plain).any(axis=1)
         assert out_rows.mean() < 0.01, (k, int(out_rows.sum()))
-        assert (row_noise[out_rows, 0] > 2e-6).all(), (k, np.flatnonzero(out_rows)[:8].tolist(), row_noise[out_rows, 0][:8].tolist())
+        floor = max(2e-7, float(np.median(row_noise)))          # what float32 makes of an ordinary row of this table
+        assert (row_noise[out_rows, 0] > 5.0 * floor).all(), (k, floor, np.flatnonzero(out_rows)[:8].tolist(), row_noise[out_rows, 0][:8].tolist())
         assert float(err.max()) < 2e-3, (k, float(err.max()))
     for c, P in zip((model._attr_cnn, model._ckge_attr_cnn, model._ckga_attr_cnn), oracle.cnn):
         for name, got in c.numpy_params().items():
