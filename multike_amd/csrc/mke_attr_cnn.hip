@@ -83,7 +83,9 @@ struct ConvParams {
   double* __restrict__ ssq;          // per-block sums of z^2 (MKE_LOSS_PARTIALS slots; the ones no block owns are cleared)
   // bwd with the dflat product in the block (k_attr_conv<WPL, 16, true, false, 4, true>): dflat tile = 16 rows of dz x W^T; the blocks
   // behind the first conv_blocks of the grid are riders that compute the weight-gradient product `tall` ([flat, 1]^T dz over K splits)
-  const float* __restrict__ dz;      // [n][dim] dL/dzpre
+  const float* __restrict__ dz;      // [n][dim]: g = dL/dout-side gradient of the loss tail (dz = dz_of(g, z, S, T) is formed on load)
+  const float* __restrict__ zmat;    // [n][dim] z
+  const double* __restrict__ dotp;   // per-block sums of g . z (with ssq: the two batch-wide scalars of the transform)
   int conv_blocks;
   GemmParams tall;
 };
@@ -146,8 +148,12 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
     static_assert(2 * 2 * DP >= 4 * LPT * WPL, "a triple's dflat row must fit its own d1 strip");
     if ((int)blockIdx.x >= p.conv_blocks) {      // block-uniform: a rider of the weight-gradient product
       const int r = (int)blockIdx.x - p.conv_blocks;
-      gemm_tall_block<5, 20, false>(p.tall, r % p.tall.gx, r / p.tall.gx,
-                                    reinterpret_cast<float (*)[5][4][64]>(ALIAS ? &s_c1[0][0][0][0] : &s_rider[0]));
+      double S, T;
+      totals_of_partials2(p.ssq, p.dotp, S, T);
+      const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
+      const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;
+      gemm_tall_block_dz<5, 32, 4>(p.tall, r % p.tall.gx, r / p.tall.gx,
+                                   reinterpret_cast<float (*)[5][4][64]>(ALIAS ? &s_c1[0][0][0][0] : &s_rider[0]), p.zmat, inv, coef);
       return;
     }
   }
@@ -184,8 +190,24 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
     float* s_dz = &s_x[0][0][0];
     static_assert(sizeof(s_x) >= sizeof(float) * NSLOT * LPT * WPL, "the dz tile (16 rows of dim <= 16 WPL floats) must fit the x strips");
     {
+      // the tile's g and z are requested before the two batch-wide sums are added up (one round trip for all of it)
+      constexpr int NEL = (NSLOT * LPT * WPL + NT - 1) / NT;
       const int64_t e0 = m0 * d, e_end = min(p.n, m0 + NSLOT) * d;
-      for (int e = threadIdx.x; e < NSLOT * d; e += NT) s_dz[e] = e0 + e < e_end ? p.dz[e0 + e] : 0.f;
+      float gv[NEL], zv[NEL];
+#pragma unroll
+      for (int q = 0; q < NEL; ++q) {
+        const int64_t e = e0 + threadIdx.x + q * NT;
+        const bool ok = threadIdx.x + q * NT < NSLOT * d && e < e_end;
+        gv[q] = ok ? p.dz[e] : 0.f;
+        zv[q] = ok ? p.zmat[e] : 0.f;
+      }
+      double S, T;
+      totals_of_partials2(p.ssq, p.dotp, S, T);
+      const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
+      const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;
+#pragma unroll
+      for (int q = 0; q < NEL; ++q)
+        if (threadIdx.x + q * NT < NSLOT * d) s_dz[threadIdx.x + q * NT] = dz_of(gv[q], zv[q], inv, coef);
     }
     __syncthreads();
     float av[KSB];
@@ -690,10 +712,19 @@ struct TailParams {
   int32_t* __restrict__ tent;
   int32_t tag;
   double* __restrict__ lossp;
+  const float* __restrict__ w;   // nullable pair: side job wt[k][f] = w[f][k], f < 4 dim, k < dim (the dense layer's weights transposed,
+  float* __restrict__ wt;        // for the dflat product inside the convolution-backward launch)
 };
 
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p) {
+  if (p.wt) {
+    const int total_w = 4 * p.dim * p.dim;
+    for (int e = blockIdx.x * MKE_BLOCK + threadIdx.x; e < total_w; e += gridDim.x * MKE_BLOCK) {
+      const int k = e / (4 * p.dim), f = e - k * (4 * p.dim);
+      p.wt[e] = p.w[f * p.dim + k];
+    }
+  }
   const int j = threadIdx.x & 15;
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
@@ -758,18 +789,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_loss(const TailParams p
 }
 
 // dzpre = inv * (g_out - out * (g_out . out)) * (1 - z^2), in place over gout
-// w / wt (nullable): side job of the launch — wt[k][f] = w[f][k] for f < 4 dim, k < dim (the dense layer's weights transposed: the
-// B operand of the dflat product inside the convolution-backward launch then reads 16 consecutive floats per quarter-wave)
 __global__ __launch_bounds__(MKE_BLOCK) void k_attr_tail_bwd(const float* __restrict__ z, float* __restrict__ g,
                                                              const double* __restrict__ sumsq, const double* __restrict__ dotp,
-                                                             int64_t n, int dim, const float* __restrict__ w, float* __restrict__ wt) {
-  if (wt) {
-    const int total_w = 4 * dim * dim;
-    for (int e = blockIdx.x * MKE_BLOCK + threadIdx.x; e < total_w; e += gridDim.x * MKE_BLOCK) {
-      const int k = e / (4 * dim), f = e - k * (4 * dim);      // consecutive threads write consecutive wt elements
-      wt[e] = w[f * dim + k];
-    }
-  }
+                                                             int64_t n, int dim) {
   // the first four elements of every thread (all of them when the grid is sized by the launcher) are requested before the
   // partial sums: one memory round trip in front of the arithmetic instead of three
   const int64_t total = n * dim;
@@ -938,18 +960,31 @@ extern "C" int mke_attr_tail_z(float* z, const float* bias, int64_t n, int dim, 
   return check_launch("k_attr_tail_z");
 }
 
+namespace mke {
+static int tail_loss_impl(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
+                          int ent_normalize, const int32_t* ih, const float* weights, float scale, int64_t n, int dim,
+                          float* gout, double* dot_partials, float* grad_ent, int32_t* touched_ent, int32_t tag,
+                          double* loss_partials, const float* w, float* wt, void* stream);
+}
 extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
                                   int ent_normalize, const int32_t* ih, const float* weights, float scale, int64_t n, int dim,
                                   float* gout, double* dot_partials, float* grad_ent, int32_t* touched_ent, int32_t tag,
                                   double* loss_partials, void* stream) {
-  using namespace mke;
+  return mke::tail_loss_impl(z, sumsq_partials, ent_table, ent_stride, ent_normalize, ih, weights, scale, n, dim, gout, dot_partials,
+                             grad_ent, touched_ent, tag, loss_partials, nullptr, nullptr, stream);
+}
+namespace mke {
+static int tail_loss_impl(const float* z, const double* sumsq_partials, const float* ent_table, int ent_stride,
+                          int ent_normalize, const int32_t* ih, const float* weights, float scale, int64_t n, int dim,
+                          float* gout, double* dot_partials, float* grad_ent, int32_t* touched_ent, int32_t tag,
+                          double* loss_partials, const float* w, float* wt, void* stream) {
   if (n < 0 || dim <= 0 || ent_stride % 16 != 0 || dim > ent_stride || ent_stride > MKE_MAX_STRIDE) { set_error("bad n/dim/stride"); return MKE_E_SHAPE; }
   if (!z || !sumsq_partials || !ent_table || !gout || !dot_partials || !loss_partials || (n > 0 && !ih)) { set_error("mke_attr_tail_loss: NULL pointer"); return MKE_E_NULL; }
   if (grad_ent && !touched_ent) { set_error("NULL touched array"); return MKE_E_NULL; }
   TailParams p;
   p.z = z; p.sumsq = sumsq_partials; p.ent = ent_table; p.ent_stride = ent_stride; p.ent_norm = ent_normalize; p.ih = ih;
   p.ws = weights; p.scale = scale; p.n = n; p.dim = dim; p.gout = gout; p.dotp = dot_partials; p.gent = grad_ent;
-  p.tent = touched_ent; p.tag = tag; p.lossp = loss_partials;
+  p.tent = touched_ent; p.tag = tag; p.lossp = loss_partials; p.w = w; p.wt = wt;
   const int fpl = ent_stride / 16;
   int64_t blocks = (n + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK;
   blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, MKE_LOSS_PARTIALS));
@@ -957,15 +992,6 @@ extern "C" int mke_attr_tail_loss(const float* z, const double* sumsq_partials, 
     hipLaunchKernelGGL((k_attr_tail_loss<FPL>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   });
   return check_launch("k_attr_tail_loss");
-}
-
-namespace mke {
-static int tail_bwd_impl(const float* z, float* gout, const double* sumsq_partials, const double* dot_partials, int64_t n, int dim,
-                         const float* w, float* wt, hipStream_t st) {
-  int64_t blocks = (n * dim + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
-  blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 1024));
-  hipLaunchKernelGGL(k_attr_tail_bwd, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, z, gout, sumsq_partials, dot_partials, n, dim, w, wt);
-  return check_launch("k_attr_tail_bwd");
 }
 }  // namespace mke
 
@@ -978,7 +1004,7 @@ extern "C" int mke_attr_tail_bwd(const float* z, float* gout, const double* sums
   int64_t blocks = (n * dim + MKE_BLOCK * 4 - 1) / (MKE_BLOCK * 4);
   blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 1024));
   hipLaunchKernelGGL(k_attr_tail_bwd, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, (hipStream_t)stream, z, gout, sumsq_partials,
-                     dot_partials, n, dim, (const float*)nullptr, (float*)nullptr);
+                     dot_partials, n, dim);
   int rc = check_launch("k_attr_tail_bwd");
   if (rc || !grad_bias) return rc;
   hipLaunchKernelGGL(k_colsum_add, dim3(64), dim3(MKE_BLOCK), 0, (hipStream_t)stream, gout, n, dim, grad_bias);
@@ -1085,28 +1111,29 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
     }
   }
   const bool upd = a->update != 0 && (phases & MKE_ATTR_UPD);
+  // round 4 (64 < dim <= 80): the rest of the backward is ONE launch — every convolution-backward block forms its 16 rows of
+  // dz = dL/dzpre from g and z with the two batch-wide sums, multiplies them with W^T on the matrix cores straight into its LDS strips
+  // (dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split over K, atomic) rides on extra blocks of the same grid,
+  // forming dz on the way into its MFMAs.  W^T (the B operand read 16 consecutive floats per quarter-wave) is left in the unused dflat
+  // scratch by the loss-tail launch.  4 launches per step: forward, loss tail, backward, updates.
+  const bool fused = g_attr_fused_bwd && d > 64 && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
   if ((phases & MKE_ATTR_TAIL) &&
-      (rc = mke_attr_tail_loss(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
-                               a->ent_grad, a->ent_touched, a->tag, lossp, stream))) return rc;
+      (rc = tail_loss_impl(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
+                           a->ent_grad, a->ent_touched, a->tag, lossp, fused ? W : nullptr, fused ? dflat : nullptr, stream))) return rc;
   // backward
   if (phases & MKE_ATTR_BWD) {
-  // the fused backward (below) wants W transposed: written by the tail-backward launch into the (then unused) dflat region
-  const bool fused = g_attr_fused_bwd && d > 64 && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;   // narrower rows: the strips are too small to host the rider's exchange area (one block per CU)
-  if ((rc = tail_bwd_impl(z, gout, ssq, dot, n, d, fused ? W : nullptr, fused ? dflat : nullptr, st))) return rc;   // gout = dL/dzpre
+  if (!fused && (rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre (the fused launch forms it on load)
   if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
   ConvParams p{};
   p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
   p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
   p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
   if (fused) {
-    // round 4: ONE launch for the rest of the backward — every convolution-backward block computes its 16 rows of dflat = dz W^T
-    // itself (matrix cores, straight into its LDS strips: dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split
-    // over K, atomic) rides on extra blocks of the same grid
-    p.dz = gout; p.W = dflat /* W^T [dim][4 dim] */; p.conv_blocks = (int)((n + 15) / 16);
+    p.dz = gout /* g */; p.zmat = z; p.ssq = ssq; p.dotp = dot; p.W = dflat /* W^T [dim][4 dim] */; p.conv_blocks = (int)((n + 15) / 16);
     GemmParams& t = p.tall;
     t = GemmParams{};
     t.A = flat; t.B = gout; t.C = gW; t.M = 4 * d + 1; t.N = d; t.K = (int)n; t.a_rs = 1; t.a_cs = fs; t.b_rs = d; t.b_cs = 1; t.ldc = d;
-    t.k_per_split = 320;   // 16 x KS(20) k per block: 4 wavefronts x 20 k-steps of 4
+    t.k_per_split = 512;   // 16 x KS(32) k per rider: 190 riders at n = 5000 — with the 313 convolution blocks they are all resident at once
     t.gx = (t.M + 15) / 16; t.gy = 1; t.gz = (t.K + t.k_per_split - 1) / t.k_per_split; t.atomic = 1;
     if ((rc = conv_dispatch(p, true, st))) return rc;
   } else {

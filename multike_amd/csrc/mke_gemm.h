@@ -155,6 +155,75 @@ __device__ __forceinline__ void gemm_tall_block(const GemmParams& p, int bx, int
 }
 
 
+// dz = inv (g - z coef) (1 - z^2): the backward of the attribute step's batch-wide l2_normalize + tanh, applied where an operand is
+// loaded (inv = rsqrt(max(S, eps)), coef = S > eps ? T inv^2 : 0; S = sum z^2, T = sum g . z over the whole batch)
+__device__ __forceinline__ float dz_of(float g, float z, float inv, float coef) { return inv * (g - z * coef) * (1.0f - z * z); }
+
+// gemm_tall_block's K-split form (atomic accumulation into C) whose B operand is dz, computed on the way into the MFMAs from g (= p.B)
+// and z (same layout): KS k-steps per wavefront in NQ rounds of KS / NQ — the next round's g and z fragments are in flight under the
+// current round's MFMAs; all of them at once would be 2 KS NCT live registers.
+template <int NCT, int KS, int NQ>
+__device__ __forceinline__ void gemm_tall_block_dz(const GemmParams& p, int bx, int by, float (*s_part)[NCT][4][64],
+                                                   const float* __restrict__ zmat, float inv, float coef) {
+  static_assert(KS % NQ == 0, "rounds of equal length");
+  constexpr int KH = KS / NQ;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = bx * 16;
+  const int k_lo = by * p.k_per_split;
+  const int k_hi = min(p.K, k_lo + p.k_per_split);
+  const int k0 = k_lo + 4 * KS * wv + kq;  // this lane's first k
+  const int row = min(m0 + r16, p.M - 1);
+  const float* ap = p.A + (int64_t)row * p.a_rs;
+  const int a_cs = (int)p.a_cs;
+  const int64_t z_off = zmat - p.B;
+  int bcol[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) bcol[c] = min(16 * c + r16, p.N - 1);
+  float a[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) a[i] = ap[min(k0 + 4 * i, p.K - 1) * a_cs];
+  f32x4 acc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float g[2][KH][NCT], z[2][KH][NCT];
+  auto load_round = [&](int h, int buf) {
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      const float* bp = p.B + (int64_t)min(k0 + 4 * (h * KH + i), p.K - 1) * p.b_rs;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) { g[buf][i][c] = bp[bcol[c]]; z[buf][i][c] = bp[z_off + bcol[c]]; }
+    }
+  };
+  load_round(0, 0);
+#pragma unroll
+  for (int h = 0; h < NQ; ++h) {
+    const int buf = h & 1;
+    if (h + 1 < NQ) load_round(h + 1, buf ^ 1);
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      const float ai = (k0 + 4 * (h * KH + i) < k_hi) ? a[h * KH + i] : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, dz_of(g[buf][i][c], z[buf][i][c], inv, coef), acc[c], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_part[wv][c][r][lane] = acc[c][r];
+  __syncthreads();
+  for (int c = wv; c < NCT; c += MKE_BLOCK / 64) {
+    const int col = 16 * c + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = s_part[0][c][r][lane] + s_part[1][c][r][lane] + s_part[2][c][r][lane] + s_part[3][c][r][lane];
+      const int orow = m0 + 4 * kq + r;
+      if (col < p.N && orow < p.M) atomic_add_f32(p.C + (int64_t)orow * p.ldc + col, v);
+    }
+  }
+}
+
 int launch_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc,
                     int M, int N, int K, int splits, int accumulate, hipStream_t st, double* tanh_sumsq_partials, int epi_plain);
 bool launch_gemm_tallsplit_plus(const float* A0, int64_t a0_rs, int64_t a0_cs, const float* B0, int64_t b0_rs, float* C0, int64_t ldc0,
