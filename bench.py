@@ -282,8 +282,8 @@ def attribute_step_variant(args):
     """Side line: one attribute-view step (code/MultiKE_model.py:134-151 + conv :34-63) at the same batch size — the other
     half of an ITC epoch's GPU time.  Bytes per triple (algorithmic): 3 row gathers (entity, attribute, literal) + 2 gradient
     rows (entity, attribute) + 4 ids/weight = 5 * 4 * dim + 16; flops per triple: 2 * (4 dim * dim dense + 7.2K conv MACs)
-    forward, ~3x that with the backward.  The step is 7 dependent launches of 7-20 us at this size: it is bound by kernel
-    floors and latency, not by HBM or the matrix pipe — the roofline block says how far below both it sits."""
+    forward, ~3x that with the backward.  The step is 4 dependent launches of 6-23 us at this size (6 until round 4): it is bound by
+    kernel floors and latency, not by HBM or the matrix pipe — the roofline block says how far below both it sits."""
     from multike_amd.attr_cnn import AttrCNN
     from multike_amd.tables import EmbeddingTable, StepEngine
     d, B = args.dim, args.batch
@@ -311,7 +311,7 @@ def attribute_step_variant(args):
     flops_per = 3 * 2 * (4 * d * d + 7200)
     return {"name": "attribute-view step (CNN scorer, fwd + bwd + updates)", "value": B / dt, "unit": "attribute triples/s",
             "steps": n_steps, "ms_per_step": dt * 1e3, "scored_per_step": B,
-            "roofline": {"bound": "launch floors / latency (7 dependent launches per step)",
+            "roofline": {"bound": "launch floors / latency (4 dependent launches per step)",
                          "alg_bytes_per_triple": bytes_per, "achieved_GBps": B * bytes_per / dt / 1e9,
                          "frac_hbm": B * bytes_per / dt / 1e9 / HBM_PEAK_GBS,
                          "flops_per_triple": flops_per, "achieved_TFLOPs": B * flops_per / dt / 1e12,
