@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 101 /* 0.1.1: mke_align_rank gained the `ties` output (argument order changed) */
+#define MKE_VERSION 102 /* 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
