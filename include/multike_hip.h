@@ -60,8 +60,8 @@ const char* mke_last_error(void);
  *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
  *   "update_chunk"  : rows per wavefront of the row-update kernels on large tables: 0 = by table size (default), 16, 64
  *   "attr_fused_bwd" : attribute step, 64 < dim <= 80: 1 (default) = the dflat product inside the convolution-backward launch and
- *                     the weight-gradient product on rider blocks of it (5 launches per step); 0 = the two products as their own
- *                     launch (6 launches)
+ *                     the weight-gradient product on rider blocks of it, both forming dz = dL/dzpre on load (4 launches per step);
+ *                     0 = tail backward, the two products and the convolution backward as launches of their own (6)
  *   "oc_score_quarter" : mke_oc_score with a quarter-wave per positive (four positives per wavefront) instead of a wavefront:
  *                     -1 = by shape (default: n_ranks >= 4, neg_per_pos <= 8 n_ranks, stride <= 128), 0 = never, 1 = always
  *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
