@@ -87,7 +87,30 @@ def gap_table(db, sampler_ordinal=3, steps=20):
     return "\n".join(out)
 
 
+def pmc_table(db, needle="mke"):
+    """Per (kernel, counter) averages of a `rocprofv3 --kernel-trace --pmc ...` run (kernels whose name contains `needle`)."""
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    t = lambda p: [x for x in tabs if x.startswith(p)][0]
+    pe, ip, kd, ks = t("rocpd_pmc_event"), t("rocpd_info_pmc"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
+    q = (f"select s.kernel_name, i.name, count(*), avg(e.value) from {pe} e join {ip} i on e.pmc_id=i.id "
+         f"join {kd} d on d.event_id=e.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, i.name")
+    by = {}
+    for name, ctr, n, avg in c.execute(q):
+        if needle in name:
+            by.setdefault(name, {})[ctr] = (n, avg)
+    ctrs = sorted({k for v in by.values() for k in v})
+    out = ["| kernel | dispatches | " + " | ".join(ctrs) + " |", "|---|---|" + "---|" * len(ctrs)]
+    for name, v in sorted(by.items(), key=lambda kv: -max(x[1] for x in kv[1].values())):
+        n = max(x[0] for x in v.values())
+        out.append(f"| `{name[:70]}` | {n} | " + " | ".join(f"{v[k][1]:.3g}" if k in v else "" for k in ctrs) + " |")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--pmc":           # rocpd_summary.py <db> --pmc [kernel-name substring]
+        print(pmc_table(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 else "mke"))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--gaps":          # rocpd_summary.py <db> --gaps [sampler ordinal] [steps]
         print(gap_table(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 else 20))
         sys.exit(0)
