@@ -10,6 +10,8 @@ class MultiKE_CV(_ScheduledMultiKE):
         super().__init__(data, args, predicate_align_model)
         self.flag1, self.flag2, self.early_stop = -1, -1, False
         self.defer_predicate_update = True       # the soft predicate-alignment refresh's host work under the next epoch's kernels
+        if hasattr(self.predicate_align_model, "_refresh_device"):
+            self.predicate_align_model.device = self.device    # ... and its per-triple work in HBM (no list upload)
         self._define_variables()
         self._define_name_view_graph()
         self._define_relation_view_graph()

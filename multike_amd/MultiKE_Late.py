@@ -278,9 +278,26 @@ class _ScheduledMultiKE(MultiKE):
         ev, snaps = pend
         ev.synchronize()
         pam = self.predicate_align_model
-        pam.update_predicate_alignment(snaps[0][1].numpy())
-        pam.update_predicate_alignment(snaps[1][1].numpy(), predicate_type='attribute')
-        self._refresh_predicate_lists()
+        import torch
+        if getattr(pam, "device", None) is None:
+            pam.update_predicate_alignment(snaps[0][1].numpy())
+            pam.update_predicate_alignment(snaps[1][1].numpy(), predicate_type='attribute')
+            self._refresh_predicate_lists()
+            return
+        # the lists are built in HBM from static inputs (the KGs' triples) and two small tables: on a stream of their own, so that
+        # neither the table uploads nor the gathers queue behind the phases already enqueued on the training streams
+        if getattr(self, "_refresh_stream", None) is None:
+            self._refresh_stream = torch.cuda.Stream(device=self.device)
+        rs = self._refresh_stream
+        with torch.cuda.stream(rs):
+            pam.update_predicate_alignment(snaps[0][1].numpy())
+            pam.update_predicate_alignment(snaps[1][1].numpy(), predicate_type='attribute')
+            self._refresh_predicate_lists()
+        done = torch.cuda.Event()
+        done.record(rs)
+        for st in (torch.cuda.current_stream(), getattr(self, "_side_stream", None)):
+            if st is not None:
+                st.wait_event(done)
 
     def _refresh_neighbours(self, i):
         """Truncated negative sampling: k-NN candidate lists every `truncated_freq` epochs
@@ -316,6 +333,8 @@ class MultiKE_Late(_ScheduledMultiKE):
         super().__init__(data, args, attr_align_model)
         self.flag1, self.flag2, self.early_stop = -1, -1, False
         self.defer_predicate_update = True       # the soft predicate-alignment refresh's host work under the next epoch's kernels
+        if hasattr(self.predicate_align_model, "_refresh_device"):
+            self.predicate_align_model.device = self.device    # ... and its per-triple work in HBM (no list upload)
         self._define_variables()
         self._define_name_view_graph()
         self._define_relation_view_graph()

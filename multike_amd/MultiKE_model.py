@@ -24,7 +24,7 @@ from . import _lib
 from . import losses
 from .attr_cnn import AttrCNN
 from .runner import RelationViewRunner
-from .sampling import KGSide, KnownTripleSet, RelationBatcher
+from .sampling import KGSide, KnownTripleSet, RelationBatcher, int_triples
 from .tables import ADAGRAD_INIT_ACC, EmbeddingTable, StepEngine
 from .utils import generate_out_folder, save_embeddings
 
@@ -128,6 +128,9 @@ class _TripleList:
         self.device = device
         if self.n == 0:
             self.cols, self.w = None, None
+            return
+        if getattr(triples, "dev", None) is not None:      # base.kgs.TripleArray made in HBM (the device-side predicate refresh)
+            self.cols, self.w = triples.dev
             return
         if hasattr(triples, "cols"):          # base.kgs.TripleArray: one [n, 3] upload, the columns split on the device
             t = torch.as_tensor(triples.cols.astype(np.int32), device=device)
@@ -233,7 +236,7 @@ class MultiKE:
         sides = []
         for kg in (self.kg1, self.kg2):
             # membership only: the order in which the hash set is filled does not matter, so no sort
-            known = np.array(list(kg.local_relation_triples_set), dtype=np.int32).reshape(-1, 3)
+            known = int_triples(kg.local_relation_triples_set)
             t = torch.as_tensor(known, device=dev)
             sides.append(KGSide(kg.entities_list,
                                 KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous()), device=dev))

@@ -38,16 +38,48 @@ class TripleArray:
     and concatenated with array operations and uploaded to HBM without a per-tuple conversion.  Reads like the list it
     replaces: len(), iteration / indexing yield tuples, `a + b` concatenates."""
 
-    __slots__ = ("cols", "w")
+    __slots__ = ("_cols", "_w", "dev", "_host", "_n")
 
     def __init__(self, cols, w=None):
-        self.cols = np.ascontiguousarray(cols, dtype=np.int64).reshape(-1, 3)
-        self.w = None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
-        if self.w is not None and len(self.w) != len(self.cols):
+        self._cols = np.ascontiguousarray(cols, dtype=np.int64).reshape(-1, 3)
+        self._w = None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+        self.dev, self._host, self._n = None, None, len(self._cols)
+        if self._w is not None and len(self._w) != len(self._cols):
             raise ValueError("weights and triples differ in length")
 
+    @classmethod
+    def on_device(cls, dev_cols, dev_w, host):
+        """A list that was produced in HBM: `dev_cols` three int32 device columns, `dev_w` float32 device weights (or None) —
+        what the training loops read, without an upload — and `host()` -> (int array [n, 3], float64 weights or None), the
+        same list made on the host, called only if somebody reads the list as a list."""
+        self = cls.__new__(cls)
+        self._cols, self._w, self.dev, self._host, self._n = None, None, (tuple(dev_cols), dev_w), host, int(dev_cols[0].shape[0])
+        return self
+
+    def _materialise(self):
+        if self._cols is None:
+            cols, w = self._host()
+            self._cols = np.ascontiguousarray(cols, dtype=np.int64).reshape(-1, 3)
+            self._w = None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+            if len(self._cols) != self._n:
+                raise RuntimeError("the device-built triple list and its host form differ in length")
+
+    @property
+    def cols(self):
+        self._materialise()
+        return self._cols
+
+    @property
+    def w(self):
+        self._materialise()
+        return self._w
+
+    @property
+    def weighted(self):
+        return (self.dev[1] is not None) if self._cols is None else (self._w is not None)
+
     def __len__(self):
-        return len(self.cols)
+        return self._n
 
     def _tuple(self, i):
         h, p, t = self.cols[i].tolist()
@@ -67,6 +99,15 @@ class TripleArray:
     def __add__(self, other):
         if not isinstance(other, TripleArray):
             other = TripleArray.from_tuples(other)
+        if self.dev is not None and other.dev is not None and self.weighted == other.weighted:   # both live in HBM: so does the sum
+            import torch
+            a, b = self, other
+
+            def host():
+                c = _HostView(a) + _HostView(b)
+                return c.cols, c.w
+            return TripleArray.on_device(tuple(torch.cat([x, y]) for x, y in zip(a.dev[0], b.dev[0])),
+                                         None if a.dev[1] is None else torch.cat([a.dev[1], b.dev[1]]), host)
         if (self.w is None) != (other.w is None) and len(self) and len(other):
             raise ValueError("cannot concatenate weighted and unweighted triples")
         w = None if (self.w is None and other.w is None) else np.concatenate(
@@ -81,6 +122,11 @@ class TripleArray:
         if not triples:
             return cls(np.zeros((0, 3), dtype=np.int64))
         return cls([t[:3] for t in triples], [t[3] for t in triples] if len(triples[0]) > 3 else None)
+
+
+def _HostView(x):
+    """The same list without its device form (so that `a + _HostView(b)` concatenates on the host)."""
+    return TripleArray(x.cols, x.w)
 
 
 # ----------------------------------------------------------------------------------------------------------------

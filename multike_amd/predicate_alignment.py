@@ -209,6 +209,59 @@ class PredicateAlignModel:
             out[f"w{which}"] = TripleArray(t, np.where(hit, zoom_weight(wt[p], self.args.predicate_soft_sim), UNMATCHED_WEIGHT))
         return out
 
+    device = None      # set by a single-GPU driver: refreshes after the first build their lists in HBM (`_refresh_device`)
+
+    def _device_state(self, kind, which, t):
+        """Static per (kind, KG): the triples' columns in HBM and the number of triples per predicate on the host."""
+        import torch
+        st = self.__dict__.setdefault("_dev_state", {})
+        key = (kind, which)
+        hit = st.get(key)
+        if hit is None or hit[0] is not t:
+            cols = tuple(torch.as_tensor(np.ascontiguousarray(t[:, k]), dtype=torch.int32, device=self.device) for k in range(3))
+            hit = (t, cols, cols[1].long(), np.bincount(t[:, 1]) if len(t) else np.zeros(1, np.int64))
+            st[key] = hit
+        return hit[1:]
+
+    def _refresh_device(self, kind, id_set, t1, t2):
+        """`_refresh_arrays` with the per-triple work in HBM: the host makes the two look-up tables per KG (predicate id ->
+        matched predicate, weight: a few hundred entries), knows every list's length from the per-predicate triple counts
+        (so nothing waits for the device), and the four lists are gathered / compacted on the device in the triples' own order.
+        Weights: the float32 rounding of the float64 value per PREDICATE — what the upload of the host-made list holds.  The
+        host form of a list is made on demand by `_refresh_arrays` (nobody reads it during training)."""
+        import torch
+        dev = self.device
+        out, host_cache = {}, {}
+
+        def host(name):
+            if not host_cache:
+                host_cache.update(self._refresh_arrays(kind, id_set, t1, t2))
+            r = host_cache[name]
+            return r.cols, r.w
+
+        for which, t, own, other in ((1, t1, 0, 1), (2, t2, 1, 0)):
+            cols, p_long, per_pred = self._device_state(kind, which, t)
+            n_pred = max([len(per_pred)] + [int(link[own]) + 1 for link in id_set])
+            to = np.full(n_pred, -1, dtype=np.int32)
+            wt = np.zeros(n_pred, dtype=np.float64)
+            for link in id_set:
+                to[link[own]], wt[link[own]] = link[other], link[2]
+            m = int(per_pred[(to[:len(per_pred)] >= 0)].sum())
+            zw = np.where(to >= 0, zoom_weight(wt, self.args.predicate_soft_sim), UNMATCHED_WEIGHT).astype(np.float32)
+            to_d = torch.as_tensor(to, device=dev)
+            tab = torch.as_tensor(np.concatenate([wt.astype(np.float32), zw]), device=dev)
+            wt_d, zw_d = tab[:n_pred], tab[n_pred:]
+            if len(t):
+                idx = torch.nonzero_static(to_d[p_long] >= 0, size=m).squeeze(1)
+                pm = p_long[idx]
+                sup = (cols[0][idx], to_d[pm], cols[2][idx])
+                out[f"sup{which}"] = TripleArray.on_device(sup, wt_d[pm], lambda n_=f"sup{which}": host(n_))
+                out[f"w{which}"] = TripleArray.on_device(cols, zw_d[p_long], lambda n_=f"w{which}": host(n_))
+            else:
+                r = self._refresh_arrays(kind, id_set, t1, t2)
+                out[f"sup{which}"], out[f"w{which}"] = r[f"sup{which}"], r[f"w{which}"]
+        return out
+
     def _refresh(self, kind, alignment_set):
         kg1, kg2 = self.kgs.kg1, self.kgs.kg2
         ids1, ids2 = getattr(kg1, kind + "s_id_dict"), getattr(kg2, kind + "s_id_dict")
@@ -220,7 +273,7 @@ class PredicateAlignModel:
         a1, a2 = self._int_triples(kind, 1), self._int_triples(kind, 2)
         if a1 is not None and a2 is not None:
             link2dic(id_set)                                          # one-to-one check, as the reference asserts
-            r = self._refresh_arrays(kind, id_set, a1, a2)
+            r = (self._refresh_device if self.device is not None else self._refresh_arrays)(kind, id_set, a1, a2)
             setattr(self, f"sup_{kind}_alignment_triples1", r["sup1"])
             setattr(self, f"sup_{kind}_alignment_triples2", r["sup2"])
             setattr(self, f"{kind}_triples_w_weights1", r["w1"])

@@ -98,6 +98,23 @@ def sample_negatives(pos, side: KGSide, neg_per_pos: int, seed=(0, 0), stream_id
     return out
 
 
+def int_triples(triples) -> np.ndarray:
+    """(h, r, t) id triples — an array, or the reference's list / set of tuples — as an int32 array [n, 3].  Tuples go through one
+    flat iterator (np.asarray of 700K tuples builds 700K temporary rows: 0.23 s against 0.07)."""
+    if isinstance(triples, np.ndarray) or hasattr(triples, "__array__"):
+        return np.asarray(triples, dtype=np.int32).reshape(-1, 3)
+    if hasattr(triples, "cols"):
+        return np.asarray(triples.cols, dtype=np.int32).reshape(-1, 3)
+    import itertools
+    n = len(triples)
+    if n == 0:
+        return np.zeros((0, 3), dtype=np.int32)
+    first = next(iter(triples))
+    if len(first) != 3:
+        return np.asarray(list(triples), dtype=np.int32).reshape(-1, 3)
+    return np.fromiter(itertools.chain.from_iterable(triples), dtype=np.int64, count=3 * n).reshape(n, 3).astype(np.int32)
+
+
 class RelationBatcher:
     """Epoch/step bookkeeping of the relation view on device.
 
@@ -107,8 +124,8 @@ class RelationBatcher:
     def __init__(self, triples1, triples2, side1: KGSide, side2: KGSide, batch_size: int, neg_per_pos: int,
                  device="cuda", seed: int = 0):
         self.device = torch.device(device)
-        self.t1 = torch.as_tensor(np.asarray(triples1, dtype=np.int32).reshape(-1, 3), device=self.device)
-        self.t2 = torch.as_tensor(np.asarray(triples2, dtype=np.int32).reshape(-1, 3), device=self.device)
+        self.t1 = torch.as_tensor(int_triples(triples1), device=self.device)
+        self.t2 = torch.as_tensor(int_triples(triples2), device=self.device)
         self.side1, self.side2 = side1, side2
         self.batch_size, self.neg_per_pos = int(batch_size), int(neg_per_pos)
         self.n1, self.n2 = self.t1.shape[0], self.t2.shape[0]

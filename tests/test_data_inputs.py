@@ -165,3 +165,32 @@ def test_levenshtein_matrix_against_scalar_dp():
         for j, b in enumerate(names2):
             want = 1.0 if len(a) + len(b) == 0 else 2.0 * lcs(a, b) / (len(a) + len(b))
             assert abs(m[i, j] - want) < 1e-15, (a, b)
+
+
+def test_predicate_refresh_built_on_the_device_equals_the_host_lists(folder):
+    """`PredicateAlignModel.device` set (what the single-GPU drivers do): a refresh gathers / compacts its four lists with tensor
+    operations (torch CPU tensors here) — same triples in the same order, weights = the float32 of the host's float64, and the
+    list still reads as the reference's list (host form on demand) and still matches the reference-made fixture."""
+    import torch
+    g = GOLD["predicate_alignment"]
+    k = read_kgs_from_folder(folder, "631/", "swapping", True)
+    args = types.SimpleNamespace(training_data=folder, predicate_init_sim=0.9, predicate_soft_sim=0.85)
+    host, dev = pa.PredicateAlignModel(k, args), pa.PredicateAlignModel(k, args)
+    dev.device = torch.device("cpu")
+    for p in (host, dev):
+        p.update_predicate_alignment(np.asarray(g["rel_embed"]))
+    for name in ("sup_relation_alignment_triples1", "sup_relation_alignment_triples2", "relation_triples_w_weights1",
+                 "relation_triples_w_weights2"):
+        a, b = getattr(host, name), getattr(dev, name)
+        assert b.dev is not None and a.dev is None and len(a) == len(b) and len(a) > 0
+        cols, w = b.dev
+        assert np.array_equal(np.stack([c.numpy() for c in cols], axis=1), a.cols.astype(np.int32))
+        assert np.array_equal(w.numpy(), a.w.astype(np.float32))
+        assert np.array_equal(b.cols, a.cols) and np.array_equal(b.w, a.w) and list(b[:3]) == list(a[:3])
+    both = dev.sup_relation_alignment_triples1 + dev.sup_relation_alignment_triples2
+    want = host.sup_relation_alignment_triples1 + host.sup_relation_alignment_triples2
+    assert both.dev is not None and len(both) == len(want)
+    assert np.array_equal(torch.stack(both.dev[0], dim=1).numpy(), want.cols.astype(np.int32)) and np.array_equal(both.cols, want.cols)
+    got = _snap(dev)
+    for key in ("sup_rel1", "sup_rel2", "rel_w1", "relation_alignment_set"):
+        _close(got[key], g["refreshed"][key])

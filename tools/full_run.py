@@ -1,6 +1,6 @@
 """The reference's run_ITC.py / run_SSL.py flow at DBP-WD-100K scale on a synthetic dataset folder, timed phase by phase.
 python tools/full_run.py [n_pairs] [max_epoch] [ITC|SSL]"""
-import os, sys, tempfile, time, contextlib, io
+import os, sys, tempfile, time, contextlib, io, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multike_amd.data_model import DataModel
 from multike_amd.MultiKE_CSL import MultiKE_CV
@@ -42,18 +42,50 @@ print(f"DataModel {t_data:.1f}s (entities {k.entities_num}, relation triples {k.
       f"{k.kg1.attribute_triples_num}+{k.kg2.attribute_triples_num}, literals {len(data.literal_list)}); PredicateAlignModel {t_pam:.1f}s")
 t = time.time()
 buf = io.StringIO()
+wall = collections.OrderedDict()
 with contextlib.redirect_stdout(buf):
+    cprof = None
+    if os.environ.get("FULL_RUN_TIMELINE") == "1":
+        import cProfile, pstats
+        cprof = cProfile.Profile(); cprof.enable()
     model = (MultiKE_CV if method == "ITC" else MultiKE_Late)(data, args, pam)
+    if os.environ.get("FULL_RUN_HOST_REFRESH") == "1":     # A/B: the predicate refresh's per-triple work on the host (as before round 4)
+        pam.device = None
+    torch.cuda.synchronize(); t_ctor = time.time() - t
+    if cprof:
+        cprof.disable()
+    if os.environ.get("FULL_RUN_TIMELINE") == "1":   # host wall time inside each call of run()'s loop (no synchronisation added)
+        def timed(name):
+            f = getattr(model, name)
+            def g(*a_, **k_):
+                t0 = time.time()
+                try:
+                    return f(*a_, **k_)
+                finally:
+                    e = wall.setdefault(name, [0, 0.0, 0.0]); dt = time.time() - t0
+                    e[0] += 1; e[1] += dt; e[2] = max(e[2], dt)
+            setattr(model, name, g)
+        for nm in ("_prepare", "_test", "_train_views", "train_common_space_learning_1epo", "_valid", "_update_predicate_alignment",
+                   "_finish_predicate_update", "_refresh_neighbours", "save", "_join_save", "train_relation_view_1epo",
+                   "train_attribute_view_1epo", "train_cross_kg_entity_inference_relation_view_1epo",
+                   "train_cross_kg_entity_inference_attribute_view_1epo", "train_cross_kg_relation_inference_1epo",
+                   "train_cross_kg_attribute_inference_1epo"):
+            if hasattr(model, nm):
+                timed(nm)
     if prof: prof.enable()
     res = model.run()
     if prof: prof.disable()
 torch.cuda.synchronize()
 if prof:
     pstats.Stats(prof).sort_stats("tottime").print_stats(40)
-print(f"{type(model).__name__}.run(): {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
+print(f"{type(model).__name__}: constructor {t_ctor:.2f}s + run() {time.time() - t - t_ctor:.2f}s = {time.time() - t:.1f}s for {epochs} epochs (validation from epoch 100 every 10, k-NN refresh every 20, predicate refresh every 10, final save + 4 tests)")
 print("test Hits@1:", {k_: round(float(v), 3) for k_, v in res.items()})
 log = buf.getvalue().splitlines()
-import re, collections
+import re
+if cprof:
+    print("the constructor:"); pstats.Stats(cprof).sort_stats("cumulative").print_stats(22)
+if wall:
+    print("host wall time by call of run()'s loop: " + " | ".join(f"{k} {v[0]} x, {v[1]:.3f} s (max {v[2] * 1e3:.0f} ms)" for k, v in wall.items()))
 agg = collections.OrderedDict()
 for l in log:
     m = re.match(r"epoch \d+ of (.*?), avg\. loss: .*?time: ([0-9.]+)s", l)

@@ -167,7 +167,15 @@ for c in range(cases // 4):
             if abs(got[s] - L) > 5e-5 * abs(L):
                 report("MAPPING", c, desc, f"step {s} loss {got[s]} vs {L}")
         if not np.allclose(ent.raw().cpu().numpy(), E, rtol=3e-4, atol=2e-6 + 3e-5 * np.abs(E).max()):
-            report("MAPPING", c, desc, f"ent max diff {np.abs(ent.raw().cpu().numpy() - E).max():.2e}")
+            # yardstick: the same oracle replayed in float32 (NumPy order) on the same batches — rows read through l2_normalize with
+            # ||w||^2 << lr W make the Adagrad step expand rounding noise (EXPERIMENTS R4.2); a kernel fault would not show up in it
+            E32 = ent0.astype(np.float32); accE32 = np.full_like(E32, 0.1)
+            tabs32 = [(t.astype(np.float32), tr) for t, tr in ((lit, False), (v0[1], True), (v0[2], True))]
+            M32 = [m.astype(np.float32) for m in Ms]; accM32 = [np.full_like(m, 0.1) for m in M32]
+            for s in range(steps):
+                mo.space_mapping_step_dense(E32, accE32, tabs32, M32, accM32, idx[s], np.float32(0.01), np.float32(ow))
+            report("MAPPING", c, desc, f"ent max diff {np.abs(ent.raw().cpu().numpy() - E).max():.2e} (the float32 replay of the oracle: "
+                                       f"{np.abs(E32.astype(np.float64) - E).max():.2e}; median row norm {np.median(np.linalg.norm(E, axis=1)):.4f})")
         for k in range(3):
             if not np.allclose(st.M[k].cpu().numpy(), M64[k], rtol=3e-4, atol=3e-6):
                 report("MAPPING", c, desc, f"M{k} max diff {np.abs(st.M[k].cpu().numpy() - M64[k]).max():.2e}")

@@ -18,10 +18,12 @@ print(len(rows), "dispatches from the first training epoch on")
 busy = 0; cur_s, cur_e = rows[0][0], rows[0][1]
 gaps = []
 prev_n = rows[0][2][:40]
-for s, e, n in rows[1:]:
+short = lambda x: x.replace("_ZN2at6native", "at::").replace("_ZN3mke", "mke::")[:34]
+for k_, (s, e, n) in enumerate(rows[1:], 1):
     n = n[:40]
     if s > cur_e:
-        busy += cur_e - cur_s; gaps.append((s - cur_e, cur_e, prev_n + "  ->  " + n)); cur_s, cur_e = s, e
+        after = " ".join(short(r[2]) for r in rows[k_ + 1:k_ + 5]) if s - cur_e > 1e7 else ""   # what the host enqueued next: names the call
+        busy += cur_e - cur_s; gaps.append((s - cur_e, cur_e, prev_n + "  ->  " + n + ("  | then " + after if after else ""))); cur_s, cur_e = s, e
     else:
         cur_e = max(cur_e, e)
     prev_n = n
