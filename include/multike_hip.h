@@ -64,6 +64,9 @@ const char* mke_last_error(void);
  *                     0 = tail backward, the two products and the convolution backward as launches of their own (6)
  *   "oc_score_quarter" : mke_oc_score with a quarter-wave per positive (four positives per wavefront) instead of a wavefront:
  *                     -1 = by shape (default: n_ranks >= 4, neg_per_pos <= 8 n_ranks, stride <= 128), 0 = never, 1 = always
+ *   "sampler_fast"  : mke_neg_sample*: 1 (default) = a round's coin block evaluated in the idle last lane of the group's draw
+ *                     evaluation and duplicates among first draws found through an LDS table; 0 = separate coin evaluation and
+ *                     a shuffle loop.  Same Philox stream, same output bit for bit
  *   "deterministic" : 1 = the host side (tables.StepEngine) takes the deterministic path below (read by the caller; the
  *                     kernels themselves are selected by which entry point is called)
  *   "score_half_groups" : largest neg_per_pos for which mke_triple_score_fwd_bwd scores TWO groups per wavefront (one per

@@ -35,6 +35,7 @@ int g_count_in_score = 1;    // runner: the next step's reference counting rides
 int g_score_lane_ids = 1;    // training kernel: a group's ids and reference counts fetched once, one negative per lane (mke_score.hip)
 int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on large tables: 0 = by table size, 16, 64
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
+int g_sampler_fast = 1;      // mke_sampler.hip: coin block in the draw evaluation's idle lane, LDS duplicate test (0: the earlier form)
 extern int g_attr_fused_bwd;     // mke_attr_cnn.hip: dflat product inside the convolution-backward launch, dW on rider blocks
 extern int g_oc_score_quarter;   // mke_oc.hip: quarter-wave per positive in the owner-computes score kernel: -1 = by shape, 0 / 1
 }
@@ -81,14 +82,9 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
     mke::g_attr_fused_bwd = value != 0;
     return MKE_OK;
   }
-  if (!strcmp(name, "oc_score_quarter")) {
-    if (old_value) *old_value = mke::g_oc_score_quarter;
-    mke::g_oc_score_quarter = value < 0 ? -1 : (value != 0);
-    return MKE_OK;
-  }
-  if (!strcmp(name, "attr_fused_bwd")) {
-    if (old_value) *old_value = mke::g_attr_fused_bwd;
-    mke::g_attr_fused_bwd = value != 0;
+  if (!strcmp(name, "sampler_fast")) {
+    if (old_value) *old_value = mke::g_sampler_fast;
+    mke::g_sampler_fast = value != 0;
     return MKE_OK;
   }
   if (!strcmp(name, "deterministic")) {

@@ -8,7 +8,7 @@
 // indexed by (positive, round, slot, attempt), so any positive can be sampled by any wavefront in any
 // order and the CPU oracle (oracle/sampler_oracle.py) reproduces the device output bit for bit.
 //
-// Shape: one group of 32 lanes (neg_per_pos <= 32: two positives per wavefront) or 64 lanes per positive, lane q of
+// Shape: one group of 16 (neg_per_pos <= 15: four positives per wavefront), 32 (<= 32: two) or 64 lanes per positive, lane q of
 // the group = slot q of the round (neg_per_pos <= 64).
 #include "mke_common.h"
 
@@ -61,9 +61,20 @@ __device__ __forceinline__ bool set_contains(const uint64_t* __restrict__ keys, 
 // GS lanes per positive (GS = 32 when neg_per_pos <= 32: two positives per wavefront, else 64).  Everything that is
 // per positive (round count, collected, coin, candidate list) lives in the group's lanes; wave-wide primitives
 // (__shfl, __ballot) are used with group-relative indices / masks.
-template <int GS>
+//
+// FAST (round 4; same stream, same output bit for bit — the kernel is bound by VALU issue, 32-bit integer multiplies being
+// quarter rate: two Philox4x32-10 evaluations = 80 of them per round):
+//  * the round's coin block (counter word 2 = 0xFFFFFFFF) is evaluated by the group's LAST lane in the same Philox
+//    evaluation in which lanes < need evaluate their first draw block (word 2 = slot) — one evaluation per round instead
+//    of two; needs an idle lane (neg_per_pos < GS), else the coin keeps its own evaluation;
+//  * "is any first draw a duplicate of an earlier slot's" is answered by inserting the draws into a 2 GS-slot open-addressing
+//    table of the group in LDS (compare-and-swap, ~1.2 probes) instead of neg_per_pos rounds of shuffles; the exact sequential
+//    fix-up below runs only when the table saw an equal value (0.3 % of the groups at 25 draws from 100K).
+template <int GS, bool FAST>
 __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) {
   constexpr int PPW = 64 / GS;
+  constexpr int TS = 2 * GS;                                // slots of a group's duplicate table
+  __shared__ uint32_t s_dup[FAST ? (MKE_BLOCK / GS) * TS : 1];
   const int lane = threadIdx.x & 63;
   const int gl = lane & (GS - 1);        // slot inside the group
   const int gbase = lane & ~(GS - 1);    // first lane of the group
@@ -83,21 +94,56 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_neg_sample(const SampleParams p) 
   for (int round = 0; round < p.max_try; ++round) {
     if (!__ballot(collected < N)) break;  // every positive of the wave is done
     const int need = N - collected;       // 0 for finished groups
-    const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, sid, p.seed_lo, p.seed_hi);
-    const bool corrupt_head = (cph.v[0] >> 31) != 0;
+    const bool active = gl < need;
+    const bool merged = FAST && N < GS;   // the group's last lane is never a draw lane: it evaluates the coin block
+    bool corrupt_head;
+    uint32_t first_word = 0;
+    if (merged) {
+      const Philox4 ph = philox4x32_10(gi, (uint32_t)round, gl == GS - 1 ? 0xFFFFFFFFu : (uint32_t)gl, sid, p.seed_lo, p.seed_hi);
+      first_word = ph.v[0];               // draw lanes: attempt 0 = word 0 of block 0 of (positive, round, slot)
+      corrupt_head = ((uint32_t)__shfl((int)ph.v[0], gbase + GS - 1, 64) >> 31) != 0;
+    } else {
+      const Philox4 cph = philox4x32_10(gi, (uint32_t)round, 0xFFFFFFFFu, sid, p.seed_lo, p.seed_hi);
+      corrupt_head = (cph.v[0] >> 31) != 0;
+    }
     const int x = corrupt_head ? h : t;
     const bool use_tbl = sd.cand_table != nullptr && (sd.cand_valid == nullptr || sd.cand_valid[x] != 0);
     const uint32_t n = use_tbl ? (uint32_t)sd.cand_k : (uint32_t)sd.n_ent;
-    const bool active = gl < need;
     uint32_t attempt = 0;
     uint32_t pos = 0xFFFFFFFFu;
-    if (active) pos = draw_next(gi, (uint32_t)round, (uint32_t)gl, sid, p.seed_lo, p.seed_hi, n, attempt);
+    if (active) {
+      bool have = false;
+      if (merged) {                       // draw_next's first iteration on the word already at hand
+        attempt = 1;
+        const uint64_t m = (uint64_t)first_word * (uint64_t)n;
+        const uint32_t l = (uint32_t)m;
+        have = l >= n || l >= (0u - n) % n;
+        pos = (uint32_t)(m >> 32);
+      }
+      if (!have) pos = draw_next(gi, (uint32_t)round, (uint32_t)gl, sid, p.seed_lo, p.seed_hi, n, attempt);
+    }
     // duplicate detection among first draws (q runs to the largest `need` of the wave)
-    const int need_max = max(need, __shfl_xor(need, 32, 64));
+    int need_max = max(need, __shfl_xor(need, 32, 64));
+    if (GS == 16) need_max = max(need_max, __shfl_xor(need_max, 16, 64));
     bool dup = false;
-    for (int q = 0; q < need_max; ++q) {
-      const uint32_t v = (uint32_t)__shfl((int)pos, gbase + q, 64);
-      dup |= active && q < need && gl > q && pos == v;
+    if (FAST) {
+      uint32_t* tbl = s_dup + (threadIdx.x / GS) * TS;
+      tbl[gl] = 0xFFFFFFFFu;
+      tbl[gl + GS] = 0xFFFFFFFFu;
+      if (active) {
+        uint32_t sl = (pos * 0x9E3779B1u) >> (32 - (GS == 16 ? 5 : GS == 32 ? 6 : 7));
+        for (;;) {
+          const uint32_t old = atomicCAS(&tbl[sl], 0xFFFFFFFFu, pos);
+          if (old == 0xFFFFFFFFu) break;
+          if (old == pos) { dup = true; break; }
+          sl = (sl + 1) & (TS - 1);
+        }
+      }
+    } else {
+      for (int q = 0; q < need_max; ++q) {
+        const uint32_t v = (uint32_t)__shfl((int)pos, gbase + q, 64);
+        dup |= active && q < need && gl > q && pos == v;
+      }
     }
     if (__ballot(dup)) {
       // sequential without-replacement semantics: slot q must differ from the final draws of slots < q
@@ -159,6 +205,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_tripleset_query(const int32_t* __
 }  // namespace mke
 
 namespace mke {
+extern int g_sampler_fast;  // mke_set_option("sampler_fast"): 0 = the two-evaluation / shuffle-loop form (A/B)
 int validate_side(const mke_kg_side& sd, int neg_per_pos) {
   // random.sample raises ValueError when the population is smaller than the sample (batch.py:98,101)
   if (sd.n_ent < neg_per_pos) { set_error("candidate population (%d) smaller than neg_per_pos (%d)", sd.n_ent, neg_per_pos); return MKE_E_SHAPE; }
@@ -178,10 +225,19 @@ int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t*
   p.side[1] = pos_kg ? sides[1] : sides[0];
   p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.sid = stream_id;
   p.nh = neg_h; p.nr = neg_r; p.nt = neg_t;
-  const int64_t pos_per_block = (MKE_BLOCK / 64) * (neg_per_pos <= 32 ? 2 : 1);
+  // lanes per positive: 16 (four positives per wavefront; fast form only, which needs an idle lane: neg_per_pos <= 15), 32, 64
+  const int gs = (g_sampler_fast && neg_per_pos <= 15) ? 16 : (neg_per_pos <= 32 ? 32 : 64);
+  const int64_t pos_per_block = (MKE_BLOCK / 64) * (64 / gs);
   const int64_t blocks = (n_pos + pos_per_block - 1) / pos_per_block;
-  if (neg_per_pos <= 32) hipLaunchKernelGGL((k_neg_sample<32>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
-  else hipLaunchKernelGGL((k_neg_sample<64>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, p);
+  const dim3 grid((unsigned)blocks), blk(MKE_BLOCK);
+  if (g_sampler_fast) {
+    if (gs == 16) hipLaunchKernelGGL((k_neg_sample<16, true>), grid, blk, 0, st, p);
+    else if (gs == 32) hipLaunchKernelGGL((k_neg_sample<32, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((k_neg_sample<64, true>), grid, blk, 0, st, p);
+  } else {
+    if (gs == 32) hipLaunchKernelGGL((k_neg_sample<32, false>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((k_neg_sample<64, false>), grid, blk, 0, st, p);
+  }
   return check_launch("k_neg_sample");
 }
 

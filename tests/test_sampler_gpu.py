@@ -92,12 +92,14 @@ def test_bit_exact_full_batch_and_invariants():
     assert chi2 < 100, chi2  # 49 dof: P(chi2 > 100) ~ 2e-5
 
 
-def test_small_population_many_duplicates():
-    """population barely larger than the sample: exercises the without-replacement fix-up path."""
+@pytest.mark.parametrize("N,n", [(30, 33), (12, 14), (15, 16), (16, 19), (32, 34), (50, 52), (63, 64), (64, 66)])
+def test_small_population_many_duplicates(N, n):
+    """population barely larger than the sample: exercises the without-replacement fix-up path — in every group shape of the
+    kernel (16 / 32 / 64 lanes per positive, with and without an idle lane for the coin block)."""
     from gpu_util import dev_i32
     from multike_amd.sampling import KGSide, sample_negatives
     rng = np.random.default_rng(1)
-    P, N, n = 300, 30, 33
+    P = 300
     ph, pr, pt = rng.integers(0, n, P), rng.integers(0, 4, P), rng.integers(0, n, P)
     side = KGSide(np.arange(n), None)
     got = [x.cpu().numpy() for x in sample_negatives(tuple(dev_i32(a) for a in (ph, pr, pt)), side, N, seed=(2, 2))]
@@ -149,3 +151,33 @@ def test_sample_distinct_bit_exact_and_distinct():
     with pytest.raises(_lib.MultiKEHipError, match="batch <= n"):
         _lib.sample_distinct(5, 6, 1)
     assert _lib.sample_distinct(5, 0, 3).shape == (3, 0)
+
+
+def test_fast_and_plain_kernel_forms_are_the_same_stream():
+    """`sampler_fast` (coin block in the draw evaluation's idle lane, LDS duplicate table, 16-lane groups) is a
+    performance option: the output is the plain form's, bit for bit, at every group shape, with and without the known-triple
+    filter and the truncated-sampling candidate table."""
+    from gpu_util import dev_i32
+    from multike_amd import _lib
+    from multike_amd.sampling import KGSide, KnownTripleSet, sample_negatives
+    rng = np.random.default_rng(11)
+    n, P = 700, 1999
+    tri = np.stack([rng.integers(0, n, 6000), rng.integers(0, 9, 6000), rng.integers(0, n, 6000)], axis=1).astype(np.int32)
+    ks = KnownTripleSet(dev_i32(tri[:, 0]), dev_i32(tri[:, 1]), dev_i32(tri[:, 2]))
+    pos = tuple(dev_i32(tri[:P, k]) for k in range(3))
+    try:
+        for N in (1, 7, 15, 16, 25, 31, 32, 33, 63, 64):
+            for near in (False, True):
+                side = KGSide(np.arange(n), ks)
+                if near:
+                    K = 70
+                    tab = np.stack([rng.choice(n, K, replace=False) for _ in range(n)]).astype(np.int32)
+                    side.set_neighbours(dev_i32(tab), torch.as_tensor((np.arange(n) % 4 != 0).astype(np.uint8), device="cuda"))
+                outs = []
+                for fast in (0, 1):
+                    _lib.set_option("sampler_fast", fast)
+                    outs.append([x.cpu().numpy() for x in sample_negatives(pos, side, N, seed=(5, N), stream_id=2, pos_offset=31)])
+                for a, b in zip(*outs):
+                    assert np.array_equal(a, b), (N, near)
+    finally:
+        _lib.set_option("sampler_fast", 1)
