@@ -738,7 +738,10 @@ def main():
         if not np.isfinite(ep_loss):
             raise SystemExit(f"bench.py: non-finite loss {ep_loss} on the sharded path")
         roofline = roofline_object("k_oc_score" if shard_mode != "rowfetch" else "k_triple_score", ms, tr, d, None)
-        roofline.update({"scope": "per GPU (rank 0): the triples whose corrupt entity this rank owns", "exchange": shard_info})
+        roofline.update({"scope": "per GPU (rank 0): the triples whose corrupt entity this rank owns", "exchange": shard_info,
+                         "basis_note": "the algorithmic model counts 3 rows read + 3 written per scored triple; the owner-computes kernel "
+                                       "reads 2 vectors per POSITIVE and one row per negative, so this fraction overstates its traffic "
+                                       "(it can exceed 1) — a rate in the model's bytes, not a measurement of the memory system"})
 
     if rank == 0:
         out = {

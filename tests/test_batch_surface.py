@@ -178,3 +178,19 @@ def test_uniform_over_candidates_chi_square(sampler_golden):
     exp = n_draws / len(e1)
     chi2 = float(((counts[e1] - exp) ** 2 / exp).sum())
     assert chi2 < 2.2 * len(e1), chi2                                            # 49 dof: p ~ 1e-6 at 110
+
+
+def test_int_triples_accepts_arrays_lists_sets_and_triple_arrays():
+    """`sampling.int_triples`: the reference's containers of (h, r, t) tuples (list, set), arrays and `TripleArray`s all become the
+    same int32 [n, 3] array; weighted 4-tuples keep their first three columns only through the generic path."""
+    from multike_amd.base.kgs import TripleArray
+    from multike_amd.sampling import int_triples
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 1000, size=(257, 3)).astype(np.int64)
+    lst = [tuple(int(x) for x in r) for r in a]
+    for form in (a, a.astype(np.int32), lst, TripleArray(a)):
+        got = int_triples(form)
+        assert got.dtype == np.int32 and got.shape == (257, 3) and np.array_equal(got, a)
+    got = int_triples(set(lst))
+    assert got.dtype == np.int32 and sorted(map(tuple, got.tolist())) == sorted(set(lst))
+    assert int_triples([]).shape == (0, 3) and int_triples(set()).shape == (0, 3)
