@@ -96,3 +96,40 @@ def test_views_learn_alignment_from_shared_structure(tmp_path):
     assert before["rv"] < 0.02 and before["av"] < 0.02
     assert after["nv"] == before["nv"]                       # the name view is a constant table
     assert after["rv"] > 0.8 and after["av"] > 0.5 and after["final"] > 0.7, (before, after)
+
+
+def test_predicate_refresh_in_hbm_equals_the_host_lists(tmp_path):
+    """After DataModel (attribute values are ids: both predicate kinds take the array path), a soft predicate-alignment refresh
+    with `PredicateAlignModel.device` set builds its eight lists on the GPU: same triples in the same order, weights = the float32
+    of the host's float64, for relations AND attributes; the concatenations the drivers train on stay in HBM."""
+    import torch
+    from multike_amd.data_model import DataModel
+    from multike_amd.predicate_alignment import PredicateAlignModel
+    from multike_amd.synthetic import write_dataset_folder
+    folder = str(tmp_path) + "/"
+    wf = write_dataset_folder(folder)
+    args = _args(folder, wf)
+    data = DataModel(args)
+    host, dev = PredicateAlignModel(data.kgs, args), PredicateAlignModel(data.kgs, args)
+    dev.device = torch.device("cuda")
+    rng = np.random.default_rng(2)
+    rel = rng.standard_normal((data.kgs.relations_num, args.dim))
+    attr = rng.standard_normal((data.kgs.attributes_num, args.dim))
+    for p in (host, dev):
+        p.update_predicate_alignment(rel)
+        p.update_predicate_alignment(attr, predicate_type="attribute")
+    seen = 0
+    for kind in ("relation", "attribute"):
+        for name in (f"sup_{kind}_alignment_triples1", f"sup_{kind}_alignment_triples2", f"{kind}_triples_w_weights1",
+                     f"{kind}_triples_w_weights2"):
+            a, b = getattr(host, name), getattr(dev, name)
+            assert a.dev is None and b.dev is not None and len(a) == len(b)
+            cols, w = b.dev
+            assert cols[0].is_cuda and np.array_equal(torch.stack(cols, dim=1).cpu().numpy(), a.cols.astype(np.int32))
+            assert np.array_equal(w.cpu().numpy(), a.w.astype(np.float32))
+            seen += len(a)
+    assert seen > 0
+    both = dev.sup_attribute_alignment_triples1 + dev.sup_attribute_alignment_triples2
+    want = host.sup_attribute_alignment_triples1 + host.sup_attribute_alignment_triples2
+    assert both.dev is not None and np.array_equal(torch.stack(both.dev[0], dim=1).cpu().numpy(), want.cols.astype(np.int32))
+    assert np.array_equal(both.cols, want.cols) and np.array_equal(both.w, want.w)
