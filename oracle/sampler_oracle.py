@@ -34,9 +34,10 @@ def mt_epoch_slice(triples, batch_size, step):
     return triples[lo:min(lo + batch_size, len(triples))]
 
 
-def _mt_one_positive(h, r, t, known, everyone, want, near, max_try):
+def _mt_one_positive(h, r, t, known, everyone, want, near, max_try, stats=None):
     """Rounds for one positive — code/base/batch.py:91-112.  RNG call order is part of the contract:
-    one np.random.binomial(1, 0.5), then one random.sample(candidates, still_needed), per round."""
+    one np.random.binomial(1, 0.5), then one random.sample(candidates, still_needed), per round.
+    `stats` (tests/test_sampler_oracle.py): a dict whose "rounds" list receives the rounds this positive used."""
     got = []
     pool_h = near.get(h, everyone)
     pool_t = near.get(t, everyone)
@@ -54,15 +55,17 @@ def _mt_one_positive(h, r, t, known, everyone, want, near, max_try):
             break
         missing = want - len(got)
     assert len(got) == want
+    if stats is not None:
+        stats.setdefault("rounds", []).append(attempt + 1)
     return got
 
 
-def mt_negatives(pos_batch, known, everyone, want, near=None, max_try=10):
+def mt_negatives(pos_batch, known, everyone, want, near=None, max_try=10, stats=None):
     """code/base/batch.py:86-116 generate_neg_triples_fast."""
     near = {} if near is None else near
     out = []
     for (h, r, t) in pos_batch:
-        out.extend(_mt_one_positive(h, r, t, known, everyone, want, near, max_try))
+        out.extend(_mt_one_positive(h, r, t, known, everyone, want, near, max_try, stats))
     assert len(out) == want * len(pos_batch)
     return out
 
@@ -125,9 +128,12 @@ def triple_key(h, r, t):
 
 
 def philox_negatives(pos_h, pos_r, pos_t, want, n_all, ent_lo=0, ent_list=None, cand_table=None, cand_valid=None,
-                     known=None, seed=(0, 0), stream_id=0, pos_offset=0, max_try=10):
+                     known=None, seed=(0, 0), stream_id=0, pos_offset=0, max_try=10, stats=None, _coin_per_slot=False):
     """Specification of mke_neg_sample.  `known` is a Python set of (h, r, t) or None.
-    Returns int32 arrays (neg_h, neg_r, neg_t) of length len(pos_h) * want."""
+    Returns int32 arrays (neg_h, neg_r, neg_t) of length len(pos_h) * want.
+    `stats`: a dict whose "rounds" list receives the rounds each positive used.  `_coin_per_slot=True` is a deliberately
+    WRONG variant (one coin per negative instead of one per round) that exists only so that
+    tests/test_sampler_oracle.py can show its two-sample tests have the power to reject it."""
     k0, k1 = seed[0] & _MASK, seed[1] & _MASK
     P = len(pos_h)
     nh = np.zeros(P * want, dtype=np.int32)
@@ -137,10 +143,11 @@ def philox_negatives(pos_h, pos_r, pos_t, want, n_all, ent_lo=0, ent_list=None, 
     for i in range(P):
         h, r, t = int(pos_h[i]), int(pos_r[i]), int(pos_t[i])
         gi = (i + pos_offset) & _MASK
-        got = 0
+        got = used = 0
         for rnd in range(max_try):
             if got >= want:
                 break
+            used += 1
             need = want - got
             coin = philox4x32_10(gi, rnd, _MASK, stream_id, k0, k1)[0] >> 31
             x = h if coin else t
@@ -153,7 +160,10 @@ def philox_negatives(pos_h, pos_r, pos_t, want, n_all, ent_lo=0, ent_list=None, 
                 while p in finals:  # without replacement: differ from every earlier slot's final draw
                     p = dr.next()
                 finals.append(p)
-            for p in finals:
+            for slot, p in enumerate(finals):
+                if _coin_per_slot:
+                    coin = philox4x32_10(gi, rnd, (_MASK - 1 - slot) & _MASK, stream_id, k0, k1)[0] >> 31
+                    x = h if coin else t
                 if use_tbl:
                     e = int(cand_table[x, p])
                 elif ent_list is not None:
@@ -167,6 +177,8 @@ def philox_negatives(pos_h, pos_r, pos_t, want, n_all, ent_lo=0, ent_list=None, 
                 nh[o], nr[o], nt[o] = cand[0], cand[1], cand[2]
                 got += 1
         assert got == want
+        if stats is not None:
+            stats.setdefault("rounds", []).append(used)
     return nh, nr, nt
 
 
