@@ -72,6 +72,11 @@ def parse():
                     help="whole untimed epochs run BEFORE the --warmup steps (clocks, caches, first launches); the timed region "
                          "is unchanged: exactly --steps complete steps")
     ap.add_argument("--cpu-steps", type=int, default=360, help="upper bound of steps per cpu_baseline leg")
+    ap.add_argument("--windows", type=int, default=None,
+                    help="how many times the --steps window is timed (same bracket every time; `value` = the median window, the "
+                         "first window is reported beside it).  Default: as many as make the timed work >= 60 ms, at least 50 "
+                         "for windows of <= 100 steps, 5 otherwise")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the head / tail entities of the synthetic triples (0 = uniform)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     for k in ("n_ent", "n_rel", "dim", "neg", "batch"):
@@ -350,7 +355,7 @@ def pmc_traffic(config, custom=False):
     and on this workload; None otherwise."""
     if custom:
         return None
-    for rnd in ("r04", "r03", "r02"):          # newest round first; a file is quoted only for the build it was collected on
+    for rnd in ("r05", "r04", "r03", "r02"):          # newest round first; a file is quoted only for the build it was collected on
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{config}.json")) as f:
                 pmc = json.load(f)
@@ -361,24 +366,75 @@ def pmc_traffic(config, custom=False):
     return None
 
 
+def _windows(w, first, steps, n_win):
+    """n_win windows of `steps` steps each (every one inside an epoch), the bracket of FusedWorkload.timed"""
+    dts, scored = [], []
+    i = first
+    for _ in range(n_win):
+        i = w.window_start(i, steps)
+        dts.append(w.timed(i, steps))
+        scored.append(sum(w.triples_of(k) for k in range(i, i + steps)))
+        i += steps
+    dts, scored = np.array(dts), np.array(scored)
+    mid = int(np.argsort(dts)[len(dts) // 2])
+    stats = {"n": int(n_win), "steps_per_window": int(steps), "min": float(dts.min() * 1e3), "p10": float(np.percentile(dts, 10) * 1e3),
+             "median": float(dts[mid] * 1e3), "p90": float(np.percentile(dts, 90) * 1e3), "max": float(dts.max() * 1e3)}
+    return float(dts[mid]), int(scored[mid]), stats, i
+
+
+def launch_histogram(ms, width_us=None):
+    """Histogram of the per-launch durations of the instrumented pass (HIP events), in us."""
+    us = np.asarray(ms) * 1e3
+    if width_us is None:
+        width_us = max(0.5, round(float(np.ptp(us)) / 12, 1)) if len(us) > 1 else 1.0
+    lo = np.floor(us.min() / width_us) * width_us
+    edges = lo + width_us * np.arange(int(np.ceil((us.max() - lo) / width_us)) + 2)
+    h, _ = np.histogram(us, bins=edges)
+    return {"bin_us": float(width_us), "first_edge_us": float(lo), "counts": [int(x) for x in h[:max(1, int(np.nonzero(h)[0].max()) + 1)]],
+            "min_us": float(us.min()), "p10_us": float(np.percentile(us, 10)), "median_us": float(np.median(us)),
+            "p90_us": float(np.percentile(us, 90)), "max_us": float(us.max())}
+
+
 def hbm_resident_variant(args):
     """Side line at BASELINE.json configs[4]'s per-GPU shape (C5-synth: |E| 2M, |R| 2K, dim 256, neg 64, batch 5000): the 2 GB
     table + slot + gradient scratch do not fit the 256 MB Infinity Cache, so this — not the C2 headline, whose 192 MB working
     set is cache-resident — is the HBM measurement of the same kernels.  Same code path as the headline: native
-    step loop timed over `steps` steps after `warmup`, then the instrumented pass for the kernel's own duration."""
+    step loop, windows of `steps` steps after `warmup` (median window reported, spread beside it), then the instrumented pass
+    for the kernel's own duration and its launch-time histogram."""
     cfg = {k: CONFIGS["c5"][k] for k in ("n_ent", "n_rel", "dim", "neg", "batch")}
     t_setup = time.perf_counter()
     w = FusedWorkload(cfg, device_init=True)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
-    warm, steps = 200, max(200, min(args.steps, 600))
+    warm, steps = 200, 100
     w.run_steps(0, warm)
-    dt = w.timed(warm, steps)
-    scored = sum(w.triples_of(i) for i in range(warm, warm + steps))
-    roof = w.instrumented(warm + steps, 100, pmc_traffic("c5"), dt / steps * 1e6)
+    dt, scored, stats, nxt = _windows(w, warm, steps, 8)
+    roof = w.instrumented(nxt, 200, pmc_traffic("c5"), dt / steps * 1e6)
+    roof["launch_histogram"] = w.last_hist
     return {"name": "C5-synth: the HBM-resident shape (BASELINE configs[4] per GPU: |E|=2M |R|=2K dim=256 neg=64 batch=5000)",
             "value": scored / dt, "unit": "triples/s", "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
-            "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "setup_s_untimed": t_setup, "roofline": roof}
+            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "setup_s_untimed": t_setup, "roofline": roof}
+
+
+def zipf_variant(args, exponent=1.0):
+    """Side line (SURVEY 8d "a Zipf(1.0) head/tail variant to expose atomic contention"): the headline shape with the head and
+    tail entities of the synthetic triples drawn ~ rank^-1 inside each KG (hub rows: the positives' shared-row flushes of many
+    groups of a step land on the same rows; the sampler's corruptions stay uniform, as code/base/batch.py:86-116 draws them).
+    Same code path, own roofline object; `vs_uniform_launch` = this kernel's launch time / the uniform headline's is filled in
+    by the caller."""
+    cfg = {k: CONFIGS["c2"][k] for k in ("n_ent", "n_rel", "dim", "neg", "batch")}
+    w = FusedWorkload(cfg, zipf=exponent)
+    warm, steps = w.n_steps_epoch, 20
+    w.run_steps(0, warm + 5)
+    dt, scored, stats, nxt = _windows(w, warm + 5, steps, 50)
+    roof = w.instrumented(nxt, 100, None, dt / steps * 1e6)
+    roof["launch_histogram"] = w.last_hist
+    deg = np.bincount(np.concatenate([np.concatenate([t[:, 0], t[:, 2]]) for t in w.kgs.triples]), minlength=cfg["n_ent"])
+    return {"name": f"C2-synth Zipf({exponent:g}): head / tail entities of the triples ~ rank^-{exponent:g} (hub rows)",
+            "value": scored / dt, "unit": "triples/s", "steps": steps, "warmup": warm + 5, "ms_per_step": dt / steps * 1e3,
+            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "roofline": roof,
+            "degree": {"max": int(deg.max()), "p99.9": float(np.percentile(deg, 99.9)), "mean": float(deg.mean()),
+                       "share_of_references_on_top_100_rows": float(np.sort(deg)[-100:].sum() / deg.sum())}}
 
 
 def self_launch(args):
@@ -433,7 +489,7 @@ class FusedWorkload:
     """The single-GPU form of the step on one synthetic shape: tables, batcher, native runner, and the two measurements —
     the timed region (native step loop, no Python between steps) and the instrumented pass (HIP events per launch)."""
 
-    def __init__(self, cfg, sample_chunk=None, rel_grad_copies=1, device_init=False):
+    def __init__(self, cfg, sample_chunk=None, rel_grad_copies=1, device_init=False, zipf=0.0):
         from multike_amd.runner import RelationViewRunner
         from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
         from multike_amd.synthetic import SyntheticKGs
@@ -442,7 +498,7 @@ class FusedWorkload:
         self.cfg = cfg
         d, N, B = cfg["dim"], cfg["neg"], cfg["batch"]
         self.d, self.N, self.B = d, N, B
-        self.kgs = kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234)
+        self.kgs = kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234, zipf=zipf)
         if device_init:      # side lines of big shapes: the same distribution drawn on the device (9 s on the host at 2M x 256)
             g = torch.Generator(device="cuda"); g.manual_seed(1234)
             def init(n):
@@ -472,6 +528,13 @@ class FusedWorkload:
         self.eng = StepEngine()
         self.n_steps_epoch = self.bat.steps
         self.ev = []
+        self._epoch_ready = 0          # index of the epoch whose shuffle has been done
+
+    def _begin_epoch(self, ep):
+        """the epoch-boundary shuffle of epoch `ep` (code/MultiKE_model.py:314-315), once"""
+        if ep > self._epoch_ready:
+            self.bat.shuffle()
+            self._epoch_ready = ep
 
     def run_steps(self, i0, i1):
         """global step indices [i0, i1): whole epochs go through runner.run_epochs; a partial epoch is ONE call into the
@@ -482,16 +545,28 @@ class FusedWorkload:
             s = i % n
             if s == 0 and i1 - i >= n:
                 n_ep = (i1 - i) // n
-                if i > 0:
-                    bat.shuffle()
-                runner.run_epochs(n_ep)
+                self._begin_epoch(i // n)
+                runner.run_epochs(n_ep)       # shuffles between its epochs itself
+                self._epoch_ready = i // n + n_ep - 1
                 i += n_ep * n
                 continue
             e = min(n, s + (i1 - i))
-            if s == 0 and i > 0:
-                bat.shuffle()
+            if s == 0:
+                self._begin_epoch(i // n)
             runner.run(s, e)
             i += e - s
+
+    def window_start(self, i, steps):
+        """First global step index >= i at which a window of `steps` steps lies inside one epoch; the steps skipped are RUN
+        (untimed) and the next epoch's shuffle is done here, outside the window's bracket.  Windows longer than an epoch are
+        left where they are."""
+        n = self.n_steps_epoch
+        if steps >= n or (i % n) + steps <= n:
+            return i
+        nxt = (i // n + 1) * n
+        self.run_steps(i, nxt)
+        self._begin_epoch(nxt // n)
+        return nxt
 
     def triples_of(self, i):
         s = i % self.n_steps_epoch
@@ -550,6 +625,7 @@ class FusedWorkload:
         whole = np.array([e[0].elapsed_time(e[3]) for e, _, _ in self.ev])
         tr = np.array([n for _, n, _ in self.ev])
         roofline = roofline_object("k_triple_score", ms, tr, self.d, traffic)
+        self.last_hist = launch_histogram(ms)
         # second kernel of the step, reported beside it: rows left to it (referenced more than once in the step) x 6 row
         # streams (grad, w, acc read; 0, w, acc written); rows referenced once were updated inside k_triple_score
         last_tag = self.ev[-1][2]
@@ -661,7 +737,7 @@ def main():
             for i in range(i0, i1):
                 run_step(i)
     else:
-        fused = FusedWorkload(cfg, sample_chunk=args.sample_chunk, rel_grad_copies=args.rel_grad_copies)
+        fused = FusedWorkload(cfg, sample_chunk=args.sample_chunk, rel_grad_copies=args.rel_grad_copies, zipf=args.zipf)
         kgs, ent0, rel0 = fused.kgs, fused.ent0, fused.rel0
         n_steps_epoch = fused.n_steps_epoch
         run_steps, triples_of = fused.run_steps, fused.triples_of
@@ -679,40 +755,81 @@ def main():
         torch.cuda.synchronize()
     args_w0 = pre                                   # global step index of the first --warmup step
     run_steps(args_w0, args_w0 + args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args_w0 + args.warmup, args_w0 + args.warmup + args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    scored = sum(triples_of(i) for i in range(args_w0 + args.warmup, args_w0 + args.warmup + args.steps))
+
+    def time_window(first):
+        """exactly --steps steps between barrier + synchronize pairs; max over ranks"""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(first, first + args.steps)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device="cpu" if staged else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax)
+        return dt_
+
+    # The contract's timed region (W warm-up steps, then exactly K steps) is the FIRST window.  It is then repeated, same
+    # bracket, same K, so that the line carries a spread: `value` / `ms_per_step` are the MEDIAN window (first window beside it).
+    first = args_w0 + args.warmup
+    if fused is not None:
+        first = fused.window_start(first, args.steps)
+    dt_first = time_window(first)
+    n_win = args.windows
+    if n_win is None:
+        n_win = max(50 if args.steps <= 100 else 5, int(np.ceil(0.060 / max(dt_first, 1e-6))))
+        n_win = min(n_win, 400)
+    win_dt, win_scored = [dt_first], [sum(triples_of(i) for i in range(first, first + args.steps))]
+    nxt = first + args.steps
+    for _ in range(max(1, n_win) - 1):
+        if fused is not None:
+            nxt = fused.window_start(nxt, args.steps)
+        win_dt.append(time_window(nxt))
+        win_scored.append(sum(triples_of(i) for i in range(nxt, nxt + args.steps)))
+        nxt += args.steps
+    win_dt, win_scored = np.array(win_dt), np.array(win_scored)
+    rate = win_scored / win_dt
+    mid = int(np.argsort(win_dt)[len(win_dt) // 2])            # the median window (an actual window, not an interpolation)
+    dt, scored = float(win_dt[mid]), int(win_scored[mid])
     value = scored / dt
+    window_ms = {"n": int(len(win_dt)), "steps_per_window": args.steps, "min": float(win_dt.min() * 1e3),
+                 "p10": float(np.percentile(win_dt, 10) * 1e3), "median": float(dt * 1e3),
+                 "p90": float(np.percentile(win_dt, 90) * 1e3), "max": float(win_dt.max() * 1e3),
+                 "first_window": float(dt_first * 1e3), "first_window_value": float(win_scored[0] / dt_first),
+                 "timed_total_ms": float(win_dt.sum() * 1e3),
+                 "value_min": float(rate.min()), "value_max": float(rate.max()),
+                 "what": "every window = --steps consecutive steps inside one epoch, bracketed by barrier + synchronize; "
+                         "`value` and `ms_per_step` are the median window's"}
+    args_end = nxt                                   # first global step index after the timed windows
 
     roofline = None
     if not sharded:
-        base = args_w0 + args.warmup + args.steps
+        base = args_end
         n_inst = max(min(args.steps, 300), 100)      # >= 100 launches whatever --steps is (the driver passes 20)
         # PMC bytes per launch of this kernel (separate rocprofv3 --pmc passes), or None
-        roofline = fused.instrumented(base, n_inst, pmc_traffic(args.config, getattr(args, "custom", False)), dt / args.steps * 1e6)
+        roofline = fused.instrumented(base, n_inst, pmc_traffic(args.config, getattr(args, "custom", False) or bool(args.zipf)), dt / args.steps * 1e6)
+        roofline["launch_histogram"] = fused.last_hist
 
     variants = None
-    if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False):
+    if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False) and not args.zipf:
         variants = reference_default_variants(args, kgs, ent0, rel0, fused.sides)
         del fused
+        torch.cuda.empty_cache()
+        zv = zipf_variant(args, 1.0)
+        zv["roofline"]["vs_uniform_launch"] = zv["roofline"]["avg_launch_us"] / roofline["avg_launch_us"]
+        zv["vs_uniform_step"] = zv["ms_per_step"] / (dt / args.steps * 1e3)
+        variants.insert(0, zv)
         torch.cuda.empty_cache()
         variants.insert(0, hbm_resident_variant(args))
 
     if sharded:
         # same instrumentation on the sharded path: events around this rank's score-kernel launches (extra steps)
         trainer.score_events = []
-        base = args_w0 + args.warmup + args.steps
+        base = args_end
         run_steps(base, base + min(args.steps, 50))
         torch.cuda.synchronize()
         ms = np.array([a.elapsed_time(b) for a, b, _ in trainer.score_events])
@@ -747,9 +864,10 @@ def main():
         out = {
             "metric": "scored triples/sec (pos+neg)", "value": value, "unit": "triples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "window_ms": window_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not staged else "synthetic; DRY RUN: ranks share GPUs, collectives staged through the host (not a result)",
-            "config": {"workload": f"relation-view train step, {args.label} |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} "
+            "config": {"workload": f"relation-view train step, {args.label}{f' Zipf({args.zipf:g})' if args.zipf else ''} |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} "
                                    f"batch={B}" + (f"/GPU, rows sharded id%{world}" if sharded else ""),
                        "step": "on-device negative sampling + fused gather/score/loss/gradient + Jacobian/Adagrad row update",
                        "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,
