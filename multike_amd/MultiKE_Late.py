@@ -217,24 +217,28 @@ class _ScheduledMultiKE(MultiKE):
         side = self._side_stream
         self._defer_losses, self._pending = True, []
         try:
-            # the longer chain (attribute group, 12.7 ms of 7-launch steps at the C2 shape) is enqueued first, on the side
-            # stream: 18.0 ms per epoch against 18.8 the other way round and 22.0 on one stream.  Measured and not kept:
-            # a higher stream priority for either group (no change), enqueueing the two groups from two host threads
-            # (18.9 ms: the device, not the host, is what the two chains share).
-            # Round 4: the phases that do not read the soft predicate-alignment lists (the two views, the two entity-inference
-            # loops) are enqueued FIRST on both streams; a predicate refresh deferred from the end of the previous epoch
-            # (`_update_predicate_alignment`: 15-30 ms of host work every ten epochs) then runs on the host while the device
-            # works through them, and the two list-reading loops follow.
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                attribute_group_a()
-            attr_a, self._pending = self._pending, []
+            # two streams: 18.0 ms per epoch against 22.0 on one (C2 shape).  Measured and not kept: a higher stream priority
+            # for either group (no change), enqueueing the two groups from two host threads (18.9 ms: the device, not the
+            # host, is what the two chains share).
+            # A predicate refresh deferred from the end of the previous epoch (`_update_predicate_alignment`) replaces the lists
+            # three loops read: the relation- and attribute-inference loops, and — through
+            # `attribute_triples_w_weights1/2` (code/predicate_alignment.py:170-174, read at code/MultiKE_model.py:325-328) —
+            # the attribute VIEW itself.  Only the relation view and its entity-inference loop are list-independent: they are
+            # enqueued first, the refresh is finished while the device works through them, and everything else follows it —
+            # the order in which the reference's epoch i + 1 sees the lists of the refresh at the end of epoch i
+            # (code/MultiKE_CSL.py:80-87).  (Round 4 enqueued the attribute view before the refresh: one epoch on stale weights
+            # after every refresh.)
+            start = torch.cuda.Event()
+            start.record(main)                      # what the side stream must see: everything before this epoch
             relation_group_a()
             rel_a, self._pending = self._pending, []
             self._finish_predicate_update()
+            side.wait_event(start)
             with torch.cuda.stream(side):
+                attribute_group_a()
                 attribute_group_b()
-            attr_b, self._pending = self._pending, []
+            attr_ab, self._pending = self._pending, []
+            attr_a, attr_b = attr_ab, []
             relation_group_b()
             self._pending = rel_a + self._pending + attr_a + attr_b       # the reference prints the relation group's losses first
             main.wait_stream(side)

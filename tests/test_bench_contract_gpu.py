@@ -51,6 +51,11 @@ def test_n1_line():
     # no difference of figures from two different loops is printed (it went negative in round 3)
     assert "boundaries_and_gaps" not in b and all(v > 0 for v in b["instrumented_loop"].values())
     assert d["rccl"]["world"] == 1 and len(d["rccl"]["devices"]) == 1
+    # the headline is the MEDIAN of >= 50 windows of --steps steps; the spread is in the line
+    w = d["window_ms"]
+    assert w["n"] >= 50 and w["steps_per_window"] == d["steps"] and w["min"] <= w["p10"] <= w["median"] <= w["p90"] <= w["max"]
+    assert abs(w["median"] - d["ms_per_step"] * d["steps"]) < 1e-9 and w["timed_total_ms"] >= 50.0
+    assert w["value_min"] <= d["value"] <= w["value_max"]
     assert r["peak"] == 8000.0 and r["alg_bytes_per_triple"] == 12 + 24 * d["config"]["dim"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
@@ -61,6 +66,13 @@ def test_n1_line():
     assert abs(c5["value"] - c5["scored_per_step"] / (c5["ms_per_step"] * 1e-3)) / c5["value"] < 0.02
     _check_roofline(c5["roofline"])
     assert c5["roofline"]["alg_bytes_per_triple"] == 12 + 24 * 256
+    h = c5["roofline"]["launch_histogram"]      # the spread of the HBM shape's launch time is in the line
+    assert sum(h["counts"]) == c5["roofline"]["launches_timed"] and h["min_us"] <= h["median_us"] <= h["max_us"]
+    assert c5["window_ms"]["n"] >= 5 and c5["window_ms"]["min"] <= c5["window_ms"]["median"] <= c5["window_ms"]["max"]
+    zv = v.pop(0)                     # the heavy-tailed variant (hub rows), own roofline object
+    assert "Zipf(1)" in zv["name"] and zv["scored_per_step"] == d["config"]["scored_per_step"] and zv["value"] > 50e6
+    _check_roofline(zv["roofline"])
+    assert zv["roofline"]["vs_uniform_launch"] > 0.9 and zv["degree"]["max"] > 100 * zv["degree"]["mean"]
     # then the reference's default shape (code/args.json:25-28) as side lines
     assert [x["scored_per_step"] for x in v[:2]] == [d["config"]["batch"] * 11] * 2 and all(x["value"] > 50e6 for x in v[:2])
     k = v[1]["knn_refresh_ms_untimed"]

@@ -133,3 +133,65 @@ def test_predicate_refresh_in_hbm_equals_the_host_lists(tmp_path):
     want = host.sup_attribute_alignment_triples1 + host.sup_attribute_alignment_triples2
     assert both.dev is not None and np.array_equal(torch.stack(both.dev[0], dim=1).cpu().numpy(), want.cols.astype(np.int32))
     assert np.array_equal(both.cols, want.cols) and np.array_equal(both.w, want.w)
+
+
+def test_deferred_predicate_refresh_is_seen_by_the_next_epochs_attribute_view(tmp_path):
+    """code/MultiKE_CSL.py:80-87: the soft predicate-alignment refresh at the end of epoch i replaces
+    `attribute_triples_w_weights1/2` (code/predicate_alignment.py:170-174), which epoch i + 1's ATTRIBUTE VIEW reads
+    (code/MultiKE_model.py:325-328) — not only the two inference loops.  The product defers the refresh's host work under the
+    next epoch's first kernels; the attribute view must still be enqueued AFTER it (round 4 enqueued it before: one epoch on
+    stale weights).  Asserted: the list objects every phase of epoch i + 1 reads are the refreshed ones, and the deferred
+    two-stream run gives the losses of the in-line one-stream run."""
+    import contextlib
+    import io
+    import torch
+    from multike_amd.data_model import DataModel
+    from multike_amd.MultiKE_CSL import MultiKE_CV
+    from multike_amd.predicate_alignment import PredicateAlignModel
+    from multike_amd.synthetic import write_dataset_folder
+    folder = str(tmp_path) + "/"
+    wf = write_dataset_folder(folder, n_pairs=300, n_extra=20, n_rel=12, n_attr=10, shared_structure=0.7)
+    args = _args(folder, wf)
+    args.start_predicate_soft_alignment = 1
+
+    def run(deferred):
+        with contextlib.redirect_stdout(io.StringIO()):
+            data = DataModel(args)
+            m = MultiKE_CV(data, args, PredicateAlignModel(data.kgs, args))
+            m.defer_predicate_update, m.overlap_views = deferred, deferred
+            m._prepare()
+            pam, seen, losses = m.predicate_align_model, [], []
+            for name in ("train_attribute_view_1epo", "train_cross_kg_attribute_inference_1epo", "train_cross_kg_relation_inference_1epo"):
+                orig = getattr(m, name)
+                def wrapped(i, *a, _orig=orig, _name=name, **k):
+                    seen.append((i, _name, pam.attribute_triples_w_weights1, m._ckga_attr_triples, m._ckgp_rel_triples))
+                    out = _orig(i, *a, **k)
+                    losses.append((i, _name, out))
+                    return out
+                setattr(m, name, wrapped)
+            for i in range(1, 5):
+                m._train_views(i)
+                m.train_common_space_learning_1epo(i, m._entity_list)
+                if i == 2:
+                    before = (pam.attribute_triples_w_weights1, m._ckga_attr_triples, m._ckgp_rel_triples)
+                    m._update_predicate_alignment()
+            m._finish_predicate_update()
+            torch.cuda.synchronize()
+        return m, seen, losses, before
+    m, seen, losses, before = run(True)
+    pam = m.predicate_align_model
+    assert pam.attribute_triples_w_weights1 is not before[0]               # the refresh did replace the lists
+    for i, name, w1, ckga, ckgp in seen:
+        if i <= 2:
+            assert w1 is before[0] and ckga is before[1] and ckgp is before[2], (i, name)
+        else:       # every list-reading phase of the epochs after the refresh — the attribute view included — reads the new lists
+            assert w1 is pam.attribute_triples_w_weights1 and ckga is m._ckga_attr_triples and ckgp is m._ckgp_rel_triples, (i, name)
+    _, _, ref_losses, _ = run(False)
+    assert [(i, n) for i, n, _ in losses if n == "train_attribute_view_1epo"] == [(i, n) for i, n, _ in ref_losses if n == "train_attribute_view_1epo"]
+    def val(v):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return float(v.finish()) if hasattr(v, "finish") else float(v)
+    got = {(i, n): val(v) for i, n, v in losses if v is not None}
+    want = {(i, n): val(v) for i, n, v in ref_losses if v is not None}
+    for k in want:
+        assert abs(got[k] - want[k]) <= 2e-4 * abs(want[k]), (k, got[k], want[k])
