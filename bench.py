@@ -432,7 +432,7 @@ def zipf_variant(args, exponent=1.0):
     deg = np.bincount(np.concatenate([np.concatenate([t[:, 0], t[:, 2]]) for t in w.kgs.triples]), minlength=cfg["n_ent"])
     return {"name": f"C2-synth Zipf({exponent:g}): head / tail entities of the triples ~ rank^-{exponent:g} (hub rows)",
             "value": scored / dt, "unit": "triples/s", "steps": steps, "warmup": warm + 5, "ms_per_step": dt / steps * 1e3,
-            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "roofline": roof,
+            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "roofline": roof, "hub_rows": w.hub_rows,
             "degree": {"max": int(deg.max()), "p99.9": float(np.percentile(deg, 99.9)), "mean": float(deg.mean()),
                        "share_of_references_on_top_100_rows": float(np.sort(deg)[-100:].sum() / deg.sum())}}
 
@@ -524,7 +524,9 @@ class FusedWorkload:
                                      KnownTripleSet(t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous())))
         self.bat = RelationBatcher(kgs.triples[0], kgs.triples[1], self.sides[0], self.sides[1], B, N, seed=1234)
         self.bat.shuffle()  # epoch-boundary code path (randperm + regather) exercised once before the timed region
-        self.runner = RelationViewRunner(self.E, self.R, self.bat, "relation", lr=0.001, sample_chunk=sample_chunk or None)
+        self.runner = RelationViewRunner(self.E, self.R, self.bat, "relation", lr=0.001, sample_chunk=sample_chunk or None,
+                                         hot_rows=None if os.environ.get("MKE_BENCH_HOT", "1") != "0" else False)   # A/B knob
+        self.hub_rows = {"n": self.E.n_hot, "copies": self.E.hot_copies}
         self.eng = StepEngine()
         self.n_steps_epoch = self.bat.steps
         self.ev = []
@@ -594,11 +596,12 @@ class FusedWorkload:
         e[0].record()
         _lib.count_entity_refs(pos[0], pos[2], neg[0], neg[2], N, E.refcount)
         e[1].record()
+        hot = E.hot_struct()           # hub rows declared by the runner (none on the uniform synthetic KGs)
         _lib.triple_score_fwd_bwd_x(E.data, True, R.data, True, d, pos, None, neg, None, N, 1.0, E.grad, R.grad,
-                                    E.touched, R.touched, tag, E.refcount, E.slot("relation"), _lib.OPT_ADAGRAD, 0.001, lp)
+                                    E.touched, R.touched, tag, E.refcount, E.slot("relation"), _lib.OPT_ADAGRAD, 0.001, lp, hot=hot)
         e[2].record()
         _lib.rows_update_multi([(R.data, R.slot("relation"), R.grad, R.touched, True),
-                                (E.data, E.slot("relation"), E.grad, E.touched, True, E.refcount)], tag, E.stride, d,
+                                (E.data, E.slot("relation"), E.grad, E.touched, True, E.refcount, hot)], tag, E.stride, d,
                                _lib.OPT_ADAGRAD, 0.001)
         e[3].record()
         self.ev.append((e, pos[0].numel() * (1 + N), tag))
@@ -835,6 +838,16 @@ def main():
         ms = np.array([a.elapsed_time(b) for a, b, _ in trainer.score_events])
         tr = np.array([n for _, _, n in trainer.score_events])
         trainer.score_events = None
+        # host cost of the step path: the enqueue loop timed WITHOUT waiting for the device (Python + ctypes + torch.distributed
+        # calls per global step); above the device time per step the host, not the GPU, paces the job
+        n_host = min(40, n_steps_epoch - 1)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        base_h = base + min(args.steps, 50)            # steps are issued in order
+        run_steps(base_h, base_h + n_host)
+        th = time.perf_counter() - th
+        torch.cuda.synchronize()
+        host_us = th / max(1, n_host) * 1e6
         shard_info = trainer.check() if hasattr(trainer, "check") else {}   # raises when a row set overflowed (results invalid)
         # the replicated relation table must be bit-identical on every rank (its gradient is all-reduced, the update identical);
         # a transport that delivered different sums to different ranks shows up here, and the epoch's loss must be finite
@@ -856,6 +869,8 @@ def main():
             raise SystemExit(f"bench.py: non-finite loss {ep_loss} on the sharded path")
         roofline = roofline_object("k_oc_score" if shard_mode != "rowfetch" else "k_triple_score", ms, tr, d, None)
         roofline.update({"scope": "per GPU (rank 0): the triples whose corrupt entity this rank owns", "exchange": shard_info,
+                         "host_us_per_step": host_us, "host_note": "enqueue loop of the step path without waiting for the device"
+                                             + ("; MKE_OC_FORCE_COLLECTIVES=1: the G > 1 path with its collectives on the one-rank group" if getattr(trainer, "force_collectives", False) else ""),
                          "basis_note": "the algorithmic model counts 3 rows read + 3 written per scored triple; the owner-computes kernel "
                                        "reads 2 vectors per POSITIVE and one row per negative, so this fraction overstates its traffic "
                                        "(it can exceed 1) — a rate in the model's bytes, not a measurement of the memory system"})

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 102 /* 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
+#define MKE_VERSION 103 /* 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
@@ -171,6 +171,18 @@ int mke_triple_score_fwd_bwd_x(
  * (mke_count_entity_refs semantics; a different buffer than `ref_count`; NULL = plain mke_triple_score_fwd_bwd_x): the counting
  * finishes under the scoring blocks instead of paying a launch or a tail of its own.  mke_count_job: section (2). */
 struct mke_count_job;
+/* Hub rows (version 103).  A KG's degree distribution is heavy-tailed (code/base/batch.py:45-54 feeds real triples): a few
+ * hundred entities are head or tail of several positives of EVERY step, and the flushes of all those groups' shared-row
+ * gradients serialise on the same few cache lines of the gradient scratch.  For the rows listed here the flush of group g
+ * goes to one of `copies` private copies instead — extra rows behind the table's own in the SAME scratch:
+ *     copy k of hot row i = scratch row  row0 + k * n_hot + i      (k = g % copies; the scratch has row0 + copies * n_hot rows)
+ * touched[entity] is set as usual; mke_rows_update_multi adds the copies to the row's own gradient (and re-zeroes them) when
+ * it visits the row (mke_update_table.hot).  Contributions of corrupted triples keep going to the row itself. */
+typedef struct mke_hot_rows {
+  const int32_t* slot;   /* device int32 [n_ent]: index of the row among the n_hot hub rows, or -1 */
+  int32_t n_hot, copies;
+  int64_t row0;          /* first copy row (>= n_ent) */
+} mke_hot_rows;
 int mke_triple_score_fwd_bwd_xc(
     float* ent_table, int64_t n_ent, int ent_normalize,
     const float* rel_table, int64_t n_rel, int rel_normalize,
@@ -182,6 +194,18 @@ int mke_triple_score_fwd_bwd_xc(
     int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
     int32_t* ref_count, float* ent_acc /*nullable for SGD*/, int optimizer, float lr,
     const struct mke_count_job* next_count /*nullable*/, double* loss_partials, void* stream);
+/* The same with hub rows (hot == NULL or hot->n_hot == 0: identical to mke_triple_score_fwd_bwd_xc). */
+int mke_triple_score_fwd_bwd_xch(
+    float* ent_table, int64_t n_ent, int ent_normalize,
+    const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim,
+    const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w /*nullable*/, int64_t n_pos,
+    const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w /*nullable*/, int64_t n_neg,
+    int neg_per_pos, float scale,
+    float* grad_ent, float* grad_rel, int grad_rel_copies,
+    int32_t* touched_ent, int32_t* touched_rel, int32_t tag,
+    int32_t* ref_count, float* ent_acc /*nullable for SGD*/, int optimizer, float lr,
+    const struct mke_count_job* next_count /*nullable*/, const mke_hot_rows* hot /*nullable*/, double* loss_partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (2) Per-row optimizer step on the rows touched in this step: Jacobian of normalise-on-read, then
@@ -227,6 +251,8 @@ typedef struct mke_update_table {
   int32_t* slot_of;
   int n_ranks;
   int64_t capacity;
+  /* version 103: hub rows of this table (see mke_hot_rows; slot == NULL: none) */
+  mke_hot_rows hot;
 } mke_update_table;
 int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                           int optimizer, float lr, void* stream);
@@ -431,6 +457,8 @@ typedef struct mke_relation_plan {
   int32_t tag_base;
   const float* pos_w;                        /* nullable: per-positive weights, epoch order like pos_* (weighted positives-only
                                                 loops, code/MultiKE_model.py:393-414); neg_per_pos == 0 runs positives only */
+  mke_hot_rows hot;                          /* version 103: hub rows of the entity table (slot == NULL: none); ent_grad then has
+                                                hot.row0 + hot.copies * hot.n_hot rows */
 } mke_relation_plan;
 
 int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);

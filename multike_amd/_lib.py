@@ -25,7 +25,7 @@ _SUPPORTED_FPL = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20)
 # every symbol include/multike_hip.h declares (tests/test_abi.py checks the .so exports each of them)
 SYMBOLS = (
     "mke_version", "mke_last_error", "mke_set_option", "mke_triple_score_fwd_bwd", "mke_triple_score_fwd_bwd_x",
-    "mke_count_entity_refs", "mke_triple_score_fwd_bwd_xc", "mke_triple_score_fwd_bwd_det", "mke_stage_reduce", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
+    "mke_count_entity_refs", "mke_triple_score_fwd_bwd_xc", "mke_triple_score_fwd_bwd_xch", "mke_triple_score_fwd_bwd_det", "mke_stage_reduce", "mke_rows_update", "mke_rows_update_multi", "mke_rows_update_multi_count",
     "mke_neg_sample", "mke_tripleset_build", "mke_tripleset_query", "mke_gathered_logistic_fwd_bwd",
     "mke_gathered_alignment_fwd_bwd", "mke_align_fwd_bwd", "mke_gather_rows", "mke_relation_steps",
     "mke_rowset_build", "mke_rowset_remap", "mke_rows_gather_padded", "mke_rows_scatter_add",
@@ -127,11 +127,17 @@ class KGSideStruct(C.Structure):
                 ("known_capacity", C.c_uint64)]
 
 
+class HotRowsStruct(C.Structure):
+    """mke_hot_rows"""
+    _fields_ = [("slot", C.c_void_p), ("n_hot", C.c_int32), ("copies", C.c_int32), ("row0", C.c_int64)]
+
+
 class UpdateTableStruct(C.Structure):
     """mke_update_table"""
     _fields_ = [("table", C.c_void_p), ("acc", C.c_void_p), ("grad", C.c_void_p), ("touched", C.c_void_p),
                 ("n_rows", C.c_int64), ("normalize", C.c_int), ("grad_copies", C.c_int), ("ref_count", C.c_void_p),
-                ("src_rows", C.c_void_p), ("slot_of", C.c_void_p), ("n_ranks", C.c_int), ("capacity", C.c_int64)]
+                ("src_rows", C.c_void_p), ("slot_of", C.c_void_p), ("n_ranks", C.c_int), ("capacity", C.c_int64),
+                ("hot", HotRowsStruct)]
 
 
 class RelationPlanStruct(C.Structure):
@@ -150,6 +156,7 @@ class RelationPlanStruct(C.Structure):
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("stream_id", C.c_uint32),
         ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float),
         ("loss_partials", C.c_void_p), ("loss_ring", C.c_int), ("tag_base", C.c_int32), ("pos_w", C.c_void_p),
+        ("hot", HotRowsStruct),
     ]
 
 _lib = None
@@ -309,12 +316,28 @@ def count_entity_refs(pos_h, pos_t, neg_h, neg_t, neg_per_pos, ref_count):
 
 
 def triple_score_fwd_bwd_x(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale, grad_ent,
-                           grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, loss_partials):
+                           grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, loss_partials, hot=None):
     """mke_triple_score_fwd_bwd_x: the fused step with the exclusive-row fast path (ref_count filled by
-    count_entity_refs for the same batch)."""
+    count_entity_refs for the same batch).  hot (HotRowsStruct of the entity table, `EmbeddingTable.hot_struct()`): the hub
+    rows' flushes go to their private copies (mke_triple_score_fwd_bwd_xch); the update must then get the same struct."""
     ph, pr, pt = pos
     nh, nr, nt = neg
     rel_copies = 1 if grad_rel.dim() == 2 else grad_rel.shape[0]
+    if hot is not None and hot.n_hot > 0:
+        rc = lib().mke_triple_score_fwd_bwd_xch(
+            _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
+            _dev(rel, torch.float32, "rel_table"), C.c_int64(rel.shape[0]), C.c_int(int(rel_normalize)),
+            C.c_int(ent.shape[1]), C.c_int(dim),
+            _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+            _dev(pos_w, torch.float32, "pos_w"), C.c_int64(ph.numel()),
+            _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"),
+            _dev(neg_w, torch.float32, "neg_w"), C.c_int64(nh.numel()), C.c_int(neg_per_pos), C.c_float(scale),
+            _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"), C.c_int(rel_copies),
+            _dev(touched_ent, torch.int32, "touched_ent"), _dev(touched_rel, torch.int32, "touched_rel"), C.c_int32(tag),
+            _dev(ref_count, torch.int32, "ref_count"), _dev(ent_acc, torch.float32, "ent_acc"), C.c_int(optimizer), C.c_float(lr),
+            None, C.byref(hot), _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+        _check(rc, "mke_triple_score_fwd_bwd_xch")
+        return
     rc = lib().mke_triple_score_fwd_bwd_x(
         _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
         _dev(rel, torch.float32, "rel_table"), C.c_int64(rel.shape[0]), C.c_int(int(rel_normalize)),
@@ -345,7 +368,7 @@ def ptr(t: torch.Tensor | None, dtype, name: str) -> int | None:
 
 
 def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
-    """tables: list of (data, acc, grad, touched, normalize[, ref_count]); or, for the owner side of the sharded
+    """tables: list of (data, acc, grad, touched, normalize[, ref_count[, hot]]) (hot: the table's HotRowsStruct); or, for the owner side of the sharded
     step, a dict(table=, acc=, normalize=, src_rows=, slot_of=, n_ranks=, capacity=) (mke_update_table.slot_of)."""
     arr = (UpdateTableStruct * len(tables))()
     for k, tpl in enumerate(tables):
@@ -364,6 +387,8 @@ def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
             continue
         data, acc, grad, touched, normalize = tpl[:5]
         arr[k].ref_count = ptr(tpl[5], torch.int32, "ref_count") if len(tpl) > 5 and tpl[5] is not None else None
+        if len(tpl) > 6 and tpl[6] is not None:
+            arr[k].hot = tpl[6]
         arr[k].table = ptr(data, torch.float32, "table")
         arr[k].acc = ptr(acc, torch.float32, "acc")
         arr[k].grad = ptr(grad, torch.float32, "grad")

@@ -120,6 +120,8 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
   ut[0].n_rows = pl->n_rel; ut[0].normalize = pl->rel_normalize; ut[0].grad_copies = pl->rel_grad_copies; ut[0].ref_count = nullptr;
   ut[1].table = pl->ent_table; ut[1].acc = pl->ent_acc; ut[1].grad = pl->ent_grad; ut[1].touched = pl->ent_touched;
   ut[1].n_rows = pl->n_ent; ut[1].normalize = pl->ent_normalize; ut[1].grad_copies = 1; ut[1].ref_count = nullptr;
+  ut[1].hot = pl->hot;     // hub rows of the entity table (slot == NULL: none)
+  const mke_hot_rows* hot = (pl->hot.slot && pl->hot.n_hot > 0) ? &pl->hot : nullptr;
 
   if (pl->overlap) {
     if (N <= 0 || !pl->ent_ref_count) { set_error("overlap mode needs negatives and the reference-count scratch"); return MKE_E_SHAPE; }
@@ -169,12 +171,12 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
       counted_ahead = true;
     }
     const bool in_score = g_count_in_score != 0;
-    rc = mke_triple_score_fwd_bwd_xc(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
+    rc = mke_triple_score_fwd_bwd_xch(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
                                      pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
                                      N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,
                                      nullptr, (hi - lo) * N, N, pl->scale, pl->ent_grad, pl->rel_grad, pl->rel_grad_copies,
                                      pl->ent_touched, pl->rel_touched, tag, refc, pl->ent_acc, pl->optimizer, pl->lr,
-                                     in_score ? cjp : nullptr,
+                                     in_score ? cjp : nullptr, hot,
                                      pl->loss_partials + (int64_t)(s % pl->loss_ring) * MKE_LOSS_PARTIALS, stream);
     if (rc) return rc;
     ut[1].ref_count = refc;

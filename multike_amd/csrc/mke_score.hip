@@ -63,6 +63,10 @@ struct ScoreParams {
   // blocks; as riders of the update launch they were a 4 us tail of it)
   mke_count_job cj;
   int count_blocks;
+  // hub rows (mke_hot_rows): the flush of a group's head / tail gradient goes to a private copy row when the row is listed
+  const int32_t* __restrict__ hot_slot;
+  int32_t n_hot, hot_copies;
+  int32_t hot_row0;
 };
 
 #define MKE_STAGE_REL (1ll << 40)
@@ -93,14 +97,15 @@ __device__ __forceinline__ void atomic_add_at(float* __restrict__ q, int dim, in
 // one gradient-row contribution: atomic add + touched flag, or (deterministic mode) a plain store into its slot
 template <int FPL, bool DET = false, bool O32 = false>
 __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, float* __restrict__ table_grad, int32_t* __restrict__ touched,
-                                         int row, int64_t slot, int j, const float (&v)[FPL], float sgn) {
+                                         int row, int64_t slot, int j, const float (&v)[FPL], float sgn, int grad_row = -1) {
   if (DET) {
     float* o = p.stage_rows + slot * p.stride + j;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) o[k * 16] = sgn * v[k];
     if (j == 0) p.stage_keys[slot] = (is_rel ? MKE_STAGE_REL : 0ll) | (int64_t)row;
   } else {
-    atomic_add_at<FPL>(row_at<FPL, O32>(table_grad, row, p.stride, j), p.dim, j, v, sgn);
+    // grad_row >= 0: a hub row's private copy takes the sum; the flag stays with the row itself
+    atomic_add_at<FPL>(row_at<FPL, O32>(table_grad, grad_row >= 0 ? grad_row : row, p.stride, j), p.dim, j, v, sgn);
     if (j == 0) touched[row] = p.tag;
   }
 }
@@ -181,6 +186,14 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
       const int s = (int)(wk / p.n_pos);
       float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
       const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
+      // hub rows: looked up with the positive's rows, used at the flush (copy = group index modulo the number of copies)
+      int hot_h = -1, hot_t = -1;
+      if (!DET && p.hot_slot) {
+        const int sh = p.hot_slot[ph], st = p.hot_slot[pt];
+        const int cp = p.hot_row0 + (int)(g % p.hot_copies) * p.n_hot;
+        hot_h = sh >= 0 ? cp + sh : -1;
+        hot_t = st >= 0 ? cp + st : -1;
+      }
       // LIDS: the group's first block of negative ids is requested with the positive's ids, its reference counts with the
       // positive's rows (see below): two round trips fewer at the head of a wavefront's chain
       const int npp_ = p.npp;
@@ -418,14 +431,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
             for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : (q == 1 ? gR[k] : -gT[k]);
             float* __restrict__ base = q == 1 ? grel : p.gent;
             const int row = q == 0 ? ph : (q == 1 ? pr : pt);
-            if (q < 3) emit_row<FPL, DET>(p, q == 1, base, q == 1 ? p.trel : p.tent, row, stage_slot(g, npp, npp, q), j, v, 1.0f);
+            if (q < 3) emit_row<FPL, DET>(p, q == 1, base, q == 1 ? p.trel : p.tent, row, stage_slot(g, npp, npp, q), j, v, 1.0f,
+                                          q == 0 ? hot_h : (q == 2 ? hot_t : -1));
           } else {
             // two quarter-waves per group: quarter 0 -> h, quarter 1 -> t, then quarter 0 -> r
             float v[FPL];
 #pragma unroll
             for (int k = 0; k < FPL; ++k) v[k] = q == 0 ? gH[k] : -gT[k];
             const int row = q == 0 ? ph : pt;
-            emit_row<FPL, DET>(p, false, p.gent, p.tent, row, stage_slot(g, npp, npp, q == 0 ? 0 : 2), j, v, 1.0f);
+            emit_row<FPL, DET>(p, false, p.gent, p.tent, row, stage_slot(g, npp, npp, q == 0 ? 0 : 2), j, v, 1.0f, q == 0 ? hot_h : hot_t);
             if (q == 0) emit_row<FPL, DET>(p, true, grel, p.trel, pr, stage_slot(g, npp, npp, 1), j, gR, 1.0f);
           }
         }
@@ -478,7 +492,8 @@ static int score_impl(
     const float* neg_w, int64_t n_neg, int neg_per_pos, float scale, float* grad_ent, float* grad_rel,
     int grad_rel_copies, int32_t* touched_ent, int32_t* touched_rel, int32_t tag, double* loss_partials, void* stream,
     int32_t* ref_count, float* ent_w, float* ent_acc, int optimizer, float lr, float* stage_rows = nullptr,
-    int64_t* stage_keys = nullptr, int64_t stage_slots = 0, const mke_count_job* next_count = nullptr) {
+    int64_t* stage_keys = nullptr, int64_t stage_slots = 0, const mke_count_job* next_count = nullptr,
+    const mke_hot_rows* hot = nullptr) {
   using namespace mke;
   if (!ent_table || !rel_table || !loss_partials) { set_error("mke_triple_score_fwd_bwd: NULL table/loss"); return MKE_E_NULL; }
   if (n_pos < 0 || n_neg < 0 || n_ent <= 0 || n_rel <= 0) { set_error("negative count"); return MKE_E_SHAPE; }
@@ -520,6 +535,14 @@ static int score_impl(
     if (!stage_rows || !grad_ent || need > stage_slots) { set_error("deterministic mode: %lld staging slots needed, %lld given", (long long)need, (long long)stage_slots); return MKE_E_SHAPE; }
   }
   p.stage_rows = stage_rows; p.stage_keys = stage_keys;
+  p.hot_slot = nullptr; p.n_hot = 0; p.hot_copies = 1; p.hot_row0 = 0;
+  if (hot && hot->slot && hot->n_hot > 0 && grad_ent && !stage_keys) {
+    if (hot->copies < 1 || hot->row0 < n_ent || (hot->row0 + (int64_t)hot->copies * hot->n_hot) * stride >= (1ll << 31)) {
+      set_error("hub rows: copies >= 1, row0 >= n_ent and the copy rows inside 2^31 floats of the scratch");
+      return MKE_E_SHAPE;
+    }
+    p.hot_slot = hot->slot; p.n_hot = hot->n_hot; p.hot_copies = hot->copies; p.hot_row0 = (int32_t)hot->row0;
+  }
   p.cj = mke_count_job{};
   p.count_blocks = 0;
   if (next_count && next_count->n_pos + next_count->n_neg > 0) {
@@ -540,7 +563,8 @@ static int score_impl(
   hipStream_t st = (hipStream_t)stream;
   const int fpl = stride / 16;
   // every row address of the launch fits 32 bits of byte offset (entity table = accumulator = gradient scratch in size)
-  const bool o32 = g_score_o32 && n_ent * (int64_t)stride < (1ll << 30) && n_rel * (int64_t)stride < (1ll << 30);
+  const int64_t grad_rows = p.hot_slot ? (int64_t)p.hot_row0 + (int64_t)p.hot_copies * p.n_hot : n_ent;
+  const bool o32 = g_score_o32 && grad_rows * (int64_t)stride < (1ll << 30) && n_rel * (int64_t)stride < (1ll << 30);
   MKE_DISPATCH_FPL(fpl, {
     // corrupt rows in flight per quarter-wave.  2, not 4, at FPL <= 5: with the accumulator rows of the exclusive-row path
     // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
@@ -605,6 +629,23 @@ extern "C" int mke_triple_score_fwd_bwd_xc(
                     n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
                     touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
                     optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr, nullptr, nullptr, 0, next_count);
+}
+
+extern "C" int mke_triple_score_fwd_bwd_xch(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int grad_rel_copies, int32_t* touched_ent,
+    int32_t* touched_rel, int32_t tag, int32_t* ref_count, float* ent_acc, int optimizer, float lr,
+    const mke_count_job* next_count, const mke_hot_rows* hot, double* loss_partials, void* stream) {
+  using namespace mke;
+  if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
+  if (ref_count && optimizer == MKE_OPT_ADAGRAD && !ent_acc) { set_error("exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  if (ref_count && !grad_ent) { set_error("exclusive-row path needs the gradient scratch (it is a training step)"); return MKE_E_NULL; }
+  return score_impl(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t, pos_w,
+                    n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
+                    touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
+                    optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr, nullptr, nullptr, 0, next_count, hot);
 }
 
 extern "C" int mke_triple_score_fwd_bwd_x(

@@ -32,11 +32,15 @@ struct UpdateParams {
   int32_t* __restrict__ slot_of;
   int n_ranks;
   int64_t capacity;
+  // hub rows (mke_hot_rows): private copies of a row's gradient behind the table's own rows in `grad`
+  const int32_t* __restrict__ hot_slot;
+  int32_t n_hot, hot_copies;
+  int64_t hot_row0;
 };
 
 // SHARD: the owner side of the sharded step (gradient gathered through slot_of); a compile-time switch so that the
 // single-GPU step does not carry its registers and branches
-template <int FPL, bool SHARD>
+template <int FPL, bool SHARD, bool HOT = false>   // HOT: hub rows compiled in (their batched copy loads cost the plain instantiation 40 registers)
 __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t row, int j) {
   constexpr int64_t STRIDE = FPL * 16;   // == p.stride (the dispatch picks FPL from it): a shift-add, not a 64-bit multiply
   float* gp = p.grad + row * STRIDE + j;
@@ -65,6 +69,30 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
       float* gc = gp + c * ce;
 #pragma unroll
       for (int k = 0; k < FPL; ++k) { g[k] += gc[k * 16]; gc[k * 16] = 0.f; }
+    }
+  }
+  if (HOT && !SHARD && p.hot_slot) {  // a hub row: the groups' flushes went to its private copies
+    const int hs = p.hot_slot[row];
+    if (hs >= 0) {
+      // HB copies in flight together (one at a time they were a 16-deep chain of round trips: +4.7 us on the launch)
+      constexpr int HB = FPL <= 5 ? 4 : 2;
+      for (int c0 = 0; c0 < p.hot_copies; c0 += HB) {
+        float t[HB][FPL];
+#pragma unroll
+        for (int c = 0; c < HB; ++c) {
+          float* gc = p.grad + (p.hot_row0 + (int64_t)min(c0 + c, p.hot_copies - 1) * p.n_hot + hs) * STRIDE + j;
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) t[c][k] = gc[k * 16];
+        }
+#pragma unroll
+        for (int c = 0; c < HB; ++c) {
+          if (c0 + c < p.hot_copies) {
+            float* gc = p.grad + (p.hot_row0 + (int64_t)(c0 + c) * p.n_hot + hs) * STRIDE + j;
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) { g[k] += t[c][k]; gc[k * 16] = 0.f; }
+          }
+        }
+      }
     }
   }
 #pragma unroll
@@ -117,7 +145,7 @@ __device__ __forceinline__ void update_one_row(const UpdateParams& p, int64_t ro
 // shape: 1.1 on average) issues 96 quarter-populated dword loads / stores for it — the row update was bound by vector-memory
 // instruction issue (3.3 M wave-instructions per launch), not by the 204 MB it moves; here a row is 3 loads + 3 stores of
 // 16 bytes per lane.  Same arithmetic per element; the two row sums are reduced over 64 lanes instead of 16.
-template <int V>
+template <int V, bool HOT = false>
 __device__ __forceinline__ void update_one_row_wave(const UpdateParams& p, int64_t row, int lane) {
   const int64_t off = row * (int64_t)(V * 64) + lane * V;
   float* gp = p.grad + off;
@@ -150,6 +178,19 @@ __device__ __forceinline__ void update_one_row_wave(const UpdateParams& p, int64
 #pragma unroll
       for (int k = 0; k < V; ++k) { g[k] += t[k]; t[k] = 0.f; }
       st(gp + c * ce, t);
+    }
+  }
+  if (HOT && p.hot_slot) {  // a hub row: the groups' flushes went to its private copies
+    const int hs = p.hot_slot[row];
+    if (hs >= 0) {
+      for (int c = 0; c < p.hot_copies; ++c) {
+        float* gc = p.grad + (p.hot_row0 + (int64_t)c * p.n_hot + hs) * (int64_t)(V * 64) + lane * V;
+        float t[V];
+        ld(gc, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { g[k] += t[k]; t[k] = 0.f; }
+        st(gc, t);
+      }
     }
   }
   {
@@ -196,7 +237,7 @@ __device__ __forceinline__ void update_one_row_wave(const UpdateParams& p, int64
 // One wavefront, one 16-row chunk: ballot the flags, deal the set bits round-robin to the four quarter-waves.  Every
 // quarter looks up ITS row of the round (the (4*round + q)-th set bit) so that the four row visits of a round execute
 // together in one instruction stream — a branch per set bit would serialise them.
-template <int FPL, bool SHARD>
+template <int FPL, bool SHARD, bool HOT = false>
 __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, int j, int q) {
   const int64_t base = wave * p.chunk;
   if (base >= p.n_rows) return;  // wave-uniform
@@ -216,7 +257,7 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
   if constexpr (!SHARD && FPL % 4 == 0) {
     if (p.chunk == 64) {   // one flag per lane, wide rows: the whole wavefront visits the set rows one after the other
       while (m) {
-        update_one_row_wave<FPL / 4>(p, base + __builtin_ctzll(m), lane);
+        update_one_row_wave<FPL / 4, HOT>(p, base + __builtin_ctzll(m), lane);
         m &= m - 1;
       }
       return;
@@ -226,7 +267,7 @@ __device__ __forceinline__ void walk_chunk(const UpdateParams& p, int64_t wave, 
   // quarter q takes the q-th, (q+4)-th, ... set bit: a running copy of the mask with the bits already dealt removed
   for (int k = 0; k < q; ++k) m &= m - 1;
   while (__ballot(m != 0)) {   // wave-uniform trip count: the quarters visit their rows of a round together
-    if (m) update_one_row<FPL, SHARD>(p, base + __builtin_ctzll(m), j);
+    if (m) update_one_row<FPL, SHARD, HOT>(p, base + __builtin_ctzll(m), j);
     m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;
   }
 }
@@ -250,7 +291,7 @@ struct MultiUpdateParams {
   int dense_blocks;
 };
 
-template <int FPL, bool SHARD>
+template <int FPL, bool SHARD, bool HOT = false>
 __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpdateParams mp) {
   // rider blocks come FIRST in the grid: they are dispatched with the first update blocks and finish under them (at the end
   // of the grid they were a tail of their own: 13.6 -> 16.7 us at the C2 shape)
@@ -273,7 +314,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   const UpdateParams& p = mp.t[ti];
   const int j = threadIdx.x & 15;
   const int64_t wave = ((ub - first) * MKE_BLOCK + threadIdx.x) >> 6;
-  walk_chunk<FPL, SHARD>(p, wave, j, (threadIdx.x & 63) >> 4);
+  walk_chunk<FPL, SHARD, HOT>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
 extern int g_update_chunk;  // mke_set_option("update_chunk"): rows per wavefront for large tables (16 or 64)
@@ -305,6 +346,9 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
     p.refcount = tables[k].ref_count;
     p.src_rows = tables[k].src_rows; p.slot_of = tables[k].slot_of; p.n_ranks = tables[k].n_ranks; p.capacity = tables[k].capacity;
     if (p.slot_of) p.copies = 1;
+    const bool hot = tables[k].hot.slot && tables[k].hot.n_hot > 0 && !tables[k].slot_of;
+    p.hot_slot = hot ? tables[k].hot.slot : nullptr; p.n_hot = hot ? tables[k].hot.n_hot : 0;
+    p.hot_copies = hot ? tables[k].hot.copies : 1; p.hot_row0 = hot ? tables[k].hot.row0 : 0;
     p.tag = tag; p.n_rows = tables[k].n_rows; p.stride = stride; p.dim = dim; p.normalize = tables[k].normalize;
     p.optimizer = optimizer; p.lr = lr; p.chunk = chunk_for(tables[k].n_rows);
     blocks += (tables[k].n_rows + rows_per_block - 1) / rows_per_block;
@@ -329,8 +373,12 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
   const int fpl = stride / 16;
   bool shard = false;
   for (int k = 0; k < n_tables; ++k) shard = shard || tables[k].slot_of != nullptr;
+  bool hot = false;
+  for (int k = 0; k < n_tables; ++k) hot = hot || mp.t[k].hot_slot != nullptr;
   if (shard) {
     MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_rows_update_multi<FPL, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp); });
+  } else if (hot) {
+    MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_rows_update_multi<FPL, false, true>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp); });
   } else {
     MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_rows_update_multi<FPL, false>), dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, mp); });
   }
@@ -356,6 +404,7 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
   p.table = table; p.acc = acc; p.grad = grad; p.copies = grad_copies < 1 ? 1 : grad_copies; p.touched = touched; p.tag = tag; p.n_rows = n_rows;
   p.refcount = nullptr;
   p.src_rows = nullptr; p.slot_of = nullptr; p.n_ranks = 0; p.capacity = 0;
+  p.hot_slot = nullptr; p.n_hot = 0; p.hot_copies = 1; p.hot_row0 = 0;
   p.stride = stride; p.dim = dim; p.normalize = normalize; p.optimizer = optimizer; p.lr = lr;
   p.chunk = chunk_for(n_rows);
   const int64_t rows_per_block = (int64_t)(MKE_BLOCK / 64) * p.chunk;

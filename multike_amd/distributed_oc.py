@@ -227,6 +227,15 @@ class OcComm:
         dist.all_gather_object(out, obj, group=self.group)
         return out
 
+    def for_plan(self):
+        """A communicator of its own for the once-per-epoch all-gather of the negative codes: that collective is issued from
+        the plan's side stream while the step collectives run on the main stream — on one communicator the steps would queue
+        behind it (a process group's collectives execute in issue order)."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return self
+        return type(self)(dist.new_group(ranks=list(range(dist.get_world_size(self.group)))) if self.group is None else
+                          dist.new_group(ranks=dist.get_process_group_ranks(self.group)))
+
 
 class OcGlooComm(OcComm):
     """gloo has no reduce-scatter: all-reduce the whole buffer and keep this rank's block (CPU tests only)."""
@@ -372,6 +381,8 @@ class OwnerComputesTrainer:
         if comm is None:
             comm = OcComm() if (self.device.type == "cuda" or not dist.is_initialized()) else OcGlooComm()
         self.comm = comm
+        # the epoch plan's collective (the ranks' shares of the epoch's negative codes) on a communicator of its own
+        self._plan_comm = comm.for_plan() if (world > 1 and hasattr(comm, "for_plan")) else comm
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.dim = ent0.shape[1]
         self.stride = _lib.stride_for(self.dim)
@@ -385,6 +396,11 @@ class OwnerComputesTrainer:
         # inboxes (IPC handles exchanged once) and mke_oc_score reads / writes them straight over xGMI; two stream-ordered
         # barriers per step.  Correct by construction and tested with two ranks on one GPU; not measured on several.
         self.prefetch = bool(prefetch)
+        # MKE_OC_FORCE_COLLECTIVES=1: a one-rank group takes the G > 1 step path — its three collectives issued for real on the
+        # one-rank communicator — so that the host cost of that path (Python + torch.distributed per step) can be measured on
+        # one GPU (bench.py --force-sharded reports `host_us_per_step`)
+        import os as _os
+        self.force_collectives = _os.environ.get("MKE_OC_FORCE_COLLECTIVES", "0") == "1"
         self.peer_direct = bool(peer_direct) and world > 1
         if self.peer_direct:
             self.chunks = 1
@@ -508,14 +524,27 @@ class OwnerComputesTrainer:
         ph, pr, pt = pos
         n_all, parts, part_id = self._n_all, self._parts, self._part_id
         plan = {"bs": bs}
-        codes = self._persist(("codes", bs), torch.zeros(0, **i32), max(1, n_all * N))
+        # Every rank draws the negatives of ITS contiguous 1 / G of the epoch positions (the Philox stream is a function of
+        # the epoch position, so who draws a positive's negatives does not matter), packs them as codes, and ONE all-gather
+        # per epoch — on the plan's own communicator, from the stream the plan is computed on — gives every rank the whole
+        # epoch's codes in position order.  (Rounds 2-4: every rank drew all of them — 63 us per step of rank compute at the
+        # C5 shape with 8 ranks.)
+        n_per = -(-n_all // G) if n_all else 0            # positions per rank (the last rank's share may be shorter)
+        codes = self._persist(("codes", bs), torch.zeros(0, **i32), max(1, G * n_per * N))
         if n_all and N:
-            # scratch of the sampler's (h, r, t) output: kept across epochs (2.4 GB per column at the C5 shape — a fresh
-            # allocation per epoch was tens of ms of hipMalloc inside the plan)
-            neg = tuple(self._persist(("neg", k_), torch.zeros(0, **i32), n_all * N)[:n_all * N] for k_ in range(3))
-            self.backend.sample_at((ph[:n_all], pr[:n_all], pt[:n_all]), self._all_idx, b.pos_kg[:n_all], b.side1, b.side2, N,
-                                   b.rng_seed, rng_stream, neg)
-            self.backend.pack_codes(ph[:n_all], neg[0], neg[2], N, codes[:n_all * N])
+            lo_r, hi_r = min(n_all, self.rank * n_per), min(n_all, (self.rank + 1) * n_per)
+            mine = codes[self.rank * n_per * N:(self.rank + 1) * n_per * N] if G == 1 else \
+                self._persist(("codes_mine", bs), torch.zeros(0, **i32), n_per * N)[:n_per * N]
+            if hi_r > lo_r:
+                n_r = hi_r - lo_r
+                # scratch of the sampler's (h, r, t) output: kept across epochs (a fresh allocation per epoch was tens of ms of
+                # hipMalloc inside the plan); one plan at a time writes it (plans are computed in epoch order on one stream)
+                neg = tuple(self._persist(("neg", k_), torch.zeros(0, **i32), n_per * N)[:n_r * N] for k_ in range(3))
+                self.backend.sample_at((ph[lo_r:hi_r], pr[lo_r:hi_r], pt[lo_r:hi_r]), self._all_idx[lo_r:hi_r], b.pos_kg[lo_r:hi_r],
+                                       b.side1, b.side2, N, b.rng_seed, rng_stream, neg)
+                self.backend.pack_codes(ph[lo_r:hi_r], neg[0], neg[2], N, mine[:n_r * N])
+            if G > 1:
+                self._plan_comm.all_gather(codes[:G * n_per * N], mine)
         plan["codes"] = codes
         # slot of every positive's HR / RT vector in its owner's block (rank among the positives of its part with the same
         # owner, epoch order), this rank's owned positives per part in slot order (part k's list starts at own[lo_k]), and
@@ -705,7 +734,7 @@ class OwnerComputesTrainer:
         tag = self.tag
         ev = self.score_events
         slot0 = s * self.chunks
-        if G == 1:  # every row is local: no collective between the phases
+        if G == 1 and not self.force_collectives:  # every row is local: no collective between the phases
             last = len(ks) - 1
             if last == 0 and ev is None:
                 be.run(self, ks[0], tag, BASES | COUNT | SCORE | APPLY | UPDATE, 0, slot0)

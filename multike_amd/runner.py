@@ -21,7 +21,7 @@ _OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
 class RelationViewRunner:
     def __init__(self, ent: EmbeddingTable, rel: EmbeddingTable, batcher: RelationBatcher, opt_name: str = "relation",
                  lr: float = 0.001, optimizer: str = "Adagrad", scale: float = 1.0, sample_chunk: int | None = None,
-                 max_try: int = 10, exclusive_rows: bool = True, overlap: bool | None = None):
+                 max_try: int = 10, exclusive_rows: bool = True, overlap: bool | None = None, hot_rows: bool | None = None):
         if optimizer not in _OPT:
             raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
         self.ent, self.rel, self.bat = ent, rel, batcher
@@ -29,6 +29,11 @@ class RelationViewRunner:
         self.steps = batcher.steps
         self.exclusive_rows = exclusive_rows
         N = batcher.neg_per_pos
+        # Hub rows: entities that are head / tail of HOT_MIN (20) or more positives of an average step get private copies of their
+        # gradient row for the groups' flushes (the degree distribution is static: the positives are the KGs' triples in a new
+        # order every epoch).  hot_rows=None: when the table has no hub declaration yet and the KG has any; False: never.
+        if hot_rows is not False and ent.n_hot == 0 and ent.grad_copies == 1 and ent._grad is None and N > 0 and self.steps > 0:
+            self._declare_hot_rows(ent, batcher)
         # Default: negatives of a whole chunk are sampled by one launch on the same stream — by default the whole epoch
         # (910K positives x 25 x 12 B = 273 MB at the DBP-WD shape: nothing next to 288 GB).
         # overlap=True (opt-in): the next step's reference counts and the next chunk's negatives are produced on a
@@ -53,6 +58,18 @@ class RelationViewRunner:
         self._epoch_tag_base = None
         self.plan = _lib.RelationPlanStruct()
         self._fill_static()
+
+    # measured on the Zipf(1.0) C2 shape (EXPERIMENTS R5.2): 4 copies already take the score launch from 44 to 37-38 us (uniform: 35.5);
+    # more copies and a lower threshold only lengthen the update launch (each hub row sums its copies: 32 copies +4.5 us)
+    HOT_MIN, HOT_MAX, HOT_COPIES = 20.0, 1024, 8
+
+    def _declare_hot_rows(self, ent: EmbeddingTable, b: RelationBatcher):
+        deg = torch.bincount(torch.cat([b.pos_h, b.pos_t]).long(), minlength=ent.n_rows).float() / max(1, self.steps)
+        hot = torch.nonzero(deg >= self.HOT_MIN).reshape(-1)
+        if hot.numel() > self.HOT_MAX:
+            hot = torch.topk(deg, self.HOT_MAX).indices
+        if hot.numel():
+            ent.set_hot_rows(hot.cpu().numpy(), self.HOT_COPIES)
 
     def _fill_static(self):
         p, e, r, b = self.plan, self.ent, self.rel, self.bat
@@ -79,6 +96,7 @@ class RelationViewRunner:
         p.neg_h, p.neg_r, p.neg_t = (_lib.ptr(x, torch.int32, "neg") for x in self.neg)
         p.optimizer, p.lr, p.scale = _OPT[self.optimizer], self.lr, self.scale
         p.loss_partials, p.loss_ring = _lib.ptr(self.loss, torch.float64, "loss"), self.loss.shape[0]
+        p.hot = e.hot_struct()
 
     def _fill_epoch(self):
         p, b = self.plan, self.bat

@@ -41,6 +41,10 @@ class EmbeddingTable:
         self._grad = None
         self._touched = None
         self._refcount = None
+        # hub rows (include/multike_hip.h mke_hot_rows): rows that several positives of EVERY step have as head or tail; the
+        # groups' flushes go to `hot_copies` private copies kept behind the table's own rows in the gradient scratch
+        self.hot_slot = None          # int32 [n_rows]: index among the hub rows, or -1
+        self.n_hot, self.hot_copies = 0, 1
 
     @property
     def refcount(self) -> torch.Tensor:
@@ -52,10 +56,39 @@ class EmbeddingTable:
     # -- scratch (shared by every optimizer of this table; steps are serial on the stream) --
     @property
     def grad(self) -> torch.Tensor:
+        """[n_rows][stride] zero-invariant gradient scratch ([copies][n_rows][stride] when privatised as a whole)."""
         if self._grad is None:
-            self._grad = torch.zeros_like(self.data) if self.grad_copies == 1 else \
-                torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
+            if self.grad_copies == 1:
+                self._grad_full = torch.zeros(self.n_rows + self.hot_copies * self.n_hot, self.stride, dtype=torch.float32, device=self.device)
+                self._grad = self._grad_full[:self.n_rows]       # same storage: the hub rows' copies sit behind it
+            else:
+                self._grad = self._grad_full = torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
         return self._grad
+
+    def set_hot_rows(self, rows, copies: int = 16):
+        """Declare the hub rows of this table (ids, at most a few thousand): their gradient flushes are privatised `copies`
+        ways (mke_triple_score_fwd_bwd_xch / mke_update_table.hot).  Must be called before the scratch is first used, or
+        while it is all zero (between steps): the scratch is re-allocated with the copy rows behind the table's own."""
+        rows = np.unique(np.asarray(rows, dtype=np.int64))
+        if self.grad_copies != 1:
+            raise _lib.MultiKEHipError("hub rows and a wholly privatised gradient scratch exclude each other")
+        if len(rows) and (rows[0] < 0 or rows[-1] >= self.n_rows):
+            raise _lib.MultiKEHipError("hub row id outside the table")
+        slot = np.full(self.n_rows, -1, dtype=np.int32)
+        slot[rows] = np.arange(len(rows), dtype=np.int32)
+        self.hot_slot = torch.as_tensor(slot, device=self.device)
+        self.n_hot, self.hot_copies = int(len(rows)), max(1, int(copies))
+        self._grad = None            # re-created (all zero) with the copy rows on next use
+        if (self.n_rows + self.hot_copies * self.n_hot) * self.stride >= 2 ** 30:
+            self.hot_slot, self.n_hot, self.hot_copies = None, 0, 1      # would leave the kernels' 32-bit row offsets
+
+    def hot_struct(self):
+        """mke_hot_rows of this table (zeroed when it has none); touching `grad` first makes sure the scratch has the rows."""
+        h = _lib.HotRowsStruct()
+        if self.n_hot:
+            _ = self.grad
+            h.slot, h.n_hot, h.copies, h.row0 = _lib.ptr(self.hot_slot, torch.int32, "hot_slot"), self.n_hot, self.hot_copies, self.n_rows
+        return h
 
     @property
     def touched(self) -> torch.Tensor:

@@ -36,10 +36,15 @@ def _worker(rank, world, port, ret, n_ent, steps, chunks, excl):
         rng = np.random.default_rng(SEED)
         ent0 = mo.xavier_truncated_normal((n_ent, DIM), rng).astype(np.float64)
         rel0 = mo.xavier_truncated_normal((N_REL, DIM), rng).astype(np.float64)
-        tr = OwnerComputesTrainer(kgs, ent0, rel0, B, NEG, rank, world, seed=SEED, lr=0.05, backend=OcOracleBackend(),
+        be = OcOracleBackend()
+        drawn, orig_sample_at = [], be.sample_at
+        be.sample_at = lambda pos, *a, **k: (drawn.append(int(pos[0].numel())), orig_sample_at(pos, *a, **k))[1]
+        tr = OwnerComputesTrainer(kgs, ent0, rel0, B, NEG, rank, world, seed=SEED, lr=0.05, backend=be,
                                   device="cpu", dtype=torch.float64, chunks=chunks, exclusive_rows=excl)
         for i in range(steps):
             tr.step(i)
+        # no rank draws more than its 1 / world share of an epoch's negatives (one sampler call per planned epoch)
+        assert drawn and max(drawn) <= -(-tr._n_all // world), (drawn, tr._n_all)
         full = tr.gather_entity_table().numpy()
         assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0   # scratch consumed
         assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0

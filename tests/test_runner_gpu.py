@@ -11,11 +11,11 @@ from oracle import multike_oracle as mo
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=3, n_ent=4000, n_rel=30, d=75, B=500, N=10):
+def _setup(seed=3, n_ent=4000, n_rel=30, d=75, B=500, N=10, zipf=0.0):
     from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
     from multike_amd.synthetic import SyntheticKGs
     from multike_amd.tables import EmbeddingTable
-    kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, seed=seed)
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=n_rel, seed=seed, zipf=zipf)
     rng = np.random.default_rng(seed)
     ent = mo.xavier_truncated_normal((n_ent, d), rng)
     rel = mo.xavier_truncated_normal((n_rel, d), rng)
@@ -140,3 +140,47 @@ def test_run_epochs_prefetch_equals_plain_epochs():
     np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
     assert int(r1.refcount.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("d,N,n_ent,wide", [(75, 10, 4000, False), (256, 40, 3000, False), (32, 3, 2000, False), (64, 25, 20000, True)])
+def test_hub_rows_private_copies_are_the_same_function(d, N, n_ent, wide):
+    """Heavy-tailed KGs (SURVEY 8d's Zipf(1.0) variant; code/base/batch.py:45-54 feeds real, hub-heavy triples): the runner
+    declares the entities that several positives of every step share as hub rows and sends the groups' flushes of their
+    gradient to private copies (include/multike_hip.h mke_hot_rows).  Same function: losses and tables equal the run without
+    hub rows and the Python-driven steps; the copy rows are all zero again after every epoch.  wide: the whole-wavefront row
+    form of the update kernel (forced through "update_chunk")."""
+    from multike_amd import _lib
+    from multike_amd.runner import RelationViewRunner
+    from multike_amd.tables import StepEngine
+    kgs, ent, rel, fresh = _setup(seed=11, n_ent=n_ent, d=d, N=N, zipf=1.0)
+    old = _lib.set_option("update_chunk", 64 if wide else 0)
+    old_min = RelationViewRunner.HOT_MIN
+    RelationViewRunner.HOT_MIN = 6.0          # these small KGs: 15-20 hub rows instead of the 3-4 above the product's threshold
+    try:
+        E1, R1, bat1 = fresh()
+        r1 = RelationViewRunner(E1, R1, bat1, lr=0.01)
+        assert E1.n_hot >= 12 and E1.hot_copies == 8 and E1._grad_full.shape[0] == n_ent + 8 * E1.n_hot
+        E2, R2, bat2 = fresh()
+        r2 = RelationViewRunner(E2, R2, bat2, lr=0.01, hot_rows=False)
+        assert E2.n_hot == 0
+        for ep in range(2):
+            r1.run(); r2.run()
+            np.testing.assert_allclose(r1.step_losses().cpu().numpy(), r2.step_losses().cpu().numpy(), rtol=2e-6)
+            assert float(E1._grad_full.abs().max()) == 0.0            # the table's own rows AND the copies consumed
+            bat1.shuffle(); bat2.shuffle()
+        # hub rows: a gradient row is a float32 sum of tens of terms in two different orders
+        np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
+        # ... and the Python-driven steps on a hub-declared table (no copies used there) still agree
+        E3, R3, bat3 = fresh()
+        eng = StepEngine()
+        for s in range(bat3.steps):
+            pos, neg = bat3.batch(s)
+            eng.relation_step(E3, R3, "relation", pos, neg, neg_per_pos=N, lr=0.01)
+        E4, R4, bat4 = fresh()
+        r4 = RelationViewRunner(E4, R4, bat4, lr=0.01)
+        r4.run()
+        np.testing.assert_allclose(E4.raw().cpu().numpy(), E3.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
+    finally:
+        _lib.set_option("update_chunk", old)
+        RelationViewRunner.HOT_MIN = old_min

@@ -25,22 +25,77 @@ from multike_amd.synthetic import SyntheticKGs
 from multike_amd.tables import xavier_truncated_normal
 
 
+class _Work:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class LoopbackComm(OcComm):
-    def __init__(self, world, rank):
+    """Stand-in for the three collectives on ONE GPU: the all-gathered buffer = `world` copies of this rank's block, the
+    reduce-scatter keeps this rank's slice, the all-reduce is the identity — the REAL byte counts are copied in HBM.
+    wire_gbps > 0: the collective also holds its stream for bytes-on-the-wire / wire_gbps (a device-side sleep), the
+    modelled cost of the links (376 GB/s for an all-gather / reduce-scatter of equal blocks over 7 xGMI links),
+    plus latency_us per call.  async_op=True (the trainer's chunked schedule): the copy and the wait run on the communicator's
+    own stream, as torch.distributed's do, and the handle's wait() orders the caller's stream after them — what is measured
+    is then how much of the modelled wire time the schedule hides behind this rank's kernels."""
+
+    def __init__(self, world, rank, wire_gbps=0.0, latency_us=0.0):
         super().__init__(None)
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.wire_gbps, self.latency_us = world, rank, wire_gbps, latency_us
+        self.stream = torch.cuda.Stream()
+        self.clock_hz = 100e6          # torch.cuda._sleep counts cycles of the 100 MHz wall clock register on gfx9 (calibrated in main)
+        self.calls = 0
+
+    def for_plan(self):
+        return self
+
+    def _run(self, fn, wire_bytes, async_op):
+        self.calls += 1
+        cur = torch.cuda.current_stream()
+        hold = (wire_bytes / (self.wire_gbps * 1e9) if self.wire_gbps > 0 else 0.0) + self.latency_us * 1e-6
+        if not async_op:
+            fn()
+            if hold > 0:
+                torch.cuda._sleep(int(hold * self.clock_hz))
+            return None
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            fn()
+            if hold > 0:
+                torch.cuda._sleep(int(hold * self.clock_hz))
+            ev = torch.cuda.Event()
+            ev.record()
+        return _Work(ev)
 
     def all_gather(self, out, mine, async_op=False):
-        out.view(self.world, -1).copy_(mine.reshape(1, -1).expand(self.world, -1))
+        wire = (self.world - 1) * mine.numel() * mine.element_size()         # bytes this rank receives
+        return self._run(lambda: out.view(self.world, -1).copy_(mine.reshape(1, -1).expand(self.world, -1)), wire, async_op)
 
     def reduce_scatter(self, out, inp, async_op=False):
-        out.copy_(inp.view(self.world, -1)[self.rank].view_as(out))
+        wire = (self.world - 1) * out.numel() * out.element_size()
+        return self._run(lambda: out.copy_(inp.view(self.world, -1)[self.rank].view_as(out)), wire, async_op)
 
     def all_reduce(self, t, op=None):
-        pass
+        if self.latency_us > 0 or self.wire_gbps > 0:      # small replicated gradient: latency-bound
+            self._run(lambda: None, 2 * (self.world - 1) / self.world * t.numel() * t.element_size(), False)
 
     def barrier(self, token):
         pass
+
+
+def calibrate_sleep():
+    """cycles of torch.cuda._sleep per second on this device"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    e0.record()
+    torch.cuda._sleep(10_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    return 10_000_000 / (e0.elapsed_time(e1) * 1e-3)
 
 
 def main():
@@ -49,6 +104,9 @@ def main():
     ap.add_argument("--config", choices=["c2", "c5"], default="c2")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--chunks", type=int, default=1)
+    ap.add_argument("--wire-gbps", type=float, default=0.0, help="modelled link rate of an all-gather / reduce-scatter (0: HBM copies only)")
+    ap.add_argument("--latency-us", type=float, default=0.0, help="modelled launch latency per collective call")
+    ap.add_argument("--prefetch", action="store_true", help="the next epoch's plan on the side stream while the steps run (the product's default)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
     a = ap.parse_args()
     for kv in a.set:
@@ -60,7 +118,9 @@ def main():
     g = torch.Generator(device="cpu"); g.manual_seed(1)
     ent0 = (torch.randn(cfg["n_ent"], cfg["dim"], generator=g) * float(np.sqrt(2.6 / (cfg["n_ent"] + cfg["dim"])))).numpy()
     rel0 = xavier_truncated_normal(cfg["n_rel"], cfg["dim"], "cpu", seed=2).numpy()
-    tr = OwnerComputesTrainer(kgs, ent0, rel0, B, cfg["neg"], 0, G, seed=1, chunks=a.chunks, comm=LoopbackComm(G, 0), prefetch=False)
+    comm = LoopbackComm(G, 0, a.wire_gbps, a.latency_us)
+    comm.clock_hz = calibrate_sleep()
+    tr = OwnerComputesTrainer(kgs, ent0, rel0, B, cfg["neg"], 0, G, seed=1, chunks=a.chunks, comm=comm, prefetch=a.prefetch)
     names = {BASES | COUNT: "bases+count", BASES: "bases", SCORE: "score", APPLY: "apply", UPDATE: "update", APPLY | UPDATE: "apply+update",
              BASES | COUNT | SCORE | APPLY | UPDATE: "whole step (one call)"}
     ev = []
@@ -89,6 +149,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(5, n):
         tr.step(i)
+    host = (time.perf_counter() - t0) / max(1, n - 5)         # the enqueue loop alone (nothing waits for the device)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / max(1, n - 5)
     # instrumented pass
@@ -106,7 +167,9 @@ def main():
            "phase_us": {k: float(np.mean(v)) for k, v in phases.items()},
            "compute_us_per_step": float(sum(np.mean(v) * (len(v) / max(1, len(phases.get("score", v)))) for v in phases.values())),
            "epoch_plan_ms": plan_ms, "epoch_plan_us_per_step": plan_ms * 1e3 / tr.steps,
-           "wall_us_per_step_loopback": wall * 1e6,
+           "wall_us_per_step_loopback": wall * 1e6, "host_us_per_step": host * 1e6,
+           "wire_gbps_modelled": a.wire_gbps, "latency_us_modelled": a.latency_us, "prefetch": a.prefetch,
+           "rank_share_of_epoch_sampled": 1.0 / G,
            "note": "rank 0's kernels at world-size shapes on one GPU; collectives are loop-back device copies (not measured links)"}
     print(json.dumps(out))
 
