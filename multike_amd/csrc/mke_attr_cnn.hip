@@ -137,13 +137,15 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
   // runs not to overlap: 4 DP already is (the c1 strips); the x strips get their own row length (2 DPX = 16 mod 32)
   constexpr int DPX = LPT == 16 ? DP + ((8 - DP % 16) + 16) % 16 : DP;
   __shared__ float s_x[NSLOT][2][DPX];
-  __shared__ float s_c1[NSLOT][2][2][DP];
-  __shared__ float s_d2[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
-  __shared__ float s_d1[BWD ? NSLOT : 1][2][2][BWD ? DP : 1];
+  // the c1 / d2 / d1 strips as ONE array: the rider blocks' exchange area (20 KB) is aliased onto its start whatever the width
+  // (aliased onto the c1 strips alone it fitted only above dim 64, and at dim 64 itself the block then took 82 KB of LDS = one
+  // per compute unit: 62 us per step against 52 at dim 75)
+  __shared__ float s_strips[BWD ? 3 : 1][NSLOT][2][2][DP];
+  float (&s_c1)[NSLOT][2][2][DP] = s_strips[0];
+  float (&s_d2)[NSLOT][2][2][DP] = s_strips[BWD ? 1 : 0];
+  float (&s_d1)[NSLOT][2][2][DP] = s_strips[BWD ? 2 : 0];
   if constexpr (DFL) {
-    // the rider's exchange area (20 KB): aliased onto the c1 strips where they are large enough (dim > 64: the block is at 79 KB
-    // of LDS, two per CU), its own array otherwise
-    constexpr bool ALIAS = sizeof(s_c1) >= sizeof(float) * (MKE_BLOCK / 64) * 5 * 4 * 64;
+    constexpr bool ALIAS = sizeof(s_strips) >= sizeof(float) * (MKE_BLOCK / 64) * 5 * 4 * 64;
     __shared__ float s_rider[ALIAS ? 1 : (MKE_BLOCK / 64) * 5 * 4 * 64];
     static_assert(2 * 2 * DP >= 4 * LPT * WPL, "a triple's dflat row must fit its own d1 strip");
     if ((int)blockIdx.x >= p.conv_blocks) {      // block-uniform: a rider of the weight-gradient product
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
       const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
       const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;
       gemm_tall_block_dz<5, 32, 4>(p.tall, r % p.tall.gx, r / p.tall.gx,
-                                   reinterpret_cast<float (*)[5][4][64]>(ALIAS ? &s_c1[0][0][0][0] : &s_rider[0]), p.zmat, inv, coef);
+                                   reinterpret_cast<float (*)[5][4][64]>(ALIAS ? &s_strips[0][0][0][0][0] : &s_rider[0]), p.zmat, inv, coef);
       return;
     }
   }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
       for (int c = 0; c < NTB; ++c) bw[i][c] = p.W[kc * ncol + min(16 * (wv + 4 * c) + r16, ncol - 1)];
     }
     float* s_dz = &s_x[0][0][0];
-    static_assert(sizeof(s_x) >= sizeof(float) * NSLOT * LPT * WPL, "the dz tile (16 rows of dim <= 16 WPL floats) must fit the x strips");
+    static_assert(sizeof(s_x) >= sizeof(float) * NSLOT * (LPT * WPL + 1), "the dz tile (16 rows of dim <= 16 WPL floats, odd row stride) must fit the x strips");
     {
       // the tile's g and z are requested before the two batch-wide sums are added up (one round trip for all of it)
       constexpr int NEL = (NSLOT * LPT * WPL + NT - 1) / NT;
@@ -205,14 +207,19 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
       totals_of_partials2(p.ssq, p.dotp, S, T);
       const float inv = rsqrtf(fmaxf((float)S, MKE_L2_EPS));
       const float coef = (float)S > MKE_L2_EPS ? (float)T * inv * inv : 0.f;
+      // row stride of the tile in LDS: odd (dim 64 with stride 64 put the 16 rows of a fragment read on ONE bank: 62.5 us per
+      // step against 52.3 at dim 75)
+      const int sd = d | 1;
 #pragma unroll
-      for (int q = 0; q < NEL; ++q)
-        if (threadIdx.x + q * NT < NSLOT * d) s_dz[threadIdx.x + q * NT] = dz_of(gv[q], zv[q], inv, coef);
+      for (int q = 0; q < NEL; ++q) {
+        const int e = threadIdx.x + q * NT;
+        if (e < NSLOT * d) s_dz[(e / d) * sd + e % d] = dz_of(gv[q], zv[q], inv, coef);
+      }
     }
     __syncthreads();
     float av[KSB];
 #pragma unroll
-    for (int i = 0; i < KSB; ++i) av[i] = s_dz[r16 * d + min(4 * i + kq, d - 1)];
+    for (int i = 0; i < KSB; ++i) av[i] = s_dz[r16 * (d | 1) + min(4 * i + kq, d - 1)];
     f32x4 acc[NTB];
 #pragma unroll
     for (int c = 0; c < NTB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -842,7 +849,7 @@ int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const fl
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
-int g_attr_fused_bwd = 1;     // mke_set_option("attr_fused_bwd"): dflat inside the convolution-backward launch, dW on rider blocks (dim <= 80)
+int g_attr_fused_bwd = 1;     // mke_set_option("attr_fused_bwd"): dflat inside the convolution-backward launch, dW on rider blocks (every dim <= 80)
 
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   // dim <= 96: two triples per wavefront, 32 lanes each (dim 75: three passes of 32 lanes instead of two of 64)
@@ -1111,12 +1118,12 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
     }
   }
   const bool upd = a->update != 0 && (phases & MKE_ATTR_UPD);
-  // round 4 (64 < dim <= 80): the rest of the backward is ONE launch — every convolution-backward block forms its 16 rows of
+  // dim <= 80 (round 4: 64 < dim <= 80; round 5: every narrower width too): the rest of the backward is ONE launch — every convolution-backward block forms its 16 rows of
   // dz = dL/dzpre from g and z with the two batch-wide sums, multiplies them with W^T on the matrix cores straight into its LDS strips
   // (dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split over K, atomic) rides on extra blocks of the same grid,
   // forming dz on the way into its MFMAs.  W^T (the B operand read 16 consecutive floats per quarter-wave) is left in the unused dflat
   // scratch by the loss-tail launch.  4 launches per step: forward, loss tail, backward, updates.
-  const bool fused = g_attr_fused_bwd && d > 64 && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
+  const bool fused = g_attr_fused_bwd && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
   if ((phases & MKE_ATTR_TAIL) &&
       (rc = tail_loss_impl(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                            a->ent_grad, a->ent_touched, a->tag, lossp, fused ? W : nullptr, fused ? dflat : nullptr, stream))) return rc;

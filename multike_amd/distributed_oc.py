@@ -237,6 +237,85 @@ class OcComm:
                           dist.new_group(ranks=dist.get_process_group_ranks(self.group)))
 
 
+class _EventWork:
+    """Handle of an asynchronous collective: wait() orders the CURRENT stream after it (no host wait)."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+class OcRcclComm(OcComm):
+    """The three collectives through RCCL directly (multike_amd/rccl.py), enqueued ON THE CALLER'S STREAM: stream order is the
+    dependency, no event and no second stream per collective (torch.distributed's two stream hops per collective cost ~26 us
+    of device time and ~30 us of host time each on this part: EXPERIMENTS R5.3).  async_op=True (the chunk-pipelined schedule)
+    goes to this communicator's own stream with two pooled events.  The default of the HIP trainers on an "nccl" process
+    group; MKE_OC_COMM=torch selects OcComm."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        from .rccl import Communicator
+        self.c = Communicator(group)
+        self.c.self_check()                 # all three collectives give the right sums, or raise before any training step
+        self._side, self._events, self._k = None, None, 0
+
+    def _async(self, fn):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._events = [torch.cuda.Event() for _ in range(64)]
+        cur = torch.cuda.current_stream()
+        e_in, e_out = self._events[self._k % 64], self._events[(self._k + 1) % 64]
+        self._k += 2
+        e_in.record(cur)
+        self._side.wait_event(e_in)
+        fn(self._side)
+        e_out.record(self._side)
+        return _EventWork(e_out)
+
+    def all_gather(self, out, mine, async_op=False):
+        o, m = out.view(-1), mine.reshape(-1)
+        if async_op:
+            return self._async(lambda st: self.c.all_gather(o, m, st))
+        self.c.all_gather(o, m)
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        o, i = out.view(-1), inp.view(-1)
+        if async_op:
+            return self._async(lambda st: self.c.reduce_scatter(o, i, st))
+        self.c.reduce_scatter(o, i)
+
+    def all_reduce(self, t, op=None):
+        if op is not None:
+            return super().all_reduce(t, op)
+        self.c.all_reduce(t.view(-1))
+
+    def barrier(self, token):
+        self.c.all_reduce(token.view(-1))
+
+    def for_plan(self):
+        """A second RCCL communicator (concurrent with the step collectives), one per step communicator."""
+        if getattr(self, "_plan", None) is None:
+            self._plan = OcRcclComm(self.group)
+        return self._plan
+
+
+_DEFAULT_RCCL = None        # the process's step communicator over the world: every trainer of a model shares it
+
+
+def default_comm(device, world, force=False):
+    """The communicator a HIP trainer uses when none is given."""
+    import os
+    global _DEFAULT_RCCL
+    if device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl" and (world > 1 or force) \
+            and os.environ.get("MKE_OC_COMM", "rccl") != "torch":
+        if _DEFAULT_RCCL is None or _DEFAULT_RCCL.c.world != dist.get_world_size():
+            _DEFAULT_RCCL = OcRcclComm()
+        return _DEFAULT_RCCL
+    return OcComm() if (device.type == "cuda" or not dist.is_initialized()) else OcGlooComm()
+
+
 class OcGlooComm(OcComm):
     """gloo has no reduce-scatter: all-reduce the whole buffer and keep this rank's block (CPU tests only)."""
 
@@ -378,8 +457,10 @@ class OwnerComputesTrainer:
             rel0 = np.empty((tables_of.rel.shape[0], tables_of.dim), dtype=np.float32)
         self.backend = backend or OcHipBackend()
         self.device = torch.device(device or ("cuda" if self.backend.device_type == "cuda" else "cpu"))
+        import os as _os
+        self.force_collectives = _os.environ.get("MKE_OC_FORCE_COLLECTIVES", "0") == "1"
         if comm is None:
-            comm = OcComm() if (self.device.type == "cuda" or not dist.is_initialized()) else OcGlooComm()
+            comm = default_comm(self.device, world, self.force_collectives)
         self.comm = comm
         # the epoch plan's collective (the ranks' shares of the epoch's negative codes) on a communicator of its own
         self._plan_comm = comm.for_plan() if (world > 1 and hasattr(comm, "for_plan")) else comm
@@ -399,8 +480,6 @@ class OwnerComputesTrainer:
         # MKE_OC_FORCE_COLLECTIVES=1: a one-rank group takes the G > 1 step path — its three collectives issued for real on the
         # one-rank communicator — so that the host cost of that path (Python + torch.distributed per step) can be measured on
         # one GPU (bench.py --force-sharded reports `host_us_per_step`)
-        import os as _os
-        self.force_collectives = _os.environ.get("MKE_OC_FORCE_COLLECTIVES", "0") == "1"
         self.peer_direct = bool(peer_direct) and world > 1
         if self.peer_direct:
             self.chunks = 1

@@ -1,4 +1,4 @@
-"""Attribute-view step only (B = 5000, dim 75), for rocprofv3 --kernel-trace: `python tools/attr_prof.py [steps] [B]`."""
+"""Attribute-view step only (B = 5000, dim 75), for rocprofv3 --kernel-trace: `python tools/attr_prof.py [steps] [B] [dim]`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,7 @@ from multike_amd import _lib
 for kv in filter(None, os.environ.get("MKE_SET", "").split(",")):      # MKE_SET=option=value,...: A/B of a kernel choice
     _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-d, B = 75, (int(sys.argv[2]) if len(sys.argv) > 2 else 5000)
+d, B = (int(sys.argv[3]) if len(sys.argv) > 3 else 75), (int(sys.argv[2]) if len(sys.argv) > 2 else 5000)
 E = EmbeddingTable(200_000, d, "av", seed=1); A = EmbeddingTable(600, d, "attr", normalize=False, seed=2)
 lit = np.random.default_rng(0).standard_normal((100_000, d)).astype(np.float32); lit /= np.linalg.norm(lit, axis=1, keepdims=True)
 L = EmbeddingTable(100_000, d, "lit", normalize=False, trainable=False, values=lit)

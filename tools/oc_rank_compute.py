@@ -48,6 +48,7 @@ class LoopbackComm(OcComm):
         self.stream = torch.cuda.Stream()
         self.clock_hz = 100e6          # torch.cuda._sleep counts cycles of the 100 MHz wall clock register on gfx9 (calibrated in main)
         self.calls = 0
+        self.events, self.k = None, 0
 
     def for_plan(self):
         return self
@@ -61,14 +62,19 @@ class LoopbackComm(OcComm):
             if hold > 0:
                 torch.cuda._sleep(int(hold * self.clock_hz))
             return None
-        self.stream.wait_stream(cur)
+        # as OcRcclComm._async: the communicator's own stream, two pooled events
+        if self.events is None:
+            self.events = [torch.cuda.Event() for _ in range(64)]
+        e_in, e_out = self.events[self.k % 64], self.events[(self.k + 1) % 64]
+        self.k += 2
+        e_in.record(cur)
+        self.stream.wait_event(e_in)
         with torch.cuda.stream(self.stream):
             fn()
             if hold > 0:
                 torch.cuda._sleep(int(hold * self.clock_hz))
-            ev = torch.cuda.Event()
-            ev.record()
-        return _Work(ev)
+            e_out.record(self.stream)
+        return _Work(e_out)
 
     def all_gather(self, out, mine, async_op=False):
         wire = (self.world - 1) * mine.numel() * mine.element_size()         # bytes this rank receives
