@@ -694,6 +694,8 @@ def main():
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
 
+    from multike_amd.utils import touch_library_kernels
+    touch_library_kernels(torch.device("cuda", local_rank))      # what the model's constructor does (code-object loads of the library families)
     d, N, B = args.dim, args.neg, args.batch
     cfg = dict(n_ent=args.n_ent, n_rel=args.n_rel, dim=d, neg=N, batch=B)
     sharded = world > 1 or args.force_sharded

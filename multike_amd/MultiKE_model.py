@@ -26,7 +26,7 @@ from .attr_cnn import AttrCNN
 from .runner import RelationViewRunner
 from .sampling import KGSide, KnownTripleSet, RelationBatcher, int_triples
 from .tables import ADAGRAD_INIT_ACC, EmbeddingTable, StepEngine
-from .utils import generate_out_folder, save_embeddings
+from .utils import generate_out_folder, save_embeddings, touch_library_kernels
 
 _HIP_OPTS = ("Adagrad", "SGD")            # touched-rows rules: fused / native multi-step paths
 _DENSE_OPTS = tuple(_lib.DENSE_OPTS)        # Adam, Adadelta: whole-variable kernels, step-wise loops
@@ -191,6 +191,7 @@ class MultiKE:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._lists: dict = {}
+        touch_library_kernels(self.device)      # code-object loads of the library kernel families: here, not inside the first epochs
         self._defer_losses = False      # drivers set it while they enqueue independent phases on two streams
         # test / debugging hook: `recorder(phase, **index_streams)` is called by every native train_*_1epo with the exact
         # device index streams the epoch consumed (positives, sampled negatives, weights, step offsets) — what a float64
