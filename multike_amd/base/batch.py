@@ -160,7 +160,8 @@ def neighbour_table(entity_embeds, entity_list, neighbors_num, n_ent_total, devi
         return (table, valid) if part is None else (table, valid, ids[p_lo:p_hi])
 
     # The working order and the column sample are keyed permutations computed on the device with INTEGER arithmetic only
-    # (argsort of splitmix64(i + seed)): a function of (n, seed) alone, identical on every rank, device architecture and torch
+    # (argsort of a splitmix64-style mix of i + seed — `>>` on int64 is an arithmetic shift here, so it is not the textbook
+    # function, only a fixed one): a function of (n, seed) alone, identical on every rank, device architecture and torch
     # build.  Round 3 drew them from a device torch.Generator — fast (a CPU permutation of 100K ids is 9 ms the GPU waits for),
     # but in part mode the slices of the multi-GPU refresh are DEFINED in this order, and a generator stream that differed
     # between ranks would silently leave candidate rows unfilled.

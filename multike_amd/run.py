@@ -81,6 +81,16 @@ def main(argv=None):
         data = DataModel(args)
         return data, PredicateAlignModel(data.kgs, args)
 
+    def _checksum(data):
+        import hashlib
+        import numpy as np
+        h = hashlib.sha256()
+        for name in ("value_vectors", "local_name_vectors"):
+            v = getattr(data, name, None)
+            if v is not None:
+                h.update(np.ascontiguousarray(np.asarray(v, dtype=np.float32)).tobytes())
+        return h.hexdigest()
+
     if world > 1:
         import contextlib
         import io
@@ -89,13 +99,28 @@ def main(argv=None):
         # same bytes on every rank instead of N independently trained copies
         quiet = contextlib.redirect_stdout(io.StringIO()) if rank else contextlib.nullcontext()    # the readers print per rank
         with quiet:
+            # rank 0's outcome travels to the others (an object broadcast, which the waiting ranks sit in with the process
+            # group's own timeout): a failed preparation ends every rank with the error instead of leaving them in a barrier,
+            # and the checksum of the literal vectors is compared afterwards — ranks that do not see the same dataset folder
+            # (several nodes, a read-only mount) would otherwise train on different constants without a word
+            status = [None]
             if rank == 0:
-                data, predicate_align_model = load_data()
-            dist.barrier()
+                try:
+                    data, predicate_align_model = load_data()
+                    status[0] = ("ok", _checksum(data))
+                except Exception as e:          # noqa: BLE001 — reported on every rank, re-raised below
+                    status[0] = ("failed", f"{type(e).__name__}: {e}")
+            dist.broadcast_object_list(status, src=0)
+            if status[0][0] != "ok":
+                dist.destroy_process_group()
+                raise SystemExit(f"multike_amd.run: rank 0 could not prepare the dataset: {status[0][1]}")
             if rank != 0:
                 retrain, args.retrain_literal_embeds = getattr(args, "retrain_literal_embeds", False), False
                 data, predicate_align_model = load_data()
                 args.retrain_literal_embeds = retrain
+                if _checksum(data) != status[0][1]:
+                    raise SystemExit(f"multike_amd.run: rank {rank} loaded other literal / name vectors than rank 0 — every rank must "
+                                     "read the same dataset folder (with rank 0's literal cache in it)")
             cls = ShardedMultiKE_CV if a.method == "ITC" else ShardedMultiKE_Late
             model = cls(data, args, predicate_align_model, rank, world, comm_oc, comm_v)
             res = model.run()               # the schedule prints once (rank 0), not once per rank
