@@ -2,7 +2,7 @@
 steps, ON THE STREAM THE KERNELS RUN ON.
 
 Why not torch.distributed for them: ProcessGroupNCCL runs every collective on a stream of its own and orders it against the
-caller's stream with two events.  Measured on MI355X (`tools/.scratch/async_probe.py`, EXPERIMENTS R5.3): a hop to another
+caller's stream with two events.  Measured on MI355X (`tools/stream_hop_probe.py`, EXPERIMENTS R5.3): a hop to another
 stream and back costs ~26 us on the DEVICE timeline (inter-queue barrier packets) and ~30 us of host time, per collective —
 three collectives per global step, on a step whose kernels take 76 us at the C2 shape.  A collective enqueued on the compute
 stream itself needs no event at all: stream order is the dependency.  (`async_op=True`, the chunk-pipelined schedule, still
