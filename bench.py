@@ -185,6 +185,11 @@ def cpu_baseline(args, kgs, ent, rel):
         # was normalised as a whole first, then Jacobian + Adagrad over EVERY row (the passes the reference's dense graph
         # makes every step).  On a host with a large last-level cache the whole-table pass streams the 60 MB table in ahead
         # of the step's random row gathers and can come out FASTER than the touched-rows form, which misses on ~half of them
+        # which leg is which (round-4 review, weak 9): `whole_table_passes_value` is the reference-FAITHFUL cost model — TF1's dense
+        # graph normalises the whole variable and applies Adagrad to every row at every step (code/base/initializers.py:26,
+        # code/MultiKE_model.py:15-31) — while `value` is the same arithmetic restricted to the touched rows (what any sparse
+        # implementation, this package included, does).  Neither is TensorFlow itself (BASELINE.md estimates that at 0.18 M/s).
+        "reference_faithful_leg": "whole_table_passes_value",
         "whole_table_passes_value": vd,
         "whole_table_passes_sample": f"{dsteps} steps ({ddt:.1f}s) on {threads_all} threads, interleaved step by step with the "
                                      f"touched-rows leg: whole-table normalise + Jacobian/Adagrad over all {ent.shape[0]} rows",

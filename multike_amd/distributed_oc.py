@@ -310,9 +310,23 @@ def default_comm(device, world, force=False):
     global _DEFAULT_RCCL
     if device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl" and (world > 1 or force) \
             and os.environ.get("MKE_OC_COMM", "rccl") != "torch":
-        if _DEFAULT_RCCL is None or _DEFAULT_RCCL.c.world != dist.get_world_size():
-            _DEFAULT_RCCL = OcRcclComm()
-        return _DEFAULT_RCCL
+        if _DEFAULT_RCCL is None or (_DEFAULT_RCCL is not False and _DEFAULT_RCCL.c.world != dist.get_world_size()):
+            # every rank tries; the ranks then agree (one torch.distributed all-reduce) on whether ALL of them succeeded — a
+            # communicator that came up on some ranks only must not be used by any
+            try:
+                cand, err = OcRcclComm(), None
+            except Exception as e:      # noqa: BLE001 — reported below, the torch.distributed communicator takes over
+                cand, err = None, e
+            ok = torch.tensor([1 if cand is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 1:
+                _DEFAULT_RCCL = cand
+            else:
+                import warnings
+                warnings.warn(f"multike_amd: RCCL through ctypes did not come up on every rank ({err!r} on this one): using torch.distributed for the collectives")
+                _DEFAULT_RCCL = False
+        if _DEFAULT_RCCL is not False:
+            return _DEFAULT_RCCL
     return OcComm() if (device.type == "cuda" or not dist.is_initialized()) else OcGlooComm()
 
 
