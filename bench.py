@@ -718,8 +718,8 @@ def main():
             import tempfile
             dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))   # a rendezvous file: no TCP port to collide on
-        # MKE_SHARD_MODE=oc (default): owner-computes step (multike_amd/distributed_oc.py: the negatives go to the rows, 2
-        # vectors per positive cross the links); =rowfetch: round 1's row-exchange step (multike_amd/distributed.py)
+        # MKE_SHARD_MODE=oc (default): owner-computes step (multike_amd/distributed_oc.py: the negatives go to the rows, ~1
+        # vector per positive crosses the links); =rowfetch: round 1's row-exchange step (multike_amd/distributed.py)
         shard_mode = os.environ.get("MKE_SHARD_MODE", "oc")
         if shard_mode == "rowfetch":
             from multike_amd.distributed import HostStagedComm, ShardedRelationTrainer
@@ -730,9 +730,9 @@ def main():
             # split-batch pipelining pays when a collective's wire time is well above what an asynchronous collective
             # costs on its own (tools/rccl_latency.py at world 1: ~30 us of device time per async call + wait against
             # ~15 us in line; 27 us against 13 us on the host): two parts when a rank's all-gather moves >= 32 MB
-            # (the c5 shape at 8 ranks: 75 MB), one otherwise (c2: 23.5 MB)
+            # (the c5 shape at 8 ranks: 40 MB now that one vector per positive travels), one otherwise (c2: 12.4 MB)
             stride_f = (d + 15) // 16 * 16
-            wire = (world - 1) * 2 * 1.05 * B * stride_f * 4
+            wire = (world - 1) * 2 * 0.56 * B * stride_f * 4
             chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 and wire >= 32e6 else "1"))
             # MKE_SHARD_PEER=1: peer-mapped blocks read / written directly by the score kernel instead of the all-gather /
             # reduce-scatter (opt-in: exercised with two ranks on one GPU only)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 103 /* 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
+#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
@@ -777,22 +777,30 @@ int mke_dense_layer_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw
  *      single-device).  Entity rows are sharded id % n_ranks (local row = id / n_ranks); the relation table is replicated.
  *      A global step = n_pos positives in the reference's epoch order; rank g is HOME of positives [g*per, (g+1)*per).
  *      Instead of moving entity rows to the triples, each rank scores the negatives whose corrupted entity it owns; what
- *      crosses the links per positive p is HR_p = h^ + r^ (built by the owner of h), RT_p = r^ - t^ (built by the owner of
- *      t) and the gradients w.r.t. them.  Per step, on every rank:
+ *      crosses the links per positive p is HR_p = h^ + r^ (built by the owner of h) when a negative of p corrupts the tail,
+ *      RT_p = r^ - t^ (built by the owner of t) when one corrupts the head, and the gradients w.r.t. them.  The reference's
+ *      sampler tosses one coin per ROUND (code/base/batch.py:97-105), so almost every positive needs only ONE of the two; the
+ *      positive's own term is scored like a negative, by the owner of the entity the travelling vector lacks
+ *      (d = HR_p - t^ at the owner of t, or h^ + RT_p at the owner of h).  Per step, on every rank:
  *          mke_oc_bases  -> all-gather of the send blocks (mke_oc_count meanwhile) -> mke_oc_score -> reduce-scatter of
  *          g_all -> mke_oc_apply -> all-reduce of rel_grad -> mke_rows_update_multi(relation table, shard)
  *      Block of rank o (mke_oc_block_floats floats): [capacity] HR vectors (slot order) | [capacity] RT vectors.
- *      codes: the negatives as (corrupt entity << 1) | corrupted-head, packed by every home rank for its own positives
- *      (mke_oc_pack_codes; table-independent, exchanged once per epoch); the codes of home rank g's positives of this step
- *      are codes[code_off[g] + j * neg_per_pos + n] (j-th positive of its slice).
+ *      codes: the negatives as (corrupt entity << 1) | corrupted-head (entity ids < 2^29), packed by every home rank for its
+ *      own positives (mke_oc_pack_codes; table-independent, exchanged once per epoch); the codes of home rank g's positives
+ *      of this step are codes[code_off[g] + j * neg_per_pos + n] (j-th positive of its slice).  The FIRST code of a positive
+ *      also carries which vectors its group needs: MKE_OC_NEED_RT (some negative corrupts the head), MKE_OC_NEED_HR (some
+ *      negative corrupts the tail, or none corrupts the head: the positive's own term needs one of the two).
  *      slot_h[i] / slot_t[i]: slot of positive i's HR / RT vector in its owner's block (i-th positive of the step; any
- *      numbering the ranks agree on); own_h / own_t: the positives whose head / tail this rank owns, in slot order.
+ *      numbering the ranks agree on), -1 when that vector is not needed; own_h / own_t: the positives whose head / tail this
+ *      rank owns AND whose HR / RT vector is needed, in slot order.
  *      g_all: [n_ranks][2 * capacity][stride] — every slot is overwritten each step; gv: this rank's block after the
  *      reduce-scatter.  ref_count (nullable): zero-invariant counters of the exclusive-row fast path (a corrupt row
  *      referenced once in the whole global step is updated in place by mke_oc_score).  Same arithmetic as
  *      mke_triple_score_fwd_bwd_x; both tables are read through l2_normalize (the relation view's tables).
  * ------------------------------------------------------------------------------------------------ */
 #define MKE_OC_MAX_RANKS 16
+#define MKE_OC_NEED_HR 0x40000000u
+#define MKE_OC_NEED_RT 0x80000000u
 typedef struct mke_oc_step {
   float* ent; float* ent_acc /*nullable: SGD*/; float* ent_grad; int32_t* ent_touched; int32_t* ref_count /*nullable*/;
   int64_t n_local;
@@ -815,16 +823,20 @@ typedef struct mke_oc_step {
   const float* pos_w;   /* nullable: [n_pos] weights of the positives (the weighted cross-KG loops, code/losses.py:44-50) */
 } mke_oc_step;
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
-/* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output */
+/* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output; the group flags
+ * (MKE_OC_NEED_*) go into codes[p * neg_per_pos] */
 int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, const int32_t* neg_t, int64_t n_pos, int neg_per_pos,
                       int32_t* codes, void* stream);
 /* Per-epoch plan (table-independent; new design, no reference counterpart): part k of the epoch = epoch positions
- * [part_lo[k], part_lo[k+1]) (device array of n_parts + 1 offsets).  slot_h[i] / slot_t[i] = rank of positive i among the
- * positives of its part whose head / tail has the same owner (id % n_ranks), in epoch order; own_h / own_t[part_lo[k] + s] =
- * position inside part k of the positive holding slot s of THIS rank's block (s < counts[...][rank]);
- * counts[(x * n_parts + k) * n_ranks + g] = positives of part k whose head (x = 0) / tail (x = 1) rank g owns. */
-int mke_oc_plan(const int32_t* pos_h, const int32_t* pos_t, const int64_t* part_lo, int n_parts, int n_ranks, int rank,
-                int32_t* slot_h, int32_t* slot_t, int32_t* own_h, int32_t* own_t, int32_t* counts, void* stream);
+ * [part_lo[k], part_lo[k+1]) (device array of n_parts + 1 offsets); codes = the WHOLE epoch's codes by epoch position
+ * (codes[i * neg_per_pos + n]; nullable when neg_per_pos == 0: every positive then needs HR).  slot_h[i] / slot_t[i] = rank of
+ * positive i among the positives of its part that need HR / RT and whose head / tail has the same owner (id % n_ranks), in
+ * epoch order, -1 when positive i does not need that vector; own_h / own_t[part_lo[k] + s] = position inside part k of the
+ * positive holding slot s of THIS rank's block (s < counts[...][rank]);
+ * counts[(x * n_parts + k) * n_ranks + g] = positives of part k needing HR (x = 0) / RT (x = 1) whose head / tail rank g owns. */
+int mke_oc_plan(const int32_t* pos_h, const int32_t* pos_t, const int32_t* codes, int neg_per_pos, const int64_t* part_lo,
+                int n_parts, int n_ranks, int rank, int32_t* slot_h, int32_t* slot_t, int32_t* own_h, int32_t* own_t,
+                int32_t* counts, void* stream);
 int mke_oc_bases(const mke_oc_step* step, float* send_block, void* stream);
 int mke_oc_count(const mke_oc_step* step, void* stream);
 int mke_oc_score(const mke_oc_step* step, const float* v_all, int64_t block_floats, float* g_all,

@@ -713,10 +713,15 @@ def oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos: int, codes):
     _check(rc, "mke_oc_pack_codes")
 
 
-def oc_plan(pos_h, pos_t, part_lo, n_parts: int, n_ranks: int, rank: int, slot_h, slot_t, own_h, own_t, counts):
-    """The epoch's slots / owned lists / per-(part, owner) counts in one launch (mke_oc_plan)."""
+OC_NEED_HR, OC_NEED_RT, OC_CODE_MASK = 0x40000000, 0x80000000, 0x3FFFFFFF
+
+
+def oc_plan(pos_h, pos_t, codes, neg_per_pos: int, part_lo, n_parts: int, n_ranks: int, rank: int, slot_h, slot_t, own_h, own_t, counts):
+    """The epoch's slots / owned lists / per-(part, owner) counts in one launch (mke_oc_plan); `codes`: the whole epoch's codes
+    by epoch position (their group flags say which vector a positive needs), None when neg_per_pos == 0."""
     i32 = torch.int32
-    rc = lib().mke_oc_plan(_dev(pos_h, i32, "pos_h"), _dev(pos_t, i32, "pos_t"), _dev(part_lo, torch.int64, "part_lo"),
+    rc = lib().mke_oc_plan(_dev(pos_h, i32, "pos_h"), _dev(pos_t, i32, "pos_t"),
+                           _dev(codes, i32, "codes") if neg_per_pos else None, C.c_int(neg_per_pos), _dev(part_lo, torch.int64, "part_lo"),
                            C.c_int(n_parts), C.c_int(n_ranks), C.c_int(rank), _dev(slot_h, i32, "slot_h"), _dev(slot_t, i32, "slot_t"),
                            _dev(own_h, i32, "own_h"), _dev(own_t, i32, "own_t"), _dev(counts, i32, "counts"), _stream())
     _check(rc, "mke_oc_plan")

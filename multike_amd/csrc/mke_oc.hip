@@ -9,20 +9,25 @@
 //   (0) per EPOCH (table-independent): every rank packs the negatives of its own positives as (corrupt entity, side) codes
 //                    (k_oc_pack_codes); one all-gather per epoch gives every rank the codes of all negatives;
 //   (1) k_oc_bases : builds HR_p for the positives whose head it owns and RT_p for those whose tail it owns (relation
-//                    table replicated: no row leaves its owner);
-//   ... all-gather of the blocks: every rank now holds HR / RT of ALL G x P positives ...
+//                    table replicated: no row leaves its owner) — but ONLY the vector a positive's negatives need: the
+//                    reference's sampler tosses one coin per ROUND (code/base/batch.py:97-105), so the negatives of a
+//                    positive almost always corrupt the same side and ONE of the two vectors is enough (both only for the
+//                    few positives whose re-draw rounds fell on the other side).  The group's need is carried in the top
+//                    two bits of its first code (MKE_OC_NEED_HR / MKE_OC_NEED_RT), the slot of an unneeded vector is -1;
+//   ... all-gather of the blocks: every rank now holds the needed vector(s) of ALL G x P positives ...
 //   (2) k_oc_count : reference counts of its own rows over the whole global step (exclusive-row fast path; needs only the
 //                    codes, so it runs while the all-gather is on the wire);
 //   (3) k_oc_score : one wavefront per positive of the GLOBAL step scores the negatives whose corrupt entity THIS rank
 //                    owns — the corrupt row is local: updated in place when referenced once, else scattered into the
 //                    local gradient scratch — and writes its partial dL/dHR_p, dL/dRT_p into the slot the vector came
-//                    from; the positive's own term is added by its home rank;
+//                    from; the positive's own term d = HR_p - t^ (or h^ + RT_p when only RT_p travels) is one more such
+//                    term, scored by the owner of t (of h) against its local row;
 //   ... reduce-scatter of the gradient vectors: the owner of h_p receives sum dL/dHR_p, the owner of t_p sum dL/dRT_p ...
 //   (4) k_oc_apply : adds them to the head / tail rows' gradient (local) and to the replicated relation gradient;
 //   ... all-reduce of the relation gradient; mke_rows_update_multi on the shard + the relation table (every row is
 //       updated once per step from the sum of all its contributions: dense-Adagrad-equivalent).
-// Per rank and step that is 2 vectors out and 2 gradient vectors back per positive instead of N rows + N gradient rows:
-// (G-1)/G * 2 * 2 * P * stride * 4 bytes against (G-1)/G * 2 * P * (N + 2) * stride * 4 — 13.5x less at N = 25, and no
+// Per rank and step that is ~1 vector out and ~1 gradient vector back per positive instead of N rows + N gradient rows:
+// (G-1)/G * 2 * ~1 * P * stride * 4 bytes against (G-1)/G * 2 * P * (N + 2) * stride * 4 — 27x less at N = 25, and no
 // row-set construction, id exchange or remap.  Same arithmetic as the fused single-GPU kernel (mke_score.hip).
 #include "mke_common.h"
 
@@ -44,7 +49,10 @@ struct OcParams {
 // codes of the negatives of home rank g's positives of this part: [n_mine_g][neg_per_pos]
 __device__ __forceinline__ const int32_t* oc_codes(const OcParams& p, int g) { return p.s.codes + p.s.code_off[g]; }
 
-// (corrupt entity << 1) | corrupted-head, one per negative; a negative equal to its positive counts as a corrupted tail
+// (corrupt entity << 1) | corrupted-head, one per negative; a negative equal to its positive counts as a corrupted tail.
+// Bits 30 / 31 of a group's FIRST code are written afterwards by k_oc_mark_groups (entity ids stay below 2^29).
+#define OC_CODE_MASK 0x3FFFFFFF
+__device__ __forceinline__ int oc_code(int32_t c) { return c & OC_CODE_MASK; }
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_pack_codes(const int32_t* __restrict__ pos_h, const int32_t* __restrict__ neg_h,
                                                              const int32_t* __restrict__ neg_t, int64_t n_pos, int neg_per_pos,
                                                              int32_t* __restrict__ codes) {
@@ -55,23 +63,43 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_pack_codes(const int32_t* __re
   }
 }
 
+// which of its two vectors a positive's negatives need, into the top bits of the group's first code: MKE_OC_NEED_RT when any
+// negative corrupts the head, MKE_OC_NEED_HR when any corrupts the tail — and when none corrupts the head (the positive's own
+// term needs one of the two).  A thread per positive; the codes were just written (L2).
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_mark_groups(int64_t n_pos, int neg_per_pos, int32_t* __restrict__ codes) {
+  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n_pos; i += (int64_t)gridDim.x * MKE_BLOCK) {
+    int32_t* c = codes + i * neg_per_pos;
+    int any_h = 0, any_t = 0;
+    for (int n = 0; n < neg_per_pos; ++n) {
+      const int side = c[n] & 1;
+      any_h |= side;
+      any_t |= side ^ 1;
+    }
+    uint32_t w = (uint32_t)oc_code(c[0]);
+    if (any_h) w |= MKE_OC_NEED_RT;
+    if (any_t || !any_h) w |= MKE_OC_NEED_HR;
+    c[0] = (int32_t)w;
+  }
+}
+
 // reference counts of the rows this rank owns over the whole global step: the negatives' codes of every home rank + the
-// owned positives' heads / tails.  Block `block` of `n_blocks` (its own launch, or rider blocks of k_oc_bases: the counts need
+// heads / tails of the step's positives that it owns (each is referenced once more: by mke_oc_apply or by the positive's own
+// term in mke_oc_score).  Block `block` of `n_blocks` (its own launch, or rider blocks of k_oc_bases: the counts need
 // only the epoch's codes, nothing of this step's)
 __device__ __forceinline__ void oc_count_range(const OcParams& p, int block, int n_blocks) {
   const mke_oc_step& s = p.s;
   const int64_t n_codes = s.n_pos * s.neg_per_pos;
-  const int64_t total = n_codes + s.n_own_h + s.n_own_t;
+  const int64_t total = n_codes + 2 * s.n_pos;
   for (int64_t e = (int64_t)block * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)n_blocks * MKE_BLOCK) {
     if (e < n_codes) {
       const int64_t i = e / s.neg_per_pos;
       const int g = (int)(i / s.per);
-      const int c = oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)] >> 1;
+      const int c = oc_code(oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)]) >> 1;
       if (c % s.n_ranks == s.rank) atomicAdd(&s.ref_count[c / s.n_ranks], 1);
     } else {
       const int64_t k = e - n_codes;
-      const int ent = k < s.n_own_h ? s.pos_h[s.own_h[k]] : s.pos_t[s.own_t[k - s.n_own_h]];
-      atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
+      const int ent = k < s.n_pos ? s.pos_h[k] : s.pos_t[k - s.n_pos];
+      if (ent % s.n_ranks == s.rank) atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
     }
   }
 }
@@ -103,6 +131,38 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_bases(const OcParams p) {
 
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) { oc_count_range(p, blockIdx.x, gridDim.x); }
 
+// The positive's own term, scored by the owner of the entity the travelling vector lacks (a quarter-wave): with HR_p on the
+// wire the owner of t forms d = HR_p - t^, with only RT_p the owner of h forms d = h^ + RT_p; loss and coefficient of a
+// POSITIVE (code/losses.py:4-12), c d added to the vector's gradient, -+ c d scattered to the local row (never in place:
+// the row is also referenced by nothing else only by accident, and the update launch visits it anyway).
+template <int FPL>
+__device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRIDE, int j, bool use_hr, int ent_local, float pw,
+                                                  const float (&HR)[FPL], const float (&RT)[FPL], float (&gHR)[FPL], float (&gRT)[FPL]) {
+  float E[FPL];
+  load_row<FPL>(s.ent, ent_local, STRIDE, j, E);
+  l2_normalize_row<FPL>(E, true);
+  float d[FPL];
+  float x = 0.f;
+  const float sg = use_hr ? -1.0f : 1.0f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    d[k] = fmaf(sg, E[k], use_hr ? HR[k] : RT[k]);
+    x = fmaf(d[k], d[k], x);
+  }
+  x = sub16_sum(x);
+  const float c = 2.0f * s.scale * pw * sigmoid_f(x);
+  const float ch = use_hr ? 1.0f : 0.0f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    d[k] *= c;
+    gHR[k] = fmaf(ch, d[k], gHR[k]);
+    gRT[k] = fmaf(1.0f - ch, d[k], gRT[k]);
+  }
+  atomic_add_row<FPL>(s.ent_grad, ent_local, STRIDE, s.dim, j, d, sg);
+  if (j == 0) s.ent_touched[ent_local] = s.tag;
+  return pw * softplus_f(x);
+}
+
 // One wavefront per positive of the global step.  Lane l holds the code of negative l (neg_per_pos <= 64); the negatives
 // this rank owns are dealt round-robin to the four quarter-waves (the (4 round + q)-th set bit of the ballot), U of them
 // in flight per quarter.
@@ -117,49 +177,30 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   const int64_t C = s.capacity;
   float loss = 0.f;
   for (int64_t i = wave0; i < s.n_pos; i += nwaves) {
-    const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
+    const int ph = s.pos_h[i], pt = s.pos_t[i];
     const int home = (int)(i / s.per);
+    const int sh = s.slot_h[i], st = s.slot_t[i];   // -1: that vector does not travel (no negative of this positive needs it)
     // the vectors' home: this rank's all-gathered copy, or (peer-direct) the owner's own send block over xGMI
-    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * STRIDE;
-    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * STRIDE;
-    // codes first (one negative per lane), then the owned rows' reference counts together with the positive's two vectors: a
+    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + max(st, 0)) * STRIDE;
+    // codes first (one negative per lane), then the owned rows' reference counts together with the positive's vector(s): a
     // round below is one round trip, and the accumulator row is gathered only for rows that are finished in place
     int code = 0;
-    if (lane < N) code = oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane];
+    if (lane < N) code = oc_code(oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane]);
     const bool mine = lane < N && ((code >> 1) % G) == s.rank;
     const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
-    load_row<FPL>(vh, 0, STRIDE, j, HR);
-    load_row<FPL>(vt, 0, STRIDE, j, RT);
 #pragma unroll
-    for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
+    for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
+    if (sh >= 0) load_row<FPL>(vh, 0, STRIDE, j, HR);
+    if (st >= 0) load_row<FPL>(vt, 0, STRIDE, j, RT);
     const uint64_t mask = __ballot(mine);
     const int total = __popcll(mask);
 
-    if (home == s.rank && q == 0) {  // the positive itself: d = h^ + r^ - t^ = HR + RT - r^
-      float R[FPL];
-      load_row<FPL>(s.rel, pr, STRIDE, j, R);
-      l2_normalize_row<FPL>(R, true);
-      float d[FPL];
-      float x = 0.f;
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        d[k] = (HR[k] + RT[k]) - R[k];
-        x = fmaf(d[k], d[k], x);
-      }
-      x = sub16_sum(x);
+    // the positive itself: with HR on the wire the owner of t scores it, else the owner of h (wave-uniform test)
+    if ((sh >= 0 ? pt : ph) % G == s.rank && q == 0) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;   // weighted positives: code/losses.py:44-50
-      loss += pw * softplus_f(x);
-      const float c = 2.0f * s.scale * pw * sigmoid_f(x);
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        d[k] *= c;
-        gHR[k] += d[k];   // -> head row +g, relation row +g
-        gRT[k] += d[k];   // -> relation row +g, tail row -g;  the relation row's surplus g is taken back here:
-      }
-      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)STRIDE);
-      atomic_add_row<FPL>(grel, pr, STRIDE, s.dim, j, d, -1.0f);
-      if (j == 0) s.rel_touched[pr] = s.tag;
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, HR, RT, gHR, gRT);
     }
 
     // quarter q takes the q-th, (q+4)-th, ... set bit of the ballot: a running copy of the mask with the bits already
@@ -256,11 +297,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
       gHR[k] += __shfl_xor(gHR[k], 16, 64); gHR[k] += __shfl_xor(gHR[k], 32, 64);
       gRT[k] += __shfl_xor(gRT[k], 16, 64); gRT[k] += __shfl_xor(gRT[k], 32, 64);
     }
-    if (q < 2) {
+    if (q < 2 && (q == 0 ? sh : st) >= 0) {
       const int64_t gb = 2 * C * (int64_t)STRIDE;
       const int own = q == 0 ? ph % G : pt % G;
       float* o = (s.n_peers ? s.peer_g[own] : p.g_all + (int64_t)own * gb) +
-                 (q == 0 ? (int64_t)s.slot_h[i] : C + s.slot_t[i]) * STRIDE + j;
+                 (q == 0 ? (int64_t)sh : C + st) * STRIDE + j;
 #pragma unroll
       for (int k = 0; k < FPL; ++k) o[k * 16] = q == 0 ? gHR[k] : gRT[k];
     }
@@ -292,45 +333,26 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
     const int64_t i_raw = sub0 + it * nsub;
     const bool act = i_raw < s.n_pos;
     const int64_t i = act ? i_raw : 0;
-    const int ph = s.pos_h[i], pr = s.pos_r[i], pt = s.pos_t[i];
+    const int ph = s.pos_h[i], pt = s.pos_t[i];
     const int home = (int)(i / s.per);
-    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)s.slot_h[i] * STRIDE;
-    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + s.slot_t[i]) * STRIDE;
+    const int sh = act ? s.slot_h[i] : -1, st = act ? s.slot_t[i] : -1;   // -1: that vector does not travel
+    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + max(st, 0)) * STRIDE;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
-    load_row<FPL>(vh, 0, STRIDE, j, HR);
-    load_row<FPL>(vt, 0, STRIDE, j, RT);
 #pragma unroll
-    for (int k = 0; k < FPL; ++k) gHR[k] = gRT[k] = 0.f;
-    if (act && home == s.rank) {  // the positive itself: d = h^ + r^ - t^ = HR + RT - r^
-      float R[FPL];
-      load_row<FPL>(s.rel, pr, STRIDE, j, R);
-      l2_normalize_row<FPL>(R, true);
-      float d[FPL];
-      float x = 0.f;
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        d[k] = (HR[k] + RT[k]) - R[k];
-        x = fmaf(d[k], d[k], x);
-      }
-      x = sub16_sum(x);
+    for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
+    if (sh >= 0) load_row<FPL>(vh, 0, STRIDE, j, HR);
+    if (st >= 0) load_row<FPL>(vt, 0, STRIDE, j, RT);
+    // the positive itself: with HR on the wire the owner of t scores it, else the owner of h
+    if (act && (sh >= 0 ? pt : ph) % G == s.rank) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;
-      loss += pw * softplus_f(x);
-      const float c = 2.0f * s.scale * pw * sigmoid_f(x);
-#pragma unroll
-      for (int k = 0; k < FPL; ++k) {
-        d[k] *= c;
-        gHR[k] += d[k];
-        gRT[k] += d[k];
-      }
-      float* grel = s.rel_grad + (i % s.rel_grad_copies) * (s.n_rel * (int64_t)STRIDE);
-      atomic_add_row<FPL>(grel, pr, STRIDE, s.dim, j, d, -1.0f);
-      if (j == 0) s.rel_touched[pr] = s.tag;
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, HR, RT, gHR, gRT);
     }
     const int32_t* cp = oc_codes(p, home) + (i - (int64_t)home * s.per) * N;
     for (int c0 = 0; c0 < N; c0 += 16) {                      // the group's codes, 16 per quarter at a time
       int code = 0;
       const bool has = act && c0 + j < N;
-      if (has) code = cp[c0 + j];
+      if (has) code = oc_code(cp[c0 + j]);
       const bool mine = has && ((code >> 1) % G) == s.rank;
       const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
       const uint64_t mall = __ballot(mine);
@@ -403,12 +425,18 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
         }
       }
     }
-    if (act) {   // this positive's partial gradient vectors: every slot of g_all is written by exactly one quarter-wave per step
+    {   // this positive's partial gradient vector(s): every live slot of g_all is written by exactly one quarter-wave per step
       const int64_t gb = 2 * C * (int64_t)STRIDE;
-      float* oh = (s.n_peers ? s.peer_g[ph % G] : p.g_all + (int64_t)(ph % G) * gb) + (int64_t)s.slot_h[i] * STRIDE + j;
-      float* ot = (s.n_peers ? s.peer_g[pt % G] : p.g_all + (int64_t)(pt % G) * gb) + (C + s.slot_t[i]) * STRIDE + j;
+      float* oh = (s.n_peers ? s.peer_g[ph % G] : p.g_all + (int64_t)(ph % G) * gb) + (int64_t)max(sh, 0) * STRIDE + j;
+      float* ot = (s.n_peers ? s.peer_g[pt % G] : p.g_all + (int64_t)(pt % G) * gb) + (C + max(st, 0)) * STRIDE + j;
+      if (sh >= 0) {
 #pragma unroll
-      for (int k = 0; k < FPL; ++k) { oh[k * 16] = gHR[k]; ot[k * 16] = gRT[k]; }
+        for (int k = 0; k < FPL; ++k) oh[k * 16] = gHR[k];
+      }
+      if (st >= 0) {
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) ot[k * 16] = gRT[k];
+      }
     }
   }
   const double tot = block_sum_double(j == 0 ? loss : 0.f);
@@ -450,8 +478,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
 
 // ---- per-epoch plan: the slot of every positive's HR / RT vector in its owner's block -------------------------------------
 // Part k of the epoch = epoch positions [part_lo[k], part_lo[k + 1]).  Inside a part, the positives whose head (tail) is
-// owned by rank g = id % G get slots 0, 1, 2, ... of g's block in epoch order (a stable counting sort by owner with G
-// buckets); rank `rank`'s own positives are also listed, as positions inside the part, in slot order, at
+// owned by rank g = id % G AND whose negatives need HR (RT) — the flag bits of the group's first code, codes laid out by
+// epoch position; a positive without negatives needs HR — get slots 0, 1, 2, ... of g's block in epoch order (a stable
+// counting sort by owner with G buckets), every other positive slot -1; rank `rank`'s own positives are also listed, as positions inside the part, in slot order, at
 // own_*[part_lo[k] + slot] (a part's list starts at the part's own offset: no prefix over parts is needed), and the
 // per-(part, owner) counts go out for the host (block capacity, list lengths).  One block of 1024 threads per (part, h | t):
 // a chunk of 1024 positives is ranked by a ballot per distinct owner in each wavefront, the 16 wavefronts' counts meet in LDS.
@@ -459,6 +488,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
 // 12 us per step of 184; at 8 ranks an epoch is 23 global steps and the same plan cost 70 us per step).
 #define OC_PLAN_THREADS 1024
 __global__ __launch_bounds__(OC_PLAN_THREADS) void k_oc_plan(const int32_t* __restrict__ pos_h, const int32_t* __restrict__ pos_t,
+                                                             const int32_t* __restrict__ codes, int neg_per_pos,
                                                              const int64_t* __restrict__ part_lo, int n_parts, int G, int rank,
                                                              int32_t* __restrict__ slot_h, int32_t* __restrict__ slot_t,
                                                              int32_t* __restrict__ own_h, int32_t* __restrict__ own_t,
@@ -478,7 +508,8 @@ __global__ __launch_bounds__(OC_PLAN_THREADS) void k_oc_plan(const int32_t* __re
     __syncthreads();
     for (int64_t base = lo; base < hi; base += OC_PLAN_THREADS) {
       const int64_t i = base + tid;
-      const bool valid = i < hi;
+      const uint32_t need = i < hi ? (neg_per_pos ? (uint32_t)codes[i * neg_per_pos] : MKE_OC_NEED_HR) : 0u;
+      const bool valid = (need & (x ? MKE_OC_NEED_RT : MKE_OC_NEED_HR)) != 0;
       const int o = valid ? ids[i] % G : -1;
       int rk = 0;
       uint64_t todo = __ballot(valid);
@@ -495,6 +526,8 @@ __global__ __launch_bounds__(OC_PLAN_THREADS) void k_oc_plan(const int32_t* __re
         for (int w = 0; w < wv; ++w) sl += s_wcnt[w][o];
         slot[i] = sl;
         if (o == rank) own[lo + sl] = (int32_t)(i - lo);
+      } else if (i < hi) {
+        slot[i] = -1;
       }
       __syncthreads();
       if (tid < G) {
@@ -550,17 +583,20 @@ extern "C" int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, con
   if (!pos_h || !neg_h || !neg_t || !codes) { set_error("mke_oc_pack_codes: NULL pointer"); return MKE_E_NULL; }
   hipLaunchKernelGGL(k_oc_pack_codes, dim3(oc_blocks(n_pos * neg_per_pos, MKE_BLOCK, 4096)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
                      pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
+  hipLaunchKernelGGL(k_oc_mark_groups, dim3(oc_blocks(n_pos, MKE_BLOCK, 4096)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, n_pos, neg_per_pos, codes);
   return check_launch("k_oc_pack_codes");
 }
 
-extern "C" int mke_oc_plan(const int32_t* pos_h, const int32_t* pos_t, const int64_t* part_lo, int n_parts, int n_ranks, int rank,
-                           int32_t* slot_h, int32_t* slot_t, int32_t* own_h, int32_t* own_t, int32_t* counts, void* stream) {
+extern "C" int mke_oc_plan(const int32_t* pos_h, const int32_t* pos_t, const int32_t* codes, int neg_per_pos, const int64_t* part_lo,
+                           int n_parts, int n_ranks, int rank, int32_t* slot_h, int32_t* slot_t, int32_t* own_h, int32_t* own_t,
+                           int32_t* counts, void* stream) {
   using namespace mke;
   if (n_parts < 0 || n_ranks < 1 || n_ranks > MKE_OC_MAX_RANKS || rank < 0 || rank >= n_ranks) { set_error("mke_oc_plan: bad n_parts / n_ranks / rank"); return MKE_E_SHAPE; }
   if (n_parts == 0) return MKE_OK;
   if (!pos_h || !pos_t || !part_lo || !slot_h || !slot_t || !own_h || !own_t || !counts) { set_error("mke_oc_plan: NULL pointer"); return MKE_E_NULL; }
+  if (neg_per_pos < 0 || (neg_per_pos > 0 && !codes)) { set_error("mke_oc_plan: neg_per_pos > 0 needs the epoch's codes"); return MKE_E_NULL; }
   hipLaunchKernelGGL(k_oc_plan, dim3((unsigned)(n_parts < 32768 ? n_parts : 32768), 2), dim3(OC_PLAN_THREADS), 0, (hipStream_t)stream,
-                     pos_h, pos_t, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts);
+                     pos_h, pos_t, codes, neg_per_pos, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts);
   return check_launch("k_oc_plan");
 }
 
@@ -573,7 +609,7 @@ static int oc_bases_impl(const mke_oc_step* s, float* send_block, bool with_coun
   OcParams p{};
   p.s = *s; p.send = send_block;
   const int64_t subs = s->n_own_h + s->n_own_t;
-  const int64_t n_count = (with_count && s->ref_count) ? s->n_pos * s->neg_per_pos + subs : 0;
+  const int64_t n_count = (with_count && s->ref_count) ? s->n_pos * (s->neg_per_pos + 2) : 0;
   if (subs == 0) return n_count ? mke_oc_count(s, stream) : MKE_OK;
   p.count_blocks = n_count ? (int)oc_blocks(n_count, MKE_BLOCK, 1024) : 0;
   const int fpl = s->stride / 16;
@@ -592,7 +628,7 @@ extern "C" int mke_oc_count(const mke_oc_step* s, void* stream) {
   int rc = oc_check(s, "mke_oc_count");
   if (rc) return rc;
   if (!s->ref_count) return MKE_OK;
-  const int64_t total = s->n_pos * s->neg_per_pos + s->n_own_h + s->n_own_t;
+  const int64_t total = s->n_pos * (s->neg_per_pos + 2);
   if (total == 0) return MKE_OK;
   OcParams p{};
   p.s = *s;

@@ -8,22 +8,26 @@ The reference has no multi-device code; this is new design.  One process per GPU
     positive do not depend on the world size);
   * rows never leave their owner.  A negative differs from its positive (h, r, t) in one entity c and its score needs only
     c's row and one of two vectors of the positive — HR_p = h^ + r^ (corrupted tail: d = HR_p - c^) or RT_p = r^ - t^
-    (corrupted head: d = c^ + RT_p) — so the NEGATIVES go to the rows.  Per global step:
-        (once per epoch, prefetched on a side stream: every rank draws ALL negatives itself and packs them as (entity, side) codes)
-        owner of h_p builds HR_p, owner of t_p builds RT_p                                                  [mke_oc_bases]
-        ALL-GATHER of the blocks (2 vectors per positive)
+    (corrupted head: d = c^ + RT_p) — so the NEGATIVES go to the rows.  And the reference's sampler tosses ONE coin per round
+    (code/base/batch.py:97-105): a positive's negatives almost always corrupt the same side, so only ONE of the two vectors
+    travels for it (both for the few positives whose re-draw rounds fell on the other side); the positive's own term
+    d = HR_p - t^ (or h^ + RT_p) is scored like a negative by the owner of t (of h).  Per global step:
+        (once per epoch, prefetched on a side stream: every rank draws 1 / world of the epoch's negatives, packs them as
+         (entity, side) codes with the group's need flags, one all-gather of the codes)
+        owner of h_p builds HR_p, owner of t_p builds RT_p — the needed ones                                [mke_oc_bases]
+        ALL-GATHER of the blocks (~1 vector per positive)
         reference counts of the own rows over the whole global step (needs only the codes)                 [mke_oc_count]
         every rank scores, for ALL world x batch positives, the negatives whose corrupt entity it owns: corrupt-row
         gradient applied locally (in place when referenced once, else scattered), partial dL/dHR_p, dL/dRT_p written into
-        the slot the vector came from; the home rank adds the positive's own term                          [mke_oc_score]
+        the slot the vector came from; the positive's own term by the owner of its other entity            [mke_oc_score]
         REDUCE-SCATTER of the gradient vectors (same layout): the owner of h_p / t_p receives the sum
         head / tail rows' and relation rows' gradient from it                                              [mke_oc_apply]
         ALL-REDUCE of the relation gradient;  one update of every touched shard row and relation row  [mke_rows_update_multi]
     i.e. every row is updated once per step from the sum of all its contributions (dense-Adagrad-equivalent, SURVEY.md
     §8e "semantics note").  Slots are assigned per epoch from the (replicated) epoch order, so capacity is known exactly
     before the epoch starts: nothing can overflow mid-epoch.
-Bytes per rank and step over the links: (G-1)/G * 2 * (2 P stride 4 + 4 P N) against (G-1)/G * 2 * P (N + 2) stride 4 of a
-row exchange — 12x less at N = 25 / dim 75, 30x less at N = 64 / dim 256 (DESIGN.md §5 has the latency model).
+Bytes per rank and step over the links: (G-1)/G * 2 * ~1 * P stride 4 against (G-1)/G * 2 * P (N + 2) stride 4 of a
+row exchange — 27x less at N = 25 / dim 75, 66x less at N = 64 / dim 256 (DESIGN.md §5 has the latency model).
 
 `chunks` > 1 splits the global step's positives into that many parts whose all-gather / reduce-scatter run on the
 communicator's own stream while the previous / next part is scored (split-batch pipelining; the single update at the end
@@ -82,9 +86,9 @@ class OcHipBackend:
     def pack_codes(self, pos_h, neg_h, neg_t, neg_per_pos, codes):
         _lib.oc_pack_codes(pos_h, neg_h, neg_t, neg_per_pos, codes)
 
-    def plan(self, pos_h, pos_t, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts):
+    def plan(self, pos_h, pos_t, codes, neg_per_pos, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts):
         """slots, owned lists and per-(part, owner) counts of the whole epoch in ONE launch (mke_oc_plan)."""
-        _lib.oc_plan(pos_h, pos_t, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts)
+        _lib.oc_plan(pos_h, pos_t, codes, neg_per_pos, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts)
 
     def _struct(self, tr: "OwnerComputesTrainer", st: OcStep):
         f32, i32 = torch.float32, torch.int32
@@ -485,6 +489,8 @@ class OwnerComputesTrainer:
         if not 0 <= self.N <= 64:   # 0: positives only (the shape of the cross-KG inference loops, code/MultiKE_model.py:349-369)
             raise _lib.MultiKEHipError("the sharded relation view takes 0..64 negatives per positive")
         self.n_ent = ent0.shape[0]
+        if self.n_ent >= 1 << 29:   # a code is (entity << 1) | side with the group's two need flags above it
+            raise _lib.MultiKEHipError("the sharded relation view packs entity ids into 29 bits")
         self.batch_size = int(batch_size)
         self.chunks = max(1, int(chunks))
         # peer-direct (opt-in): no all-gather / reduce-scatter — every rank maps the other ranks' send blocks and gradient
@@ -639,31 +645,37 @@ class OwnerComputesTrainer:
             if G > 1:
                 self._plan_comm.all_gather(codes[:G * n_per * N], mine)
         plan["codes"] = codes
-        # slot of every positive's HR / RT vector in its owner's block (rank among the positives of its part with the same
-        # owner, epoch order), this rank's owned positives per part in slot order (part k's list starts at own[lo_k]), and
-        # the per-(part, owner) counts.  HIP backend: one launch (mke_oc_plan); other backends (the CPU tests): torch.
+        # slot of every positive's HR / RT vector in its owner's block (rank among the positives of its part that NEED that
+        # vector — the group flags in the first code of every positive — and have the same owner, epoch order; -1 when not
+        # needed), this rank's owned positives per part in slot order (part k's list starts at own[lo_k]), and the
+        # per-(part, owner) counts.  HIP backend: one launch (mke_oc_plan); other backends (the CPU tests): torch.
         slot = [self._persist(("slot", x, bs), torch.zeros(0, **i32), max(1, n_all)) for x in range(2)]
         own = [self._persist(("own", x, bs), torch.zeros(0, **i32), max(1, n_all)) for x in range(2)]
         plan["slot"], plan["own"] = slot, own
         if n_all:
             cnt = self._persist(("cnt", bs), torch.zeros(0, **i32), 2 * len(parts) * G)
             if hasattr(self.backend, "plan"):
-                self.backend.plan(ph, pt, self._part_lo, len(parts), G, self.rank, slot[0], slot[1], own[0], own[1], cnt)
+                self.backend.plan(ph, pt, codes, N, self._part_lo, len(parts), G, self.rank, slot[0], slot[1], own[0], own[1], cnt)
             else:
+                if N:
+                    first = codes[:n_all * N].view(n_all, N)[:, 0].long() & 0xFFFFFFFF
+                    needs = ((first & _lib.OC_NEED_HR) != 0, (first & _lib.OC_NEED_RT) != 0)
+                else:
+                    needs = (torch.ones(n_all, dtype=torch.bool, device=dev), torch.zeros(n_all, dtype=torch.bool, device=dev))
                 for x, ids in enumerate((ph, pt)):
-                    owner = ids[:n_all].long() % G
-                    key = part_id * G + owner
+                    owner = torch.where(needs[x], ids[:n_all].long() % G, G)        # bucket G: the vector does not travel
+                    key = part_id * (G + 1) + owner
                     order = torch.argsort(key, stable=True)
                     ks = key[order]
-                    counts = torch.bincount(ks, minlength=len(parts) * G)
+                    counts = torch.bincount(ks, minlength=len(parts) * (G + 1))
                     start = torch.cumsum(counts, 0) - counts
                     sl = torch.empty(n_all, dtype=torch.int64, device=dev)
                     sl[order] = torch.arange(n_all, device=dev) - start[ks]
-                    slot[x][:n_all].copy_(sl.to(torch.int32))
+                    slot[x][:n_all].copy_(torch.where(needs[x], sl, -1).to(torch.int32))
                     mine = torch.nonzero(owner == self.rank).reshape(-1)
                     lo_m = self._lo_of[part_id[mine]]
                     own[x][(lo_m + sl[mine])] = (mine - lo_m).to(torch.int32)
-                    cnt[x * len(parts) * G:(x + 1) * len(parts) * G].copy_(counts.to(torch.int32))
+                    cnt[x * len(parts) * G:(x + 1) * len(parts) * G].copy_(counts.view(len(parts), G + 1)[:, :G].reshape(-1).to(torch.int32))
             c = cnt[:2 * len(parts) * G].view(2, len(parts), G)
             host = self._persistent.get(("cnt_host", bs))
             if host is None or host.shape != c.shape:
@@ -686,11 +698,13 @@ class OwnerComputesTrainer:
         self._codes, self._slot, self._own = plan["codes"], plan["slot"], plan["own"]
         self._own_cnt = []                      # per part: how many HR / RT vectors of it this rank owns
         worst = 0
+        self.vectors_planned = 0                # HR + RT vectors that travel in this epoch (all owners): ~1 per positive
         for x in range(2):
             mine = np.zeros(len(parts), dtype=np.int64)
             if self._n_all:
                 cnt = plan["cnt_host"][x].numpy().reshape(len(parts), G)
                 worst = max(worst, int(cnt.max()))
+                self.vectors_planned += int(cnt.sum())
                 mine = cnt[:, self.rank].astype(np.int64)
             self._own_cnt.append(mine)
         # -- capacity: exact for this epoch, buffers only ever grow ----------------------------------------
@@ -892,7 +906,8 @@ class OwnerComputesTrainer:
     # ------------------------------------------------------------------------------------------------
     def check(self) -> dict:
         """Capacity is fixed per epoch from the data before the epoch runs (`_plan_epoch`): nothing to flag."""
-        return {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks}
+        return {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks,
+                "vectors_per_positive": self.vectors_planned / max(1, self._n_all)}
 
     def gather_entity_table(self) -> torch.Tensor:
         """Reassemble the full [n_ent, dim] raw table on every rank (tests / checkpoint)."""

@@ -153,7 +153,11 @@ class OcOracleBackend(OracleBackend):
     def pack_codes(self, pos_h, neg_h, neg_t, neg_per_pos, codes):
         ph = np.repeat(pos_h.numpy(), neg_per_pos)
         nh, nt = neg_h.numpy(), neg_t.numpy()
-        codes.numpy()[:] = np.where(nh != ph, (nh << 1) | 1, nt << 1)
+        cd = np.where(nh != ph, (nh << 1) | 1, nt << 1).astype(np.int64).reshape(-1, neg_per_pos)
+        any_h = (cd & 1).any(axis=1)
+        any_t = ((cd & 1) == 0).any(axis=1)
+        cd[:, 0] |= np.where(any_h, 0x80000000, 0) | np.where(any_t | ~any_h, 0x40000000, 0)     # the group's need flags
+        codes.numpy()[:] = cd.reshape(-1).astype(np.uint32).view(np.int32)
 
     @classmethod
     def _nrm(cls, x):
@@ -165,7 +169,7 @@ class OcOracleBackend(OracleBackend):
         out = send.numpy().reshape(2 * C, S)
         ph, pr, pt = st.pos_h.numpy(), st.pos_r.numpy(), st.pos_t.numpy()
         oh, ot = st.own_h.numpy(), st.own_t.numpy()
-        out[:len(oh), :d] = self._nrm(ent[ph[oh] // G]) + self._nrm(rel[pr[oh]])
+        out[:len(oh), :d] = self._nrm(ent[ph[oh] // G]) + self._nrm(rel[pr[oh]])            # needed vectors only (own lists)
         out[C:C + len(ot), :d] = self._nrm(rel[pr[ot]]) - self._nrm(ent[pt[ot] // G])
 
     def _codes_of(self, tr, st):
@@ -177,15 +181,15 @@ class OcOracleBackend(OracleBackend):
             a, e = g * st.per, min(n, (g + 1) * st.per)
             if e > a:
                 out[a:e] = cd[off:off + (e - a) * N].reshape(e - a, N)
-        return out
+        return out & 0x3FFFFFFF      # without the group flags
 
     def count(self, tr, st):
         G = tr.world
         rc = tr.ref_count.numpy()
         c = self._codes_of(tr, st).reshape(-1) >> 1
         np.add.at(rc, c[c % G == tr.rank] // G, 1)
-        np.add.at(rc, st.pos_h.numpy()[st.own_h.numpy()] // G, 1)
-        np.add.at(rc, st.pos_t.numpy()[st.own_t.numpy()] // G, 1)
+        for ids in (st.pos_h.numpy(), st.pos_t.numpy()):          # every owned head / tail of the step's positives
+            np.add.at(rc, ids[ids % G == tr.rank] // G, 1)
 
     def _row_update(self, w, a, g, lr):
         """Jacobian of the normalisation + Adagrad on one raw row (in place)."""
@@ -209,18 +213,26 @@ class OcOracleBackend(OracleBackend):
         loss = 0.0
         sc = float(getattr(tr, "scale", 1.0))
         for i in range(len(ph)):
-            HR, RT = V[ph[i] % G, sh[i], :d], V[pt[i] % G, C + stt[i], :d]
+            HR = V[ph[i] % G, sh[i], :d] if sh[i] >= 0 else None        # slot -1: that vector does not travel
+            RT = V[pt[i] % G, C + stt[i], :d] if stt[i] >= 0 else None
             gHR, gRT = np.zeros(d), np.zeros(d)
-            if i // st.per == rank:
-                dv = HR + RT - self._nrm(rel[pr[i], :d])
+            # the positive's own term: the owner of t against HR (d = HR - t^), or the owner of h against RT (d = h^ + RT)
+            other = pt[i] if HR is not None else ph[i]
+            if other % G == rank:
+                row = other // G
+                eh = self._nrm(ent[row, :d])
+                dv = HR - eh if HR is not None else eh + RT
                 x = float(dv @ dv)
                 pw = float(st.pos_w[i]) if st.pos_w is not None else 1.0
                 loss += pw * np.log1p(np.exp(x))
                 g = pw * sc * 2.0 / (1.0 + np.exp(-x)) * dv
-                gHR += g
-                gRT += g
-                rg[pr[i], :d] -= g
-                trl[pr[i]] = st.tag
+                if HR is not None:
+                    gHR += g
+                    eg[row, :d] -= g
+                else:
+                    gRT += g
+                    eg[row, :d] += g
+                te[row] = st.tag
             for cd in codes[i]:
                 c, head = int(cd) >> 1, int(cd) & 1
                 if c % G != rank:
@@ -242,10 +254,12 @@ class OcOracleBackend(OracleBackend):
                 else:
                     eg[row, :d] += gc
                     te[row] = st.tag
-            Gout[ph[i] % G, sh[i], :] = 0
-            Gout[pt[i] % G, C + stt[i], :] = 0
-            Gout[ph[i] % G, sh[i], :d] = gHR
-            Gout[pt[i] % G, C + stt[i], :d] = gRT
+            if sh[i] >= 0:
+                Gout[ph[i] % G, sh[i], :] = 0
+                Gout[ph[i] % G, sh[i], :d] = gHR
+            if stt[i] >= 0:
+                Gout[pt[i] % G, C + stt[i], :] = 0
+                Gout[pt[i] % G, C + stt[i], :d] = gRT
         lp = loss_partials.numpy()
         lp[:] = 0
         lp[0] = loss * sc
