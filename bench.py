@@ -407,6 +407,8 @@ def hbm_resident_variant(args):
     step loop, windows of `steps` steps after `warmup` (median window reported, spread beside it), then the instrumented pass
     for the kernel's own duration and its launch-time histogram."""
     cfg = {k: CONFIGS["c5"][k] for k in ("n_ent", "n_rel", "dim", "neg", "batch")}
+    from multike_amd.tables import PLACEMENT_LOG
+    n_placed = len(PLACEMENT_LOG)
     t_setup = time.perf_counter()
     w = FusedWorkload(cfg, device_init=True)
     torch.cuda.synchronize()
@@ -418,7 +420,10 @@ def hbm_resident_variant(args):
     roof["launch_histogram"] = w.last_hist
     return {"name": "C5-synth: the HBM-resident shape (BASELINE configs[4] per GPU: |E|=2M |R|=2K dim=256 neg=64 batch=5000)",
             "value": scored / dt, "unit": "triples/s", "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3,
-            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "setup_s_untimed": t_setup, "roofline": roof}
+            "window_ms": stats, "scored_per_step": cfg["batch"] * (1 + cfg["neg"]), "setup_s_untimed": t_setup, "roofline": roof,
+            # placement by trial of the three 2 GB arrays (multike_amd/tables.py placed_rows): per array, the probe time of every
+            # candidate allocation tried and which one was kept — HBM allocations come in two classes ~9 % apart on this probe
+            "placement": PLACEMENT_LOG[n_placed:]}
 
 
 def zipf_variant(args, exponent=1.0):
@@ -879,7 +884,7 @@ def main():
                          "host_us_per_step": host_us, "host_note": "enqueue loop of the step path without waiting for the device"
                                              + ("; MKE_OC_FORCE_COLLECTIVES=1: the G > 1 path with its collectives on the one-rank group" if getattr(trainer, "force_collectives", False) else ""),
                          "basis_note": "the algorithmic model counts 3 rows read + 3 written per scored triple; the owner-computes kernel "
-                                       "reads 2 vectors per POSITIVE and one row per negative, so this fraction overstates its traffic "
+                                       "reads ~1 vector per POSITIVE and one row per negative, so this fraction overstates its traffic "
                                        "(it can exceed 1) — a rate in the model's bytes, not a measurement of the memory system"})
 
     if rank == 0:
@@ -899,6 +904,9 @@ def main():
         }
         if variants is not None:
             out["variants"] = variants
+        from multike_amd.tables import PLACEMENT_LOG
+        if PLACEMENT_LOG and variants is None:       # arrays of >= 1 GB placed by trial (the C5 variant carries its own log)
+            out["placement"] = PLACEMENT_LOG
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kgs, ent0, rel0)
         line = json.dumps(out)

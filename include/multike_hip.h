@@ -409,6 +409,14 @@ int mke_gather_rows(
     const int32_t* idx /*nullable = identity*/, int64_t n,
     float* out /* [n][dim] */, void* stream);
 
+/* Placement probe (no reference counterpart; read-only): rows idx[0..n) of a and (nullable) b, c — arrays of the same
+ * [rows][stride] shape — read TOGETHER, the way the relation step reads a row of the table, its accumulator and its gradient;
+ * out[i] = the sum of what was read of row idx[i].  The host side times it on candidate allocations of a >= 1 GB table's
+ * companion arrays: on MI355X the step's time depends on how the three arrays' physical pages sit relative to each other
+ * (+-12 % at the 2M x 256 shape), which no virtual-address choice controls. */
+int mke_probe_rows(const float* a, const float* b /*nullable*/, const float* c /*nullable*/, int stride, const int32_t* idx,
+                   int64_t n, float* out /* [n] */, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (6) Native step runner of the relation view: enqueues steps [step_begin, step_end) of an epoch —
  *     negative sampling (batched `sample_chunk` steps per launch), the fused triple step and the row

@@ -33,7 +33,7 @@ SYMBOLS = (
     "mke_dense_update", "mke_align_rank", "mke_gemm_f32", "mke_attr_scratch_floats", "mke_attr_step", "mke_attr_steps", "mke_attr_step_phases",
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
-    "mke_topk_long", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
+    "mke_topk_long", "mke_probe_rows", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -587,6 +587,14 @@ def gather_rows(table, normalize, dim, idx, out):
                                C.c_int(dim), _dev(idx, torch.int32, "idx"), C.c_int64(n),
                                _dev(out, torch.float32, "out"), _stream())
     _check(rc, "mke_gather_rows")
+
+
+def probe_rows(a, b, c, idx, out):
+    """mke_probe_rows: rows idx of a (and b, c when given) read together; out [len(idx)] float32."""
+    rc = lib().mke_probe_rows(_dev(a, torch.float32, "a"), _dev(b, torch.float32, "b"), _dev(c, torch.float32, "c"),
+                              C.c_int(a.shape[1]), _dev(idx, torch.int32, "idx"), C.c_int64(idx.numel()),
+                              _dev(out, torch.float32, "out"), _stream())
+    _check(rc, "mke_probe_rows")
 
 
 def rowset_build(streams, flags, counts, req, id_map, overflow, n_ranks, capacity):

@@ -173,6 +173,31 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_gather_rows(const float* __restri
   }
 }
 
+// Placement probe (read-only): row idx[i] of up to three arrays of the same shape at the same time — the access pattern of the
+// relation step (table, accumulator, gradient scratch of one row together).  One float per visited row goes out so that the loads
+// are not dead.  The tables' host side times it on candidate allocations of a large table's companion arrays and keeps the
+// fastest combination (multike_amd/tables.py place_companions; EXPERIMENTS R5.10).
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_probe_rows(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ c, int stride,
+                                                          const int32_t* __restrict__ idx, int64_t n, float* __restrict__ out) {
+  const int j = threadIdx.x & 15;
+  const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
+  for (int64_t i = sub0; i < n; i += nsub) {
+    const int64_t row = idx[i];
+    float A[FPL], B[FPL], Cc[FPL];
+    load_row<FPL>(a, row, stride, j, A);
+    if (b) load_row<FPL>(b, row, stride, j, B);
+    if (c) load_row<FPL>(c, row, stride, j, Cc);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) v += A[k] + (b ? B[k] : 0.f) + (c ? Cc[k] : 0.f);
+    v = sub16_sum(v);
+    if (j == 0) out[i] = v;
+  }
+}
+
 // dense kernels bounds-check every column, so any supported FPL >= ceil(dim/16) is correct
 static inline int dense_fpl(int dim) {
   static const int ok[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20};
@@ -294,6 +319,20 @@ extern "C" int mke_align_steps(const mke_align_plan* pl, void* stream) {
     }
   }
   return MKE_OK;
+}
+
+extern "C" int mke_probe_rows(const float* a, const float* b, const float* c, int stride, const int32_t* idx, int64_t n, float* out,
+                              void* stream) {
+  using namespace mke;
+  if (n < 0) { set_error("negative n"); return MKE_E_SHAPE; }
+  if (n == 0) return MKE_OK;
+  if (!a || !idx || !out) { set_error("mke_probe_rows: NULL pointer"); return MKE_E_NULL; }
+  if (stride <= 0 || stride % 16 != 0 || stride > MKE_MAX_STRIDE) { set_error("bad stride"); return MKE_E_SHAPE; }
+  const int fpl = stride / 16;
+  MKE_DISPATCH_FPL(fpl, {
+    hipLaunchKernelGGL((k_probe_rows<FPL>), dim3(grid_for_rows(n)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, a, b, c, stride, idx, n, out);
+  });
+  return check_launch("k_probe_rows");
 }
 
 extern "C" int mke_gather_rows(const float* table, int normalize, int stride, int dim, const int32_t* idx, int64_t n,

@@ -48,7 +48,7 @@ import torch.distributed as dist
 
 from . import _lib
 from .sampling import KGSide, KnownTripleSet, RelationBatcher, side_array
-from .tables import ADAGRAD_INIT_ACC
+from .tables import ADAGRAD_INIT_ACC, PLACEMENT_LOG, placed_rows
 
 
 @dataclass
@@ -524,9 +524,12 @@ class OwnerComputesTrainer:
                 o.ref_count = torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = o.ref_count if exclusive_rows else None
         else:
-            self.ent = torch.zeros(max(1, self.n_local), st, dtype=dtype, device=dev)
+            place = dtype == torch.float32          # big float32 shards: on the fastest of a few candidate allocations (tables.placed_rows)
+            mk = (lambda fill: placed_rows(max(1, self.n_local), st, dev, fill, PLACEMENT_LOG)) if place else \
+                (lambda fill: torch.full((max(1, self.n_local), st), fill, dtype=dtype, device=dev))
+            self.ent = mk(0.0)
             self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
-            self.ent_grad = torch.zeros_like(self.ent)
+            self.ent_grad = mk(0.0)
             self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
             # --- replicated relation state ----------------------------------------------------------
@@ -537,7 +540,8 @@ class OwnerComputesTrainer:
         if ent_table is not None:
             self.ent_acc, self.rel_acc = ent_table.slot(opt_name), rel_table.slot(opt_name)
         else:
-            self.ent_acc = torch.full_like(self.ent, ADAGRAD_INIT_ACC)     # per-optimizer slots (code/MultiKE_model.py:17)
+            self.ent_acc = placed_rows(self.ent.shape[0], st, dev, ADAGRAD_INIT_ACC, PLACEMENT_LOG) if self.ent.dtype == torch.float32 \
+                else torch.full_like(self.ent, ADAGRAD_INIT_ACC)           # per-optimizer slots (code/MultiKE_model.py:17)
             self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
         if batcher is not None:

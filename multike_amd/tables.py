@@ -19,6 +19,76 @@ from . import _lib
 
 ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_value (TF1)
 
+# ---- placement by trial of the big row arrays ----------------------------------------------------------------------------
+# Measured on MI355X (tools/hbm_map.py, profiles/r05_hbm_map.log; EXPERIMENTS R5.10): HBM allocations come in two classes — a
+# read-only gather of random 1 KB rows takes 322-332 us on most 2 GB allocations and 349-357 us (+9 %) on others, the slow ones
+# lying in runs of 12-26 GB in allocation order (~30 % of a fresh device), stable for the life of the allocation — and the
+# relation step at the 2M x 256 shape runs 295-323 us on arrays of the fast class and 367-369 us on arrays of the slow class
+# (tools/c5_probe.py): the "lottery" of +-12 % between runs that rounds 3-4 could only describe.  No virtual-address choice
+# controls it, so arrays of >= MKE_PLACE_MIN_MB (default 1024) are placed by trial: candidates are allocated (all kept alive,
+# so that they are different physical pages), each is timed with the probe (mke_probe_rows, ~0.2 ms), the fastest is kept and
+# the rest returned to the driver.  MKE_PLACE=0 turns it off.
+_PLACE_IDX = {}
+
+
+def _probe_us(arr: torch.Tensor) -> float:
+    import os
+    n = arr.shape[0]
+    key = (arr.device, n)
+    if key not in _PLACE_IDX:
+        g = torch.Generator(device=arr.device); g.manual_seed(12345)
+        k = int(os.environ.get("MKE_PLACE_PROBE_ROWS", 1 << 20))
+        _PLACE_IDX.clear()
+        _PLACE_IDX[key] = (torch.randint(0, n, (k,), device=arr.device, generator=g, dtype=torch.int32),
+                           torch.empty(k, dtype=torch.float32, device=arr.device))
+    idx, out = _PLACE_IDX[key]
+    best = float("inf")
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.probe_rows(arr, None, None, idx, out)
+        e1.record()
+        e1.synchronize()
+        if rep:
+            best = min(best, e0.elapsed_time(e1) * 1e3)
+    return best
+
+
+def placed_rows(n_rows: int, stride: int, device, fill: float = 0.0, report: list | None = None) -> torch.Tensor:
+    """A float32 [n_rows][stride] array filled with `fill`; big ones (see above) on the fastest of up to MKE_PLACE_TRIES
+    (default 10) candidate allocations.  The search stops as soon as a candidate is clearly (4 %) faster than another one seen
+    — the two classes are 9 % apart and each is +-1.5 % wide — or when the tries / a quarter of the free memory are used up."""
+    import os
+    device = torch.device(device)
+    nbytes = n_rows * stride * 4
+    big = device.type == "cuda" and stride % 16 == 0 and stride <= _lib.MAX_STRIDE and \
+        nbytes >= int(os.environ.get("MKE_PLACE_MIN_MB", 1024)) << 20 and os.environ.get("MKE_PLACE", "1") != "0"
+    if not big:
+        return torch.full((n_rows, stride), fill, dtype=torch.float32, device=device) if fill else \
+            torch.zeros(n_rows, stride, dtype=torch.float32, device=device)
+    tries = int(os.environ.get("MKE_PLACE_TRIES", 10))
+    budget = torch.cuda.mem_get_info(device)[0] // 4
+    cands, times = [], []
+    while len(cands) < tries and (len(cands) + 1) * nbytes <= budget:
+        c = torch.empty(n_rows, stride, dtype=torch.float32, device=device)
+        cands.append(c)
+        times.append(_probe_us(c))
+        if min(times) < 0.96 * max(times) and times[-1] <= 1.02 * min(times):
+            break
+    k = int(np.argmin(times)) if times else -1
+    if report is not None:
+        report.append({"bytes": nbytes, "probe_us": [round(t, 1) for t in times], "kept": k})
+    if k < 0:
+        return torch.full((n_rows, stride), fill, dtype=torch.float32, device=device)
+    keep = cands[k]
+    del cands, c
+    torch.cuda.empty_cache()          # the rejected candidates go back to the driver (not into PyTorch's pool, which would hand them out again)
+    keep.fill_(fill)
+    return keep
+
+
+PLACEMENT_LOG: list = []     # one entry per placed array of this process (bench.py prints it)
+
 
 class EmbeddingTable:
     def __init__(self, n_rows: int, dim: int, name: str = "", normalize: bool = True, trainable: bool = True,
@@ -27,7 +97,7 @@ class EmbeddingTable:
         self.normalize, self.trainable = bool(normalize), bool(trainable)
         self.stride = _lib.stride_for(self.dim)
         self.device = torch.device(device)
-        self.data = torch.zeros(self.n_rows, self.stride, dtype=torch.float32, device=self.device)
+        self.data = placed_rows(self.n_rows, self.stride, self.device, 0.0, PLACEMENT_LOG)
         if values is not None:
             v = torch.as_tensor(np.asarray(values), dtype=torch.float32)
             assert v.shape == (self.n_rows, self.dim), (v.shape, (self.n_rows, self.dim))
@@ -59,7 +129,7 @@ class EmbeddingTable:
         """[n_rows][stride] zero-invariant gradient scratch ([copies][n_rows][stride] when privatised as a whole)."""
         if self._grad is None:
             if self.grad_copies == 1:
-                self._grad_full = torch.zeros(self.n_rows + self.hot_copies * self.n_hot, self.stride, dtype=torch.float32, device=self.device)
+                self._grad_full = placed_rows(self.n_rows + self.hot_copies * self.n_hot, self.stride, self.device, 0.0, PLACEMENT_LOG)
                 self._grad = self._grad_full[:self.n_rows]       # same storage: the hub rows' copies sit behind it
             else:
                 self._grad = self._grad_full = torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
@@ -100,7 +170,7 @@ class EmbeddingTable:
         """Adagrad accumulator of one optimizer (created on first use, filled with 0.1)."""
         s = self.slots.get(optimizer_name)
         if s is None:
-            s = torch.full_like(self.data, ADAGRAD_INIT_ACC)
+            s = placed_rows(self.n_rows, self.stride, self.device, ADAGRAD_INIT_ACC, PLACEMENT_LOG)
             self.slots[optimizer_name] = s
         return s
 

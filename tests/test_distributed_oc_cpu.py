@@ -87,7 +87,8 @@ def _reference(world, n_ent, steps):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,n_ent,chunks,excl", [(2, 600, 1, True), (3, 602, 1, True), (2, 600, 3, True), (2, 600, 2, False)])
+@pytest.mark.parametrize("world,n_ent,chunks,excl", [(2, 600, 1, True), (3, 602, 1, True), (2, 600, 3, True), (2, 600, 2, False),
+                                                     (3, 80, 2, True)])   # 80 entities: a sixth of the positives need BOTH vectors
 def test_owner_computes_equals_single_process_oracle(world, n_ent, chunks, excl):
     """world 3 with 602 entities: shards of unequal size, KG id ranges that do not fall on shard boundaries, ragged slices;
     chunks 2 / 3: split-batch parts; steps run past the epoch boundary (shuffle + re-plan)."""
@@ -113,6 +114,7 @@ def test_owner_computes_equals_single_process_oracle(world, n_ent, chunks, excl)
     # one coin per round (code/base/batch.py:97-105): a positive's negatives corrupt one side unless a re-draw round fell on the
     # other, so ~1 vector per positive travels — and never fewer than one (the positive's own term needs it)
     assert 1.0 <= info["vectors_per_positive"] < 1.25, info
+    assert n_ent > 100 or info["vectors_per_positive"] > 1.05
 
 
 def test_parts_and_slices_partition_every_global_step():

@@ -106,6 +106,35 @@ def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg):
     assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("quarter,dim,neg", [(0, 75, 8), (1, 75, 8), (0, 20, 25), (1, 20, 25)])
+def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg):
+    """A 60-entity KG: the sampler's re-draw rounds (known-triple hits) are frequent, their coin falls on the other side for half
+    of them, so a fifth of the positives need BOTH HR and RT on the wire while the rest need one (slot -1 for the other) — the
+    three cases of the one-vector-per-positive exchange in one step, both score kernels, against the dense float64 oracle."""
+    from multike_amd import _lib
+    n_ent = 60
+    _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
+    steps = min(spe, 6)
+    old = _lib.set_option("oc_score_quarter", quarter)
+    try:
+        tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg)
+        vpp = tr.check()["vectors_per_positive"]
+        assert 1.05 < vpp < 1.6, vpp
+        slots = torch.stack([tr._slot[0][:tr._n_all], tr._slot[1][:tr._n_all]])
+        assert bool(((slots >= 0).sum(0) >= 1).all()) and bool((slots < 0).any()) and bool(((slots >= 0).sum(0) == 2).any())
+        for i in range(steps):
+            tr.step(i)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("oc_score_quarter", old)
+    e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+    assert int(tr.ref_count.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("chunks", [1, 2])
 def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     """Same global steps as the single-table StepEngine path (same device batcher, same seed => same shuffle): losses and
