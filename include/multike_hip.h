@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
+#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes, mke_oc_step.hot (hub rows of the shard), + mke_probe_rows; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
@@ -829,6 +829,11 @@ typedef struct mke_oc_step {
    * mke_oc_score. */
   int n_peers; const float* peer_v[MKE_OC_MAX_RANKS]; float* peer_g[MKE_OC_MAX_RANKS];
   const float* pos_w;   /* nullable: [n_pos] weights of the positives (the weighted cross-KG loops, code/losses.py:44-50) */
+  /* version 104: hub rows of this rank's shard (mke_hot_rows over LOCAL rows; slot == NULL: none) — rows that are head / tail of
+   * many positives of every global step: mke_oc_apply and the positives' own terms add to their private copies (ent_grad then
+   * has hot.row0 + hot.copies * hot.n_hot rows, hot.row0 >= n_local), they are not reference-counted and never finished in
+   * place; mke_oc_run's update adds the copies */
+  mke_hot_rows hot;
 } mke_oc_step;
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output; the group flags

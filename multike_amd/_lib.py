@@ -87,6 +87,11 @@ class MappingStepArgs(C.Structure):
                 ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32), ("update", C.c_int)]
 
 
+class HotRowsStruct(C.Structure):
+    """mke_hot_rows"""
+    _fields_ = [("slot", C.c_void_p), ("n_hot", C.c_int32), ("copies", C.c_int32), ("row0", C.c_int64)]
+
+
 class OcStepStruct(C.Structure):
     """mke_oc_step"""
     _fields_ = [("ent", C.c_void_p), ("ent_acc", C.c_void_p), ("ent_grad", C.c_void_p), ("ent_touched", C.c_void_p),
@@ -98,7 +103,8 @@ class OcStepStruct(C.Structure):
                 ("own_t", C.c_void_p), ("n_own_t", C.c_int64), ("neg_per_pos", C.c_int), ("capacity", C.c_int64),
                 ("codes", C.c_void_p), ("code_off", C.c_int64 * 16),
                 ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32),
-                ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16), ("pos_w", C.c_void_p)]
+                ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16), ("pos_w", C.c_void_p),
+                ("hot", HotRowsStruct)]
 
 
 class AEPlanStruct(C.Structure):
@@ -125,11 +131,6 @@ class KGSideStruct(C.Structure):
     _fields_ = [("ent_list", C.c_void_p), ("ent_lo", C.c_int32), ("n_ent", C.c_int32), ("cand_table", C.c_void_p),
                 ("cand_valid", C.c_void_p), ("cand_k", C.c_int32), ("known_keys", C.c_void_p),
                 ("known_capacity", C.c_uint64)]
-
-
-class HotRowsStruct(C.Structure):
-    """mke_hot_rows"""
-    _fields_ = [("slot", C.c_void_p), ("n_hot", C.c_int32), ("copies", C.c_int32), ("row0", C.c_int64)]
 
 
 class UpdateTableStruct(C.Structure):

@@ -49,6 +49,18 @@ struct OcParams {
 // codes of the negatives of home rank g's positives of this part: [n_mine_g][neg_per_pos]
 __device__ __forceinline__ const int32_t* oc_codes(const OcParams& p, int g) { return p.s.codes + p.s.code_off[g]; }
 
+// Hub rows of the shard (mke_oc_step.hot; the fused kernel's mke_hot_rows on this rank's rows): an entity that is head or tail of
+// many positives of EVERY global step receives that many same-address atomic row adds from k_oc_apply and from the positives'
+// own terms (measured as rank 0 of 8 on Zipf(1.0) triples: apply 7.4 -> 60 us, score 50 -> 76, the counting 13 -> 39).  Their
+// contributions go to one of `copies` private rows behind the shard's own rows in the gradient scratch (the update launch
+// adds the copies when it visits the row), they are not reference-counted (a hub row is never finished in place).
+__device__ __forceinline__ bool oc_is_hot(const mke_oc_step& s, int row) { return s.hot.slot && s.hot.slot[row] >= 0; }
+__device__ __forceinline__ int64_t oc_grad_row(const mke_oc_step& s, int row, int64_t k) {
+  if (!s.hot.slot) return row;
+  const int hs = s.hot.slot[row];
+  return hs >= 0 ? s.hot.row0 + (k % s.hot.copies) * s.hot.n_hot + hs : (int64_t)row;
+}
+
 // (corrupt entity << 1) | corrupted-head, one per negative; a negative equal to its positive counts as a corrupted tail.
 // Bits 30 / 31 of a group's FIRST code are written afterwards by k_oc_mark_groups (entity ids stay below 2^29).
 #define OC_CODE_MASK 0x3FFFFFFF
@@ -99,7 +111,7 @@ __device__ __forceinline__ void oc_count_range(const OcParams& p, int block, int
     } else {
       const int64_t k = e - n_codes;
       const int ent = k < s.n_pos ? s.pos_h[k] : s.pos_t[k - s.n_pos];
-      if (ent % s.n_ranks == s.rank) atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
+      if (ent % s.n_ranks == s.rank && !oc_is_hot(s, ent / s.n_ranks)) atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
     }
   }
 }
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) { oc_c
 // POSITIVE (code/losses.py:4-12), c d added to the vector's gradient, -+ c d scattered to the local row (never in place:
 // the row is also referenced by nothing else only by accident, and the update launch visits it anyway).
 template <int FPL>
-__device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRIDE, int j, bool use_hr, int ent_local, float pw,
+__device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRIDE, int j, bool use_hr, int ent_local, float pw, int64_t i,
                                                   const float (&HR)[FPL], const float (&RT)[FPL], float (&gHR)[FPL], float (&gRT)[FPL]) {
   float E[FPL];
   load_row<FPL>(s.ent, ent_local, STRIDE, j, E);
@@ -158,7 +170,7 @@ __device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRI
     gHR[k] = fmaf(ch, d[k], gHR[k]);
     gRT[k] = fmaf(1.0f - ch, d[k], gRT[k]);
   }
-  atomic_add_row<FPL>(s.ent_grad, ent_local, STRIDE, s.dim, j, d, sg);
+  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, ent_local, i), STRIDE, s.dim, j, d, sg);
   if (j == 0) s.ent_touched[ent_local] = s.tag;
   return pw * softplus_f(x);
 }
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     int code = 0;
     if (lane < N) code = oc_code(oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane]);
     const bool mine = lane < N && ((code >> 1) % G) == s.rank;
-    const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
+    const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, (code >> 1) / G) ? 2 : s.ref_count[(code >> 1) / G]) : 0;   // a hub row is never finished in place
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
 #pragma unroll
     for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h (wave-uniform test)
     if ((sh >= 0 ? pt : ph) % G == s.rank && q == 0) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;   // weighted positives: code/losses.py:44-50
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, i, HR, RT, gHR, gRT);
     }
 
     // quarter q takes the q-th, (q+4)-th, ... set bit of the ballot: a running copy of the mask with the bits already
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h
     if (act && (sh >= 0 ? pt : ph) % G == s.rank) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, i, HR, RT, gHR, gRT);
     }
     const int32_t* cp = oc_codes(p, home) + (i - (int64_t)home * s.per) * N;
     for (int c0 = 0; c0 < N; c0 += 16) {                      // the group's codes, 16 per quarter at a time
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
       const bool has = act && c0 + j < N;
       if (has) code = oc_code(cp[c0 + j]);
       const bool mine = has && ((code >> 1) % G) == s.rank;
-      const int rcl = (mine && s.ref_count) ? s.ref_count[(code >> 1) / G] : 0;
+      const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, (code >> 1) / G) ? 2 : s.ref_count[(code >> 1) / G]) : 0;
       const uint64_t mall = __ballot(mine);
       unsigned rest = (unsigned)(mall >> (16 * q)) & 0xFFFFu;  // this quarter's owned negatives of the chunk
       while (__ballot(rest != 0)) {                            // the four quarters visit their next owned negative together
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
       for (int c = 0; c < FPL; ++c) v[c] += w[c];
     }
   }
-  atomic_add_row<FPL>(s.ent_grad, row, s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
+  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, row, sub), s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
   float* grel = s.rel_grad + (sub % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
   atomic_add_row<FPL>(grel, r, s.stride, s.dim, j, v, 1.0f);
   if (j == 0) {
@@ -558,6 +570,7 @@ static int oc_check(const mke_oc_step* s, const char* who) {
   if ((s->n_own_h > 0 && !s->own_h) || (s->n_own_t > 0 && !s->own_t)) { set_error("%s: NULL owned-slot list", who); return MKE_E_NULL; }
   if (!s->ent || !s->rel) { set_error("%s: NULL table", who); return MKE_E_NULL; }
   if (s->optimizer != MKE_OPT_ADAGRAD && s->optimizer != MKE_OPT_SGD) { set_error("%s: Adagrad or SGD", who); return MKE_E_UNSUPPORTED; }
+  if (s->hot.slot && (s->hot.n_hot < 1 || s->hot.copies < 1 || s->hot.copies > 64 || s->hot.row0 < s->n_local)) { set_error("%s: bad hub-row declaration", who); return MKE_E_SHAPE; }
   return MKE_OK;
 }
 
@@ -701,7 +714,7 @@ extern "C" int mke_oc_run(const mke_oc_step* s, int phases, float* send_block, c
     ut[0].table = const_cast<float*>(s->rel); ut[0].acc = s->rel_acc; ut[0].grad = s->rel_grad; ut[0].touched = nullptr;
     ut[0].n_rows = s->n_rel; ut[0].normalize = 1; ut[0].grad_copies = s->rel_grad_copies;
     ut[1].table = s->ent; ut[1].acc = s->ent_acc; ut[1].grad = s->ent_grad; ut[1].touched = s->ent_touched;
-    ut[1].n_rows = s->n_local; ut[1].normalize = 1; ut[1].grad_copies = 1; ut[1].ref_count = s->ref_count;
+    ut[1].n_rows = s->n_local; ut[1].normalize = 1; ut[1].grad_copies = 1; ut[1].ref_count = s->ref_count; ut[1].hot = s->hot;
     if ((rc = launch_rows_update_multi(ut, 2, s->tag, s->stride, s->dim, s->optimizer, s->lr, (hipStream_t)stream, nullptr, nullptr))) return rc;
   }
   return MKE_OK;

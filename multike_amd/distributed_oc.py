@@ -112,6 +112,9 @@ class OcHipBackend:
             s.code_off[g] = int(o)
         s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, tr.scale, st.tag
         s.pos_w = _lib.ptr(st.pos_w, f32, "pos_w") if st.pos_w is not None else None
+        if tr.hot_slot is not None:           # hub rows of the shard: private gradient copies behind the shard's own rows
+            s.hot.slot, s.hot.n_hot = _lib.ptr(tr.hot_slot, i32, "hot_slot"), tr.n_hot
+            s.hot.copies, s.hot.row0 = tr.HOT_COPIES, tr.ent_grad_rows
         s.n_peers = 0
         if tr.peer_direct and tr.world > 1:   # peer-mapped blocks (chunk 0: peer-direct runs unchunked)
             gb = 2 * tr.C * tr.stride * 4
@@ -186,8 +189,11 @@ class OcHipBackend:
 
     def update(self, tr, tag):
         # relation table: EVERY row (touched = None) — after the all-reduce a row may carry a gradient no local triple touched
+        hot = None
+        if tr.hot_slot is not None:
+            hot = _lib.HotRowsStruct(_lib.ptr(tr.hot_slot, torch.int32, "hot_slot"), tr.n_hot, tr.HOT_COPIES, tr.ent_grad_rows)
         _lib.rows_update_multi([(tr.rel, tr.rel_acc, tr.rel_grad, None, True),
-                                (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched, True, tr.ref_count)],
+                                (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched, True, tr.ref_count, hot)],
                                tag, tr.stride, tr.dim, _lib.OPT_ADAGRAD, tr.lr)
 
     def run(self, tr, k, tag, phases, c, loss_slot):
@@ -450,6 +456,11 @@ class TripleListBatcher:
 
 
 class OwnerComputesTrainer:
+    # hub rows of the shard (mke_oc_step.hot): entities that are head or tail of >= HOT_MIN positives of an average GLOBAL step get
+    # HOT_COPIES private copies of their gradient row for mke_oc_apply and the positives' own terms (the fused runner's rule,
+    # multike_amd/runner.py; measured as rank 0 of 8 on Zipf(1.0) triples: EXPERIMENTS R5.12)
+    HOT_MIN, HOT_MAX, HOT_COPIES = 20.0, 1024, 8
+
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
@@ -529,7 +540,8 @@ class OwnerComputesTrainer:
                 (lambda fill: torch.full((max(1, self.n_local), st), fill, dtype=dtype, device=dev))
             self.ent = mk(0.0)
             self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
-            self.ent_grad = mk(0.0)
+            self.ent_grad = None                    # allocated by _declare_hot_rows (with the hub rows' copies behind the shard's rows)
+            self._mk_rows = mk
             self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
             # --- replicated relation state ----------------------------------------------------------
@@ -563,6 +575,7 @@ class OwnerComputesTrainer:
                                        int(global_batch) if global_batch else batch_size * world, neg_per_pos,
                                        device=dev, seed=seed)
         self.steps = self.bat.steps
+        self._declare_hot_rows(ent_table, tables_of)
         # trainers sharing the touched-flag arrays keep apart in tag space (a flag is `touched[row] == tag`)
         self._n_sharing = 0
         if tables_of is not None:
@@ -579,6 +592,38 @@ class OwnerComputesTrainer:
         self._parts = None
         self._persistent = {}
         self._plan_epoch()
+
+    def _declare_hot_rows(self, ent_table, tables_of):
+        """hot_slot (int32 [n_local]: index among this rank's hub rows or -1), n_hot, and the gradient scratch with the copies
+        behind the shard's own rows.  Performance only: any row may or may not be declared (the arithmetic is the same sum)."""
+        self.hot_slot, self.n_hot, self.ent_grad_rows = None, 0, max(1, self.n_local)
+        if tables_of is not None:                           # shared scratch: the declaration comes with it
+            self.hot_slot, self.n_hot, self.HOT_COPIES = tables_of.hot_slot, tables_of.n_hot, tables_of.HOT_COPIES
+            return
+        if ent_table is not None:                           # an EmbeddingTable shard: whatever its holder declared
+            if ent_table.n_hot:
+                self.hot_slot, self.n_hot, self.HOT_COPIES = ent_table.hot_slot, ent_table.n_hot, ent_table.hot_copies
+                self.ent_grad = ent_table.grad
+            return
+        b, G = self.bat, self.world
+        n_all = int(b.off[-1]) if self.steps else 0
+        if self.device.type == "cuda" and isinstance(self.backend, OcHipBackend) and n_all and self._dtype_is_f32():
+            ids = torch.cat([b.pos_h[:n_all], b.pos_t[:n_all]]).long()
+            deg = torch.bincount(ids, minlength=self.n_ent).float() / max(1, self.steps)      # references per global step
+            hot = torch.nonzero(deg >= self.HOT_MIN).reshape(-1)
+            hot = hot[hot % G == self.rank]
+            if hot.numel() > self.HOT_MAX:
+                hot = hot[torch.topk(deg[hot], self.HOT_MAX).indices]
+            if hot.numel():
+                slot = torch.full((max(1, self.n_local),), -1, dtype=torch.int32, device=self.device)
+                slot[(hot // G)] = torch.arange(hot.numel(), dtype=torch.int32, device=self.device)
+                self.hot_slot, self.n_hot = slot, int(hot.numel())
+        rows = self.ent_grad_rows + self.HOT_COPIES * self.n_hot
+        full = self._mk_rows(0.0) if rows == self.ent.shape[0] else torch.zeros(rows, self.stride, dtype=self.ent.dtype, device=self.device)
+        self.ent_grad_full, self.ent_grad = full, full[:self.ent.shape[0]]
+
+    def _dtype_is_f32(self):
+        return self.ent.dtype == torch.float32
 
     # ------------------------------------------------------------------------------------------------
     def parts_of_step(self, s: int):

@@ -26,7 +26,7 @@ ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_
 # relation step at the 2M x 256 shape runs 295-323 us on arrays of the fast class and 367-369 us on arrays of the slow class
 # (tools/c5_probe.py): the "lottery" of +-12 % between runs that rounds 3-4 could only describe.  No virtual-address choice
 # controls it, so arrays of >= MKE_PLACE_MIN_MB (default 1024) are placed by trial: candidates are allocated (all kept alive,
-# so that they are different physical pages), each is timed with the probe (mke_probe_rows, ~0.2 ms), the fastest is kept and
+# so that they are different physical pages), each is timed with the probe (mke_probe_rows, 2M random rows, ~0.3 ms), the fastest is kept and
 # the rest returned to the driver.  MKE_PLACE=0 turns it off.
 _PLACE_IDX = {}
 
@@ -37,7 +37,7 @@ def _probe_us(arr: torch.Tensor) -> float:
     key = (arr.device, n)
     if key not in _PLACE_IDX:
         g = torch.Generator(device=arr.device); g.manual_seed(12345)
-        k = int(os.environ.get("MKE_PLACE_PROBE_ROWS", 1 << 20))
+        k = int(os.environ.get("MKE_PLACE_PROBE_ROWS", 1 << 21))
         _PLACE_IDX.clear()
         _PLACE_IDX[key] = (torch.randint(0, n, (k,), device=arr.device, generator=g, dtype=torch.int32),
                            torch.empty(k, dtype=torch.float32, device=arr.device))

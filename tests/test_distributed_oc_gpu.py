@@ -135,6 +135,39 @@ def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg):
     assert int(tr.ref_count.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("quarter", [0, 1])
+def test_hub_rows_of_the_shard_are_the_same_function(quarter):
+    """Zipf(1.2) head / tail entities: a few rows are head or tail of dozens of positives of every step.  The trainer declares them
+    (mke_oc_step.hot): mke_oc_apply and the positives' own terms add to private copies behind the shard's rows, the update launch
+    adds the copies.  Same tables as the run without the declaration (HOT_MIN out of reach), copies all zero afterwards."""
+    from multike_amd import _lib
+    from multike_amd.distributed_oc import OwnerComputesTrainer
+    from multike_amd.synthetic import SyntheticKGs
+    n_ent, dim, neg, b = 4000, 75, 8, 512
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED, zipf=1.2)
+    rng = np.random.default_rng(SEED)
+    ent0, rel0 = mo.xavier_truncated_normal((n_ent, dim), rng), mo.xavier_truncated_normal((N_REL, dim), rng)
+    old = _lib.set_option("oc_score_quarter", quarter)
+    try:
+        out = []
+        for hot_min in (20.0, 1e9):
+            class T(OwnerComputesTrainer):
+                HOT_MIN = hot_min
+            tr = T(kgs, ent0, rel0, b, neg, 0, 1, seed=SEED, lr=0.02)
+            assert (tr.n_hot > 0) == (hot_min < 1e9), tr.n_hot
+            for i in range(min(tr.steps, 8)):
+                tr.step(i)
+            torch.cuda.synchronize()
+            assert float(tr.ent_grad_full.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+            out.append((tr.epoch_loss(), tr.gather_entity_table().cpu().numpy(), tr.rel[:, :dim].cpu().numpy(), tr.n_hot))
+    finally:
+        _lib.set_option("oc_score_quarter", old)
+    assert out[0][3] >= 3
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=2e-6)
+
+
 @pytest.mark.parametrize("chunks", [1, 2])
 def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     """Same global steps as the single-table StepEngine path (same device batcher, same seed => same shuffle): losses and

@@ -40,6 +40,7 @@ for cfg in c2 c5; do
     timeout 600 python tools/oc_rank_compute.py --world 8 --config $cfg --chunks $ch --wire-gbps 376 --latency-us 15 --prefetch 2>/dev/null | tail -1 > $o/r05_oc_${cfg}_ch${ch}_wire.json
   done
 done
+timeout 600 python tools/oc_rank_compute.py --world 8 --config c2 --zipf 1.0 --chunks 1 --prefetch 2>/dev/null | tail -1 > $o/r05_oc_c2_zipf_nowire.json
 MKE_BENCH_COMM=staged timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 > $o/r05_bench_gpus2_staged.json.log 2>&1
 fi
 if [ $part = all ] || [ $part = rest ]; then
@@ -49,6 +50,8 @@ timeout 300 python tools/knn_bench.py > $o/r05_knn.log 2>&1
 timeout 300 python tools/ae_bench.py > $o/r05_ae.log 2>&1
 timeout 600 python tools/full_run.py 100000 200 ITC > $o/r05_full_run.log 2>&1
 timeout 600 bash tools/gpu_idle.sh > $o/r05_gpu_idle.log 2>&1
+timeout 300 python tools/hbm_map.py --n 120 > $o/r05_hbm_map_box2.log 2>&1
+for u in 1 2 3; do timeout 300 python bench.py --config c5 --steps 100 --windows 4 --no-cpu-baseline --no-variants > $o/r05_bench_c5_placed_$u.json.log 2>/dev/null; done
 fi
 if [ $part = all ] || [ $part = tests ]; then
 ( echo "python -m pytest tests -q -m gpu   (final tree of round 5, fresh MI355X box)"; timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4 ) > $o/r05_pytest_gpu.log 2>&1
