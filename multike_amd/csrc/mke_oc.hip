@@ -150,27 +150,27 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) { oc_c
 template <int FPL>
 __device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRIDE, int j, bool use_hr, int ent_local, float pw, int64_t i,
                                                   const float (&HR)[FPL], const float (&RT)[FPL], float (&gHR)[FPL], float (&gRT)[FPL]) {
-  float E[FPL];
-  load_row<FPL>(s.ent, ent_local, STRIDE, j, E);
-  l2_normalize_row<FPL>(E, true);
   float d[FPL];
+  load_row<FPL>(s.ent, ent_local, STRIDE, j, d);
+  l2_normalize_row<FPL>(d, true);
   float x = 0.f;
   const float sg = use_hr ? -1.0f : 1.0f;
 #pragma unroll
   for (int k = 0; k < FPL; ++k) {
-    d[k] = fmaf(sg, E[k], use_hr ? HR[k] : RT[k]);
+    const float v = use_hr ? HR[k] : RT[k];
+    d[k] = fmaf(sg, d[k], v);
     x = fmaf(d[k], d[k], x);
   }
   x = sub16_sum(x);
   const float c = 2.0f * s.scale * pw * sigmoid_f(x);
-  const float ch = use_hr ? 1.0f : 0.0f;
+  const float ch = use_hr ? c : 0.0f, ct = use_hr ? 0.0f : c;
 #pragma unroll
   for (int k = 0; k < FPL; ++k) {
-    d[k] *= c;
     gHR[k] = fmaf(ch, d[k], gHR[k]);
-    gRT[k] = fmaf(1.0f - ch, d[k], gRT[k]);
+    gRT[k] = fmaf(ct, d[k], gRT[k]);
   }
-  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, ent_local, i), STRIDE, s.dim, j, d, sg);
+  // the row's own gradient is sg * c * d: the scale rides on the sign argument (no second scaled copy of d)
+  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, ent_local, i), STRIDE, s.dim, j, d, sg * c);
   if (j == 0) s.ent_touched[ent_local] = s.tag;
   return pw * softplus_f(x);
 }

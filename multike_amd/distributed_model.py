@@ -56,6 +56,12 @@ class ShardedITC:
         self.rel, self.attr = full("rel", True), full("attr", False)
         self.lit = full("lit", False, train=False)
         self.sizes = (int(batch_size), int(attribute_batch_size), int(entity_batch_size))
+        # hub rows of the relation view's shard (performance only; before any trainer takes the table's gradient scratch):
+        # mke_oc_apply and the positives' own terms add to private copies of the rows many positives of every step share
+        from .distributed_oc import hub_rows_of_shard
+        hubs = hub_rows_of_shard(kgs.triples, n_ent, batch_size, rank, world)
+        if len(hubs):
+            self.rv_ent.set_hot_rows(hubs, OwnerComputesTrainer.HOT_COPIES)
         # one tag range per component (they share the tables' touched-flag arrays: a flag is `touched[row] == tag`)
         base = iter(k << 26 for k in range(1, 16))
         oc = dict(rank=rank, world=world, seed=seed, lr=learning_rate, comm=comm_oc, ent_table=self.rv_ent, rel_table=self.rel, n_ent=n_ent)

@@ -455,6 +455,20 @@ class TripleListBatcher:
         return (self.epoch * 2) & 0xFFFFFFFF
 
 
+def hub_rows_of_shard(triples, n_ent: int, global_batch: int, rank: int, world: int, hot_min: float = 20.0, hot_max: int = 1024):
+    """LOCAL rows (id // world) of this rank's entities that are head or tail of >= hot_min positives of an average global
+    step, from the two KGs' relation triples (static degrees: an epoch is the same triples in a new order) — what a holder
+    of an EmbeddingTable shard passes to `set_hot_rows` before it builds the trainers on it."""
+    ids = np.concatenate([np.asarray(t, dtype=np.int64).reshape(-1, 3)[:, [0, 2]].reshape(-1) for t in triples])
+    n = sum(len(t) for t in triples)
+    steps = max(1, -(-n // max(1, int(global_batch))))
+    deg = np.bincount(ids, minlength=n_ent) / steps
+    hot = np.nonzero((deg >= hot_min) & (np.arange(n_ent) % world == rank))[0]
+    if len(hot) > hot_max:
+        hot = hot[np.argsort(-deg[hot])[:hot_max]]
+    return np.sort(hot // world)
+
+
 class OwnerComputesTrainer:
     # hub rows of the shard (mke_oc_step.hot): entities that are head or tail of >= HOT_MIN positives of an average GLOBAL step get
     # HOT_COPIES private copies of their gradient row for mke_oc_apply and the positives' own terms (the fused runner's rule,
