@@ -1123,12 +1123,21 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   // (dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split over K, atomic) rides on extra blocks of the same grid,
   // forming dz on the way into its MFMAs.  W^T (the B operand read 16 consecutive floats per quarter-wave) is left in the unused dflat
   // scratch by the loss-tail launch.  4 launches per step: forward, loss tail, backward, updates.
-  const bool fused = g_attr_fused_bwd && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
+  const bool fused_tail = g_attr_fused_bwd && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
   if ((phases & MKE_ATTR_TAIL) &&
       (rc = tail_loss_impl(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
-                           a->ent_grad, a->ent_touched, a->tag, lossp, fused ? W : nullptr, fused ? dflat : nullptr, stream))) return rc;
-  // backward
+                           a->ent_grad, a->ent_touched, a->tag, lossp, fused_tail ? W : nullptr, fused_tail ? dflat : nullptr, stream))) return rc;
+  // backward.  The fused launch reads W^T from the scratch where the step's loss tail left it.  A call that runs the backward
+  // WITHOUT the tail (mke_attr_step_phases: the sharded view all-reduces a scalar between the two) takes the fused path only
+  // when the last tail enqueued on this scratch was this step's (same tag, same parameters) and did leave W^T — otherwise (the
+  // option toggled in between, a BWD-only call out of the blue) the unfused path, which needs nothing but g in `gout`
+  // (round-4 advice).  Host-side bookkeeping of what was ENQUEUED; stream order makes it true on the device.
+  static const float* wt_scratch = nullptr;
+  static const float* wt_params = nullptr;
+  static int32_t wt_tag = 0;
+  if (phases & MKE_ATTR_TAIL) { wt_scratch = fused_tail ? dflat : nullptr; wt_params = a->params; wt_tag = a->tag; }
   if (phases & MKE_ATTR_BWD) {
+  const bool fused = fused_tail && wt_scratch == dflat && wt_params == a->params && wt_tag == a->tag;
   if (!fused && (rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre (the fused launch forms it on load)
   if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
   ConvParams p{};

@@ -474,6 +474,7 @@ class OwnerComputesTrainer:
     # HOT_COPIES private copies of their gradient row for mke_oc_apply and the positives' own terms (the fused runner's rule,
     # multike_amd/runner.py; measured as rank 0 of 8 on Zipf(1.0) triples: EXPERIMENTS R5.12)
     HOT_MIN, HOT_MAX, HOT_COPIES = 20.0, 1024, 8
+    SAMPLE_RUN = 1 << 26          # ids per column of the epoch sampler's scratch (the plan samples its share in runs of SAMPLE_RUN / N positions)
 
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
@@ -698,13 +699,18 @@ class OwnerComputesTrainer:
             mine = codes[self.rank * n_per * N:(self.rank + 1) * n_per * N] if G == 1 else \
                 self._persist(("codes_mine", bs), torch.zeros(0, **i32), n_per * N)[:n_per * N]
             if hi_r > lo_r:
-                n_r = hi_r - lo_r
                 # scratch of the sampler's (h, r, t) output: kept across epochs (a fresh allocation per epoch was tens of ms of
-                # hipMalloc inside the plan); one plan at a time writes it (plans are computed in epoch order on one stream)
-                neg = tuple(self._persist(("neg", k_), torch.zeros(0, **i32), n_per * N)[:n_r * N] for k_ in range(3))
-                self.backend.sample_at((ph[lo_r:hi_r], pr[lo_r:hi_r], pt[lo_r:hi_r]), self._all_idx[lo_r:hi_r], b.pos_kg[lo_r:hi_r],
-                                       b.side1, b.side2, N, b.rng_seed, rng_stream, neg)
-                self.backend.pack_codes(ph[lo_r:hi_r], neg[0], neg[2], N, mine[:n_r * N])
+                # hipMalloc inside the plan) and BOUNDED — the share is sampled in runs of at most 2^26 / N positions (256 MB per
+                # column; the whole share at once was 2.4 GB per column at the C5 shape on one rank: round-4 advice); one plan at a
+                # time writes it (plans are computed in epoch order on one stream)
+                run = max(1, self.SAMPLE_RUN // N)
+                neg = tuple(self._persist(("neg", k_), torch.zeros(0, **i32), min(n_per, run) * N) for k_ in range(3))
+                for a in range(lo_r, hi_r, run):
+                    e = min(hi_r, a + run)
+                    out = tuple(x[:(e - a) * N] for x in neg)
+                    self.backend.sample_at((ph[a:e], pr[a:e], pt[a:e]), self._all_idx[a:e], b.pos_kg[a:e],
+                                           b.side1, b.side2, N, b.rng_seed, rng_stream, out)
+                    self.backend.pack_codes(ph[a:e], out[0], out[2], N, mine[(a - lo_r) * N:(e - lo_r) * N])
             if G > 1:
                 self._plan_comm.all_gather(codes[:G * n_per * N], mine)
         plan["codes"] = codes

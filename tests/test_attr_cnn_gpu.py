@@ -159,3 +159,43 @@ def test_conv_op_gradcheck_against_the_training_step():
     np.testing.assert_allclose(cnn.params.grad.cpu().numpy(), step_g.cpu().numpy(), rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(th.grad.cpu().numpy(), ent.grad[:, :d].cpu().numpy(), rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(ta.grad.cpu().numpy(), attr.grad[:, :d].cpu().numpy(), rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("tail_opt,bwd_opt", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_backward_phase_alone_does_not_trust_a_stale_transposed_weight(tail_opt, bwd_opt):
+    """mke_attr_step_phases with the loss tail and the backward in SEPARATE calls (the sharded view all-reduces a scalar in
+    between).  The fused backward reads W^T from where the tail left it: when the option differed at the tail's call, or no tail of
+    this step ran, the backward call must take the unfused path — whatever the option says at ITS call — and give the same
+    gradients as the one-call step (round-4 advice)."""
+    from multike_amd import _lib
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import StepEngine
+    g = np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+    pre = "n0_"
+    d = int(g[pre + "meta"][0])
+    P = {k: g[pre + "p_" + k] for k in ao.PARAM_NAMES}
+    scale = float(g[pre + "scale"])
+
+    def grads(split):
+        ent, attr, lit, idx = _tables(g[pre + "hs"], g[pre + "as"], g[pre + "vs"])
+        cnn, eng = AttrCNN(d, params=P), StepEngine()
+        if not split:
+            cnn.step(eng, ent, attr, lit, idx, idx, idx, None, scale=scale, update=False)
+        else:
+            args, _part = cnn._args(eng, ent, attr, lit, idx, idx, idx, None, int(idx.numel()), scale, "o", 0.01, "Adagrad", False, 1)
+            old = _lib.set_option("attr_fused_bwd", tail_opt)
+            try:
+                _lib.attr_step_phases(args, _lib.ATTR_FWD)
+                _lib.attr_step_phases(args, _lib.ATTR_TAIL)
+                _lib.set_option("attr_fused_bwd", bwd_opt)
+                _lib.attr_step_phases(args, _lib.ATTR_BWD)
+            finally:
+                _lib.set_option("attr_fused_bwd", old)
+        torch.cuda.synchronize()
+        return {k: cnn.gviews[k].cpu().numpy().copy() for k in ao.PARAM_NAMES}, attr.grad[:, :d].cpu().numpy().copy()
+
+    one, one_attr = grads(False)
+    two, two_attr = grads(True)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(two[k], one[k], rtol=2e-3, atol=2e-5 * max(1.0, np.abs(one[k]).max()), err_msg=k)
+    np.testing.assert_allclose(two_attr, one_attr, rtol=2e-3, atol=2e-6)

@@ -32,6 +32,8 @@ def _worker(rank, world, port, ret, n_ent, steps, chunks, excl):
         from multike_amd.distributed_oc import OwnerComputesTrainer
         from multike_amd.synthetic import SyntheticKGs
         from oracle_backend import OcOracleBackend
+        if n_ent < 100:
+            OwnerComputesTrainer.SAMPLE_RUN = 23 * NEG        # the rank's share of an epoch sampled in several runs (bounded scratch)
         kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
         rng = np.random.default_rng(SEED)
         ent0 = mo.xavier_truncated_normal((n_ent, DIM), rng).astype(np.float64)
