@@ -62,35 +62,36 @@ __device__ __forceinline__ int64_t oc_grad_row(const mke_oc_step& s, int row, in
 }
 
 // (corrupt entity << 1) | corrupted-head, one per negative; a negative equal to its positive counts as a corrupted tail.
-// Bits 30 / 31 of a group's FIRST code are written afterwards by k_oc_mark_groups (entity ids stay below 2^29).
+// Bits 30 / 31 of a group's FIRST code carry its need flags (entity ids stay below 2^29).
 #define OC_CODE_MASK 0x3FFFFFFF
 __device__ __forceinline__ int oc_code(int32_t c) { return c & OC_CODE_MASK; }
+// GS lanes per positive (16 / 32 / 64 >= neg_per_pos), lane = slot: the reads of the sampler's output are coalesced and the group's
+// need flags — MKE_OC_NEED_RT when any negative corrupts the head, MKE_OC_NEED_HR when any corrupts the tail or none corrupts
+// the head (the positive's own term needs one of the two) — are two ballots; slot 0 stores them with its code.  (As two kernels,
+// pack then a thread per positive marking its group, the marking alone took 569 us per epoch share at the C5 shape.)
+template <int GS>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_pack_codes(const int32_t* __restrict__ pos_h, const int32_t* __restrict__ neg_h,
                                                              const int32_t* __restrict__ neg_t, int64_t n_pos, int neg_per_pos,
                                                              int32_t* __restrict__ codes) {
-  const int64_t total = n_pos * neg_per_pos;
-  for (int64_t e = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * MKE_BLOCK) {
-    const int nh = neg_h[e], nt = neg_t[e];
-    codes[e] = nh != pos_h[e / neg_per_pos] ? ((nh << 1) | 1) : (nt << 1);
-  }
-}
-
-// which of its two vectors a positive's negatives need, into the top bits of the group's first code: MKE_OC_NEED_RT when any
-// negative corrupts the head, MKE_OC_NEED_HR when any corrupts the tail — and when none corrupts the head (the positive's own
-// term needs one of the two).  A thread per positive; the codes were just written (L2).
-__global__ __launch_bounds__(MKE_BLOCK) void k_oc_mark_groups(int64_t n_pos, int neg_per_pos, int32_t* __restrict__ codes) {
-  for (int64_t i = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x; i < n_pos; i += (int64_t)gridDim.x * MKE_BLOCK) {
-    int32_t* c = codes + i * neg_per_pos;
-    int any_h = 0, any_t = 0;
-    for (int n = 0; n < neg_per_pos; ++n) {
-      const int side = c[n] & 1;
-      any_h |= side;
-      any_t |= side ^ 1;
+  const int lane = threadIdx.x & 63, gl = lane & (GS - 1), gbase = lane & ~(GS - 1);
+  const int64_t g0 = (((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6) * (64 / GS) + lane / GS;
+  const int64_t gstep = (((int64_t)gridDim.x * MKE_BLOCK) >> 6) * (64 / GS);
+  const int64_t iters = (n_pos + gstep - 1) / gstep;                 // wave-uniform trip count (ballots inside)
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t i = g0 + it * gstep;
+    const bool has = i < n_pos && gl < neg_per_pos;
+    uint32_t code = 0;
+    if (has) {
+      const int64_t e = i * neg_per_pos + gl;
+      const int nh = neg_h[e], nt = neg_t[e];
+      code = nh != pos_h[i] ? (((uint32_t)nh << 1) | 1u) : ((uint32_t)nt << 1);
     }
-    uint32_t w = (uint32_t)oc_code(c[0]);
-    if (any_h) w |= MKE_OC_NEED_RT;
-    if (any_t || !any_h) w |= MKE_OC_NEED_HR;
-    c[0] = (int32_t)w;
+    const uint64_t gm = GS == 64 ? ~0ull : (((1ull << (GS & 63)) - 1ull) << gbase);
+    const bool any_h = (__ballot(has && (code & 1u)) & gm) != 0, any_t = (__ballot(has && !(code & 1u)) & gm) != 0;
+    if (has) {
+      if (gl == 0) code |= (any_h ? MKE_OC_NEED_RT : 0u) | ((any_t || !any_h) ? MKE_OC_NEED_HR : 0u);
+      codes[i * neg_per_pos + gl] = (int32_t)code;
+    }
   }
 }
 
@@ -594,9 +595,12 @@ extern "C" int mke_oc_pack_codes(const int32_t* pos_h, const int32_t* neg_h, con
   if (n_pos < 0 || neg_per_pos < 0) { set_error("mke_oc_pack_codes: negative count"); return MKE_E_SHAPE; }
   if (n_pos * neg_per_pos == 0) return MKE_OK;
   if (!pos_h || !neg_h || !neg_t || !codes) { set_error("mke_oc_pack_codes: NULL pointer"); return MKE_E_NULL; }
-  hipLaunchKernelGGL(k_oc_pack_codes, dim3(oc_blocks(n_pos * neg_per_pos, MKE_BLOCK, 4096)), dim3(MKE_BLOCK), 0, (hipStream_t)stream,
-                     pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
-  hipLaunchKernelGGL(k_oc_mark_groups, dim3(oc_blocks(n_pos, MKE_BLOCK, 4096)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, n_pos, neg_per_pos, codes);
+  if (neg_per_pos > 64) { set_error("mke_oc_pack_codes: neg_per_pos <= 64"); return MKE_E_SHAPE; }
+  const int gs = neg_per_pos <= 16 ? 16 : (neg_per_pos <= 32 ? 32 : 64);
+  const dim3 grid(oc_blocks(n_pos, (MKE_BLOCK / 64) * (64 / gs), 16384)), blk(MKE_BLOCK);
+  if (gs == 16) hipLaunchKernelGGL((k_oc_pack_codes<16>), grid, blk, 0, (hipStream_t)stream, pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
+  else if (gs == 32) hipLaunchKernelGGL((k_oc_pack_codes<32>), grid, blk, 0, (hipStream_t)stream, pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
+  else hipLaunchKernelGGL((k_oc_pack_codes<64>), grid, blk, 0, (hipStream_t)stream, pos_h, neg_h, neg_t, n_pos, neg_per_pos, codes);
   return check_launch("k_oc_pack_codes");
 }
 

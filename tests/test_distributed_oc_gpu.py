@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 N_ENT, N_REL, DIM, B, NEG, SEED = 3000, 20, 75, 300, 8, 11
 
 
-def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
+def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, zipf=0.0):
     from multike_amd.sampling import KGSide, RelationBatcher
     from multike_amd.synthetic import SyntheticKGs
-    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED, zipf=zipf)
     rng = np.random.default_rng(SEED)
     e = mo.xavier_truncated_normal((n_ent, dim), rng).astype(np.float32).astype(np.float64)
     r = mo.xavier_truncated_normal((N_REL, dim), rng).astype(np.float32).astype(np.float64)
@@ -48,14 +48,17 @@ def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B):
     return e, r, losses, bat.steps
 
 
-def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, peer=False):
+def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, peer=False, zipf=0.0, hot_min=None):
     from multike_amd.distributed_oc import OwnerComputesTrainer
     from multike_amd.synthetic import SyntheticKGs
-    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED)
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED, zipf=zipf)
     rng = np.random.default_rng(SEED)
     ent0 = mo.xavier_truncated_normal((n_ent, dim), rng)
     rel0 = mo.xavier_truncated_normal((N_REL, dim), rng)
-    return OwnerComputesTrainer(kgs, ent0, rel0, b, neg, rank, world, seed=SEED, lr=0.02, comm=comm, chunks=chunks,
+    cls = OwnerComputesTrainer
+    if hot_min is not None:             # the hub-row threshold of the shard (references per global step)
+        cls = type("T", (OwnerComputesTrainer,), {"HOT_MIN": float(hot_min)})
+    return cls(kgs, ent0, rel0, b, neg, rank, world, seed=SEED, lr=0.02, comm=comm, chunks=chunks,
                                 exclusive_rows=excl, peer_direct=peer)
 
 

@@ -54,7 +54,7 @@ timeout 300 python tools/hbm_map.py --n 120 > $o/r05_hbm_map_box2.log 2>&1
 for u in 1 2 3; do timeout 300 python bench.py --config c5 --steps 100 --windows 4 --no-cpu-baseline --no-variants > $o/r05_bench_c5_placed_$u.json.log 2>/dev/null; done
 fi
 if [ $part = all ] || [ $part = tests ]; then
-( echo "python -m pytest tests -q -m gpu   (final tree of round 5, fresh MI355X box)"; timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4 ) > $o/r05_pytest_gpu.log 2>&1
+( echo "python -m pytest tests -q -m gpu   (final tree of round 5, fresh MI355X box)"; timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 ) > $o/r05_pytest_gpu.log 2>&1
 ( echo "round-5 record sweeps on the final tree: python tools/fuzz_step.py 3000 5; python tools/fuzz_aux.py 1500 5; python tools/fuzz_model.py 60 5; python tools/fuzz_oc.py 60 5; python tools/fuzz_sharded.py 10 5"
   timeout 900 python tools/fuzz_step.py 3000 5 2>&1 | tail -3
   timeout 900 python tools/fuzz_aux.py 1500 5 2>&1 | tail -6

@@ -1,5 +1,6 @@
 """Randomised sweep of the owner-computes sharded trainer against the float64 dense oracle: random world sizes (1..5 ranks
-sharing the one GPU, collectives staged through gloo or peer-direct), entity counts that do not divide by the world size, row
+sharing the one GPU, collectives staged through gloo or peer-direct), entity counts that do not divide by the world size (from 60:
+re-draw rounds then make a fifth of the positives need BOTH vectors), Zipf head / tail entities with a low hub-row threshold, row
 widths, negatives per positive (0..64), chunk counts, exclusive-row path on / off.  python tools/fuzz_oc.py [cases] [seed]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,12 +40,15 @@ if __name__ == "__main__":
     only = {int(x) for x in os.environ.get("MKE_FUZZ_ONLY", "").split(",") if x}   # rerun these cases of the same draw sequence
     for c in range(cases):
         world = int(rng.choice([1, 2, 2, 3, 4, 5]))
-        kw = dict(n_ent=int(rng.integers(400, 5000)), dim=int(rng.choice([7, 16, 20, 33, 75, 100, 128, 200, 256, 300])),
+        kw = dict(n_ent=int(rng.choice([int(rng.integers(60, 400)), int(rng.integers(400, 5000))])), dim=int(rng.choice([7, 16, 20, 33, 75, 100, 128, 200, 256, 300])),
                   neg=int(rng.choice([0, 1, 3, 8, 25, 33, 64])), b=int(rng.integers(20, 400)), chunks=int(rng.integers(1, 4)),
                   excl=bool(rng.random() < 0.7), peer=bool(world > 1 and rng.random() < 0.3))
         if kw["dim"] >= 200:
             kw["n_ent"] = min(kw["n_ent"], 1500)
-        ref_kw = dict(n_ent=kw["n_ent"], dim=kw["dim"], neg=kw["neg"], b=kw["b"])
+        kw["neg"] = min(kw["neg"], kw["n_ent"] // 2 - 6)          # a KG's candidate population must hold the sample
+        kw["zipf"] = float(rng.choice([0.0, 0.0, 1.0, 1.3]))
+        kw["hot_min"] = [None, 3.0][int(rng.integers(0, 2))] if kw["zipf"] else None
+        ref_kw = dict(n_ent=kw["n_ent"], dim=kw["dim"], neg=kw["neg"], b=kw["b"], zipf=kw["zipf"])
         _, _, _, spe = T._reference(world, 1, **ref_kw)
         steps = int(min(spe, rng.integers(1, 7)))
         desc = f"world={world} steps={steps} {kw}"
