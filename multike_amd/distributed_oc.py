@@ -551,8 +551,8 @@ class OwnerComputesTrainer:
             self.ref_count = o.ref_count if exclusive_rows else None
         else:
             place = dtype == torch.float32          # big float32 shards: on the fastest of a few candidate allocations (tables.placed_rows)
-            mk = (lambda fill: placed_rows(max(1, self.n_local), st, dev, fill, PLACEMENT_LOG)) if place else \
-                (lambda fill: torch.full((max(1, self.n_local), st), fill, dtype=dtype, device=dev))
+            mk = (lambda fill, with_=(): placed_rows(max(1, self.n_local), st, dev, fill, PLACEMENT_LOG, with_)) if place else \
+                (lambda fill, with_=(): torch.full((max(1, self.n_local), st), fill, dtype=dtype, device=dev))
             self.ent = mk(0.0)
             self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
             self.ent_grad = None                    # allocated by _declare_hot_rows (with the hub rows' copies behind the shard's rows)
@@ -567,7 +567,7 @@ class OwnerComputesTrainer:
         if ent_table is not None:
             self.ent_acc, self.rel_acc = ent_table.slot(opt_name), rel_table.slot(opt_name)
         else:
-            self.ent_acc = placed_rows(self.ent.shape[0], st, dev, ADAGRAD_INIT_ACC, PLACEMENT_LOG) if self.ent.dtype == torch.float32 \
+            self.ent_acc = placed_rows(self.ent.shape[0], st, dev, ADAGRAD_INIT_ACC, PLACEMENT_LOG, [self.ent]) if self.ent.dtype == torch.float32 \
                 else torch.full_like(self.ent, ADAGRAD_INIT_ACC)           # per-optimizer slots (code/MultiKE_model.py:17)
             self.rel_acc = torch.full_like(self.rel, ADAGRAD_INIT_ACC)
         # --- global epoch order (identical on every rank: same seed) ----------------------------------
@@ -634,7 +634,7 @@ class OwnerComputesTrainer:
                 slot[(hot // G)] = torch.arange(hot.numel(), dtype=torch.int32, device=self.device)
                 self.hot_slot, self.n_hot = slot, int(hot.numel())
         rows = self.ent_grad_rows + self.HOT_COPIES * self.n_hot
-        full = self._mk_rows(0.0) if rows == self.ent.shape[0] else torch.zeros(rows, self.stride, dtype=self.ent.dtype, device=self.device)
+        full = self._mk_rows(0.0, [self.ent, self.ent_acc]) if rows == self.ent.shape[0] else torch.zeros(rows, self.stride, dtype=self.ent.dtype, device=self.device)
         self.ent_grad_full, self.ent_grad = full, full[:self.ent.shape[0]]
 
     def _dtype_is_f32(self):

@@ -26,12 +26,14 @@ ADAGRAD_INIT_ACC = 0.1  # tf.train.AdagradOptimizer default initial_accumulator_
 # relation step at the 2M x 256 shape runs 295-323 us on arrays of the fast class and 367-369 us on arrays of the slow class
 # (tools/c5_probe.py): the "lottery" of +-12 % between runs that rounds 3-4 could only describe.  No virtual-address choice
 # controls it, so arrays of >= MKE_PLACE_MIN_MB (default 1024) are placed by trial: candidates are allocated (all kept alive,
-# so that they are different physical pages), each is timed with the probe (mke_probe_rows, 2M random rows, ~0.3 ms), the fastest is kept and
-# the rest returned to the driver.  MKE_PLACE=0 turns it off.
+# so that they are different physical pages), each is timed with the probe (mke_probe_rows, 2M random rows, 0.3-1 ms) TOGETHER
+# with the table's arrays that exist already, the fastest is kept and the rest returned to the driver.  MKE_PLACE=0 turns it off.
 _PLACE_IDX = {}
 
 
-def _probe_us(arr: torch.Tensor) -> float:
+def _probe_us(arr: torch.Tensor, companions=()) -> float:
+    """us per launch of mke_probe_rows: 2M random rows of `arr` — and of up to two companion arrays of the same shape, read
+    together the way the step reads a row of the table, its accumulator and its gradient."""
     import os
     n = arr.shape[0]
     key = (arr.device, n)
@@ -42,11 +44,13 @@ def _probe_us(arr: torch.Tensor) -> float:
         _PLACE_IDX[key] = (torch.randint(0, n, (k,), device=arr.device, generator=g, dtype=torch.int32),
                            torch.empty(k, dtype=torch.float32, device=arr.device))
     idx, out = _PLACE_IDX[key]
+    comp = [c for c in companions if c is not None and c.dim() == 2 and c.shape[1] == arr.shape[1] and c.shape[0] >= n][:2]
+    comp += [None] * (2 - len(comp))
     best = float("inf")
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.probe_rows(arr, None, None, idx, out)
+        _lib.probe_rows(arr, comp[0], comp[1], idx, out)
         e1.record()
         e1.synchronize()
         if rep:
@@ -54,10 +58,12 @@ def _probe_us(arr: torch.Tensor) -> float:
     return best
 
 
-def placed_rows(n_rows: int, stride: int, device, fill: float = 0.0, report: list | None = None) -> torch.Tensor:
-    """A float32 [n_rows][stride] array filled with `fill`; big ones (see above) on the fastest of up to MKE_PLACE_TRIES
-    (default 10) candidate allocations.  The search stops as soon as a candidate is clearly (4 %) faster than another one seen
-    — the two classes are 9 % apart and each is +-1.5 % wide — or when the tries / a quarter of the free memory are used up."""
+def placed_rows(n_rows: int, stride: int, device, fill: float = 0.0, report: list | None = None, companions=()) -> torch.Tensor:
+    """A float32 [n_rows][stride] array filled with `fill`; big ones (see above) on the fastest of MKE_PLACE_TRIES (default 8)
+    candidate allocations, all alive while they are compared.  companions: the arrays of the same table that exist already (the
+    table for its accumulator, both for the gradient scratch): the candidates are probed TOGETHER with them — single arrays of
+    the fast class still made steps 12 % apart (tools/c5_probe.py: the combination has a term of its own, and the probe of
+    the three arrays read together ranks the triples as the step does)."""
     import os
     device = torch.device(device)
     nbytes = n_rows * stride * 4
@@ -66,18 +72,16 @@ def placed_rows(n_rows: int, stride: int, device, fill: float = 0.0, report: lis
     if not big:
         return torch.full((n_rows, stride), fill, dtype=torch.float32, device=device) if fill else \
             torch.zeros(n_rows, stride, dtype=torch.float32, device=device)
-    tries = int(os.environ.get("MKE_PLACE_TRIES", 10))
+    tries = int(os.environ.get("MKE_PLACE_TRIES", 8))
     budget = torch.cuda.mem_get_info(device)[0] // 4
     cands, times = [], []
     while len(cands) < tries and (len(cands) + 1) * nbytes <= budget:
         c = torch.empty(n_rows, stride, dtype=torch.float32, device=device)
         cands.append(c)
-        times.append(_probe_us(c))
-        if min(times) < 0.96 * max(times) and times[-1] <= 1.02 * min(times):
-            break
+        times.append(_probe_us(c, companions))
     k = int(np.argmin(times)) if times else -1
     if report is not None:
-        report.append({"bytes": nbytes, "probe_us": [round(t, 1) for t in times], "kept": k})
+        report.append({"bytes": nbytes, "read_with": len([c for c in companions if c is not None]), "probe_us": [round(t, 1) for t in times], "kept": k})
     if k < 0:
         return torch.full((n_rows, stride), fill, dtype=torch.float32, device=device)
     keep = cands[k]
@@ -129,7 +133,8 @@ class EmbeddingTable:
         """[n_rows][stride] zero-invariant gradient scratch ([copies][n_rows][stride] when privatised as a whole)."""
         if self._grad is None:
             if self.grad_copies == 1:
-                self._grad_full = placed_rows(self.n_rows + self.hot_copies * self.n_hot, self.stride, self.device, 0.0, PLACEMENT_LOG)
+                self._grad_full = placed_rows(self.n_rows + self.hot_copies * self.n_hot, self.stride, self.device, 0.0, PLACEMENT_LOG,
+                                              [self.data] + [v for v in self.slots.values() if torch.is_tensor(v)][:1])
                 self._grad = self._grad_full[:self.n_rows]       # same storage: the hub rows' copies sit behind it
             else:
                 self._grad = self._grad_full = torch.zeros((self.grad_copies,) + tuple(self.data.shape), dtype=torch.float32, device=self.device)
@@ -170,7 +175,7 @@ class EmbeddingTable:
         """Adagrad accumulator of one optimizer (created on first use, filled with 0.1)."""
         s = self.slots.get(optimizer_name)
         if s is None:
-            s = placed_rows(self.n_rows, self.stride, self.device, ADAGRAD_INIT_ACC, PLACEMENT_LOG)
+            s = placed_rows(self.n_rows, self.stride, self.device, ADAGRAD_INIT_ACC, PLACEMENT_LOG, [self.data, self._grad_full if self._grad is not None else None])
             self.slots[optimizer_name] = s
         return s
 
