@@ -299,7 +299,8 @@ def attribute_step_variant(args):
     d, B = args.dim, args.batch
     n_ent, n_attr, n_lit = args.n_ent, 600, 100_000
     E = EmbeddingTable(n_ent, d, "av_ent_embeds", seed=1)
-    A = EmbeddingTable(n_attr, d, "attr_embeds", normalize=False, seed=2)
+    from multike_amd.MultiKE_model import ATTR_GRAD_COPIES
+    A = EmbeddingTable(n_attr, d, "attr_embeds", normalize=False, seed=2, grad_copies=ATTR_GRAD_COPIES)   # as the model builds it
     lit = torch.nn.functional.normalize(torch.randn(n_lit, d, generator=torch.Generator().manual_seed(0)), dim=1).numpy()
     L = EmbeddingTable(n_lit, d, "literal_embeds", normalize=False, trainable=False, values=lit)
     cnn, eng = AttrCNN(d, seed=3), StepEngine()

@@ -609,6 +609,9 @@ typedef struct mke_attr_step_args {
   float* scratch; double* partials;
   int optimizer; float lr; int32_t tag; int update;
   float* workspace;   /* nullable: MKE_CNN_WORKSPACE_FLOATS(dim) floats, zero before first use, left zero (see mke_attr_conv_bwd) */
+  int attr_grad_copies;   /* version 104: 0 / 1 = attr_grad is [n_attr][attr_stride]; c > 1 = [c][n_attr][attr_stride], all zero between steps:
+                             triple t adds to copy t % c and the update sums them (a few hundred attribute rows take a step's 5,000
+                             triples, and real attribute frequencies are heavy-tailed: same-address atomics serialise) */
 } mke_attr_step_args;
 int64_t mke_attr_scratch_floats(int64_t n, int dim);
 int mke_attr_step(const mke_attr_step_args* args, void* stream);

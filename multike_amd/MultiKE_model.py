@@ -29,6 +29,7 @@ from .tables import ADAGRAD_INIT_ACC, EmbeddingTable, StepEngine
 from .utils import generate_out_folder, save_embeddings, touch_library_kernels
 
 _HIP_OPTS = ("Adagrad", "SGD")            # touched-rows rules: fused / native multi-step paths
+ATTR_GRAD_COPIES = 4
 _DENSE_OPTS = tuple(_lib.DENSE_OPTS)        # Adam, Adadelta: whole-variable kernels, step-wise loops
 
 
@@ -214,7 +215,12 @@ class MultiKE:
         self.rel_embeds = EmbeddingTable(self.kgs.relations_num, d, "rel_embeds", True, device=dev, seed=seed + 2)
         self.av_ent_embeds = EmbeddingTable(self.kgs.entities_num, d, "av_ent_embeds", True, device=dev, seed=seed + 3)
         # "False important!" (code/MultiKE_model.py:96-97): attribute embeddings are NOT read through l2_normalize
-        self.attr_embeds = EmbeddingTable(self.kgs.attributes_num, d, "attr_embeds", False, device=dev, seed=seed + 4)
+        # A few hundred attribute rows take every step's 5,000 triples and real attribute frequencies are heavy-tailed: the gradient
+        # scratch of this table is privatised 4 ways (triple t adds to copy t % 4, the update sums them): with Zipf(1.0) attribute
+        # ids the step went 52.8 -> 76.5 us without and stays at the uniform figure with them (EXPERIMENTS R5.16).  The dense
+        # optimizers' step-wise path reads the scratch as one [rows][stride] array: one copy there.
+        copies = 1 if self.args.optimizer in _DENSE_OPTS else ATTR_GRAD_COPIES
+        self.attr_embeds = EmbeddingTable(self.kgs.attributes_num, d, "attr_embeds", False, device=dev, seed=seed + 4, grad_copies=copies)
         self.ent_embeds = EmbeddingTable(self.kgs.entities_num, d, "ent_embeds", True, device=dev, seed=seed + 5)
         g = torch.Generator(device="cpu")
         g.manual_seed(seed + 6)

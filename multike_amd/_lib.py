@@ -50,7 +50,7 @@ class AttrStepArgs(C.Structure):
         ("ih", C.c_void_p), ("ia", C.c_void_p), ("iv", C.c_void_p), ("weights", C.c_void_p), ("n", C.c_int64),
         ("scale", C.c_float), ("params", C.c_void_p), ("param_grads", C.c_void_p), ("param_acc", C.c_void_p),
         ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
-        ("update", C.c_int), ("workspace", C.c_void_p),
+        ("update", C.c_int), ("workspace", C.c_void_p), ("attr_grad_copies", C.c_int),
     ]
 
 

@@ -100,6 +100,7 @@ class AttrCNN:
         a.attr_normalize = int(attr.normalize)
         a.attr_acc = _lib.ptr(attr.slot(opt_name), f32, "acc") if (adagrad and attr.trainable and update) else None
         a.attr_grad = _lib.ptr(attr.grad, f32, "grad") if attr.trainable else None
+        a.attr_grad_copies = attr.grad_copies          # a wholly privatised scratch ([copies][rows][stride]): hub attributes
         a.attr_touched = _lib.ptr(attr.touched, i32, "touched") if attr.trainable else None
         a.lit_table, a.lit_stride, a.dim = _lib.ptr(lit.data, f32, "lit"), lit.stride, d
         a.ih, a.ia, a.iv = _lib.ptr(ih, i32, "ih"), _lib.ptr(ia, i32, "ia"), _lib.ptr(iv, i32, "iv")

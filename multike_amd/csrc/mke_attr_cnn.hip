@@ -74,6 +74,8 @@ struct ConvParams {
   const float* __restrict__ dflat;   // bwd in  [n][4d]
   float* __restrict__ gparams;       // bwd out, same packing, atomically accumulated
   float* __restrict__ gattr;         // bwd out: attribute-table gradient scratch (nullable)
+  int gattr_copies;                  // >= 1: the scratch is [copies][n_attr][attr_stride], triple t adds to copy t % copies (a few hundred
+  int64_t gattr_copy_elems;          // attribute rows take 5,000 triples per step and their frequencies are heavy-tailed)
   int32_t* __restrict__ tattr;
   int32_t tag;
   float* __restrict__ ws;            // bwd: MKE_CNN_WORKSPACE_FLOATS(dim) zero-invariant floats (nullable)
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(NW * 64, DFL ? 2 : 1) void k_attr_conv(const ConvPa
         }
         a_gam[i] += (dx[0] * raw[0][i] + dx[1] * raw[1][i]) * bn_s;
         a_bet[i] += dx[0] + dx[1];
-        if (live && w < d && p.gattr) atomic_add_f32(p.gattr + (int64_t)ra * p.attr_stride + w, dx[0] * gam[i] * bn_s);
+        if (live && w < d && p.gattr) atomic_add_f32(p.gattr + (t % p.gattr_copies) * p.gattr_copy_elems + (int64_t)ra * p.attr_stride + w, dx[0] * gam[i] * bn_s);
       }
       if (live && tl == 0 && p.gattr) p.tattr[ra] = p.tag;
       wave_lds_sync();
@@ -952,7 +954,7 @@ extern "C" int mke_attr_conv_bwd(const float* attr_table, int attr_stride, int a
   ConvParams p{};
   p.attr = attr_table; p.attr_stride = attr_stride; p.attr_norm = attr_normalize; p.lit = lit_table; p.lit_stride = lit_stride;
   p.dim = dim; p.ia = ia; p.iv = iv; p.n = n; p.params = params; p.dflat = dflat; p.gparams = grad_params;
-  p.gattr = grad_attr; p.tattr = touched_attr; p.tag = tag; p.ws = workspace;
+  p.gattr = grad_attr; p.gattr_copies = 1; p.gattr_copy_elems = 0; p.tattr = touched_attr; p.tag = tag; p.ws = workspace;
   int rc = conv_dispatch(p, true, (hipStream_t)stream);
   if (rc || !workspace) return rc;
   return ws_fold(workspace, grad_params, dim, (hipStream_t)stream);
@@ -1144,6 +1146,7 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   p.attr = a->attr_table; p.attr_stride = a->attr_stride; p.attr_norm = a->attr_normalize; p.lit = a->lit_table;
   p.lit_stride = a->lit_stride; p.dim = d; p.ia = a->ia; p.iv = a->iv; p.n = n; p.params = a->params; p.dflat = dflat;
   p.gparams = a->param_grads; p.gattr = a->attr_grad; p.tattr = a->attr_touched; p.tag = a->tag; p.ws = a->workspace;
+  p.gattr_copies = a->attr_grad_copies > 1 ? a->attr_grad_copies : 1; p.gattr_copy_elems = a->n_attr * (int64_t)a->attr_stride;
   if (fused) {
     p.dz = gout /* g */; p.zmat = z; p.ssq = ssq; p.dotp = dot; p.W = dflat /* W^T [dim][4 dim] */; p.conv_blocks = (int)((n + 15) / 16);
     GemmParams& t = p.tall;
@@ -1172,7 +1175,8 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
     mke_update_table tabs[2];
     int nt = 0;
     if (a->ent_grad) tabs[nt++] = mke_update_table{a->ent_table, a->ent_acc, a->ent_grad, a->ent_touched, a->n_ent, a->ent_normalize, 1, nullptr};
-    if (a->attr_grad) tabs[nt++] = mke_update_table{a->attr_table, a->attr_acc, a->attr_grad, a->attr_touched, a->n_attr, a->attr_normalize, 1, nullptr};
+    if (a->attr_grad) tabs[nt++] = mke_update_table{a->attr_table, a->attr_acc, a->attr_grad, a->attr_touched, a->n_attr, a->attr_normalize,
+                                                    a->attr_grad_copies > 1 ? a->attr_grad_copies : 1, nullptr};
     DenseJob dj{a->params, a->param_acc, a->param_grads, (int64_t)MKE_CNN_PARAMS(d), a->optimizer, a->lr, a->workspace,
                 MKE_CNN_CONV_PARAMS(d), CNN_WS_STRIDE(d), CNN_WS_COPIES};
     UpdateTouchedHint hint(a->n);   // at most one head row per triple

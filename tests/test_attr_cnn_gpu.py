@@ -199,3 +199,37 @@ def test_backward_phase_alone_does_not_trust_a_stale_transposed_weight(tail_opt,
     for k in ao.PARAM_NAMES:
         np.testing.assert_allclose(two[k], one[k], rtol=2e-3, atol=2e-5 * max(1.0, np.abs(one[k]).max()), err_msg=k)
     np.testing.assert_allclose(two_attr, one_attr, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [75, 32, 130])
+def test_privatised_attribute_scratch_is_the_same_function(d):
+    """The model builds `attr_embeds` with its gradient scratch privatised (triple t adds to copy t % copies; heavy-tailed
+    attribute ids pile thousands of same-address atomics on a row otherwise).  Three steps with Zipf-like attribute ids: the same
+    tables, parameters and losses as with one copy; every copy back at zero."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    rng = np.random.default_rng(d)
+    n_ent, n_attr, n_lit, B = 3000, 40, 500, 1200
+    e0, a0 = rng.standard_normal((n_ent, d)).astype(np.float32), rng.standard_normal((n_attr, d)).astype(np.float32) * 0.3
+    l0 = rng.standard_normal((n_lit, d)).astype(np.float32)
+    pr = np.arange(1, n_attr + 1) ** -1.5
+    batches = [(rng.integers(0, n_ent, B), rng.choice(n_attr, B, p=pr / pr.sum()), rng.integers(0, n_lit, B), rng.random(B).astype(np.float32))
+               for _ in range(3)]
+    out = []
+    for copies in (1, 16):
+        E = EmbeddingTable(n_ent, d, "e", values=e0)
+        A = EmbeddingTable(n_attr, d, "a", normalize=False, values=a0, grad_copies=copies)
+        L = EmbeddingTable(n_lit, d, "l", normalize=False, trainable=False, values=l0)
+        cnn, eng = AttrCNN(d, seed=5), StepEngine()
+        losses = []
+        for h, a, v, w in batches:
+            t = lambda x, dt=torch.int32: torch.as_tensor(x, device="cuda").to(dt)
+            losses.append(float(cnn.step(eng, E, A, L, t(h), t(a), t(v), t(w, torch.float32), lr=0.01).sum()))
+        torch.cuda.synchronize()
+        assert float(A.grad.abs().max()) == 0.0
+        out.append((losses, E.raw().cpu().numpy(), A.raw().cpu().numpy(), {k: v.cpu().numpy().copy() for k, v in cnn.views.items()} if hasattr(cnn, "views") else {}))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=1e-3, atol=2e-6)
+    for k in out[0][3]:
+        np.testing.assert_allclose(out[1][3][k], out[0][3][k], rtol=1e-3, atol=2e-6, err_msg=k)

@@ -10,13 +10,19 @@ for kv in filter(None, os.environ.get("MKE_SET", "").split(",")):      # MKE_SET
     _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 d, B = (int(sys.argv[3]) if len(sys.argv) > 3 else 75), (int(sys.argv[2]) if len(sys.argv) > 2 else 5000)
-E = EmbeddingTable(200_000, d, "av", seed=1); A = EmbeddingTable(600, d, "attr", normalize=False, seed=2)
+E = EmbeddingTable(200_000, d, "av", seed=1); A = EmbeddingTable(600, d, "attr", normalize=False, seed=2, grad_copies=int(os.environ.get("ATTR_COPIES", "4")))
 lit = np.random.default_rng(0).standard_normal((100_000, d)).astype(np.float32); lit /= np.linalg.norm(lit, axis=1, keepdims=True)
 L = EmbeddingTable(100_000, d, "lit", normalize=False, trainable=False, values=lit)
 cnn = AttrCNN(d, seed=3); eng = StepEngine()
 g = torch.Generator(device="cuda"); g.manual_seed(0)
+ZIPF = float(os.environ.get("ATTR_ZIPF", "0"))       # attribute ids ~ rank^-ZIPF (real attribute frequencies are heavy-tailed: a label-like attribute is in a large share of the triples)
 def batch():
-    return (torch.randint(0, 200_000, (B,), device="cuda", generator=g, dtype=torch.int32), torch.randint(0, 600, (B,), device="cuda", generator=g, dtype=torch.int32),
+    if ZIPF > 0:
+        pr = torch.arange(1, 601, device="cuda", dtype=torch.float64) ** (-ZIPF)
+        ia = torch.multinomial((pr / pr.sum()).float(), B, replacement=True, generator=g).to(torch.int32)
+    else:
+        ia = torch.randint(0, 600, (B,), device="cuda", generator=g, dtype=torch.int32)
+    return (torch.randint(0, 200_000, (B,), device="cuda", generator=g, dtype=torch.int32), ia,
             torch.randint(0, 100_000, (B,), device="cuda", generator=g, dtype=torch.int32), torch.rand(B, device="cuda", generator=g))
 bs = [batch() for _ in range(8)]
 for i in range(10): cnn.step(eng, E, A, L, *bs[i % 8])
