@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-variants", action="store_true", help="skip the reference-default-shape side lines (N=10, truncated)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of each cpu_baseline leg")
     ap.add_argument("--sample-chunk", type=int, default=0, help="steps sampled per sampler launch (0 = whole epoch)")
-    ap.add_argument("--rel-grad-copies", type=int, default=1, help="privatised copies of the relation gradient scratch")
+    ap.add_argument("--rel-grad-copies", type=int, default=8, help="privatised copies of the relation gradient scratch (the model's default: MultiKE_model.REL_GRAD_COPIES)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded multi-GPU path even at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-epochs", type=int, default=1,
@@ -77,6 +77,7 @@ def parse():
                          "first window is reported beside it).  Default: as many as make the timed work >= 60 ms, at least 50 "
                          "for windows of <= 100 steps, 5 otherwise")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the head / tail entities of the synthetic triples (0 = uniform)")
+    ap.add_argument("--rel-zipf", type=float, default=0.0, help="Zipf exponent of the relation ids of the synthetic triples (0 = uniform)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     for k in ("n_ent", "n_rel", "dim", "neg", "batch"):
@@ -500,7 +501,7 @@ class FusedWorkload:
     """The single-GPU form of the step on one synthetic shape: tables, batcher, native runner, and the two measurements —
     the timed region (native step loop, no Python between steps) and the instrumented pass (HIP events per launch)."""
 
-    def __init__(self, cfg, sample_chunk=None, rel_grad_copies=1, device_init=False, zipf=0.0):
+    def __init__(self, cfg, sample_chunk=None, rel_grad_copies=8, device_init=False, zipf=0.0, rel_zipf=0.0):
         from multike_amd.runner import RelationViewRunner
         from multike_amd.sampling import KGSide, KnownTripleSet, RelationBatcher
         from multike_amd.synthetic import SyntheticKGs
@@ -509,7 +510,7 @@ class FusedWorkload:
         self.cfg = cfg
         d, N, B = cfg["dim"], cfg["neg"], cfg["batch"]
         self.d, self.N, self.B = d, N, B
-        self.kgs = kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234, zipf=zipf)
+        self.kgs = kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234, zipf=zipf, rel_zipf=rel_zipf)
         if device_init:      # side lines of big shapes: the same distribution drawn on the device (9 s on the host at 2M x 256)
             g = torch.Generator(device="cuda"); g.manual_seed(1234)
             def init(n):
@@ -753,7 +754,7 @@ def main():
             for i in range(i0, i1):
                 run_step(i)
     else:
-        fused = FusedWorkload(cfg, sample_chunk=args.sample_chunk, rel_grad_copies=args.rel_grad_copies, zipf=args.zipf)
+        fused = FusedWorkload(cfg, sample_chunk=args.sample_chunk, rel_grad_copies=args.rel_grad_copies, zipf=args.zipf, rel_zipf=args.rel_zipf)
         kgs, ent0, rel0 = fused.kgs, fused.ent0, fused.rel0
         n_steps_epoch = fused.n_steps_epoch
         run_steps, triples_of = fused.run_steps, fused.triples_of
@@ -827,11 +828,11 @@ def main():
         base = args_end
         n_inst = max(min(args.steps, 300), 100)      # >= 100 launches whatever --steps is (the driver passes 20)
         # PMC bytes per launch of this kernel (separate rocprofv3 --pmc passes), or None
-        roofline = fused.instrumented(base, n_inst, pmc_traffic(args.config, getattr(args, "custom", False) or bool(args.zipf)), dt / args.steps * 1e6)
+        roofline = fused.instrumented(base, n_inst, pmc_traffic(args.config, getattr(args, "custom", False) or bool(args.zipf) or bool(args.rel_zipf)), dt / args.steps * 1e6)
         roofline["launch_histogram"] = fused.last_hist
 
     variants = None
-    if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False) and not args.zipf:
+    if not sharded and not args.no_variants and args.config == "c2" and not getattr(args, "custom", False) and not args.zipf and not args.rel_zipf:
         variants = reference_default_variants(args, kgs, ent0, rel0, fused.sides)
         del fused
         torch.cuda.empty_cache()
@@ -895,7 +896,7 @@ def main():
             "window_ms": window_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not staged else "synthetic; DRY RUN: ranks share GPUs, collectives staged through the host (not a result)",
-            "config": {"workload": f"relation-view train step, {args.label}{f' Zipf({args.zipf:g})' if args.zipf else ''} |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} "
+            "config": {"workload": f"relation-view train step, {args.label}{f' Zipf({args.zipf:g})' if args.zipf else ''}{f' relation-Zipf({args.rel_zipf:g})' if args.rel_zipf else ''} |E|={args.n_ent} |R|={args.n_rel} dim={d} neg={N} "
                                    f"batch={B}" + (f"/GPU, rows sharded id%{world}" if sharded else ""),
                        "step": "on-device negative sampling + fused gather/score/loss/gradient + Jacobian/Adagrad row update",
                        "n_ent": args.n_ent, "n_rel": args.n_rel, "dim": d, "neg": N, "batch": B,

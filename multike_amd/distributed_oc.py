@@ -97,7 +97,8 @@ class OcHipBackend:
         s.ent_grad, s.ent_touched = _lib.ptr(tr.ent_grad, f32, "grad"), _lib.ptr(tr.ent_touched, i32, "touched")
         s.ref_count = _lib.ptr(tr.ref_count, i32, "ref_count") if tr.ref_count is not None else None
         s.n_local = tr.n_local
-        s.rel, s.rel_grad, s.rel_grad_copies = _lib.ptr(tr.rel, f32, "rel"), _lib.ptr(tr.rel_grad, f32, "rel_grad"), 1
+        s.rel, s.rel_grad = _lib.ptr(tr.rel, f32, "rel"), _lib.ptr(tr.rel_grad, f32, "rel_grad")
+        s.rel_grad_copies = 1 if tr.rel_grad.dim() == 2 else tr.rel_grad.shape[0]     # privatised relation gradient (all-reduced whole)
         s.rel_acc = _lib.ptr(tr.rel_acc, f32, "rel_acc")
         s.rel_touched, s.n_rel = _lib.ptr(tr.rel_touched, i32, "rel_touched"), tr.rel.shape[0]
         s.stride, s.dim, s.rank, s.n_ranks = tr.stride, tr.dim, tr.rank, tr.world
@@ -474,6 +475,7 @@ class OwnerComputesTrainer:
     # HOT_COPIES private copies of their gradient row for mke_oc_apply and the positives' own terms (the fused runner's rule,
     # multike_amd/runner.py; measured as rank 0 of 8 on Zipf(1.0) triples: EXPERIMENTS R5.12)
     HOT_MIN, HOT_MAX, HOT_COPIES = 20.0, 1024, 8
+    REL_COPIES = 4
     SAMPLE_RUN = 1 << 26          # ids per column of the epoch sampler's scratch (the plan samples its share in runs of SAMPLE_RUN / N positions)
 
     def __init__(self, kgs, ent0: np.ndarray, rel0: np.ndarray, batch_size: int, neg_per_pos: int, rank: int, world: int,
@@ -562,7 +564,14 @@ class OwnerComputesTrainer:
             # --- replicated relation state ----------------------------------------------------------
             self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
             self.rel[:, :self.dim] = torch.as_tensor(rel0, dtype=dtype, device=dev)
-            self.rel_grad = torch.zeros_like(self.rel)
+            # relation gradient: mke_oc_apply adds one vector per owned slot to the relation's row, and relation frequencies are
+            # heavy-tailed (relation ids ~ Zipf(1.0): apply 7.7 -> 23.2 us as rank 0 of 8, Zipf(1.5): 68 us).  Privatised REL_COPIES
+            # ways (slot k adds to copy k % copies; the all-reduce carries the copies, the update sums them) while that stays
+            # under 1 MB on the wire — beyond (2K relations x 256 floats) one copy: the all-reduce would cost more than it saves
+            copies = 1
+            if self.backend.device_type == "cuda" and dtype == torch.float32:
+                copies = max(1, min(self.REL_COPIES, (1 << 20) // max(1, self.rel.numel() * 4)))
+            self.rel_grad = torch.zeros_like(self.rel) if copies == 1 else torch.zeros((copies,) + tuple(self.rel.shape), dtype=dtype, device=dev)
             self.rel_touched = torch.zeros(rel0.shape[0], **i32)
         if ent_table is not None:
             self.ent_acc, self.rel_acc = ent_table.slot(opt_name), rel_table.slot(opt_name)

@@ -11,11 +11,12 @@ import numpy as np
 
 
 class SyntheticKGs:
-    def __init__(self, n_ent=200_000, n_rel=550, triples_per_entity=4.6, seed=1234, kg1_share=0.5055, zipf=0.0):
+    def __init__(self, n_ent=200_000, n_rel=550, triples_per_entity=4.6, seed=1234, kg1_share=0.5055, zipf=0.0, rel_zipf=0.0):
         """zipf > 0: head/tail entities drawn with probability ~ rank^-zipf inside each KG (hub entities), the
         contention variant of SURVEY.md §8d; 0 = uniform."""
         rng = np.random.default_rng(seed)
         self.zipf = float(zipf)
+        self.rel_zipf = float(rel_zipf)     # relation ids ~ rank^-rel_zipf inside each KG (real relation frequencies are heavy-tailed too)
         self.entities_num, self.relations_num = int(n_ent), int(n_rel)
         e1 = n_ent // 2
         r1 = max(1, int(round(n_rel * 0.6)))
@@ -25,11 +26,17 @@ class SyntheticKGs:
         counts = (int(total * kg1_share), total - int(total * kg1_share))
         self.triples = []
         for (elo, ehi), (rlo, rhi), n in zip(self.ent_range, self.rel_range, counts):
-            self.triples.append(self._uniform_unique(rng, elo, ehi, rlo, max(rhi, rlo + 1), n, self.zipf))
+            self.triples.append(self._uniform_unique(rng, elo, ehi, rlo, max(rhi, rlo + 1), n, self.zipf, self.rel_zipf))
 
     @staticmethod
-    def _uniform_unique(rng, elo, ehi, rlo, rhi, n, zipf=0.0):
+    def _uniform_unique(rng, elo, ehi, rlo, rhi, n, zipf=0.0, rel_zipf=0.0):
         got = np.zeros((0, 3), dtype=np.int32)
+        if rel_zipf > 0:
+            rp = np.arange(1, rhi - rlo + 1, dtype=np.float64) ** (-rel_zipf)
+            rcdf = np.cumsum(rp / rp.sum())
+            draw_r = lambda m: rlo + np.minimum(np.searchsorted(rcdf, rng.random(m)), rhi - rlo - 1)
+        else:
+            draw_r = lambda m: rng.integers(rlo, rhi, m)
         if zipf > 0:
             pr = np.arange(1, ehi - elo + 1, dtype=np.float64) ** (-zipf)
             cdf = np.cumsum(pr / pr.sum())
@@ -39,7 +46,7 @@ class SyntheticKGs:
             draw = lambda m: rng.integers(elo, ehi, m)
         while len(got) < n:
             m = int((n - len(got)) * 1.1) + 16
-            cand = np.stack([draw(m), rng.integers(rlo, rhi, m), draw(m)], 1)
+            cand = np.stack([draw(m), draw_r(m), draw(m)], 1)
             allt = np.concatenate([got, cand.astype(np.int32)], 0)
             key = (allt[:, 0].astype(np.int64) << 38) | (allt[:, 2].astype(np.int64) << 12) | allt[:, 1].astype(np.int64)
             _, first = np.unique(key, return_index=True)

@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--latency-us", type=float, default=0.0, help="modelled launch latency per collective call")
     ap.add_argument("--prefetch", action="store_true", help="the next epoch's plan on the side stream while the steps run (the product's default)")
     ap.add_argument("--zipf", type=float, default=0.0, help="head / tail entities of the synthetic triples ~ rank^-zipf (hub rows)")
+    ap.add_argument("--rel-zipf", type=float, default=0.0, help="relation ids of the synthetic triples ~ rank^-rel_zipf")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
     a = ap.parse_args()
     for kv in a.set:
@@ -121,7 +122,7 @@ def main():
         _lib.set_option(k, int(v))
     cfg = dict(n_ent=200_000, n_rel=550, dim=75, neg=25) if a.config == "c2" else dict(n_ent=2_000_000, n_rel=2000, dim=256, neg=64)
     G, B = a.world, 5000
-    kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234, zipf=a.zipf)
+    kgs = SyntheticKGs(n_ent=cfg["n_ent"], n_rel=cfg["n_rel"], seed=1234, zipf=a.zipf, rel_zipf=a.rel_zipf)
     g = torch.Generator(device="cpu"); g.manual_seed(1)
     ent0 = (torch.randn(cfg["n_ent"], cfg["dim"], generator=g) * float(np.sqrt(2.6 / (cfg["n_ent"] + cfg["dim"])))).numpy()
     rel0 = xavier_truncated_normal(cfg["n_rel"], cfg["dim"], "cpu", seed=2).numpy()
@@ -168,7 +169,7 @@ def main():
     phases = {}
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
-    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "options": a.set, "world": G, "rank": 0, "chunks": a.chunks, "global_batch": B * G,
+    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
            "capacity_vectors": tr.C,
            "phase_us": {k: float(np.mean(v)) for k, v in phases.items()},
