@@ -50,10 +50,14 @@ class ShardedITC:
         self.n_ent = n_ent = tables["ent"].shape[0]
         shard = lambda k, norm=True, train=True: EmbeddingTable(max(1, len(range(rank, n_ent, world))), d, k, normalize=norm,
                                                                 trainable=train, values=_pad1(tables[k][rank::world], d))
-        full = lambda k, norm, train=True: EmbeddingTable(tables[k].shape[0], d, k, normalize=norm, trainable=train, values=tables[k])
+        # the relation / attribute tables' gradient scratch is privatised as in the one-GPU model (heavy-tailed relation / attribute
+        # frequencies: EXPERIMENTS R5.16-17); it is all-reduced whole, so only while it stays under 1 MB on the wire
+        def full(k, norm, train=True, copies=1):
+            c = max(1, min(copies, (1 << 20) // max(1, tables[k].shape[0] * _lib.stride_for(d) * 4)))
+            return EmbeddingTable(tables[k].shape[0], d, k, normalize=norm, trainable=train, values=tables[k], grad_copies=c)
         self.rv_ent, self.av_ent, self.ent = shard("rv_ent"), shard("av_ent"), shard("ent")
         self.name = shard("name", norm=False, train=False)
-        self.rel, self.attr = full("rel", True), full("attr", False)
+        self.rel, self.attr = full("rel", True, copies=OwnerComputesTrainer.REL_COPIES), full("attr", False, copies=4)
         self.lit = full("lit", False, train=False)
         self.sizes = (int(batch_size), int(attribute_batch_size), int(entity_batch_size))
         # hub rows of the relation view's shard (performance only; before any trainer takes the table's gradient scratch):
