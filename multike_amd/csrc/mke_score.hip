@@ -111,6 +111,14 @@ __device__ __forceinline__ void emit_row(const ScoreParams& p, bool is_rel, floa
 }
 
 // One triple scored on its own: 3 gathers, loss, 3 scatters.  sign=+1 positive, -1 negative.
+// hub rows (mke_hot_rows): the scratch row that takes contribution `k` to entity row e (-1: the row itself)
+template <bool DET>
+__device__ __forceinline__ int hot_copy_row(const ScoreParams& p, int e, int64_t k) {
+  if (DET || !p.hot_slot) return -1;
+  const int s = p.hot_slot[e];
+  return s >= 0 ? p.hot_row0 + (int)(k % p.hot_copies) * p.n_hot + s : -1;
+}
+
 template <int FPL, bool DET = false>
 __device__ __forceinline__ float independent_triple(const ScoreParams& p, float* __restrict__ grel, int j, int h, int r,
                                                     int t, float w, float sign, int64_t slot0) {
@@ -134,9 +142,11 @@ __device__ __forceinline__ float independent_triple(const ScoreParams& p, float*
     const float c = 2.0f * sign * w * p.scale * sigmoid_f(z);
 #pragma unroll
     for (int k = 0; k < FPL; ++k) H[k] *= c;
-    emit_row<FPL, DET>(p, false, p.gent, p.tent, h, slot0, j, H, 1.0f);
+    // positives-only steps (the cross-KG loops) score every triple here: a hub entity's row takes its private copy (slot0 / 3 = the
+    // triple's index spreads the copies)
+    emit_row<FPL, DET>(p, false, p.gent, p.tent, h, slot0, j, H, 1.0f, hot_copy_row<DET>(p, h, slot0 / 3));
     emit_row<FPL, DET>(p, true, grel, p.trel, r, slot0 + 1, j, H, 1.0f);
-    emit_row<FPL, DET>(p, false, p.gent, p.tent, t, slot0 + 2, j, H, -1.0f);
+    emit_row<FPL, DET>(p, false, p.gent, p.tent, t, slot0 + 2, j, H, -1.0f, hot_copy_row<DET>(p, t, slot0 / 3));
   }
   return l;
 }

@@ -244,6 +244,7 @@ def run_positive_steps(ent: EmbeddingTable, rel: EmbeddingTable, opt_name: str, 
     p.neg_h = p.neg_r = p.neg_t = None
     p.optimizer, p.lr, p.scale = _OPT[optimizer], lr, scale
     p.loss_partials, p.loss_ring, p.tag_base = _lib.ptr(loss, torch.float64, "loss"), steps, tag_base
+    p.hot = ent.hot_struct()          # hub rows the relation view declared on this table: the same entities lead the supervision triples
     _lib.relation_steps(p, 0, steps)
     return loss
 

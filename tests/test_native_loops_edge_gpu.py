@@ -91,3 +91,36 @@ def test_attr_steps_equal_single_steps_with_an_empty_step():
     np.testing.assert_allclose(ring.sum(dim=1).cpu().numpy(), single, rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(c1.params.cpu().numpy(), c2.params.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_positive_only_steps_use_the_hub_copies_and_stay_the_same_function():
+    """The cross-KG loops' positives-only steps (code/MultiKE_model.py:349-369) on Zipf head / tail entities: with hub rows declared
+    on the entity table every triple's head / tail gradient of a hub goes to a private copy (mke_relation_plan.hot); the same
+    tables as without the declaration, every copy back at zero."""
+    import numpy as np
+    import torch
+    from multike_amd.runner import run_positive_steps
+    from multike_amd.synthetic import SyntheticKGs
+    from multike_amd.tables import EmbeddingTable
+    kgs = SyntheticKGs(n_ent=3000, n_rel=20, seed=3, zipf=1.2)
+    tr = np.concatenate(kgs.triples)
+    B = 500
+    steps = len(tr) // B
+    cols = tuple(torch.as_tensor(np.ascontiguousarray(tr[:steps * B, k]), device="cuda") for k in range(3))
+    w = torch.rand(steps * B, device="cuda")
+    off = np.arange(steps + 1, dtype=np.int64) * B
+    out = []
+    for hubs in (False, True):
+        E, R = EmbeddingTable(3000, 75, "e", seed=1), EmbeddingTable(20, 75, "r", seed=2, grad_copies=4)
+        if hubs:
+            deg = np.bincount(tr[:, [0, 2]].reshape(-1), minlength=3000) / steps
+            E.set_hot_rows(np.nonzero(deg >= 4)[0], 8)
+            assert E.n_hot >= 5
+        loss = run_positive_steps(E, R, "ckgp", cols, w, off, 1, 0.01, scale=2.0)
+        torch.cuda.synchronize()
+        assert float(E._grad_full.abs().max()) == 0.0 and float(R.grad.abs().max()) == 0.0
+        out.append((loss.sum(1).cpu().numpy(), E.raw().cpu().numpy(), R.raw().cpu().numpy()))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=2e-4, atol=6e-6)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=2e-4, atol=6e-6)

@@ -168,9 +168,10 @@ def test_hub_rows_private_copies_are_the_same_function(d, N, n_ent, wide):
             np.testing.assert_allclose(r1.step_losses().cpu().numpy(), r2.step_losses().cpu().numpy(), rtol=2e-6)
             assert float(E1._grad_full.abs().max()) == 0.0            # the table's own rows AND the copies consumed
             bat1.shuffle(); bat2.shuffle()
-        # hub rows: a gradient row is a float32 sum of tens of terms in two different orders
-        np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
-        np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
+        # hub rows: a gradient row is a float32 sum of tens of terms in two different orders (and the atomics' order changes from
+        # run to run: one element of 1.28M was seen 3.7e-6 apart at |x| = 7e-3)
+        np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-4, atol=6e-6)
+        np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=2e-4, atol=6e-6)
         # ... and the Python-driven steps on a hub-declared table (no copies used there) still agree
         E3, R3, bat3 = fresh()
         eng = StepEngine()
