@@ -170,8 +170,8 @@ def test_hub_rows_private_copies_are_the_same_function(d, N, n_ent, wide):
             bat1.shuffle(); bat2.shuffle()
         # hub rows: a gradient row is a float32 sum of tens of terms in two different orders (and the atomics' order changes from
         # run to run: one element of 1.28M was seen 3.7e-6 apart at |x| = 7e-3)
-        np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-4, atol=6e-6)
-        np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=2e-4, atol=6e-6)
+        np.testing.assert_allclose(E1.raw().cpu().numpy(), E2.raw().cpu().numpy(), rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(R1.raw().cpu().numpy(), R2.raw().cpu().numpy(), rtol=2e-4, atol=1e-5)
         # ... and the Python-driven steps on a hub-declared table (no copies used there) still agree
         E3, R3, bat3 = fresh()
         eng = StepEngine()
@@ -181,7 +181,7 @@ def test_hub_rows_private_copies_are_the_same_function(d, N, n_ent, wide):
         E4, R4, bat4 = fresh()
         r4 = RelationViewRunner(E4, R4, bat4, lr=0.01)
         r4.run()
-        np.testing.assert_allclose(E4.raw().cpu().numpy(), E3.raw().cpu().numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(E4.raw().cpu().numpy(), E3.raw().cpu().numpy(), rtol=2e-4, atol=1e-5)   # same sums, other orders: one element of 1.28M was seen 4.6e-6 apart (1 run in 10)
     finally:
         _lib.set_option("update_chunk", old)
         RelationViewRunner.HOT_MIN = old_min
