@@ -230,6 +230,6 @@ def test_privatised_attribute_scratch_is_the_same_function(d):
         out.append((losses, E.raw().cpu().numpy(), A.raw().cpu().numpy(), {k: v.cpu().numpy().copy() for k, v in cnn.views.items()} if hasattr(cnn, "views") else {}))
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6)
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(out[1][2], out[0][2], rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=1e-3, atol=1e-5)      # hub attribute rows: thousands of terms in two orders
     for k in out[0][3]:
-        np.testing.assert_allclose(out[1][3][k], out[0][3][k], rtol=1e-3, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(out[1][3][k], out[0][3][k], rtol=1e-3, atol=1e-5, err_msg=k)

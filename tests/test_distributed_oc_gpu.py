@@ -167,8 +167,8 @@ def test_hub_rows_of_the_shard_are_the_same_function(quarter):
         _lib.set_option("oc_score_quarter", old)
     assert out[0][3] >= 3
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-4, atol=2e-6)
-    np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-4, atol=1e-5)   # the same float32 sums in two orders
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=1e-5)   # the same float32 sums in two orders
 
 
 @pytest.mark.parametrize("chunks", [1, 2])
