@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes, mke_oc_step.hot (hub rows of the shard), + mke_probe_rows; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
+#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes, mke_oc_step.hot (hub rows of the shard), mke_attr_step_args.attr_grad_copies, + mke_probe_rows; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
