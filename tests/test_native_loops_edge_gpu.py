@@ -105,8 +105,9 @@ def test_positive_only_steps_use_the_hub_copies_and_stay_the_same_function():
     from multike_amd.tables import EmbeddingTable
     kgs = SyntheticKGs(n_ent=3000, n_rel=20, seed=3, zipf=1.2)
     tr = np.concatenate(kgs.triples)
-    B = 500
-    steps = len(tr) // B
+    B = 2000
+    steps = 3            # few sequential steps: two float32 runs that sum a hub's terms in different orders drift apart step by step
+                         # (27 steps of 500 at lr 0.01 left single elements 1-3e-5 = 1-2 % apart in 4 runs of 5)
     cols = tuple(torch.as_tensor(np.ascontiguousarray(tr[:steps * B, k]), device="cuda") for k in range(3))
     w = torch.rand(steps * B, device="cuda")
     off = np.arange(steps + 1, dtype=np.int64) * B
