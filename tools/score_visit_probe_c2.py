@@ -46,18 +46,21 @@ def main():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-shared", "-fPIC", src, "-o", so])
     lib = C.CDLL(so)
     lib.launch.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    import sys
     n, n_neg, n_posrows = 200_000, 125_000, 15_000
+    if len(sys.argv) > 2:       # [in-place share] [rows] [positive rows]: e.g. 0 25000 0 = what rank 0 of 8 scatters in `k_oc_score` at C2
+        n = int(sys.argv[2])    # (125K corrupt rows of its 25K-row shard, every one an atomic row add)
+        n_posrows = int(sys.argv[3]) if len(sys.argv) > 3 else n_posrows
     w, acc, grad = (torch.zeros(n, 80, device="cuda") for _ in range(3))
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     st = torch.cuda.current_stream().cuda_stream
-    import sys
     share = float(sys.argv[1]) if len(sys.argv) > 1 else None      # force the in-place share (the product reports 65 % at C2): flags by coin
     ts = []
     for rep in range(80):
         # corrupt entities are drawn with replacement (as the sampler's are across positives); a row drawn once is finished in place
         e = torch.randint(0, n, (n_neg,), device="cuda", generator=g)
         cnt = torch.bincount(torch.cat([e, torch.randint(0, n, (n_posrows,), device="cuda", generator=g)]), minlength=n)
-        pos_rows = torch.randint(0, n, (n_posrows,), device="cuda", generator=g)
+        pos_rows = torch.randint(0, n, (max(n_posrows, 1),), device="cuda", generator=g)[:n_posrows]
         rows = torch.cat([e, pos_rows]).to(torch.int32)
         ip = (cnt[e] == 1) if share is None else (torch.rand(n_neg, device="cuda", generator=g) < share)
         inplace = torch.cat([ip, torch.zeros(n_posrows, dtype=torch.bool, device="cuda")]).to(torch.uint8)
