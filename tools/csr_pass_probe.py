@@ -24,23 +24,25 @@ extern "C" __global__ __launch_bounds__(256) void k_pass2(float* w, float* acc, 
   const int j = threadIdx.x & 15;
   const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   if (v >= n_rows_touched) return;
-  const int64_t ro = (int64_t)rows[v] * 80 + j;
+  const int64_t ro = (int64_t)rows[v] * (16 * FPL) + j;
   const int lo = off[v], hi = off[v + 1];
-  float x[5], y[5], g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float x[FPL], y[FPL], g[FPL];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { x[k] = w[ro + 16 * k]; y[k] = acc[ro + 16 * k]; }
+  for (int k = 0; k < FPL; ++k) g[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) { x[k] = w[ro + 16 * k]; y[k] = acc[ro + 16 * k]; }
   for (int r = lo; r < hi; r += 2) {                      // two references in flight
     const bool two = r + 1 < hi;
-    const int64_t v0 = (int64_t)ref_vec[r] * 80 + j, v1 = (int64_t)ref_vec[two ? r + 1 : r] * 80 + j;
+    const int64_t v0 = (int64_t)ref_vec[r] * (16 * FPL) + j, v1 = (int64_t)ref_vec[two ? r + 1 : r] * (16 * FPL) + j;
     const float c0 = coef[r], c1 = two ? coef[r + 1] : 0.f;
-    float a[5], b[5];
+    float a[FPL], b[FPL];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { a[k] = vec[v0 + 16 * k]; b[k] = vec[v1 + 16 * k]; }
+    for (int k = 0; k < FPL; ++k) { a[k] = vec[v0 + 16 * k]; b[k] = vec[v1 + 16 * k]; }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) g[k] = fmaf(c1, b[k] - x[k], fmaf(c0, a[k] - x[k], g[k]));
+    for (int k = 0; k < FPL; ++k) g[k] = fmaf(c1, b[k] - x[k], fmaf(c0, a[k] - x[k], g[k]));
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) { acc[ro + 16 * k] = fmaf(g[k], g[k], y[k]); w[ro + 16 * k] = x[k] - 1e-3f * g[k]; }
+  for (int k = 0; k < FPL; ++k) { acc[ro + 16 * k] = fmaf(g[k], g[k], y[k]); w[ro + 16 * k] = x[k] - 1e-3f * g[k]; }
 }
 extern "C" int launch(float* w, float* acc, const float* vec, const float* coef, const int32_t* rows, const int32_t* off,
                       const int32_t* ref_vec, int64_t n, void* st) {
@@ -54,15 +56,18 @@ def main():
     d = tempfile.mkdtemp(prefix="mke_probe_")
     src, so = os.path.join(d, "p.hip"), os.path.join(d, "p.so")
     open(src, "w").write(SRC)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", src, "-o", so])
+    fpl = int(os.environ.get("PROBE_FPL", "5"))          # floats per lane: 5 = 80-float rows (C2), 16 = 256-float rows (C5)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", f"-DFPL={fpl}", "-shared", "-fPIC", src, "-o", so])
     lib = C.CDLL(so)
     lib.launch.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     st = torch.cuda.current_stream().cuda_stream
-    for name, n_table, n_touched, n_refs, n_vec in (("one GPU, C2", 200_000, 35_000, 59_000, 10_000),
-                                                    ("rank 0 of 8, C2", 25_000, 25_000, 125_000, 40_000)):
-        w, acc = torch.zeros(n_table, 80, device="cuda"), torch.zeros(n_table, 80, device="cuda")
-        vec = torch.zeros(n_vec, 80, device="cuda")
+    cases = (("one GPU, C2", 200_000, 35_000, 59_000, 10_000), ("rank 0 of 8, C2", 25_000, 25_000, 125_000, 40_000))
+    if fpl == 16:       # C5: 2M rows x 256 floats, 64 negatives; a rank of eight owns 250K rows, ~104K of them touched per global step
+        cases = (("rank 0 of 8, C5", 250_000, 104_000, 325_000, 40_000),)
+    for name, n_table, n_touched, n_refs, n_vec in cases:
+        w, acc = torch.zeros(n_table, 16 * fpl, device="cuda"), torch.zeros(n_table, 16 * fpl, device="cuda")
+        vec = torch.zeros(n_vec, 16 * fpl, device="cuda")
         ts = []
         for rep in range(60):
             rows = torch.randperm(n_table, device="cuda", generator=g)[:n_touched].sort().values.to(torch.int32)
@@ -84,7 +89,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         ts = sorted(ts[5:])
-        nb = n_touched * 4 * 320 + n_refs * 328
+        nb = n_touched * 4 * 64 * fpl + n_refs * (64 * fpl + 8)
         print(json.dumps({"case": name, "touched_rows": n_touched, "references": n_refs, "MB": round(nb / 1e6, 1),
                           "median_us": round(ts[len(ts) // 2], 2), "min_us": round(ts[0], 2), "p90_us": round(ts[int(len(ts) * 0.9)], 2)}), flush=True)
 
