@@ -49,6 +49,27 @@ struct OcParams {
 // codes of the negatives of home rank g's positives of this part: [n_mine_g][neg_per_pos]
 __device__ __forceinline__ const int32_t* oc_codes(const OcParams& p, int g) { return p.s.codes + p.s.code_off[g]; }
 
+// id / G and id % G for the (non-negative) entity ids: a shift and a mask when the world size is a power of two (2, 4, 8 GPUs),
+// else an UNSIGNED 32-bit division.  The plain `int / int` of a run-time divisor is ~30 vector instructions on this part and the
+// 64-bit `i / per` ~150; SQ counters of k_oc_score_q as rank 0 of 8 showed the launch bound by instruction issue (1,660 vector
+// instructions per wavefront x 10 wavefronts per SIMD: EXPERIMENTS R5.26), a quarter of them these divisions.
+struct OcDiv { uint32_t g; int shift; };
+__device__ __forceinline__ OcDiv oc_divisor(int g) { OcDiv d; d.g = (uint32_t)g; d.shift = (g & (g - 1)) == 0 ? __builtin_ctz((unsigned)g) : -1; return d; }
+__device__ __forceinline__ int oc_div(const OcDiv& d, int x) { return d.shift >= 0 ? (int)((uint32_t)x >> d.shift) : (int)((uint32_t)x / d.g); }
+__device__ __forceinline__ int oc_mod(const OcDiv& d, int x) { return d.shift >= 0 ? (int)((uint32_t)x & (d.g - 1u)) : (int)((uint32_t)x % d.g); }
+// the score kernels take the power-of-two case as a template parameter (with the run-time test the compiler computes BOTH forms and
+// selects: nothing saved)
+template <bool P2> struct OcDivP { uint32_t g; int shift; };
+template <bool P2> __device__ __forceinline__ OcDivP<P2> oc_divisor_p(int g) { OcDivP<P2> d; d.g = (uint32_t)g; d.shift = P2 ? __builtin_ctz((unsigned)g) : 0; return d; }
+template <bool P2> __device__ __forceinline__ int oc_div(const OcDivP<P2>& d, int x) {
+  if constexpr (P2) return (int)((uint32_t)x >> d.shift); else return (int)((uint32_t)x / d.g);
+}
+template <bool P2> __device__ __forceinline__ int oc_mod(const OcDivP<P2>& d, int x) {
+  if constexpr (P2) return (int)((uint32_t)x & (d.g - 1u)); else return (int)((uint32_t)x % d.g);
+}
+// home rank of global-step position i (i < n_pos < 2^31, checked on the host): 32-bit
+__device__ __forceinline__ int oc_home(const mke_oc_step& s, int64_t i) { return (int)((uint32_t)i / (uint32_t)s.per); }
+
 // Hub rows of the shard (mke_oc_step.hot; the fused kernel's mke_hot_rows on this rank's rows): an entity that is head or tail of
 // many positives of EVERY global step receives that many same-address atomic row adds from k_oc_apply and from the positives'
 // own terms (measured as rank 0 of 8 on Zipf(1.0) triples: apply 7.4 -> 60 us, score 50 -> 76, the counting 13 -> 39).  Their
@@ -103,16 +124,17 @@ __device__ __forceinline__ void oc_count_range(const OcParams& p, int block, int
   const mke_oc_step& s = p.s;
   const int64_t n_codes = s.n_pos * s.neg_per_pos;
   const int64_t total = n_codes + 2 * s.n_pos;
+  const OcDiv dv = oc_divisor(s.n_ranks);
   for (int64_t e = (int64_t)block * MKE_BLOCK + threadIdx.x; e < total; e += (int64_t)n_blocks * MKE_BLOCK) {
     if (e < n_codes) {
-      const int64_t i = e / s.neg_per_pos;
-      const int g = (int)(i / s.per);
+      const int64_t i = n_codes <= 0xFFFFFFFFll ? (int64_t)((uint32_t)e / (uint32_t)s.neg_per_pos) : e / s.neg_per_pos;   // uniform choice
+      const int g = oc_home(s, i);
       const int c = oc_code(oc_codes(p, g)[(i - (int64_t)g * s.per) * s.neg_per_pos + (e - i * s.neg_per_pos)]) >> 1;
-      if (c % s.n_ranks == s.rank) atomicAdd(&s.ref_count[c / s.n_ranks], 1);
+      if (oc_mod(dv, c) == s.rank) atomicAdd(&s.ref_count[oc_div(dv, c)], 1);
     } else {
       const int64_t k = e - n_codes;
       const int ent = k < s.n_pos ? s.pos_h[k] : s.pos_t[k - s.n_pos];
-      if (ent % s.n_ranks == s.rank && !oc_is_hot(s, ent / s.n_ranks)) atomicAdd(&s.ref_count[ent / s.n_ranks], 1);
+      if (oc_mod(dv, ent) == s.rank && !oc_is_hot(s, oc_div(dv, ent))) atomicAdd(&s.ref_count[oc_div(dv, ent)], 1);
     }
   }
 }
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_bases(const OcParams p) {
   const int32_t pos = is_h ? s.own_h[k] : s.own_t[k];
   const int e = is_h ? s.pos_h[pos] : s.pos_t[pos];
   float E[FPL], R[FPL];
-  load_row<FPL>(s.ent, e / s.n_ranks, s.stride, j, E);
+  load_row<FPL>(s.ent, oc_div(oc_divisor(s.n_ranks), e), s.stride, j, E);
   load_row<FPL>(s.rel, s.pos_r[pos], s.stride, j, R);
   l2_normalize_row<FPL>(E, true);
   l2_normalize_row<FPL>(R, true);
@@ -179,7 +201,7 @@ __device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRI
 // One wavefront per positive of the global step.  Lane l holds the code of negative l (neg_per_pos <= 64); the negatives
 // this rank owns are dealt round-robin to the four quarter-waves (the (4 round + q)-th set bit of the ballot), U of them
 // in flight per quarter.
-template <int FPL, int U>
+template <int FPL, int U, bool P2>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   constexpr int STRIDE = FPL * 16;   // == s.stride (the dispatch picks FPL from it): row offsets by shift-add, not a 64-bit multiply
   const mke_oc_step& s = p.s;
@@ -187,21 +209,22 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   const int64_t wave0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
   const int G = s.n_ranks, N = s.neg_per_pos;
+  const OcDivP<P2> dv = oc_divisor_p<P2>(G);
   const int64_t C = s.capacity;
   float loss = 0.f;
   for (int64_t i = wave0; i < s.n_pos; i += nwaves) {
     const int ph = s.pos_h[i], pt = s.pos_t[i];
-    const int home = (int)(i / s.per);
+    const int home = oc_home(s, i);
     const int sh = s.slot_h[i], st = s.slot_t[i];   // -1: that vector does not travel (no negative of this positive needs it)
     // the vectors' home: this rank's all-gathered copy, or (peer-direct) the owner's own send block over xGMI
-    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
-    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + max(st, 0)) * STRIDE;
+    const float* vh = (s.n_peers ? s.peer_v[oc_mod(dv, ph)] : p.v_all + (int64_t)oc_mod(dv, ph) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[oc_mod(dv, pt)] : p.v_all + (int64_t)oc_mod(dv, pt) * p.block_floats) + (C + max(st, 0)) * STRIDE;
     // codes first (one negative per lane), then the owned rows' reference counts together with the positive's vector(s): a
     // round below is one round trip, and the accumulator row is gathered only for rows that are finished in place
     int code = 0;
     if (lane < N) code = oc_code(oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane]);
-    const bool mine = lane < N && ((code >> 1) % G) == s.rank;
-    const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, (code >> 1) / G) ? 2 : s.ref_count[(code >> 1) / G]) : 0;   // a hub row is never finished in place
+    const bool mine = lane < N && oc_mod(dv, code >> 1) == s.rank;
+    const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;   // a hub row is never finished in place
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
 #pragma unroll
     for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
@@ -211,9 +234,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     const int total = __popcll(mask);
 
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h (wave-uniform test)
-    if ((sh >= 0 ? pt : ph) % G == s.rank && q == 0) {
+    if (oc_mod(dv, sh >= 0 ? pt : ph) == s.rank && q == 0) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;   // weighted positives: code/losses.py:44-50
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, i, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
     }
 
     // quarter q takes the q-th, (q+4)-th, ... set bit of the ballot: a running copy of the mask with the bits already
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         const int cd = __shfl(code, src, 64);
         cnt[u] = __shfl(rcl, src, 64);
         sideH[u] = cd & 1;
-        e[u] = (cd >> 1) / G;
+        e[u] = oc_div(dv, cd >> 1);
         rest &= rest - 1; rest &= rest - 1; rest &= rest - 1; rest &= rest - 1;
       }
 #pragma unroll
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     }
     if (q < 2 && (q == 0 ? sh : st) >= 0) {
       const int64_t gb = 2 * C * (int64_t)STRIDE;
-      const int own = q == 0 ? ph % G : pt % G;
+      const int own = oc_mod(dv, q == 0 ? ph : pt);
       float* o = (s.n_peers ? s.peer_g[own] : p.g_all + (int64_t)own * gb) +
                  (q == 0 ? (int64_t)sh : C + st) * STRIDE + j;
 #pragma unroll
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
 // codes 16 at a time, the owned ones are visited one after the other (the four quarters of a wavefront iterate together until the
 // busiest is done), the partial gradient vectors need no cross-quarter reduction.  Same arithmetic, same slots, same in-place /
 // scatter rule per corrupt row as k_oc_score.
-template <int FPL>
+template <int FPL, bool P2>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
   constexpr int STRIDE = FPL * 16;
   const mke_oc_step& s = p.s;
@@ -339,6 +362,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
   const int64_t sub0 = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;   // quarter-wave index
   const int64_t nsub = ((int64_t)gridDim.x * MKE_BLOCK) >> 4;
   const int G = s.n_ranks, N = s.neg_per_pos;
+  const OcDivP<P2> dv = oc_divisor_p<P2>(G);
   const int64_t C = s.capacity;
   float loss = 0.f;
   const int64_t iters = (s.n_pos + nsub - 1) / nsub;          // wave-uniform trip count (ballots inside)
@@ -347,27 +371,27 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
     const bool act = i_raw < s.n_pos;
     const int64_t i = act ? i_raw : 0;
     const int ph = s.pos_h[i], pt = s.pos_t[i];
-    const int home = (int)(i / s.per);
+    const int home = oc_home(s, i);
     const int sh = act ? s.slot_h[i] : -1, st = act ? s.slot_t[i] : -1;   // -1: that vector does not travel
-    const float* vh = (s.n_peers ? s.peer_v[ph % G] : p.v_all + (int64_t)(ph % G) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
-    const float* vt = (s.n_peers ? s.peer_v[pt % G] : p.v_all + (int64_t)(pt % G) * p.block_floats) + (C + max(st, 0)) * STRIDE;
+    const float* vh = (s.n_peers ? s.peer_v[oc_mod(dv, ph)] : p.v_all + (int64_t)oc_mod(dv, ph) * p.block_floats) + (int64_t)max(sh, 0) * STRIDE;
+    const float* vt = (s.n_peers ? s.peer_v[oc_mod(dv, pt)] : p.v_all + (int64_t)oc_mod(dv, pt) * p.block_floats) + (C + max(st, 0)) * STRIDE;
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
 #pragma unroll
     for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
     if (sh >= 0) load_row<FPL>(vh, 0, STRIDE, j, HR);
     if (st >= 0) load_row<FPL>(vt, 0, STRIDE, j, RT);
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h
-    if (act && (sh >= 0 ? pt : ph) % G == s.rank) {
+    if (act && oc_mod(dv, sh >= 0 ? pt : ph) == s.rank) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, (sh >= 0 ? pt : ph) / G, pw, i, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
     }
     const int32_t* cp = oc_codes(p, home) + (i - (int64_t)home * s.per) * N;
     for (int c0 = 0; c0 < N; c0 += 16) {                      // the group's codes, 16 per quarter at a time
       int code = 0;
       const bool has = act && c0 + j < N;
       if (has) code = oc_code(cp[c0 + j]);
-      const bool mine = has && ((code >> 1) % G) == s.rank;
-      const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, (code >> 1) / G) ? 2 : s.ref_count[(code >> 1) / G]) : 0;
+      const bool mine = has && oc_mod(dv, code >> 1) == s.rank;
+      const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;
       const uint64_t mall = __ballot(mine);
       unsigned rest = (unsigned)(mall >> (16 * q)) & 0xFFFFu;  // this quarter's owned negatives of the chunk
       while (__ballot(rest != 0)) {                            // the four quarters visit their next owned negative together
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
         rest &= rest - 1;
         if (!live) continue;
         const bool sideH = cd & 1;
-        const int e = (cd >> 1) / G;
+        const int e = oc_div(dv, cd >> 1);
         float Cr[FPL], A[FPL];
         load_row<FPL>(s.ent, e, STRIDE, j, Cr);
         const bool in_place = s.ref_count && cnt == 1;
@@ -440,8 +464,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
     }
     {   // this positive's partial gradient vector(s): every live slot of g_all is written by exactly one quarter-wave per step
       const int64_t gb = 2 * C * (int64_t)STRIDE;
-      float* oh = (s.n_peers ? s.peer_g[ph % G] : p.g_all + (int64_t)(ph % G) * gb) + (int64_t)max(sh, 0) * STRIDE + j;
-      float* ot = (s.n_peers ? s.peer_g[pt % G] : p.g_all + (int64_t)(pt % G) * gb) + (C + max(st, 0)) * STRIDE + j;
+      float* oh = (s.n_peers ? s.peer_g[oc_mod(dv, ph)] : p.g_all + (int64_t)oc_mod(dv, ph) * gb) + (int64_t)max(sh, 0) * STRIDE + j;
+      float* ot = (s.n_peers ? s.peer_g[oc_mod(dv, pt)] : p.g_all + (int64_t)oc_mod(dv, pt) * gb) + (C + max(st, 0)) * STRIDE + j;
       if (sh >= 0) {
 #pragma unroll
         for (int k = 0; k < FPL; ++k) oh[k * 16] = gHR[k];
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
   const bool is_h = sub < s.n_own_h;
   const int64_t k = is_h ? sub : sub - s.n_own_h;
   const int32_t pos = is_h ? s.own_h[k] : s.own_t[k];
-  const int row = (is_h ? s.pos_h[pos] : s.pos_t[pos]) / s.n_ranks;
+  const int row = oc_div(oc_divisor(s.n_ranks), is_h ? s.pos_h[pos] : s.pos_t[pos]);
   const int r = s.pos_r[pos];
   float v[FPL];
   load_row<FPL>(p.gv, (is_h ? 0 : s.capacity) + k, s.stride, j, v);
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(OC_PLAN_THREADS) void k_oc_plan(const int32_t* __re
       const int64_t i = base + tid;
       const uint32_t need = i < hi ? (neg_per_pos ? (uint32_t)codes[i * neg_per_pos] : MKE_OC_NEED_HR) : 0u;
       const bool valid = (need & (x ? MKE_OC_NEED_RT : MKE_OC_NEED_HR)) != 0;
-      const int o = valid ? ids[i] % G : -1;
+      const int o = valid ? oc_mod(oc_divisor(G), ids[i]) : -1;
       int rk = 0;
       uint64_t todo = __ballot(valid);
       while (todo) {                                 // wave-uniform: one round per distinct owner present in the wavefront
@@ -560,6 +584,7 @@ static int oc_check(const mke_oc_step* s, const char* who) {
   if (!s) { set_error("%s: NULL step", who); return MKE_E_NULL; }
   if (s->n_ranks < 1 || s->n_ranks > MKE_OC_MAX_RANKS || s->rank < 0 || s->rank >= s->n_ranks) { set_error("%s: bad rank / n_ranks", who); return MKE_E_SHAPE; }
   if (s->stride <= 0 || s->stride % 16 != 0 || s->dim <= 0 || s->dim > s->stride || s->stride > MKE_MAX_STRIDE) { set_error("%s: bad stride/dim", who); return MKE_E_SHAPE; }
+  if (s->n_pos > 0x7FFFFFFFll || s->per > 0x7FFFFFFFll) { set_error("%s: n_pos / per beyond 2^31", who); return MKE_E_RANGE; }
   if (s->n_pos < 0 || s->per < 1 || s->per * s->n_ranks < s->n_pos || s->neg_per_pos < 0 || s->neg_per_pos > 64) { set_error("%s: bad n_pos / per / neg_per_pos (<= 64)", who); return MKE_E_SHAPE; }
   if (s->n_own_h < 0 || s->n_own_t < 0 || s->n_own_h > s->capacity || s->n_own_t > s->capacity) { set_error("%s: owned vectors exceed the capacity", who); return MKE_E_SHAPE; }
   if (s->rel_grad_copies < 1 || s->rel_grad_copies > 64) { set_error("%s: rel_grad_copies must be in [1,64]", who); return MKE_E_SHAPE; }
@@ -666,14 +691,17 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   // a quarter-wave per positive when a rank owns only a few of a positive's negatives (N / G <= 8 at G >= 4, rows up to 128 floats:
   // wider rows leave two wavefronts per SIMD at 194 registers) — k_oc_score_q;
   // option "oc_score_quarter": -1 = by shape (default), 0 = never, 1 = always
+  const bool pow2 = (s->n_ranks & (s->n_ranks - 1)) == 0;     // id / G, id % G as shift / mask (2, 4, 8 ranks)
   const bool quarter = g_oc_score_quarter < 0 ? (s->n_ranks >= 4 && s->neg_per_pos <= 8 * s->n_ranks && s->stride <= 128) : g_oc_score_quarter != 0;
   if (quarter) {
-    MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); });
+    if (pow2) { MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); }); }
+    else { MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); }); }
     return check_launch("k_oc_score_q");
   }
   MKE_DISPATCH_FPL(fpl, {
     constexpr int U = FPL <= 5 ? 2 : 1;
-    hipLaunchKernelGGL((k_oc_score<FPL, U>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    if (pow2) hipLaunchKernelGGL((k_oc_score<FPL, U, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_oc_score<FPL, U, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   });
   return check_launch("k_oc_score");
 }
