@@ -116,7 +116,7 @@ template <bool DET>
 __device__ __forceinline__ int hot_copy_row(const ScoreParams& p, int e, int64_t k) {
   if (DET || !p.hot_slot) return -1;
   const int s = p.hot_slot[e];
-  return s >= 0 ? p.hot_row0 + (int)(k % p.hot_copies) * p.n_hot + s : -1;
+  return s >= 0 ? p.hot_row0 + (int)((uint32_t)k % (uint32_t)p.hot_copies) * p.n_hot + s : -1;   // k < 2^32 (the launcher checks the item count)
 }
 
 template <int FPL, bool DET = false>
@@ -185,29 +185,35 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
 
   const int npp = p.npp;
   if (npp > 0) {
-    const int S = p.splits;  // wavefronts sharing one group's negatives (1 when QPG == 2)
+    const int S = QPG == 2 ? 1 : p.splits;  // wavefronts sharing one group's negatives (two groups per wavefront: always 1 — the launcher's `half` needs splits == 1 — and a compile-time 1 folds every division by it below)
     const int64_t nitems = p.n_pos * S;
     const int64_t nwork = (nitems + GPW - 1) / GPW;
     for (int64_t wv = wave0; wv < nwork; wv += nwaves) {
       const int64_t wk_raw = wv * GPW + sub;
       const bool active = wk_raw < nitems;       // the second half of the last wavefront may have no group
       const int64_t wk = active ? wk_raw : 0;
-      const int64_t g = wk % p.n_pos;  // slices of one group are n_pos work items apart: different CUs
-      const int s = (int)(wk / p.n_pos);
-      float* __restrict__ grel = bwd ? p.grel + (wk % p.grel_copies) * p.grel_copy_elems : nullptr;
+      // group and slice of this work item: slices of one group are n_pos work items apart (different CUs).  Two groups per
+      // wavefront (QPG == 2) means one slice per group: no division at all; otherwise UNSIGNED 32-bit ones (the launcher checks
+      // n_pos * splits < 2^32) — the 64-bit `wk % n_pos`, `wk / n_pos`, `wk % copies` of a run-time divisor were ~400 of the
+      // training kernel's ~2,400 vector instructions per wavefront, all of them ahead of its first load (EXPERIMENTS R5.28)
+      int64_t g;
+      int s;
+      if constexpr (QPG == 2) { g = wk; s = 0; }
+      else { s = (int)((uint32_t)wk / (uint32_t)p.n_pos); g = (int64_t)((uint32_t)wk - (uint32_t)s * (uint32_t)p.n_pos); }
+      float* __restrict__ grel = bwd ? p.grel + (int64_t)((uint32_t)wk % (uint32_t)p.grel_copies) * p.grel_copy_elems : nullptr;
       const int ph = p.ph[g], pr = p.pr[g], pt = p.pt[g];
       // hub rows: looked up with the positive's rows, used at the flush (copy = group index modulo the number of copies)
       int hot_h = -1, hot_t = -1;
       if (!DET && p.hot_slot) {
         const int sh = p.hot_slot[ph], st = p.hot_slot[pt];
-        const int cp = p.hot_row0 + (int)(g % p.hot_copies) * p.n_hot;
+        const int cp = p.hot_row0 + (int)((uint32_t)g % (uint32_t)p.hot_copies) * p.n_hot;
         hot_h = sh >= 0 ? cp + sh : -1;
         hot_t = st >= 0 ? cp + st : -1;
       }
       // LIDS: the group's first block of negative ids is requested with the positive's ids, its reference counts with the
       // positive's rows (see below): two round trips fewer at the head of a wavefront's chain
       const int npp_ = p.npp;
-      const int per_ = (npp_ + p.splits - 1) / p.splits;
+      const int per_ = (npp_ + S - 1) / S;
       const int nlo_ = s * per_, nend_ = min(npp_, nlo_ + per_);
       const int lbase = lane & ~(LPG - 1);   // first lane of this lane's group
       int el = 0, fl = 0, rcl = 0, nblk = 0;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_triple_score(const ScoreParams p)
     const int64_t sub0 = ((int64_t)bid * MKE_BLOCK + threadIdx.x) >> 4;
     const int64_t nsub = ((int64_t)nblk * MKE_BLOCK) >> 4;
     for (int64_t i = sub0; i < p.n_pos + p.n_neg; i += nsub) {
-      float* __restrict__ grel = bwd ? p.grel + (i % p.grel_copies) * p.grel_copy_elems : nullptr;
+      float* __restrict__ grel = bwd ? p.grel + (int64_t)((uint32_t)i % (uint32_t)p.grel_copies) * p.grel_copy_elems : nullptr;
       if (i < p.n_pos) {
         loss += independent_triple<FPL, DET>(p, grel, j, p.ph[i], p.pr[i], p.pt[i], p.pw ? p.pw[i] : 1.0f, 1.0f, i * 3);
       } else {
@@ -588,6 +594,7 @@ static int score_impl(
     // n negatives at every width; 0: never).
     const int half_max = g_score_half_max >= 0 ? g_score_half_max : (FPL <= 8 ? 64 : 31);
     const bool half = neg_per_pos > 0 && neg_per_pos <= half_max && splits == 1;
+    if (n_pos * (int64_t)splits > 0xFFFFFFFFll || n_pos + n_neg > 0xFFFFFFFFll) { set_error("more than 2^32 work items in one launch"); return MKE_E_RANGE; }
     if (stage_keys) {
       // deterministic mode: staging stores instead of atomics
       if (half) {
