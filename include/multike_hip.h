@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKE_VERSION 104 /* 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes, mke_oc_step.hot (hub rows of the shard), mke_attr_step_args.attr_grad_copies, + mke_probe_rows; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
+#define MKE_VERSION 105 /* 0.1.5: + entity-major second pass of the owner-computes step (mke_oc_step.em_*, mke_oc_em_plan, MKE_OC_PASS2: additions only), + mke_oc_steps / mke_oc_comm (the G > 1 step loop as ONE native call), per-plan tuning (mke_tuning); 0.1.4: mke_oc_* exchange ONE vector per positive (the side its negatives corrupt): group flags in the codes, slot -1, mke_oc_plan takes the codes, mke_oc_step.hot (hub rows of the shard), mke_attr_step_args.attr_grad_copies, + mke_probe_rows; 0.1.3: + hub rows (mke_hot_rows: mke_triple_score_fwd_bwd_xch, mke_update_table.hot, mke_relation_plan.hot; additions only); 0.1.2: + mke_oc_plan, mke_topk_long, options "attr_fused_bwd" / "oc_score_quarter" (additions only); 0.1.1: mke_align_rank gained `ties` */
 
 /* error codes (negative = argument errors) */
 #define MKE_OK 0
@@ -837,7 +837,21 @@ typedef struct mke_oc_step {
    * has hot.row0 + hot.copies * hot.n_hot rows, hot.row0 >= n_local), they are not reference-counted and never finished in
    * place; mke_oc_run's update adds the copies */
   mke_hot_rows hot;
+  /* version 105: ENTITY-MAJOR second pass (em_coef != NULL selects it; new design).  mke_oc_score then writes
+   * no row gradient at all: per (positive, owned negative) — and for the positive's own term — it stores ONE coefficient,
+   * em_coef[(em_pos0 + i) * (neg_per_pos + 1) + n] (n == neg_per_pos: the own term), and mke_oc_pass2 finishes every touched
+   * owned row of the GLOBAL STEP in place from the row's reference list (mke_oc_em_plan, sorted by row: a fixed summation
+   * order, so results are bit-reproducible run to run): ghat = sum coef (c^ + sg V) + sum (+-) gv, then the Jacobian of the
+   * normalisation and the optimizer — no gradient scratch, no touched flags, no reference counts, no hub-row copies, no
+   * atomics on entity rows, and the entity table takes no part in mke_oc_apply / the update launch.
+   * em_refs: pairs (locator, coefficient index) of the whole epoch; em_rows / em_off: touched owned rows of THIS step and their
+   * offsets into em_refs (em_off[em_n_rows] valid); em_v[c] / em_gv[c]: chunk c's all-gathered vectors [n_ranks][block] and
+   * reduce-scattered gradient block (the step's parts, at most MKE_OC_EM_MAX_CHUNKS). */
+  float* em_coef; int64_t em_pos0;
+  const uint32_t* em_refs; const int32_t* em_rows; const int32_t* em_off; int64_t em_n_rows;
+  int em_chunks; int64_t em_block_floats; const float* em_v[4]; const float* em_gv[4];
 } mke_oc_step;
+#define MKE_OC_EM_MAX_CHUNKS 4
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output; the group flags
  * (MKE_OC_NEED_*) go into codes[p * neg_per_pos] */
@@ -864,9 +878,39 @@ int mke_oc_apply(const mke_oc_step* step, const float* gv, void* stream);
 #define MKE_OC_COUNT 2
 #define MKE_OC_SCORE 4
 #define MKE_OC_APPLY 8
-#define MKE_OC_UPDATE 16   /* mke_rows_update_multi: relation table (every row) + the shard's touched rows */
+#define MKE_OC_UPDATE 16   /* mke_rows_update_multi: relation table (every row) + the shard's touched rows (entity-major: relation table only) */
+#define MKE_OC_PASS2 32    /* entity-major second pass over the touched owned rows of the global step (after the LAST part's reduce-scatter) */
 int mke_oc_run(const mke_oc_step* step, int phases, float* send_block, const float* v_all, int64_t block_floats, float* g_all,
                const float* gv, double* loss_partials, void* stream);
+
+/* Entity-major second pass of the owner-computes step (version 105; new design, no reference counterpart; semantics matched:
+ * code/MultiKE_model.py:304-310 — ONE update per row per step from the sum of all its contributions).
+ * mke_oc_em_plan (per epoch, table-independent, after mke_oc_plan): the references of every global step to the rows THIS rank
+ * owns, sorted by (step, local row, positive, kind) —
+ *     negative n of positive i whose corrupt entity is owned         -> (vector of i's group, coefficient (i, n))
+ *     own term of positive i (owner of t when HR travels, else of h) -> (vector, coefficient (i, neg_per_pos))
+ *     head / tail of positive i owned and its HR / RT vector travels -> (+ / - the reduce-scattered gradient vector), and the
+ *         same vector (+) into the positive's RELATION row, listed as local row n_local + r: mke_oc_pass2 STORES this rank's
+ *         partial relation gradient into rel_grad (copy 0; one writer per row and step) for the all-reduce — no mke_oc_apply
+ * Epoch positions [step_lo[s], step_lo[s+1]) are global step s; its parts are the `chunks` ceil-split slices of the step
+ * (chunk of positive i = i / ceil(size / chunks)).  Outputs: refs[2 k], refs[2 k + 1] = locator and coefficient index of
+ * reference k; rows[u] / off[u] = local row (>= n_local: relation row) and first reference of the u-th touched (step, row); step_row0[s] = first u of
+ * step s (n_steps + 1 entries); n_refs[0] = references owned (> capacity: the plan is INVALID, enlarge and re-plan).
+ * keys / keys_alt: capacity + 1 scratch keys each; flags / scan: capacity + 1 scratch ints each; temp: mke_oc_em_plan_temp_bytes. */
+typedef struct mke_oc_em_plan_args {
+  const int32_t* pos_h; const int32_t* pos_r; const int32_t* pos_t; const int32_t* codes; int neg_per_pos;
+  const int32_t* slot_h; const int32_t* slot_t;
+  const int64_t* step_lo; int n_steps; int chunks; int64_t n_all; int64_t max_step /* host: most positives of a step */;
+  int n_ranks, rank; int64_t n_local, n_rel;
+  uint64_t* keys; uint64_t* keys_alt; int64_t capacity;
+  uint32_t* refs; int32_t* rows; int32_t* off; int32_t* flags; int32_t* scan;
+  int64_t* step_row0; int64_t* n_refs;
+  void* temp; int64_t temp_bytes;
+} mke_oc_em_plan_args;
+int64_t mke_oc_em_plan_temp_bytes(int64_t capacity);
+int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream);
+/* the second pass of the step `step` describes (its em_* fields; launched once per global step) */
+int mke_oc_pass2(const mke_oc_step* step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ SYMBOLS = (
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_topk_long", "mke_probe_rows", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
+    "mke_oc_em_plan_temp_bytes", "mke_oc_em_plan", "mke_oc_pass2",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -104,7 +105,24 @@ class OcStepStruct(C.Structure):
                 ("codes", C.c_void_p), ("code_off", C.c_int64 * 16),
                 ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float), ("tag", C.c_int32),
                 ("n_peers", C.c_int), ("peer_v", C.c_void_p * 16), ("peer_g", C.c_void_p * 16), ("pos_w", C.c_void_p),
-                ("hot", HotRowsStruct)]
+                ("hot", HotRowsStruct),
+                # version 105: entity-major second pass
+                ("em_coef", C.c_void_p), ("em_pos0", C.c_int64), ("em_refs", C.c_void_p), ("em_rows", C.c_void_p), ("em_off", C.c_void_p),
+                ("em_n_rows", C.c_int64), ("em_chunks", C.c_int), ("em_block_floats", C.c_int64), ("em_v", C.c_void_p * 4),
+                ("em_gv", C.c_void_p * 4)]
+
+
+OC_EM_MAX_CHUNKS = 4
+
+
+class OcEmPlanArgs(C.Structure):
+    """mke_oc_em_plan_args"""
+    _fields_ = [("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("codes", C.c_void_p), ("neg_per_pos", C.c_int),
+                ("slot_h", C.c_void_p), ("slot_t", C.c_void_p), ("step_lo", C.c_void_p), ("n_steps", C.c_int), ("chunks", C.c_int),
+                ("n_all", C.c_int64), ("max_step", C.c_int64), ("n_ranks", C.c_int), ("rank", C.c_int), ("n_local", C.c_int64), ("n_rel", C.c_int64),
+                ("keys", C.c_void_p), ("keys_alt", C.c_void_p), ("capacity", C.c_int64),
+                ("refs", C.c_void_p), ("rows", C.c_void_p), ("off", C.c_void_p), ("flags", C.c_void_p), ("scan", C.c_void_p),
+                ("step_row0", C.c_void_p), ("n_refs", C.c_void_p), ("temp", C.c_void_p), ("temp_bytes", C.c_int64)]
 
 
 class AEPlanStruct(C.Structure):
@@ -184,6 +202,7 @@ def lib():
         L.mke_mapping_scratch_floats.restype = C.c_int64
         L.mke_ae_scratch_floats.restype = C.c_int64
         L.mke_oc_block_floats.restype = C.c_int64
+        L.mke_oc_em_plan_temp_bytes.restype = C.c_int64
         _lib = L
         # MKE_OPTIONS="name=value,name=value": mke_set_option calls applied at load (performance knobs for experiments)
         for kv in filter(None, os.environ.get("MKE_OPTIONS", "").split(",")):
@@ -757,7 +776,23 @@ def oc_apply(step: OcStepStruct, gv):
     _check(rc, "mke_oc_apply")
 
 
-OC_BASES, OC_COUNT, OC_SCORE, OC_APPLY, OC_UPDATE = 1, 2, 4, 8, 16
+OC_BASES, OC_COUNT, OC_SCORE, OC_APPLY, OC_UPDATE, OC_PASS2 = 1, 2, 4, 8, 16, 32
+
+
+def oc_em_plan_temp_bytes(capacity: int) -> int:
+    n = lib().mke_oc_em_plan_temp_bytes(C.c_int64(capacity))
+    if n < 0:
+        raise MultiKEHipError("mke_oc_em_plan_temp_bytes: capacity out of range")
+    return int(n)
+
+
+def oc_em_plan(args: OcEmPlanArgs):
+    """mke_oc_em_plan: the epoch's references to this rank's rows, sorted by (step, row) — struct of raw device addresses."""
+    _check(lib().mke_oc_em_plan(C.byref(args), _stream()), "mke_oc_em_plan")
+
+
+def oc_pass2(step: OcStepStruct):
+    _check(lib().mke_oc_pass2(C.byref(step), _stream()), "mke_oc_pass2")
 
 
 def oc_run(step: OcStepStruct, phases: int, send, v_all, block_floats: int, g_all, gv, loss_partials):

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_count(const OcParams p) { oc_c
 // wire the owner of t forms d = HR_p - t^, with only RT_p the owner of h forms d = h^ + RT_p; loss and coefficient of a
 // POSITIVE (code/losses.py:4-12), c d added to the vector's gradient, -+ c d scattered to the local row (never in place:
 // the row is also referenced by nothing else only by accident, and the update launch visits it anyway).
-template <int FPL>
+template <int FPL, bool EM = false>
 __device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRIDE, int j, bool use_hr, int ent_local, float pw, int64_t i,
                                                   const float (&HR)[FPL], const float (&RT)[FPL], float (&gHR)[FPL], float (&gRT)[FPL]) {
   float d[FPL];
@@ -192,16 +192,20 @@ __device__ __forceinline__ float oc_positive_term(const mke_oc_step& s, int STRI
     gHR[k] = fmaf(ch, d[k], gHR[k]);
     gRT[k] = fmaf(ct, d[k], gRT[k]);
   }
-  // the row's own gradient is sg * c * d: the scale rides on the sign argument (no second scaled copy of d)
-  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, ent_local, i), STRIDE, s.dim, j, d, sg * c);
-  if (j == 0) s.ent_touched[ent_local] = s.tag;
+  if constexpr (EM) {   // entity-major: the row's owner-side pass re-forms sg c d = c (e^ + sg V) from this one scalar
+    if (j == 0) s.em_coef[(s.em_pos0 + i) * (s.neg_per_pos + 1) + s.neg_per_pos] = c;
+  } else {
+    // the row's own gradient is sg * c * d: the scale rides on the sign argument (no second scaled copy of d)
+    atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, ent_local, i), STRIDE, s.dim, j, d, sg * c);
+    if (j == 0) s.ent_touched[ent_local] = s.tag;
+  }
   return pw * softplus_f(x);
 }
 
 // One wavefront per positive of the global step.  Lane l holds the code of negative l (neg_per_pos <= 64); the negatives
 // this rank owns are dealt round-robin to the four quarter-waves (the (4 round + q)-th set bit of the ballot), U of them
 // in flight per quarter.
-template <int FPL, int U, bool P2>
+template <int FPL, int U, bool P2, bool EM = false>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
   constexpr int STRIDE = FPL * 16;   // == s.stride (the dispatch picks FPL from it): row offsets by shift-add, not a 64-bit multiply
   const mke_oc_step& s = p.s;
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     int code = 0;
     if (lane < N) code = oc_code(oc_codes(p, home)[(i - (int64_t)home * s.per) * N + lane]);
     const bool mine = lane < N && oc_mod(dv, code >> 1) == s.rank;
-    const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;   // a hub row is never finished in place
+    int rcl = 0;
+    if constexpr (!EM) rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;   // a hub row is never finished in place
     float HR[FPL], RT[FPL], gHR[FPL], gRT[FPL];
 #pragma unroll
     for (int k = 0; k < FPL; ++k) HR[k] = RT[k] = gHR[k] = gRT[k] = 0.f;
@@ -232,11 +237,12 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     if (st >= 0) load_row<FPL>(vt, 0, STRIDE, j, RT);
     const uint64_t mask = __ballot(mine);
     const int total = __popcll(mask);
+    float* const coefp = EM ? s.em_coef + (s.em_pos0 + i) * (N + 1) : nullptr;   // this positive's coefficients (entity-major)
 
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h (wave-uniform test)
     if (oc_mod(dv, sh >= 0 ? pt : ph) == s.rank && q == 0) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;   // weighted positives: code/losses.py:44-50
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL, EM>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
     }
 
     // quarter q takes the q-th, (q+4)-th, ... set bit of the ballot: a running copy of the mask with the bits already
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
     uint64_t rest = mask;
     for (int k = 0; k < q; ++k) rest &= rest - 1;
     for (int base = 0; base < total; base += 4 * U) {
-      int e[U], cnt[U];
+      int e[U], cnt[U], nidx[U];
       bool live[U], sideH[U];
       float Cr[U][FPL], A[U][FPL];
 #pragma unroll
@@ -252,7 +258,8 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         live[u] = rest != 0;
         const int src = live[u] ? __builtin_ctzll(rest) : 0;
         const int cd = __shfl(code, src, 64);
-        cnt[u] = __shfl(rcl, src, 64);
+        cnt[u] = EM ? 0 : __shfl(rcl, src, 64);
+        nidx[u] = src;
         sideH[u] = cd & 1;
         e[u] = oc_div(dv, cd >> 1);
         rest &= rest - 1; rest &= rest - 1; rest &= rest - 1; rest &= rest - 1;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
       for (int u = 0; u < U; ++u) {
         if (live[u]) {
           load_row<FPL>(s.ent, e[u], STRIDE, j, Cr[u]);
-          if (s.ref_count && s.ent_acc && cnt[u] == 1) load_row<FPL>(s.ent_acc, e[u], STRIDE, j, A[u]);
+          if constexpr (!EM) { if (s.ref_count && s.ent_acc && cnt[u] == 1) load_row<FPL>(s.ent_acc, e[u], STRIDE, j, A[u]); }
         } else {
 #pragma unroll
           for (int k = 0; k < FPL; ++k) Cr[u][k] = 0.f;
@@ -288,6 +295,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
         loss += __logf(s1);
         const float c = -2.0f * s.scale * t_ * __builtin_amdgcn_rcpf(s1);
         const float cHR = sideH[u] ? 0.f : c, cRT = sideH[u] ? c : 0.f;
+        if constexpr (EM) {   // entity-major: one scalar out per (positive, negative); the row's owner-side pass does the rest
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) {
+            gHR[k] = fmaf(cHR, d[k], gHR[k]);
+            gRT[k] = fmaf(cRT, d[k], gRT[k]);
+          }
+          if (j == 0) coefp[nidx[u]] = c;
+          continue;
+        }
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
           gHR[k] = fmaf(cHR, d[k], gHR[k]);
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score(const OcParams p) {
 // codes 16 at a time, the owned ones are visited one after the other (the four quarters of a wavefront iterate together until the
 // busiest is done), the partial gradient vectors need no cross-quarter reduction.  Same arithmetic, same slots, same in-place /
 // scatter rule per corrupt row as k_oc_score.
-template <int FPL, bool P2>
+template <int FPL, bool P2, bool EM = false>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
   constexpr int STRIDE = FPL * 16;
   const mke_oc_step& s = p.s;
@@ -383,29 +399,32 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
     // the positive itself: with HR on the wire the owner of t scores it, else the owner of h
     if (act && oc_mod(dv, sh >= 0 ? pt : ph) == s.rank) {
       const float pw = s.pos_w ? s.pos_w[i] : 1.0f;
-      loss += oc_positive_term<FPL>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
+      loss += oc_positive_term<FPL, EM>(s, STRIDE, j, sh >= 0, oc_div(dv, sh >= 0 ? pt : ph), pw, i, HR, RT, gHR, gRT);
     }
     const int32_t* cp = oc_codes(p, home) + (i - (int64_t)home * s.per) * N;
+    float* const coefp = EM ? s.em_coef + (s.em_pos0 + i) * (N + 1) : nullptr;   // this positive's coefficients (entity-major)
     for (int c0 = 0; c0 < N; c0 += 16) {                      // the group's codes, 16 per quarter at a time
       int code = 0;
       const bool has = act && c0 + j < N;
       if (has) code = oc_code(cp[c0 + j]);
       const bool mine = has && oc_mod(dv, code >> 1) == s.rank;
-      const int rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;
+      int rcl = 0;
+      if constexpr (!EM) rcl = (mine && s.ref_count) ? (oc_is_hot(s, oc_div(dv, code >> 1)) ? 2 : s.ref_count[oc_div(dv, code >> 1)]) : 0;
       const uint64_t mall = __ballot(mine);
       unsigned rest = (unsigned)(mall >> (16 * q)) & 0xFFFFu;  // this quarter's owned negatives of the chunk
       while (__ballot(rest != 0)) {                            // the four quarters visit their next owned negative together
         const bool live = rest != 0;
-        const int src = 16 * q + (live ? __builtin_ctz(rest) : 0);
+        const int bit = live ? __builtin_ctz(rest) : 0;
+        const int src = 16 * q + bit;
         const int cd = __shfl(code, src, 64);
-        const int cnt = __shfl(rcl, src, 64);
+        const int cnt = EM ? 0 : __shfl(rcl, src, 64);
         rest &= rest - 1;
         if (!live) continue;
         const bool sideH = cd & 1;
         const int e = oc_div(dv, cd >> 1);
         float Cr[FPL], A[FPL];
         load_row<FPL>(s.ent, e, STRIDE, j, Cr);
-        const bool in_place = s.ref_count && cnt == 1;
+        const bool in_place = !EM && s.ref_count && cnt == 1;
         if (in_place && s.ent_acc) load_row<FPL>(s.ent_acc, e, STRIDE, j, A);
         float ss = 0.f;
 #pragma unroll
@@ -425,6 +444,15 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
         loss += __logf(s1);
         const float c = -2.0f * s.scale * t_ * __builtin_amdgcn_rcpf(s1);
         const float cHR = sideH ? 0.f : c, cRT = sideH ? c : 0.f;
+        if constexpr (EM) {   // entity-major: one scalar out per (positive, negative)
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) {
+            gHR[k] = fmaf(cHR, d[k], gHR[k]);
+            gRT[k] = fmaf(cRT, d[k], gRT[k]);
+          }
+          if (j == 0) coefp[c0 + bit] = c;
+          continue;
+        }
 #pragma unroll
         for (int k = 0; k < FPL; ++k) {
           gHR[k] = fmaf(cHR, d[k], gHR[k]);
@@ -482,7 +510,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_score_q(const OcParams p) {
 
 // quarter-wave per owned slot: the summed gradient vector goes to the head (+) / tail (-) row's gradient and to the
 // relation row's
-template <int FPL>
+template <int FPL, bool ENT = true>   // ENT false (entity-major step): the relation rows only — the head / tail rows take gv in mke_oc_pass2
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
   const mke_oc_step& s = p.s;
   const int j = threadIdx.x & 15;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
   const bool is_h = sub < s.n_own_h;
   const int64_t k = is_h ? sub : sub - s.n_own_h;
   const int32_t pos = is_h ? s.own_h[k] : s.own_t[k];
-  const int row = oc_div(oc_divisor(s.n_ranks), is_h ? s.pos_h[pos] : s.pos_t[pos]);
+  const int row = ENT ? oc_div(oc_divisor(s.n_ranks), is_h ? s.pos_h[pos] : s.pos_t[pos]) : 0;
   const int r = s.pos_r[pos];
   float v[FPL];
   load_row<FPL>(p.gv, (is_h ? 0 : s.capacity) + k, s.stride, j, v);
@@ -504,11 +532,11 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_apply(const OcParams p) {
       for (int c = 0; c < FPL; ++c) v[c] += w[c];
     }
   }
-  atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, row, sub), s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
+  if constexpr (ENT) atomic_add_row<FPL>(s.ent_grad, oc_grad_row(s, row, sub), s.stride, s.dim, j, v, is_h ? 1.0f : -1.0f);
   float* grel = s.rel_grad + (sub % s.rel_grad_copies) * (s.n_rel * (int64_t)s.stride);
   atomic_add_row<FPL>(grel, r, s.stride, s.dim, j, v, 1.0f);
   if (j == 0) {
-    s.ent_touched[row] = s.tag;
+    if constexpr (ENT) s.ent_touched[row] = s.tag;
     s.rel_touched[r] = s.tag;
   }
 }
@@ -597,6 +625,12 @@ static int oc_check(const mke_oc_step* s, const char* who) {
   if (!s->ent || !s->rel) { set_error("%s: NULL table", who); return MKE_E_NULL; }
   if (s->optimizer != MKE_OPT_ADAGRAD && s->optimizer != MKE_OPT_SGD) { set_error("%s: Adagrad or SGD", who); return MKE_E_UNSUPPORTED; }
   if (s->hot.slot && (s->hot.n_hot < 1 || s->hot.copies < 1 || s->hot.copies > 64 || s->hot.row0 < s->n_local)) { set_error("%s: bad hub-row declaration", who); return MKE_E_SHAPE; }
+  if (s->em_coef) {   // entity-major second pass
+    if (s->n_peers) { set_error("%s: the entity-major pass does not run peer-direct", who); return MKE_E_UNSUPPORTED; }
+    if (s->em_pos0 < 0 || s->em_n_rows < 0 || s->em_chunks < 1 || s->em_chunks > MKE_OC_EM_MAX_CHUNKS) { set_error("%s: bad em_pos0 / em_n_rows / em_chunks (1..%d)", who, MKE_OC_EM_MAX_CHUNKS); return MKE_E_SHAPE; }
+    if ((s->em_pos0 + s->n_pos) * (s->neg_per_pos + 1) > 0x7FFFFFFFll) { set_error("%s: the step's coefficients exceed 2^31", who); return MKE_E_RANGE; }
+    if (s->capacity >= (1 << 23)) { set_error("%s: entity-major locators hold slots below 2^23", who); return MKE_E_RANGE; }
+  }
   return MKE_OK;
 }
 
@@ -683,8 +717,9 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   using namespace mke;
   int rc = oc_check(s, "mke_oc_score");
   if (rc) return rc;
-  if ((!s->n_peers && (!v_all || !g_all)) || !loss_partials || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_score: NULL pointer"); return MKE_E_NULL; }
-  if (s->ref_count && s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_score: the exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
+  const bool em = s->em_coef != nullptr;
+  if ((!s->n_peers && (!v_all || !g_all)) || !loss_partials || !s->rel_grad || !s->rel_touched || (!em && (!s->ent_grad || !s->ent_touched))) { set_error("mke_oc_score: NULL pointer"); return MKE_E_NULL; }
+  if (!em && s->ref_count && s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_score: the exclusive-row path with Adagrad needs ent_acc"); return MKE_E_NULL; }
   OcParams p{};
   p.s = *s; p.v_all = v_all; p.block_floats = block_floats; p.g_all = g_all; p.lossp = loss_partials;
   const int fpl = s->stride / 16;
@@ -693,15 +728,19 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   // option "oc_score_quarter": -1 = by shape (default), 0 = never, 1 = always
   const bool pow2 = (s->n_ranks & (s->n_ranks - 1)) == 0;     // id / G, id % G as shift / mask (2, 4, 8 ranks)
   const bool quarter = g_oc_score_quarter < 0 ? (s->n_ranks >= 4 && s->neg_per_pos <= 8 * s->n_ranks && s->stride <= 128) : g_oc_score_quarter != 0;
+  const dim3 grid(MKE_LOSS_PARTIALS), blk(MKE_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
   if (quarter) {
-    if (pow2) { MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); }); }
-    else { MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_score_q<FPL, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p); }); }
+    MKE_DISPATCH_FPL(fpl, {
+      if (em) { if (pow2) hipLaunchKernelGGL((k_oc_score_q<FPL, true, true>), grid, blk, 0, st, p); else hipLaunchKernelGGL((k_oc_score_q<FPL, false, true>), grid, blk, 0, st, p); }
+      else { if (pow2) hipLaunchKernelGGL((k_oc_score_q<FPL, true>), grid, blk, 0, st, p); else hipLaunchKernelGGL((k_oc_score_q<FPL, false>), grid, blk, 0, st, p); }
+    });
     return check_launch("k_oc_score_q");
   }
   MKE_DISPATCH_FPL(fpl, {
     constexpr int U = FPL <= 5 ? 2 : 1;
-    if (pow2) hipLaunchKernelGGL((k_oc_score<FPL, U, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_oc_score<FPL, U, false>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    if (em) { if (pow2) hipLaunchKernelGGL((k_oc_score<FPL, U, true, true>), grid, blk, 0, st, p); else hipLaunchKernelGGL((k_oc_score<FPL, U, false, true>), grid, blk, 0, st, p); }
+    else { if (pow2) hipLaunchKernelGGL((k_oc_score<FPL, U, true>), grid, blk, 0, st, p); else hipLaunchKernelGGL((k_oc_score<FPL, U, false>), grid, blk, 0, st, p); }
   });
   return check_launch("k_oc_score");
 }
@@ -712,12 +751,15 @@ extern "C" int mke_oc_apply(const mke_oc_step* s, const float* gv, void* stream)
   if (rc) return rc;
   const int64_t subs = s->n_own_h + s->n_own_t;
   if (subs == 0) return MKE_OK;
-  if (!gv || !s->ent_grad || !s->rel_grad || !s->ent_touched || !s->rel_touched) { set_error("mke_oc_apply: NULL pointer"); return MKE_E_NULL; }
+  const bool em = s->em_coef != nullptr;
+  if (!gv || !s->rel_grad || !s->rel_touched || (!em && (!s->ent_grad || !s->ent_touched))) { set_error("mke_oc_apply: NULL pointer"); return MKE_E_NULL; }
   OcParams p{};
   p.s = *s; p.gv = gv;
   const int fpl = s->stride / 16;
+  const dim3 grid((unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK));
   MKE_DISPATCH_FPL(fpl, {
-    hipLaunchKernelGGL((k_oc_apply<FPL>), dim3((unsigned)((subs + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK)), dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    if (em) hipLaunchKernelGGL((k_oc_apply<FPL, false>), grid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_oc_apply<FPL>), grid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, p);
   });
   return check_launch("k_oc_apply");
 }
@@ -734,20 +776,23 @@ extern "C" int mke_oc_run(const mke_oc_step* s, int phases, float* send_block, c
                           const float* gv, double* loss_partials, void* stream) {
   using namespace mke;
   int rc = MKE_OK;
+  if (s && s->em_coef) phases &= ~MKE_OC_COUNT;                              // entity-major: nothing is reference-counted
   const bool both = (phases & MKE_OC_BASES) && (phases & MKE_OC_COUNT);   // one launch: the counting rides with the bases
   if ((phases & MKE_OC_BASES) && (rc = oc_bases_impl(s, send_block, both, stream))) return rc;
   if ((phases & MKE_OC_COUNT) && !both && (rc = mke_oc_count(s, stream))) return rc;
   if ((phases & MKE_OC_SCORE) && (rc = mke_oc_score(s, v_all, block_floats, g_all, loss_partials, stream))) return rc;
   if ((phases & MKE_OC_APPLY) && (rc = mke_oc_apply(s, gv, stream))) return rc;
+  if ((phases & MKE_OC_PASS2) && (rc = mke_oc_pass2(s, stream))) return rc;
   if (phases & MKE_OC_UPDATE) {
     if ((rc = oc_check(s, "mke_oc_run"))) return rc;
-    if (s->optimizer == MKE_OPT_ADAGRAD && (!s->ent_acc || !s->rel_acc)) { set_error("mke_oc_run: Adagrad needs ent_acc and rel_acc"); return MKE_E_NULL; }
+    if (s->optimizer == MKE_OPT_ADAGRAD && ((!s->em_coef && !s->ent_acc) || !s->rel_acc)) { set_error("mke_oc_run: Adagrad needs ent_acc and rel_acc"); return MKE_E_NULL; }
     mke_update_table ut[2] = {};
     ut[0].table = const_cast<float*>(s->rel); ut[0].acc = s->rel_acc; ut[0].grad = s->rel_grad; ut[0].touched = nullptr;
     ut[0].n_rows = s->n_rel; ut[0].normalize = 1; ut[0].grad_copies = s->rel_grad_copies;
     ut[1].table = s->ent; ut[1].acc = s->ent_acc; ut[1].grad = s->ent_grad; ut[1].touched = s->ent_touched;
     ut[1].n_rows = s->n_local; ut[1].normalize = 1; ut[1].grad_copies = 1; ut[1].ref_count = s->ref_count; ut[1].hot = s->hot;
-    if ((rc = launch_rows_update_multi(ut, 2, s->tag, s->stride, s->dim, s->optimizer, s->lr, (hipStream_t)stream, nullptr, nullptr))) return rc;
+    // entity-major: the shard's rows were finished by mke_oc_pass2 — the relation table alone
+    if ((rc = launch_rows_update_multi(ut, s->em_coef ? 1 : 2, s->tag, s->stride, s->dim, s->optimizer, s->lr, (hipStream_t)stream, nullptr, nullptr))) return rc;
   }
   return MKE_OK;
 }

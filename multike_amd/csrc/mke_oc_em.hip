@@ -1,0 +1,368 @@
+// mke_oc_em.hip — entity-major second pass of the owner-computes (multi-GPU) relation-view step (gfx950).
+//
+// New design (the reference is single-device: one dense update per row per step, code/MultiKE_model.py:304-310).  Measured in
+// round 5 (EXPERIMENTS R5.22-R5.26): at 8 ranks a rank's score launch was bound by its atomic row adds (C2: 36 of 49.5 us, C5:
+// 266 of 270 us as empty kernels making the same visits), and k_oc_apply + the update launch then re-read the scratch those
+// atomics filled.  Here the score launch (pass 1, mke_oc.hip with EM = true) stores ONE coefficient per (positive, owned
+// negative) and this file does the rest:
+//   * mke_oc_em_plan (per epoch, table-independent, on the plan's side stream): every reference of every global step to a row
+//     this rank owns — its owned negatives, the positives' own terms it scores, the heads / tails whose gradient vector comes
+//     back by the reduce-scatter — as a 64-bit key (step, local row | positive, kind), sorted (hipcub radix sort, keys only:
+//     the key IS the order, so the result does not depend on how the keys were appended), resolved to (locator, coefficient
+//     index) pairs, with the touched rows of each step and their CSR offsets;
+//   * k_oc_em_pass2 (per global step): a quarter-wave per touched owned row — raw row + accumulator read once, c^ formed once,
+//     ghat = c^ sum coef + sum coef sg V + sum (+-) gv over the row's references in list order, Jacobian of the normalisation,
+//     Adagrad / SGD, row and accumulator written.  No gradient scratch, no touched flags, no reference counts, no atomics;
+//     the summation order per row is the list's: bit-reproducible run to run.
+#include "mke_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace mke {
+
+// kinds of a reference inside its positive (the low 7 bits of the key's descriptor): 0 .. 63 = negative n
+#define EM_KIND_OWN 64      // the positive's own term, scored on this rank
+#define EM_KIND_GV_H 65     // head row <- + gv[HR slot]
+#define EM_KIND_GV_T 66     // tail row <- - gv[RT slot]
+#define EM_KIND_REL_H 67    // relation row (local row n_local + r) <- + gv[HR slot]   (HR = h^ + r^)
+#define EM_KIND_REL_T 68    // relation row <- + gv[RT slot]                             (RT = r^ - t^)
+// locator: bit 31 = gradient vector (gv) instead of a base vector; bits 30:28 chunk; 27:24 owner rank (base vectors) / bit 24 =
+// "always +" (gradient vectors into a relation row); bit 23 RT half; 22:0 slot
+#define EM_LOC_GV 0x80000000u
+#define EM_LOC_PLUS (1u << 24)
+
+struct EmPlanParams {
+  mke_oc_em_plan_args a;
+  int desc_bits;        // 7 + bits(max_step)
+  uint32_t ep;          // elements per positive: neg_per_pos + 5
+  int64_t rows_tot;     // n_local + n_rel: the relation rows follow the shard's rows
+  unsigned long long* cursor;   // == a.n_refs
+};
+
+__device__ __forceinline__ int em_step_of(const int64_t* __restrict__ step_lo, int n_steps, int64_t p) {
+  int lo = 0, hi = n_steps;      // step_lo[lo] <= p < step_lo[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (step_lo[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// One thread per (epoch position, element): the owned ones append their key (wave-aggregated cursor; the order of the
+// appends is irrelevant, the sort that follows is total).
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_keys(const EmPlanParams pp) {
+  const mke_oc_em_plan_args& a = pp.a;
+  const int64_t total = a.n_all * (int64_t)pp.ep;
+  const int64_t nthreads = (int64_t)gridDim.x * MKE_BLOCK;
+  const int64_t iters = (total + nthreads - 1) / nthreads;       // wave-uniform trip count (ballots inside)
+  const int N = a.neg_per_pos, G = a.n_ranks;
+  const int lane = threadIdx.x & 63;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t t = it * nthreads + (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+    bool mine = false;
+    uint64_t key = 0;
+    if (t < total) {
+      const int64_t p = total <= 0xFFFFFFFFll ? (int64_t)((uint32_t)t / pp.ep) : t / pp.ep;
+      const int n = (int)(t - p * pp.ep);
+      int ent = -1, kind = n;
+      if (n < N) {
+        ent = (a.codes[p * N + n] & 0x3FFFFFFF) >> 1;
+      } else if (n == N) {          // own term: the owner of t when HR travels, else the owner of h
+        ent = a.slot_h[p] >= 0 ? a.pos_t[p] : a.pos_h[p];
+        kind = EM_KIND_OWN;
+      } else if (n == N + 1 || n == N + 3) {     // the owner of the head receives sum dL/dHR: head row and relation row
+        if (a.slot_h[p] >= 0) ent = a.pos_h[p];
+        kind = n == N + 1 ? EM_KIND_GV_H : EM_KIND_REL_H;
+      } else {                                   // the owner of the tail receives sum dL/dRT: tail row and relation row
+        if (a.slot_t[p] >= 0) ent = a.pos_t[p];
+        kind = n == N + 2 ? EM_KIND_GV_T : EM_KIND_REL_T;
+      }
+      if (ent >= 0 && (int)((uint32_t)ent % (uint32_t)G) == a.rank) {
+        mine = true;
+        const int s = em_step_of(a.step_lo, a.n_steps, p);
+        const uint64_t row = kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[p] : (uint64_t)((uint32_t)ent / (uint32_t)G);
+        const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
+        const uint64_t desc = ((uint64_t)(p - a.step_lo[s]) << 7) | (uint32_t)kind;
+        key = (srow << pp.desc_bits) | desc;
+      }
+    }
+    const uint64_t m = __ballot(mine);
+    if (m) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(pp.cursor, (unsigned long long)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (mine) {
+        const unsigned long long k = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < (unsigned long long)a.capacity) a.keys[k] = key;
+      }
+    }
+  }
+}
+
+// sorted key k -> (locator, coefficient index) and the "a new (step, row) starts here" flag; entry `capacity` (and every
+// sentinel) is the end marker
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp, const uint64_t* __restrict__ sorted) {
+  const mke_oc_em_plan_args& a = pp.a;
+  const int64_t k = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (k > a.capacity) return;
+  const uint64_t SENT = ~0ull;
+  const uint64_t key = k < a.capacity ? sorted[k] : SENT;
+  const uint64_t prev = k > 0 ? sorted[k - 1] : SENT;
+  if (key == SENT) {
+    a.flags[k] = (k == 0 || prev != SENT) ? 1 : 0;        // the first sentinel closes the last row's list
+    return;
+  }
+  const uint64_t srow = key >> pp.desc_bits;
+  a.flags[k] = (k == 0 || (prev >> pp.desc_bits) != srow) ? 1 : 0;
+  const uint64_t desc = key & ((1ull << pp.desc_bits) - 1ull);
+  const int s = (int)(srow / (uint64_t)pp.rows_tot);
+  const int64_t i = (int64_t)(desc >> 7);
+  const int kind = (int)(desc & 127);
+  const int64_t lo = a.step_lo[s], size = a.step_lo[s + 1] - lo;
+  const int64_t part = (size + a.chunks - 1) / a.chunks;
+  const uint32_t chunk = (uint32_t)(i / (part > 0 ? part : 1));
+  const int64_t p = lo + i;
+  const int N = a.neg_per_pos, G = a.n_ranks;
+  bool rt;
+  uint32_t loc, cidx = 0;
+  if (kind >= EM_KIND_GV_H) {
+    rt = kind == EM_KIND_GV_T || kind == EM_KIND_REL_T;
+    loc = EM_LOC_GV | (kind >= EM_KIND_REL_H ? EM_LOC_PLUS : 0u) | (uint32_t)(rt ? a.slot_t[p] : a.slot_h[p]);
+  } else {
+    if (kind == EM_KIND_OWN) {
+      rt = a.slot_h[p] < 0;                                 // HR travels: d = HR - t^, else d = h^ + RT
+      cidx = (uint32_t)(i * (N + 1) + N);
+    } else {
+      rt = (a.codes[p * N + kind] & 1) != 0;                // corrupted head: d = c^ + RT
+      cidx = (uint32_t)(i * (N + 1) + kind);
+    }
+    const uint32_t owner = (uint32_t)(rt ? a.pos_t[p] : a.pos_h[p]) % (uint32_t)G;
+    loc = (owner << 24) | (uint32_t)(rt ? a.slot_t[p] : a.slot_h[p]);
+  }
+  loc |= (chunk << 28) | (rt ? (1u << 23) : 0u);
+  a.refs[2 * k] = loc;
+  a.refs[2 * k + 1] = cidx;
+}
+
+// flagged k: the scan[k]-th touched (step, row) starts at reference k; step boundaries fall out of the same walk
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_rows(const EmPlanParams pp, const uint64_t* __restrict__ sorted) {
+  const mke_oc_em_plan_args& a = pp.a;
+  const int64_t k = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (k > a.capacity || !a.flags[k]) return;
+  const uint64_t SENT = ~0ull;
+  const uint64_t key = k < a.capacity ? sorted[k] : SENT;
+  const int u = a.scan[k];
+  a.off[u] = (int32_t)k;
+  int s_cur = a.n_steps;
+  if (key != SENT) {
+    const uint64_t srow = key >> pp.desc_bits;
+    s_cur = (int)(srow / (uint64_t)pp.rows_tot);
+    a.rows[u] = (int32_t)(srow - (uint64_t)s_cur * (uint64_t)pp.rows_tot);
+  }
+  const int s_prev = k > 0 ? (int)((sorted[k - 1] >> pp.desc_bits) / (uint64_t)pp.rows_tot) : -1;
+  for (int s = s_prev + 1; s <= s_cur; ++s) a.step_row0[s] = u;
+}
+
+static inline int bits_for(uint64_t v) {   // smallest b with v < 2^b
+  int b = 0;
+  while (b < 64 && (v >> b)) ++b;
+  return b;
+}
+
+// ---- pass 2 -------------------------------------------------------------------------------------------------------------
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) {
+  constexpr int STRIDE = FPL * 16;
+  constexpr int U = FPL <= 8 ? 4 : 2;            // vectors in flight per quarter-wave
+  const int lane = threadIdx.x & 63, j = lane & 15, qb = lane & 48;
+  const int64_t u = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  const bool act = u < s.em_n_rows;
+  const int row = act ? s.em_rows[u] : 0;
+  const int lo = act ? s.em_off[u] : 0, hi = act ? s.em_off[u + 1] : 0;
+  // rows [n_local, n_local + n_rel) are the (replicated) relation table's: this rank's PARTIAL gradient — the sum of the gradient
+  // vectors of its owned slots — is stored (not added: one writer per row and step) for the all-reduce and the relation update
+  const bool is_rel = row >= s.n_local;
+  float* wp = s.ent + (int64_t)row * STRIDE + j;
+  const bool adagrad = s.optimizer == MKE_OPT_ADAGRAD;
+  float* ap = adagrad ? s.ent_acc + (int64_t)row * STRIDE + j : nullptr;
+  float w[FPL], acc[FPL], g[FPL];
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) { w[k] = 0.f; acc[k] = 0.f; g[k] = 0.f; }
+  if (act && !is_rel) {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
+    if (adagrad) {
+#pragma unroll
+      for (int k = 0; k < FPL; ++k) acc[k] = ap[k * 16];
+    }
+  }
+  float csum = 0.f;
+  const int64_t C = s.capacity;
+  for (int base = lo; __ballot(base < hi); base += 16) {     // wave-uniform trip count: the quarters walk their lists together
+    // the quarter's next 16 references, one per lane; their coefficients gathered by the lanes that hold them
+    uint32_t myloc = 0, mycidx = 0;
+    const bool has = base + j < hi;
+    if (has) {
+      const uint2 r = *reinterpret_cast<const uint2*>(s.em_refs + 2 * (int64_t)(base + j));
+      myloc = r.x; mycidx = r.y;
+    }
+    float mycoef = 0.f;
+    if (has && !(myloc & EM_LOC_GV)) mycoef = s.em_coef[mycidx];
+    const int n = min(16, hi - base);                        // <= 0 for a quarter that is done
+    for (int t0 = 0; __ballot(t0 < n); t0 += U) {
+      float V[U][FPL];
+      float wgt[U];
+      uint32_t loc[U];
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        loc[x] = (uint32_t)__shfl((int)myloc, qb + min(t0 + x, 15), 64);
+        const bool live = t0 + x < n;
+        if (live) {
+          const uint32_t l = loc[x];
+          const uint32_t chunk = (l >> 28) & 7u;
+          const bool gvk = (l & EM_LOC_GV) != 0;
+          const float* b0 = gvk ? s.em_gv[0] : s.em_v[0];
+          if (chunk == 1) b0 = gvk ? s.em_gv[1] : s.em_v[1];
+          if (chunk == 2) b0 = gvk ? s.em_gv[2] : s.em_v[2];
+          if (chunk == 3) b0 = gvk ? s.em_gv[3] : s.em_v[3];
+          const int64_t slot = (int64_t)(l & 0x7FFFFFu) + ((l & (1u << 23)) ? C : 0);
+          const float* vp = b0 + (gvk ? 0 : (int64_t)((l >> 24) & 15u) * s.em_block_floats) + slot * STRIDE + j;
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) V[x][k] = vp[k * 16];
+        } else {
+#pragma unroll
+          for (int k = 0; k < FPL; ++k) V[x][k] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        const float c = __shfl(mycoef, qb + min(t0 + x, 15), 64);
+        const bool live = t0 + x < n;
+        const bool rt = (loc[x] & (1u << 23)) != 0;
+        const bool gvk = (loc[x] & EM_LOC_GV) != 0;
+        // base vector: + coef sg V (sg = +1 with RT: d = c^ + RT; -1 with HR: d = HR - c^) and coef to the c^ term;
+        // gradient vector: + gv for a head (HR = h^ + r^), - gv for a tail (RT = r^ - t^)
+        wgt[x] = !live ? 0.f : (gvk ? ((rt && !(loc[x] & EM_LOC_PLUS)) ? -1.0f : 1.0f) : (rt ? c : -c));
+        csum += (live && !gvk) ? c : 0.f;
+      }
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+#pragma unroll
+        for (int k = 0; k < FPL; ++k) g[k] = fmaf(wgt[x], V[x][k], g[k]);
+      }
+    }
+  }
+  if (!act) return;
+  if (is_rel) {
+    float* gp = s.rel_grad + (int64_t)(row - s.n_local) * STRIDE + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) gp[k * 16] = g[k];
+    return;
+  }
+  // ghat = c^ csum + g;  Jacobian of x * rsqrt(max(sum x^2, eps)):  g_raw = (ghat - c^ (c^ . ghat)) * inv
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) ss = fmaf(w[k], w[k], ss);
+  ss = sub16_sum(ss);
+  const float inv = rsqrtf(fmaxf(ss, MKE_L2_EPS));
+  const float ci = csum * inv;
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    g[k] = fmaf(ci, w[k], g[k]);
+    dot = fmaf(w[k], g[k], dot);
+  }
+  dot = sub16_sum(dot);
+  const float coef = (ss > MKE_L2_EPS) ? dot * inv * inv : 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) g[k] = (g[k] - w[k] * coef) * inv;
+  if (adagrad) {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      acc[k] = fmaf(g[k], g[k], acc[k]);
+      w[k] -= s.lr * g[k] * adagrad_scale(acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) ap[k * 16] = acc[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) w[k] -= s.lr * g[k];
+  }
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
+}
+
+}  // namespace mke
+
+extern "C" int64_t mke_oc_em_plan_temp_bytes(int64_t capacity) {
+  if (capacity < 0 || capacity >= 0x7FFFFFFFll) return -1;
+  size_t a = 0, b = 0;
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(capacity + 1), 0, 64, (hipStream_t)0);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(capacity + 1), (hipStream_t)0);
+  return (int64_t)(a > b ? a : b) + 256;
+}
+
+extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
+  using namespace mke;
+  if (!args) { set_error("mke_oc_em_plan: NULL args"); return MKE_E_NULL; }
+  const mke_oc_em_plan_args& a = *args;
+  if (a.n_steps < 0 || a.n_all < 0 || a.neg_per_pos < 0 || a.neg_per_pos > 64 || a.chunks < 1 || a.chunks > MKE_OC_EM_MAX_CHUNKS ||
+      a.n_ranks < 1 || a.n_ranks > MKE_OC_MAX_RANKS || a.rank < 0 || a.rank >= a.n_ranks || a.n_local < 1 || a.n_rel < 1 || a.max_step < 0) {
+    set_error("mke_oc_em_plan: bad n_steps / n_all / neg_per_pos / chunks (1..%d) / ranks / n_local", MKE_OC_EM_MAX_CHUNKS);
+    return MKE_E_SHAPE;
+  }
+  if (a.capacity < 1 || a.capacity >= 0x7FFFFFFFll) { set_error("mke_oc_em_plan: capacity must be in [1, 2^31)"); return MKE_E_RANGE; }
+  if (!a.keys || !a.keys_alt || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
+  if (a.n_all > 0 && (!a.pos_h || !a.pos_r || !a.pos_t || !a.slot_h || !a.slot_t || !a.step_lo || (a.neg_per_pos > 0 && !a.codes))) { set_error("mke_oc_em_plan: NULL input"); return MKE_E_NULL; }
+  if (a.temp_bytes < mke_oc_em_plan_temp_bytes(a.capacity)) { set_error("mke_oc_em_plan: temp storage below mke_oc_em_plan_temp_bytes"); return MKE_E_SHAPE; }
+  if (a.max_step >= (1ll << 25) || a.max_step * (a.neg_per_pos + 1) > 0x7FFFFFFFll) { set_error("mke_oc_em_plan: a global step holds at most 2^25 positives"); return MKE_E_RANGE; }
+  hipStream_t st = (hipStream_t)stream;
+  EmPlanParams pp;
+  pp.a = a;
+  pp.desc_bits = 7 + bits_for((uint64_t)a.max_step);
+  pp.ep = (uint32_t)a.neg_per_pos + 5u;
+  pp.rows_tot = a.n_local + a.n_rel;
+  pp.cursor = reinterpret_cast<unsigned long long*>(a.n_refs);
+  const int srow_bits = bits_for((uint64_t)a.n_steps * (uint64_t)pp.rows_tot + 1ull);   // + 1: an all-ones (step, row) never occurs => the sentinel sorts last
+  if (pp.desc_bits + srow_bits > 64) { set_error("mke_oc_em_plan: steps x rows x positives do not fit a 64-bit key"); return MKE_E_RANGE; }
+  hipError_t e;
+  if ((e = hipMemsetAsync(a.n_refs, 0, sizeof(int64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
+  if ((e = hipMemsetAsync(a.keys, 0xFF, (size_t)(a.capacity + 1) * sizeof(uint64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
+  const int64_t total = a.n_all * (int64_t)pp.ep;
+  if (total > 0) {
+    int64_t blocks = (total + MKE_BLOCK - 1) / MKE_BLOCK;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_em_keys, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, pp);
+    int rc = check_launch("k_em_keys");
+    if (rc) return rc;
+  }
+  size_t tb = (size_t)a.temp_bytes;
+  const int n = (int)(a.capacity + 1);
+  if ((e = hipcub::DeviceRadixSort::SortKeys(a.temp, tb, a.keys, a.keys_alt, n, 0, pp.desc_bits + srow_bits, st)) != hipSuccess) { set_error("mke_oc_em_plan: radix sort: %s", hipGetErrorString(e)); return (int)e; }
+  const dim3 grid((unsigned)((a.capacity + 1 + MKE_BLOCK - 1) / MKE_BLOCK));
+  hipLaunchKernelGGL(k_em_resolve, grid, dim3(MKE_BLOCK), 0, st, pp, (const uint64_t*)a.keys_alt);
+  int rc = check_launch("k_em_resolve");
+  if (rc) return rc;
+  tb = (size_t)a.temp_bytes;
+  if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, a.flags, a.scan, n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(k_em_rows, grid, dim3(MKE_BLOCK), 0, st, pp, (const uint64_t*)a.keys_alt);
+  return check_launch("k_em_rows");
+}
+
+extern "C" int mke_oc_pass2(const mke_oc_step* s, void* stream) {
+  using namespace mke;
+  if (!s) { set_error("mke_oc_pass2: NULL step"); return MKE_E_NULL; }
+  if (!s->em_coef) { set_error("mke_oc_pass2: the step is not entity-major (em_coef == NULL)"); return MKE_E_UNSUPPORTED; }
+  if (s->stride <= 0 || s->stride % 16 != 0 || s->dim <= 0 || s->dim > s->stride || s->stride > MKE_MAX_STRIDE) { set_error("mke_oc_pass2: bad stride/dim"); return MKE_E_SHAPE; }
+  if (s->em_n_rows < 0 || s->em_chunks < 1 || s->em_chunks > MKE_OC_EM_MAX_CHUNKS || s->n_peers) { set_error("mke_oc_pass2: bad em_n_rows / em_chunks, or peer-direct"); return MKE_E_SHAPE; }
+  if (s->em_n_rows == 0) return MKE_OK;
+  if (!s->em_refs || !s->em_rows || !s->em_off || !s->ent || !s->rel_grad) { set_error("mke_oc_pass2: NULL reference lists / table"); return MKE_E_NULL; }
+  for (int c = 0; c < s->em_chunks; ++c)
+    if (!s->em_v[c] || !s->em_gv[c]) { set_error("mke_oc_pass2: NULL vector block of chunk %d", c); return MKE_E_NULL; }
+  if (s->optimizer != MKE_OPT_ADAGRAD && s->optimizer != MKE_OPT_SGD) { set_error("mke_oc_pass2: Adagrad or SGD"); return MKE_E_UNSUPPORTED; }
+  if (s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_pass2: Adagrad needs ent_acc"); return MKE_E_NULL; }
+  const int fpl = s->stride / 16;
+  const dim3 grid((unsigned)((s->em_n_rows + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK));
+  MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_em_pass2<FPL>), grid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, *s); });
+  return check_launch("k_oc_em_pass2");
+}

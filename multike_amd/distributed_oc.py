@@ -90,11 +90,33 @@ class OcHipBackend:
         """slots, owned lists and per-(part, owner) counts of the whole epoch in ONE launch (mke_oc_plan)."""
         _lib.oc_plan(pos_h, pos_t, codes, neg_per_pos, part_lo, n_parts, n_ranks, rank, slot_h, slot_t, own_h, own_t, counts)
 
+    def em_plan(self, tr, ph, pr, pt, codes, slot, bufs):
+        """mke_oc_em_plan: the epoch's references to this rank's rows sorted by (step, row, positive, kind), the touched rows of
+        every global step and their CSR offsets (entity-major second pass) — one native call, nothing synchronises."""
+        i32, i64 = torch.int32, torch.int64
+        a = _lib.OcEmPlanArgs()
+        a.pos_h, a.pos_r, a.pos_t = _lib.ptr(ph, i32, "pos"), _lib.ptr(pr, i32, "pos"), _lib.ptr(pt, i32, "pos")
+        a.codes, a.neg_per_pos = _lib.ptr(codes, i32, "codes"), tr.N
+        a.slot_h, a.slot_t = _lib.ptr(slot[0], i32, "slot"), _lib.ptr(slot[1], i32, "slot")
+        a.step_lo, a.n_steps, a.chunks = _lib.ptr(tr._step_lo, i64, "step_lo"), tr.steps, tr.chunks
+        a.n_all, a.max_step = tr._n_all, tr._max_step
+        a.n_ranks, a.rank, a.n_local, a.n_rel = tr.world, tr.rank, max(1, tr.n_local), tr.rel.shape[0]
+        a.keys, a.keys_alt, a.capacity = _lib.ptr(bufs["keys"], i64, "keys"), _lib.ptr(bufs["keys_alt"], i64, "keys"), bufs["capacity"]
+        a.refs, a.rows, a.off = _lib.ptr(bufs["refs"], i32, "refs"), _lib.ptr(bufs["rows"], i32, "rows"), _lib.ptr(bufs["off"], i32, "off")
+        a.flags, a.scan = _lib.ptr(bufs["flags"], i32, "flags"), _lib.ptr(bufs["scan"], i32, "scan")
+        a.step_row0, a.n_refs = _lib.ptr(bufs["row0"], i64, "row0"), _lib.ptr(bufs["n_refs"], i64, "n_refs")
+        a.temp, a.temp_bytes = _lib.ptr(bufs["temp"], torch.uint8, "temp"), bufs["temp"].numel()
+        _lib.oc_em_plan(a)
+
+    def em_temp_bytes(self, capacity):
+        return _lib.oc_em_plan_temp_bytes(capacity)
+
     def _struct(self, tr: "OwnerComputesTrainer", st: OcStep):
         f32, i32 = torch.float32, torch.int32
         s = _lib.OcStepStruct()
         s.ent, s.ent_acc = _lib.ptr(tr.ent, f32, "ent"), _lib.ptr(tr.ent_acc, f32, "acc")
-        s.ent_grad, s.ent_touched = _lib.ptr(tr.ent_grad, f32, "grad"), _lib.ptr(tr.ent_touched, i32, "touched")
+        s.ent_grad = _lib.ptr(tr.ent_grad, f32, "grad") if tr.ent_grad is not None else None      # entity-major: no entity scratch
+        s.ent_touched = _lib.ptr(tr.ent_touched, i32, "touched") if tr.ent_touched is not None else None
         s.ref_count = _lib.ptr(tr.ref_count, i32, "ref_count") if tr.ref_count is not None else None
         s.n_local = tr.n_local
         s.rel, s.rel_grad = _lib.ptr(tr.rel, f32, "rel"), _lib.ptr(tr.rel_grad, f32, "rel_grad")
@@ -143,8 +165,10 @@ class OcHipBackend:
             self._steps = []
             return
         oh, ot = _lib.ptr(tr._own[0], i32, "own"), _lib.ptr(tr._own[1], i32, "own")
+        em = tr._em if tr.em else None
         key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts),
-               tr._peer_send[0].data_ptr() if tr.peer_direct and tr.world > 1 else 0)
+               tr._peer_send[0].data_ptr() if tr.peer_direct and tr.world > 1 else 0,
+               (em["refs"].data_ptr(), em["rows"].data_ptr(), em["off"].data_ptr(), tr._em_coef.data_ptr()) if em else 0)
         cache = self.__dict__.setdefault("_tables", {})
         if key in cache:                                  # the two epoch buffer sets alternate: one table each
             self._steps = cache[key]
@@ -165,6 +189,13 @@ class OcHipBackend:
                 s.per = max(1, -(-(hi - lo) // tr.world))
                 for g in range(tr.world):
                     s.code_off[g] = (lo + g * int(s.per)) * tr.N      # codes are laid out by epoch position
+                if em:      # entity-major: the step's coefficient buffer, this part's first positive in it, the chunks' vector blocks
+                    step = tr._parts[k][0]
+                    s.em_coef, s.em_pos0 = tr._em_coef.data_ptr(), lo - int(b.off[step])
+                    s.em_refs = em["refs"].data_ptr()
+                    s.em_chunks, s.em_block_floats = len(tr._parts_of[step]), tr.block
+                    for c in range(int(s.em_chunks)):
+                        s.em_v[c], s.em_gv[c] = tr._addr[c][1], tr._addr[c][3]
                 out.append(s)
             if len(cache) > 4:
                 cache.clear()
@@ -175,6 +206,11 @@ class OcHipBackend:
         for k, (s, (_, lo, _hi)) in enumerate(zip(self._steps, tr._parts)):     # a part's owned list starts at the part's own offset
             s.own_h, s.n_own_h = oh + 4 * lo, cnth[k]
             s.own_t, s.n_own_t = ot + 4 * lo, cntt[k]
+        if em:              # the touched rows of each global step: positions change from epoch to epoch
+            r0 = em["row0_host"].tolist()
+            rp, op = em["rows"].data_ptr(), em["off"].data_ptr()
+            for s, (step, _, _) in zip(self._steps, tr._parts):
+                s.em_rows, s.em_off, s.em_n_rows = rp + 4 * r0[step], op + 4 * r0[step], r0[step + 1] - r0[step]
 
     def bases(self, tr, st, send):
         _lib.oc_bases(self._cached(tr, st), send)
@@ -206,7 +242,7 @@ class OcHipBackend:
         _lib.oc_run(s, phases, a[0], a[1], tr.block, a[2], a[3], self._ring + loss_slot * self._ring_stride)
 
 
-BASES, COUNT, SCORE, APPLY, UPDATE = _lib.OC_BASES, _lib.OC_COUNT, _lib.OC_SCORE, _lib.OC_APPLY, _lib.OC_UPDATE
+BASES, COUNT, SCORE, APPLY, UPDATE, PASS2 = _lib.OC_BASES, _lib.OC_COUNT, _lib.OC_SCORE, _lib.OC_APPLY, _lib.OC_UPDATE, _lib.OC_PASS2
 
 
 class OcComm:
@@ -482,7 +518,8 @@ class OwnerComputesTrainer:
                  seed: int = 0, lr: float = 0.001, backend=None, device=None, dtype=torch.float32, comm=None,
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
                  batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None, ent_table=None, rel_table=None,
-                 opt_name: str = "relation", n_ent: int = None, tag_base: int = None, global_batch: int = None):
+                 opt_name: str = "relation", n_ent: int = None, tag_base: int = None, global_batch: int = None,
+                 entity_major: bool = None):
         """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
         loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
         with); scale: the loss factor (2 for code/MultiKE_model.py:349-369); tables_of: another trainer of the same
@@ -490,6 +527,7 @@ class OwnerComputesTrainer:
         share their variables and have one optimizer each (code/MultiKE_model.py:17-31): shared tables and (zero-invariant)
         gradient / flag scratch, own Adagrad accumulators, own tag range; `ent0` / `rel0` are then unused."""
         self.scale = float(scale)
+        self._em_request = entity_major
         # ent_table / rel_table (multike_amd.tables.EmbeddingTable: this rank's shard of `n_ent` global rows, and the
         # replicated relation table): train THOSE — the trainer then shares them with whatever else holds them (other
         # trainers, the common-space step of multike_amd.distributed_views) and takes its Adagrad slot by `opt_name`.
@@ -531,6 +569,17 @@ class OwnerComputesTrainer:
         self.peer_direct = bool(peer_direct) and world > 1
         if self.peer_direct:
             self.chunks = 1
+        # ENTITY-MAJOR second pass (round 6): the score launch stores one coefficient per (positive, owned negative),
+        # mke_oc_pass2 finishes every touched owned row in place from the row's reference list of the epoch plan — no gradient
+        # scratch, flags, reference counts, hub-row copies or atomics on entity rows, results bit-reproducible run to run.  The
+        # default of the HIP backend (MKE_OC_EM=0 / entity_major=False: the atomics form of rounds 2-5); not with peer-direct.
+        em = self._em_request
+        if em is None:
+            em = _os.environ.get("MKE_OC_EM", "1") != "0"
+        self.em = bool(em) and hasattr(self.backend, "em_plan") and not self.peer_direct and self.chunks <= _lib.OC_EM_MAX_CHUNKS \
+            and dtype == torch.float32
+        if self.em:
+            exclusive_rows = False
         dev, st = self.device, self.stride
         i32 = dict(dtype=torch.int32, device=dev)
         # --- row-sharded entity state ---------------------------------------------------------------
@@ -559,7 +608,7 @@ class OwnerComputesTrainer:
             self.ent[:self.n_local, :self.dim] = torch.as_tensor(ent0[mine], dtype=dtype, device=dev)
             self.ent_grad = None                    # allocated by _declare_hot_rows (with the hub rows' copies behind the shard's rows)
             self._mk_rows = mk
-            self.ent_touched = torch.zeros(max(1, self.n_local), **i32)
+            self.ent_touched = None if self.em else torch.zeros(max(1, self.n_local), **i32)
             self.ref_count = torch.zeros(max(1, self.n_local), **i32) if exclusive_rows else None
             # --- replicated relation state ----------------------------------------------------------
             self.rel = torch.zeros(rel0.shape[0], st, dtype=dtype, device=dev)
@@ -569,7 +618,7 @@ class OwnerComputesTrainer:
             # ways (slot k adds to copy k % copies; the all-reduce carries the copies, the update sums them) while that stays
             # under 1 MB on the wire — beyond (2K relations x 256 floats) one copy: the all-reduce would cost more than it saves
             copies = 1
-            if self.backend.device_type == "cuda" and dtype == torch.float32:
+            if self.backend.device_type == "cuda" and dtype == torch.float32 and not self.em:    # entity-major: one writer per relation row
                 copies = max(1, min(self.REL_COPIES, (1 << 20) // max(1, self.rel.numel() * 4)))
             self.rel_grad = torch.zeros_like(self.rel) if copies == 1 else torch.zeros((copies,) + tuple(self.rel.shape), dtype=dtype, device=dev)
             self.rel_touched = torch.zeros(rel0.shape[0], **i32)
@@ -610,6 +659,7 @@ class OwnerComputesTrainer:
         self.loss_ring = torch.zeros(max(1, self.steps) * self.chunks, _lib.LOSS_PARTIALS, dtype=torch.float64, device=dev)
         self.score_events = None  # set to a list to collect (start, end, triples) HIP events of the score kernel
         self.C = 0
+        self._em_capacity = {}
         self._dtype = dtype
         self._planned_epoch = -1
         self._stepped = -1
@@ -621,6 +671,10 @@ class OwnerComputesTrainer:
         """hot_slot (int32 [n_local]: index among this rank's hub rows or -1), n_hot, and the gradient scratch with the copies
         behind the shard's own rows.  Performance only: any row may or may not be declared (the arithmetic is the same sum)."""
         self.hot_slot, self.n_hot, self.ent_grad_rows = None, 0, max(1, self.n_local)
+        if self.em:                                         # entity-major: no entity scratch at all, nothing to privatise
+            if ent_table is None and tables_of is None:
+                self.ent_grad_full = self.ent_grad = None
+            return
         if tables_of is not None:                           # shared scratch: the declaration comes with it
             self.hot_slot, self.n_hot, self.HOT_COPIES = tables_of.hot_slot, tables_of.n_hot, tables_of.HOT_COPIES
             return
@@ -683,6 +737,9 @@ class OwnerComputesTrainer:
         self._parts_of = {}
         for k, (ps, _, _) in enumerate(parts):
             self._parts_of.setdefault(ps, []).append(k)
+        off = np.asarray(b.off[:self.steps + 1], dtype=np.int64) if self.steps else np.zeros(1, dtype=np.int64)
+        self._step_lo = torch.as_tensor(off, device=dev)                       # [steps + 1] epoch positions of the global steps
+        self._max_step = int((off[1:] - off[:-1]).max()) if self.steps else 0
 
     # ---- per-epoch plan: table-independent, so the NEXT epoch's is computed on a side stream while this epoch trains -----
     def _compute_plan(self, pos, rng_stream, bs):
@@ -761,10 +818,51 @@ class OwnerComputesTrainer:
                 self._persistent[("cnt_host", bs)] = host
             host.copy_(c, non_blocking=True)
             plan["cnt_host"] = host
+        if self.em:
+            plan["em"] = self._compute_em_plan(ph, pr, pt, codes, slot, bs)
         if dev.type == "cuda":
             plan["event"] = torch.cuda.Event()
             plan["event"].record()
         return plan
+
+    def _em_buffers(self, bs, capacity):
+        """Scratch (shared by the two buffer sets: plans are computed one at a time on one stream) and outputs (per buffer set)
+        of the entity-major plan at `capacity` references."""
+        dev = self.device
+        i32, i64 = dict(dtype=torch.int32, device=dev), dict(dtype=torch.int64, device=dev)
+        z32, z64 = torch.zeros(0, **i32), torch.zeros(0, **i64)
+        out = {"capacity": capacity}
+        out["keys"] = self._persist(("em_keys",), z64, capacity + 1)
+        out["keys_alt"] = self._persist(("em_keys_alt",), z64, capacity + 1)
+        out["flags"] = self._persist(("em_flags",), z32, capacity + 1)
+        out["scan"] = self._persist(("em_scan",), z32, capacity + 1)
+        out["temp"] = self._persist(("em_temp",), torch.zeros(0, dtype=torch.uint8, device=dev), self.backend.em_temp_bytes(capacity))
+        out["refs"] = self._persist(("em_refs", bs), z32, 2 * capacity)
+        out["rows"] = self._persist(("em_rows", bs), z32, capacity)
+        out["off"] = self._persist(("em_off", bs), z32, capacity + 1)
+        out["row0"] = self._persist(("em_row0", bs), z64, self.steps + 1)
+        out["n_refs"] = self._persist(("em_n_refs", bs), z64, 1)
+        return out
+
+    def _compute_em_plan(self, ph, pr, pt, codes, slot, bs, capacity=None):
+        """The entity-major reference lists of the epoch in buffer set `bs` (device work only; the touched-row offsets of the
+        steps and the reference count go to pinned host memory asynchronously, read by `_finish_plan`)."""
+        G, N = self.world, self.N
+        upper = max(1, self._n_all * (N + 5))                          # every element of every positive
+        if capacity is None:
+            capacity = self._em_capacity.get(bs, 0)
+            if not capacity:                                           # 1 / G of the epoch's references + slack (uniform corruptions)
+                capacity = upper if G == 1 else min(upper, int(1.25 * self._n_all * (N + 3) / G) + 4096)
+        self._em_capacity[bs] = capacity
+        bufs = self._em_buffers(bs, capacity)
+        self.backend.em_plan(self, ph, pr, pt, codes, slot, bufs)
+        host = self._persistent.get(("em_host", bs))
+        if host is None or host.numel() != self.steps + 2:
+            host = self._persistent[("em_host", bs)] = torch.empty(self.steps + 2, dtype=torch.int64, pin_memory=self.device.type == "cuda")
+        host[:self.steps + 1].copy_(bufs["row0"][:self.steps + 1], non_blocking=True)
+        host[self.steps + 1:].copy_(bufs["n_refs"][:1], non_blocking=True)
+        bufs["host"] = host
+        return bufs
 
     def _finish_plan(self, plan):
         """Make a computed plan the current one: wait for its counts (the only host synchronisation of an epoch), size the
@@ -800,6 +898,22 @@ class OwnerComputesTrainer:
                 self._map_peers(gb)
             self._addr = [tuple(t.data_ptr() for t in (self._send[c], self._v_all[c], self._g_all[c], self._gv[c]))
                           for c in range(self.chunks)]
+        if self.em:
+            em = plan["em"]
+            n_refs = int(em["host"][self.steps + 1])
+            if n_refs > em["capacity"]:        # more references than the 1 / G estimate allowed for (skewed ownership): re-plan in line, exactly
+                b = self.bat
+                pos = (b.pos_h, b.pos_r, b.pos_t)
+                em = self._compute_em_plan(pos[0], pos[1], pos[2], plan["codes"], plan["slot"], plan["bs"], capacity=int(n_refs * 1.1) + 4096)
+                if dev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+                n_refs = int(em["host"][self.steps + 1])
+            em["row0_host"] = em["host"][:self.steps + 1].clone()
+            em["n_refs_host"] = n_refs
+            self._em = em
+            need_coef = max(1, self._max_step * (self.N + 1))
+            if getattr(self, "_em_coef", None) is None or self._em_coef.numel() < need_coef:
+                self._em_coef = torch.zeros(need_coef, dtype=torch.float32, device=dev)
         self._planned_epoch = self.bat.epoch
         self._plan_bs = plan["bs"]
         self._st_cache = {}
@@ -919,6 +1033,10 @@ class OwnerComputesTrainer:
         tag = self.tag
         ev = self.score_events
         slot0 = s * self.chunks
+        if self.em:
+            self._step_em(s, ks, tag, slot0)
+            self._stepped = i
+            return
         if G == 1 and not self.force_collectives:  # every row is local: no collective between the phases
             last = len(ks) - 1
             if last == 0 and ev is None:
@@ -981,11 +1099,68 @@ class OwnerComputesTrainer:
             be.run(self, ks[-1], tag, UPDATE, 0, slot0)
         self._stepped = i
 
+    def _step_em(self, s, ks, tag, slot0):
+        """Global step s in the entity-major form: per part  bases -> ALL-GATHER -> score (one coefficient per owned negative,
+        the partial gradient vectors) -> REDUCE-SCATTER;  then ONE second pass over the touched owned rows of the whole step
+        (mke_oc_pass2: finishes the entity rows in place, stores this rank's partial relation gradient), the relation gradient's
+        ALL-REDUCE and the relation table's update."""
+        be, G, cm, ev = self.backend, self.world, self.comm, self.score_events
+        if not ks:
+            return
+        last = len(ks) - 1
+
+        def score(c, k, share):
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            be.run(self, k, tag, SCORE, c, slot0 + c)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1, (self._parts[k][2] - self._parts[k][1]) * (1 + self.N) // share))
+
+        if G == 1 and not self.force_collectives:        # every row is local: no collective between the phases
+            if last == 0 and ev is None:
+                be.run(self, ks[0], tag, BASES | SCORE | PASS2 | UPDATE, 0, slot0)
+                return
+            for c, k in enumerate(ks):
+                be.run(self, k, tag, BASES, c, slot0 + c)
+                score(c, k, 1)
+            be.run(self, ks[-1], tag, PASS2 | UPDATE, 0, slot0)
+            return
+        pipelined = len(ks) > 1 and self.device.type == "cuda"
+        works = {}
+        for c, k in enumerate(ks):
+            be.run(self, k, tag, BASES, c, slot0 + c)
+            works[("ag", c)] = cm.all_gather(self._v_all[c], self._send[c], async_op=pipelined)
+        for c, k in enumerate(ks):
+            if works.get(("ag", c)) is not None:
+                works[("ag", c)].wait()
+            score(c, k, G)
+            works[("rs", c)] = cm.reduce_scatter(self._gv[c], self._g_all[c], async_op=pipelined)
+        for c in range(len(ks)):
+            if works.get(("rs", c)) is not None:
+                works[("rs", c)].wait()
+        be.run(self, ks[-1], tag, PASS2, 0, slot0)              # every part's vectors and gradient vectors are in place
+        cm.all_reduce(self.rel_grad)                            # this rank's partial relation gradient, stored by the second pass
+        be.run(self, ks[-1], tag, UPDATE, 0, slot0)
+
     # ------------------------------------------------------------------------------------------------
     def check(self) -> dict:
         """Capacity is fixed per epoch from the data before the epoch runs (`_plan_epoch`): nothing to flag."""
         return {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks,
                 "vectors_per_positive": self.vectors_planned / max(1, self._n_all)}
+
+    def scratch_clean(self) -> bool:
+        """The zero invariants between steps: gradient scratch all zero, reference counts all zero (the entity-major form has
+        no entity scratch and no counts: only the relation gradient)."""
+        ok = float(self.rel_grad.abs().max()) == 0.0
+        g = getattr(self, "ent_grad_full", None)
+        g = g if g is not None else self.ent_grad
+        if g is not None:
+            ok = ok and float(g.abs().max()) == 0.0
+        if self.ref_count is not None:
+            ok = ok and int(self.ref_count.abs().sum()) == 0
+        return ok
 
     def gather_entity_table(self) -> torch.Tensor:
         """Reassemble the full [n_ent, dim] raw table on every rank (tests / checkpoint)."""

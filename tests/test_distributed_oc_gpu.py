@@ -48,7 +48,7 @@ def _reference(world, steps, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, zipf=0.0):
     return e, r, losses, bat.steps
 
 
-def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, peer=False, zipf=0.0, hot_min=None):
+def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg=NEG, b=B, peer=False, zipf=0.0, hot_min=None, em=None):
     from multike_amd.distributed_oc import OwnerComputesTrainer
     from multike_amd.synthetic import SyntheticKGs
     kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED, zipf=zipf)
@@ -59,33 +59,35 @@ def _make(rank, world, comm=None, chunks=1, excl=True, n_ent=N_ENT, dim=DIM, neg
     if hot_min is not None:             # the hub-row threshold of the shard (references per global step)
         cls = type("T", (OwnerComputesTrainer,), {"HOT_MIN": float(hot_min)})
     return cls(kgs, ent0, rel0, b, neg, rank, world, seed=SEED, lr=0.02, comm=comm, chunks=chunks,
-                                exclusive_rows=excl, peer_direct=peer)
+                                exclusive_rows=excl, peer_direct=peer, entity_major=em)
 
 
+@pytest.mark.parametrize("em", [True, False])   # entity-major second pass (round 6, the default) / the atomics form of rounds 2-5
 @pytest.mark.parametrize("chunks,excl,dim,neg", [(1, True, 75, 8), (2, True, 75, 25), (1, False, 75, 8), (1, True, 256, 64),
                                                   (3, True, 20, 1),
                                                   (1, True, 75, 0)])   # positives only: the shape of the cross-KG loops
-def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg):
+def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg, em):
     """G = 1: every vector / code / gradient slot is local; the kernels alone against the float64 dense oracle over the
     first epoch's steps (the oracle's CPU batcher and the device batcher draw different permutations at the epoch
     boundary; that boundary is covered by the next test)."""
     n_ent = 3000 if dim < 256 else 1200
     _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
     steps = min(spe, 9)
-    tr = _make(0, 1, chunks=chunks, excl=excl, n_ent=n_ent, dim=dim, neg=neg)
+    tr = _make(0, 1, chunks=chunks, excl=excl, n_ent=n_ent, dim=dim, neg=neg, em=em)
+    assert tr.em == em
     for i in range(steps):
         tr.step(i)
     e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
     np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
     np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
-    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
-    assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
+    assert tr.scratch_clean()
     assert tr.stride == dim or float(tr.ent[:, dim:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("em", [True, False])
 @pytest.mark.parametrize("excl,dim,neg", [(True, 75, 8), (True, 75, 25), (False, 75, 33), (True, 256, 64), (True, 20, 1), (True, 75, 0)])
-def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg):
+def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg, em):
     """k_oc_score_q (a quarter-wave per positive, four positives per wavefront: the multi-rank shapes' kernel) forced on at one rank
     — every negative owned, so the per-quarter chains are as long as they get; codes in chunks of 16 (neg 25, 33, 64 span several),
     ragged last wavefronts — against the same float64 dense oracle as the wavefront-per-positive kernel."""
@@ -95,7 +97,7 @@ def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg):
     steps = min(spe, 7)
     old = _lib.set_option("oc_score_quarter", 1)
     try:
-        tr = _make(0, 1, excl=excl, n_ent=n_ent, dim=dim, neg=neg)
+        tr = _make(0, 1, excl=excl, n_ent=n_ent, dim=dim, neg=neg, em=em)
         for i in range(steps):
             tr.step(i)
         torch.cuda.synchronize()
@@ -105,12 +107,12 @@ def test_quarter_wave_score_kernel_equals_dense_oracle(excl, dim, neg):
     np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
     np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
-    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
-    assert tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0
+    assert tr.scratch_clean()
 
 
+@pytest.mark.parametrize("em", [True, False])
 @pytest.mark.parametrize("quarter,dim,neg", [(0, 75, 8), (1, 75, 8), (0, 20, 25), (1, 20, 25)])
-def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg):
+def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg, em):
     """A 60-entity KG: the sampler's re-draw rounds (known-triple hits) are frequent, their coin falls on the other side for half
     of them, so a fifth of the positives need BOTH HR and RT on the wire while the rest need one (slot -1 for the other) — the
     three cases of the one-vector-per-positive exchange in one step, both score kernels, against the dense float64 oracle."""
@@ -120,7 +122,7 @@ def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg):
     steps = min(spe, 6)
     old = _lib.set_option("oc_score_quarter", quarter)
     try:
-        tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg)
+        tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg, em=em)
         vpp = tr.check()["vectors_per_positive"]
         assert 1.05 < vpp < 1.6, vpp
         slots = torch.stack([tr._slot[0][:tr._n_all], tr._slot[1][:tr._n_all]])
@@ -134,8 +136,7 @@ def test_positives_needing_both_vectors_equal_dense_oracle(quarter, dim, neg):
     np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
     np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
-    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
-    assert int(tr.ref_count.abs().sum()) == 0
+    assert tr.scratch_clean()
 
 
 @pytest.mark.parametrize("quarter", [0, 1])
@@ -156,12 +157,12 @@ def test_hub_rows_of_the_shard_are_the_same_function(quarter):
         for hot_min in (20.0, 1e9):
             class T(OwnerComputesTrainer):
                 HOT_MIN = hot_min
-            tr = T(kgs, ent0, rel0, b, neg, 0, 1, seed=SEED, lr=0.02)
+            tr = T(kgs, ent0, rel0, b, neg, 0, 1, seed=SEED, lr=0.02, entity_major=False)
             assert (tr.n_hot > 0) == (hot_min < 1e9), tr.n_hot
             for i in range(min(tr.steps, 8)):
                 tr.step(i)
             torch.cuda.synchronize()
-            assert float(tr.ent_grad_full.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+            assert tr.scratch_clean()
             out.append((tr.epoch_loss(), tr.gather_entity_table().cpu().numpy(), tr.rel[:, :dim].cpu().numpy(), tr.n_hot))
     finally:
         _lib.set_option("oc_score_quarter", old)
@@ -169,6 +170,46 @@ def test_hub_rows_of_the_shard_are_the_same_function(quarter):
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-4, atol=1e-5)   # the same float32 sums in two orders
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-4, atol=1e-5)   # the same float32 sums in two orders
+
+
+def test_entity_major_hub_entities_equal_dense_oracle():
+    """Zipf(1.2) head / tail entities under the entity-major second pass: a few rows (and relation rows) have reference lists of
+    dozens to hundreds of entries per step — walked in list order by their quarter-wave — against the float64 dense oracle."""
+    n_ent, dim, neg, b = 4000, 75, 8, 512
+    _, _, _, spe = _reference(1, 1, n_ent, dim, neg, b, zipf=1.2)
+    steps = min(spe, 6)
+    tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg, b=b, zipf=1.2, em=True)
+    longest = int((tr._em["off"][1:tr._em["row0_host"][-1] + 1] - tr._em["off"][:tr._em["row0_host"][-1]]).max())
+    assert longest > 64, longest                   # lists that span several 16-reference rounds
+    for i in range(steps):
+        tr.step(i)
+    e, r, losses, _ = _reference(1, steps, n_ent, dim, neg, b, zipf=1.2)
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert tr.scratch_clean()
+
+
+@pytest.mark.parametrize("chunks,quarter", [(1, 0), (2, 1)])
+def test_entity_major_step_is_bit_reproducible(chunks, quarter):
+    """The entity-major step has no atomics on table rows: every row's gradient is summed in its reference list's order (the
+    epoch plan sorts by (step, row, positive, kind)), the relation rows' partial gradients likewise — two runs from the same
+    state give the same BITS (tables, accumulators and the epoch loss), across an epoch boundary.  (The atomics form of rounds
+    2-5 differs from run to run in the last bits.)"""
+    from multike_amd import _lib
+    old = _lib.set_option("oc_score_quarter", quarter)
+    try:
+        out = []
+        for _ in range(2):
+            tr = _make(0, 1, chunks=chunks, neg=25, em=True)
+            for i in range(tr.steps + 2):
+                tr.step(i)
+            torch.cuda.synchronize()
+            out.append((tr.ent.clone(), tr.ent_acc.clone(), tr.rel.clone(), tr.rel_acc.clone(), tr.loss_ring.clone()))
+    finally:
+        _lib.set_option("oc_score_quarter", old)
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("chunks", [1, 2])
@@ -207,18 +248,18 @@ def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), R.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG):
+def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG, em=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
-        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer, neg=neg)
+        tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer, neg=neg, em=em)
         for i in range(steps):
             tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
-        ok = float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+        ok = tr.scratch_clean()
         loss = tr.epoch_loss()
         if rank == 0:
             ret.put((full, tr.rel[:, :DIM].cpu().numpy().copy(), loss, ok))
@@ -227,8 +268,10 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG)
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks,peer,neg", [(1, False, NEG), (2, False, NEG), (1, True, NEG), (1, False, 0)])   # neg 0: positives only
-def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg):
+@pytest.mark.parametrize("chunks,peer,neg,em", [(1, False, NEG, True), (2, False, NEG, True), (1, False, 0, True),
+                                                (1, False, NEG, False), (2, False, NEG, False), (1, True, NEG, False),
+                                                (1, False, 0, False)])   # neg 0: positives only
+def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em):
     """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
     negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
     import torch.multiprocessing as mp
@@ -239,7 +282,7 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg):
     ret = ctx.Queue()
     # peer = True: no all-gather / reduce-scatter — each process maps the other's send block and gradient inbox (IPC) and the
     # score kernel reads / writes them directly
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer, neg)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer, neg, em)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, ok = ret.get(timeout=480)
@@ -339,7 +382,7 @@ def test_one_rank_cross_kg_positive_steps_equal_dense_oracle(weighted):
     np.testing.assert_allclose(tr.epoch_loss(), sum(losses[2:]), rtol=2e-6)   # the ring keeps the last 3 steps
     np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(tr.rel[:, :DIM].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
-    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0
+    assert tr.scratch_clean()
 
 
 def _ck_two_rank_worker(rank, world, port, ret, steps, weighted):
@@ -415,7 +458,7 @@ def test_relation_group_on_shared_tables_one_rank():
     np.testing.assert_allclose(lb, tot, rtol=2e-6)
     np.testing.assert_allclose(a.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(a.rel[:, :DIM].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
-    assert float(a.ent_grad.abs().max()) == 0.0 and float(a.rel_grad.abs().max()) == 0.0 and int(a.ref_count.abs().sum()) == 0
+    assert a.scratch_clean()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -472,7 +515,7 @@ def _c5_full_size(rank, world, comm, steps=2):
     mask = torch.ones(tr.ent.shape[0], dtype=torch.bool, device="cuda")
     mask[loc] = False
     assert torch.equal(tr.ent[mask], shard0[mask])                       # the shard's untouched rows: bit-identical
-    assert float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0 and int(tr.ref_count.abs().sum()) == 0
+    assert tr.scratch_clean()
     moved = float((tr.ent[loc] - shard0[loc]).abs().max())
     assert moved > 0.0
     return dict(rank=rank, used=int(len(used)), owned=int(len(mine)), loss=loss, oracle_loss=exp)

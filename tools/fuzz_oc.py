@@ -21,8 +21,7 @@ def worker(rank, world, rdv, ret, kw, steps):
         for i in range(steps):
             tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
-        ok = float(tr.ent_grad.abs().max()) == 0.0 and float(tr.rel_grad.abs().max()) == 0.0 and \
-            (tr.ref_count is None or int(tr.ref_count.abs().sum()) == 0)
+        ok = tr.scratch_clean()
         loss = tr.epoch_loss()
         if rank == 0:
             ret.put((full, tr.rel[:, :kw["dim"]].cpu().numpy().copy(), loss, ok))

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from multike_amd import _lib
-from multike_amd.distributed_oc import APPLY, BASES, COUNT, SCORE, UPDATE, OcComm, OwnerComputesTrainer
+from multike_amd.distributed_oc import APPLY, BASES, COUNT, PASS2, SCORE, UPDATE, OcComm, OwnerComputesTrainer
 from multike_amd.synthetic import SyntheticKGs
 from multike_amd.tables import xavier_truncated_normal
 
@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--prefetch", action="store_true", help="the next epoch's plan on the side stream while the steps run (the product's default)")
     ap.add_argument("--zipf", type=float, default=0.0, help="head / tail entities of the synthetic triples ~ rank^-zipf (hub rows)")
     ap.add_argument("--rel-zipf", type=float, default=0.0, help="relation ids of the synthetic triples ~ rank^-rel_zipf")
+    ap.add_argument("--em", type=int, default=1, help="1 (default): entity-major second pass; 0: the atomics form of rounds 2-5")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
     a = ap.parse_args()
     for kv in a.set:
@@ -128,9 +129,10 @@ def main():
     rel0 = xavier_truncated_normal(cfg["n_rel"], cfg["dim"], "cpu", seed=2).numpy()
     comm = LoopbackComm(G, 0, a.wire_gbps, a.latency_us)
     comm.clock_hz = calibrate_sleep()
-    tr = OwnerComputesTrainer(kgs, ent0, rel0, B, cfg["neg"], 0, G, seed=1, chunks=a.chunks, comm=comm, prefetch=a.prefetch)
+    tr = OwnerComputesTrainer(kgs, ent0, rel0, B, cfg["neg"], 0, G, seed=1, chunks=a.chunks, comm=comm, prefetch=a.prefetch, entity_major=bool(a.em))
     names = {BASES | COUNT: "bases+count", BASES: "bases", SCORE: "score", APPLY: "apply", UPDATE: "update", APPLY | UPDATE: "apply+update",
-             BASES | COUNT | SCORE | APPLY | UPDATE: "whole step (one call)"}
+             BASES | COUNT | SCORE | APPLY | UPDATE: "whole step (one call)", PASS2: "pass2", PASS2 | UPDATE: "pass2+update",
+             BASES | SCORE | PASS2 | UPDATE: "whole step (one call)"}
     ev = []
     orig = tr.backend.run
 
@@ -169,7 +171,8 @@ def main():
     phases = {}
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
-    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "chunks": a.chunks, "global_batch": B * G,
+    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
+           "em_rows_per_step": (int(tr._em["row0_host"][-1]) / max(1, tr.steps)) if tr.em else None, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
            "capacity_vectors": tr.C,
            "phase_us": {k: float(np.mean(v)) for k, v in phases.items()},
