@@ -912,6 +912,37 @@ int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream);
 /* the second pass of the step `step` describes (its em_* fields; launched once per global step) */
 int mke_oc_pass2(const mke_oc_step* step, void* stream);
 
+/* The step loop of the owner-computes relation view as ONE native call (version 105; new design — the single-device
+ * counterpart is mke_relation_steps; semantics: code/MultiKE_model.py:304-322, one optimizer step per global batch, in epoch
+ * order).  mke_oc_comm: the three collectives of the step.  kind NCCL: `all_gather` / `reduce_scatter` / `all_reduce` are the
+ * addresses of ncclAllGather / ncclReduceScatter / ncclAllReduce of the RCCL the caller created `ctx` (an ncclComm_t) with —
+ * this library neither links nor loads RCCL; kind CALLBACK: int fn(void* ctx, const float* send, float* recv, int64_t count,
+ * void* stream) for all_gather (count = floats SENT) and reduce_scatter (count = floats RECEIVED), int fn(void* ctx, float*
+ * buf, int64_t count, void* stream) for all_reduce, each returning 0 after enqueueing (or completing) the collective in
+ * stream order; kind LOOPBACK: a one-GPU measurement stand-in — the bytes a rank of `world` would receive are written in HBM
+ * and the stream is held for bytes / wire_gbps + latency_us (what tools/oc_rank_compute.py models the links with). */
+#define MKE_OC_COMM_NCCL 0
+#define MKE_OC_COMM_CALLBACK 1
+#define MKE_OC_COMM_LOOPBACK 2
+typedef struct mke_oc_comm {
+  int kind; void* ctx; void* all_gather; void* reduce_scatter; void* all_reduce;
+  int world, rank; float wire_gbps, latency_us;   /* LOOPBACK only */
+} mke_oc_comm;
+/* parts: HOST array of the epoch's parts in order (mke_oc_step; at most `chunks` per global step), step_part0: HOST array of
+ * n_steps + 1 first-part indices; chunk c's exchange buffers send[c] (this rank's block), v_all[c] ([n_ranks] blocks), g_all[c]
+ * ([n_ranks][2 capacity][stride]) and gv[c]; the losses of part c of step s go to loss_ring + (s * chunks + c) * loss_stride
+ * doubles (MKE_LOSS_PARTIALS each); step s of the call carries tag tag_base + (s - step_begin) + 1.  comm == NULL: one rank, no
+ * collectives.  comm_stream (nullable): with chunks > 1, the all-gather / reduce-scatter of a part run there, ordered against
+ * `stream` by events created for the duration of the call, so that they overlap the other parts' scoring; NULL or == stream:
+ * everything in stream order on `stream`. */
+typedef struct mke_oc_loop {
+  const mke_oc_step* parts; const int32_t* step_part0; int n_steps;
+  int chunks; float* send[4]; float* v_all[4]; float* g_all[4]; float* gv[4]; int64_t block_floats;
+  double* loss_ring; int64_t loss_stride; int32_t tag_base;
+  const mke_oc_comm* comm; void* comm_stream;
+} mke_oc_loop;
+int mke_oc_steps(const mke_oc_loop* loop, int step_begin, int step_end, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

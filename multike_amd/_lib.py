@@ -34,7 +34,7 @@ SYMBOLS = (
     "mke_sample_distinct", "mke_neg_sample_at", "mke_rows_update_dense", "mke_dense_update_opt", "mke_align_steps", "mke_sim_select", "mke_sim_sample", "mke_topk_rows", "mke_topk_candidates", "mke_mapping_scratch_floats", "mke_mapping_step", "mke_mapping_step_phases", "mke_mapping_steps",
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_topk_long", "mke_probe_rows", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
-    "mke_oc_em_plan_temp_bytes", "mke_oc_em_plan", "mke_oc_pass2",
+    "mke_oc_em_plan_temp_bytes", "mke_oc_em_plan", "mke_oc_pass2", "mke_oc_steps",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -123,6 +123,24 @@ class OcEmPlanArgs(C.Structure):
                 ("keys", C.c_void_p), ("keys_alt", C.c_void_p), ("capacity", C.c_int64),
                 ("refs", C.c_void_p), ("rows", C.c_void_p), ("off", C.c_void_p), ("flags", C.c_void_p), ("scan", C.c_void_p),
                 ("step_row0", C.c_void_p), ("n_refs", C.c_void_p), ("temp", C.c_void_p), ("temp_bytes", C.c_int64)]
+
+
+OC_COMM_NCCL, OC_COMM_CALLBACK, OC_COMM_LOOPBACK = 0, 1, 2
+OC_CB_MOVE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # all_gather / reduce_scatter callbacks
+OC_CB_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)              # all_reduce callback
+
+
+class OcCommStruct(C.Structure):
+    """mke_oc_comm"""
+    _fields_ = [("kind", C.c_int), ("ctx", C.c_void_p), ("all_gather", C.c_void_p), ("reduce_scatter", C.c_void_p), ("all_reduce", C.c_void_p),
+                ("world", C.c_int), ("rank", C.c_int), ("wire_gbps", C.c_float), ("latency_us", C.c_float)]
+
+
+class OcLoopStruct(C.Structure):
+    """mke_oc_loop"""
+    _fields_ = [("parts", C.c_void_p), ("step_part0", C.c_void_p), ("n_steps", C.c_int), ("chunks", C.c_int),
+                ("send", C.c_void_p * 4), ("v_all", C.c_void_p * 4), ("g_all", C.c_void_p * 4), ("gv", C.c_void_p * 4), ("block_floats", C.c_int64),
+                ("loss_ring", C.c_void_p), ("loss_stride", C.c_int64), ("tag_base", C.c_int32), ("comm", C.c_void_p), ("comm_stream", C.c_void_p)]
 
 
 class AEPlanStruct(C.Structure):
@@ -789,6 +807,11 @@ def oc_em_plan_temp_bytes(capacity: int) -> int:
 def oc_em_plan(args: OcEmPlanArgs):
     """mke_oc_em_plan: the epoch's references to this rank's rows, sorted by (step, row) — struct of raw device addresses."""
     _check(lib().mke_oc_em_plan(C.byref(args), _stream()), "mke_oc_em_plan")
+
+
+def oc_steps(loop: OcLoopStruct, step_begin: int, step_end: int):
+    """mke_oc_steps: global steps [step_begin, step_end) of the current epoch enqueued by one native call."""
+    _check(lib().mke_oc_steps(C.byref(loop), C.c_int(step_begin), C.c_int(step_end), _stream()), "mke_oc_steps")
 
 
 def oc_pass2(step: OcStepStruct):

@@ -178,9 +178,10 @@ class OcHipBackend:
             sh, stt = _lib.ptr(tr._slot[0], i32, "slot"), _lib.ptr(tr._slot[1], i32, "slot")
             pw = getattr(b, "pos_w", None)
             pw = _lib.ptr(pw, torch.float32, "pos_w") if pw is not None else None
+            arr = (_lib.OcStepStruct * len(tr._parts))()     # contiguous: mke_oc_steps walks it (the list below holds views)
             out = []
             for k, (_, lo, hi) in enumerate(tr._parts):
-                s = _lib.OcStepStruct()
+                s = arr[k]
                 C.memmove(C.byref(s), C.byref(base), C.sizeof(s))
                 s.pos_h, s.pos_r, s.pos_t = ph + 4 * lo, pr + 4 * lo, pt + 4 * lo
                 s.slot_h, s.slot_t = sh + 4 * lo, stt + 4 * lo
@@ -200,8 +201,13 @@ class OcHipBackend:
             if len(cache) > 4:
                 cache.clear()
             self._steps = cache[key] = out
+            out_arr = self.__dict__.setdefault("_arrays", {})
+            if len(out_arr) > 4:
+                out_arr.clear()
+            out_arr[key] = arr
             self._ring = tr.loss_ring.data_ptr()
             self._ring_stride = tr.loss_ring.shape[1] * 8
+        self._parts_arr = self._arrays[key]
         cnth, cntt = (x.tolist() for x in tr._own_cnt)
         for k, (s, (_, lo, _hi)) in enumerate(zip(self._steps, tr._parts)):     # a part's owned list starts at the part's own offset
             s.own_h, s.n_own_h = oh + 4 * lo, cnth[k]
@@ -211,6 +217,31 @@ class OcHipBackend:
             rp, op = em["rows"].data_ptr(), em["off"].data_ptr()
             for s, (step, _, _) in zip(self._steps, tr._parts):
                 s.em_rows, s.em_off, s.em_n_rows = rp + 4 * r0[step], op + 4 * r0[step], r0[step + 1] - r0[step]
+        # the whole epoch's schedule for mke_oc_steps (one native call per run of steps)
+        lp = _lib.OcLoopStruct()
+        lp.parts, lp.n_steps, lp.chunks = C.addressof(self._parts_arr), tr.steps, tr.chunks
+        first = (C.c_int32 * (tr.steps + 1))()
+        k = 0
+        for st in range(tr.steps):
+            first[st] = k
+            k += len(tr._parts_of.get(st, ()))
+        first[tr.steps] = k
+        self._step_part0 = first
+        lp.step_part0 = C.addressof(first)
+        for c in range(tr.chunks):
+            lp.send[c], lp.v_all[c], lp.g_all[c], lp.gv[c] = tr._addr[c]
+        lp.block_floats = tr.block
+        lp.loss_ring, lp.loss_stride = self._ring, tr.loss_ring.shape[1]
+        self._loop = lp
+
+    def run_steps(self, tr, s0, s1, tag_base, comm_struct, comm_stream):
+        """Global steps [s0, s1) of the current epoch in ONE native call (mke_oc_steps): kernels, collectives and — with several
+        parts per step — the two-stream pipeline are enqueued from C++."""
+        lp = self._loop
+        lp.tag_base = tag_base
+        lp.comm = C.addressof(comm_struct) if comm_struct is not None else None
+        lp.comm_stream = comm_stream
+        _lib.oc_steps(lp, s0, s1)
 
     def bases(self, tr, st, send):
         _lib.oc_bases(self._cached(tr, st), send)
@@ -341,6 +372,20 @@ class OcRcclComm(OcComm):
     def barrier(self, token):
         self.c.all_reduce(token.view(-1))
 
+    def native(self, tr=None):
+        """mke_oc_comm over this communicator: RCCL's own entry points, called from the native step loop (mke_oc_steps)."""
+        if getattr(self, "_native", None) is None:
+            from . import rccl
+            L = rccl.lib()
+            cs = _lib.OcCommStruct()
+            cs.kind, cs.ctx = _lib.OC_COMM_NCCL, self.c._comm.value
+            cs.all_gather = C.cast(L.ncclAllGather, C.c_void_p).value
+            cs.reduce_scatter = C.cast(L.ncclReduceScatter, C.c_void_p).value
+            cs.all_reduce = C.cast(L.ncclAllReduce, C.c_void_p).value
+            cs.world, cs.rank = self.c.world, self.c.rank
+            self._native = cs
+        return self._native
+
     def for_plan(self):
         """A second RCCL communicator (concurrent with the step collectives), one per step communicator."""
         if getattr(self, "_plan", None) is None:
@@ -419,6 +464,46 @@ class OcHostStagedComm(OcGlooComm):
     def barrier(self, token):
         torch.cuda.synchronize()           # gloo orders hosts, not streams
         dist.barrier(group=self.group)
+
+    def native(self, tr):
+        """mke_oc_comm of kind CALLBACK: the native step loop calls back into these staged collectives (the buffers are found by
+        their device address among the trainer's exchange buffers; the callback works on the stream the loop hands it)."""
+        def find(addr, count):
+            for t in tr._exchange_tensors():
+                if t.data_ptr() == addr:
+                    return t.view(-1)[:count]
+            raise _lib.MultiKEHipError("native callback: unknown exchange buffer")
+
+        def move(fn, scale_in, scale_out):
+            def cb(ctx, send, recv, count, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                        fn(find(recv, count * scale_out), find(send, count * scale_in))
+                    return 0
+                except Exception:      # noqa: BLE001 — an exception must not unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return _lib.OC_CB_MOVE(cb)
+
+        def reduce(ctx, buf, count, stream):
+            try:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                    self.all_reduce(find(buf, count))
+                return 0
+            except Exception:          # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        G = dist.get_world_size(self.group)
+        keep = (move(self.all_gather, 1, G), move(self.reduce_scatter, G, 1), _lib.OC_CB_REDUCE(reduce))
+        cs = _lib.OcCommStruct()
+        cs.kind = _lib.OC_COMM_CALLBACK
+        cs.all_gather, cs.reduce_scatter, cs.all_reduce = (C.cast(f, C.c_void_p).value for f in keep)
+        cs.world, cs.rank = G, dist.get_rank(self.group)
+        cs._keep = keep                # the thunks live as long as the struct
+        return cs
 
 
 class TripleListBatcher:
@@ -1019,6 +1104,54 @@ class OwnerComputesTrainer:
         return OcStep(b.pos_h[lo:hi], b.pos_r[lo:hi], b.pos_t[lo:hi], per, self._slot[0][lo:hi], self._slot[1][lo:hi],
                       self._own[0][lo:lo + nh], self._own[1][lo:lo + nt], tag, self._codes, code_off,
                       pos_w=(pw[lo:hi] if pw is not None else None))
+
+    def _exchange_tensors(self):
+        return [*self._send, *self._v_all, *self._g_all, *self._gv, self.rel_grad]
+
+    def _native_loop(self):
+        """(usable, mke_oc_comm or None): the step loop can go through mke_oc_steps — HIP backend, a communicator with a native
+        form (RCCL through ctypes, the tests' host-staged ranks, the tools' loop-back) or a single rank, no peer-direct, no
+        per-launch event collection.  MKE_OC_NATIVE=0 keeps the Python loop."""
+        import os
+        if not hasattr(self.backend, "run_steps") or self.peer_direct or self.score_events is not None or self.chunks > _lib.OC_EM_MAX_CHUNKS \
+                or os.environ.get("MKE_OC_NATIVE", "1") == "0":
+            return False, None
+        if self.world == 1 and not self.force_collectives:
+            return True, None
+        if not hasattr(self.comm, "native"):
+            return False, None
+        key = (self.C, self._send[0].data_ptr())
+        if getattr(self, "_comm_native_key", None) != key:      # callbacks look the exchange buffers up by address
+            self._comm_native, self._comm_native_key = self.comm.native(self), key
+        return True, self._comm_native
+
+    def run(self, i0: int, n: int):
+        """Global steps i0 .. i0 + n - 1 (in order): one native call per run of steps inside an epoch (mke_oc_steps) when the
+        communicator has a native form, else the Python step loop."""
+        i, end = i0, i0 + n
+        while i < end:
+            s = i % self.steps
+            m = min(end - i, self.steps - s)
+            ok, cs = self._native_loop()
+            if not ok:
+                for k in range(m):
+                    self.step(i + k)
+                i += m
+                continue
+            if s == 0 and i > 0:
+                self._advance_epoch()
+            if s == 0 and self.prefetch:
+                self._prefetch_next_epoch()                  # the next epoch's plan overlaps this epoch's steps
+            ok, cs = self._native_loop()                     # the exchange buffers may have grown with the new epoch's plan
+            comm_stream = None
+            if cs is not None and self.chunks > 1 and self.device.type == "cuda":
+                if getattr(self, "_comm_stream", None) is None:
+                    self._comm_stream = torch.cuda.Stream(device=self.device)
+                comm_stream = self._comm_stream.cuda_stream
+            self.backend.run_steps(self, s, s + m, self.tag, cs, comm_stream)
+            self.tag += m
+            i += m
+            self._stepped = i - 1
 
     def step(self, i: int):
         """Global step i (steps must be issued in order)."""

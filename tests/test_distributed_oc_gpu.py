@@ -74,9 +74,8 @@ def test_one_rank_equals_dense_oracle(chunks, excl, dim, neg, em):
     _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
     steps = min(spe, 9)
     tr = _make(0, 1, chunks=chunks, excl=excl, n_ent=n_ent, dim=dim, neg=neg, em=em)
-    assert tr.em == em
-    for i in range(steps):
-        tr.step(i)
+    assert tr.em == em and tr._native_loop()[0]
+    tr.run(0, steps)                    # the native step loop (mke_oc_steps); the other tests of this file drive step() from Python
     e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
     np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
     np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
@@ -212,6 +211,26 @@ def test_entity_major_step_is_bit_reproducible(chunks, quarter):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_native_step_loop_is_the_python_loop_bit_for_bit(chunks):
+    """mke_oc_steps enqueues exactly what the Python step loop enqueues (entity-major form: no atomics, so the two runs agree to
+    the bit), across an epoch boundary, in runs of steps that start and end inside epochs."""
+    out = []
+    for native in (False, True):
+        tr = _make(0, 1, chunks=chunks, neg=25, em=True)
+        n = tr.steps + 3
+        if native:
+            tr.run(0, 2)
+            tr.run(2, n - 2)
+        else:
+            for i in range(n):
+                tr.step(i)
+        torch.cuda.synchronize()
+        out.append((tr.ent.clone(), tr.ent_acc.clone(), tr.rel.clone(), tr.rel_acc.clone(), tr.loss_ring.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("chunks", [1, 2])
 def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     """Same global steps as the single-table StepEngine path (same device batcher, same seed => same shuffle): losses and
@@ -248,7 +267,7 @@ def test_one_rank_across_the_epoch_boundary_equals_single_table_path(chunks):
     np.testing.assert_allclose(tr.rel[:, :d].cpu().numpy(), R.raw().cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG, em=None):
+def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG, em=None, native=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)   # `port`: a rendezvous FILE (no TCP port to collide on)
@@ -256,8 +275,12 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG,
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
         tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer, neg=neg, em=em)
-        for i in range(steps):
-            tr.step(i)
+        if native:                      # mke_oc_steps: the schedule (two streams when chunks > 1) enqueued from C++, collectives by callback
+            assert tr._native_loop()[0]
+            tr.run(0, steps)
+        else:
+            for i in range(steps):
+                tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
         ok = tr.scratch_clean()
         loss = tr.epoch_loss()
@@ -268,10 +291,12 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG,
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks,peer,neg,em", [(1, False, NEG, True), (2, False, NEG, True), (1, False, 0, True),
-                                                (1, False, NEG, False), (2, False, NEG, False), (1, True, NEG, False),
-                                                (1, False, 0, False)])   # neg 0: positives only
-def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em):
+@pytest.mark.parametrize("chunks,peer,neg,em,native", [(1, False, NEG, True, False), (2, False, NEG, True, False), (1, False, 0, True, False),
+                                                       (1, False, NEG, True, True), (2, False, NEG, True, True), (3, False, 25, True, True),
+                                                       (2, False, NEG, False, True),
+                                                       (1, False, NEG, False, False), (2, False, NEG, False, False), (1, True, NEG, False, False),
+                                                       (1, False, 0, False, False)])   # neg 0: positives only
+def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em, native):
     """world_size 2 with the HIP kernels: owner = id % 2; each rank scores, for all 600 positives of the global step, the
     negatives whose corrupt entity it owns; gradient vectors summed across ranks; relation gradient all-reduced."""
     import torch.multiprocessing as mp
@@ -282,7 +307,7 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em):
     ret = ctx.Queue()
     # peer = True: no all-gather / reduce-scatter — each process maps the other's send block and gradient inbox (IPC) and the
     # score kernel reads / writes them directly
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer, neg, em)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, peer, neg, em, native)) for r in range(world)]
     for p in procs:
         p.start()
     full, rel, loss, ok = ret.get(timeout=480)

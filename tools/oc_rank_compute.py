@@ -91,6 +91,13 @@ class LoopbackComm(OcComm):
     def barrier(self, token):
         pass
 
+    def native(self, tr=None):
+        """mke_oc_comm of kind LOOPBACK: the same stand-in inside the library, for the native step loop (mke_oc_steps)."""
+        cs = _lib.OcCommStruct()
+        cs.kind, cs.world, cs.rank = _lib.OC_COMM_LOOPBACK, self.world, self.rank
+        cs.wire_gbps, cs.latency_us = self.wire_gbps, self.latency_us
+        return cs
+
 
 def calibrate_sleep():
     """cycles of torch.cuda._sleep per second on this device"""
