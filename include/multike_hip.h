@@ -852,6 +852,7 @@ typedef struct mke_oc_step {
   int em_chunks; int64_t em_block_floats; const float* em_v[4]; const float* em_gv[4];
 } mke_oc_step;
 #define MKE_OC_EM_MAX_CHUNKS 4
+#define MKE_OC_EM_WAVES 32768
 int64_t mke_oc_block_floats(int64_t capacity, int stride);
 /* codes[e] of negative e = (p, n) of positives pos_h[0..n_pos): neg_h / neg_t are mke_neg_sample's output; the group flags
  * (MKE_OC_NEED_*) go into codes[p * neg_per_pos] */
@@ -903,6 +904,8 @@ typedef struct mke_oc_em_plan_args {
   const int64_t* step_lo; int n_steps; int chunks; int64_t n_all; int64_t max_step /* host: most positives of a step */;
   int n_ranks, rank; int64_t n_local, n_rel;
   uint64_t* keys; uint64_t* keys_alt; int64_t capacity;
+  uint32_t* vals_alt;       /* capacity + 1 scratch ints (the sorted descriptors) */
+  int32_t* wave_scratch;    /* 2 * (MKE_OC_EM_WAVES + 1) scratch ints */
   uint32_t* refs; int32_t* rows; int32_t* off; int32_t* flags; int32_t* scan;
   int64_t* step_row0; int64_t* n_refs;
   void* temp; int64_t temp_bytes;

@@ -7,9 +7,10 @@
 // negative) and this file does the rest:
 //   * mke_oc_em_plan (per epoch, table-independent, on the plan's side stream): every reference of every global step to a row
 //     this rank owns — its owned negatives, the positives' own terms it scores, the heads / tails whose gradient vector comes
-//     back by the reduce-scatter — as a 64-bit key (step, local row | positive, kind), sorted (hipcub radix sort, keys only:
-//     the key IS the order, so the result does not depend on how the keys were appended), resolved to (locator, coefficient
-//     index) pairs, with the touched rows of each step and their CSR offsets;
+//     back by the reduce-scatter, the relation rows' gradient vectors — listed in element order without atomics (count per
+//     wavefront range, prefix sum, fill), STABLY sorted by (step, local row) (hipcub radix sort of 32-bit keys with the
+//     (positive, kind) descriptor as payload: a row's references stay in (positive, kind) order), resolved to (locator,
+//     coefficient index) pairs, with the touched rows of each step and their CSR offsets;
 //   * k_oc_em_pass2 (per global step): a quarter-wave per touched owned row — raw row + accumulator read once, c^ formed once,
 //     ghat = c^ sum coef + sum coef sg V + sum (+-) gv over the row's references in list order, Jacobian of the normalisation,
 //     Adagrad / SGD, row and accumulator written.  No gradient scratch, no touched flags, no reference counts, no atomics;
@@ -33,10 +34,14 @@ namespace mke {
 
 struct EmPlanParams {
   mke_oc_em_plan_args a;
-  int desc_bits;        // 7 + bits(max_step)
   uint32_t ep;          // elements per positive: neg_per_pos + 5
+  uint64_t ep_magic;    // ceil(2^40 / ep)
+  int g_shift;          // log2(n_ranks) when it is a power of two, else -1
   int64_t rows_tot;     // n_local + n_rel: the relation rows follow the shard's rows
-  unsigned long long* cursor;   // == a.n_refs
+  int64_t per;          // elements per wavefront range (a multiple of 64)
+  int n_waves;          // wavefront ranges
+  int32_t* wave_cnt;    // [n_waves + 1] owned elements per range
+  int32_t* wave_off;    // [n_waves + 1] exclusive prefix (wave_off[n_waves] = all)
 };
 
 __device__ __forceinline__ int em_step_of(const int64_t* __restrict__ step_lo, int n_steps, int64_t p) {
@@ -48,84 +53,124 @@ __device__ __forceinline__ int em_step_of(const int64_t* __restrict__ step_lo, i
   return lo;
 }
 
-// A wavefront per contiguous range of (epoch position, element) pairs, walked twice: count the owned ones, reserve their slots
-// with ONE cursor atomic, walk again and append the keys at ballot ranks (the second walk reads the range out of the caches).
-// A returning atomic on one address costs ~12 ns: one per 64 elements was 5.2 ms of a 6.2 ms plan at the C2 shape with 8 ranks,
-// one per 4,096 still 1.9 of 8.7 ms at C5.  The order of the appends is irrelevant: the sort that follows is total.
-__device__ __forceinline__ bool em_key_of(const EmPlanParams& pp, int64_t t, int64_t total, uint64_t& key) {
+// element t = (epoch position p, element n of the position): n < N negative n; then the own term, the head / tail rows' gradient
+// vectors, the relation row's two gradient vectors.  Owned by this rank -> (step * rows_tot + local row, (position in step, kind)).
+// The elements are enumerated position-major, kinds ascending: a STABLE sort by (step, row) of the owned elements in this order
+// leaves every row's references sorted by (positive, kind) — the summation order of the second pass.
+// The loads of an element are unconditional (clamped indices) and independent of each other, so that the EM_U elements a lane
+// handles per round are in flight together: with one dependent load per round the walks ran at the latency of a round trip per
+// 64 elements and wavefront (2.8 + 4.5 ms per epoch at the C5 shape with 8 ranks).
+struct EmElem { int ent; int kind; int64_t p; };
+__device__ __forceinline__ EmElem em_elem_of(const EmPlanParams& pp, int64_t t, int64_t total) {
   const mke_oc_em_plan_args& a = pp.a;
-  if (t >= total) return false;
-  const int N = a.neg_per_pos, G = a.n_ranks;
-  const int64_t p = total <= 0xFFFFFFFFll ? (int64_t)((uint32_t)t / pp.ep) : t / pp.ep;
-  const int n = (int)(t - p * pp.ep);
-  int ent = -1, kind = n;
-  if (n < N) {
-    ent = (a.codes[p * N + n] & 0x3FFFFFFF) >> 1;
-  } else if (n == N) {          // own term: the owner of t when HR travels, else the owner of h
-    ent = a.slot_h[p] >= 0 ? a.pos_t[p] : a.pos_h[p];
-    kind = EM_KIND_OWN;
-  } else if (n == N + 1 || n == N + 3) {     // the owner of the head receives sum dL/dHR: head row and relation row
-    if (a.slot_h[p] >= 0) ent = a.pos_h[p];
-    kind = n == N + 1 ? EM_KIND_GV_H : EM_KIND_REL_H;
-  } else {                                   // the owner of the tail receives sum dL/dRT: tail row and relation row
-    if (a.slot_t[p] >= 0) ent = a.pos_t[p];
-    kind = n == N + 2 ? EM_KIND_GV_T : EM_KIND_REL_T;
+  const int N = a.neg_per_pos;
+  const bool in = t < total;
+  const int64_t tc = in ? t : 0;
+  // t / ep as one multiply-high when t < 2^32: M = ceil(2^40 / ep) is exact there (the error t (M - 2^40 / ep) / 2^40 < 2^-8 is
+  // below the 1 / ep >= 1 / 69 that separates t / ep from the next integer)
+  const int64_t p = total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)tc * pp.ep_magic) >> 40) : tc / pp.ep;
+  const int n = (int)(tc - p * pp.ep);
+  const int code = N > 0 ? a.codes[p * N + (n < N ? n : 0)] : 0;
+  const int sh = a.slot_h[p], st = a.slot_t[p], ph = a.pos_h[p], pt = a.pos_t[p];
+  EmElem e;
+  e.p = p;
+  e.kind = n < N ? n : (n == N ? EM_KIND_OWN : (n == N + 1 ? EM_KIND_GV_H : (n == N + 2 ? EM_KIND_GV_T : (n == N + 3 ? EM_KIND_REL_H : EM_KIND_REL_T))));
+  const int own_ent = sh >= 0 ? pt : ph;               // own term: the owner of t when HR travels, else the owner of h
+  const int head_ent = sh >= 0 ? ph : -1;              // the owner of the head receives sum dL/dHR: head row and relation row
+  const int tail_ent = st >= 0 ? pt : -1;              // the owner of the tail receives sum dL/dRT: tail row and relation row
+  e.ent = n < N ? ((code & 0x3FFFFFFF) >> 1) : (n == N ? own_ent : ((n == N + 1 || n == N + 3) ? head_ent : tail_ent));
+  if (!in) e.ent = -1;
+  return e;
+}
+__device__ __forceinline__ bool em_owned(const EmPlanParams& pp, const EmElem& e) {
+  if (e.ent < 0) return false;
+  const int G = pp.a.n_ranks;
+  const int owner = pp.g_shift >= 0 ? (e.ent & (G - 1)) : (int)((uint32_t)e.ent % (uint32_t)G);     // uniform choice
+  return owner == pp.a.rank;
+}
+#define EM_U 4
+
+// A wavefront per contiguous range of elements, in two launches with a prefix sum between them: count the owned ones; append
+// (key, descriptor) at the range's offset + ballot rank — no cursor atomic (a returning atomic on one address costs ~12 ns:
+// one per 64 elements was 5.2 ms of a 6.2 ms plan at the C2 shape with 8 ranks), and the list comes out in element order.
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_count(const EmPlanParams pp) {
+  const int64_t total = pp.a.n_all * (int64_t)pp.ep;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  if (wave >= pp.n_waves) return;
+  const int64_t t0 = wave * pp.per, t1 = t0 + pp.per < total ? t0 + pp.per : total;
+  int cnt = 0;
+  for (int64_t t = t0 + lane; t - lane < t1; t += 64 * EM_U) {
+    EmElem e[EM_U];
+#pragma unroll
+    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total, total);
+#pragma unroll
+    for (int u = 0; u < EM_U; ++u) cnt += em_owned(pp, e[u]) ? 1 : 0;
   }
-  if (ent < 0 || (int)((uint32_t)ent % (uint32_t)G) != a.rank) return false;
-  const int s = em_step_of(a.step_lo, a.n_steps, p);
-  const uint64_t row = kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[p] : (uint64_t)((uint32_t)ent / (uint32_t)G);
-  const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
-  const uint64_t desc = ((uint64_t)(p - a.step_lo[s]) << 7) | (uint32_t)kind;
-  key = (srow << pp.desc_bits) | desc;
-  return true;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if (lane == 0) pp.wave_cnt[wave] = cnt;
+  if (wave == 0 && lane == 0) pp.wave_cnt[pp.n_waves] = 0;
 }
 
-__global__ __launch_bounds__(MKE_BLOCK) void k_em_keys(const EmPlanParams pp) {
+template <typename KEY>
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KEY* __restrict__ keys, uint32_t* __restrict__ vals) {
   const mke_oc_em_plan_args& a = pp.a;
   const int64_t total = a.n_all * (int64_t)pp.ep;
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * MKE_BLOCK) >> 6;
-  const int64_t per = ((total + nwaves - 1) / nwaves + 63) & ~63ll;       // elements per wavefront, a multiple of 64
-  const int64_t t0 = wave * per, t1 = t0 + per < total ? t0 + per : total;
-  if (t0 >= total) return;                                                // wave-uniform
-  int mine_cnt = 0;
-  uint64_t key;
-  for (int64_t t = t0 + lane; t - lane < t1; t += 64) mine_cnt += em_key_of(pp, t < t1 ? t : total, total, key) ? 1 : 0;
-  int tot = mine_cnt;
+  const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
+  if (wave >= pp.n_waves) return;
+  if (wave == 0 && lane == 0) a.n_refs[0] = pp.wave_off[pp.n_waves];
+  const int64_t t0 = wave * pp.per, t1 = t0 + pp.per < total ? t0 + pp.per : total;
+  if (t0 >= total) return;                                  // wave-uniform
+  int64_t base = pp.wave_off[wave];
+  int s_cur = em_step_of(a.step_lo, a.n_steps, total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)t0 * pp.ep_magic) >> 40) : t0 / pp.ep);   // wave-uniform
+  const int G = a.n_ranks;
+  for (int64_t t = t0 + lane; t - lane < t1; t += 64 * EM_U) {     // wave-uniform trip count (ballots inside)
+    EmElem e[EM_U];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-  if (tot == 0) return;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(pp.cursor, (unsigned long long)tot);
-  base = __shfl(base, 0, 64);
-  for (int64_t t = t0 + lane; t - lane < t1; t += 64) {
-    const bool mine = em_key_of(pp, t < t1 ? t : total, total, key);
-    const uint64_t m = __ballot(mine);
-    if (mine) {
-      const unsigned long long k = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (k < (unsigned long long)a.capacity) a.keys[k] = key;
+    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total, total);
+    {   // the step of the round's first element: every lane's position is at or after it
+      const int64_t tf = t - lane;
+      const int64_t pf = total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)tf * pp.ep_magic) >> 40) : tf / pp.ep;
+      while (s_cur + 1 < a.n_steps && a.step_lo[s_cur + 1] <= pf) ++s_cur;
     }
-    base += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < EM_U; ++u) {
+      const bool mine = em_owned(pp, e[u]);
+      const uint64_t m = __ballot(mine);
+      if (mine) {
+        int s = s_cur;                                      // a step at or before the element's: a short linear advance
+        while (s + 1 < a.n_steps && a.step_lo[s + 1] <= e[u].p) ++s;
+        const uint64_t row = e[u].kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[e[u].p]
+                                                        : (uint64_t)(pp.g_shift >= 0 ? (uint32_t)e[u].ent >> pp.g_shift : (uint32_t)e[u].ent / (uint32_t)G);
+        const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
+        const uint32_t desc = ((uint32_t)(e[u].p - a.step_lo[s]) << 7) | (uint32_t)e[u].kind;
+        const int64_t k = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < a.capacity) { keys[k] = (KEY)srow; vals[k] = desc; }
+      }
+      base += __popcll(m);
+    }
   }
 }
 
-// sorted key k -> (locator, coefficient index) and the "a new (step, row) starts here" flag; entry `capacity` (and every
+// sorted reference k -> (locator, coefficient index) and the "a new (step, row) starts here" flag; entry `capacity` (and every
 // sentinel) is the end marker
-__global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp, const uint64_t* __restrict__ sorted) {
+template <typename KEY>
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp, const KEY* __restrict__ sorted, const uint32_t* __restrict__ descs) {
   const mke_oc_em_plan_args& a = pp.a;
   const int64_t k = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
   if (k > a.capacity) return;
-  const uint64_t SENT = ~0ull;
-  const uint64_t key = k < a.capacity ? sorted[k] : SENT;
-  const uint64_t prev = k > 0 ? sorted[k - 1] : SENT;
-  if (key == SENT) {
+  const KEY SENT = (KEY)~(KEY)0;
+  const KEY srow = k < a.capacity ? sorted[k] : SENT;
+  const KEY prev = k > 0 ? sorted[k - 1] : SENT;
+  if (srow == SENT) {
     a.flags[k] = (k == 0 || prev != SENT) ? 1 : 0;        // the first sentinel closes the last row's list
     return;
   }
-  const uint64_t srow = key >> pp.desc_bits;
-  a.flags[k] = (k == 0 || (prev >> pp.desc_bits) != srow) ? 1 : 0;
-  const uint64_t desc = key & ((1ull << pp.desc_bits) - 1ull);
-  const int s = (int)(srow / (uint64_t)pp.rows_tot);
+  a.flags[k] = (k == 0 || prev != srow) ? 1 : 0;
+  const uint32_t desc = descs[k];
+  const int s = (int)((uint64_t)srow / (uint64_t)pp.rows_tot);
   const int64_t i = (int64_t)(desc >> 7);
   const int kind = (int)(desc & 127);
   const int64_t lo = a.step_lo[s], size = a.step_lo[s + 1] - lo;
@@ -155,21 +200,21 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp,
 }
 
 // flagged k: the scan[k]-th touched (step, row) starts at reference k; step boundaries fall out of the same walk
-__global__ __launch_bounds__(MKE_BLOCK) void k_em_rows(const EmPlanParams pp, const uint64_t* __restrict__ sorted) {
+template <typename KEY>
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_rows(const EmPlanParams pp, const KEY* __restrict__ sorted) {
   const mke_oc_em_plan_args& a = pp.a;
   const int64_t k = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
   if (k > a.capacity || !a.flags[k]) return;
-  const uint64_t SENT = ~0ull;
-  const uint64_t key = k < a.capacity ? sorted[k] : SENT;
+  const KEY SENT = (KEY)~(KEY)0;
+  const KEY srow = k < a.capacity ? sorted[k] : SENT;
   const int u = a.scan[k];
   a.off[u] = (int32_t)k;
   int s_cur = a.n_steps;
-  if (key != SENT) {
-    const uint64_t srow = key >> pp.desc_bits;
-    s_cur = (int)(srow / (uint64_t)pp.rows_tot);
-    a.rows[u] = (int32_t)(srow - (uint64_t)s_cur * (uint64_t)pp.rows_tot);
+  if (srow != SENT) {
+    s_cur = (int)((uint64_t)srow / (uint64_t)pp.rows_tot);
+    a.rows[u] = (int32_t)((uint64_t)srow - (uint64_t)s_cur * (uint64_t)pp.rows_tot);
   }
-  const int s_prev = k > 0 ? (int)((sorted[k - 1] >> pp.desc_bits) / (uint64_t)pp.rows_tot) : -1;
+  const int s_prev = k > 0 ? (int)((uint64_t)sorted[k - 1] / (uint64_t)pp.rows_tot) : -1;
   for (int s = s_prev + 1; s <= s_cur; ++s) a.step_row0[s] = u;
 }
 
@@ -177,6 +222,38 @@ static inline int bits_for(uint64_t v) {   // smallest b with v < 2^b
   int b = 0;
   while (b < 64 && (v >> b)) ++b;
   return b;
+}
+
+template <typename KEY>
+static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) {
+  const mke_oc_em_plan_args& a = pp.a;
+  KEY* keys = reinterpret_cast<KEY*>(a.keys);
+  KEY* keys_alt = reinterpret_cast<KEY*>(a.keys_alt);
+  uint32_t* vals = reinterpret_cast<uint32_t*>(a.flags);           // the unsorted descriptors are dead after the sort
+  hipError_t e;
+  if ((e = hipMemsetAsync(keys, 0xFF, (size_t)(a.capacity + 1) * sizeof(KEY), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
+  const int64_t total = a.n_all * (int64_t)pp.ep;
+  const dim3 wgrid((unsigned)((pp.n_waves * 64 + MKE_BLOCK - 1) / MKE_BLOCK));
+  size_t tb = (size_t)a.temp_bytes;
+  if (total > 0) {
+    hipLaunchKernelGGL(k_em_count, wgrid, dim3(MKE_BLOCK), 0, st, pp);
+    int rc = check_launch("k_em_count");
+    if (rc) return rc;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, pp.wave_cnt, pp.wave_off, pp.n_waves + 1, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL((k_em_fill<KEY>), wgrid, dim3(MKE_BLOCK), 0, st, pp, keys, vals);
+    if ((rc = check_launch("k_em_fill"))) return rc;
+  } else if ((e = hipMemsetAsync(a.n_refs, 0, sizeof(int64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
+  const int n = (int)(a.capacity + 1);
+  tb = (size_t)a.temp_bytes;
+  if ((e = hipcub::DeviceRadixSort::SortPairs(a.temp, tb, keys, keys_alt, vals, a.vals_alt, n, 0, key_bits, st)) != hipSuccess) { set_error("mke_oc_em_plan: radix sort: %s", hipGetErrorString(e)); return (int)e; }
+  const dim3 grid((unsigned)((a.capacity + 1 + MKE_BLOCK - 1) / MKE_BLOCK));
+  hipLaunchKernelGGL((k_em_resolve<KEY>), grid, dim3(MKE_BLOCK), 0, st, pp, (const KEY*)keys_alt, (const uint32_t*)a.vals_alt);
+  int rc = check_launch("k_em_resolve");
+  if (rc) return rc;
+  tb = (size_t)a.temp_bytes;
+  if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, a.flags, a.scan, n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL((k_em_rows<KEY>), grid, dim3(MKE_BLOCK), 0, st, pp, (const KEY*)keys_alt);
+  return check_launch("k_em_rows");
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------------------------------
@@ -307,7 +384,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
 extern "C" int64_t mke_oc_em_plan_temp_bytes(int64_t capacity) {
   if (capacity < 0 || capacity >= 0x7FFFFFFFll) return -1;
   size_t a = 0, b = 0;
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(capacity + 1), 0, 64, (hipStream_t)0);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(capacity + 1), 0, 64, (hipStream_t)0);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(capacity + 1), (hipStream_t)0);
   return (int64_t)(a > b ? a : b) + 256;
 }
@@ -322,41 +399,28 @@ extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
     return MKE_E_SHAPE;
   }
   if (a.capacity < 1 || a.capacity >= 0x7FFFFFFFll) { set_error("mke_oc_em_plan: capacity must be in [1, 2^31)"); return MKE_E_RANGE; }
-  if (!a.keys || !a.keys_alt || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
+  if (!a.keys || !a.keys_alt || !a.vals_alt || !a.wave_scratch || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
   if (a.n_all > 0 && (!a.pos_h || !a.pos_r || !a.pos_t || !a.slot_h || !a.slot_t || !a.step_lo || (a.neg_per_pos > 0 && !a.codes))) { set_error("mke_oc_em_plan: NULL input"); return MKE_E_NULL; }
   if (a.temp_bytes < mke_oc_em_plan_temp_bytes(a.capacity)) { set_error("mke_oc_em_plan: temp storage below mke_oc_em_plan_temp_bytes"); return MKE_E_SHAPE; }
   if (a.max_step >= (1ll << 25) || a.max_step * (a.neg_per_pos + 1) > 0x7FFFFFFFll) { set_error("mke_oc_em_plan: a global step holds at most 2^25 positives"); return MKE_E_RANGE; }
-  hipStream_t st = (hipStream_t)stream;
   EmPlanParams pp;
   pp.a = a;
-  pp.desc_bits = 7 + bits_for((uint64_t)a.max_step);
   pp.ep = (uint32_t)a.neg_per_pos + 5u;
+  pp.ep_magic = ((1ull << 40) + pp.ep - 1) / pp.ep;
+  pp.g_shift = (a.n_ranks & (a.n_ranks - 1)) == 0 ? __builtin_ctz((unsigned)a.n_ranks) : -1;
   pp.rows_tot = a.n_local + a.n_rel;
-  pp.cursor = reinterpret_cast<unsigned long long*>(a.n_refs);
-  const int srow_bits = bits_for((uint64_t)a.n_steps * (uint64_t)pp.rows_tot + 1ull);   // + 1: an all-ones (step, row) never occurs => the sentinel sorts last
-  if (pp.desc_bits + srow_bits > 64) { set_error("mke_oc_em_plan: steps x rows x positives do not fit a 64-bit key"); return MKE_E_RANGE; }
-  hipError_t e;
-  if ((e = hipMemsetAsync(a.n_refs, 0, sizeof(int64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
-  if ((e = hipMemsetAsync(a.keys, 0xFF, (size_t)(a.capacity + 1) * sizeof(uint64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
   const int64_t total = a.n_all * (int64_t)pp.ep;
-  if (total > 0) {
-    int64_t blocks = (total + (int64_t)MKE_BLOCK * 8 - 1) / ((int64_t)MKE_BLOCK * 8);      // >= 8 rounds of 64 per wavefront
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_em_keys, dim3((unsigned)blocks), dim3(MKE_BLOCK), 0, st, pp);
-    int rc = check_launch("k_em_keys");
-    if (rc) return rc;
-  }
-  size_t tb = (size_t)a.temp_bytes;
-  const int n = (int)(a.capacity + 1);
-  if ((e = hipcub::DeviceRadixSort::SortKeys(a.temp, tb, a.keys, a.keys_alt, n, 0, pp.desc_bits + srow_bits, st)) != hipSuccess) { set_error("mke_oc_em_plan: radix sort: %s", hipGetErrorString(e)); return (int)e; }
-  const dim3 grid((unsigned)((a.capacity + 1 + MKE_BLOCK - 1) / MKE_BLOCK));
-  hipLaunchKernelGGL(k_em_resolve, grid, dim3(MKE_BLOCK), 0, st, pp, (const uint64_t*)a.keys_alt);
-  int rc = check_launch("k_em_resolve");
-  if (rc) return rc;
-  tb = (size_t)a.temp_bytes;
-  if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, a.flags, a.scan, n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL(k_em_rows, grid, dim3(MKE_BLOCK), 0, st, pp, (const uint64_t*)a.keys_alt);
-  return check_launch("k_em_rows");
+  int64_t nw = (total + 511) / 512;                       // >= 8 rounds of 64 elements per wavefront
+  if (nw > MKE_OC_EM_WAVES) nw = MKE_OC_EM_WAVES;
+  if (nw < 1) nw = 1;
+  pp.n_waves = (int)nw;
+  pp.per = ((total + nw - 1) / nw + 63) & ~63ll;
+  pp.wave_cnt = a.wave_scratch;
+  pp.wave_off = a.wave_scratch + (MKE_OC_EM_WAVES + 1);
+  // + 1: an all-ones (step, row) never occurs, so the all-ones sentinel of the unused tail sorts last
+  const int key_bits = bits_for((uint64_t)a.n_steps * (uint64_t)pp.rows_tot + 1ull);
+  if (key_bits <= 32) return em_plan_sorted<uint32_t>(pp, key_bits, (hipStream_t)stream);
+  return em_plan_sorted<uint64_t>(pp, key_bits, (hipStream_t)stream);
 }
 
 extern "C" int mke_oc_pass2(const mke_oc_step* s, void* stream) {

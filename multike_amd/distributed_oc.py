@@ -102,6 +102,7 @@ class OcHipBackend:
         a.n_all, a.max_step = tr._n_all, tr._max_step
         a.n_ranks, a.rank, a.n_local, a.n_rel = tr.world, tr.rank, max(1, tr.n_local), tr.rel.shape[0]
         a.keys, a.keys_alt, a.capacity = _lib.ptr(bufs["keys"], i64, "keys"), _lib.ptr(bufs["keys_alt"], i64, "keys"), bufs["capacity"]
+        a.vals_alt, a.wave_scratch = _lib.ptr(bufs["vals_alt"], i32, "vals_alt"), _lib.ptr(bufs["waves"], i32, "waves")
         a.refs, a.rows, a.off = _lib.ptr(bufs["refs"], i32, "refs"), _lib.ptr(bufs["rows"], i32, "rows"), _lib.ptr(bufs["off"], i32, "off")
         a.flags, a.scan = _lib.ptr(bufs["flags"], i32, "flags"), _lib.ptr(bufs["scan"], i32, "scan")
         a.step_row0, a.n_refs = _lib.ptr(bufs["row0"], i64, "row0"), _lib.ptr(bufs["n_refs"], i64, "n_refs")
@@ -921,6 +922,8 @@ class OwnerComputesTrainer:
         out["keys_alt"] = self._persist(("em_keys_alt",), z64, capacity + 1)
         out["flags"] = self._persist(("em_flags",), z32, capacity + 1)
         out["scan"] = self._persist(("em_scan",), z32, capacity + 1)
+        out["vals_alt"] = self._persist(("em_vals_alt",), z32, capacity + 1)
+        out["waves"] = self._persist(("em_waves",), z32, 2 * (_lib.OC_EM_WAVES + 1))
         out["temp"] = self._persist(("em_temp",), torch.zeros(0, dtype=torch.uint8, device=dev), self.backend.em_temp_bytes(capacity))
         out["refs"] = self._persist(("em_refs", bs), z32, 2 * capacity)
         out["rows"] = self._persist(("em_rows", bs), z32, capacity)

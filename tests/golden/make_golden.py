@@ -454,6 +454,88 @@ def schedule_fixture(out_json):
             out_json["schedules"][f"{method}/{name}"] = trace
 
 
+def pins_fixture(ref_batch, out):
+    """Three importable pieces of the reference EXECUTED on small inputs (round-5 review, item 5):
+      * `base.batch.generate_neighbours` / `find_neighbours` (code/base/batch.py:119-150) on a 700 x 20 matrix, k = 15 — the
+        matrix is drawn so that every row's k-th and (k+1)-th similarities are at least 2e-5 apart (ten times the float32 error of a 20-term inner product of unit vectors) (no ties at the boundary:
+        the expected neighbour SETS are exact whatever the arithmetic's last bits);
+      * `MultiKE_Late.wva` / `_compute_weight` (code/MultiKE_Late.py:64-88) on three random views;
+      * `AutoEncoderModel.encoder_multi_batches` (code/literal_encoder.py:114-144) on an instance made with `object.__new__`
+        and NumPy weights injected behind `.eval(session=...)` (the method itself is NumPy), sigmoid and tanh, a row count that
+        is and one that is not a multiple of the batch size."""
+    import contextlib
+    import io
+    from unittest import mock
+    # ---- k-NN refresh ------------------------------------------------------------------------------------------------
+    n, d, k = 700, 20, 15
+    seed = 0
+    while True:
+        rng = np.random.default_rng(4000 + seed)
+        e = rng.standard_normal((n, d)).astype(np.float32)
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        sim = np.sort(e.astype(np.float64) @ e.astype(np.float64).T, axis=1)[:, ::-1]
+        gap = sim[:, k - 1] - sim[:, k]
+        bad = np.nonzero(gap <= 2e-5)[0]
+        tries = 0
+        while len(bad) and tries < 200:          # re-draw the rows whose boundary is too tight (a few of 700), re-check all
+            e[bad] = rng.standard_normal((len(bad), d)).astype(np.float32)
+            e[bad] /= np.linalg.norm(e[bad], axis=1, keepdims=True)
+            sim = np.sort(e.astype(np.float64) @ e.astype(np.float64).T, axis=1)[:, ::-1]
+            gap = sim[:, k - 1] - sim[:, k]
+            bad = np.nonzero(gap <= 2e-5)[0]
+            tries += 1
+        if not len(bad):
+            break
+        seed += 1
+        if seed > 20:
+            raise SystemExit("no tie-free matrix found")
+    ids = (np.arange(n) * 3 + 5).tolist()
+    dic = ref_batch.generate_neighbours(e, ids, k, 2)
+    out["knn_embeds"], out["knn_ids"], out["knn_k"] = e, np.asarray(ids, dtype=np.int64), np.int64(k)
+    out["knn_table"] = np.asarray([sorted(dic[i]) for i in ids], dtype=np.int64)
+    out["knn_min_gap"] = np.float64(gap.min())
+    # ---- weighted view averaging ------------------------------------------------------------------------------------
+    tf = sys.modules["tensorflow"]
+    tf.__getattr__ = lambda name: mock.MagicMock(name="tf." + name)
+    tf.nn.__getattr__ = lambda name: mock.MagicMock(name="tf.nn." + name)
+    ref_late = importlib.import_module("MultiKE_Late")
+    rng = np.random.default_rng(4100)
+    views = [rng.standard_normal((300, 24)).astype(np.float32) for _ in range(3)]
+    views[1] = (0.5 * views[0] + views[1]).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        w = ref_late.wva(*views)
+    for i, v in enumerate(views):
+        out[f"wva_view{i}"] = v
+    out["wva_weights"] = np.asarray(w, dtype=np.float64)
+    # ---- the NumPy final encode of the literal auto-encoder -----------------------------------------------------------
+    ref_le = importlib.import_module("literal_encoder")
+
+    class _Var:
+        def __init__(self, a):
+            self.a = a
+
+        def eval(self, session=None):
+            return self.a
+
+    dims = [12, 8, 6, 4]
+    rng = np.random.default_rng(4200)
+    ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(3)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(3)]
+    for i in range(3):
+        out[f"enc_w{i}"], out[f"enc_b{i}"] = ws[i], bs[i]
+    for rows in (25, 30):
+        x = rng.standard_normal((rows, dims[0])).astype(np.float32)
+        out[f"enc_x{rows}"] = x
+        for act in ("sigmoid", "tanh"):
+            m = object.__new__(ref_le.AutoEncoderModel)
+            m.args = types.SimpleNamespace(dim=dims[-1], batch_size=10, encoder_active=act)
+            m.input_dimension, m.layer_num, m.session = dims[0], 3, None
+            m.weights = {f"encoder_h{i}": _Var(ws[i]) for i in range(3)}
+            m.biases = {f"encoder_b{i}": _Var(bs[i]) for i in range(3)}
+            with contextlib.redirect_stdout(io.StringIO()):
+                out[f"enc_out{rows}_{act}"] = np.asarray(m.encoder_multi_batches(x), dtype=np.float64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -487,6 +569,9 @@ def main():
     data_fixture(importlib.import_module("base.kgs"), ref_utils, importlib.import_module("predicate_alignment"), dj)
     with open(os.path.join(HERE, "data_golden.json"), "w") as f:
         json.dump(dj, f, separators=(",", ":"), sort_keys=True)
+    pins = {}
+    pins_fixture(ref_batch, pins)
+    np.savez_compressed(os.path.join(HERE, "pins_golden.npz"), **pins)
     sj = {}
     schedule_fixture(sj)
     with open(os.path.join(HERE, "schedule_golden.json"), "w") as f:

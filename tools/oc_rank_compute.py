@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--prefetch", action="store_true", help="the next epoch's plan on the side stream while the steps run (the product's default)")
     ap.add_argument("--zipf", type=float, default=0.0, help="head / tail entities of the synthetic triples ~ rank^-zipf (hub rows)")
     ap.add_argument("--rel-zipf", type=float, default=0.0, help="relation ids of the synthetic triples ~ rank^-rel_zipf")
+    ap.add_argument("--native", type=int, default=1, help="1 (default): the timed steps go through mke_oc_steps (one native call); 0: the Python step loop")
     ap.add_argument("--em", type=int, default=1, help="1 (default): entity-major second pass; 0: the atomics form of rounds 2-5")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
     a = ap.parse_args()
@@ -150,35 +151,41 @@ def main():
         e1.record()
         ev.append((names.get(phases, str(phases)), e0, e1))
 
-    n = min(a.steps, tr.steps - 1)
+    n = a.steps if a.native else min(a.steps, tr.steps - 1)
     for i in range(min(5, n)):
         tr.step(i)
     torch.cuda.synchronize()
-    # per-epoch plan (sampler of ALL the epoch's negatives + code packing + mke_oc_plan), in line
-    b = tr.bat
-    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    p0.record()
-    plan = tr._compute_plan((b.pos_h, b.pos_r, b.pos_t), b.rng_stream, 1)
-    p1.record()
-    torch.cuda.synchronize()
-    plan_ms = p0.elapsed_time(p1)
     # untimed wall of the steps (collectives = device copies of the same byte counts: an in-HBM stand-in, not a link)
     t0 = time.perf_counter()
-    for i in range(5, n):
-        tr.step(i)
+    if a.native:
+        tr.run(5, n - 5)                                      # mke_oc_steps: runs of steps enqueued from C++ (epoch boundaries in Python)
+    else:
+        for i in range(5, n):
+            tr.step(i)
     host = (time.perf_counter() - t0) / max(1, n - 5)         # the enqueue loop alone (nothing waits for the device)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / max(1, n - 5)
     # instrumented pass
     tr.backend.run = timed_run
     torch.cuda._sleep(int(2.4e9 * 0.03))
-    for i in range(n, min(tr.steps, n + 40)):
+    for i in range(n, n + 40):
+        if i % tr.steps == 0 and not a.native:
+            break
         tr.step(i)
     torch.cuda.synchronize()
+    # per-epoch plan (sampler of this rank's share of the epoch's negatives + code packing + mke_oc_plan + the entity-major
+    # lists), in line, after everything else (it overwrites a buffer set a prefetched plan may be waiting in)
+    b = tr.bat
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    p0.record()
+    tr._compute_plan((b.pos_h, b.pos_r, b.pos_t), b.rng_stream, 1)
+    p1.record()
+    torch.cuda.synchronize()
+    plan_ms = p0.elapsed_time(p1)
     phases = {}
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
-    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
+    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "native_loop": bool(a.native), "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
            "em_rows_per_step": (int(tr._em["row0_host"][-1]) / max(1, tr.steps)) if tr.em else None, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
            "capacity_vectors": tr.C,
