@@ -738,9 +738,10 @@ def main():
             # costs on its own (tools/rccl_latency.py at world 1: ~30 us of device time per async call + wait against
             # ~15 us in line; 27 us against 13 us on the host): two parts when a rank's all-gather moves >= 32 MB
             # (the c5 shape at 8 ranks: 40 MB now that one vector per positive travels), one otherwise (c2: 12.4 MB)
-            stride_f = (d + 15) // 16 * 16
-            wire = (world - 1) * 2 * 0.56 * B * stride_f * 4
-            chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "2" if world > 1 and wire >= 32e6 else "1"))
+            # Round 6: with the step loop native (mke_oc_steps) the host can feed two streams, but the split still loses on the
+            # DEVICE timeline — four stream hops per part at ~13 us each and two half-size score launches — at both shapes
+            # (tools/oc_rank_compute.py, profiles/r06_oc_native.log): one part per step unless MKE_SHARD_CHUNKS says otherwise
+            chunks = int(os.environ.get("MKE_SHARD_CHUNKS", "1"))
             # MKE_SHARD_PEER=1: peer-mapped blocks read / written directly by the score kernel instead of the all-gather /
             # reduce-scatter (opt-in: exercised with two ranks on one GPU only)
             trainer = OwnerComputesTrainer(kgs, ent0, rel0, B, N, rank, world, seed=1234, chunks=chunks,
@@ -751,6 +752,9 @@ def main():
         triples_of = trainer.global_scored
 
         def run_steps(i0, i1):
+            if hasattr(trainer, "run"):              # owner-computes: one native call per run of steps inside an epoch (mke_oc_steps)
+                trainer.run(i0, i1 - i0)
+                return
             for i in range(i0, i1):
                 run_step(i)
     else:

@@ -633,7 +633,8 @@ class OwnerComputesTrainer:
             comm = default_comm(self.device, world, self.force_collectives)
         self.comm = comm
         # the epoch plan's collective (the ranks' shares of the epoch's negative codes) on a communicator of its own
-        self._plan_comm = comm.for_plan() if (world > 1 and hasattr(comm, "for_plan")) else comm
+        # (round 5 put the epoch plan's collective on a communicator of its own, issued from the side stream: nothing ordered
+        # it against the step collectives across ranks — it now goes through `comm` at a fixed point of the step sequence)
         self.rank, self.world, self.lr = rank, world, float(lr)
         self.dim = ent0.shape[1]
         self.stride = _lib.stride_for(self.dim)
@@ -829,6 +830,27 @@ class OwnerComputesTrainer:
 
     # ---- per-epoch plan: table-independent, so the NEXT epoch's is computed on a side stream while this epoch trains -----
     def _compute_plan(self, pos, rng_stream, bs):
+        """The whole plan of an epoch order in line on the current stream: this rank's share of the negatives as codes, the
+        all-gather of the codes ON THE STEP COMMUNICATOR, the slots and reference lists."""
+        plan = self._plan_sample(pos, rng_stream, bs)
+        self._plan_gather(plan)
+        return self._plan_rest(plan)
+
+    def _plan_gather(self, plan):
+        """The ONE collective of an epoch plan: every rank's 1 / G of the epoch's negative codes, all-gathered on the step
+        communicator, on the stream the steps run on, at a fixed point of the step sequence (`_gather_at`) — so the ranks issue
+        every collective of the job in one order (round 5 issued it from the side stream on a communicator of its own:
+        concurrent collectives on two communicators, with nothing ordering them across ranks)."""
+        if "mine" in plan and self.world > 1:
+            if "sampled" in plan:
+                torch.cuda.current_stream().wait_event(plan["sampled"])
+            self.comm.all_gather(plan["codes_all"], plan["mine"])
+            if self.device.type == "cuda":
+                plan["gathered"] = torch.cuda.Event()
+                plan["gathered"].record()
+        plan["stage"] = "gathered"
+
+    def _plan_sample(self, pos, rng_stream, bs):
         """Device work only (no host synchronisation), into buffer set `bs`: the negatives of EVERY positive of the epoch
         (one sampler launch — every rank draws all of them itself: the Philox stream is a function of the epoch position,
         so the ranks agree without exchanging a byte) packed as codes; the slot of every positive's HR / RT vector in its
@@ -841,7 +863,7 @@ class OwnerComputesTrainer:
         plan = {"bs": bs}
         # Every rank draws the negatives of ITS contiguous 1 / G of the epoch positions (the Philox stream is a function of
         # the epoch position, so who draws a positive's negatives does not matter), packs them as codes, and ONE all-gather
-        # per epoch — on the plan's own communicator, from the stream the plan is computed on — gives every rank the whole
+        # per epoch (`_plan_gather`: on the step communicator, at a fixed point of the step sequence) gives every rank the whole
         # epoch's codes in position order.  (Rounds 2-4: every rank drew all of them — 63 us per step of rank compute at the
         # C5 shape with 8 ranks.)
         n_per = -(-n_all // G) if n_all else 0            # positions per rank (the last rank's share may be shorter)
@@ -864,8 +886,22 @@ class OwnerComputesTrainer:
                                            b.side1, b.side2, N, b.rng_seed, rng_stream, out)
                     self.backend.pack_codes(ph[a:e], out[0], out[2], N, mine[(a - lo_r) * N:(e - lo_r) * N])
             if G > 1:
-                self._plan_comm.all_gather(codes[:G * n_per * N], mine)
-        plan["codes"] = codes
+                plan["codes_all"], plan["mine"] = codes[:G * n_per * N], mine
+        plan["codes"], plan["pos"], plan["stage"] = codes, pos, "sampled"
+        if dev.type == "cuda":
+            plan["sampled"] = torch.cuda.Event()
+            plan["sampled"].record()
+        return plan
+
+    def _plan_rest(self, plan):
+        """What follows the codes' all-gather (device work only): slots, owned lists, counts, the entity-major reference lists."""
+        b, G, dev, N = self.bat, self.world, self.device, self.N
+        i32 = dict(dtype=torch.int32, device=dev)
+        ph, pr, pt = plan["pos"]
+        bs, codes = plan["bs"], plan["codes"]
+        n_all, parts, part_id = self._n_all, self._parts, self._part_id
+        if "gathered" in plan:
+            torch.cuda.current_stream().wait_event(plan["gathered"])
         # slot of every positive's HR / RT vector in its owner's block (rank among the positives of its part that NEED that
         # vector — the group flags in the first code of every positive — and have the same owner, epoch order; -1 when not
         # needed), this rank's owned positives per part in slot order (part k's list starts at own[lo_k]), and the
@@ -909,6 +945,7 @@ class OwnerComputesTrainer:
         if dev.type == "cuda":
             plan["event"] = torch.cuda.Event()
             plan["event"].record()
+        plan["stage"] = "done"
         return plan
 
     def _em_buffers(self, bs, capacity):
@@ -1023,9 +1060,14 @@ class OwnerComputesTrainer:
         staged = b.stage_next_epoch()                           # randperm + gather on the current stream (tiny)
         nxt = ((b.epoch + 1) * 2) & 0xFFFFFFFF
         bs = 1 - getattr(self, "_plan_bs", 0)
+        first = self._plan_sample if self.world > 1 else self._compute_plan      # G > 1: the collective waits for `_gather_at`
         if self.device.type != "cuda":
-            self._next_plan = self._compute_plan(staged, nxt, bs)
+            self._next_plan = first(staged, nxt, bs)
             return
+        self._on_side(lambda: setattr(self, "_next_plan", first(staged, nxt, bs)))
+
+    def _on_side(self, fn):
+        """Run fn with the plan's side stream current (and pinned for the native calls), ordered after the current stream."""
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
@@ -1033,13 +1075,32 @@ class OwnerComputesTrainer:
         with torch.cuda.stream(self._side):
             old = _lib.pin_stream(self._side.cuda_stream)
             try:
-                self._next_plan = self._compute_plan(staged, nxt, bs)
+                fn()
             finally:
                 _lib.pin_stream(old)
+
+    @property
+    def _gather_at(self):
+        """The step of an epoch before which the NEXT epoch's codes are all-gathered (mid-epoch: the sampling has half an epoch
+        of head start, the lists the other half)."""
+        return min(self.steps - 1, max(1, self.steps // 2)) if self.steps > 1 else 0
+
+    def _plan_midpoint(self):
+        """At step `_gather_at` of every epoch, on every rank: the prefetched plan's collective (main stream, step communicator),
+        then the rest of the plan back on the side stream."""
+        plan = getattr(self, "_next_plan", None)
+        if plan is None or plan.get("stage") != "sampled":
+            return
+        self._plan_gather(plan)
+        if self.device.type != "cuda":
+            self._plan_rest(plan)
+        else:
+            self._on_side(lambda: self._plan_rest(plan))
 
     def _advance_epoch(self):
         """Epoch boundary: random.shuffle of both positive lists (code/MultiKE_model.py:314-315) + the new epoch's plan."""
         if getattr(self, "_next_plan", None) is not None:
+            self._plan_midpoint()                            # (an epoch of one step: its midpoint is the boundary itself)
             plan, self._next_plan = self._next_plan, None
             if "event" in plan:
                 torch.cuda.current_stream().wait_event(plan["event"])
@@ -1145,6 +1206,11 @@ class OwnerComputesTrainer:
                 self._advance_epoch()
             if s == 0 and self.prefetch:
                 self._prefetch_next_epoch()                  # the next epoch's plan overlaps this epoch's steps
+            k = self._gather_at
+            if s == k:
+                self._plan_midpoint()
+            elif s < k < s + m and getattr(self, "_next_plan", None) is not None and self._next_plan.get("stage") == "sampled":
+                m = k - s                                    # stop at the epoch's gather point: the collective goes between two steps
             ok, cs = self._native_loop()                     # the exchange buffers may have grown with the new epoch's plan
             comm_stream = None
             if cs is not None and self.chunks > 1 and self.device.type == "cuda":
@@ -1163,6 +1229,8 @@ class OwnerComputesTrainer:
             self._advance_epoch()
         if s == 0 and self.prefetch:
             self._prefetch_next_epoch()                      # the next epoch's plan overlaps this epoch's steps
+        if s == self._gather_at:
+            self._plan_midpoint()
         be, G, cm = self.backend, self.world, self.comm
         ks = self._parts_of.get(s, [])
         self.tag += 1

@@ -91,20 +91,23 @@ def test_sharded_line_one_rank():
     assert d["rccl"]["world"] == 1 and d["rccl"]["backend"].startswith("nccl")      # a real one-rank RCCL group
 
 
-@pytest.mark.timeout(900)
-def test_bare_multi_gpu_command_launches_itself():
-    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 line): bench.py starts the two
-    ranks itself and rank 0 prints the one JSON line, with the process group's own view of the job in `rccl`."""
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bare_multi_gpu_command_launches_itself(gpus):
+    """`python bench.py --gpus N` with NO launcher around it (the shape of the driver's N = 1 line): bench.py starts the N
+    ranks itself and rank 0 prints the one JSON line, with the process group's own view of the job in `rccl` — world == N and
+    EVERY rank reporting its device (N = 8: the size of the driver's scaling run, here as 8 ranks sharing the GPU)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["MKE_BENCH_COMM"] = "staged"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
-                         capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=1100, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and [x["rank"] for x in d["rccl"]["devices"]] == [0, 1]
+    assert d["n_gpus"] == gpus and d["rccl"]["world"] == gpus and [x["rank"] for x in d["rccl"]["devices"]] == list(range(gpus))
     assert "DRY RUN" in d["data"] and "gloo" in d["rccl"]["backend"]
+    assert d["config"]["scored_per_step"] == gpus * d["config"]["batch"] * (1 + d["config"]["neg"])
 
 
 @pytest.mark.timeout(900)

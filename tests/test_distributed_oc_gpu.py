@@ -321,6 +321,33 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em, native):
     np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,chunks,em,native", [(8, 1, True, True), (8, 2, True, True), (8, 1, False, False), (5, 2, True, True)])
+def test_eight_ranks_on_one_gpu_equal_dense_oracle(world, chunks, em, native):
+    """world_size 8 — the size the multi-GPU bench runs at: owner = id & 7 (the shift / mask instantiation of the score kernels
+    and of the plan walks), 2,400 positives per global step, each rank scoring the eighth of the negatives it owns, entity-major
+    second pass + the native step loop (collectives by callback into the host-staged communicator), against the float64 dense
+    oracle.  world 5: the division instantiation."""
+    import torch.multiprocessing as mp
+    import tempfile
+    port = tempfile.mktemp(prefix="mke_rdv_")
+    steps = 4
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, ret, chunks, steps, False, NEG, em, native)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, rel, loss, ok = ret.get(timeout=800)
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    e, r, losses, spe = _reference(world, steps)
+    assert steps <= spe and ok
+    np.testing.assert_allclose(loss, sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
+
+
 def test_one_rank_rccl_collectives_run():
     """1-rank RCCL group: the trainer's own communicator class (all_gather_into_tensor / reduce_scatter_tensor / all_reduce)
     is importable and the G = 1 short-cuts leave it untouched."""
