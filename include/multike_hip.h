@@ -9,9 +9,11 @@
  *     need the HIP headers; NULL = the legacy default stream).
  *   - Return value: 0 = ok, <0 = bad argument (MKE_E_*), >0 = a hipError_t from the launch.
  *     mke_last_error() returns a thread-local human-readable message for the last non-zero return.
- *   - No global mutable state except the process-wide tuning knobs of mke_set_option: the library is re-entrant;
- *     two host threads may enqueue on two streams.  mke_relation_steps in overlap mode creates (and destroys) a
- *     private stream and events for the duration of the call.
+ *   - No global mutable state inside a call: the library is re-entrant, two host threads may enqueue on two streams, and
+ *     every performance knob travels WITH the plan / arguments of a call (mke_tuning, version 105: two trainers in one
+ *     process may hold different settings).  mke_set_option only sets the process-wide DEFAULTS that a tuning field left
+ *     at MKE_TUNE_DEFAULT (or a NULL mke_tuning) falls back to.  mke_relation_steps in overlap mode creates (and
+ *     destroys) a private stream and events for the duration of the call.
  *
  * The reference (nju-websoft/MultiKE) has NO native code; each entry point below replaces a group of
  * TensorFlow-1.x graph ops that the reference builds in Python.  The "replaces" lines cite the
@@ -56,7 +58,18 @@ extern "C" {
 int mke_version(void);
 const char* mke_last_error(void);
 
-/* Process-wide tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
+/* Per-call tuning (version 105; performance only, never results): a field at MKE_TUNE_DEFAULT follows the process default
+ * (mke_set_option).  Carried by pointer (NULL = all defaults) in mke_relation_plan, mke_attr_step_args and mke_oc_step, and
+ * taken as an argument by the *_t entry points; the library reads it for the duration of that one call only. */
+#define MKE_TUNE_DEFAULT (-2)
+typedef struct mke_tuning {
+  int score_splits, score_half_groups, score_offsets32, score_lane_ids, count_in_score, update_chunk, oc_score_quarter,
+      attr_fused_bwd, sampler_fast;
+  int reserved[7];   /* MKE_TUNE_DEFAULT */
+} mke_tuning;
+int mke_tuning_init(mke_tuning* t);   /* every field = MKE_TUNE_DEFAULT */
+
+/* Process-wide DEFAULTS of the tuning knobs (performance only, never results).  Unknown name -> MKE_E_UNSUPPORTED.
  *   "score_splits"  : wavefronts sharing one positive's negatives in mke_triple_score_fwd_bwd (0 = auto)
  *   "update_chunk"  : rows per wavefront of the row-update kernels on large tables: 0 = by table size (default), 16, 64
  *   "attr_fused_bwd" : attribute step, 64 < dim <= 80: 1 (default) = the dflat product inside the convolution-backward launch and
@@ -467,6 +480,7 @@ typedef struct mke_relation_plan {
                                                 loops, code/MultiKE_model.py:393-414); neg_per_pos == 0 runs positives only */
   mke_hot_rows hot;                          /* version 103: hub rows of the entity table (slot == NULL: none); ent_grad then has
                                                 hot.row0 + hot.copies * hot.n_hot rows */
+  const mke_tuning* tuning;                  /* version 105: host pointer, NULL = the process defaults */
 } mke_relation_plan;
 
 int mke_relation_steps(const mke_relation_plan* plan, int step_begin, int step_end, void* stream);
@@ -612,6 +626,7 @@ typedef struct mke_attr_step_args {
   int attr_grad_copies;   /* version 104: 0 / 1 = attr_grad is [n_attr][attr_stride]; c > 1 = [c][n_attr][attr_stride], all zero between steps:
                              triple t adds to copy t % c and the update sums them (a few hundred attribute rows take a step's 5,000
                              triples, and real attribute frequencies are heavy-tailed: same-address atomics serialise) */
+  const mke_tuning* tuning;   /* version 105: host pointer, NULL = the process defaults */
 } mke_attr_step_args;
 int64_t mke_attr_scratch_floats(int64_t n, int dim);
 int mke_attr_step(const mke_attr_step_args* args, void* stream);
@@ -850,6 +865,7 @@ typedef struct mke_oc_step {
   float* em_coef; int64_t em_pos0;
   const uint32_t* em_refs; const int32_t* em_rows; const int32_t* em_off; int64_t em_n_rows;
   int em_chunks; int64_t em_block_floats; const float* em_v[4]; const float* em_gv[4];
+  const mke_tuning* tuning;   /* version 105: host pointer, NULL = the process defaults */
 } mke_oc_step;
 #define MKE_OC_EM_MAX_CHUNKS 4
 #define MKE_OC_EM_WAVES 32768
@@ -945,6 +961,18 @@ typedef struct mke_oc_loop {
   const mke_oc_comm* comm; void* comm_stream;
 } mke_oc_loop;
 int mke_oc_steps(const mke_oc_loop* loop, int step_begin, int step_end, void* stream);
+
+/* The per-step entry points with their tuning as an argument (version 105): mke_triple_score_fwd_bwd_xch and
+ * mke_rows_update_multi_count, `tuning` = NULL being exactly those. */
+int mke_triple_score_fwd_bwd_t(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int grad_rel_copies, int32_t* touched_ent,
+    int32_t* touched_rel, int32_t tag, int32_t* ref_count, float* ent_acc, int optimizer, float lr,
+    const mke_count_job* next_count, const mke_hot_rows* hot, const mke_tuning* tuning, double* loss_partials, void* stream);
+int mke_rows_update_multi_t(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
+                            float lr, const mke_count_job* count, const mke_tuning* tuning, void* stream);
 
 #ifdef __cplusplus
 }

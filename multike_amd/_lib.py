@@ -35,6 +35,7 @@ SYMBOLS = (
     "mke_ae_scratch_floats", "mke_ae_train_steps", "mke_ae_step_phases", "mke_ae_encode", "mke_dense_layer_fwd",
     "mke_topk_long", "mke_probe_rows", "mke_oc_block_floats", "mke_oc_pack_codes", "mke_oc_plan", "mke_oc_bases", "mke_oc_count", "mke_oc_score", "mke_oc_apply", "mke_oc_run",
     "mke_oc_em_plan_temp_bytes", "mke_oc_em_plan", "mke_oc_pass2", "mke_oc_steps",
+    "mke_tuning_init", "mke_triple_score_fwd_bwd_t", "mke_rows_update_multi_t",
 )
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 AE_MAX_LAYERS = 4
@@ -51,7 +52,7 @@ class AttrStepArgs(C.Structure):
         ("ih", C.c_void_p), ("ia", C.c_void_p), ("iv", C.c_void_p), ("weights", C.c_void_p), ("n", C.c_int64),
         ("scale", C.c_float), ("params", C.c_void_p), ("param_grads", C.c_void_p), ("param_acc", C.c_void_p),
         ("scratch", C.c_void_p), ("partials", C.c_void_p), ("optimizer", C.c_int), ("lr", C.c_float), ("tag", C.c_int32),
-        ("update", C.c_int), ("workspace", C.c_void_p), ("attr_grad_copies", C.c_int),
+        ("update", C.c_int), ("workspace", C.c_void_p), ("attr_grad_copies", C.c_int), ("tuning", C.c_void_p),
     ]
 
 
@@ -109,7 +110,33 @@ class OcStepStruct(C.Structure):
                 # version 105: entity-major second pass
                 ("em_coef", C.c_void_p), ("em_pos0", C.c_int64), ("em_refs", C.c_void_p), ("em_rows", C.c_void_p), ("em_off", C.c_void_p),
                 ("em_n_rows", C.c_int64), ("em_chunks", C.c_int), ("em_block_floats", C.c_int64), ("em_v", C.c_void_p * 4),
-                ("em_gv", C.c_void_p * 4)]
+                ("em_gv", C.c_void_p * 4), ("tuning", C.c_void_p)]
+
+
+TUNE_DEFAULT = -2
+TUNING_FIELDS = ("score_splits", "score_half_groups", "score_offsets32", "score_lane_ids", "count_in_score", "update_chunk",
+                 "oc_score_quarter", "attr_fused_bwd", "sampler_fast")
+
+
+class TuningStruct(C.Structure):
+    """mke_tuning: the performance knobs of ONE plan / call (a field at TUNE_DEFAULT follows mke_set_option's process default)."""
+    _fields_ = [(f, C.c_int) for f in TUNING_FIELDS] + [("reserved", C.c_int * 7)]
+
+
+def tuning(**knobs) -> TuningStruct:
+    """A mke_tuning with the given knobs set and every other field at the process default.  The caller keeps it alive for as long
+    as a plan points at it."""
+    t = TuningStruct()
+    _check(lib().mke_tuning_init(C.byref(t)), "mke_tuning_init")
+    for k, v in knobs.items():
+        if k not in TUNING_FIELDS:
+            raise MultiKEHipError(f"unknown tuning knob {k!r}")
+        setattr(t, k, int(v))
+    return t
+
+
+def tuning_ptr(t) -> int | None:
+    return C.addressof(t) if t is not None else None
 
 
 OC_EM_MAX_CHUNKS = 4
@@ -194,7 +221,7 @@ class RelationPlanStruct(C.Structure):
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("stream_id", C.c_uint32),
         ("optimizer", C.c_int), ("lr", C.c_float), ("scale", C.c_float),
         ("loss_partials", C.c_void_p), ("loss_ring", C.c_int), ("tag_base", C.c_int32), ("pos_w", C.c_void_p),
-        ("hot", HotRowsStruct),
+        ("hot", HotRowsStruct), ("tuning", C.c_void_p),
     ]
 
 _lib = None
@@ -355,13 +382,30 @@ def count_entity_refs(pos_h, pos_t, neg_h, neg_t, neg_per_pos, ref_count):
 
 
 def triple_score_fwd_bwd_x(ent, ent_normalize, rel, rel_normalize, dim, pos, pos_w, neg, neg_w, neg_per_pos, scale, grad_ent,
-                           grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, loss_partials, hot=None):
+                           grad_rel, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, loss_partials, hot=None,
+                           tuning=None):
     """mke_triple_score_fwd_bwd_x: the fused step with the exclusive-row fast path (ref_count filled by
     count_entity_refs for the same batch).  hot (HotRowsStruct of the entity table, `EmbeddingTable.hot_struct()`): the hub
     rows' flushes go to their private copies (mke_triple_score_fwd_bwd_xch); the update must then get the same struct."""
     ph, pr, pt = pos
     nh, nr, nt = neg
     rel_copies = 1 if grad_rel.dim() == 2 else grad_rel.shape[0]
+    if tuning is not None:       # this call's knobs (TuningStruct): mke_triple_score_fwd_bwd_t
+        rc = lib().mke_triple_score_fwd_bwd_t(
+            _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
+            _dev(rel, torch.float32, "rel_table"), C.c_int64(rel.shape[0]), C.c_int(int(rel_normalize)),
+            C.c_int(ent.shape[1]), C.c_int(dim),
+            _dev(ph, torch.int32, "pos_h"), _dev(pr, torch.int32, "pos_r"), _dev(pt, torch.int32, "pos_t"),
+            _dev(pos_w, torch.float32, "pos_w"), C.c_int64(ph.numel()),
+            _dev(nh, torch.int32, "neg_h"), _dev(nr, torch.int32, "neg_r"), _dev(nt, torch.int32, "neg_t"),
+            _dev(neg_w, torch.float32, "neg_w"), C.c_int64(nh.numel()), C.c_int(neg_per_pos), C.c_float(scale),
+            _dev(grad_ent, torch.float32, "grad_ent"), _dev(grad_rel, torch.float32, "grad_rel"), C.c_int(rel_copies),
+            _dev(touched_ent, torch.int32, "touched_ent"), _dev(touched_rel, torch.int32, "touched_rel"), C.c_int32(tag),
+            _dev(ref_count, torch.int32, "ref_count"), _dev(ent_acc, torch.float32, "ent_acc"), C.c_int(optimizer), C.c_float(lr),
+            None, (C.byref(hot) if hot is not None and hot.n_hot > 0 else None), C.byref(tuning),
+            _dev(loss_partials, torch.float64, "loss_partials"), _stream())
+        _check(rc, "mke_triple_score_fwd_bwd_t")
+        return
     if hot is not None and hot.n_hot > 0:
         rc = lib().mke_triple_score_fwd_bwd_xch(
             _dev(ent, torch.float32, "ent_table"), C.c_int64(ent.shape[0]), C.c_int(int(ent_normalize)),
@@ -406,7 +450,7 @@ def ptr(t: torch.Tensor | None, dtype, name: str) -> int | None:
     return _dev(t, dtype, name).value
 
 
-def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
+def rows_update_multi(tables, tag, stride, dim, optimizer, lr, tuning=None):
     """tables: list of (data, acc, grad, touched, normalize[, ref_count[, hot]]) (hot: the table's HotRowsStruct); or, for the owner side of the sharded
     step, a dict(table=, acc=, normalize=, src_rows=, slot_of=, n_ranks=, capacity=) (mke_update_table.slot_of)."""
     arr = (UpdateTableStruct * len(tables))()
@@ -435,6 +479,11 @@ def rows_update_multi(tables, tag, stride, dim, optimizer, lr):
         arr[k].n_rows = data.shape[0]
         arr[k].normalize = int(normalize)
         arr[k].grad_copies = 1 if grad.dim() == 2 else grad.shape[0]
+    if tuning is not None:       # this call's knobs (TuningStruct)
+        rc = lib().mke_rows_update_multi_t(arr, C.c_int(len(tables)), C.c_int32(tag), C.c_int(stride), C.c_int(dim),
+                                           C.c_int(optimizer), C.c_float(lr), None, C.byref(tuning), _stream())
+        _check(rc, "mke_rows_update_multi_t")
+        return
     rc = lib().mke_rows_update_multi(arr, C.c_int(len(tables)), C.c_int32(tag), C.c_int(stride), C.c_int(dim),
                                      C.c_int(optimizer), C.c_float(lr), _stream())
     _check(rc, "mke_rows_update_multi")

@@ -36,8 +36,16 @@ int g_score_lane_ids = 1;    // training kernel: a group's ids and reference cou
 int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on large tables: 0 = by table size, 16, 64
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
 int g_sampler_fast = 1;      // mke_sampler.hip: coin block in the draw evaluation's idle lane, LDS duplicate test (0: the earlier form)
-extern int g_attr_fused_bwd;     // mke_attr_cnn.hip: dflat product inside the convolution-backward launch, dW on rider blocks
-extern int g_oc_score_quarter;   // mke_oc.hip: quarter-wave per positive in the owner-computes score kernel: -1 = by shape, 0 / 1
+int g_attr_fused_bwd = 1;    // mke_attr_cnn.hip: dflat product inside the convolution-backward launch, dW on rider blocks (every dim <= 80)
+int g_oc_score_quarter = -1; // mke_oc.hip: quarter-wave per positive in the owner-computes score kernel: -1 = by shape, 0 / 1
+thread_local const mke_tuning* tl_tuning = nullptr;   // the tuning of the API call in progress on this thread (mke_common.h)
+}
+
+extern "C" int mke_tuning_init(mke_tuning* t) {
+  if (!t) { mke::set_error("mke_tuning_init: NULL"); return MKE_E_NULL; }
+  int* f = reinterpret_cast<int*>(t);
+  for (size_t i = 0; i < sizeof(mke_tuning) / sizeof(int); ++i) f[i] = MKE_TUNE_DEFAULT;
+  return MKE_OK;
 }
 
 extern "C" int mke_set_option(const char* name, int value, int* old_value) {

@@ -851,7 +851,6 @@ int launch_gemm_f32_pair(const float* A0, int64_t a0_rs, int64_t a0_cs, const fl
 int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
                              float lr, hipStream_t st, const mke_count_job* count, const DenseJob* dense);
 
-int g_attr_fused_bwd = 1;     // mke_set_option("attr_fused_bwd"): dflat inside the convolution-backward launch, dW on rider blocks (every dim <= 80)
 
 static int conv_dispatch(const ConvParams& p, bool bwd, hipStream_t st) {
   // dim <= 96: two triples per wavefront, 32 lanes each (dim 75: three passes of 32 lanes instead of two of 64)
@@ -1032,6 +1031,7 @@ extern "C" int64_t mke_attr_scratch_floats(int64_t n, int dim) {
 static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ssq, double* dot, void* stream, int phases);
 
 extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
+  mke::TuningScope scope(a ? a->tuning : nullptr);   // the arguments' knobs for the duration of this call
   if (!a) { mke::set_error("mke_attr_step: NULL args"); return MKE_E_NULL; }
   if (!a->partials) { mke::set_error("mke_attr_step: NULL pointer"); return MKE_E_NULL; }
   return attr_step_impl(a, a->partials, a->partials + MKE_LOSS_PARTIALS, a->partials + 2 * MKE_LOSS_PARTIALS, stream, MKE_ATTR_ALL);
@@ -1044,6 +1044,7 @@ extern "C" int mke_attr_step(const mke_attr_step_args* a, void* stream) {
 // (replace each array by [global sum, 0, 0, ...]: the consuming kernel adds the entries up itself), and the parameter /
 // attribute-table gradients between MKE_ATTR_BWD and MKE_ATTR_UPD.
 extern "C" int mke_attr_step_phases(const mke_attr_step_args* a, int phases, void* stream) {
+  mke::TuningScope scope(a ? a->tuning : nullptr);   // the arguments' knobs for the duration of this call
   using namespace mke;
   if (!a) { set_error("mke_attr_step_phases: NULL args"); return MKE_E_NULL; }
   if (phases <= 0 || phases > MKE_ATTR_ALL) { set_error("mke_attr_step_phases: bad phase mask"); return MKE_E_SHAPE; }
@@ -1053,6 +1054,7 @@ extern "C" int mke_attr_step_phases(const mke_attr_step_args* a, int phases, voi
 
 extern "C" int mke_attr_steps(const mke_attr_step_args* args, const int64_t* step_off, int n_steps, double* loss_ring, int ring,
                               void* stream) {
+  mke::TuningScope scope(args ? args->tuning : nullptr);   // the arguments' knobs for the duration of this call
   using namespace mke;
   if (!args || !step_off || !loss_ring) { set_error("mke_attr_steps: NULL pointer"); return MKE_E_NULL; }
   if (n_steps < 0 || ring < 1) { set_error("mke_attr_steps: bad n_steps/ring"); return MKE_E_SHAPE; }
@@ -1125,7 +1127,7 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   // (dflat never goes to memory), and [dW; dbias] = [flat, 1]^T dz (split over K, atomic) rides on extra blocks of the same grid,
   // forming dz on the way into its MFMAs.  W^T (the B operand read 16 consecutive floats per quarter-wave) is left in the unused dflat
   // scratch by the loss-tail launch.  4 launches per step: forward, loss tail, backward, updates.
-  const bool fused_tail = g_attr_fused_bwd && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
+  const bool fused_tail = tune_attr_fused_bwd() && d <= 80 && (int64_t)n * fs < (1LL << 31) && n >= d;
   if ((phases & MKE_ATTR_TAIL) &&
       (rc = tail_loss_impl(z, ssq, a->ent_table, a->ent_stride, a->ent_normalize, a->ih, a->weights, a->scale, n, d, gout, dot,
                            a->ent_grad, a->ent_touched, a->tag, lossp, fused_tail ? W : nullptr, fused_tail ? dflat : nullptr, stream))) return rc;

@@ -119,6 +119,28 @@ struct UpdateTouchedHint {
   ~UpdateTouchedHint() { g_update_touched_hint = 0; }
 };
 
+// Per-call tuning (mke_tuning): the entry point that carries one installs it for the duration of the call (thread-local, so two
+// host threads with different plans do not see each other); the launchers read a knob through tune(): the call's value, else the
+// process default set by mke_set_option.
+extern thread_local const mke_tuning* tl_tuning;
+struct TuningScope {
+  const mke_tuning* prev;
+  explicit TuningScope(const mke_tuning* t) : prev(tl_tuning) { if (t) tl_tuning = t; }
+  ~TuningScope() { tl_tuning = prev; }
+};
+extern int g_score_splits, g_score_half_max, g_score_o32, g_score_lane_ids, g_count_in_score, g_update_chunk, g_oc_score_quarter,
+    g_attr_fused_bwd, g_sampler_fast;
+#define MKE_TUNE(field, dflt) ((mke::tl_tuning && mke::tl_tuning->field != MKE_TUNE_DEFAULT) ? mke::tl_tuning->field : (dflt))
+inline int tune_score_splits() { const int v = MKE_TUNE(score_splits, g_score_splits); return v < 0 ? 0 : v; }
+inline int tune_score_half_max() { const int v = MKE_TUNE(score_half_groups, g_score_half_max); return v < 0 ? -1 : (v > 64 ? 64 : v); }
+inline int tune_score_o32() { return MKE_TUNE(score_offsets32, g_score_o32) != 0; }
+inline int tune_score_lane_ids() { return MKE_TUNE(score_lane_ids, g_score_lane_ids) != 0; }
+inline int tune_count_in_score() { return MKE_TUNE(count_in_score, g_count_in_score) != 0; }
+inline int tune_update_chunk() { const int v = MKE_TUNE(update_chunk, g_update_chunk); return v == 16 ? 16 : (v == 64 ? 64 : 0); }
+inline int tune_oc_score_quarter() { const int v = MKE_TUNE(oc_score_quarter, g_oc_score_quarter); return v < 0 ? -1 : (v != 0); }
+inline int tune_attr_fused_bwd() { return MKE_TUNE(attr_fused_bwd, g_attr_fused_bwd) != 0; }
+inline int tune_sampler_fast() { return MKE_TUNE(sampler_fast, g_sampler_fast) != 0; }
+
 // Block-wide sum of one float per thread, accumulated in double; thread 0 gets the result.
 __device__ __forceinline__ double block_sum_double(float v) {
   __shared__ double s_part[MKE_BLOCK / 64];

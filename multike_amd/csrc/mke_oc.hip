@@ -33,7 +33,6 @@
 
 namespace mke {
 
-int g_oc_score_quarter = -1;   // mke_set_option("oc_score_quarter")
 
 struct OcParams {
   mke_oc_step s;
@@ -714,6 +713,7 @@ extern "C" int mke_oc_count(const mke_oc_step* s, void* stream) {
 
 extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t block_floats, float* g_all, double* loss_partials,
                             void* stream) {
+  mke::TuningScope scope((s && s->tuning) ? s->tuning : nullptr);   // the step's knobs for the duration of this call
   using namespace mke;
   int rc = oc_check(s, "mke_oc_score");
   if (rc) return rc;
@@ -727,7 +727,8 @@ extern "C" int mke_oc_score(const mke_oc_step* s, const float* v_all, int64_t bl
   // wider rows leave two wavefronts per SIMD at 194 registers) — k_oc_score_q;
   // option "oc_score_quarter": -1 = by shape (default), 0 = never, 1 = always
   const bool pow2 = (s->n_ranks & (s->n_ranks - 1)) == 0;     // id / G, id % G as shift / mask (2, 4, 8 ranks)
-  const bool quarter = g_oc_score_quarter < 0 ? (s->n_ranks >= 4 && s->neg_per_pos <= 8 * s->n_ranks && s->stride <= 128) : g_oc_score_quarter != 0;
+  const int oq = tune_oc_score_quarter();
+  const bool quarter = oq < 0 ? (s->n_ranks >= 4 && s->neg_per_pos <= 8 * s->n_ranks && s->stride <= 128) : oq != 0;
   const dim3 grid(MKE_LOSS_PARTIALS), blk(MKE_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   if (quarter) {
@@ -774,6 +775,7 @@ int launch_rows_update_multi(const mke_update_table* tables, int n_tables, int32
 // goes into one call: single rank: 31;  G > 1: 1 | all-gather | 6 | reduce-scatter | 8 | all-reduce | 16.
 extern "C" int mke_oc_run(const mke_oc_step* s, int phases, float* send_block, const float* v_all, int64_t block_floats, float* g_all,
                           const float* gv, double* loss_partials, void* stream) {
+  mke::TuningScope scope((s && s->tuning) ? s->tuning : nullptr);   // the step's knobs for the duration of this call
   using namespace mke;
   int rc = MKE_OK;
   if (s && s->em_coef) phases &= ~MKE_OC_COUNT;                              // entity-major: nothing is reference-counted

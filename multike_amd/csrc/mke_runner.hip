@@ -5,7 +5,6 @@
 #include "mke_common.h"
 
 namespace mke {
-extern int g_count_in_score;   // mke_set_option("count_in_score"), default 1
 #define RUN_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("mke_relation_steps: %s: %s", #x, hipGetErrorString(e_)); rc = (int)e_; goto done; } } while (0)
 #define RUN_MKE(x) do { rc = (x); if (rc) goto done; } while (0)
 
@@ -108,6 +107,7 @@ done:
 extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, int step_end, void* stream) {
   using namespace mke;
   if (!pl) { set_error("mke_relation_steps: NULL plan"); return MKE_E_NULL; }
+  TuningScope scope(pl->tuning);       // the plan's knobs for the duration of this call
   if (!pl->step_off || !pl->pos_h || !pl->pos_r || !pl->pos_t || !pl->loss_partials) { set_error("mke_relation_steps: NULL pointer in plan"); return MKE_E_NULL; }
   if (step_begin < 0 || step_end > pl->n_steps || step_begin > step_end) { set_error("step range [%d,%d) outside [0,%d)", step_begin, step_end, pl->n_steps); return MKE_E_SHAPE; }
   if (pl->loss_ring < 1 || pl->sample_chunk < 1) { set_error("loss_ring and sample_chunk must be >= 1"); return MKE_E_SHAPE; }
@@ -170,7 +170,7 @@ extern "C" int mke_relation_steps(const mke_relation_plan* pl, int step_begin, i
       cjp = &cj;
       counted_ahead = true;
     }
-    const bool in_score = g_count_in_score != 0;
+    const bool in_score = tune_count_in_score() != 0;
     rc = mke_triple_score_fwd_bwd_xch(pl->ent_table, pl->n_ent, pl->ent_normalize, pl->rel_table, pl->n_rel, pl->rel_normalize,
                                      pl->stride, pl->dim, pl->pos_h + lo, pl->pos_r + lo, pl->pos_t + lo, pl->pos_w ? pl->pos_w + lo : nullptr, hi - lo,
                                      N ? pl->neg_h + no : nullptr, N ? pl->neg_r + no : nullptr, N ? pl->neg_t + no : nullptr,

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_tripleset_query(const int32_t* __
 }  // namespace mke
 
 namespace mke {
-extern int g_sampler_fast;  // mke_set_option("sampler_fast"): 0 = the two-evaluation / shuffle-loop form (A/B)
 int validate_side(const mke_kg_side& sd, int neg_per_pos) {
   // random.sample raises ValueError when the population is smaller than the sample (batch.py:98,101)
   if (sd.n_ent < neg_per_pos) { set_error("candidate population (%d) smaller than neg_per_pos (%d)", sd.n_ent, neg_per_pos); return MKE_E_SHAPE; }
@@ -226,11 +225,11 @@ int launch_neg_sample(const int32_t* pos_h, const int32_t* pos_r, const int32_t*
   p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.sid = stream_id;
   p.nh = neg_h; p.nr = neg_r; p.nt = neg_t;
   // lanes per positive: 16 (four positives per wavefront; fast form only, which needs an idle lane: neg_per_pos <= 15), 32, 64
-  const int gs = (g_sampler_fast && neg_per_pos <= 15) ? 16 : (neg_per_pos <= 32 ? 32 : 64);
+  const int gs = (tune_sampler_fast() && neg_per_pos <= 15) ? 16 : (neg_per_pos <= 32 ? 32 : 64);
   const int64_t pos_per_block = (MKE_BLOCK / 64) * (64 / gs);
   const int64_t blocks = (n_pos + pos_per_block - 1) / pos_per_block;
   const dim3 grid((unsigned)blocks), blk(MKE_BLOCK);
-  if (g_sampler_fast) {
+  if (tune_sampler_fast()) {
     if (gs == 16) hipLaunchKernelGGL((k_neg_sample<16, true>), grid, blk, 0, st, p);
     else if (gs == 32) hipLaunchKernelGGL((k_neg_sample<32, true>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((k_neg_sample<64, true>), grid, blk, 0, st, p);

@@ -17,10 +17,6 @@ namespace mke {
 #ifndef MKE_SCORE_U
 #define MKE_SCORE_U 2
 #endif
-extern int g_score_splits;    // mke_set_option("score_splits")
-extern int g_score_lane_ids;  // mke_set_option("score_lane_ids")
-extern int g_score_o32;       // mke_set_option("score_offsets32"), default 1
-extern int g_score_half_max;  // mke_set_option("score_half_groups"): largest neg_per_pos scored two groups per wavefront (0 = off)
 
 struct ScoreParams {
   const float* ent;   // NOT __restrict__: ent_w below aliases it (in-place update of rows referenced once; such a row is never
@@ -541,7 +537,7 @@ static int score_impl(
     const int64_t smax = (neg_per_pos + 3) / 4;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
-    if (g_score_splits > 0) s = g_score_splits;
+    if (tune_score_splits() > 0) s = tune_score_splits();
     if (s > neg_per_pos) s = neg_per_pos;
     splits = (int)s;
   }
@@ -580,7 +576,7 @@ static int score_impl(
   const int fpl = stride / 16;
   // every row address of the launch fits 32 bits of byte offset (entity table = accumulator = gradient scratch in size)
   const int64_t grad_rows = p.hot_slot ? (int64_t)p.hot_row0 + (int64_t)p.hot_copies * p.n_hot : n_ent;
-  const bool o32 = g_score_o32 && grad_rows * (int64_t)stride < (1ll << 30) && n_rel * (int64_t)stride < (1ll << 30);
+  const bool o32 = tune_score_o32() && grad_rows * (int64_t)stride < (1ll << 30) && n_rel * (int64_t)stride < (1ll << 30);
   MKE_DISPATCH_FPL(fpl, {
     // corrupt rows in flight per quarter-wave.  2, not 4, at FPL <= 5: with the accumulator rows of the exclusive-row path
     // U = 4 costs 144-153 registers = 3 waves per SIMD, U = 2 119 = 4 waves per SIMD, and the extra wave hides more
@@ -592,7 +588,7 @@ static int score_impl(
     // N 64 209 / 201; dim 200: N 25 143 / 140, N 40 208 / 210, N 64 312 / 326; dim 256, N 64 (C5): 238 / 277 us per launch.
     // Default: rows up to 128 floats always, wider rows up to 31 negatives (mke_set_option("score_half_groups", n): up to
     // n negatives at every width; 0: never).
-    const int half_max = g_score_half_max >= 0 ? g_score_half_max : (FPL <= 8 ? 64 : 31);
+    const int half_max = tune_score_half_max() >= 0 ? tune_score_half_max() : (FPL <= 8 ? 64 : 31);
     const bool half = neg_per_pos > 0 && neg_per_pos <= half_max && splits == 1;
     if (n_pos * (int64_t)splits > 0xFFFFFFFFll || n_pos + n_neg > 0xFFFFFFFFll) { set_error("more than 2^32 work items in one launch"); return MKE_E_RANGE; }
     if (stage_keys) {
@@ -605,9 +601,9 @@ static int score_impl(
         else hipLaunchKernelGGL((k_triple_score<FPL, U, false, 4, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       }
     } else if (excl && o32) {   // the training step on tables below 4 GB: 32-bit row offsets (row_at)
-      if (half && g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      if (half && tune_score_lane_ids()) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else if (half) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
-      else if (g_score_lane_ids) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
+      else if (tune_score_lane_ids()) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
       else hipLaunchKernelGGL((k_triple_score<FPL, U, true, 4, false, true>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
     } else if (half) {
       if (excl) hipLaunchKernelGGL((k_triple_score<FPL, U, true, 2>), dim3(MKE_LOSS_PARTIALS), dim3(MKE_BLOCK), 0, st, p);
@@ -663,6 +659,20 @@ extern "C" int mke_triple_score_fwd_bwd_xch(
                     n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel, grad_rel_copies,
                     touched_ent, touched_rel, tag, loss_partials, stream, ref_count, ent_table,
                     optimizer == MKE_OPT_ADAGRAD ? ent_acc : nullptr, optimizer, lr, nullptr, nullptr, 0, next_count, hot);
+}
+
+extern "C" int mke_triple_score_fwd_bwd_t(
+    float* ent_table, int64_t n_ent, int ent_normalize, const float* rel_table, int64_t n_rel, int rel_normalize,
+    int stride, int dim, const int32_t* pos_h, const int32_t* pos_r, const int32_t* pos_t, const float* pos_w,
+    int64_t n_pos, const int32_t* neg_h, const int32_t* neg_r, const int32_t* neg_t, const float* neg_w, int64_t n_neg,
+    int neg_per_pos, float scale, float* grad_ent, float* grad_rel, int grad_rel_copies, int32_t* touched_ent,
+    int32_t* touched_rel, int32_t tag, int32_t* ref_count, float* ent_acc, int optimizer, float lr,
+    const mke_count_job* next_count, const mke_hot_rows* hot, const mke_tuning* tuning, double* loss_partials, void* stream) {
+  mke::TuningScope scope(tuning);      // this call's knobs (NULL: the process defaults)
+  return mke_triple_score_fwd_bwd_xch(ent_table, n_ent, ent_normalize, rel_table, n_rel, rel_normalize, stride, dim, pos_h, pos_r, pos_t,
+                                      pos_w, n_pos, neg_h, neg_r, neg_t, neg_w, n_neg, neg_per_pos, scale, grad_ent, grad_rel,
+                                      grad_rel_copies, touched_ent, touched_rel, tag, ref_count, ent_acc, optimizer, lr, next_count, hot,
+                                      loss_partials, stream);
 }
 
 extern "C" int mke_triple_score_fwd_bwd_x(

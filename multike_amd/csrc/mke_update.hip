@@ -317,14 +317,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_rows_update_multi(const MultiUpda
   walk_chunk<FPL, SHARD, HOT>(p, wave, j, (threadIdx.x & 63) >> 4);
 }
 
-extern int g_update_chunk;  // mke_set_option("update_chunk"): rows per wavefront for large tables (16 or 64)
 // 4 rows for small dense tables (every quarter-wave gets a row at once); 16 for tables where a step touches a good share of the
 // rows (C2: 17 % of 200K: 2.8 flags set per 16); 64 (one flag per lane) for large tables touched sparsely (C5: 1.7 % of 2M rows —
 // a quarter as many wavefronts, each still finding about one row: 77 -> 59 us).  "update_chunk" = 16 / 64 forces one.
 thread_local int64_t g_update_touched_hint = 0;
 static inline int chunk_for(int64_t n_rows) {
   if (n_rows <= 16384) return 4;
-  if (g_update_chunk) return g_update_chunk;
+  if (tune_update_chunk()) return tune_update_chunk();
   if (n_rows > 500000) return 64;
   return (g_update_touched_hint > 0 && g_update_touched_hint * 16 <= n_rows) ? 64 : 16;   // sparse step on a mid-sized table
 }
@@ -419,6 +418,12 @@ extern "C" int mke_rows_update(float* table, float* acc, float* grad, int grad_c
 
 extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                                            int optimizer, float lr, const mke_count_job* count, void* stream);
+
+extern "C" int mke_rows_update_multi_t(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim, int optimizer,
+                                       float lr, const mke_count_job* count, const mke_tuning* tuning, void* stream) {
+  mke::TuningScope scope(tuning);      // this call's knobs (NULL: the process defaults)
+  return mke_rows_update_multi_count(tables, n_tables, tag, stride, dim, optimizer, lr, count, stream);
+}
 
 extern "C" int mke_rows_update_multi(const mke_update_table* tables, int n_tables, int32_t tag, int stride, int dim,
                                      int optimizer, float lr, void* stream) {

@@ -139,6 +139,7 @@ class OcHipBackend:
         if tr.hot_slot is not None:           # hub rows of the shard: private gradient copies behind the shard's own rows
             s.hot.slot, s.hot.n_hot = _lib.ptr(tr.hot_slot, i32, "hot_slot"), tr.n_hot
             s.hot.copies, s.hot.row0 = tr.HOT_COPIES, tr.ent_grad_rows
+        s.tuning = _lib.tuning_ptr(tr.tuning)
         s.n_peers = 0
         if tr.peer_direct and tr.world > 1:   # peer-mapped blocks (chunk 0: peer-direct runs unchunked)
             gb = 2 * tr.C * tr.stride * 4
@@ -475,10 +476,15 @@ class OcHostStagedComm(OcGlooComm):
                     return t.view(-1)[:count]
             raise _lib.MultiKEHipError("native callback: unknown exchange buffer")
 
+        def on(stream):
+            # the stream the loop enqueues on, as a torch stream: handle 0 is torch's default stream (torch.cuda.ExternalStream(0)
+            # is NOT — it makes a stream of its own, and the staged copies then raced the kernels: caught at world 8)
+            return torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+
         def move(fn, scale_in, scale_out):
             def cb(ctx, send, recv, count, stream):
                 try:
-                    with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                    with torch.cuda.stream(on(stream)):
                         fn(find(recv, count * scale_out), find(send, count * scale_in))
                     return 0
                 except Exception:      # noqa: BLE001 — an exception must not unwind through the C frame
@@ -489,7 +495,7 @@ class OcHostStagedComm(OcGlooComm):
 
         def reduce(ctx, buf, count, stream):
             try:
-                with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0)):
+                with torch.cuda.stream(on(stream)):
                     self.all_reduce(find(buf, count))
                 return 0
             except Exception:          # noqa: BLE001
@@ -605,7 +611,7 @@ class OwnerComputesTrainer:
                  exclusive_rows: bool = True, chunks: int = 1, peer_direct: bool = False, prefetch: bool = True,
                  batcher=None, scale: float = 1.0, tables_of: "OwnerComputesTrainer" = None, ent_table=None, rel_table=None,
                  opt_name: str = "relation", n_ent: int = None, tag_base: int = None, global_batch: int = None,
-                 entity_major: bool = None):
+                 entity_major: bool = None, tuning: dict = None):
         """batcher: an epoch source other than the two KGs' shuffled triples (`TripleListBatcher`: the cross-KG inference
         loops — positives only, `neg_per_pos` 0, `kgs` unused and `batch_size` the GLOBAL step size the batcher was built
         with); scale: the loss factor (2 for code/MultiKE_model.py:349-369); tables_of: another trainer of the same
@@ -614,6 +620,7 @@ class OwnerComputesTrainer:
         gradient / flag scratch, own Adagrad accumulators, own tag range; `ent0` / `rel0` are then unused."""
         self.scale = float(scale)
         self._em_request = entity_major
+        self.tuning = _lib.tuning(**tuning) if tuning else None     # this trainer's knobs (mke_oc_step.tuning), e.g. {"oc_score_quarter": 1}
         # ent_table / rel_table (multike_amd.tables.EmbeddingTable: this rank's shard of `n_ent` global rows, and the
         # replicated relation table): train THOSE — the trainer then shares them with whatever else holds them (other
         # trainers, the common-space step of multike_amd.distributed_views) and takes its Adagrad slot by `opt_name`.

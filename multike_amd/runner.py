@@ -21,7 +21,12 @@ _OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
 class RelationViewRunner:
     def __init__(self, ent: EmbeddingTable, rel: EmbeddingTable, batcher: RelationBatcher, opt_name: str = "relation",
                  lr: float = 0.001, optimizer: str = "Adagrad", scale: float = 1.0, sample_chunk: int | None = None,
-                 max_try: int = 10, exclusive_rows: bool = True, overlap: bool | None = None, hot_rows: bool | None = None):
+                 max_try: int = 10, exclusive_rows: bool = True, overlap: bool | None = None, hot_rows: bool | None = None,
+                 tuning: dict | None = None, deterministic: bool | None = None):
+        """tuning: performance knobs of THIS runner's plan (names of `_lib.TUNING_FIELDS`; mke_relation_plan.tuning) — every knob
+        not named follows the process default; deterministic: the fixed-order mode for this runner (None: the process default)."""
+        self.tuning = _lib.tuning(**tuning) if tuning else None
+        self.deterministic = deterministic
         if optimizer not in _OPT:
             raise _lib.MultiKEHipError(f"optimizer {optimizer!r} not supported by the HIP path (Adagrad, SGD)")
         self.ent, self.rel, self.bat = ent, rel, batcher
@@ -97,6 +102,7 @@ class RelationViewRunner:
         p.optimizer, p.lr, p.scale = _OPT[self.optimizer], self.lr, self.scale
         p.loss_partials, p.loss_ring = _lib.ptr(self.loss, torch.float64, "loss"), self.loss.shape[0]
         p.hot = e.hot_struct()
+        p.tuning = _lib.tuning_ptr(self.tuning)
 
     def _fill_epoch(self):
         p, b = self.plan, self.bat
@@ -111,11 +117,11 @@ class RelationViewRunner:
         """Enqueue steps [step_begin, step_end) of the current epoch (default: all).  A call with step_begin == 0
         starts a new epoch (fresh tag range); other calls continue the current one."""
         step_end = self.steps if step_end is None else step_end
-        if _lib.get_option("deterministic"):
+        if (self.deterministic if self.deterministic is not None else _lib.get_option("deterministic")):
             # parity / debugging mode: step by step through StepEngine's deterministic path (fixed-order gradient sums)
             from .tables import StepEngine
             if getattr(self, "_det_engine", None) is None:
-                self._det_engine = StepEngine(self.ent.device, loss_ring=max(2, self.steps))
+                self._det_engine = StepEngine(self.ent.device, loss_ring=max(2, self.steps), deterministic=True)
                 self._det_engine.tag = 1 << 29
             N = self.bat.neg_per_pos
             for s in range(step_begin, step_end):

@@ -225,7 +225,12 @@ _OPT = {"Adagrad": _lib.OPT_ADAGRAD, "SGD": _lib.OPT_SGD}
 class StepEngine:
     """Enqueues the kernels of one training step.  One instance per model (per HIP stream)."""
 
-    def __init__(self, device="cuda", loss_ring: int = 256):
+    def __init__(self, device="cuda", loss_ring: int = 256, tuning: dict = None, deterministic: bool = None):
+        """tuning: performance knobs of THIS engine's launches (names of `_lib.TUNING_FIELDS`, e.g. {"score_splits": 2}); every
+        knob not named follows the process default (`mke_set_option`).  deterministic: the fixed-order gradient reduction for this
+        engine (None: the process default, `mke_set_option("deterministic")`).  Two engines in one process may differ."""
+        self.tuning = _lib.tuning(**tuning) if tuning else None
+        self.deterministic = deterministic
         self.device = torch.device(device)
         self.tag = 0
         self.loss_ring = torch.zeros(loss_ring, _lib.LOSS_PARTIALS, dtype=torch.float64, device=self.device)
@@ -256,7 +261,8 @@ class StepEngine:
         """loss + optimizer of a relation-view style graph (a1/a2/a3).  Returns the loss partials (a view into the
         ring; `.sum()` is the loss) without synchronising.  With grouped negatives the exclusive-row fast path is
         used (rows referenced once in the step are updated by the scoring quarter-wave itself)."""
-        if update and optimizer in _OPT and _lib.get_option("deterministic"):
+        det = self.deterministic if self.deterministic is not None else _lib.get_option("deterministic")
+        if update and optimizer in _OPT and det:
             return self._relation_step_deterministic(ent, rel, opt_name, pos, neg, neg_per_pos, lr, pos_w, neg_w, scale,
                                                      optimizer, exclusive_rows)
         tag, lp = self._next()
@@ -265,11 +271,11 @@ class StepEngine:
             acc = ent.slot(opt_name) if optimizer == "Adagrad" else None
             _lib.triple_score_fwd_bwd_x(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
                                         neg_per_pos, scale, ent.grad, rel.grad, ent.touched, rel.touched, tag, ent.refcount,
-                                        acc, _OPT[optimizer], lr, lp)
+                                        acc, _OPT[optimizer], lr, lp, tuning=self.tuning)
             _lib.rows_update_multi([(rel.data, rel.slot(opt_name) if optimizer == "Adagrad" else None, rel.grad, rel.touched,
                                      rel.normalize),
                                     (ent.data, acc, ent.grad, ent.touched, ent.normalize, ent.refcount)], tag, ent.stride,
-                                   ent.dim, _OPT[optimizer], lr)
+                                   ent.dim, _OPT[optimizer], lr, tuning=self.tuning)
             return lp
         _lib.triple_score_fwd_bwd(ent.data, ent.normalize, rel.data, rel.normalize, ent.dim, pos, pos_w, neg, neg_w,
                                   neg_per_pos, scale, ent.grad if update else None, rel.grad if update else None,
