@@ -1136,12 +1136,17 @@ static int attr_step_impl(const mke_attr_step_args* a, double* lossp, double* ss
   // when the last tail enqueued on this scratch was this step's (same tag, same parameters) and did leave W^T — otherwise (the
   // option toggled in between, a BWD-only call out of the blue) the unfused path, which needs nothing but g in `gout`
   // (round-4 advice).  Host-side bookkeeping of what was ENQUEUED; stream order makes it true on the device.
-  static const float* wt_scratch = nullptr;
-  static const float* wt_params = nullptr;
-  static int32_t wt_tag = 0;
+  // Per host thread (two threads driving two attribute graphs do not see each other's note: round-5 advice), single use: the
+  // backward that consumes it, an update of these parameters (W changes) or any other tail on this thread clears it, so a
+  // BWD-only call that re-uses a tag later never finds a stale W^T.
+  static thread_local const float* wt_scratch = nullptr;
+  static thread_local const float* wt_params = nullptr;
+  static thread_local int32_t wt_tag = 0;
   if (phases & MKE_ATTR_TAIL) { wt_scratch = fused_tail ? dflat : nullptr; wt_params = a->params; wt_tag = a->tag; }
+  if ((phases & MKE_ATTR_UPD) && !(phases & MKE_ATTR_BWD) && wt_params == a->params) wt_scratch = nullptr;   // the parameters move: W^T is stale
   if (phases & MKE_ATTR_BWD) {
   const bool fused = fused_tail && wt_scratch == dflat && wt_params == a->params && wt_tag == a->tag;
+  wt_scratch = nullptr;            // consumed (or not applicable): one backward per tail
   if (!fused && (rc = mke_attr_tail_bwd(z, gout, ssq, dot, n, d, nullptr, stream))) return rc;   // gout = dL/dzpre (the fused launch forms it on load)
   if (a->attr_grad && !a->attr_touched) { set_error("mke_attr_step: NULL touched array"); return MKE_E_NULL; }
   ConvParams p{};

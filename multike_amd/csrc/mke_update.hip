@@ -442,7 +442,15 @@ extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n
   if (n_tables < 1 || n_tables > MKE_MAX_UPDATE_TABLES) { set_error("n_tables must be in [1,%d]", MKE_MAX_UPDATE_TABLES); return MKE_E_SHAPE; }
   if (optimizer != MKE_OPT_ADAGRAD && optimizer != MKE_OPT_SGD) { set_error("unsupported optimizer %d", optimizer); return MKE_E_UNSUPPORTED; }
   if (stride <= 0 || stride % 16 != 0 || dim <= 0 || dim > stride || stride > MKE_MAX_STRIDE) { set_error("bad stride/dim: stride=%d dim=%d", stride, dim); return MKE_E_SHAPE; }
+  bool any_shard = false, any_hot = false;
   for (int k = 0; k < n_tables; ++k) {
+    any_shard = any_shard || tables[k].slot_of != nullptr;
+    any_hot = any_hot || (tables[k].hot.slot != nullptr && tables[k].hot.n_hot > 0);
+    if (tables[k].hot.slot && tables[k].hot.n_hot > 0) {   // hub rows: private copies behind the table's own rows (round-5 advice: validated here)
+      if (tables[k].hot.copies < 1 || tables[k].hot.copies > 64 || tables[k].hot.row0 < tables[k].n_rows) { set_error("table %d: hub rows need 1 <= copies <= 64 and row0 >= n_rows", k); return MKE_E_SHAPE; }
+      if (tables[k].grad_copies > 1) { set_error("table %d: hub rows and a wholly privatised gradient (grad_copies > 1) exclude each other", k); return MKE_E_UNSUPPORTED; }
+      if (tables[k].slot_of) { set_error("table %d: hub rows on a table whose gradient comes through slot_of", k); return MKE_E_UNSUPPORTED; }
+    }
     if (!tables[k].table || (!tables[k].grad && !tables[k].slot_of)) { set_error("table %d: NULL table/grad", k); return MKE_E_NULL; }
     if (tables[k].slot_of && (!tables[k].src_rows || tables[k].n_ranks < 1 || tables[k].n_ranks > 64 || tables[k].capacity < 1)) {
       set_error("table %d: slot_of needs src_rows, 1 <= n_ranks <= 64 and capacity >= 1", k);
@@ -451,5 +459,8 @@ extern "C" int mke_rows_update_multi_count(const mke_update_table* tables, int n
     if (optimizer == MKE_OPT_ADAGRAD && !tables[k].acc) { set_error("table %d: Adagrad needs an accumulator", k); return MKE_E_NULL; }
     if (tables[k].n_rows < 0) { set_error("negative n_rows"); return MKE_E_SHAPE; }
   }
+  // one launch instantiates EITHER the sharded-gradient form OR the hub-row form: a call that mixed them dropped the hub rows'
+  // copies silently (never added, never re-zeroed)
+  if (any_shard && any_hot) { set_error("mke_rows_update_multi: a slot_of table and a hub-row table cannot share one call"); return MKE_E_UNSUPPORTED; }
   return launch_rows_update_multi(tables, n_tables, tag, stride, dim, optimizer, lr, (hipStream_t)stream, count);
 }

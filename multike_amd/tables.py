@@ -113,6 +113,7 @@ class EmbeddingTable:
         self.grad_copies = int(grad_copies)
         self.slots: dict[str, torch.Tensor] = {}
         self._grad = None
+        self._grad_handed = False        # the scratch's address has been given out (plans, argument structs)
         self._touched = None
         self._refcount = None
         # hub rows (include/multike_hip.h mke_hot_rows): rows that several positives of EVERY step have as head or tail; the
@@ -131,6 +132,7 @@ class EmbeddingTable:
     @property
     def grad(self) -> torch.Tensor:
         """[n_rows][stride] zero-invariant gradient scratch ([copies][n_rows][stride] when privatised as a whole)."""
+        self._grad_handed = True         # from here on its address may sit in a plan: set_hot_rows refuses to re-allocate it
         if self._grad is None:
             if self.grad_copies == 1:
                 self._grad_full = placed_rows(self.n_rows + self.hot_copies * self.n_hot, self.stride, self.device, 0.0, PLACEMENT_LOG,
@@ -149,13 +151,18 @@ class EmbeddingTable:
             raise _lib.MultiKEHipError("hub rows and a wholly privatised gradient scratch exclude each other")
         if len(rows) and (rows[0] < 0 or rows[-1] >= self.n_rows):
             raise _lib.MultiKEHipError("hub row id outside the table")
+        copies = max(1, int(copies))
+        if (self.n_rows + copies * len(rows)) * self.stride >= 2 ** 30:
+            return                   # would leave the kernels' 32-bit row offsets: no declaration, the scratch stays as it is
+        if self._grad is not None and self._grad_handed:
+            # a plan / argument struct may hold the old scratch's address (round-5 advice): the declaration must come first
+            raise _lib.MultiKEHipError("set_hot_rows after the gradient scratch was handed out: declare hub rows before building "
+                                       "runners / trainers on the table")
         slot = np.full(self.n_rows, -1, dtype=np.int32)
         slot[rows] = np.arange(len(rows), dtype=np.int32)
         self.hot_slot = torch.as_tensor(slot, device=self.device)
-        self.n_hot, self.hot_copies = int(len(rows)), max(1, int(copies))
+        self.n_hot, self.hot_copies = int(len(rows)), copies
         self._grad = None            # re-created (all zero) with the copy rows on next use
-        if (self.n_rows + self.hot_copies * self.n_hot) * self.stride >= 2 ** 30:
-            self.hot_slot, self.n_hot, self.hot_copies = None, 0, 1      # would leave the kernels' 32-bit row offsets
 
     def hot_struct(self):
         """mke_hot_rows of this table (zeroed when it has none); touching `grad` first makes sure the scratch has the rows."""
