@@ -859,12 +859,18 @@ typedef struct mke_oc_step {
    * order, so results are bit-reproducible run to run): ghat = sum coef (c^ + sg V) + sum (+-) gv, then the Jacobian of the
    * normalisation and the optimizer — no gradient scratch, no touched flags, no reference counts, no hub-row copies, no
    * atomics on entity rows, and the entity table takes no part in mke_oc_apply / the update launch.
-   * em_refs: pairs (locator, coefficient index) of the whole epoch; em_rows / em_off: touched owned rows of THIS step and their
-   * offsets into em_refs (em_off[em_n_rows] valid); em_v[c] / em_gv[c]: chunk c's all-gathered vectors [n_ranks][block] and
+   * em_refs: pairs (locator, coefficient index) of the whole epoch; em_rows / em_off: the work items of THIS step (a touched owned
+   * row, or one 32-reference segment of a long row's list) and their offsets into em_refs (em_off[em_n_rows] valid); em_v[c] / em_gv[c]: chunk c's all-gathered vectors [n_ranks][block] and
    * reduce-scattered gradient block (the step's parts, at most MKE_OC_EM_MAX_CHUNKS). */
   float* em_coef; int64_t em_pos0;
   const uint32_t* em_refs; const int32_t* em_rows; const int32_t* em_off; int64_t em_n_rows;
   int em_chunks; int64_t em_block_floats; const float* em_v[4]; const float* em_gv[4];
+  /* long rows (lists of more than 32 references: hub entities, frequent relations): em_rows / em_off are the plan's work ITEMS
+   * (item_row / item_off of this step); em_part[w] the partial slot of item w and em_long_rows / em_long_part0 this step's long
+   * rows, slots as the plan numbered them — slot p of this step lives at em_partials + (p - em_part0) * (stride + 16) floats
+   * (em_part0 = the plan's step_part0 of this step; the buffer holds the step's slots only); mke_oc_pass2 adds a combine launch
+   * when em_n_long > 0. */
+  const int32_t* em_part; const int32_t* em_long_rows; const int32_t* em_long_part0; int64_t em_n_long; int64_t em_part0; float* em_partials;
   const mke_tuning* tuning;   /* version 105: host pointer, NULL = the process defaults */
 } mke_oc_step;
 #define MKE_OC_EM_MAX_CHUNKS 4
@@ -924,6 +930,13 @@ typedef struct mke_oc_em_plan_args {
   int32_t* wave_scratch;    /* 2 * (MKE_OC_EM_WAVES + 1) scratch ints */
   uint32_t* refs; int32_t* rows; int32_t* off; int32_t* flags; int32_t* scan;
   int64_t* step_row0; int64_t* n_refs;
+  /* the second pass's WORK ITEMS: a touched row's list in segments of at most 32 references.  item_row[w] = local row (bit 31:
+   * a segment of a LONG row — more than one segment), item_off[w] = its first reference (item_off[w + 1] ends it), item_part[w]
+   * = the partial slot a long row's segment writes (-1: the item finishes its row); long_row[l] / long_part0[l] = the long rows
+   * and their first partial slot (long_part0[l + 1] ends them); step_item0 / step_long0 / step_part0[s] = first item / long row /
+   * partial slot of global step s (n_steps + 1 entries each).  item_* : capacity + 1 ints each; long_*: capacity / 32 + 2. */
+  int32_t* item_row; int32_t* item_off; int32_t* item_part; int32_t* long_row; int32_t* long_part0;
+  int64_t* step_item0; int64_t* step_long0; int64_t* step_part0;
   void* temp; int64_t temp_bytes;
 } mke_oc_em_plan_args;
 int64_t mke_oc_em_plan_temp_bytes(int64_t capacity);

@@ -110,7 +110,9 @@ class OcStepStruct(C.Structure):
                 # version 105: entity-major second pass
                 ("em_coef", C.c_void_p), ("em_pos0", C.c_int64), ("em_refs", C.c_void_p), ("em_rows", C.c_void_p), ("em_off", C.c_void_p),
                 ("em_n_rows", C.c_int64), ("em_chunks", C.c_int), ("em_block_floats", C.c_int64), ("em_v", C.c_void_p * 4),
-                ("em_gv", C.c_void_p * 4), ("tuning", C.c_void_p)]
+                ("em_gv", C.c_void_p * 4),
+                ("em_part", C.c_void_p), ("em_long_rows", C.c_void_p), ("em_long_part0", C.c_void_p), ("em_n_long", C.c_int64),
+                ("em_part0", C.c_int64), ("em_partials", C.c_void_p), ("tuning", C.c_void_p)]
 
 
 TUNE_DEFAULT = -2
@@ -150,7 +152,10 @@ class OcEmPlanArgs(C.Structure):
                 ("n_all", C.c_int64), ("max_step", C.c_int64), ("n_ranks", C.c_int), ("rank", C.c_int), ("n_local", C.c_int64), ("n_rel", C.c_int64),
                 ("keys", C.c_void_p), ("keys_alt", C.c_void_p), ("capacity", C.c_int64), ("vals_alt", C.c_void_p), ("wave_scratch", C.c_void_p),
                 ("refs", C.c_void_p), ("rows", C.c_void_p), ("off", C.c_void_p), ("flags", C.c_void_p), ("scan", C.c_void_p),
-                ("step_row0", C.c_void_p), ("n_refs", C.c_void_p), ("temp", C.c_void_p), ("temp_bytes", C.c_int64)]
+                ("step_row0", C.c_void_p), ("n_refs", C.c_void_p),
+                ("item_row", C.c_void_p), ("item_off", C.c_void_p), ("item_part", C.c_void_p), ("long_row", C.c_void_p), ("long_part0", C.c_void_p),
+                ("step_item0", C.c_void_p), ("step_long0", C.c_void_p), ("step_part0", C.c_void_p),
+                ("temp", C.c_void_p), ("temp_bytes", C.c_int64)]
 
 
 OC_COMM_NCCL, OC_COMM_CALLBACK, OC_COMM_LOOPBACK = 0, 1, 2

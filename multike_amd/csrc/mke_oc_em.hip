@@ -218,6 +218,54 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_rows(const EmPlanParams pp, co
   for (int s = s_prev + 1; s <= s_cur; ++s) a.step_row0[s] = u;
 }
 
+// ---- work items of the second pass: a row's list in segments of at most EM_SEG references ------------------------------------
+// A row with a long list (a hub entity of a skewed KG, a frequent relation: thousands of references per step) walked by ONE
+// quarter-wave is a chain of thousands of round trips — the whole launch waits for it (measured at Zipf(1.0): the second pass 20 ->
+// hundreds of us).  Its list is cut into segments; each segment is a work item of its own that leaves a PARTIAL sum (the gradient
+// vector and the coefficient sum: neither needs the row), and a combine launch adds a long row's partials in segment order and
+// finishes the row — still one fixed summation order.  Rows whose list fits one segment (all but a handful) are finished by
+// their single item as before.
+#define EM_SEG 32
+struct EmItemParams {
+  const int32_t* rows_u; const int32_t* off_u; const int64_t* step_row0; int n_steps; int64_t cap;
+  int32_t* nseg; int32_t* lflag; int32_t* lns;                 // per touched row: segments, long?, segments if long
+  const int32_t* itemoff; const int32_t* lidx; const int32_t* part0;   // their exclusive scans
+  int32_t* item_row; int32_t* item_off; int32_t* item_part; int32_t* long_row; int32_t* long_part0;
+  int64_t* step_item0; int64_t* step_long0; int64_t* step_part0;
+};
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_nseg(const EmItemParams p) {
+  const int64_t u = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  if (u > p.cap) return;
+  const int64_t U = p.step_row0[p.n_steps];
+  int ns = 0;
+  if (u < U) ns = (p.off_u[u + 1] - p.off_u[u] + EM_SEG - 1) / EM_SEG;
+  p.nseg[u] = ns;
+  p.lflag[u] = ns > 1;
+  p.lns[u] = ns > 1 ? ns : 0;
+}
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_items(const EmItemParams p) {
+  const int64_t u = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  const int64_t U = p.step_row0[p.n_steps];
+  if (u <= p.n_steps) {     // the steps' first item / long row / partial
+    const int64_t r0 = p.step_row0[u];
+    p.step_item0[u] = p.itemoff[r0]; p.step_long0[u] = p.lidx[r0]; p.step_part0[u] = p.part0[r0];
+  }
+  if (u > U || u > p.cap) return;
+  if (u == U) {             // end markers
+    p.item_off[p.itemoff[U]] = p.off_u[U];
+    p.long_part0[p.lidx[U]] = p.part0[U];
+    return;
+  }
+  const int ns = p.nseg[u], w0 = p.itemoff[u], lo = p.off_u[u];
+  const bool lng = ns > 1;
+  for (int k = 0; k < ns; ++k) {
+    p.item_row[w0 + k] = p.rows_u[u] | (lng ? (int32_t)0x80000000 : 0);
+    p.item_off[w0 + k] = lo + k * EM_SEG;
+    p.item_part[w0 + k] = lng ? p.part0[u] + k : -1;
+  }
+  if (lng) { p.long_row[p.lidx[u]] = p.rows_u[u]; p.long_part0[p.lidx[u]] = p.part0[u]; }
+}
+
 static inline int bits_for(uint64_t v) {   // smallest b with v < 2^b
   int b = 0;
   while (b < 64 && (v >> b)) ++b;
@@ -253,10 +301,66 @@ static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) 
   tb = (size_t)a.temp_bytes;
   if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, a.flags, a.scan, n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL((k_em_rows<KEY>), grid, dim3(MKE_BLOCK), 0, st, pp, (const KEY*)keys_alt);
-  return check_launch("k_em_rows");
+  if ((rc = check_launch("k_em_rows"))) return rc;
+  // work items (segments of at most EM_SEG references), the long rows and their partial slots; the scratch is the sort's, dead now
+  EmItemParams ip;
+  ip.rows_u = a.rows; ip.off_u = a.off; ip.step_row0 = a.step_row0; ip.n_steps = a.n_steps; ip.cap = a.capacity;
+  int32_t* k0 = reinterpret_cast<int32_t*>(a.keys);
+  int32_t* k1 = reinterpret_cast<int32_t*>(a.keys_alt);
+  ip.nseg = a.flags; ip.lflag = k0; ip.lns = k1;
+  int32_t* itemoff = a.scan; int32_t* lidx = k0 + (a.capacity + 1); int32_t* part0 = k1 + (a.capacity + 1);
+  ip.itemoff = itemoff; ip.lidx = lidx; ip.part0 = part0;
+  ip.item_row = a.item_row; ip.item_off = a.item_off; ip.item_part = a.item_part; ip.long_row = a.long_row; ip.long_part0 = a.long_part0;
+  ip.step_item0 = a.step_item0; ip.step_long0 = a.step_long0; ip.step_part0 = a.step_part0;
+  hipLaunchKernelGGL(k_em_nseg, grid, dim3(MKE_BLOCK), 0, st, ip);
+  if ((rc = check_launch("k_em_nseg"))) return rc;
+  int32_t* const ins[3] = {ip.nseg, ip.lflag, ip.lns};
+  int32_t* const outs[3] = {itemoff, lidx, part0};
+  for (int k = 0; k < 3; ++k) {
+    tb = (size_t)a.temp_bytes;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, ins[k], outs[k], n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(k_em_items, grid, dim3(MKE_BLOCK), 0, st, ip);
+  return check_launch("k_em_items");
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------------------------------
+// ghat = c^ csum + g;  Jacobian of x * rsqrt(max(sum x^2, eps)):  g_raw = (ghat - c^ (c^ . ghat)) * inv;  optimizer; stores
+template <int FPL>
+__device__ __forceinline__ void em_finish_row(const mke_oc_step& s, float* wp, float* ap, float (&w)[FPL], float (&acc)[FPL], float (&g)[FPL], float csum) {
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) ss = fmaf(w[k], w[k], ss);
+  ss = sub16_sum(ss);
+  const float inv = rsqrtf(fmaxf(ss, MKE_L2_EPS));
+  const float ci = csum * inv;
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) {
+    g[k] = fmaf(ci, w[k], g[k]);
+    dot = fmaf(w[k], g[k], dot);
+  }
+  dot = sub16_sum(dot);
+  const float coef = (ss > MKE_L2_EPS) ? dot * inv * inv : 0.f;
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) g[k] = (g[k] - w[k] * coef) * inv;
+  if (s.optimizer == MKE_OPT_ADAGRAD) {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+      acc[k] = fmaf(g[k], g[k], acc[k]);
+      w[k] -= s.lr * g[k] * adagrad_scale(acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) ap[k * 16] = acc[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) w[k] -= s.lr * g[k];
+  }
+#pragma unroll
+  for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
+}
+
+// a quarter-wave per work item (a touched owned row, or one segment of a long row's list)
 template <int FPL>
 __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) {
   constexpr int STRIDE = FPL * 16;
@@ -264,7 +368,9 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
   const int lane = threadIdx.x & 63, j = lane & 15, qb = lane & 48;
   const int64_t u = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
   const bool act = u < s.em_n_rows;
-  const int row = act ? s.em_rows[u] : 0;
+  const int rowf = act ? s.em_rows[u] : 0;
+  const bool seg = rowf < 0;                     // bit 31: a segment of a long row — leaves a partial sum, does not touch the row
+  const int row = rowf & 0x7FFFFFFF;
   const int lo = act ? s.em_off[u] : 0, hi = act ? s.em_off[u + 1] : 0;
   // rows [n_local, n_local + n_rel) are the (replicated) relation table's: this rank's PARTIAL gradient — the sum of the gradient
   // vectors of its owned slots — is stored (not added: one writer per row and step) for the all-reduce and the relation update
@@ -275,7 +381,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
   float w[FPL], acc[FPL], g[FPL];
 #pragma unroll
   for (int k = 0; k < FPL; ++k) { w[k] = 0.f; acc[k] = 0.f; g[k] = 0.f; }
-  if (act && !is_rel) {
+  if (act && !is_rel && !seg) {
 #pragma unroll
     for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
     if (adagrad) {
@@ -328,7 +434,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
         const bool rt = (loc[x] & (1u << 23)) != 0;
         const bool gvk = (loc[x] & EM_LOC_GV) != 0;
         // base vector: + coef sg V (sg = +1 with RT: d = c^ + RT; -1 with HR: d = HR - c^) and coef to the c^ term;
-        // gradient vector: + gv for a head (HR = h^ + r^), - gv for a tail (RT = r^ - t^)
+        // gradient vector: + gv for a head (HR = h^ + r^), - gv for a tail (RT = r^ - t^), + for a relation row
         wgt[x] = !live ? 0.f : (gvk ? ((rt && !(loc[x] & EM_LOC_PLUS)) ? -1.0f : 1.0f) : (rt ? c : -c));
         csum += (live && !gvk) ? c : 0.f;
       }
@@ -340,43 +446,68 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
     }
   }
   if (!act) return;
+  if (seg) {               // a long row's segment: the partial gradient vector and coefficient sum (EM_PART floats per slot)
+    float* pp = s.em_partials + ((int64_t)s.em_part[u] - s.em_part0) * (STRIDE + 16) + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) pp[k * 16] = g[k];
+    pp[STRIDE] = csum;
+    return;
+  }
   if (is_rel) {
     float* gp = s.rel_grad + (int64_t)(row - s.n_local) * STRIDE + j;
 #pragma unroll
     for (int k = 0; k < FPL; ++k) gp[k * 16] = g[k];
     return;
   }
-  // ghat = c^ csum + g;  Jacobian of x * rsqrt(max(sum x^2, eps)):  g_raw = (ghat - c^ (c^ . ghat)) * inv
-  float ss = 0.f;
+  em_finish_row<FPL>(s, wp, ap, w, acc, g, csum);
+}
+
+// a quarter-wave per LONG row: its segments' partials added in segment order, then the row is finished as above
+template <int FPL>
+__global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_combine(const mke_oc_step s) {
+  constexpr int STRIDE = FPL * 16;
+  constexpr int PS = STRIDE + 16;
+  const int j = threadIdx.x & 15;
+  const int64_t l = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
+  if (l >= s.em_n_long) return;
+  const int row = s.em_long_rows[l];
+  const int p0 = (int)(s.em_long_part0[l] - s.em_part0), p1 = (int)(s.em_long_part0[l + 1] - s.em_part0);
+  const bool is_rel = row >= s.n_local;
+  float* wp = s.ent + (int64_t)row * STRIDE + j;
+  const bool adagrad = s.optimizer == MKE_OPT_ADAGRAD;
+  float* ap = adagrad ? s.ent_acc + (int64_t)row * STRIDE + j : nullptr;
+  float w[FPL], acc[FPL], g[FPL];
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) ss = fmaf(w[k], w[k], ss);
-  ss = sub16_sum(ss);
-  const float inv = rsqrtf(fmaxf(ss, MKE_L2_EPS));
-  const float ci = csum * inv;
-  float dot = 0.f;
+  for (int k = 0; k < FPL; ++k) { w[k] = 0.f; acc[k] = 0.f; g[k] = 0.f; }
+  if (!is_rel) {
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) {
-    g[k] = fmaf(ci, w[k], g[k]);
-    dot = fmaf(w[k], g[k], dot);
-  }
-  dot = sub16_sum(dot);
-  const float coef = (ss > MKE_L2_EPS) ? dot * inv * inv : 0.f;
+    for (int k = 0; k < FPL; ++k) w[k] = wp[k * 16];
+    if (adagrad) {
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) g[k] = (g[k] - w[k] * coef) * inv;
-  if (adagrad) {
-#pragma unroll
-    for (int k = 0; k < FPL; ++k) {
-      acc[k] = fmaf(g[k], g[k], acc[k]);
-      w[k] -= s.lr * g[k] * adagrad_scale(acc[k]);
+      for (int k = 0; k < FPL; ++k) acc[k] = ap[k * 16];
     }
-#pragma unroll
-    for (int k = 0; k < FPL; ++k) ap[k * 16] = acc[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < FPL; ++k) w[k] -= s.lr * g[k];
   }
+  float csum = 0.f;
+  for (int p = p0; p < p1; p += 2) {              // two partials in flight
+    const bool two = p + 1 < p1;
+    const float* a0 = s.em_partials + (int64_t)p * PS + j;
+    const float* a1 = s.em_partials + (int64_t)(two ? p + 1 : p) * PS + j;
+    float x0[FPL], x1[FPL];
 #pragma unroll
-  for (int k = 0; k < FPL; ++k) wp[k * 16] = w[k];
+    for (int k = 0; k < FPL; ++k) { x0[k] = a0[k * 16]; x1[k] = a1[k * 16]; }
+    const float c0 = a0[STRIDE], c1 = a1[STRIDE];
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) { g[k] += x0[k]; if (two) g[k] += x1[k]; }
+    csum += c0;
+    if (two) csum += c1;
+  }
+  if (is_rel) {
+    float* gp = s.rel_grad + (int64_t)(row - s.n_local) * STRIDE + j;
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) gp[k * 16] = g[k];
+    return;
+  }
+  em_finish_row<FPL>(s, wp, ap, w, acc, g, csum);
 }
 
 }  // namespace mke
@@ -399,7 +530,8 @@ extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
     return MKE_E_SHAPE;
   }
   if (a.capacity < 1 || a.capacity >= 0x7FFFFFFFll) { set_error("mke_oc_em_plan: capacity must be in [1, 2^31)"); return MKE_E_RANGE; }
-  if (!a.keys || !a.keys_alt || !a.vals_alt || !a.wave_scratch || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
+  if (!a.keys || !a.keys_alt || !a.vals_alt || !a.wave_scratch || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp ||
+      !a.item_row || !a.item_off || !a.item_part || !a.long_row || !a.long_part0 || !a.step_item0 || !a.step_long0 || !a.step_part0) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
   if (a.n_all > 0 && (!a.pos_h || !a.pos_r || !a.pos_t || !a.slot_h || !a.slot_t || !a.step_lo || (a.neg_per_pos > 0 && !a.codes))) { set_error("mke_oc_em_plan: NULL input"); return MKE_E_NULL; }
   if (a.temp_bytes < mke_oc_em_plan_temp_bytes(a.capacity)) { set_error("mke_oc_em_plan: temp storage below mke_oc_em_plan_temp_bytes"); return MKE_E_SHAPE; }
   if (a.max_step >= (1ll << 25) || a.max_step * (a.neg_per_pos + 1) > 0x7FFFFFFFll) { set_error("mke_oc_em_plan: a global step holds at most 2^25 positives"); return MKE_E_RANGE; }
@@ -437,6 +569,11 @@ extern "C" int mke_oc_pass2(const mke_oc_step* s, void* stream) {
   if (s->optimizer == MKE_OPT_ADAGRAD && !s->ent_acc) { set_error("mke_oc_pass2: Adagrad needs ent_acc"); return MKE_E_NULL; }
   const int fpl = s->stride / 16;
   const dim3 grid((unsigned)((s->em_n_rows + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK));
+  if (s->em_n_long < 0 || (s->em_n_long > 0 && (!s->em_part || !s->em_long_rows || !s->em_long_part0 || !s->em_partials))) { set_error("mke_oc_pass2: long rows without their lists / partial buffer"); return MKE_E_NULL; }
   MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_em_pass2<FPL>), grid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, *s); });
-  return check_launch("k_oc_em_pass2");
+  int rc = check_launch("k_oc_em_pass2");
+  if (rc || s->em_n_long == 0) return rc;
+  const dim3 lgrid((unsigned)((s->em_n_long + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK));
+  MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_em_combine<FPL>), lgrid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, *s); });
+  return check_launch("k_oc_em_combine");
 }

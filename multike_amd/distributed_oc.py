@@ -106,6 +106,9 @@ class OcHipBackend:
         a.refs, a.rows, a.off = _lib.ptr(bufs["refs"], i32, "refs"), _lib.ptr(bufs["rows"], i32, "rows"), _lib.ptr(bufs["off"], i32, "off")
         a.flags, a.scan = _lib.ptr(bufs["flags"], i32, "flags"), _lib.ptr(bufs["scan"], i32, "scan")
         a.step_row0, a.n_refs = _lib.ptr(bufs["row0"], i64, "row0"), _lib.ptr(bufs["n_refs"], i64, "n_refs")
+        a.item_row, a.item_off, a.item_part = (_lib.ptr(bufs[k], i32, k) for k in ("item_row", "item_off", "item_part"))
+        a.long_row, a.long_part0 = _lib.ptr(bufs["long_row"], i32, "long_row"), _lib.ptr(bufs["long_part0"], i32, "long_part0")
+        a.step_item0, a.step_long0, a.step_part0 = (_lib.ptr(bufs["steps3"][k], i64, "steps3") for k in range(3))
         a.temp, a.temp_bytes = _lib.ptr(bufs["temp"], torch.uint8, "temp"), bufs["temp"].numel()
         _lib.oc_em_plan(a)
 
@@ -170,7 +173,8 @@ class OcHipBackend:
         em = tr._em if tr.em else None
         key = (tr.C, b.pos_h.data_ptr(), tr._slot[0].data_ptr(), tr._slot[1].data_ptr(), oh, ot, tr._codes.data_ptr(), len(tr._parts),
                tr._peer_send[0].data_ptr() if tr.peer_direct and tr.world > 1 else 0,
-               (em["refs"].data_ptr(), em["rows"].data_ptr(), em["off"].data_ptr(), tr._em_coef.data_ptr()) if em else 0)
+               (em["refs"].data_ptr(), em["item_row"].data_ptr(), em["item_off"].data_ptr(), tr._em_coef.data_ptr(),
+                tr._em_partials.data_ptr()) if em else 0)
         cache = self.__dict__.setdefault("_tables", {})
         if key in cache:                                  # the two epoch buffer sets alternate: one table each
             self._steps = cache[key]
@@ -214,11 +218,15 @@ class OcHipBackend:
         for k, (s, (_, lo, _hi)) in enumerate(zip(self._steps, tr._parts)):     # a part's owned list starts at the part's own offset
             s.own_h, s.n_own_h = oh + 4 * lo, cnth[k]
             s.own_t, s.n_own_t = ot + 4 * lo, cntt[k]
-        if em:              # the touched rows of each global step: positions change from epoch to epoch
-            r0 = em["row0_host"].tolist()
-            rp, op = em["rows"].data_ptr(), em["off"].data_ptr()
+        if em:              # the work items / long rows of each global step: positions change from epoch to epoch
+            i0, l0, p0 = (em[k].tolist() for k in ("item0_host", "long0_host", "part0_host"))
+            rp, op, pp = em["item_row"].data_ptr(), em["item_off"].data_ptr(), em["item_part"].data_ptr()
+            lr, lp = em["long_row"].data_ptr(), em["long_part0"].data_ptr()
             for s, (step, _, _) in zip(self._steps, tr._parts):
-                s.em_rows, s.em_off, s.em_n_rows = rp + 4 * r0[step], op + 4 * r0[step], r0[step + 1] - r0[step]
+                s.em_rows, s.em_off, s.em_n_rows = rp + 4 * i0[step], op + 4 * i0[step], i0[step + 1] - i0[step]
+                s.em_part = pp + 4 * i0[step]
+                s.em_long_rows, s.em_long_part0, s.em_n_long = lr + 4 * l0[step], lp + 4 * l0[step], l0[step + 1] - l0[step]
+                s.em_part0, s.em_partials = p0[step], tr._em_partials.data_ptr()
         # the whole epoch's schedule for mke_oc_steps (one native call per run of steps)
         lp = _lib.OcLoopStruct()
         lp.parts, lp.n_steps, lp.chunks = C.addressof(self._parts_arr), tr.steps, tr.chunks
@@ -973,6 +981,12 @@ class OwnerComputesTrainer:
         out["rows"] = self._persist(("em_rows", bs), z32, capacity)
         out["off"] = self._persist(("em_off", bs), z32, capacity + 1)
         out["row0"] = self._persist(("em_row0", bs), z64, self.steps + 1)
+        # the work items of the second pass (rows, or 32-reference segments of long rows), the long rows and their partial slots
+        for k in ("item_row", "item_off", "item_part"):
+            out[k] = self._persist(("em_" + k, bs), z32, capacity + 1)
+        for k in ("long_row", "long_part0"):
+            out[k] = self._persist(("em_" + k, bs), z32, capacity // 32 + 2)
+        out["steps3"] = self._persist(("em_steps3", bs), z64, 3 * (self.steps + 1)).view(-1)[:3 * (self.steps + 1)].view(3, self.steps + 1)
         out["n_refs"] = self._persist(("em_n_refs", bs), z64, 1)
         return out
 
@@ -988,11 +1002,13 @@ class OwnerComputesTrainer:
         self._em_capacity[bs] = capacity
         bufs = self._em_buffers(bs, capacity)
         self.backend.em_plan(self, ph, pr, pt, codes, slot, bufs)
+        S1 = self.steps + 1
         host = self._persistent.get(("em_host", bs))
-        if host is None or host.numel() != self.steps + 2:
-            host = self._persistent[("em_host", bs)] = torch.empty(self.steps + 2, dtype=torch.int64, pin_memory=self.device.type == "cuda")
-        host[:self.steps + 1].copy_(bufs["row0"][:self.steps + 1], non_blocking=True)
-        host[self.steps + 1:].copy_(bufs["n_refs"][:1], non_blocking=True)
+        if host is None or host.numel() != 4 * S1 + 1:
+            host = self._persistent[("em_host", bs)] = torch.empty(4 * S1 + 1, dtype=torch.int64, pin_memory=self.device.type == "cuda")
+        host[:S1].copy_(bufs["row0"][:S1], non_blocking=True)
+        host[S1:4 * S1].copy_(bufs["steps3"].reshape(-1), non_blocking=True)
+        host[4 * S1:].copy_(bufs["n_refs"][:1], non_blocking=True)
         bufs["host"] = host
         return bufs
 
@@ -1032,16 +1048,23 @@ class OwnerComputesTrainer:
                           for c in range(self.chunks)]
         if self.em:
             em = plan["em"]
-            n_refs = int(em["host"][self.steps + 1])
+            S1 = self.steps + 1
+            n_refs = int(em["host"][4 * S1])
             if n_refs > em["capacity"]:        # more references than the 1 / G estimate allowed for (skewed ownership): re-plan in line, exactly
                 b = self.bat
                 pos = (b.pos_h, b.pos_r, b.pos_t)
                 em = self._compute_em_plan(pos[0], pos[1], pos[2], plan["codes"], plan["slot"], plan["bs"], capacity=int(n_refs * 1.1) + 4096)
                 if dev.type == "cuda":
                     torch.cuda.current_stream().synchronize()
-                n_refs = int(em["host"][self.steps + 1])
-            em["row0_host"] = em["host"][:self.steps + 1].clone()
+                n_refs = int(em["host"][4 * S1])
+            em["row0_host"] = em["host"][:S1].clone()
+            em["item0_host"], em["long0_host"], em["part0_host"] = (em["host"][(k + 1) * S1:(k + 2) * S1].clone() for k in range(3))
             em["n_refs_host"] = n_refs
+            # the long rows' partial sums of ONE step (stride + 16 floats per slot: the gradient vector and the coefficient sum)
+            need_parts = int((em["part0_host"][1:] - em["part0_host"][:-1]).max()) if self.steps else 0
+            need_parts = max(1, need_parts) * (self.stride + 16)
+            if getattr(self, "_em_partials", None) is None or self._em_partials.numel() < need_parts:
+                self._em_partials = torch.zeros(need_parts, dtype=torch.float32, device=dev)
             self._em = em
             need_coef = max(1, self._max_step * (self.N + 1))
             if getattr(self, "_em_coef", None) is None or self._em_coef.numel() < need_coef:

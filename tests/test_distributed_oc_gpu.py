@@ -179,7 +179,8 @@ def test_entity_major_hub_entities_equal_dense_oracle():
     steps = min(spe, 6)
     tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg, b=b, zipf=1.2, em=True)
     longest = int((tr._em["off"][1:tr._em["row0_host"][-1] + 1] - tr._em["off"][:tr._em["row0_host"][-1]]).max())
-    assert longest > 64, longest                   # lists that span several 16-reference rounds
+    assert longest > 64, longest                   # lists that span several 32-reference segments:
+    assert int(tr._em["long0_host"][-1]) > 0       # ... cut into work items of their own, partial sums, a combine launch
     for i in range(steps):
         tr.step(i)
     e, r, losses, _ = _reference(1, steps, n_ent, dim, neg, b, zipf=1.2)

@@ -186,7 +186,8 @@ def main():
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
     out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "native_loop": bool(a.native), "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
-           "em_rows_per_step": (int(tr._em["row0_host"][-1]) / max(1, tr.steps)) if tr.em else None, "chunks": a.chunks, "global_batch": B * G,
+           "em_rows_per_step": (int(tr._em["row0_host"][-1]) / max(1, tr.steps)) if tr.em else None,
+           "em_long_rows_per_step": (int(tr._em["long0_host"][-1]) / max(1, tr.steps)) if tr.em else None, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
            "capacity_vectors": tr.C,
            "phase_us": {k: float(np.mean(v)) for k, v in phases.items()},
