@@ -926,7 +926,8 @@ typedef struct mke_oc_em_plan_args {
   const int64_t* step_lo; int n_steps; int chunks; int64_t n_all; int64_t max_step /* host: most positives of a step */;
   int n_ranks, rank; int64_t n_local, n_rel;
   uint64_t* keys; uint64_t* keys_alt; int64_t capacity;
-  uint32_t* vals_alt;       /* capacity + 1 scratch ints (the sorted descriptors) */
+  uint32_t* vals_alt;       /* capacity + 1 scratch ints (the sorted positions) */
+  uint64_t* scratch8;       /* capacity + 1 scratch 8-byte words (the references at their unsorted positions) */
   int32_t* wave_scratch;    /* 2 * (MKE_OC_EM_WAVES + 1) scratch ints */
   uint32_t* refs; int32_t* rows; int32_t* off; int32_t* flags; int32_t* scan;
   int64_t* step_row0; int64_t* n_refs;

@@ -150,7 +150,7 @@ class OcEmPlanArgs(C.Structure):
     _fields_ = [("pos_h", C.c_void_p), ("pos_r", C.c_void_p), ("pos_t", C.c_void_p), ("codes", C.c_void_p), ("neg_per_pos", C.c_int),
                 ("slot_h", C.c_void_p), ("slot_t", C.c_void_p), ("step_lo", C.c_void_p), ("n_steps", C.c_int), ("chunks", C.c_int),
                 ("n_all", C.c_int64), ("max_step", C.c_int64), ("n_ranks", C.c_int), ("rank", C.c_int), ("n_local", C.c_int64), ("n_rel", C.c_int64),
-                ("keys", C.c_void_p), ("keys_alt", C.c_void_p), ("capacity", C.c_int64), ("vals_alt", C.c_void_p), ("wave_scratch", C.c_void_p),
+                ("keys", C.c_void_p), ("keys_alt", C.c_void_p), ("capacity", C.c_int64), ("vals_alt", C.c_void_p), ("scratch8", C.c_void_p), ("wave_scratch", C.c_void_p),
                 ("refs", C.c_void_p), ("rows", C.c_void_p), ("off", C.c_void_p), ("flags", C.c_void_p), ("scan", C.c_void_p),
                 ("step_row0", C.c_void_p), ("n_refs", C.c_void_p),
                 ("item_row", C.c_void_p), ("item_off", C.c_void_p), ("item_part", C.c_void_p), ("long_row", C.c_void_p), ("long_part0", C.c_void_p),

@@ -570,34 +570,62 @@ __global__ __launch_bounds__(OC_PLAN_THREADS) void k_oc_plan(const int32_t* __re
     if (tid < MKE_OC_MAX_RANKS) s_cnt[tid] = 0;
     for (int i = tid; i < NWV * MKE_OC_MAX_RANKS; i += OC_PLAN_THREADS) (&s_wcnt[0][0])[i] = 0;
     __syncthreads();
-    for (int64_t base = lo; base < hi; base += OC_PLAN_THREADS) {
-      const int64_t i = base + tid;
-      const uint32_t need = i < hi ? (neg_per_pos ? (uint32_t)codes[i * neg_per_pos] : MKE_OC_NEED_HR) : 0u;
-      const bool valid = (need & (x ? MKE_OC_NEED_RT : MKE_OC_NEED_HR)) != 0;
-      const int o = valid ? oc_mod(oc_divisor(G), ids[i]) : -1;
-      int rk = 0;
-      uint64_t todo = __ballot(valid);
-      while (todo) {                                 // wave-uniform: one round per distinct owner present in the wavefront
-        const int o0 = __shfl(o, __builtin_ctzll(todo), 64);
-        const uint64_t m = __ballot(valid && o == o0);
-        if (valid && o == o0) rk = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wv][o0] = __popcll(m);
-        todo &= ~m;
+    // 4,096 positions per round of the block: wavefront wv takes 256 CONSECUTIVE ones as four ballots of 64, its running
+    // per-owner counts in the lanes (lane o = owner o), so the block synchronises three times per 4,096 positions instead of per
+    // 1,024 (the kernel was bound by those: 139 us per epoch share at the C2 shape with 8 ranks, the largest term of the plan)
+    constexpr int RND = 4;
+    for (int64_t base = lo; base < hi; base += (int64_t)OC_PLAN_THREADS * RND) {
+      int rk[RND], ow[RND];
+      int run = 0;                                   // lane o: this wavefront's positives of owner o so far in this round of the block
+      uint32_t need_[RND];
+      int id_[RND];
+#pragma unroll
+      for (int r = 0; r < RND; ++r) {                // the four rounds' loads first: in flight together (the first code of a group is a
+        const int64_t i = base + (int64_t)wv * (64 * RND) + r * 64 + lane;   // strided access: one cache line per lane)
+        need_[r] = i < hi ? (neg_per_pos ? (uint32_t)codes[i * neg_per_pos] : MKE_OC_NEED_HR) : 0u;
+        id_[r] = i < hi ? ids[i] : 0;
       }
+#pragma unroll
+      for (int r = 0; r < RND; ++r) {
+        const bool valid = (need_[r] & (x ? MKE_OC_NEED_RT : MKE_OC_NEED_HR)) != 0;
+        const int o = valid ? oc_mod(oc_divisor(G), id_[r]) : -1;
+        ow[r] = o;
+        rk[r] = 0;
+        uint64_t todo = __ballot(valid);
+        while (todo) {                               // wave-uniform: one round per distinct owner present in the wavefront
+          const int o0 = __shfl(o, __builtin_ctzll(todo), 64);
+          const uint64_t m = __ballot(valid && o == o0);
+          const int before = __shfl(run, o0, 64);
+          if (valid && o == o0) rk[r] = before + __popcll(m & ((1ull << lane) - 1ull));
+          if (lane == o0) run += __popcll(m);
+          todo &= ~m;
+        }
+      }
+      if (lane < MKE_OC_MAX_RANKS) s_wcnt[wv][lane] = run;
       __syncthreads();
-      if (valid) {
-        int sl = s_cnt[o] + rk;
-        for (int w = 0; w < wv; ++w) sl += s_wcnt[w][o];
-        slot[i] = sl;
-        if (o == rank) own[lo + sl] = (int32_t)(i - lo);
-      } else if (i < hi) {
-        slot[i] = -1;
+      int pre = 0;                                   // lane o: positives of owner o in the wavefronts before this one
+      if (lane < MKE_OC_MAX_RANKS) {
+        pre = s_cnt[lane];
+        for (int w = 0; w < wv; ++w) pre += s_wcnt[w][lane];
+      }
+#pragma unroll
+      for (int r = 0; r < RND; ++r) {
+        const int64_t i = base + (int64_t)wv * (64 * RND) + r * 64 + lane;
+        const int o = ow[r];
+        const int first = __shfl(pre, o < 0 ? 0 : o, 64);
+        if (o >= 0) {
+          const int sl = first + rk[r];
+          slot[i] = sl;
+          if (o == rank) own[lo + sl] = (int32_t)(i - lo);
+        } else if (i < hi) {
+          slot[i] = -1;
+        }
       }
       __syncthreads();
       if (tid < G) {
         int c = 0;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) { c += s_wcnt[w][tid]; s_wcnt[w][tid] = 0; }
+        for (int w = 0; w < NWV; ++w) c += s_wcnt[w][tid];
         s_cnt[tid] += c;
       }
       __syncthreads();

@@ -60,7 +60,7 @@ __device__ __forceinline__ int em_step_of(const int64_t* __restrict__ step_lo, i
 // The loads of an element are unconditional (clamped indices) and independent of each other, so that the EM_U elements a lane
 // handles per round are in flight together: with one dependent load per round the walks ran at the latency of a round trip per
 // 64 elements and wavefront (2.8 + 4.5 ms per epoch at the C5 shape with 8 ranks).
-struct EmElem { int ent; int kind; int64_t p; };
+struct EmElem { int ent; int kind; int64_t p; int code, sh, st, ph, pt; };
 __device__ __forceinline__ EmElem em_elem_of(const EmPlanParams& pp, int64_t t, int64_t total) {
   const mke_oc_em_plan_args& a = pp.a;
   const int N = a.neg_per_pos;
@@ -73,7 +73,7 @@ __device__ __forceinline__ EmElem em_elem_of(const EmPlanParams& pp, int64_t t, 
   const int code = N > 0 ? a.codes[p * N + (n < N ? n : 0)] : 0;
   const int sh = a.slot_h[p], st = a.slot_t[p], ph = a.pos_h[p], pt = a.pos_t[p];
   EmElem e;
-  e.p = p;
+  e.p = p; e.code = code; e.sh = sh; e.st = st; e.ph = ph; e.pt = pt;
   e.kind = n < N ? n : (n == N ? EM_KIND_OWN : (n == N + 1 ? EM_KIND_GV_H : (n == N + 2 ? EM_KIND_GV_T : (n == N + 3 ? EM_KIND_REL_H : EM_KIND_REL_T))));
   const int own_ent = sh >= 0 ? pt : ph;               // own term: the owner of t when HR travels, else the owner of h
   const int head_ent = sh >= 0 ? ph : -1;              // the owner of the head receives sum dL/dHR: head row and relation row
@@ -113,8 +113,36 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_count(const EmPlanParams pp) {
   if (wave == 0 && lane == 0) pp.wave_cnt[pp.n_waves] = 0;
 }
 
+// (locator, coefficient index) of an owned element — everything it needs is in the element's registers already
+__device__ __forceinline__ uint2 em_ref_of(const EmPlanParams& pp, const EmElem& e, int s, int64_t i) {
+  const mke_oc_em_plan_args& a = pp.a;
+  const int N = a.neg_per_pos, G = a.n_ranks;
+  const int64_t lo = a.step_lo[s], size = a.step_lo[s + 1] - lo;
+  const int64_t part = (size + a.chunks - 1) / a.chunks;
+  const uint32_t chunk = (uint32_t)(i / (part > 0 ? part : 1));
+  bool rt;
+  uint32_t loc, cidx = 0;
+  if (e.kind >= EM_KIND_GV_H) {
+    rt = e.kind == EM_KIND_GV_T || e.kind == EM_KIND_REL_T;
+    loc = EM_LOC_GV | (e.kind >= EM_KIND_REL_H ? EM_LOC_PLUS : 0u) | (uint32_t)(rt ? e.st : e.sh);
+  } else {
+    if (e.kind == EM_KIND_OWN) {
+      rt = e.sh < 0;                                        // HR travels: d = HR - t^, else d = h^ + RT
+      cidx = (uint32_t)(i * (N + 1) + N);
+    } else {
+      rt = (e.code & 1) != 0;                               // corrupted head: d = c^ + RT
+      cidx = (uint32_t)(i * (N + 1) + e.kind);
+    }
+    const uint32_t ent = (uint32_t)(rt ? e.pt : e.ph);
+    const uint32_t owner = pp.g_shift >= 0 ? (ent & (uint32_t)(G - 1)) : ent % (uint32_t)G;
+    loc = (owner << 24) | (uint32_t)(rt ? e.st : e.sh);
+  }
+  loc |= (chunk << 28) | (rt ? (1u << 23) : 0u);
+  return make_uint2(loc, cidx);
+}
+
 template <typename KEY>
-__global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KEY* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KEY* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ refs_unsorted) {
   const mke_oc_em_plan_args& a = pp.a;
   const int64_t total = a.n_all * (int64_t)pp.ep;
   const int lane = threadIdx.x & 63;
@@ -145,19 +173,19 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KE
         const uint64_t row = e[u].kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[e[u].p]
                                                         : (uint64_t)(pp.g_shift >= 0 ? (uint32_t)e[u].ent >> pp.g_shift : (uint32_t)e[u].ent / (uint32_t)G);
         const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
-        const uint32_t desc = ((uint32_t)(e[u].p - a.step_lo[s]) << 7) | (uint32_t)e[u].kind;
         const int64_t k = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (k < a.capacity) { keys[k] = (KEY)srow; vals[k] = desc; }
+        if (k < a.capacity) { keys[k] = (KEY)srow; vals[k] = (uint32_t)k; refs_unsorted[k] = em_ref_of(pp, e[u], s, e[u].p - a.step_lo[s]); }
       }
       base += __popcll(m);
     }
   }
 }
 
-// sorted reference k -> (locator, coefficient index) and the "a new (step, row) starts here" flag; entry `capacity` (and every
-// sentinel) is the end marker
+// sorted reference k <- the (locator, coefficient index) its element left at its unsorted position, and the "a new (step, row)
+// starts here" flag; entry `capacity` (and every sentinel) is the end marker
 template <typename KEY>
-__global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp, const KEY* __restrict__ sorted, const uint32_t* __restrict__ descs) {
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp, const KEY* __restrict__ sorted, const uint32_t* __restrict__ src,
+                                                          const uint2* __restrict__ refs_unsorted) {
   const mke_oc_em_plan_args& a = pp.a;
   const int64_t k = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
   if (k > a.capacity) return;
@@ -169,34 +197,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_resolve(const EmPlanParams pp,
     return;
   }
   a.flags[k] = (k == 0 || prev != srow) ? 1 : 0;
-  const uint32_t desc = descs[k];
-  const int s = (int)((uint64_t)srow / (uint64_t)pp.rows_tot);
-  const int64_t i = (int64_t)(desc >> 7);
-  const int kind = (int)(desc & 127);
-  const int64_t lo = a.step_lo[s], size = a.step_lo[s + 1] - lo;
-  const int64_t part = (size + a.chunks - 1) / a.chunks;
-  const uint32_t chunk = (uint32_t)(i / (part > 0 ? part : 1));
-  const int64_t p = lo + i;
-  const int N = a.neg_per_pos, G = a.n_ranks;
-  bool rt;
-  uint32_t loc, cidx = 0;
-  if (kind >= EM_KIND_GV_H) {
-    rt = kind == EM_KIND_GV_T || kind == EM_KIND_REL_T;
-    loc = EM_LOC_GV | (kind >= EM_KIND_REL_H ? EM_LOC_PLUS : 0u) | (uint32_t)(rt ? a.slot_t[p] : a.slot_h[p]);
-  } else {
-    if (kind == EM_KIND_OWN) {
-      rt = a.slot_h[p] < 0;                                 // HR travels: d = HR - t^, else d = h^ + RT
-      cidx = (uint32_t)(i * (N + 1) + N);
-    } else {
-      rt = (a.codes[p * N + kind] & 1) != 0;                // corrupted head: d = c^ + RT
-      cidx = (uint32_t)(i * (N + 1) + kind);
-    }
-    const uint32_t owner = (uint32_t)(rt ? a.pos_t[p] : a.pos_h[p]) % (uint32_t)G;
-    loc = (owner << 24) | (uint32_t)(rt ? a.slot_t[p] : a.slot_h[p]);
-  }
-  loc |= (chunk << 28) | (rt ? (1u << 23) : 0u);
-  a.refs[2 * k] = loc;
-  a.refs[2 * k + 1] = cidx;
+  reinterpret_cast<uint2*>(a.refs)[k] = refs_unsorted[src[k]];
 }
 
 // flagged k: the scan[k]-th touched (step, row) starts at reference k; step boundaries fall out of the same walk
@@ -277,7 +278,8 @@ static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) 
   const mke_oc_em_plan_args& a = pp.a;
   KEY* keys = reinterpret_cast<KEY*>(a.keys);
   KEY* keys_alt = reinterpret_cast<KEY*>(a.keys_alt);
-  uint32_t* vals = reinterpret_cast<uint32_t*>(a.flags);           // the unsorted descriptors are dead after the sort
+  uint32_t* vals = reinterpret_cast<uint32_t*>(a.flags);           // the unsorted positions are dead after the sort
+  uint2* refs_unsorted = reinterpret_cast<uint2*>(a.scratch8);     // the references at their unsorted positions (gathered after the sort)
   hipError_t e;
   if ((e = hipMemsetAsync(keys, 0xFF, (size_t)(a.capacity + 1) * sizeof(KEY), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
   const int64_t total = a.n_all * (int64_t)pp.ep;
@@ -288,14 +290,14 @@ static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) 
     int rc = check_launch("k_em_count");
     if (rc) return rc;
     if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, pp.wave_cnt, pp.wave_off, pp.n_waves + 1, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL((k_em_fill<KEY>), wgrid, dim3(MKE_BLOCK), 0, st, pp, keys, vals);
+    hipLaunchKernelGGL((k_em_fill<KEY>), wgrid, dim3(MKE_BLOCK), 0, st, pp, keys, vals, refs_unsorted);
     if ((rc = check_launch("k_em_fill"))) return rc;
   } else if ((e = hipMemsetAsync(a.n_refs, 0, sizeof(int64_t), st)) != hipSuccess) { set_error("mke_oc_em_plan: %s", hipGetErrorString(e)); return (int)e; }
   const int n = (int)(a.capacity + 1);
   tb = (size_t)a.temp_bytes;
   if ((e = hipcub::DeviceRadixSort::SortPairs(a.temp, tb, keys, keys_alt, vals, a.vals_alt, n, 0, key_bits, st)) != hipSuccess) { set_error("mke_oc_em_plan: radix sort: %s", hipGetErrorString(e)); return (int)e; }
   const dim3 grid((unsigned)((a.capacity + 1 + MKE_BLOCK - 1) / MKE_BLOCK));
-  hipLaunchKernelGGL((k_em_resolve<KEY>), grid, dim3(MKE_BLOCK), 0, st, pp, (const KEY*)keys_alt, (const uint32_t*)a.vals_alt);
+  hipLaunchKernelGGL((k_em_resolve<KEY>), grid, dim3(MKE_BLOCK), 0, st, pp, (const KEY*)keys_alt, (const uint32_t*)a.vals_alt, (const uint2*)refs_unsorted);
   int rc = check_launch("k_em_resolve");
   if (rc) return rc;
   tb = (size_t)a.temp_bytes;
@@ -312,15 +314,21 @@ static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) 
   ip.itemoff = itemoff; ip.lidx = lidx; ip.part0 = part0;
   ip.item_row = a.item_row; ip.item_off = a.item_off; ip.item_part = a.item_part; ip.long_row = a.long_row; ip.long_part0 = a.long_part0;
   ip.step_item0 = a.step_item0; ip.step_long0 = a.step_long0; ip.step_part0 = a.step_part0;
-  hipLaunchKernelGGL(k_em_nseg, grid, dim3(MKE_BLOCK), 0, st, ip);
+  // the per-row arrays are at most n_steps x (n_local + n_rel) + 1 long (the scans over the whole reference capacity were 24 us each)
+  int64_t nu64 = (int64_t)a.n_steps * pp.rows_tot + 1;
+  if (nu64 > a.capacity + 1) nu64 = a.capacity + 1;
+  const int nu = (int)nu64;
+  ip.cap = nu64 - 1;
+  const dim3 ugrid((unsigned)((nu64 + MKE_BLOCK - 1) / MKE_BLOCK));
+  hipLaunchKernelGGL(k_em_nseg, ugrid, dim3(MKE_BLOCK), 0, st, ip);
   if ((rc = check_launch("k_em_nseg"))) return rc;
   int32_t* const ins[3] = {ip.nseg, ip.lflag, ip.lns};
   int32_t* const outs[3] = {itemoff, lidx, part0};
   for (int k = 0; k < 3; ++k) {
     tb = (size_t)a.temp_bytes;
-    if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, ins[k], outs[k], n, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
+    if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, ins[k], outs[k], nu, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(k_em_items, grid, dim3(MKE_BLOCK), 0, st, ip);
+  hipLaunchKernelGGL(k_em_items, ugrid, dim3(MKE_BLOCK), 0, st, ip);
   return check_launch("k_em_items");
 }
 
@@ -530,7 +538,7 @@ extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
     return MKE_E_SHAPE;
   }
   if (a.capacity < 1 || a.capacity >= 0x7FFFFFFFll) { set_error("mke_oc_em_plan: capacity must be in [1, 2^31)"); return MKE_E_RANGE; }
-  if (!a.keys || !a.keys_alt || !a.vals_alt || !a.wave_scratch || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp ||
+  if (!a.keys || !a.keys_alt || !a.vals_alt || !a.scratch8 || !a.wave_scratch || !a.refs || !a.rows || !a.off || !a.flags || !a.scan || !a.step_row0 || !a.n_refs || !a.temp ||
       !a.item_row || !a.item_off || !a.item_part || !a.long_row || !a.long_part0 || !a.step_item0 || !a.step_long0 || !a.step_part0) { set_error("mke_oc_em_plan: NULL output / scratch"); return MKE_E_NULL; }
   if (a.n_all > 0 && (!a.pos_h || !a.pos_r || !a.pos_t || !a.slot_h || !a.slot_t || !a.step_lo || (a.neg_per_pos > 0 && !a.codes))) { set_error("mke_oc_em_plan: NULL input"); return MKE_E_NULL; }
   if (a.temp_bytes < mke_oc_em_plan_temp_bytes(a.capacity)) { set_error("mke_oc_em_plan: temp storage below mke_oc_em_plan_temp_bytes"); return MKE_E_SHAPE; }

@@ -103,6 +103,7 @@ class OcHipBackend:
         a.n_ranks, a.rank, a.n_local, a.n_rel = tr.world, tr.rank, max(1, tr.n_local), tr.rel.shape[0]
         a.keys, a.keys_alt, a.capacity = _lib.ptr(bufs["keys"], i64, "keys"), _lib.ptr(bufs["keys_alt"], i64, "keys"), bufs["capacity"]
         a.vals_alt, a.wave_scratch = _lib.ptr(bufs["vals_alt"], i32, "vals_alt"), _lib.ptr(bufs["waves"], i32, "waves")
+        a.scratch8 = _lib.ptr(bufs["scratch8"], i64, "scratch8")
         a.refs, a.rows, a.off = _lib.ptr(bufs["refs"], i32, "refs"), _lib.ptr(bufs["rows"], i32, "rows"), _lib.ptr(bufs["off"], i32, "off")
         a.flags, a.scan = _lib.ptr(bufs["flags"], i32, "flags"), _lib.ptr(bufs["scan"], i32, "scan")
         a.step_row0, a.n_refs = _lib.ptr(bufs["row0"], i64, "row0"), _lib.ptr(bufs["n_refs"], i64, "n_refs")
@@ -975,6 +976,7 @@ class OwnerComputesTrainer:
         out["flags"] = self._persist(("em_flags",), z32, capacity + 1)
         out["scan"] = self._persist(("em_scan",), z32, capacity + 1)
         out["vals_alt"] = self._persist(("em_vals_alt",), z32, capacity + 1)
+        out["scratch8"] = self._persist(("em_scratch8",), z64, capacity + 1)
         out["waves"] = self._persist(("em_waves",), z32, 2 * (_lib.OC_EM_WAVES + 1))
         out["temp"] = self._persist(("em_temp",), torch.zeros(0, dtype=torch.uint8, device=dev), self.backend.em_temp_bytes(capacity))
         out["refs"] = self._persist(("em_refs", bs), z32, 2 * capacity)
@@ -1111,9 +1113,11 @@ class OwnerComputesTrainer:
 
     @property
     def _gather_at(self):
-        """The step of an epoch before which the NEXT epoch's codes are all-gathered (mid-epoch: the sampling has half an epoch
-        of head start, the lists the other half)."""
-        return min(self.steps - 1, max(1, self.steps // 2)) if self.steps > 1 else 0
+        """The step of an epoch before which the NEXT epoch's codes are all-gathered: an eighth into the epoch — the sampling of a
+        rank's share is short (0.2 ms at the C2 shape with 8 ranks, 1.5 ms at C5) and the lists that follow the gather (1 - 12 ms)
+        want the rest of the epoch, or the host waits for them at the boundary with the GPU idle (measured at C2 with 8 ranks and
+        the gather mid-epoch: 117 us per global step for 65 us of kernels)."""
+        return min(self.steps - 1, max(1, self.steps // 8)) if self.steps > 1 else 0
 
     def _plan_midpoint(self):
         """At step `_gather_at` of every epoch, on every rank: the prefetched plan's collective (main stream, step communicator),

@@ -152,19 +152,24 @@ def main():
         ev.append((names.get(phases, str(phases)), e0, e1))
 
     n = a.steps if a.native else min(a.steps, tr.steps - 1)
-    for i in range(min(5, n)):
+    w0 = 0
+    if a.native and a.prefetch:       # two whole epochs first: the second buffer set of the epoch plan is allocated on the way
+        w0 = 2 * tr.steps
+        tr.run(0, w0)
+        n += w0
+    for i in range(w0, w0 + min(5, n - w0)):
         tr.step(i)
     torch.cuda.synchronize()
     # untimed wall of the steps (collectives = device copies of the same byte counts: an in-HBM stand-in, not a link)
     t0 = time.perf_counter()
     if a.native:
-        tr.run(5, n - 5)                                      # mke_oc_steps: runs of steps enqueued from C++ (epoch boundaries in Python)
+        tr.run(w0 + 5, n - w0 - 5)                            # mke_oc_steps: runs of steps enqueued from C++ (epoch boundaries in Python)
     else:
         for i in range(5, n):
             tr.step(i)
-    host = (time.perf_counter() - t0) / max(1, n - 5)         # the enqueue loop alone (nothing waits for the device)
+    host = (time.perf_counter() - t0) / max(1, n - w0 - 5)    # the enqueue loop alone (nothing waits for the device)
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / max(1, n - 5)
+    wall = (time.perf_counter() - t0) / max(1, n - w0 - 5)
     # instrumented pass
     tr.backend.run = timed_run
     torch.cuda._sleep(int(2.4e9 * 0.03))
