@@ -1,7 +1,8 @@
-"""Randomised sweep of the owner-computes sharded trainer against the float64 dense oracle: random world sizes (1..5 ranks
+"""Randomised sweep of the owner-computes sharded trainer against the float64 dense oracle: random world sizes (1..8 ranks
 sharing the one GPU, collectives staged through gloo or peer-direct), entity counts that do not divide by the world size (from 60:
 re-draw rounds then make a fifth of the positives need BOTH vectors), Zipf head / tail entities with a low hub-row threshold, row
-widths, negatives per positive (0..64), chunk counts, exclusive-row path on / off.  python tools/fuzz_oc.py [cases] [seed]"""
+widths, negatives per positive (0..64), chunk counts, exclusive-row path on / off, entity-major second pass on / off, native step
+loop (mke_oc_steps) or the Python loop.  python tools/fuzz_oc.py [cases] [seed]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,9 +18,13 @@ def worker(rank, world, rdv, ret, kw, steps):
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
+        native = kw.pop("native", False)
         tr = T._make(rank, world, comm=OcHostStagedComm() if world > 1 else None, **kw)
-        for i in range(steps):
-            tr.step(i)
+        if native and tr._native_loop()[0]:          # mke_oc_steps (collectives by callback at world > 1)
+            tr.run(0, steps)
+        else:
+            for i in range(steps):
+                tr.step(i)
         full = tr.gather_entity_table().cpu().numpy()
         ok = tr.scratch_clean()
         loss = tr.epoch_loss()
@@ -38,7 +43,7 @@ if __name__ == "__main__":
     bad = 0
     only = {int(x) for x in os.environ.get("MKE_FUZZ_ONLY", "").split(",") if x}   # rerun these cases of the same draw sequence
     for c in range(cases):
-        world = int(rng.choice([1, 2, 2, 3, 4, 5]))
+        world = int(rng.choice([1, 2, 2, 3, 4, 5, 6, 7, 8, 8]))
         kw = dict(n_ent=int(rng.choice([int(rng.integers(60, 400)), int(rng.integers(400, 5000))])), dim=int(rng.choice([7, 16, 20, 33, 75, 100, 128, 200, 256, 300])),
                   neg=int(rng.choice([0, 1, 3, 8, 25, 33, 64])), b=int(rng.integers(20, 400)), chunks=int(rng.integers(1, 4)),
                   excl=bool(rng.random() < 0.7), peer=bool(world > 1 and rng.random() < 0.3))
@@ -47,6 +52,8 @@ if __name__ == "__main__":
         kw["neg"] = min(kw["neg"], kw["n_ent"] // 2 - 6)          # a KG's candidate population must hold the sample
         kw["zipf"] = float(rng.choice([0.0, 0.0, 1.0, 1.3]))
         kw["hot_min"] = [None, 3.0][int(rng.integers(0, 2))] if kw["zipf"] else None
+        kw["em"] = bool(rng.random() < 0.7)                       # entity-major second pass (not with peer-direct: the trainer falls back)
+        kw["native"] = bool(rng.random() < 0.6)                   # the native step loop
         ref_kw = dict(n_ent=kw["n_ent"], dim=kw["dim"], neg=kw["neg"], b=kw["b"], zipf=kw["zipf"])
         _, _, _, spe = T._reference(world, 1, **ref_kw)
         steps = int(min(spe, rng.integers(1, 7)))
