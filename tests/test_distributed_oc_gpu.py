@@ -376,6 +376,50 @@ def test_one_rank_rccl_collectives_run():
         dist.destroy_process_group()
 
 
+def _rccl_native_worker(ret, chunks, em):
+    """(spawned: MKE_OC_FORCE_COLLECTIVES is read when the trainer is built, and a process has one default process group)"""
+    import tempfile
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MKE_OC_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        from multike_amd.distributed_oc import OcRcclComm
+        _, _, _, spe = _reference(1, 1, neg=25)
+        steps = min(spe, 6)
+        tr = _make(0, 1, chunks=chunks, neg=25, em=em)
+        ok, cs = tr._native_loop()
+        kind = (type(tr.comm).__name__, bool(ok), None if cs is None else int(cs.kind), bool(tr.force_collectives))
+        tr.run(0, steps)
+        torch.cuda.synchronize()
+        ret.put((kind, tr.epoch_loss(), tr.gather_entity_table().cpu().numpy(), tr.rel[:, :DIM].cpu().numpy().copy(), tr.scratch_clean(), steps))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("chunks,em", [(1, True), (2, True), (1, False)])
+def test_native_step_loop_over_rccl_entry_points(chunks, em):
+    """mke_oc_steps with `mke_oc_comm` of kind NCCL: the library calls ncclAllGather / ncclReduceScatter / ncclAllReduce through the
+    addresses the host side hands over (a real one-rank RCCL communicator, the G > 1 path forced: all three collectives of every
+    step are issued for real; chunks 2: on the second stream, ordered by the call's events) — against the float64 dense oracle."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_rccl_native_worker, args=(ret, chunks, em))
+    p.start()
+    kind, loss, full, rel, clean, steps = ret.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    assert kind == ("OcRcclComm", True, 0, True), kind          # RCCL through ctypes, native loop usable, MKE_OC_COMM_NCCL, forced
+    e, r, losses, _ = _reference(1, steps, neg=25)
+    np.testing.assert_allclose(loss, sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(full, e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(rel, r, rtol=2e-4, atol=2e-6)
+    assert clean
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # cross-KG inference loops on the sharded tables: positives only, `random.sample` batches of a triple list, loss x 2
 # ----------------------------------------------------------------------------------------------------------------------

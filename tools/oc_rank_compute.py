@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--prefetch", action="store_true", help="the next epoch's plan on the side stream while the steps run (the product's default)")
     ap.add_argument("--zipf", type=float, default=0.0, help="head / tail entities of the synthetic triples ~ rank^-zipf (hub rows)")
     ap.add_argument("--rel-zipf", type=float, default=0.0, help="relation ids of the synthetic triples ~ rank^-rel_zipf")
+    ap.add_argument("--hi-prio", type=int, default=0, help="1: the steps run on a high-priority stream (the epoch plan's side stream then yields to them)")
     ap.add_argument("--native", type=int, default=1, help="1 (default): the timed steps go through mke_oc_steps (one native call); 0: the Python step loop")
     ap.add_argument("--em", type=int, default=1, help="1 (default): entity-major second pass; 0: the atomics form of rounds 2-5")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="mke_set_option before the run (A/B of a kernel choice)")
@@ -135,6 +136,8 @@ def main():
     g = torch.Generator(device="cpu"); g.manual_seed(1)
     ent0 = (torch.randn(cfg["n_ent"], cfg["dim"], generator=g) * float(np.sqrt(2.6 / (cfg["n_ent"] + cfg["dim"])))).numpy()
     rel0 = xavier_truncated_normal(cfg["n_rel"], cfg["dim"], "cpu", seed=2).numpy()
+    if a.hi_prio:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     comm = LoopbackComm(G, 0, a.wire_gbps, a.latency_us)
     comm.clock_hz = calibrate_sleep()
     tr = OwnerComputesTrainer(kgs, ent0, rel0, B, cfg["neg"], 0, G, seed=1, chunks=a.chunks, comm=comm, prefetch=a.prefetch, entity_major=bool(a.em))
@@ -190,7 +193,7 @@ def main():
     phases = {}
     for name, e0, e1 in ev:
         phases.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
-    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "native_loop": bool(a.native), "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
+    out = {"tool": "oc_rank_compute", "config": a.config, "zipf": a.zipf, "rel_zipf": a.rel_zipf, "options": a.set, "world": G, "rank": 0, "entity_major": tr.em, "native_loop": bool(a.native), "hi_prio_stream": bool(a.hi_prio), "em_refs_per_step": (tr._em["n_refs_host"] / max(1, tr.steps)) if tr.em else None,
            "em_rows_per_step": (int(tr._em["row0_host"][-1]) / max(1, tr.steps)) if tr.em else None,
            "em_long_rows_per_step": (int(tr._em["long0_host"][-1]) / max(1, tr.steps)) if tr.em else None, "chunks": a.chunks, "global_batch": B * G,
            "scored_per_global_step": B * G * (1 + cfg["neg"]), "steps_per_epoch": tr.steps, "rows_owned": tr.n_local,
