@@ -190,6 +190,25 @@ def test_entity_major_hub_entities_equal_dense_oracle():
     assert tr.scratch_clean()
 
 
+def test_entity_major_plan_grows_when_a_rank_owns_more_than_its_share():
+    """The reference lists are sized for 1.25 / G of the epoch's references; a rank that owns more (skewed ownership) reports the
+    count, and the plan is redone in line at the exact size before the epoch starts.  Forced here by planning with room for 100
+    references: same results as the float64 dense oracle afterwards."""
+    n_ent, dim, neg = 3000, 75, 8
+    _, _, _, spe = _reference(1, 1, n_ent, dim, neg)
+    steps = min(spe, 5)
+    tr = _make(0, 1, n_ent=n_ent, dim=dim, neg=neg, em=True)
+    full = tr._em["capacity"]
+    tr._em_capacity = {0: 100, 1: 100}
+    tr._plan_epoch()                                   # overflows, re-plans at the reported size
+    assert 100 < tr._em["capacity"] <= full and tr._em["n_refs_host"] <= tr._em["capacity"]
+    tr.run(0, steps)
+    e, r, losses, _ = _reference(1, steps, n_ent, dim, neg)
+    np.testing.assert_allclose(tr.epoch_loss(), sum(losses), rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+
+
 @pytest.mark.parametrize("chunks,quarter", [(1, 0), (2, 1)])
 def test_entity_major_step_is_bit_reproducible(chunks, quarter):
     """The entity-major step has no atomics on table rows: every row's gradient is summed in its reference list's order (the
