@@ -190,7 +190,9 @@ def cpu_baseline(args, kgs, ent, rel):
         # graph normalises the whole variable and applies Adagrad to every row at every step (code/base/initializers.py:26,
         # code/MultiKE_model.py:15-31) — while `value` is the same arithmetic restricted to the touched rows (what any sparse
         # implementation, this package included, does).  Neither is TensorFlow itself (BASELINE.md estimates that at 0.18 M/s).
-        "reference_faithful_leg": "whole_table_passes_value",
+        # (round 5 called the dense leg "reference_faithful_leg": it is a C / OpenMP cost model of the SHAPE of TF1's dense work, far
+        # kinder to the reference than TF1 itself — the name oversold it: round-5 review, weak 7)
+        "dense_cost_model_leg": "whole_table_passes_value",
         "whole_table_passes_value": vd,
         "whole_table_passes_sample": f"{dsteps} steps ({ddt:.1f}s) on {threads_all} threads, interleaved step by step with the "
                                      f"touched-rows leg: whole-table normalise + Jacobian/Adagrad over all {ent.shape[0]} rows",
