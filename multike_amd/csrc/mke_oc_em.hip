@@ -36,6 +36,10 @@ struct EmPlanParams {
   mke_oc_em_plan_args a;
   uint32_t ep;          // elements per positive: neg_per_pos + 5
   uint64_t ep_magic;    // ceil(2^40 / ep)
+  int64_t n_codes;      // n_all * neg_per_pos: elements [0, n_codes) are the negatives in code order, [n_codes, n_codes + 5 n_all) the
+                        // five other elements of every position
+  uint64_t n_magic;     // ceil(2^40 / neg_per_pos)
+  int64_t total;        // n_codes + 5 n_all
   int g_shift;          // log2(n_ranks) when it is a power of two, else -1
   int64_t rows_tot;     // n_local + n_rel: the relation rows follow the shard's rows
   int64_t per;          // elements per wavefront range (a multiple of 64)
@@ -61,26 +65,48 @@ __device__ __forceinline__ int em_step_of(const int64_t* __restrict__ step_lo, i
 // handles per round are in flight together: with one dependent load per round the walks ran at the latency of a round trip per
 // 64 elements and wavefront (2.8 + 4.5 ms per epoch at the C5 shape with 8 ranks).
 struct EmElem { int ent; int kind; int64_t p; int code, sh, st, ph, pt; };
-__device__ __forceinline__ EmElem em_elem_of(const EmPlanParams& pp, int64_t t, int64_t total) {
+// Element t of the epoch: t < n_codes — negative t % N of position t / N, ONE load (its code; the position and the positive's slots
+// are looked up only for the eighth this rank owns); then five elements per position — own term, the head / tail rows' gradient
+// vectors, the relation row's two — from the position's slots and ids.  (Round 6 first enumerated position-major, N + 5 elements
+// per position with the five loads for every element: 62 + 148 us per epoch share at C2 with 8 ranks for the two walks.)  A
+// STABLE sort by (step, row) of the owned elements in THIS order leaves every row's references in a fixed order — its negatives by
+// (positive, n), then the other kinds by (positive, kind) — the summation order of the second pass.
+__device__ __forceinline__ EmElem em_elem_of(const EmPlanParams& pp, int64_t t) {
   const mke_oc_em_plan_args& a = pp.a;
-  const int N = a.neg_per_pos;
-  const bool in = t < total;
-  const int64_t tc = in ? t : 0;
-  // t / ep as one multiply-high when t < 2^32: M = ceil(2^40 / ep) is exact there (the error t (M - 2^40 / ep) / 2^40 < 2^-8 is
-  // below the 1 / ep >= 1 / 69 that separates t / ep from the next integer)
-  const int64_t p = total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)tc * pp.ep_magic) >> 40) : tc / pp.ep;
-  const int n = (int)(tc - p * pp.ep);
-  const int code = N > 0 ? a.codes[p * N + (n < N ? n : 0)] : 0;
-  const int sh = a.slot_h[p], st = a.slot_t[p], ph = a.pos_h[p], pt = a.pos_t[p];
   EmElem e;
-  e.p = p; e.code = code; e.sh = sh; e.st = st; e.ph = ph; e.pt = pt;
-  e.kind = n < N ? n : (n == N ? EM_KIND_OWN : (n == N + 1 ? EM_KIND_GV_H : (n == N + 2 ? EM_KIND_GV_T : (n == N + 3 ? EM_KIND_REL_H : EM_KIND_REL_T))));
-  const int own_ent = sh >= 0 ? pt : ph;               // own term: the owner of t when HR travels, else the owner of h
-  const int head_ent = sh >= 0 ? ph : -1;              // the owner of the head receives sum dL/dHR: head row and relation row
-  const int tail_ent = st >= 0 ? pt : -1;              // the owner of the tail receives sum dL/dRT: tail row and relation row
-  e.ent = n < N ? ((code & 0x3FFFFFFF) >> 1) : (n == N ? own_ent : ((n == N + 1 || n == N + 3) ? head_ent : tail_ent));
+  e.sh = e.st = e.ph = e.pt = 0;
+  e.p = -1;
+  const bool in = t < pp.total;
+  const int64_t tc = in ? t : 0;
+  // the code load is unconditional (clamped) so that the EM_U elements of a lane are in flight together
+  e.code = pp.n_codes > 0 ? a.codes[tc < pp.n_codes ? tc : pp.n_codes - 1] : 0;
+  if (tc < pp.n_codes) {
+    e.kind = -1;                                   // a negative: its n = t - p N when the position is looked up (em_locate)
+    e.ent = (e.code & 0x3FFFFFFF) >> 1;
+  } else {
+    const int64_t q = tc - pp.n_codes;
+    const int64_t p = q / 5;
+    const int kk = (int)(q - p * 5);
+    e.p = p;
+    e.sh = a.slot_h[p]; e.st = a.slot_t[p]; e.ph = a.pos_h[p]; e.pt = a.pos_t[p];
+    e.kind = kk == 0 ? EM_KIND_OWN : (kk == 1 ? EM_KIND_GV_H : (kk == 2 ? EM_KIND_GV_T : (kk == 3 ? EM_KIND_REL_H : EM_KIND_REL_T)));
+    const int own_ent = e.sh >= 0 ? e.pt : e.ph;       // own term: the owner of t when HR travels, else the owner of h
+    const int head_ent = e.sh >= 0 ? e.ph : -1;        // the owner of the head receives sum dL/dHR: head row and relation row
+    const int tail_ent = e.st >= 0 ? e.pt : -1;        // the owner of the tail receives sum dL/dRT: tail row and relation row
+    e.ent = kk == 0 ? own_ent : ((kk == 1 || kk == 3) ? head_ent : tail_ent);
+  }
   if (!in) e.ent = -1;
   return e;
+}
+// an OWNED negative's position, index in its group, and the positive's slots / ids
+__device__ __forceinline__ void em_locate(const EmPlanParams& pp, int64_t t, EmElem& e) {
+  if (e.kind >= 0) return;
+  const mke_oc_em_plan_args& a = pp.a;
+  const int N = a.neg_per_pos;
+  const int64_t p = pp.n_codes <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)t * pp.n_magic) >> 40) : t / N;
+  e.p = p;
+  e.kind = (int)(t - p * N);
+  e.sh = a.slot_h[p]; e.st = a.slot_t[p]; e.ph = a.pos_h[p]; e.pt = a.pos_t[p];
 }
 __device__ __forceinline__ bool em_owned(const EmPlanParams& pp, const EmElem& e) {
   if (e.ent < 0) return false;
@@ -94,7 +120,7 @@ __device__ __forceinline__ bool em_owned(const EmPlanParams& pp, const EmElem& e
 // (key, descriptor) at the range's offset + ballot rank — no cursor atomic (a returning atomic on one address costs ~12 ns:
 // one per 64 elements was 5.2 ms of a 6.2 ms plan at the C2 shape with 8 ranks), and the list comes out in element order.
 __global__ __launch_bounds__(MKE_BLOCK) void k_em_count(const EmPlanParams pp) {
-  const int64_t total = pp.a.n_all * (int64_t)pp.ep;
+  const int64_t total = pp.total;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   if (wave >= pp.n_waves) return;
@@ -103,7 +129,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_count(const EmPlanParams pp) {
   for (int64_t t = t0 + lane; t - lane < t1; t += 64 * EM_U) {
     EmElem e[EM_U];
 #pragma unroll
-    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total, total);
+    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total);
 #pragma unroll
     for (int u = 0; u < EM_U; ++u) cnt += em_owned(pp, e[u]) ? 1 : 0;
   }
@@ -144,7 +170,7 @@ __device__ __forceinline__ uint2 em_ref_of(const EmPlanParams& pp, const EmElem&
 template <typename KEY>
 __global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KEY* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ refs_unsorted) {
   const mke_oc_em_plan_args& a = pp.a;
-  const int64_t total = a.n_all * (int64_t)pp.ep;
+  const int64_t total = pp.total;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   if (wave >= pp.n_waves) return;
@@ -152,22 +178,35 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KE
   const int64_t t0 = wave * pp.per, t1 = t0 + pp.per < total ? t0 + pp.per : total;
   if (t0 >= total) return;                                  // wave-uniform
   int64_t base = pp.wave_off[wave];
-  int s_cur = em_step_of(a.step_lo, a.n_steps, total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)t0 * pp.ep_magic) >> 40) : t0 / pp.ep);   // wave-uniform
+  const int N = a.neg_per_pos;
+  // position of element t (both regions walk the positions in ascending order; the one wavefront whose range holds the seam
+  // between them searches again there)
+  auto pos_of = [&](int64_t t) -> int64_t {
+    if (t < pp.n_codes) return pp.n_codes <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)t * pp.n_magic) >> 40) : t / N;
+    return (t - pp.n_codes) / 5;
+  };
+  int s_cur = em_step_of(a.step_lo, a.n_steps, pos_of(t0));   // wave-uniform
   const int G = a.n_ranks;
   for (int64_t t = t0 + lane; t - lane < t1; t += 64 * EM_U) {     // wave-uniform trip count (ballots inside)
     EmElem e[EM_U];
 #pragma unroll
-    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total, total);
-    {   // the step of the round's first element: every lane's position is at or after it
+    for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total);
+    {   // the step of the round's first element: every lane's position is at or after it — except across the seam
       const int64_t tf = t - lane;
-      const int64_t pf = total <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)tf * pp.ep_magic) >> 40) : tf / pp.ep;
-      while (s_cur + 1 < a.n_steps && a.step_lo[s_cur + 1] <= pf) ++s_cur;
+      const int64_t pf = pos_of(tf);
+      if (tf < pp.n_codes && tf + 64 * EM_U > pp.n_codes) {
+        s_cur = 0;                   // the round holds the seam (its second part restarts at position 0): every element advances from step 0
+      } else {
+        if (a.step_lo[s_cur] > pf) s_cur = em_step_of(a.step_lo, a.n_steps, pf);     // first round after the seam
+        while (s_cur + 1 < a.n_steps && a.step_lo[s_cur + 1] <= pf) ++s_cur;
+      }
     }
 #pragma unroll
     for (int u = 0; u < EM_U; ++u) {
       const bool mine = em_owned(pp, e[u]);
       const uint64_t m = __ballot(mine);
       if (mine) {
+        em_locate(pp, t + 64 * u, e[u]);
         int s = s_cur;                                      // a step at or before the element's: a short linear advance
         while (s + 1 < a.n_steps && a.step_lo[s + 1] <= e[u].p) ++s;
         const uint64_t row = e[u].kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[e[u].p]
@@ -547,6 +586,9 @@ extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
   pp.a = a;
   pp.ep = (uint32_t)a.neg_per_pos + 5u;
   pp.ep_magic = ((1ull << 40) + pp.ep - 1) / pp.ep;
+  pp.n_codes = a.n_all * (int64_t)a.neg_per_pos;
+  pp.n_magic = a.neg_per_pos > 0 ? ((1ull << 40) + a.neg_per_pos - 1) / a.neg_per_pos : 0;
+  pp.total = pp.n_codes + 5 * a.n_all;
   pp.g_shift = (a.n_ranks & (a.n_ranks - 1)) == 0 ? __builtin_ctz((unsigned)a.n_ranks) : -1;
   pp.rows_tot = a.n_local + a.n_rel;
   const int64_t total = a.n_all * (int64_t)pp.ep;

@@ -999,8 +999,11 @@ class OwnerComputesTrainer:
         upper = max(1, self._n_all * (N + 5))                          # every element of every positive
         if capacity is None:
             capacity = self._em_capacity.get(bs, 0)
-            if not capacity:                                           # 1 / G of the epoch's references + slack (uniform corruptions)
-                capacity = upper if G == 1 else min(upper, int(1.25 * self._n_all * (N + 3) / G) + 4096)
+            if not capacity:
+                # 1 / G of the epoch's references + 6 % + 4,096: the sort, the gather and the row walks run over the CAPACITY (the unused
+                # tail is sentinels), so slack is paid every epoch — uniform corruptions put a rank within 0.1 % of its share, hub
+                # entities move only the five non-negative elements of a position; a rank that owns more re-plans once at the exact size
+                capacity = upper if G == 1 else min(upper, int(1.06 * self._n_all * (N + 3) / G) + 4096)
         self._em_capacity[bs] = capacity
         bufs = self._em_buffers(bs, capacity)
         self.backend.em_plan(self, ph, pr, pt, codes, slot, bufs)
