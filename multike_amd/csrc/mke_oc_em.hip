@@ -167,56 +167,74 @@ __device__ __forceinline__ uint2 em_ref_of(const EmPlanParams& pp, const EmElem&
   return make_uint2(loc, cidx);
 }
 
+// The owned elements of a round are an eighth of its lanes at 8 ranks, and what an owned element needs (its position, the
+// positive's slots and ids, its step, key and reference) is ~100 instructions and five dependent loads: done under `if (mine)` the whole
+// wavefront pays for them in nearly every round.  The rounds therefore only QUEUE the owned element indices (ballot-compacted, in
+// order, in the wavefront's own LDS strip), and whenever 64 are waiting all 64 lanes take one each — the same output order.
+__device__ __forceinline__ void em_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename KEY>
+__device__ __forceinline__ void em_emit(const EmPlanParams& pp, int64_t t, int64_t k, int& s_hint, KEY* __restrict__ keys, uint32_t* __restrict__ vals,
+                                        uint2* __restrict__ refs_unsorted) {
+  const mke_oc_em_plan_args& a = pp.a;
+  const int G = a.n_ranks;
+  EmElem e = em_elem_of(pp, t);
+  em_locate(pp, t, e);
+  int s = s_hint;                                           // a step at or before the element's, or anything after the seam
+  if (a.step_lo[s] > e.p) s = em_step_of(a.step_lo, a.n_steps, e.p);
+  while (s + 1 < a.n_steps && a.step_lo[s + 1] <= e.p) ++s;
+  s_hint = s;
+  const uint64_t row = e.kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[e.p]
+                                               : (uint64_t)(pp.g_shift >= 0 ? (uint32_t)e.ent >> pp.g_shift : (uint32_t)e.ent / (uint32_t)G);
+  const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
+  if (k < a.capacity) { keys[k] = (KEY)srow; vals[k] = (uint32_t)k; refs_unsorted[k] = em_ref_of(pp, e, s, e.p - a.step_lo[s]); }
+}
+
 template <typename KEY>
 __global__ __launch_bounds__(MKE_BLOCK) void k_em_fill(const EmPlanParams pp, KEY* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ refs_unsorted) {
   const mke_oc_em_plan_args& a = pp.a;
+  __shared__ int64_t s_q[MKE_BLOCK / 64][128];              // per wavefront: owned element indices waiting for their turn
   const int64_t total = pp.total;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 6;
   if (wave >= pp.n_waves) return;
   if (wave == 0 && lane == 0) a.n_refs[0] = pp.wave_off[pp.n_waves];
   const int64_t t0 = wave * pp.per, t1 = t0 + pp.per < total ? t0 + pp.per : total;
   if (t0 >= total) return;                                  // wave-uniform
   int64_t base = pp.wave_off[wave];
-  const int N = a.neg_per_pos;
-  // position of element t (both regions walk the positions in ascending order; the one wavefront whose range holds the seam
-  // between them searches again there)
-  auto pos_of = [&](int64_t t) -> int64_t {
-    if (t < pp.n_codes) return pp.n_codes <= 0xFFFFFFFFll ? (int64_t)(((uint64_t)(uint32_t)t * pp.n_magic) >> 40) : t / N;
-    return (t - pp.n_codes) / 5;
-  };
-  int s_cur = em_step_of(a.step_lo, a.n_steps, pos_of(t0));   // wave-uniform
-  const int G = a.n_ranks;
+  int qn = 0;                                               // wave-uniform: elements waiting
+  int s_hint = 0;                                           // per lane: the step of the last element this lane emitted
+  int64_t* q = s_q[wv];
   for (int64_t t = t0 + lane; t - lane < t1; t += 64 * EM_U) {     // wave-uniform trip count (ballots inside)
     EmElem e[EM_U];
 #pragma unroll
     for (int u = 0; u < EM_U; ++u) e[u] = em_elem_of(pp, t + 64 * u < t1 ? t + 64 * u : total);
-    {   // the step of the round's first element: every lane's position is at or after it — except across the seam
-      const int64_t tf = t - lane;
-      const int64_t pf = pos_of(tf);
-      if (tf < pp.n_codes && tf + 64 * EM_U > pp.n_codes) {
-        s_cur = 0;                   // the round holds the seam (its second part restarts at position 0): every element advances from step 0
-      } else {
-        if (a.step_lo[s_cur] > pf) s_cur = em_step_of(a.step_lo, a.n_steps, pf);     // first round after the seam
-        while (s_cur + 1 < a.n_steps && a.step_lo[s_cur + 1] <= pf) ++s_cur;
-      }
-    }
 #pragma unroll
     for (int u = 0; u < EM_U; ++u) {
       const bool mine = em_owned(pp, e[u]);
       const uint64_t m = __ballot(mine);
-      if (mine) {
-        em_locate(pp, t + 64 * u, e[u]);
-        int s = s_cur;                                      // a step at or before the element's: a short linear advance
-        while (s + 1 < a.n_steps && a.step_lo[s + 1] <= e[u].p) ++s;
-        const uint64_t row = e[u].kind >= EM_KIND_REL_H ? (uint64_t)a.n_local + (uint32_t)a.pos_r[e[u].p]
-                                                        : (uint64_t)(pp.g_shift >= 0 ? (uint32_t)e[u].ent >> pp.g_shift : (uint32_t)e[u].ent / (uint32_t)G);
-        const uint64_t srow = (uint64_t)s * (uint64_t)pp.rows_tot + row;
-        const int64_t k = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (k < a.capacity) { keys[k] = (KEY)srow; vals[k] = (uint32_t)k; refs_unsorted[k] = em_ref_of(pp, e[u], s, e[u].p - a.step_lo[s]); }
+      if (mine) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = t + 64 * u;
+      qn += __popcll(m);
+      if (qn >= 64) {                                       // wave-uniform
+        em_wave_lds_sync();
+        const int64_t tq = q[lane];
+        const int64_t spill = lane + 64 < qn ? q[lane + 64] : 0;
+        em_emit<KEY>(pp, tq, base + lane, s_hint, keys, vals, refs_unsorted);
+        em_wave_lds_sync();
+        if (lane + 64 < qn) q[lane] = spill;              // at most 63 stay behind
+        base += 64;
+        qn -= 64;
+        em_wave_lds_sync();
       }
-      base += __popcll(m);
     }
+  }
+  if (qn > 0) {
+    em_wave_lds_sync();
+    if (lane < qn) em_emit<KEY>(pp, q[lane], base + lane, s_hint, keys, vals, refs_unsorted);
   }
 }
 
