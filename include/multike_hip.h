@@ -871,6 +871,10 @@ typedef struct mke_oc_step {
    * (em_part0 = the plan's step_part0 of this step; the buffer holds the step's slots only); mke_oc_pass2 adds a combine launch
    * when em_n_long > 0. */
   const int32_t* em_part; const int32_t* em_long_rows; const int32_t* em_long_part0; int64_t em_n_long; int64_t em_part0; float* em_partials;
+  /* which work items a mke_oc_pass2 call takes: 0 all; 1 those WITHOUT a gradient-vector reference (bit 30 of the plan's item_row
+   * clear: they need only the coefficients and the all-gathered vectors, so they may run while the step's reduce-scatter is on the
+   * wire); 2 those with one (after the reduce-scatter), followed by the long rows' combine launch. */
+  int em_mode;
   const mke_tuning* tuning;   /* version 105: host pointer, NULL = the process defaults */
 } mke_oc_step;
 #define MKE_OC_EM_MAX_CHUNKS 4
@@ -935,7 +939,8 @@ typedef struct mke_oc_em_plan_args {
    * a segment of a LONG row — more than one segment), item_off[w] = its first reference (item_off[w + 1] ends it), item_part[w]
    * = the partial slot a long row's segment writes (-1: the item finishes its row); long_row[l] / long_part0[l] = the long rows
    * and their first partial slot (long_part0[l + 1] ends them); step_item0 / step_long0 / step_part0[s] = first item / long row /
-   * partial slot of global step s (n_steps + 1 entries each).  item_* : capacity + 1 ints each; long_*: capacity / 32 + 2. */
+   * partial slot of global step s (n_steps + 1 entries each).  item_* : capacity + 1 ints each; long_*: capacity / 32 + 2.  Bit 30 of
+   * item_row[w]: the item's references include a gradient vector (mke_oc_step.em_mode). */
   int32_t* item_row; int32_t* item_off; int32_t* item_part; int32_t* long_row; int32_t* long_part0;
   int64_t* step_item0; int64_t* step_long0; int64_t* step_part0;
   void* temp; int64_t temp_bytes;
@@ -973,6 +978,8 @@ typedef struct mke_oc_loop {
   int chunks; float* send[4]; float* v_all[4]; float* g_all[4]; float* gv[4]; int64_t block_floats;
   double* loss_ring; int64_t loss_stride; int32_t tag_base;
   const mke_oc_comm* comm; void* comm_stream;
+  int overlap_rs;   /* entity-major steps with one part and a comm_stream: the reduce-scatter goes to comm_stream and the work items
+                       without gradient-vector references (em_mode 1) run under it; the rest (em_mode 2) after it */
 } mke_oc_loop;
 int mke_oc_steps(const mke_oc_loop* loop, int step_begin, int step_end, void* stream);
 

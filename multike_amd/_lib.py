@@ -112,7 +112,7 @@ class OcStepStruct(C.Structure):
                 ("em_n_rows", C.c_int64), ("em_chunks", C.c_int), ("em_block_floats", C.c_int64), ("em_v", C.c_void_p * 4),
                 ("em_gv", C.c_void_p * 4),
                 ("em_part", C.c_void_p), ("em_long_rows", C.c_void_p), ("em_long_part0", C.c_void_p), ("em_n_long", C.c_int64),
-                ("em_part0", C.c_int64), ("em_partials", C.c_void_p), ("tuning", C.c_void_p)]
+                ("em_part0", C.c_int64), ("em_partials", C.c_void_p), ("em_mode", C.c_int), ("tuning", C.c_void_p)]
 
 
 TUNE_DEFAULT = -2
@@ -173,7 +173,8 @@ class OcLoopStruct(C.Structure):
     """mke_oc_loop"""
     _fields_ = [("parts", C.c_void_p), ("step_part0", C.c_void_p), ("n_steps", C.c_int), ("chunks", C.c_int),
                 ("send", C.c_void_p * 4), ("v_all", C.c_void_p * 4), ("g_all", C.c_void_p * 4), ("gv", C.c_void_p * 4), ("block_floats", C.c_int64),
-                ("loss_ring", C.c_void_p), ("loss_stride", C.c_int64), ("tag_base", C.c_int32), ("comm", C.c_void_p), ("comm_stream", C.c_void_p)]
+                ("loss_ring", C.c_void_p), ("loss_stride", C.c_int64), ("tag_base", C.c_int32), ("comm", C.c_void_p), ("comm_stream", C.c_void_p),
+                ("overlap_rs", C.c_int)]
 
 
 class AEPlanStruct(C.Structure):

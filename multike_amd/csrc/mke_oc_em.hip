@@ -324,6 +324,23 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_items(const EmItemParams p) {
   if (lng) { p.long_row[p.lidx[u]] = p.rows_u[u]; p.long_part0[p.lidx[u]] = p.part0[u]; }
 }
 
+// bit 30 of item_row: the item's references include a gradient vector (gv) — it can only run after the step's reduce-scatter; the
+// others (at 8 ranks: ~95 % of the rows, the corrupt entities of negatives) need only the coefficients and the all-gathered vectors
+// and may run WHILE the reduce-scatter is on the wire (mke_oc_step.em_mode)
+#define EM_ITEM_SEG 0x80000000u
+#define EM_ITEM_GV 0x40000000u
+#define EM_ITEM_ROW 0x3FFFFFFFu
+__global__ __launch_bounds__(MKE_BLOCK) void k_em_item_flags(const EmItemParams p, const uint32_t* __restrict__ refs) {
+  const int64_t w = (int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x;
+  const int64_t U = p.step_row0[p.n_steps];
+  const int64_t W = p.itemoff[U];
+  if (w >= W) return;
+  const int lo = p.item_off[w], hi = p.item_off[w + 1];
+  bool gv = false;
+  for (int k = lo; k < hi; ++k) gv = gv || (refs[2 * (int64_t)k] & EM_LOC_GV) != 0;
+  if (gv) p.item_row[w] |= (int32_t)EM_ITEM_GV;
+}
+
 static inline int bits_for(uint64_t v) {   // smallest b with v < 2^b
   int b = 0;
   while (b < 64 && (v >> b)) ++b;
@@ -386,7 +403,9 @@ static int em_plan_sorted(const EmPlanParams& pp, int key_bits, hipStream_t st) 
     if ((e = hipcub::DeviceScan::ExclusiveSum(a.temp, tb, ins[k], outs[k], nu, st)) != hipSuccess) { set_error("mke_oc_em_plan: scan: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(k_em_items, ugrid, dim3(MKE_BLOCK), 0, st, ip);
-  return check_launch("k_em_items");
+  if ((rc = check_launch("k_em_items"))) return rc;
+  hipLaunchKernelGGL(k_em_item_flags, grid, dim3(MKE_BLOCK), 0, st, ip, (const uint32_t*)a.refs);     // at most one item per reference
+  return check_launch("k_em_item_flags");
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------------------------------
@@ -432,10 +451,13 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_oc_em_pass2(const mke_oc_step s) 
   constexpr int U = FPL <= 8 ? 4 : 2;            // vectors in flight per quarter-wave
   const int lane = threadIdx.x & 63, j = lane & 15, qb = lane & 48;
   const int64_t u = ((int64_t)blockIdx.x * MKE_BLOCK + threadIdx.x) >> 4;
-  const bool act = u < s.em_n_rows;
-  const int rowf = act ? s.em_rows[u] : 0;
-  const bool seg = rowf < 0;                     // bit 31: a segment of a long row — leaves a partial sum, does not touch the row
-  const int row = rowf & 0x7FFFFFFF;
+  bool act = u < s.em_n_rows;
+  const uint32_t rowf = act ? (uint32_t)s.em_rows[u] : 0u;
+  const bool seg = (rowf & EM_ITEM_SEG) != 0;    // bit 31: a segment of a long row — leaves a partial sum, does not touch the row
+  // em_mode 1: only the items WITHOUT gradient-vector references (they may run while the reduce-scatter is on the wire), 2: only
+  // those with (after it); 0: all
+  if ((s.em_mode == 1 && (rowf & EM_ITEM_GV)) || (s.em_mode == 2 && !(rowf & EM_ITEM_GV))) act = false;
+  const int row = (int)(rowf & EM_ITEM_ROW);
   const int lo = act ? s.em_off[u] : 0, hi = act ? s.em_off[u + 1] : 0;
   // rows [n_local, n_local + n_rel) are the (replicated) relation table's: this rank's PARTIAL gradient — the sum of the gradient
   // vectors of its owned slots — is stored (not added: one writer per row and step) for the all-reduce and the relation update
@@ -640,7 +662,7 @@ extern "C" int mke_oc_pass2(const mke_oc_step* s, void* stream) {
   if (s->em_n_long < 0 || (s->em_n_long > 0 && (!s->em_part || !s->em_long_rows || !s->em_long_part0 || !s->em_partials))) { set_error("mke_oc_pass2: long rows without their lists / partial buffer"); return MKE_E_NULL; }
   MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_em_pass2<FPL>), grid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, *s); });
   int rc = check_launch("k_oc_em_pass2");
-  if (rc || s->em_n_long == 0) return rc;
+  if (rc || s->em_n_long == 0 || s->em_mode == 1) return rc;     // the long rows are combined after the LAST pass-2 launch of the step
   const dim3 lgrid((unsigned)((s->em_n_long + MKE_SUBS_PER_BLOCK - 1) / MKE_SUBS_PER_BLOCK));
   MKE_DISPATCH_FPL(fpl, { hipLaunchKernelGGL((k_oc_em_combine<FPL>), lgrid, dim3(MKE_BLOCK), 0, (hipStream_t)stream, *s); });
   return check_launch("k_oc_em_combine");

@@ -128,6 +128,11 @@ extern "C" int mke_oc_steps(const mke_oc_loop* lp, int step_begin, int step_end,
   // events of the pipelined schedule: [c][0] bases done, [c][1] all-gather done, [c][2] score done, [c][3] reduce-scatter done
   hipEvent_t ev[MKE_OC_EM_MAX_CHUNKS][4] = {};
   const bool may_pipeline = cm && lp->chunks > 1 && commS && commS != mainS;
+  // one part per step, entity-major: the reduce-scatter on the communication stream, the work items that do not need its result
+  // under it (two stream hops per step: worth it when the reduce-scatter is long — the caller decides, mke_oc_loop.overlap_rs)
+  const bool may_overlap_rs = cm && lp->overlap_rs && commS && commS != mainS;
+  hipEvent_t evo[2] = {};
+  if (may_overlap_rs) { for (int k = 0; k < 2; ++k) RUN_HIP(hipEventCreateWithFlags(&evo[k], hipEventDisableTiming)); }
   if (may_pipeline) {
     for (int c = 0; c < lp->chunks; ++c)
       for (int k = 0; k < 4; ++k) RUN_HIP(hipEventCreateWithFlags(&ev[c][k], hipEventDisableTiming));
@@ -152,6 +157,7 @@ extern "C" int mke_oc_steps(const mke_oc_loop* lp, int step_begin, int step_end,
       continue;
     }
     const bool pipe = may_pipeline && np > 1;
+    const bool ors = may_overlap_rs && em && np == 1 && !pipe;
     // the vectors of every part (the atomics form counts the whole step's references on rider blocks of the same launches:
     // complete before any part is scored), all-gathered
     for (int c = 0; c < np; ++c) {
@@ -174,12 +180,26 @@ extern "C" int mke_oc_steps(const mke_oc_loop* lp, int step_begin, int step_end,
         RUN_HIP(hipStreamWaitEvent(commS, ev[c][2], 0));
         RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, commS));
         RUN_HIP(hipEventRecord(ev[c][3], commS));
+      } else if (ors) {
+        RUN_HIP(hipEventRecord(evo[0], mainS));
+        RUN_HIP(hipStreamWaitEvent(commS, evo[0], 0));
+        RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, commS));
+        RUN_HIP(hipEventRecord(evo[1], commS));
       } else {
         RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, mainS));
       }
     }
     if (pipe) for (int c = 0; c < np; ++c) RUN_HIP(hipStreamWaitEvent(mainS, ev[c][3], 0));
-    if (em) {
+    if (em && ors) {
+      // (the reduce-scatter was enqueued on the communication stream above) the items without gradient-vector references now, the
+      // rest — and the long rows' combine — after it
+      part[0].em_mode = 1;
+      RUN_MKE(mke_oc_run(&part[0], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
+      RUN_HIP(hipStreamWaitEvent(mainS, evo[1], 0));
+      part[0].em_mode = 2;
+      RUN_MKE(mke_oc_run(&part[0], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
+      part[0].em_mode = 0;
+    } else if (em) {
       RUN_MKE(mke_oc_run(&part[np - 1], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
     } else {
       for (int c = 0; c < np; ++c) RUN_MKE(mke_oc_run(&part[c], MKE_OC_APPLY, lp->send[c], lp->v_all[c], lp->block_floats, lp->g_all[c], lp->gv[c], lossp[c], mainS));
@@ -196,5 +216,7 @@ done:
       for (int k = 0; k < 4; ++k)
         if (ev[c][k]) (void)hipEventDestroy(ev[c][k]);
   }
+  for (int k = 0; k < 2; ++k)
+    if (evo[k]) (void)hipEventDestroy(evo[k]);
   return rc;
 }

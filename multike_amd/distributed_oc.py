@@ -245,13 +245,14 @@ class OcHipBackend:
         lp.loss_ring, lp.loss_stride = self._ring, tr.loss_ring.shape[1]
         self._loop = lp
 
-    def run_steps(self, tr, s0, s1, tag_base, comm_struct, comm_stream):
+    def run_steps(self, tr, s0, s1, tag_base, comm_struct, comm_stream, overlap_rs=False):
         """Global steps [s0, s1) of the current epoch in ONE native call (mke_oc_steps): kernels, collectives and — with several
         parts per step — the two-stream pipeline are enqueued from C++."""
         lp = self._loop
         lp.tag_base = tag_base
         lp.comm = C.addressof(comm_struct) if comm_struct is not None else None
         lp.comm_stream = comm_stream
+        lp.overlap_rs = int(bool(overlap_rs))
         _lib.oc_steps(lp, s0, s1)
 
     def bases(self, tr, st, send):
@@ -1227,6 +1228,21 @@ class OwnerComputesTrainer:
             self._comm_native, self._comm_native_key = self.comm.native(self), key
         return True, self._comm_native
 
+    OVERLAP_RS_MIN_BYTES = 16 << 20
+
+    def _overlap_rs(self) -> bool:
+        """Entity-major, one part per step: put the reduce-scatter on the communication stream and run, under it, the second pass's
+        work items that do not need its result (at 8 ranks ~95 % of the rows: the corrupt entities) — two stream hops per step
+        (~26 us), so only when the reduce-scatter is long: >= 16 MB received per rank (the C5 shape at 8 ranks: 40 MB = 122 us in the
+        link model; C2: 12 MB = 48 us, not worth the hops).  MKE_OC_OVERLAP_RS=0 / 1 forces it."""
+        import os
+        if not self.em or self.chunks != 1 or self.world < 2 and not self.force_collectives:
+            return False
+        env = os.environ.get("MKE_OC_OVERLAP_RS")
+        if env is not None:
+            return env == "1"
+        return (self.world - 1) * 2 * self.C * self.stride * 4 >= self.OVERLAP_RS_MIN_BYTES
+
     def run(self, i0: int, n: int):
         """Global steps i0 .. i0 + n - 1 (in order): one native call per run of steps inside an epoch (mke_oc_steps) when the
         communicator has a native form, else the Python step loop."""
@@ -1251,11 +1267,12 @@ class OwnerComputesTrainer:
                 m = k - s                                    # stop at the epoch's gather point: the collective goes between two steps
             ok, cs = self._native_loop()                     # the exchange buffers may have grown with the new epoch's plan
             comm_stream = None
-            if cs is not None and self.chunks > 1 and self.device.type == "cuda":
+            overlap = self._overlap_rs() if cs is not None else False
+            if cs is not None and (self.chunks > 1 or overlap) and self.device.type == "cuda":
                 if getattr(self, "_comm_stream", None) is None:
                     self._comm_stream = torch.cuda.Stream(device=self.device)
                 comm_stream = self._comm_stream.cuda_stream
-            self.backend.run_steps(self, s, s + m, self.tag, cs, comm_stream)
+            self.backend.run_steps(self, s, s + m, self.tag, cs, comm_stream, overlap)
             self.tag += m
             i += m
             self._stepped = i - 1

@@ -294,6 +294,8 @@ def _two_rank_worker(rank, world, port, ret, chunks, steps, peer=False, neg=NEG,
     try:
         from multike_amd.distributed_oc import OcHostStagedComm
         torch.cuda.set_device(0)
+        if native == "overlap":         # the reduce-scatter on the communication stream, the second pass's gv-free work items under it
+            os.environ["MKE_OC_OVERLAP_RS"] = "1"
         tr = _make(rank, world, comm=OcHostStagedComm(), chunks=chunks, peer=peer, neg=neg, em=em)
         if native:                      # mke_oc_steps: the schedule (two streams when chunks > 1) enqueued from C++, collectives by callback
             assert tr._native_loop()[0]
@@ -342,7 +344,8 @@ def test_two_ranks_on_one_gpu_equal_dense_oracle(chunks, peer, neg, em, native):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,chunks,em,native", [(8, 1, True, True), (8, 2, True, True), (8, 1, False, False), (5, 2, True, True), (8, 1, True, False)])
+@pytest.mark.parametrize("world,chunks,em,native", [(8, 1, True, True), (8, 2, True, True), (8, 1, False, False), (5, 2, True, True), (8, 1, True, False),
+                                                    (8, 1, True, "overlap"), (3, 1, True, "overlap")])
 def test_eight_ranks_on_one_gpu_equal_dense_oracle(world, chunks, em, native):
     """world_size 8 — the size the multi-GPU bench runs at: owner = id & 7 (the shift / mask instantiation of the score kernels
     and of the plan walks), 2,400 positives per global step, each rank scoring the eighth of the negatives it owns, entity-major
@@ -395,12 +398,14 @@ def test_one_rank_rccl_collectives_run():
         dist.destroy_process_group()
 
 
-def _rccl_native_worker(ret, chunks, em):
+def _rccl_native_worker(ret, chunks, em, overlap=False):
     """(spawned: MKE_OC_FORCE_COLLECTIVES is read when the trainer is built, and a process has one default process group)"""
     import tempfile
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MKE_OC_FORCE_COLLECTIVES"] = "1"
+    if overlap:
+        os.environ["MKE_OC_OVERLAP_RS"] = "1"
     dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
@@ -418,15 +423,16 @@ def _rccl_native_worker(ret, chunks, em):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks,em", [(1, True), (2, True), (1, False)])
-def test_native_step_loop_over_rccl_entry_points(chunks, em):
+@pytest.mark.parametrize("chunks,em,overlap", [(1, True, False), (2, True, False), (1, False, False), (1, True, True)])
+def test_native_step_loop_over_rccl_entry_points(chunks, em, overlap):
     """mke_oc_steps with `mke_oc_comm` of kind NCCL: the library calls ncclAllGather / ncclReduceScatter / ncclAllReduce through the
     addresses the host side hands over (a real one-rank RCCL communicator, the G > 1 path forced: all three collectives of every
-    step are issued for real; chunks 2: on the second stream, ordered by the call's events) — against the float64 dense oracle."""
+    step are issued for real; chunks 2: on the second stream, ordered by the call's events; overlap: the reduce-scatter on the second
+    stream with the second pass's gradient-vector-free work items under it) — against the float64 dense oracle."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    p = ctx.Process(target=_rccl_native_worker, args=(ret, chunks, em))
+    p = ctx.Process(target=_rccl_native_worker, args=(ret, chunks, em, overlap))
     p.start()
     kind, loss, full, rel, clean, steps = ret.get(timeout=500)
     p.join(120)
