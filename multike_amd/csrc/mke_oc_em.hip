@@ -336,7 +336,7 @@ __global__ __launch_bounds__(MKE_BLOCK) void k_em_item_flags(const EmItemParams 
   const int64_t W = p.itemoff[U];
   if (w >= W) return;
   const int lo = p.item_off[w], hi = p.item_off[w + 1];
-  bool gv = false;
+  bool gv = ((uint32_t)p.item_row[w] & EM_ITEM_SEG) != 0;      // a long row's segments wait too: their combine follows the flagged items
   for (int k = lo; k < hi; ++k) gv = gv || (refs[2 * (int64_t)k] & EM_LOC_GV) != 0;
   if (gv) p.item_row[w] |= (int32_t)EM_ITEM_GV;
 }

@@ -181,21 +181,23 @@ extern "C" int mke_oc_steps(const mke_oc_loop* lp, int step_begin, int step_end,
         RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, commS));
         RUN_HIP(hipEventRecord(ev[c][3], commS));
       } else if (ors) {
+        // the second pass's work items that read no gradient vector go to the OTHER stream right behind the scoring; this stream
+        // carries on with the reduce-scatter, the rest of the second pass, the relation gradient's all-reduce and the relation
+        // update — 170 us of mostly wire at the C5 shape for the 155 us of rows to hide under — and joins before the next step
         RUN_HIP(hipEventRecord(evo[0], mainS));
         RUN_HIP(hipStreamWaitEvent(commS, evo[0], 0));
-        RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, commS));
+        part[0].em_mode = 1;
+        RUN_MKE(mke_oc_run(&part[0], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], commS));
         RUN_HIP(hipEventRecord(evo[1], commS));
+        RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, mainS));
       } else {
         RUN_MKE(comm_reduce_scatter(cm, lp->g_all[c], lp->gv[c], gvn, mainS));
       }
     }
     if (pipe) for (int c = 0; c < np; ++c) RUN_HIP(hipStreamWaitEvent(mainS, ev[c][3], 0));
     if (em && ors) {
-      // (the reduce-scatter was enqueued on the communication stream above) the items without gradient-vector references now, the
-      // rest — and the long rows' combine — after it
-      part[0].em_mode = 1;
-      RUN_MKE(mke_oc_run(&part[0], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
-      RUN_HIP(hipStreamWaitEvent(mainS, evo[1], 0));
+      // (the gradient-vector-free items are on the other stream, above) the rest — the owned heads / tails, the relation rows, every
+      // segment of a long row — and the long rows' combine here, after the reduce-scatter
       part[0].em_mode = 2;
       RUN_MKE(mke_oc_run(&part[0], MKE_OC_PASS2, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
       part[0].em_mode = 0;
@@ -207,6 +209,7 @@ extern "C" int mke_oc_steps(const mke_oc_loop* lp, int step_begin, int step_end,
     // the replicated relation table: all-reduce of the (small) dense gradient, one update
     RUN_MKE(comm_all_reduce(cm, part[0].rel_grad, (int64_t)part[0].rel_grad_copies * part[0].n_rel * part[0].stride, mainS));
     RUN_MKE(mke_oc_run(&part[np - 1], MKE_OC_UPDATE, lp->send[0], lp->v_all[0], lp->block_floats, lp->g_all[0], lp->gv[0], lossp[0], mainS));
+    if (ors) RUN_HIP(hipStreamWaitEvent(mainS, evo[1], 0));      // the rows finished on the other stream, before the next step reads any
   }
 done:
   if (may_pipeline) {

@@ -93,7 +93,7 @@ def test_sharded_line_one_rank():
     assert d["rccl"]["world"] == 1 and d["rccl"]["backend"].startswith("nccl")      # a real one-rank RCCL group
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(1000)
 @pytest.mark.parametrize("gpus", [2, 8])
 def test_bare_multi_gpu_command_launches_itself(gpus):
     """`python bench.py --gpus N` with NO launcher around it (the shape of the driver's N = 1 line): bench.py starts the N
@@ -105,11 +105,11 @@ def test_bare_multi_gpu_command_launches_itself(gpus):
         # N = 8: the contract of the launch (world, every rank reporting, the whole-job aggregate) on a tenth of the C2 shape — eight
         # ranks SHARING one GPU with host-staged collectives took 17 s alone but 120 s up to > 1,100 s at the full shape inside the
         # whole suite (the parent's own GPU context beside the eight); the full shape at N = 2 stays
-        small = ["--n-ent", "20000", "--batch", "500", "--windows", "6", "--prewarm-epochs", "0"] if gpus > 2 else []
+        small = ["--n-ent", "20000", "--batch", "500", "--windows", "3", "--prewarm-epochs", "0"] if gpus > 2 else []
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2"] + small,
-                             capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
-    except subprocess.TimeoutExpired as ex:      # say where it stopped (a hung rank would otherwise cost the suite its whole limit)
-        raise AssertionError(f"bench.py --gpus {gpus} did not finish in 420 s; stderr tail: {(ex.stderr or b'')[-3000:]!r}") from None
+                             capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired as ex:      # say where it stopped (nine processes on a loaded host took 17 s .. 276 s in this round's runs)
+        raise AssertionError(f"bench.py --gpus {gpus} did not finish in 900 s; stderr tail: {(ex.stderr or b'')[-3000:]!r}") from None
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
