@@ -858,7 +858,7 @@ class OwnerComputesTrainer:
         communicator, on the stream the steps run on, at a fixed point of the step sequence (`_gather_at`) — so the ranks issue
         every collective of the job in one order (round 5 issued it from the side stream on a communicator of its own:
         concurrent collectives on two communicators, with nothing ordering them across ranks)."""
-        if "mine" in plan and self.world > 1:
+        if "mine" in plan and (self.world > 1 or self.force_collectives):
             if "sampled" in plan:
                 torch.cuda.current_stream().wait_event(plan["sampled"])
             self.comm.all_gather(plan["codes_all"], plan["mine"])
@@ -902,8 +902,8 @@ class OwnerComputesTrainer:
                     self.backend.sample_at((ph[a:e], pr[a:e], pt[a:e]), self._all_idx[a:e], b.pos_kg[a:e],
                                            b.side1, b.side2, N, b.rng_seed, rng_stream, out)
                     self.backend.pack_codes(ph[a:e], out[0], out[2], N, mine[(a - lo_r) * N:(e - lo_r) * N])
-            if G > 1:
-                plan["codes_all"], plan["mine"] = codes[:G * n_per * N], mine
+            if G > 1 or self.force_collectives:      # (forced at one rank: an in-place all-gather of the whole array)
+                plan["codes_all"], plan["mine"] = codes[:G * n_per * N], mine[:n_per * N]
         plan["codes"], plan["pos"], plan["stage"] = codes, pos, "sampled"
         if dev.type == "cuda":
             plan["sampled"] = torch.cuda.Event()
@@ -1095,7 +1095,8 @@ class OwnerComputesTrainer:
         b = self.bat
         nxt = ((b.epoch + 1) * 2) & 0xFFFFFFFF
         bs = 1 - getattr(self, "_plan_bs", 0)
-        first = self._plan_sample if self.world > 1 else self._compute_plan      # G > 1: the collective waits for `_gather_at`
+        split = self.world > 1 or self.force_collectives
+        first = self._plan_sample if split else self._compute_plan               # G > 1: the collective waits for `_gather_at`
         if self.device.type != "cuda":
             self._next_plan = first(b.stage_next_epoch(), nxt, bs)
             return

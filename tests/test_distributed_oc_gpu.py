@@ -445,6 +445,47 @@ def test_native_step_loop_over_rccl_entry_points(chunks, em, overlap):
     assert clean
 
 
+def _rccl_epoch_worker(ret, forced):
+    import tempfile
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if forced:
+        os.environ["MKE_OC_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="mke_rdv_"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        tr = _make(0, 1, neg=25, em=True)          # prefetch on (the default): the next epoch's plan is staged while this one trains
+        n = 2 * tr.steps + 3
+        tr.run(0, n)
+        torch.cuda.synchronize()
+        ret.put((type(tr.comm).__name__, bool(tr.force_collectives), tr.ent.cpu().numpy(), tr.ent_acc.cpu().numpy(), tr.rel.cpu().numpy(),
+                 tr.loss_ring.cpu().numpy(), n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_step_loop_across_epoch_boundaries_with_prefetch():
+    """Round-5 advice: the G > 1 path over a real RCCL communicator ACROSS epoch boundaries with the plan prefetched — two
+    boundaries here: the step collectives issued by mke_oc_steps, the plans' code all-gather by the host side on the same
+    communicator at its fixed point of the step sequence (at one rank the sampling / gather / lists split is taken only when the
+    collectives are forced: the split plan, its events and the hand-over are exercised).  Every collective is the identity at one
+    rank and the step has no atomics, so the tables, accumulators and losses must equal, BIT FOR BIT, a run without any collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = []
+    for forced in (True, False):
+        ret = ctx.Queue()
+        p = ctx.Process(target=_rccl_epoch_worker, args=(ret, forced))
+        p.start()
+        out.append(ret.get(timeout=500))
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0][0] == "OcRcclComm" and out[0][1] and not out[1][1] and out[0][6] == out[1][6]
+    for a, b in zip(out[0][2:6], out[1][2:6]):
+        assert np.array_equal(a, b)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # cross-KG inference loops on the sharded tables: positives only, `random.sample` batches of a triple list, loss x 2
 # ----------------------------------------------------------------------------------------------------------------------
