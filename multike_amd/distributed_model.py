@@ -153,8 +153,7 @@ class ShardedITC:
         if tr is None:
             return 0.0
         i0 = self._oc_steps[id(tr)]
-        for i in range(i0, i0 + tr.steps):
-            tr.step(i)
+        tr.run(i0, tr.steps)              # one native call per run of steps inside an epoch (mke_oc_steps); the Python step loop otherwise
         self._oc_steps[id(tr)] = i0 + tr.steps
         return tr.epoch_loss()
 
