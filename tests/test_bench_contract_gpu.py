@@ -102,11 +102,12 @@ def test_bare_multi_gpu_command_launches_itself(gpus):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["MKE_BENCH_COMM"] = "staged"
     try:
-        # N = 8: the contract of the launch (world, every rank reporting, the whole-job aggregate) on a tenth of the C2 shape — eight
-        # ranks SHARING one GPU with host-staged collectives took 17 s alone but 120 s up to > 1,100 s at the full shape inside the
-        # whole suite (the parent's own GPU context beside the eight); the full shape at N = 2 stays
-        small = ["--n-ent", "20000", "--batch", "500", "--windows", "3", "--prewarm-epochs", "0"] if gpus > 2 else []
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2"] + small,
+        # N = 8: the contract of the launch (world, every rank reporting, the whole-job aggregate) on a small shape and a dozen steps —
+        # eight ranks SHARING one GPU with host-staged collectives take 5-17 s alone but 120 s up to > 1,100 s inside the whole suite
+        # (nine processes with a GPU context each: every host-staged synchronisation waits its process's turn); the full shape at N = 2 stays
+        small = ["--n-ent", "4000", "--batch", "250", "--windows", "1", "--prewarm-epochs", "0"] if gpus > 2 else []
+        steps = ["--steps", "2", "--warmup", "1"] if gpus > 2 else ["--steps", "6", "--warmup", "2"]
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + steps + small,
                              capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     except subprocess.TimeoutExpired as ex:      # say where it stopped (nine processes on a loaded host took 17 s .. 276 s in this round's runs)
         raise AssertionError(f"bench.py --gpus {gpus} did not finish in 900 s; stderr tail: {(ex.stderr or b'')[-3000:]!r}") from None
