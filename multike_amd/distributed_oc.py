@@ -1407,8 +1407,14 @@ class OwnerComputesTrainer:
     # ------------------------------------------------------------------------------------------------
     def check(self) -> dict:
         """Capacity is fixed per epoch from the data before the epoch runs (`_plan_epoch`): nothing to flag."""
-        return {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks,
-                "vectors_per_positive": self.vectors_planned / max(1, self._n_all)}
+        out = {"capacity_vectors_per_owner": self.C, "block_bytes": self.block * 4, "chunks": self.chunks,
+               "vectors_per_positive": self.vectors_planned / max(1, self._n_all),
+               "entity_major": bool(self.em), "native_step_loop": bool(self._native_loop()[0]),
+               "reduce_scatter_under_second_pass": bool(self._overlap_rs()), "communicator": type(self.comm).__name__}
+        if self.em:
+            out["references_per_global_step"] = self._em["n_refs_host"] / max(1, self.steps)
+            out["long_rows_per_global_step"] = int(self._em["long0_host"][-1]) / max(1, self.steps)
+        return out
 
     def scratch_clean(self) -> bool:
         """The zero invariants between steps: gradient scratch all zero, reference counts all zero (the entity-major form has
