@@ -7,21 +7,25 @@
 // negative) and this file does the rest:
 //   * mke_oc_em_plan (per epoch, table-independent, on the plan's side stream): every reference of every global step to a row
 //     this rank owns — its owned negatives, the positives' own terms it scores, the heads / tails whose gradient vector comes
-//     back by the reduce-scatter, the relation rows' gradient vectors — listed in element order without atomics (count per
-//     wavefront range, prefix sum, fill), STABLY sorted by (step, local row) (hipcub radix sort of 32-bit keys with the
-//     (positive, kind) descriptor as payload: a row's references stay in (positive, kind) order), resolved to (locator,
-//     coefficient index) pairs, with the touched rows of each step and their CSR offsets;
-//   * k_oc_em_pass2 (per global step): a quarter-wave per touched owned row — raw row + accumulator read once, c^ formed once,
-//     ghat = c^ sum coef + sum coef sg V + sum (+-) gv over the row's references in list order, Jacobian of the normalisation,
-//     Adagrad / SGD, row and accumulator written.  No gradient scratch, no touched flags, no reference counts, no atomics;
-//     the summation order per row is the list's: bit-reproducible run to run.
+//     back by the reduce-scatter, the relation rows' gradient vectors — listed in a fixed element order without atomics (the
+//     negatives in code order, then five elements per position; count per wavefront range, prefix sum, fill — the owned
+//     elements queued per wavefront and emitted 64 at a time, each with its (locator, coefficient index) pair), STABLY sorted
+//     by (step, local row) (hipcub radix sort of 32-bit keys, payload = the element's position in the list: a row's references
+//     keep the list's order), gathered into that order; then the touched rows of each step with their offsets, cut into WORK
+//     ITEMS of at most 32 references (a long row's segments leave partial sums), each flagged when it reads a gradient vector;
+//   * k_oc_em_pass2 (per global step): a quarter-wave per work item — raw row + accumulator read once, c^ formed once,
+//     ghat = c^ sum coef + sum coef sg V + sum (+-) gv over the references in list order, Jacobian of the normalisation,
+//     Adagrad / SGD, row and accumulator written (a relation row: this rank's partial gradient stored for the all-reduce);
+//     k_oc_em_combine adds a long row's partials in segment order and finishes it.  No gradient scratch, no touched flags, no
+//     reference counts, no atomics; the summation order per row is the list's: bit-reproducible run to run.  em_mode lets the
+//     loop run the items that read no gradient vector while the step's reduce-scatter is on the wire (mke_oc_loop.hip).
 #include "mke_common.h"
 
 #include <hipcub/hipcub.hpp>
 
 namespace mke {
 
-// kinds of a reference inside its positive (the low 7 bits of the key's descriptor): 0 .. 63 = negative n
+// kinds of a reference inside its positive: 0 .. 63 = negative n
 #define EM_KIND_OWN 64      // the positive's own term, scored on this rank
 #define EM_KIND_GV_H 65     // head row <- + gv[HR slot]
 #define EM_KIND_GV_T 66     // tail row <- - gv[RT slot]
