@@ -51,7 +51,12 @@ def test_golden_loss_and_every_gradient(ci):
                                                     # launch: dim <= 80, a quarter-wave per triple, 1..5 positions per lane),
                                                     # its upper edge, and the first width past it
                                                     (8, 100, 60, 7, 30), (40, 300, 500, 13, 200), (64, 215, 300, 10, 100),
-                                                    (80, 129, 400, 12, 150), (96, 70, 150, 9, 60)])
+                                                    (80, 129, 400, 12, 150),
+                                                    # the widths past the fused launches (separate dense / tail-backward / product
+                                                    # launches; round 6 built the fused form for 80 < dim <= 128 against these
+                                                    # cases, measured it slower and removed it: EXPERIMENTS R6.12)
+                                                    (96, 70, 150, 9, 60), (81, 200, 300, 10, 100), (100, 1000, 2000, 40, 700),
+                                                    (112, 333, 500, 12, 200), (128, 517, 900, 30, 400), (128, 5000, 20000, 300, 8000)])
 def test_three_steps_vs_oracle(d, B, n_ent, n_attr, n_lit):
     """Full step (scatter with duplicate rows, Jacobian + Adagrad on the entity table, plain Adagrad on the raw attribute
     table and on the packed CNN parameters) against the float64 dense oracle."""
