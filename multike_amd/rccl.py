@@ -29,7 +29,20 @@ class RcclError(RuntimeError):
 
 
 class _UniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]
+    _fields_ = [("internal", C.c_ubyte * 128)]     # NOT c_char: reading a c_char array field stops at the first NUL byte
+
+
+def _uid_to_bytes(uid: "_UniqueId") -> bytes:
+    """All 128 bytes of an ncclUniqueId (it holds a socket address: NUL bytes from its second byte on)."""
+    return C.string_at(C.addressof(uid), C.sizeof(uid))
+
+
+def _uid_from_bytes(raw: bytes) -> "_UniqueId":
+    if not isinstance(raw, (bytes, bytearray)) or len(raw) != C.sizeof(_UniqueId):
+        raise RcclError(f"ncclUniqueId: {C.sizeof(_UniqueId)} bytes expected, got {len(raw) if hasattr(raw, '__len__') else type(raw)}")
+    uid = _UniqueId()
+    C.memmove(C.addressof(uid), bytes(raw), C.sizeof(uid))
+    return uid
 
 
 def lib():
@@ -66,11 +79,11 @@ class Communicator:
         box = [None]
         if self.rank == 0:
             _ck(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-            box[0] = bytes(uid.internal)
+            box[0] = _uid_to_bytes(uid)
         if self.world > 1:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
-            C.memmove(C.byref(uid), box[0], 128)
+            uid = _uid_from_bytes(box[0])
         self._comm = C.c_void_p()
         _ck(L.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
 

@@ -5,6 +5,8 @@ result as the torch.distributed communicator and as the path without collectives
 multi-rank logic of the trainer is covered under gloo (tests/test_distributed_oc_cpu.py) and with host-staged ranks sharing
 the GPU (tests/test_distributed_oc_gpu.py)."""
 import os
+import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -78,3 +80,21 @@ def test_trainer_over_rccl_equals_the_other_paths(one_rank_group, chunks, monkey
     for e, r in ((e1, r1), (e2, r2)):
         np.testing.assert_allclose(e, e0, rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(r, r0, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.timeout(400)
+def test_unique_id_reaches_a_second_rank():
+    """tools/rccl_two_ranks_one_gpu.py: two processes on this GPU hand the ncclUniqueId through torch.distributed as the
+    communicator's constructor does.  RCCL refuses the second rank of a device — AFTER its bootstrap, which needs the id's
+    socket address intact on rank 1: both ranks must get that refusal (or a communicator) promptly.  With the id cut at its
+    first NUL byte (rounds 5-6 until this test) both ranks sat in ncclCommInitRank for 63 s and got a network error."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_two_ranks_one_gpu.py")], capture_output=True, text=True,
+                         timeout=380, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    import json
+    ranks = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{"rank"') and "outcome" in l]
+    assert sorted(r["rank"] for r in ranks) == [0, 1]
+    for r in ranks:
+        assert r["outcome"] == "communicator" or "invalid usage" in r["error"], r
+        assert r["seconds"] < 45, r          # the bootstrap's own connect time-out is ~60 s
