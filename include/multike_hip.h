@@ -77,6 +77,9 @@ int mke_tuning_init(mke_tuning* t);   /* every field = MKE_TUNE_DEFAULT */
  *                     0 = tail backward, the two products and the convolution backward as launches of their own (6)
  *   "oc_score_quarter" : mke_oc_score with a quarter-wave per positive (four positives per wavefront) instead of a wavefront:
  *                     -1 = by shape (default: n_ranks >= 4, neg_per_pos <= 8 n_ranks, stride <= 128), 0 = never, 1 = always
+ *   "oc_em_keys64"  : mke_oc_em_plan sorts its (step, row) keys as 64-bit words even when n_steps * (n_local + n_rel) < 2^32 (0, the
+ *                     default: 32-bit words whenever they fit) — the instantiation a KG with >= 2^32 (step, row) pairs per epoch takes;
+ *                     same lists bit for bit
  *   "sampler_fast"  : mke_neg_sample*: 1 (default) = a round's coin block evaluated in the idle last lane of the group's draw
  *                     evaluation and duplicates among first draws found through an LDS table; 0 = separate coin evaluation and
  *                     a shuffle loop.  Same Philox stream, same output bit for bit

@@ -37,6 +37,7 @@ int g_update_chunk = 0;      // rows per wavefront of the row-update kernel on l
 int g_deterministic = 0;     // fixed-order gradient reduction (parity / debugging mode)
 int g_sampler_fast = 1;      // mke_sampler.hip: coin block in the draw evaluation's idle lane, LDS duplicate test (0: the earlier form)
 int g_attr_fused_bwd = 1;    // mke_attr_cnn.hip: dflat product inside the convolution-backward launch, dW on rider blocks (every dim <= 80)
+int g_oc_em_keys64 = 0;      // mke_oc_em.hip: sort the epoch's (step, row) keys as 64-bit words even when they fit 32 bits (the path large KGs take)
 int g_oc_score_quarter = -1; // mke_oc.hip: quarter-wave per positive in the owner-computes score kernel: -1 = by shape, 0 / 1
 thread_local const mke_tuning* tl_tuning = nullptr;   // the tuning of the API call in progress on this thread (mke_common.h)
 }
@@ -93,6 +94,11 @@ extern "C" int mke_set_option(const char* name, int value, int* old_value) {
   if (!strcmp(name, "sampler_fast")) {
     if (old_value) *old_value = mke::g_sampler_fast;
     mke::g_sampler_fast = value != 0;
+    return MKE_OK;
+  }
+  if (!strcmp(name, "oc_em_keys64")) {
+    if (old_value) *old_value = mke::g_oc_em_keys64;
+    mke::g_oc_em_keys64 = value != 0;
     return MKE_OK;
   }
   if (!strcmp(name, "deterministic")) {

@@ -36,6 +36,8 @@ namespace mke {
 #define EM_LOC_GV 0x80000000u
 #define EM_LOC_PLUS (1u << 24)
 
+extern int g_oc_em_keys64;   // option "oc_em_keys64" (mke_api.hip)
+
 struct EmPlanParams {
   mke_oc_em_plan_args a;
   uint32_t ep;          // elements per positive: neg_per_pos + 5
@@ -645,7 +647,7 @@ extern "C" int mke_oc_em_plan(const mke_oc_em_plan_args* args, void* stream) {
   pp.wave_off = a.wave_scratch + (MKE_OC_EM_WAVES + 1);
   // + 1: an all-ones (step, row) never occurs, so the all-ones sentinel of the unused tail sorts last
   const int key_bits = bits_for((uint64_t)a.n_steps * (uint64_t)pp.rows_tot + 1ull);
-  if (key_bits <= 32) return em_plan_sorted<uint32_t>(pp, key_bits, (hipStream_t)stream);
+  if (key_bits <= 32 && !g_oc_em_keys64) return em_plan_sorted<uint32_t>(pp, key_bits, (hipStream_t)stream);
   return em_plan_sorted<uint64_t>(pp, key_bits, (hipStream_t)stream);
 }
 

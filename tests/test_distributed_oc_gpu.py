@@ -231,6 +231,34 @@ def test_entity_major_step_is_bit_reproducible(chunks, quarter):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("zipf", [0.0, 1.0])
+def test_epoch_plan_with_64_bit_keys_gives_the_same_lists(zipf):
+    """mke_oc_em_plan sorts (step, row) keys as 32-bit words when n_steps * (n_local + n_rel) < 2^32 and as 64-bit words otherwise
+    — a KG of tens of millions of entities; nothing at the tests' sizes gets there.  Option "oc_em_keys64" takes the 64-bit
+    instantiation at any size: the same reference lists, touched rows, work items and long-row tables bit for bit (a stable sort of the
+    same keys), and the same tables after an epoch and two steps (zipf 1.0: hub rows, long lists, the combine launch)."""
+    from multike_amd import _lib
+    runs = []
+    for k64 in (0, 1):
+        old = _lib.set_option("oc_em_keys64", k64)
+        try:
+            tr = _make(0, 1, neg=25, em=True, zipf=zipf, hot_min=None)
+            em = tr._em
+            n = int(em["n_refs_host"])
+            S1 = tr.steps + 1
+            items = int(em["host"][S1:2 * S1][-1])
+            lists = [em["refs"][:2 * n].clone(), em["item_row"][:items].clone(), em["item_off"][:items + 1].clone(), em["item_part"][:items].clone(),
+                     em["host"].clone()]
+            tr.run(0, tr.steps + 2)
+            torch.cuda.synchronize()
+            runs.append(lists + [tr.ent.clone(), tr.ent_acc.clone(), tr.rel.clone(), tr.loss_ring.clone()])
+        finally:
+            _lib.set_option("oc_em_keys64", old)
+    assert runs[0][0].numel() > 1000
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("chunks", [1, 3])
 def test_native_step_loop_is_the_python_loop_bit_for_bit(chunks):
     """mke_oc_steps enqueues exactly what the Python step loop enqueues (entity-major form: no atomics, so the two runs agree to
