@@ -138,7 +138,7 @@ class OcHipBackend:
         s.codes = _lib.ptr(st.codes, i32, "codes")
         for g, o in enumerate(st.code_off):
             s.code_off[g] = int(o)
-        s.optimizer, s.lr, s.scale, s.tag = _lib.OPT_ADAGRAD, tr.lr, tr.scale, st.tag
+        s.optimizer, s.lr, s.scale, s.tag = tr.OPTIMIZER, tr.lr, tr.scale, st.tag
         s.pos_w = _lib.ptr(st.pos_w, f32, "pos_w") if st.pos_w is not None else None
         if tr.hot_slot is not None:           # hub rows of the shard: private gradient copies behind the shard's own rows
             s.hot.slot, s.hot.n_hot = _lib.ptr(tr.hot_slot, i32, "hot_slot"), tr.n_hot
@@ -274,7 +274,7 @@ class OcHipBackend:
             hot = _lib.HotRowsStruct(_lib.ptr(tr.hot_slot, torch.int32, "hot_slot"), tr.n_hot, tr.HOT_COPIES, tr.ent_grad_rows)
         _lib.rows_update_multi([(tr.rel, tr.rel_acc, tr.rel_grad, None, True),
                                 (tr.ent, tr.ent_acc, tr.ent_grad, tr.ent_touched, True, tr.ref_count, hot)],
-                               tag, tr.stride, tr.dim, _lib.OPT_ADAGRAD, tr.lr)
+                               tag, tr.stride, tr.dim, tr.OPTIMIZER, tr.lr)
 
     def run(self, tr, k, tag, phases, c, loss_slot):
         """The phases of `phases` (OC_* bit mask) of part k (chunk buffers c) in ONE native call; buffers by raw address
@@ -1230,6 +1230,10 @@ class OwnerComputesTrainer:
         return True, self._comm_native
 
     OVERLAP_RS_MIN_BYTES = 16 << 20
+    # the update rule of the step descriptors: the reference's relation view trains with Adagrad (code/MultiKE_model.py:17-31) and the
+    # multi-GPU drivers accept nothing else (distributed_run.py); plain SGD (code/MultiKE_model.py:24) is the kernels' other rule,
+    # reachable through the C-ABI — a subclass sets it for the tests
+    OPTIMIZER = _lib.OPT_ADAGRAD
 
     def _overlap_rs(self) -> bool:
         """Entity-major, one part per step: put the reduce-scatter on the communication stream and run, under it, the second pass's

@@ -231,6 +231,57 @@ def test_entity_major_step_is_bit_reproducible(chunks, quarter):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("em,native", [(True, True), (True, False), (False, True)])
+def test_plain_sgd_rule_of_the_step_kernels(em, native):
+    """The step descriptors carry the update rule (mke_oc_step.optimizer): Adagrad in every product path, plain SGD
+    (code/MultiKE_model.py:24, tf.train.GradientDescentOptimizer) for C-ABI callers — the second pass's and the update launch's
+    other branch.  Against the float64 dense oracle's gradients applied with its SGD rule, zipf 1.0 (hub rows, long lists)."""
+    from multike_amd import _lib
+    from multike_amd.distributed_oc import OwnerComputesTrainer
+    from multike_amd.sampling import KGSide, RelationBatcher
+    from multike_amd.synthetic import SyntheticKGs
+    n_ent, dim, neg, zipf, lr = 2500, 75, 8, 1.0, 0.05
+    kgs = SyntheticKGs(n_ent=n_ent, n_rel=N_REL, seed=SEED, zipf=zipf)
+    rng = np.random.default_rng(SEED)
+    ent0 = mo.xavier_truncated_normal((n_ent, dim), rng)
+    rel0 = mo.xavier_truncated_normal((N_REL, dim), rng)
+    cls = type("SgdTrainer", (OwnerComputesTrainer,), {"OPTIMIZER": _lib.OPT_SGD})
+    tr = cls(kgs, ent0, rel0, B, neg, 0, 1, seed=SEED, lr=lr, entity_major=em)
+    steps = min(tr.steps, 6)
+    acc0 = tr.ent_acc.clone()
+    if native:
+        tr.run(0, steps)
+    else:
+        for i in range(steps):
+            tr.step(i)
+    torch.cuda.synchronize()
+    # the same steps on the oracle: gradients w.r.t. the normalised tables, then w -= lr * J^T g on the touched rows
+    e, r = ent0.astype(np.float32).astype(np.float64), rel0.astype(np.float32).astype(np.float64)
+    bat = RelationBatcher(kgs.triples[0], kgs.triples[1], KGSide(kgs.entities(0), None, device="cpu"),
+                          KGSide(kgs.entities(1), None, device="cpu"), B, neg, device="cpu", seed=SEED)
+    sets = [co.TripleSet(t[:, 0], t[:, 1], t[:, 2]) for t in kgs.triples]
+    ph, pr, pt = (x.numpy() for x in (bat.pos_h, bat.pos_r, bat.pos_t))
+    total = 0.0
+    for s in range(steps):
+        lo, hi = int(bat.off[s]), int(bat.off[s + 1])
+        mid = lo + int(bat.cnt1[s])
+        parts = []
+        for k, (a, c) in enumerate(((lo, mid), (mid, hi))):
+            elo, ehi = kgs.ent_range[k]
+            parts.append(co.neg_sample(ph[a:c], pr[a:c], pt[a:c], neg, ehi - elo, ent_lo=elo, known=sets[k], seed=bat.rng_seed,
+                                       stream_id=bat.rng_stream + k, pos_offset=a))
+        nn = [np.concatenate([parts[0][j], parts[1][j]]) for j in range(3)]
+        L, ge, gr = mo.relation_view_step_dense(e, r, None, None, (ph[lo:hi], pr[lo:hi], pt[lo:hi]), nn, lr, update=False)
+        mo.rows_update_sparse(e, None, ge, lr, True, "SGD")
+        mo.rows_update_sparse(r, None, gr, lr, True, "SGD")
+        total += L
+    np.testing.assert_allclose(tr.epoch_loss(), total, rtol=2e-6)
+    np.testing.assert_allclose(tr.gather_entity_table().cpu().numpy(), e, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(tr.rel[:, :dim].cpu().numpy(), r, rtol=2e-4, atol=2e-6)
+    assert torch.equal(tr.ent_acc, acc0)            # SGD has no slot: the accumulators are not touched
+    assert tr.scratch_clean()
+
+
 @pytest.mark.parametrize("zipf", [0.0, 1.0])
 def test_epoch_plan_with_64_bit_keys_gives_the_same_lists(zipf):
     """mke_oc_em_plan sorts (step, row) keys as 32-bit words when n_steps * (n_local + n_rel) < 2^32 and as 64-bit words otherwise
