@@ -14,6 +14,9 @@ What runs, and how:
   * `code/base/batch.py` and `code/attr_batch.py` are imported unmodified with empty stand-in modules
     for the imports they never use on this path (`tensorflow`, `gensim`), and run under fixed
     `random.seed` / `np.random.seed`.
+  * the attribute-view graph (round 6): `MultiKE._define_attribute_view_graph`, `conv` (code/MultiKE_model.py) and `xavier_init`
+    (code/base/initializers.py) are EXECUTED on an instance made without `__init__`, the graph-building calls forwarded eagerly;
+    only the leaf ops (tf.layers batch-norm / conv2d / dense, embedding_lookup) are restated — see `cnn_reference_fixture`.
   * graph-level pieces that exist only inside TF (gradient of l2_normalize, ApplyAdagrad) are produced
     with torch autograd and `torch.optim.Adagrad(initial_accumulator_value=0.1, eps=0)` on top of the
     reference's loss functions.
@@ -55,6 +58,7 @@ def install_tf_forwarder():
         return x * torch.rsqrt(torch.clamp_min(ssq, epsilon))
 
     nn.l2_normalize = l2_normalize
+    nn.tanh = torch.tanh          # bound as a DEFAULT ARGUMENT when code/MultiKE_model.py is imported (`conv(..., activation=tf.nn.tanh)`)
     tf.nn = nn
     sys.modules["tensorflow"] = tf
     sys.modules["tensorflow.nn"] = nn
@@ -293,6 +297,135 @@ def cnn_fixture(out):
         out[pre + "score"] = score.detach().numpy()
         out[pre + "loss"] = np.float64(loss.item())
         out[pre + "g_hs"], out[pre + "g_as"] = th.grad.numpy(), ta.grad.numpy()
+
+
+def cnn_reference_fixture(out):
+    """The attribute-view graph of the reference EXECUTED: `MultiKE._define_attribute_view_graph` (code/MultiKE_model.py:134-151)
+    on an instance made with `object.__new__`, with its tables built by the reference's own `xavier_init(..., is_l2_norm)`
+    (code/base/initializers.py:23-27: the normalised view of the entity table, the raw attribute table) and its scorer by the
+    reference's own `conv` (code/MultiKE_model.py:34-63).  TensorFlow's graph-building calls are forwarded to torch EAGERLY — a
+    placeholder is its fed value — so every line of the reference's composition runs: the reshapes and the concat, which axis
+    batch-norm and the two l2_normalize calls work on, the NHWC flatten order into the dense layer, the embedding lookups, the
+    loss.  What is restated here (and only here) are the LEAF ops: tf.layers.batch_normalization in inference mode with its
+    never-updated moving statistics (0, 1), tf.layers.conv2d (HWIO kernel, SAME padding of an even kernel: the extra column on
+    the right / row at the bottom), tf.layers.dense, embedding_lookup — "unpinned at the TF boundary" still applies to those.
+    Gradients: torch autograd through the executed graph, float64.  Same inputs as cnn_fixture, plus a table with repeated rows."""
+    import contextlib
+    import math
+    from unittest import mock
+    import torch.nn.functional as F
+    tf = sys.modules["tensorflow"]
+    tf.__getattr__ = lambda name: mock.MagicMock(name="tf." + name)
+    tf.nn.__getattr__ = lambda name: mock.MagicMock(name="tf.nn." + name)
+
+    class _Shape(tuple):
+        def as_list(self):
+            return list(self)
+
+    class _T(torch.Tensor):                       # a tensor whose .shape has TensorShape's as_list()
+        @property
+        def shape(self):
+            return _Shape(torch.Tensor.shape.__get__(self))
+
+    wrap = lambda t: t.as_subclass(_T)
+    queue = {"params": [], "feeds": [], "vars": {}}
+    layers = types.ModuleType("tensorflow.layers")
+
+    def batch_normalization(inputs, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, training=False, **kw):
+        assert not training and center and scale
+        p = queue["params"].pop(0)
+        shp = [1] * inputs.dim()
+        shp[axis] = -1
+        return wrap(inputs * (p["gamma"].reshape(shp) / math.sqrt(1.0 + epsilon)) + p["beta"].reshape(shp))
+
+    def conv2d(inputs, filters, kernel_size, strides, padding, activation=None):
+        p = queue["params"].pop(0)
+        kh, kw = kernel_size
+        assert padding == "same" and list(strides) == [1, 1] and tuple(p["K"].shape) == (kh, kw, inputs.shape[3], filters)
+        x = inputs.permute(0, 3, 1, 2)                                          # NHWC -> NCHW
+        x = F.pad(x, ((kw - 1) // 2, kw - 1 - (kw - 1) // 2, (kh - 1) // 2, kh - 1 - (kh - 1) // 2))
+        y = F.conv2d(x, p["K"].permute(3, 2, 0, 1), p["b"]).permute(0, 2, 3, 1)
+        return wrap(activation(y) if activation is not None else y)
+
+    def dense(inputs, units, activation=None):
+        p = queue["params"].pop(0)
+        assert p["W"].shape[1] == units
+        y = inputs @ p["W"] + p["bias"]
+        return wrap(activation(y) if activation is not None else y)
+
+    layers.batch_normalization, layers.conv2d, layers.dense = batch_normalization, conv2d, dense
+    tf.layers = layers
+    tf.reshape = lambda x, shape: wrap(torch.reshape(x, tuple(shape)))
+    tf.concat = lambda xs, axis: wrap(torch.cat(list(xs), dim=axis))
+    tf.placeholder = lambda dtype, shape=None: queue["feeds"].pop(0)
+    tf.get_variable = lambda name, shape=None, dtype=None, initializer=None: queue["vars"][name]
+    tf.name_scope = tf.variable_scope = lambda *a, **k: contextlib.nullcontext()
+    tf.nn.embedding_lookup = lambda table, ids: wrap(table[ids])
+    ref_model = importlib.import_module("MultiKE_model")
+    ref_init = importlib.import_module("base.initializers")
+    assert ref_model.conv.__defaults__[2] is torch.tanh           # the default activation was bound to the forwarder's tanh
+    for ci, (d, B, weighted, scale) in enumerate(((8, 13, False, 2.0), (75, 37, True, 1.0))):
+        rng = np.random.default_rng(500 + ci)                     # the draws of cnn_fixture, in its order
+        P = {"gamma": 1 + 0.2 * rng.standard_normal(d), "beta": 0.1 * rng.standard_normal(d),
+             "K1": 0.5 * rng.standard_normal((2, 4, 1, 2)), "b1": 0.1 * rng.standard_normal(2),
+             "K2": 0.5 * rng.standard_normal((2, 4, 2, 2)), "b2": 0.1 * rng.standard_normal(2),
+             "W": rng.standard_normal((4 * d, d)) * np.sqrt(6.0 / (5 * d)), "bias": 0.1 * rng.standard_normal(d)}
+        hs = rng.standard_normal((B, d)); hs /= np.linalg.norm(hs, axis=1, keepdims=True)
+        as_ = 0.3 * rng.standard_normal((B, d))
+        vs = rng.standard_normal((B, d)); vs /= np.linalg.norm(vs, axis=1, keepdims=True)
+        ws = rng.uniform(0.2, 1.0, B) if weighted else None
+        t64 = lambda a, g=True: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+        pre = f"n{ci}_ref_"
+
+        def run(ent_raw, attr_raw, lit, ih, ia, iv, w):
+            T_ = {k: t64(v) for k, v in P.items()}
+            te, ta = t64(ent_raw), t64(attr_raw)
+            queue["params"] = [{"gamma": T_["gamma"], "beta": T_["beta"]}, {"K": T_["K1"], "b": T_["b1"]}, {"K": T_["K2"], "b": T_["b2"]},
+                               {"W": T_["W"], "bias": T_["bias"]}]
+            queue["vars"] = {"av_ent_embeds": te, "attr_embeds": ta}
+            queue["feeds"] = [torch.as_tensor(ih), torch.as_tensor(ia), torch.as_tensor(iv), torch.tensor(w, dtype=torch.float64)]
+            m = object.__new__(ref_model.MultiKE)
+            m.args = argparse.Namespace(dim=d, learning_rate=0.01, optimizer="Adagrad")
+            # the reference's own initialiser wrappers: the normalised VIEW of the entity table, the raw attribute table ("False important!")
+            m.av_ent_embeds = ref_init.xavier_init([ent_raw.shape[0], d], "av_ent_embeds", True)
+            m.attr_embeds = ref_init.xavier_init([attr_raw.shape[0], d], "attr_embeds", False)
+            m.literal_embeds = torch.tensor(lit, dtype=torch.float64)
+            score_box = []
+            real_conv = ref_model.conv
+
+            def spy(*a, **k):
+                score_box.append(real_conv(*a, **k))
+                return score_box[-1]
+            with mock.patch.object(ref_model, "conv", spy), mock.patch.object(ref_model, "generate_optimizer", lambda *a, **k: None):
+                m._define_attribute_view_graph()
+            assert not queue["params"] and not queue["feeds"]
+            m.attribute_loss.backward()
+            return m.attribute_loss.item(), score_box[0].detach().numpy(), te.grad.numpy(), ta.grad.numpy(), {k: v.grad.numpy() for k, v in T_.items()}
+
+        # (1) cnn_fixture's case: row i of every table is triple i's row; the entity rows are unit vectors (their normalised view is
+        # themselves up to rounding).  Score and loss must equal the independent restatement's
+        w1 = ws if ws is not None else np.ones(B)
+        loss, score, _, g_as, gp = run(hs, as_, vs, np.arange(B), np.arange(B), np.arange(B), w1)
+        np.testing.assert_allclose(score, out[f"n{ci}_score"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(loss * scale, out[f"n{ci}_loss"], rtol=1e-12)
+        np.testing.assert_allclose(g_as * scale, out[f"n{ci}_g_as"], rtol=1e-8, atol=1e-12)
+        for k in P:
+            np.testing.assert_allclose(gp[k] * scale, out[f"n{ci}_g_{k}"], rtol=1e-8, atol=1e-12, err_msg=k)
+        out[pre + "score"], out[pre + "loss"], out[pre + "g_as"] = score, np.float64(loss), g_as
+        for k in P:
+            out[pre + "g_" + k] = gp[k]
+        # (2) tables with repeated and unused rows, entity rows of any length: the lookups' scatter and the normalised view's Jacobian
+        n_ent, n_attr, n_lit = B // 2 + 3, 5, B // 3 + 2
+        ent_raw = rng.standard_normal((n_ent, d)) * rng.uniform(0.3, 3.0, (n_ent, 1))
+        attr_raw = 0.3 * rng.standard_normal((n_attr, d))
+        lit = rng.standard_normal((n_lit, d)); lit /= np.linalg.norm(lit, axis=1, keepdims=True)
+        ih, ia, iv = rng.integers(0, n_ent - 2, B), rng.integers(0, n_attr, B), rng.integers(0, n_lit, B)
+        loss, score, g_ent, g_attr, gp = run(ent_raw, attr_raw, lit, ih, ia, iv, w1)
+        out[pre + "t_ent"], out[pre + "t_attr"], out[pre + "t_lit"] = ent_raw, attr_raw, lit
+        out[pre + "t_ih"], out[pre + "t_ia"], out[pre + "t_iv"], out[pre + "t_w"] = ih, ia, iv, w1
+        out[pre + "t_score"], out[pre + "t_loss"], out[pre + "t_g_ent"], out[pre + "t_g_attr"] = score, np.float64(loss), g_ent, g_attr
+        for k in P:
+            out[pre + "t_g_" + k] = gp[k]
 
 
 def eval_fixture(ref_alignment, out):
@@ -539,6 +672,7 @@ def pins_fixture(ref_batch, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="", help="cnn: rewrite cnn_golden.npz only (the other fixtures keep their bytes)")
     a = ap.parse_args()
     code = os.path.join(a.reference, "code")
     if not os.path.isdir(code):
@@ -552,11 +686,16 @@ def main():
     ref_utils = importlib.import_module("utils")
 
     out = {}
-    losses_fixture(ref_losses, tf, out)
-    np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
+    if a.only != "cnn":
+        losses_fixture(ref_losses, tf, out)
+        np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
     cnn = {}
     cnn_fixture(cnn)
+    cnn_reference_fixture(cnn)
     np.savez_compressed(os.path.join(HERE, "cnn_golden.npz"), **cnn)
+    if a.only == "cnn":
+        print("wrote cnn_golden.npz")
+        return
     ev = {}
     eval_fixture(importlib.import_module("base.alignment"), ev)
     np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **ev)

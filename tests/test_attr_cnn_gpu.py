@@ -45,6 +45,35 @@ def test_golden_loss_and_every_gradient(ci):
     np.testing.assert_allclose(attr.grad[:, :d].cpu().numpy(), g[pre + "g_as"], rtol=2e-3, atol=2e-6)
 
 
+@pytest.mark.parametrize("ci", [0, 1])
+def test_reference_executed_attribute_graph(ci):
+    """The reference's attribute-view graph EXECUTED (`MultiKE._define_attribute_view_graph` + `conv` + `xavier_init`, eager
+    leaf ops: tests/golden/make_golden.py `cnn_reference_fixture`) on tables with repeated and unused rows: the device step's
+    loss, the scratch gradients — w.r.t. the normalised entity rows on the device: the Jacobian of the view is applied here, as
+    the update launch does —, the attribute table's and every CNN parameter's."""
+    from multike_amd.attr_cnn import AttrCNN
+    from multike_amd.tables import EmbeddingTable, StepEngine
+    g = np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+    pre, ref = f"n{ci}_", f"n{ci}_ref_t_"
+    d = int(g[pre + "meta"][0])
+    P = {k: g[pre + "p_" + k] for k in ao.PARAM_NAMES}
+    ent_raw, attr_raw, lit_raw = g[ref + "ent"], g[ref + "attr"], g[ref + "lit"]
+    E = EmbeddingTable(ent_raw.shape[0], d, "av_ent", normalize=True, values=ent_raw)
+    A = EmbeddingTable(attr_raw.shape[0], d, "attr", normalize=False, values=attr_raw)
+    L = EmbeddingTable(lit_raw.shape[0], d, "lit", normalize=False, trainable=False, values=lit_raw)
+    t = lambda x: torch.as_tensor(x.astype(np.int32), device="cuda")
+    cnn = AttrCNN(d, params=P)
+    lp = cnn.step(StepEngine(), E, A, L, t(g[ref + "ih"]), t(g[ref + "ia"]), t(g[ref + "iv"]),
+                  torch.as_tensor(g[ref + "w"].astype(np.float32), device="cuda"), scale=1.0, update=False)
+    np.testing.assert_allclose(float(lp.sum()), g[ref + "loss"], rtol=5e-6)
+    for k in ao.PARAM_NAMES:
+        want = g[ref + "g_" + k]
+        np.testing.assert_allclose(cnn.gviews[k].cpu().numpy(), want, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(want).max()), err_msg=k)
+    g_raw = mo.l2_normalize_rows_backward(ent_raw.astype(np.float64), E.grad[:, :d].cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(g_raw, g[ref + "g_ent"], rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(A.grad[:, :d].cpu().numpy(), g[ref + "g_attr"], rtol=2e-3, atol=2e-6)
+
+
 @pytest.mark.parametrize("d,B,n_ent,n_attr,n_lit", [(75, 5000, 20000, 300, 8000), (75, 37, 100, 9, 50), (32, 513, 900, 20, 400),
                                                     (130, 64, 200, 11, 90),
                                                     # every width of the fused forward (conv stack + dense layer in one

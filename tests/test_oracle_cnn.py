@@ -1,5 +1,7 @@
-"""The attribute-CNN oracle (oracle/attr_cnn_oracle.py: forward + hand-derived backward) against torch autograd on
-an independent torch restatement of the TF1 semantics (tests/golden/cnn_golden.npz).  CPU only."""
+"""The attribute-CNN oracle (oracle/attr_cnn_oracle.py: forward + hand-derived backward) against (a) torch autograd on an
+independent torch restatement of the TF1 semantics and (b) the reference's own attribute-view graph EXECUTED —
+`MultiKE._define_attribute_view_graph`, `conv` and `xavier_init` of /root/reference/code run line by line over eagerly forwarded
+leaf ops (tests/golden/make_golden.py `cnn_reference_fixture`; keys `n*_ref_*` of tests/golden/cnn_golden.npz).  CPU only."""
 import os
 
 import numpy as np
@@ -26,6 +28,40 @@ def test_forward_and_backward(cnn_golden, ci):
     np.testing.assert_allclose(loss, g[pre + "loss"], rtol=1e-12)
     for k in ao.PARAM_NAMES + ("hs", "as"):
         np.testing.assert_allclose(grads[k], g[pre + "g_" + k], rtol=1e-8, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_reference_executed_graph(cnn_golden, ci):
+    """(1) the restatement's inputs through the reference's graph: score, loss (the reference multiplies by the weights and sums:
+    no scale), every gradient.  (2) tables with repeated / unused rows of any length through the reference's lookups and its
+    normalised entity view: the dense table gradients (scatter of the per-triple gradients, Jacobian of l2_normalize on the entity
+    rows, the attribute table raw) and the parameter gradients."""
+    from oracle import multike_oracle as mo
+    g = cnn_golden
+    pre, ref = f"n{ci}_", f"n{ci}_ref_"
+    P = {k: g[pre + "p_" + k] for k in ao.PARAM_NAMES}
+    ws = g[pre + "ws"] if (pre + "ws") in g.files else None
+    score, _ = ao.forward(P, g[pre + "hs"], g[pre + "as"], g[pre + "vs"])
+    np.testing.assert_allclose(score, g[ref + "score"], rtol=1e-10, atol=1e-13)
+    loss, grads = ao.loss_and_grads(P, g[pre + "hs"], g[pre + "as"], g[pre + "vs"], ws, 1.0)
+    np.testing.assert_allclose(loss, g[ref + "loss"], rtol=1e-12)
+    for k in ao.PARAM_NAMES + ("as",):
+        np.testing.assert_allclose(grads[k], g[ref + "g_" + k], rtol=1e-8, atol=1e-12, err_msg=k)
+    ent, attr, lit = g[ref + "t_ent"], g[ref + "t_attr"], g[ref + "t_lit"]
+    ih, ia, iv, w = g[ref + "t_ih"], g[ref + "t_ia"], g[ref + "t_iv"], g[ref + "t_w"]
+    hs = mo.l2_normalize_rows(ent)[ih]
+    score, _ = ao.forward(P, hs, attr[ia], lit[iv])
+    np.testing.assert_allclose(score, g[ref + "t_score"], rtol=1e-10, atol=1e-13)
+    loss, grads = ao.loss_and_grads(P, hs, attr[ia], lit[iv], w, 1.0)
+    np.testing.assert_allclose(loss, g[ref + "t_loss"], rtol=1e-12)
+    ghat, gattr = np.zeros_like(ent), np.zeros_like(attr)
+    np.add.at(ghat, ih, grads["hs"])
+    np.add.at(gattr, ia, grads["as"])
+    np.testing.assert_allclose(mo.l2_normalize_rows_backward(ent, ghat), g[ref + "t_g_ent"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(gattr, g[ref + "t_g_attr"], rtol=1e-8, atol=1e-12)
+    for k in ao.PARAM_NAMES:
+        np.testing.assert_allclose(grads[k], g[ref + "t_g_" + k], rtol=1e-8, atol=1e-12, err_msg=k)
+    assert not g[ref + "t_g_ent"][-2:].any()              # rows no triple looks up
 
 
 def test_dense_step_moves_only_touched_rows():
