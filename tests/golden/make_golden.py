@@ -299,17 +299,10 @@ def cnn_fixture(out):
         out[pre + "g_hs"], out[pre + "g_as"] = th.grad.numpy(), ta.grad.numpy()
 
 
-def cnn_reference_fixture(out):
-    """The attribute-view graph of the reference EXECUTED: `MultiKE._define_attribute_view_graph` (code/MultiKE_model.py:134-151)
-    on an instance made with `object.__new__`, with its tables built by the reference's own `xavier_init(..., is_l2_norm)`
-    (code/base/initializers.py:23-27: the normalised view of the entity table, the raw attribute table) and its scorer by the
-    reference's own `conv` (code/MultiKE_model.py:34-63).  TensorFlow's graph-building calls are forwarded to torch EAGERLY — a
-    placeholder is its fed value — so every line of the reference's composition runs: the reshapes and the concat, which axis
-    batch-norm and the two l2_normalize calls work on, the NHWC flatten order into the dense layer, the embedding lookups, the
-    loss.  What is restated here (and only here) are the LEAF ops: tf.layers.batch_normalization in inference mode with its
-    never-updated moving statistics (0, 1), tf.layers.conv2d (HWIO kernel, SAME padding of an even kernel: the extra column on
-    the right / row at the bottom), tf.layers.dense, embedding_lookup — "unpinned at the TF boundary" still applies to those.
-    Gradients: torch autograd through the executed graph, float64.  Same inputs as cnn_fixture, plus a table with repeated rows."""
+def _eager_tf(queue):
+    """TensorFlow's graph-BUILDING calls as eager torch calls (a placeholder is its fed value, a variable the tensor handed over
+    under its scoped name): what lets `MultiKE._define_*_graph` (code/MultiKE_model.py) run unmodified.  Returns the pieces a
+    fixture needs.  Leaf ops restated here: tf.layers batch-norm (inference) / conv2d / dense, embedding_lookup, constant."""
     import contextlib
     import math
     from unittest import mock
@@ -328,7 +321,6 @@ def cnn_reference_fixture(out):
             return _Shape(torch.Tensor.shape.__get__(self))
 
     wrap = lambda t: t.as_subclass(_T)
-    queue = {"params": [], "feeds": [], "vars": {}}
     layers = types.ModuleType("tensorflow.layers")
 
     def batch_normalization(inputs, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, training=False, **kw):
@@ -355,12 +347,51 @@ def cnn_reference_fixture(out):
 
     layers.batch_normalization, layers.conv2d, layers.dense = batch_normalization, conv2d, dense
     tf.layers = layers
+    scope = []
+
+    @contextlib.contextmanager
+    def variable_scope(name, *a, **k):
+        scope.append(name)
+        try:
+            yield
+        finally:
+            scope.pop()
+
+    def get_variable(name, shape=None, dtype=None, initializer=None):
+        v = queue["vars"][name]
+        assert shape is None or list(v.shape) == list(shape), (name, shape, v.shape)
+        # what tf.trainable_variables() lists (code/MultiKE_model.py:257 filters on the scoped name)
+        queue["trainable"].append(types.SimpleNamespace(name="/".join(scope + [name]) + ":0", key=name, tensor=v))
+        return v
+
     tf.reshape = lambda x, shape: wrap(torch.reshape(x, tuple(shape)))
     tf.concat = lambda xs, axis: wrap(torch.cat(list(xs), dim=axis))
     tf.placeholder = lambda dtype, shape=None: queue["feeds"].pop(0)
-    tf.get_variable = lambda name, shape=None, dtype=None, initializer=None: queue["vars"][name]
-    tf.name_scope = tf.variable_scope = lambda *a, **k: contextlib.nullcontext()
+    tf.constant = lambda value, dtype=None, name=None: torch.tensor(np.asarray(value), dtype=torch.float64)
+    tf.get_variable = get_variable
+    tf.trainable_variables = lambda: list(queue["trainable"])
+    tf.variable_scope = variable_scope
+    tf.name_scope = lambda *a, **k: contextlib.nullcontext()      # names ops, not variables
+    tf.reduce_mean = lambda x, axis=None: torch.mean(x) if axis is None else torch.mean(x, dim=axis)
     tf.nn.embedding_lookup = lambda table, ids: wrap(table[ids])
+    tf.nn.sigmoid = torch.sigmoid
+    return tf
+
+
+def cnn_reference_fixture(out):
+    """The attribute-view graph of the reference EXECUTED: `MultiKE._define_attribute_view_graph` (code/MultiKE_model.py:134-151)
+    on an instance made with `object.__new__`, with its tables built by the reference's own `xavier_init(..., is_l2_norm)`
+    (code/base/initializers.py:23-27: the normalised view of the entity table, the raw attribute table) and its scorer by the
+    reference's own `conv` (code/MultiKE_model.py:34-63).  TensorFlow's graph-building calls are forwarded to torch EAGERLY — a
+    placeholder is its fed value — so every line of the reference's composition runs: the reshapes and the concat, which axis
+    batch-norm and the two l2_normalize calls work on, the NHWC flatten order into the dense layer, the embedding lookups, the
+    loss.  What is restated here (and only here) are the LEAF ops: tf.layers.batch_normalization in inference mode with its
+    never-updated moving statistics (0, 1), tf.layers.conv2d (HWIO kernel, SAME padding of an even kernel: the extra column on
+    the right / row at the bottom), tf.layers.dense, embedding_lookup — "unpinned at the TF boundary" still applies to those.
+    Gradients: torch autograd through the executed graph, float64.  Same inputs as cnn_fixture, plus a table with repeated rows."""
+    from unittest import mock
+    queue = {"params": [], "feeds": [], "vars": {}, "trainable": []}
+    _eager_tf(queue)
     ref_model = importlib.import_module("MultiKE_model")
     ref_init = importlib.import_module("base.initializers")
     assert ref_model.conv.__defaults__[2] is torch.tanh           # the default activation was bound to the forwarder's tanh
@@ -426,6 +457,150 @@ def cnn_reference_fixture(out):
         out[pre + "t_score"], out[pre + "t_loss"], out[pre + "t_g_ent"], out[pre + "t_g_attr"] = score, np.float64(loss), g_ent, g_attr
         for k in P:
             out[pre + "t_g_" + k] = gp[k]
+
+
+def graphs_fixture(out):
+    """EVERY graph of the reference's model EXECUTED once (eagerly: `_eager_tf`): `MultiKE._define_variables` and the nine
+    `_define_*_graph` methods (code/MultiKE_model.py:86-261) run unmodified on an instance made with `object.__new__`, in the order
+    the drivers call them (code/MultiKE_CSL.py:21-31, MultiKE_Late.py:184-196), with `generate_optimizer` replaced by a recorder
+    of (loss, learning rate, var_list).  For every graph: the loss attribute the training loop prints, the loss the optimizer
+    minimises, its learning rate, which variables it may move, and the gradient of the minimised loss w.r.t. EVERY raw variable
+    (float64 autograd through the executed graph: lookups, normalised views, losses.py, conv).  What this pins is the reference's
+    composition — which tables a graph reads, through which view, with which factor, rate and variable list; the leaf ops of
+    tf.layers and ApplyAdagrad stay restated (oracle/)."""
+    from unittest import mock
+    queue = {"params": [], "feeds": [], "vars": {}, "trainable": []}
+    _eager_tf(queue)
+    ref_model = importlib.import_module("MultiKE_model")
+    rng = np.random.default_rng(77)
+    d, n_ent, n_rel, n_attr, n_lit, B, EB = 12, 40, 5, 6, 15, 17, 9
+    raw = {"rv_ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)), "rel_embeds": rng.standard_normal((n_rel, d)),
+           "av_ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)), "attr_embeds": 0.3 * rng.standard_normal((n_attr, d)),
+           "ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)),
+           "nv_mapping": np.linalg.qr(rng.standard_normal((d, d)))[0] + 0.05 * rng.standard_normal((d, d)),
+           "rv_mapping": np.linalg.qr(rng.standard_normal((d, d)))[0] + 0.05 * rng.standard_normal((d, d)),
+           "av_mapping": np.linalg.qr(rng.standard_normal((d, d)))[0] + 0.05 * rng.standard_normal((d, d))}
+    lit = rng.standard_normal((n_lit, d)); lit /= np.linalg.norm(lit, axis=1, keepdims=True)
+    name = rng.standard_normal((n_ent, d)); name /= np.linalg.norm(name, axis=1, keepdims=True)
+    cnn = [{"gamma": 1 + 0.2 * rng.standard_normal(d), "beta": 0.1 * rng.standard_normal(d),
+            "K1": 0.5 * rng.standard_normal((2, 4, 1, 2)), "b1": 0.1 * rng.standard_normal(2),
+            "K2": 0.5 * rng.standard_normal((2, 4, 2, 2)), "b2": 0.1 * rng.standard_normal(2),
+            "W": rng.standard_normal((4 * d, d)) * np.sqrt(6.0 / (5 * d)), "bias": 0.1 * rng.standard_normal(d)} for _ in range(3)]
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    V = {k: t64(v) for k, v in raw.items()}
+    C_ = [{k: t64(v) for k, v in p.items()} for p in cnn]
+    queue["vars"] = V
+    for p in C_:      # one conv() call per attribute-type graph, in definition order: batch-norm, conv, conv, dense
+        queue["params"] += [{"gamma": p["gamma"], "beta": p["beta"]}, {"K": p["K1"], "b": p["b1"]}, {"K": p["K2"], "b": p["b2"]}, {"W": p["W"], "bias": p["bias"]}]
+    ids = lambda hi, n=B: rng.integers(0, hi, n)
+    N = 3
+    feeds = {                                  # placeholders in the order each method creates them
+        "relation": [ids(n_ent), ids(n_rel), ids(n_ent), ids(n_ent, B * N), ids(n_rel, B * N), ids(n_ent, B * N)],
+        "attribute": [ids(n_ent), ids(n_attr), ids(n_lit), rng.uniform(0.2, 1.0, B)],
+        "ckge_rel": [ids(n_ent), ids(n_rel), ids(n_ent)],
+        "ckge_attr": [ids(n_ent), ids(n_attr), ids(n_lit)],
+        "ckga_attr": [ids(n_ent), ids(n_attr), ids(n_lit), rng.uniform(0.2, 1.0, B)],
+        "ckgp_rel": [ids(n_ent), ids(n_rel), ids(n_ent), rng.uniform(0.2, 1.0, B)],
+        "common": [ids(n_ent)],
+        "mapping": [rng.permutation(n_ent)[:EB]],
+    }
+    m = object.__new__(ref_model.MultiKE)
+    m.args = argparse.Namespace(dim=d, learning_rate=0.01, ITC_learning_rate=0.03, optimizer="Adagrad", cv_name_weight=0.7, cv_weight=1.5,
+                                orthogonal_weight=2.0, entity_batch_size=EB)
+    m.data = types.SimpleNamespace(value_vectors=lit, local_name_vectors=name)
+    m.kgs = types.SimpleNamespace(entities_num=n_ent, relations_num=n_rel, attributes_num=n_attr)
+    recorded = []
+    order = [("name_view", "_define_name_view_graph", None), ("relation", "_define_relation_view_graph", "relation_loss"),
+             ("attribute", "_define_attribute_view_graph", "attribute_loss"),
+             ("ckge_rel", "_define_cross_kg_entity_reference_relation_view_graph", "ckge_relation_loss"),
+             ("ckge_attr", "_define_cross_kg_entity_reference_attribute_view_graph", "ckge_attribute_loss"),
+             ("ckga_attr", "_define_cross_kg_attribute_reference_graph", "ckga_attribute_loss"),
+             ("ckgp_rel", "_define_cross_kg_relation_reference_graph", "ckgp_relation_loss"),
+             ("common", "_define_common_space_learning_graph", "cross_name_loss"), ("mapping", "_define_space_mapping_graph", "shared_comb_loss")]
+    with mock.patch.object(ref_model, "generate_optimizer",
+                           lambda loss, learning_rate, var_list=None, opt="SGD": recorded.append((loss, learning_rate, var_list, opt))):
+        m._define_variables()
+        for key, meth, attr in order:
+            n0 = len(recorded)
+            queue["feeds"] = [torch.as_tensor(x) if np.asarray(x).dtype.kind == "i" else torch.tensor(x, dtype=torch.float64) for x in feeds.get(key, [])]
+            getattr(m, meth)()
+            assert not queue["feeds"], key
+            if attr is None:
+                assert len(recorded) == n0
+                continue
+            assert len(recorded) == n0 + 1
+            minimised, lr, var_list, opt = recorded[-1]
+            assert opt == "Adagrad"
+            leaves = {**V, **{f"cnn{k}_{n}": t for k, p in enumerate(C_) for n, t in p.items()}}
+            grads = torch.autograd.grad(minimised, list(leaves.values()), allow_unused=True, retain_graph=True)
+            out[f"{key}_loss"] = np.float64(getattr(m, attr).item())
+            out[f"{key}_minimised"] = np.float64(minimised.item())
+            out[f"{key}_lr"] = np.float64(lr)
+            out[f"{key}_var_list"] = np.array([] if var_list is None else sorted(v.key for v in var_list))      # empty: every variable the loss depends on
+            out[f"{key}_has_var_list"] = np.int64(var_list is not None)
+            for (n, _), g in zip(leaves.items(), grads):
+                if g is not None and bool((g != 0).any()):
+                    out[f"{key}_g_{n}"] = g.numpy()
+            for i, x in enumerate(feeds[key]):
+                out[f"{key}_feed{i}"] = np.asarray(x)
+    assert not queue["params"]
+    out["trainable_names"] = np.array(sorted(v.name for v in queue["trainable"]))
+    for k, v in raw.items():
+        out["raw_" + k] = v
+    out["lit"], out["name"] = lit, name
+    for k, p in enumerate(cnn):
+        for n, v in p.items():
+            out[f"cnn{k}_{n}"] = v
+    out["args"] = np.array([0.01, 0.03, 0.7, 1.5, 2.0])          # learning_rate, ITC_learning_rate, cv_name_weight, cv_weight, orthogonal_weight
+    # the views the evaluation reads (code/MultiKE_model.py:263-277: embedding_lookup of the NORMALISED relation-view table)
+    out["view_rv_ent"] = m.rv_ent_embeds.detach().numpy()
+    out["view_attr"] = m.attr_embeds.detach().numpy()
+
+
+def ae_graph_fixture(out):
+    """The literal auto-encoder's graph EXECUTED: `AutoEncoderModel._init_graph` and `_loss_optimizer` with its `encoder` /
+    `decoder` (code/literal_encoder.py:41-91) on an instance made with `object.__new__`, eagerly (`_eager_tf`).  Every op of
+    this graph forwards exactly (matmul, add, sigmoid / tanh, l2_normalize without an axis, pow, reduce_mean): nothing is restated
+    but the optimizer.  Loss and float64 autograd gradients of every weight and bias, for the shipped activation string (matches
+    neither branch: a linear model), tanh, sigmoid, with and without the batch-wide normalisation."""
+    from unittest import mock
+    queue = {"params": [], "feeds": [], "vars": {}, "trainable": []}
+    _eager_tf(queue)
+    ref_le = importlib.import_module("literal_encoder")
+    dims = [30, 16, 8, 5]
+    for ci, (active, normalize) in enumerate((("thah", True), ("tanh", True), ("sigmoid", False), ("tanh", False))):
+        rng = np.random.default_rng(900 + ci)
+        n = len(dims) - 1
+        p = {}
+        for i in range(n):
+            p[f"encoder_h{i}"] = 0.3 * rng.standard_normal((dims[i], dims[i + 1]))
+            p[f"encoder_b{i}"] = 0.3 * rng.standard_normal(dims[i + 1])
+        for i in range(n):
+            j = n - i
+            p[f"decoder_h{i}"] = 0.3 * rng.standard_normal((dims[j], dims[j - 1]))
+            p[f"decoder_b{i}"] = 0.3 * rng.standard_normal(dims[j - 1])
+        x = rng.standard_normal((11, dims[0]))
+        T_ = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+        queue["vars"], queue["trainable"] = T_, []
+        queue["feeds"] = [torch.tensor(x, dtype=torch.float64)] * n          # _init_graph re-creates the placeholder inside its decoder loop
+        m = object.__new__(ref_le.AutoEncoderModel)
+        m.args = argparse.Namespace(dim=dims[-1], encoder_normalize=normalize, encoder_active=active, learning_rate=0.01, optimizer="Adagrad")
+        m.weights, m.biases = {}, {}
+        m.input_dimension, m.hidden_dimensions = dims[0], list(dims[1:])
+        m.layer_num = n
+        rec = []
+        with mock.patch.object(ref_le, "generate_optimizer", lambda loss, lr, var_list=None, opt="SGD": rec.append((loss, lr, var_list, opt))):
+            m._init_graph()
+            m._loss_optimizer()
+        assert not queue["feeds"] and len(rec) == 1 and rec[0][0] is m.loss and rec[0][2] is None
+        assert sorted(m.weights) == sorted(k for k in p if "_h" in k) and sorted(m.biases) == sorted(k for k in p if "_b" in k)
+        m.loss.backward()
+        pre = f"ae{ci}_"
+        out[pre + "meta"] = np.array([int(normalize)] + dims)
+        out[pre + "active"] = np.array(active)
+        out[pre + "x"], out[pre + "loss"] = x, np.float64(m.loss.item())
+        for k, v in p.items():
+            out[pre + "p_" + k], out[pre + "g_" + k] = v, T_[k].grad.numpy()
 
 
 def eval_fixture(ref_alignment, out):
@@ -672,7 +847,7 @@ def pins_fixture(ref_batch, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="cnn: rewrite cnn_golden.npz only (the other fixtures keep their bytes)")
+    ap.add_argument("--only", default="", help="cnn / graphs: rewrite cnn_golden.npz / graphs_golden.npz only (the other fixtures keep their bytes)")
     a = ap.parse_args()
     code = os.path.join(a.reference, "code")
     if not os.path.isdir(code):
@@ -686,15 +861,23 @@ def main():
     ref_utils = importlib.import_module("utils")
 
     out = {}
-    if a.only != "cnn":
+    if a.only not in ("cnn", "graphs"):
         losses_fixture(ref_losses, tf, out)
         np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
     cnn = {}
-    cnn_fixture(cnn)
-    cnn_reference_fixture(cnn)
-    np.savez_compressed(os.path.join(HERE, "cnn_golden.npz"), **cnn)
+    if a.only != "graphs":
+        cnn_fixture(cnn)
+        cnn_reference_fixture(cnn)
+        np.savez_compressed(os.path.join(HERE, "cnn_golden.npz"), **cnn)
     if a.only == "cnn":
         print("wrote cnn_golden.npz")
+        return
+    gr = {}
+    graphs_fixture(gr)
+    ae_graph_fixture(gr)
+    np.savez_compressed(os.path.join(HERE, "graphs_golden.npz"), **gr)
+    if a.only == "graphs":
+        print("wrote graphs_golden.npz")
         return
     ev = {}
     eval_fixture(importlib.import_module("base.alignment"), ev)

@@ -100,6 +100,38 @@ def test_native_gradients_vs_oracle(dims, L, active, normalize):
     assert abs(total - named) <= 1e-6 * max(1.0, total)
 
 
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_native_gradients_vs_the_reference_graph_executed(ci):
+    """The device step's loss and gradients against the reference's own auto-encoder graph EXECUTED (tests/golden/make_golden.py
+    `ae_graph_fixture`: code/literal_encoder.py:41-91 run unmodified, eager leaf ops, float64 autograd)."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from multike_amd import _lib
+    from multike_amd.literal_encoder import AutoEncoderModel
+    from multike_amd.synthetic import synthetic_args
+    g = np.load(os.path.join(GOLDEN, "graphs_golden.npz"))
+    pre = f"ae{ci}_"
+    normalize, dims = bool(g[pre + "meta"][0]), [int(v) for v in g[pre + "meta"][1:]]
+    active = str(g[pre + "active"])
+    x = g[pre + "x"]
+    L = x.shape[0]
+    args = synthetic_args(dim=dims[-1], batch_size=L, learning_rate=0.05, encoder_active=active, encoder_normalize=False, encoder_epoch=1)
+    # the graph is fed the rows as they are (the row normalisation of the inputs is the constructor's: code/literal_encoder.py:33-35)
+    m = AutoEncoderModel(x.astype(np.float32), args, input_dimension=dims[0], hidden_dimensions=dims[1:])
+    m._plan.normalize = int(normalize)                      # the graph's own batch-wide l2_normalize of the code matrix (:65-66)
+    m.set_params({k[len(pre) + 2:]: g[k] for k in g.files if k.startswith(pre + "p_")})
+    m._ensure_scratch(L)
+    m._plan.optimizer, m._plan.update, m._plan.lr = _lib.OPT_SGD, 0, 0.0
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    _lib.ae_train_steps(m._plan, m.word_vec_list, L, out)
+    np.testing.assert_allclose(float(out[0]), float(g[pre + "loss"]), rtol=2e-5)
+    for k, got in m._gviews.items():
+        want = g[pre + "g_" + k]
+        scale = np.abs(want).max() + 1e-30
+        assert np.abs(got.cpu().numpy() - want).max() / scale < 2e-4, (k, np.abs(got.cpu().numpy() - want).max() / scale)
+
+
 def test_full_shape_step_runs_and_learns():
     """The reference's shape (code/literal_encoder.py:26-31: 1500 -> 1024 -> 512 -> 75, batches of 5000): a few native
     epochs on 10,300 literals (2 full batches + a short one) lower the loss; the encoding has the right shape."""
