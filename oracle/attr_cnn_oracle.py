@@ -12,9 +12,12 @@ Restates `conv()` of the reference (code/MultiKE_model.py:34-63) and the three g
   tf.nn.l2_normalize(dense) with NO axis: over the whole [B,d] batch ("important!!")
   score = -sum((h - out)^2, 1) ;  loss = scale * sum_i w_i * log(1 + exp(-score_i))
 
-TensorFlow itself is not available: **parity unpinned at the TF boundary**.  The forward and the hand-derived backward
-below are pinned to torch autograd on an independent torch restatement (F.conv2d) by tests/golden/make_golden.py ->
-tests/golden/cnn_golden.npz (tests/test_oracle_cnn.py).
+TensorFlow itself is not available: **parity unpinned at the TF boundary** — for the leaf ops (tf.layers batch-norm in
+inference mode, conv2d SAME, dense).  The composition above them is pinned by the reference's own `conv` and
+`MultiKE._define_attribute_view_graph` EXECUTED over eagerly forwarded TensorFlow calls, with float64 autograd through them
+(tests/golden/make_golden.py `cnn_reference_fixture` -> keys `n*_ref_*` of tests/golden/cnn_golden.npz), and by an independent
+torch restatement (F.conv2d; `cnn_fixture`) that agrees with it to 1e-10: the forward and the hand-derived backward below are
+held to both in tests/test_oracle_cnn.py.
 """
 from __future__ import annotations
 

@@ -5,8 +5,10 @@ Restated from the reference + TF1 semantics: encoder 1500 -> 
 code/literal_encoder.py:75-78, so the shipped model is purely linear); `tf.nn.l2_normalize` with no axis over the whole
 code matrix when `encoder_normalize`; loss = mean((decoded - x)^2); one optimizer (Adagrad, acc0 = 0.1, no epsilon) over
 all weights and biases.  The final encoding is a NumPy forward over the un-normalised inputs (:114-144).
-TensorFlow is unavailable: **parity unpinned at the TF boundary**; cross-checked against torch autograd in
-tests/test_oracle_literal.py.
+TensorFlow is unavailable: **parity unpinned at the TF boundary** for the optimizer only — the graph itself (`_init_graph`,
+`_loss_optimizer`, `encoder`, `decoder`) is the reference's code EXECUTED over eagerly forwarded calls (every op of it forwards
+exactly), float64 autograd through it: tests/golden/make_golden.py `ae_graph_fixture` -> tests/golden/graphs_golden.npz, held to in
+tests/test_oracle_literal.py beside the torch-autograd cross-check.
 """
 import numpy as np
 

@@ -17,7 +17,9 @@ ApplyAdagrad with acc0 = 0.1 and no epsilon):
 
 Every `*_epoch` returns the figure the reference prints for that loop (sum of batch losses / trained positives).  Built from
 the step functions of `multike_oracle.py` / `attr_cnn_oracle.py` (pinned there: losses.py executed, torch autograd,
-torch.optim.Adagrad); **parity unpinned at the TF boundary** like them.
+torch.optim.Adagrad); **parity unpinned at the TF boundary** like them.  The COMPOSITION of every graph — tables, views, factors,
+learning rates, the optimizers' variable lists — is pinned by the reference's `_define_variables` / `_define_*_graph` methods EXECUTED
+(tests/golden/make_golden.py `graphs_fixture` -> tests/golden/graphs_golden.npz; tests/test_graphs_golden.py: one step of each graph).
 """
 from __future__ import annotations
 

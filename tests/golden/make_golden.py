@@ -253,7 +253,9 @@ def host_fixture(ref_utils, out_json):
 
 
 def cnn_fixture(out):
-    """The attribute-view CNN scorer (code/MultiKE_model.py:34-63) cannot be executed (tf.layers); its TF1 semantics
+    """The attribute-view CNN scorer (code/MultiKE_model.py:34-63), restated: an implementation of its TF1 semantics that shares
+    nothing with the reference's code (rounds 1-5: the only pin; since round 6 `cnn_reference_fixture` below EXECUTES the
+    reference's `conv` over forwarded leaf ops and asserts that the two agree).  Its TF1 semantics
     are restated here with torch.nn.functional ops — an implementation independent of oracle/attr_cnn_oracle.py —
     and differentiated by autograd in float64.  Pins the oracle's forward and hand-derived backward."""
     import torch.nn.functional as F
