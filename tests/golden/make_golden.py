@@ -461,7 +461,7 @@ def cnn_reference_fixture(out):
             out[pre + "t_g_" + k] = gp[k]
 
 
-def graphs_fixture(out):
+def graphs_fixture(out, seed=77, sizes=(12, 40, 5, 6, 15, 17, 9), neg=3, rates=(0.01, 0.03, 0.7, 1.5, 2.0)):
     """EVERY graph of the reference's model EXECUTED once (eagerly: `_eager_tf`): `MultiKE._define_variables` and the nine
     `_define_*_graph` methods (code/MultiKE_model.py:86-261) run unmodified on an instance made with `object.__new__`, in the order
     the drivers call them (code/MultiKE_CSL.py:21-31, MultiKE_Late.py:184-196), with `generate_optimizer` replaced by a recorder
@@ -474,8 +474,8 @@ def graphs_fixture(out):
     queue = {"params": [], "feeds": [], "vars": {}, "trainable": []}
     _eager_tf(queue)
     ref_model = importlib.import_module("MultiKE_model")
-    rng = np.random.default_rng(77)
-    d, n_ent, n_rel, n_attr, n_lit, B, EB = 12, 40, 5, 6, 15, 17, 9
+    rng = np.random.default_rng(seed)                   # (tools/fuzz_graphs_pin.py calls this with random sizes)
+    d, n_ent, n_rel, n_attr, n_lit, B, EB = sizes
     raw = {"rv_ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)), "rel_embeds": rng.standard_normal((n_rel, d)),
            "av_ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)), "attr_embeds": 0.3 * rng.standard_normal((n_attr, d)),
            "ent_embeds": rng.standard_normal((n_ent, d)) * rng.uniform(0.4, 2.5, (n_ent, 1)),
@@ -495,7 +495,7 @@ def graphs_fixture(out):
     for p in C_:      # one conv() call per attribute-type graph, in definition order: batch-norm, conv, conv, dense
         queue["params"] += [{"gamma": p["gamma"], "beta": p["beta"]}, {"K": p["K1"], "b": p["b1"]}, {"K": p["K2"], "b": p["b2"]}, {"W": p["W"], "bias": p["bias"]}]
     ids = lambda hi, n=B: rng.integers(0, hi, n)
-    N = 3
+    N = neg
     feeds = {                                  # placeholders in the order each method creates them
         "relation": [ids(n_ent), ids(n_rel), ids(n_ent), ids(n_ent, B * N), ids(n_rel, B * N), ids(n_ent, B * N)],
         "attribute": [ids(n_ent), ids(n_attr), ids(n_lit), rng.uniform(0.2, 1.0, B)],
@@ -507,8 +507,8 @@ def graphs_fixture(out):
         "mapping": [rng.permutation(n_ent)[:EB]],
     }
     m = object.__new__(ref_model.MultiKE)
-    m.args = argparse.Namespace(dim=d, learning_rate=0.01, ITC_learning_rate=0.03, optimizer="Adagrad", cv_name_weight=0.7, cv_weight=1.5,
-                                orthogonal_weight=2.0, entity_batch_size=EB)
+    m.args = argparse.Namespace(dim=d, learning_rate=rates[0], ITC_learning_rate=rates[1], optimizer="Adagrad", cv_name_weight=rates[2],
+                                cv_weight=rates[3], orthogonal_weight=rates[4], entity_batch_size=EB)
     m.data = types.SimpleNamespace(value_vectors=lit, local_name_vectors=name)
     m.kgs = types.SimpleNamespace(entities_num=n_ent, relations_num=n_rel, attributes_num=n_attr)
     recorded = []
@@ -553,7 +553,7 @@ def graphs_fixture(out):
     for k, p in enumerate(cnn):
         for n, v in p.items():
             out[f"cnn{k}_{n}"] = v
-    out["args"] = np.array([0.01, 0.03, 0.7, 1.5, 2.0])          # learning_rate, ITC_learning_rate, cv_name_weight, cv_weight, orthogonal_weight
+    out["args"] = np.array(rates, dtype=np.float64)          # learning_rate, ITC_learning_rate, cv_name_weight, cv_weight, orthogonal_weight
     # the views the evaluation reads (code/MultiKE_model.py:263-277: embedding_lookup of the NORMALISED relation-view table)
     out["view_rv_ent"] = m.rv_ent_embeds.detach().numpy()
     out["view_attr"] = m.attr_embeds.detach().numpy()
